@@ -1,0 +1,141 @@
+"""ctypes binding of libggnn.so (the C ABI declared in include/ggnn.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, every use of
+the HIP path raises `GGNNLibraryError`.  `torch` is imported first so that the library
+binds to the HIP runtime PyTorch already loaded (same SONAME `libamdhip64.so.7`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+LIB_NAME = "libggnn.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+GGNN_ABI_VERSION = 1
+GGNN_C = 96
+GGNN_EDGE_PARAM_ROWS = 7
+MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
+
+# Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
+EXPORTED_SYMBOLS = (
+    "ggnn_version", "ggnn_error_string", "ggnn_csr_workspace_bytes", "ggnn_build_csr",
+    "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
+    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_step_refresh", "ggnn_workspace_bytes",
+)
+
+
+class GGNNLibraryError(RuntimeError):
+    pass
+
+
+class GGNNError(RuntimeError):
+    pass
+
+
+class AggregateArgs(Structure):
+    """Mirror of `ggnn_aggregate_args` (include/ggnn.h)."""
+    _fields_ = [
+        ("rowptr", c_void_p), ("col", c_void_p), ("perm", c_void_p), ("edge_attr", c_void_p),
+        ("x_src", c_void_p), ("x_dst", c_void_p), ("p_src", c_void_p), ("p_dst", c_void_p),
+        ("edge_params", c_void_p), ("agg", c_void_p),
+        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("ldp_src", c_int64), ("ldp_dst", c_int64),
+        ("ld_agg", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
+        ("kv_off", c_int32), ("q_off", c_int32), ("a_off", c_int32), ("a_gstride", c_int32),
+        ("sc_off", c_int32), ("n_gates", c_int32),
+    ]
+
+
+class EpilogueArgs(Structure):
+    """Mirror of `ggnn_epilogue_args`."""
+    _fields_ = [
+        ("agg", c_void_p), ("w2", c_void_p), ("p_dst", c_void_p), ("c_in", c_void_p),
+        ("h_out", c_void_p), ("c_out", c_void_p), ("raw_out", c_void_p),
+        ("ldp", c_int64), ("N", c_int64),
+        ("Ka", c_int32), ("s_off", c_int32), ("n_gates", c_int32), ("mode", c_int32),
+    ]
+
+
+class RefreshEdge(Structure):
+    """Mirror of `ggnn_refresh_edge`."""
+    _fields_ = [
+        ("edge_index", c_void_p), ("x_src", c_void_p), ("x_dst", c_void_p), ("edge_attr", c_void_p),
+        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("n_src", c_int64), ("n_dst", c_int64),
+        ("E", c_int64),
+    ]
+
+
+_lib = None
+
+
+def _declare(lib):
+    lib.ggnn_version.restype = c_int
+    lib.ggnn_version.argtypes = []
+    lib.ggnn_error_string.restype = c_char_p
+    lib.ggnn_error_string.argtypes = [c_int]
+    lib.ggnn_csr_workspace_bytes.restype = c_size_t
+    lib.ggnn_csr_workspace_bytes.argtypes = [c_int64, c_int64]
+    lib.ggnn_build_csr.restype = c_int
+    lib.ggnn_build_csr.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.ggnn_project.restype = c_int
+    lib.ggnn_project.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p,
+                                 c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
+    lib.ggnn_period_gat_aggregate.restype = c_int
+    lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
+    lib.ggnn_lstm_epilogue.restype = c_int
+    lib.ggnn_lstm_epilogue.argtypes = [POINTER(EpilogueArgs), c_void_p]
+    lib.ggnn_heads_regressor.restype = c_int
+    lib.ggnn_heads_regressor.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.ggnn_heads_classifier.restype = c_int
+    lib.ggnn_heads_classifier.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.ggnn_step_update.restype = c_int
+    lib.ggnn_step_update.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                     c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]
+    lib.ggnn_step_refresh.restype = c_int
+    lib.ggnn_step_refresh.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                      c_float, c_void_p, POINTER(RefreshEdge), c_int, c_void_p]
+    lib.ggnn_workspace_bytes.restype = c_size_t
+    lib.ggnn_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+
+
+def load():
+    """Load libggnn.so (once).  Raises GGNNLibraryError if it is not built / not loadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GGNNLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C graingraphnn_amd/csrc`.  graingraphnn_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the environment
+        raise GGNNLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    missing = [s for s in EXPORTED_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise GGNNLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+    _declare(lib)
+    if lib.ggnn_version() != GGNN_ABI_VERSION:
+        raise GGNNLibraryError(
+            f"{LIB_PATH} has ABI version {lib.ggnn_version()}, expected {GGNN_ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ggnn_error_string(rc).decode()
+        raise GGNNError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

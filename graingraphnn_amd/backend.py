@@ -1,0 +1,146 @@
+"""Thin tensor-level wrapper over the C ABI (include/ggnn.h).  One method per entry point;
+tensors in, launches enqueued on the current HIP stream, nothing returned but the outputs
+written in place.  `HipBackend` is the only backend the package ships: it refuses CPU
+tensors and raises if libggnn.so cannot be loaded -- there is no CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AggregateArgs, EpilogueArgs, RefreshEdge, check, ptr
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.GGNNError(
+                "graingraphnn_amd runs on MI355X only: got a CPU tensor (no CPU fallback exists; "
+                "move the model and the graph to 'cuda')")
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.GGNNError(f"{name} must be a contiguous float32 tensor")
+    return t
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # -- CSR ---------------------------------------------------------------------------
+    def build_csr(self, edge_index, n_src, n_dst):
+        """edge_index [2, E] int64 (cuda) -> (rowptr, col, perm) int32.  Raises IndexError on
+        out-of-range indices (one host sync, only when a topology is first seen)."""
+        _require_cuda(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise _lib.GGNNError("edge_index must be int64 [2, E]")
+        ei = edge_index.contiguous()
+        E = ei.size(1)
+        dev = ei.device
+        rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(self.lib.ggnn_build_csr(ptr(ei), E, n_src, n_dst, ptr(rowptr), ptr(col), ptr(perm),
+                                      ptr(flags), ptr(ws), nbytes, _lib.current_stream()),
+              "ggnn_build_csr")
+        if int(flags[0].item()) & 1:
+            raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
+        return rowptr, col, perm
+
+    # -- projection --------------------------------------------------------------------
+    def project(self, x, F, h, wp, bp, out):
+        _require_cuda(x, h, wp, bp, out)
+        M = x.size(0)
+        k2 = 0 if h is None else h.size(1)
+        check(self.lib.ggnn_project(ptr(x), x.stride(0), F, ptr(h), 0 if h is None else h.stride(0),
+                                    k2, ptr(wp), ptr(bp), M, wp.size(0), ptr(out), out.stride(0),
+                                    _lib.current_stream()), "ggnn_project")
+
+    # -- aggregation -------------------------------------------------------------------
+    def aggregate(self, csr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg, kv_off, q_off,
+                  a_off, a_gstride, sc_off, n_gates):
+        rowptr, col, perm = csr
+        _require_cuda(rowptr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg)
+        a = AggregateArgs()
+        a.rowptr, a.col, a.perm = rowptr.data_ptr(), col.data_ptr(), perm.data_ptr()
+        a.edge_attr = edge_attr.data_ptr()
+        a.x_src, a.x_dst = x_src.data_ptr(), x_dst.data_ptr()
+        a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
+        a.edge_params, a.agg = ep.data_ptr(), agg.data_ptr()
+        a.ldx_src, a.ldx_dst = x_src.stride(0), x_dst.stride(0)
+        a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
+        a.n_src, a.n_dst, a.E = x_src.size(0), x_dst.size(0), edge_attr.numel()
+        a.kv_off, a.q_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
+            kv_off, q_off, a_off, a_gstride, sc_off, n_gates)
+        check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),
+              "ggnn_period_gat_aggregate")
+
+    # -- gate GEMM + LSTM --------------------------------------------------------------
+    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode):
+        _require_cuda(agg, w2, p_dst, c_in, h_out, c_out, raw_out)
+        a = EpilogueArgs()
+        a.agg, a.w2, a.p_dst = agg.data_ptr(), w2.data_ptr(), p_dst.data_ptr()
+        a.c_in = None if c_in is None else c_in.data_ptr()
+        a.h_out = None if h_out is None else h_out.data_ptr()
+        a.c_out = None if c_out is None else c_out.data_ptr()
+        a.raw_out = None if raw_out is None else raw_out.data_ptr()
+        a.ldp, a.N = p_dst.stride(0), agg.size(0)
+        a.Ka, a.s_off, a.n_gates, a.mode = w2.size(2), s_off, n_gates, mode
+        check(self.lib.ggnn_lstm_epilogue(ctypes.byref(a), _lib.current_stream()),
+              "ggnn_lstm_epilogue")
+
+    # -- heads -------------------------------------------------------------------------
+    def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):
+        _require_cuda(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area)
+        check(self.lib.ggnn_heads_regressor(ptr(h_joint), h_joint.size(0), ptr(h_grain),
+                                            h_grain.size(0), ptr(x_grain), x_grain.stride(0), ptr(w),
+                                            ptr(b), ptr(y_joint), ptr(y_grain), ptr(grain_area),
+                                            _lib.current_stream()), "ggnn_heads_regressor")
+
+    def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
+                         edge_event, edge):
+        _require_cuda(h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp, edge_event, edge)
+        E = edge_index_jj.size(1)
+        check(self.lib.ggnn_heads_classifier(ptr(h_joint), h_joint.size(0), ptr(edge_index_jj), E,
+                                             ptr(edge_attr_jj), ptr(w_node), ptr(w_edge),
+                                             ptr(node_tmp), ptr(edge_event), ptr(edge),
+                                             _lib.current_stream()), "ggnn_heads_classifier")
+
+    # -- rollout-step glue -------------------------------------------------------------
+    def step_update(self, x_joint, x_grain, y_joint, y_grain, dz, zmax, flags):
+        _require_cuda(x_joint, x_grain, y_joint, y_grain, flags)
+        check(self.lib.ggnn_step_update(ptr(x_joint), x_joint.size(0), x_joint.stride(0),
+                                        ptr(x_grain), x_grain.size(0), x_grain.stride(0),
+                                        x_grain.size(1), ptr(y_joint), ptr(y_grain), dz, zmax,
+                                        ptr(flags), _lib.current_stream()), "ggnn_step_update")
+
+    def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
+        """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E])."""
+        _require_cuda(x_joint, x_grain, flags)
+        arr = (RefreshEdge * max(len(edges), 1))()
+        for k, (ei, xs, xd, ea) in enumerate(edges):
+            _require_cuda(ei, xs, xd, ea)
+            arr[k].edge_index, arr[k].x_src, arr[k].x_dst = ei.data_ptr(), xs.data_ptr(), xd.data_ptr()
+            arr[k].edge_attr = ea.data_ptr()
+            arr[k].ldx_src, arr[k].ldx_dst = xs.stride(0), xd.stride(0)
+            arr[k].n_src, arr[k].n_dst, arr[k].E = xs.size(0), xd.size(0), ei.size(1)
+        check(self.lib.ggnn_step_refresh(ptr(x_joint), x_joint.size(0), x_joint.stride(0),
+                                         ptr(x_grain), x_grain.size(0), x_grain.stride(0), zmax,
+                                         ptr(flags), arr, len(edges), _lib.current_stream()),
+              "ggnn_step_refresh")
+
+
+_default = None
+
+
+def default_backend():
+    global _default
+    if _default is None:
+        _default = HipBackend()
+    return _default

@@ -1,0 +1,26 @@
+// Version / error strings / workspace sizing of libggnn.
+#include "common.h"
+
+extern "C" int ggnn_version(void) { return GGNN_ABI_VERSION; }
+
+extern "C" const char* ggnn_error_string(int code) {
+  switch (code) {
+    case GGNN_OK: return "ok";
+    case GGNN_EINVAL: return "invalid argument (null pointer, size, alignment or unsupported width)";
+    case GGNN_ELAUNCH: return "HIP launch / memset failed";
+    default: return "unknown ggnn error code";
+  }
+}
+
+// One model forward (decoder sizing, 4 gates): projections [n_joint, 28*96] + [n_grain, 16*96],
+// aggregates [n_joint, 4*196] + [n_grain, 4*100], two (h, c) pairs per node type, head scratch.
+extern "C" size_t ggnn_workspace_bytes(int64_t n_grain, int64_t n_joint, int64_t E) {
+  if (n_grain < 0 || n_joint < 0 || E < 0) return 0;
+  const size_t C = GGNN_C;
+  size_t floats = 0;
+  floats += (size_t)n_joint * 28 * C + (size_t)n_grain * 16 * C;
+  floats += (size_t)n_joint * 4 * 196 + (size_t)n_grain * 4 * 100;
+  floats += 4 * ((size_t)n_joint + (size_t)n_grain) * C;
+  floats += (size_t)n_joint * 8 + 3 * (size_t)E;
+  return floats * sizeof(float);
+}

@@ -1,0 +1,43 @@
+// Shared device/host helpers for libggnn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ggnn.h"
+
+namespace ggnn {
+
+constexpr int C = GGNN_C;  // 96 hidden channels
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? GGNN_OK : GGNN_ELAUNCH;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, observed not contractual): give every
+// XCD one contiguous range of logical blocks so neighbouring rows meet in the same L2.
+// Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct f3 {
+  float x, y, z;
+};
+// 12-byte row-fragment load/store; p must be 4-byte aligned.  The three adjacent dword
+// accesses are merged into one global_load_dwordx3 / global_store_dwordx3 by the backend.
+__device__ __forceinline__ f3 ld3(const float* __restrict__ p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* __restrict__ p, f3 v) {
+  p[0] = v.x;
+  p[1] = v.y;
+  p[2] = v.z;
+}
+
+}  // namespace ggnn

@@ -1,0 +1,127 @@
+// Output heads of GrainNN_regressor.forward (models.py:433-452) and
+// GrainNN_classifier.forward (models.py:595-609).  Sixteen lanes own one node (6 channels
+// each, three coalesced 8-byte loads), reduce their partial dots with four xor-shuffles.
+#include "common.h"
+
+namespace ggnn {
+
+template <int R>
+__device__ __forceinline__ void node_dots(const float* __restrict__ hrow,
+                                          const float* __restrict__ w, int l16, float (&out)[R]) {
+  float2 h[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h[k] = *reinterpret_cast<const float2*>(hrow + 32 * k + 2 * l16);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float2 wv = *reinterpret_cast<const float2*>(w + r * C + 32 * k + 2 * l16);
+      s += h[k].x * wv.x + h[k].y * wv.y;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
+    out[r] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_regressor_kernel(
+    const float* __restrict__ h_joint, int64_t n_joint, const float* __restrict__ h_grain,
+    int64_t n_grain, const float* __restrict__ x_grain, int64_t ldx_grain,
+    const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y_joint,
+    float* __restrict__ y_grain, float* __restrict__ grain_area) {
+  const int64_t node = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  if (node >= n_joint + n_grain) return;  // uniform per 16-lane group
+  float d[2];
+  if (node < n_joint) {
+    node_dots<2>(h_joint + node * C, w, l16, d);
+    if (l16 == 0) {  // models.py:443
+      y_joint[2 * node] = tanhf(d[0] + b[0]);
+      y_joint[2 * node + 1] = tanhf(d[1] + b[1]);
+    }
+  } else {
+    const int64_t g = node - n_joint;
+    node_dots<2>(h_grain + g * C, w + 2 * C, l16, d);
+    if (l16 == 0) {
+      const float t0 = tanhf(d[0] + b[2]);
+      grain_area[g] = t0 / 20.0f + x_grain[g * ldx_grain + 3];  // models.py:445
+      y_grain[2 * g] = t0;                                      // :450
+      y_grain[2 * g + 1] = fmaxf(d[1] + b[3], 0.f);             // :452
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_classifier_node_kernel(
+    const float* __restrict__ h_joint, int64_t n_joint, const float* __restrict__ w_node,
+    float* __restrict__ node_tmp) {
+  const int64_t node = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  if (node >= n_joint) return;
+  float d[6];
+  node_dots<6>(h_joint + node * C, w_node, l16, d);
+  if (l16 < 6) {
+    float v = d[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r) v = (l16 == r) ? d[r] : v;
+    node_tmp[node * 8 + l16] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_classifier_edge_kernel(
+    const float* __restrict__ node_tmp, int64_t n_joint, const int64_t* __restrict__ ei, int64_t E,
+    const float* __restrict__ edge_attr, const float* __restrict__ w_edge,
+    float* __restrict__ edge_event, float* __restrict__ edge) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = ei[e], d = ei[E + e];
+  if ((uint64_t)s >= (uint64_t)n_joint || (uint64_t)d >= (uint64_t)n_joint) {
+    edge_event[e] = NAN;  // never reached when the same edge_index passed ggnn_build_csr
+    edge[2 * e] = NAN;
+    edge[2 * e + 1] = NAN;
+    return;
+  }
+  const float a = edge_attr[e];
+  const float* ts = node_tmp + s * 8;
+  const float* td = node_tmp + d * 8;
+  edge[2 * e] = tanhf(ts[0] + td[3] + w_edge[0] * a + w_edge[3]);      // models.py:609
+  edge[2 * e + 1] = tanhf(ts[1] + td[4] + w_edge[1] * a + w_edge[4]);
+  edge_event[e] = ts[2] + td[5] + w_edge[2] * a + w_edge[5];           // models.py:607
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const float* h_grain,
+                                    int64_t n_grain, const float* x_grain, int64_t ldx_grain,
+                                    const float* w, const float* b, float* y_joint, float* y_grain,
+                                    float* grain_area, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!h_joint || !h_grain || !x_grain || !w || !b || !y_joint || !y_grain || !grain_area)
+    return GGNN_EINVAL;
+  if (n_joint <= 0 || n_grain <= 0 || ldx_grain < 4) return GGNN_EINVAL;
+  const int64_t nblk = ((n_joint + n_grain) * 16 + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(heads_regressor_kernel, dim3((unsigned)nblk), dim3(256), 0,
+                     (hipStream_t)stream, h_joint, n_joint, h_grain, n_grain, x_grain, ldx_grain, w,
+                     b, y_joint, y_grain, grain_area);
+  return launch_status();
+}
+
+extern "C" int ggnn_heads_classifier(const float* h_joint, int64_t n_joint,
+                                     const int64_t* edge_index_jj, int64_t E,
+                                     const float* edge_attr_jj, const float* w_node,
+                                     const float* w_edge, float* node_tmp, float* edge_event,
+                                     float* edge, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!h_joint || !w_node || !w_edge || !node_tmp || n_joint <= 0 || E < 0) return GGNN_EINVAL;
+  if (E > 0 && (!edge_index_jj || !edge_attr_jj || !edge_event || !edge)) return GGNN_EINVAL;
+  const int64_t nb_node = (n_joint * 16 + 255) / 256, nb_edge = (E + 255) / 256;
+  if (nb_node >= INT32_MAX || nb_edge >= INT32_MAX) return GGNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(heads_classifier_node_kernel, dim3((unsigned)nb_node), dim3(256), 0, s,
+                     h_joint, n_joint, w_node, node_tmp);
+  if (E > 0)
+    hipLaunchKernelGGL(heads_classifier_edge_kernel, dim3((unsigned)nb_edge), dim3(256), 0, s,
+                       node_tmp, n_joint, edge_index_jj, E, edge_attr_jj, w_edge, edge_event, edge);
+  return launch_status();
+}

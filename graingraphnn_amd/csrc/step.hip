@@ -1,0 +1,127 @@
+// Rollout-step glue on device (static topology):
+//   ggnn_step_update  = GrainNN_regressor.update, periodic branch (models.py:503-516)
+//                       + z advance (test.py:401-402)
+//   ggnn_step_refresh = z clamp (test.py:405-407) + edge-length refresh (test.py:562-575)
+// Two launches because the refresh needs every node's updated coordinates.
+#include "common.h"
+
+namespace ggnn {
+
+__global__ __launch_bounds__(256) void step_update_kernel(
+    float* __restrict__ x_joint, int64_t n_joint, int64_t ldxj, float* __restrict__ x_grain,
+    int64_t n_grain, int64_t ldxg, int f_grain, const float* __restrict__ y_joint,
+    const float* __restrict__ y_grain, float dz, float zmax, int32_t* __restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n_joint) {
+    float* x = x_joint + t * ldxj;
+    const float dx = y_joint[2 * t], dy = y_joint[2 * t + 1];
+    x[0] += dx / 5.0f;  // models.py:505 (scaling['joint'] = 5)
+    x[1] += dy / 5.0f;
+    x[2] += dz;         // test.py:402
+    x[6] = dx;          // models.py:510
+    x[7] = dy;
+  } else if (t < n_joint + n_grain) {
+    const int64_t g = t - n_joint;
+    float* x = x_grain + g * ldxg;
+    const float da = y_grain[2 * g], dv = y_grain[2 * g + 1];
+    const float z = x[2] + dz;  // test.py:401
+    x[2] = z;
+    x[3] += da / 20.0f;  // models.py:506 (scaling['grain'] = 20)
+    x[4] = dv;           // :507
+    x[f_grain - 1] = da;  // :511
+    if (g == 0) flags[1] = z > zmax ? 1 : 0;  // test.py:405
+  }
+}
+
+struct RefreshArgs {
+  ggnn_refresh_edge et[3];
+  int64_t e_off[4];  // prefix sums of E over the edge types
+  int n_et;
+};
+
+__global__ __launch_bounds__(256) void step_refresh_kernel(
+    float* __restrict__ x_joint, int64_t n_joint, int64_t ldxj, float* __restrict__ x_grain,
+    int64_t n_grain, int64_t ldxg, float zmax, const int32_t* __restrict__ flags,
+    const RefreshArgs R) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_nodes = n_joint + n_grain;
+  if (t < n_nodes) {
+    if (flags[1]) {  // test.py:405-407
+      if (t < n_joint)
+        x_joint[t * ldxj + 2] = zmax;
+      else
+        x_grain[(t - n_joint) * ldxg + 2] = zmax;
+    }
+    return;
+  }
+  const int64_t eg = t - n_nodes;
+  if (eg >= R.e_off[R.n_et]) return;
+  int k = 0;
+  while (k + 1 < R.n_et && eg >= R.e_off[k + 1]) ++k;
+  const ggnn_refresh_edge& T = R.et[k];
+  const int64_t e = eg - R.e_off[k];
+  const int64_t s = T.edge_index[e], d = T.edge_index[T.E + e];
+  if ((uint64_t)s >= (uint64_t)T.n_src || (uint64_t)d >= (uint64_t)T.n_dst) {
+    T.edge_attr[e] = NAN;  // never reached for an edge_index that passed ggnn_build_csr
+    return;
+  }
+  const float* xs = T.x_src + s * T.ldx_src;
+  const float* xd = T.x_dst + d * T.ldx_dst;
+  float r[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {  // test.py:570-571
+    const float rel = xs[c] - xd[c];
+    const float w = rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
+    r[c] = w + rel;
+  }
+  T.edge_attr[e] = sqrtf(r[0] * r[0] + r[1] * r[1]);  // test.py:572
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
+                                int64_t n_grain, int64_t ldx_grain, int f_grain,
+                                const float* y_joint, const float* y_grain, float dz, float zmax,
+                                int32_t* flags, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!x_joint || !x_grain || !y_joint || !y_grain || !flags) return GGNN_EINVAL;
+  if (n_joint <= 0 || n_grain <= 0 || ldx_joint < 8 || f_grain < 6 || ldx_grain < f_grain)
+    return GGNN_EINVAL;
+  const int64_t nblk = (n_joint + n_grain + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(step_update_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     x_joint, n_joint, ldx_joint, x_grain, n_grain, ldx_grain, f_grain, y_joint,
+                     y_grain, dz, zmax, flags);
+  return launch_status();
+}
+
+extern "C" int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint,
+                                 float* x_grain, int64_t n_grain, int64_t ldx_grain, float zmax,
+                                 const int32_t* flags, const ggnn_refresh_edge* edges,
+                                 int n_edge_types, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!x_joint || !x_grain || !flags || n_joint <= 0 || n_grain <= 0) return GGNN_EINVAL;
+  if (ldx_joint < 3 || ldx_grain < 3) return GGNN_EINVAL;
+  if (n_edge_types < 0 || n_edge_types > 3 || (n_edge_types > 0 && !edges)) return GGNN_EINVAL;
+  RefreshArgs R;
+  R.n_et = n_edge_types;
+  R.e_off[0] = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (k < n_edge_types) {
+      const ggnn_refresh_edge& T = edges[k];
+      if (T.E < 0 || T.ldx_src < 2 || T.ldx_dst < 2 || T.n_src <= 0 || T.n_dst <= 0) return GGNN_EINVAL;
+      if (T.E > 0 && (!T.edge_index || !T.x_src || !T.x_dst || !T.edge_attr)) return GGNN_EINVAL;
+      R.et[k] = T;
+      R.e_off[k + 1] = R.e_off[k] + T.E;
+    } else {
+      R.et[k] = ggnn_refresh_edge{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+      R.e_off[k + 1] = R.e_off[k];
+    }
+  }
+  const int64_t total = n_joint + n_grain + R.e_off[n_edge_types];
+  const int64_t nblk = (total + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(step_refresh_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     x_joint, n_joint, ldx_joint, x_grain, n_grain, ldx_grain, zmax, flags, R);
+  return launch_status();
+}

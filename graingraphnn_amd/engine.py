@@ -1,0 +1,110 @@
+"""Launch plan of one model forward on the HIP kernels.
+
+One HeteroPGCLSTM cell (heteropgclstm.py:148-183: 4 gates x 3 PeriodConv + LSTM update) is
+2 projection GEMMs + 3 aggregation sweeps + 2 gate-GEMM/LSTM epilogues = 7 launches; a
+model forward (encoder cell with h = c = 0, decoder cell, heads; models.py:422-452, 581-609)
+is 15-16 launches instead of the ~600 framework kernels the reference issues.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .packing import C, EDGE_TYPES, NODE_TYPES, PackedCell
+
+ET = Tuple[str, str, str]
+
+
+class GraphCSR:
+    """Destination-grouped neighbour lists of the three edge types of one topology."""
+
+    def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int]):
+        self.csr = {}
+        self.edge_index = {}
+        self.n_nodes = dict(n_nodes)
+        for et in EDGE_TYPES:
+            if et not in edge_index_dict:
+                raise KeyError(f"edge_index_dict lacks edge type {et}")
+            ei = edge_index_dict[et]
+            self.edge_index[et] = ei.contiguous()
+            self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
+
+
+_graph_cache: Dict[tuple, GraphCSR] = {}
+_GRAPH_CACHE_MAX = 8
+
+
+def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
+    """CSR of `edge_index_dict`, rebuilt only when a tensor is replaced or modified in place
+    (Cmodel.update swaps the tensors after a topological event, models.py:841-845)."""
+    key = tuple((et, edge_index_dict[et].data_ptr(), edge_index_dict[et]._version,
+                 tuple(edge_index_dict[et].shape)) for et in EDGE_TYPES if et in edge_index_dict)
+    key = key + tuple(sorted(n_nodes.items()))
+    g = _graph_cache.get(key)
+    if g is None:
+        g = GraphCSR(backend, edge_index_dict, n_nodes)
+        if len(_graph_cache) >= _GRAPH_CACHE_MAX:
+            _graph_cache.pop(next(iter(_graph_cache)))
+        _graph_cache[key] = g
+    return g
+
+
+class Workspace:
+    """Per-model device scratch, sized for one (n_grain, n_joint) and reused every step.
+    Aggregate buffers are zero-initialised once: their padding columns are never written and
+    meet zero weights in the gate GEMM, so they must stay finite."""
+
+    def __init__(self, enc: PackedCell, dec: PackedCell, n_nodes: Dict[str, int], device):
+        self.n_nodes = dict(n_nodes)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.proj, self.agg_enc, self.agg_dec, self.h1, self.c1, self.h2, self.c2 = {}, {}, {}, {}, {}, {}, {}
+        for nt in NODE_TYPES:
+            n = n_nodes[nt]
+            ncols = max(enc.layout[nt].ncols, dec.layout[nt].ncols)
+            self.proj[nt] = torch.empty(n, ncols, **f32)
+            self.agg_enc[nt] = torch.zeros(n, enc.G * enc.layout[nt].Ka, **f32)
+            self.agg_dec[nt] = torch.zeros(n, dec.G * dec.layout[nt].Ka, **f32)
+            for d in (self.h1, self.c1, self.h2, self.c2):
+                d[nt] = torch.empty(n, C, **f32)
+
+
+def _edge_attr_1d(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GGNNError("edge_attr must be float32")
+    if t.dim() == 2 and t.size(1) != 1:
+        raise _lib.GGNNError("edge_attr must be [E, 1] (edge_dim is forced to 1, periodGATconv.py:105)")
+    return t.contiguous().view(-1)
+
+
+def _check_x(x: torch.Tensor, F: int, name: str):
+    if x.dtype != torch.float32 or x.dim() != 2 or x.size(1) != F or x.stride(1) != 1:
+        raise _lib.GGNNError(f"x_dict['{name}'] must be float32 [N, {F}] with unit column stride")
+
+
+def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],
+             edge_attr: Dict[ET, torch.Tensor], h_in: Optional[Dict[str, torch.Tensor]],
+             c_in: Optional[Dict[str, torch.Tensor]], proj, agg, h_out, c_out):
+    """One HeteroPGCLSTM.forward.  Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
+    lay = pc.layout
+    for nt in NODE_TYPES:  # 2 projection GEMMs
+        P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
+        backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
+    for et in EDGE_TYPES:  # 3 aggregation sweeps
+        s, d = et[0], et[-1]
+        backend.aggregate(graph.csr[et], edge_attr[et], x[s], x[d], proj[s], proj[d], pc.ep[et],
+                          agg[d], lay[s].kv_off[et], lay[d].q_off[et], lay[d].a_off[et],
+                          lay[d].Ka, lay[d].sc_off[et], pc.G)
+    mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
+    for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
+        backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
+                              c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode)
+
+
+def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,
+                        x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor]):
+    """models.py:422-426 / 581-585: encoder from zero state, decoder from the encoder's (h, c),
+    both on the same x_dict.  Returns the decoder's h dict (views into the workspace)."""
+    ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
+    run_cell(backend, enc, graph, x, ea, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1)
+    run_cell(backend, dec, graph, x, ea, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2)
+    return ws.h2, ws.c2

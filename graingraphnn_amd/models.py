@@ -1,0 +1,149 @@
+"""Drop-in `GrainNN_regressor` / `GrainNN_classifier` (reference: models.py:351-611) on the
+MI355X HIP kernels.  Same constructors, same `forward(x_dict, edge_index_dict, edge_attr)`
+outputs, same `state_dict` key layout (284 tensors each; 1 204 612 / 1 204 806 parameters),
+so `torch.load`-ed reference checkpoints and the reference's rollout driver (test.py:177-184,
+382-383, 400) work unchanged.
+
+There is no CPU path: `forward` raises unless the model and the inputs live on a ROCm device
+and libggnn.so is built.
+"""
+import copy
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .backend import default_backend
+from .engine import Workspace, _check_x, _edge_attr_1d, graph_for, run_encoder_decoder
+from .modules import SeqGCLSTM, _param_version
+from .packing import C, EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
+
+ET_JJ = ("joint", "connect", "joint")
+
+
+class _GrainNNBase(nn.Module):
+    def _init_common(self, hyper):
+        self.in_channels_dict = {nt: len(f) for nt, f in hyper.features.items()}
+        self.out_channels = hyper.layer_size
+        self.num_layer = hyper.layers
+        self.metadata = hyper.metadata
+        self.out_win = getattr(hyper, "out_win", 1)
+        self.seq_len = getattr(hyper, "window", 1)
+        self.device = getattr(hyper, "device", "cuda")
+        self.dim = {"joint": 2, "grain": 1}
+        self.scaling = {"grain": 20, "joint": 5}
+        self._ws = None
+        self._heads = None
+
+    def _prepare(self, x_dict, edge_index_dict, edge_attr):
+        be = default_backend()
+        for nt in NODE_TYPES:
+            _check_x(x_dict[nt], self.in_channels_dict[nt], nt)
+        n_nodes = {nt: x_dict[nt].size(0) for nt in NODE_TYPES}
+        graph = graph_for(be, edge_index_dict, n_nodes)
+        enc = self.gclstm_encoder.cell_list[0].packed(True)
+        dec = self.gclstm_decoder.cell_list[0].packed(False)
+        dev = x_dict["joint"].device
+        if self._ws is None or self._ws.n_nodes != n_nodes or self._ws.proj["joint"].device != dev:
+            self._ws = Workspace(enc, dec, n_nodes, dev)
+        return be, graph, enc, dec, self._ws
+
+    def _packed_heads(self, fn, *mods):
+        ver = tuple(_param_version(m) for m in mods)
+        if self._heads is None or self._heads[0] != ver:
+            self._heads = (ver, fn(*mods))
+        return self._heads[1]
+
+
+class GrainNN_regressor(_GrainNNBase):
+    """models.py:351-516."""
+
+    def __init__(self, hyper, history=False, edge_len=False):
+        super().__init__()
+        if history or edge_len:
+            raise NotImplementedError(
+                "history / edge_len branches are disabled in every shipped config "
+                "(train.py:221,225; test.py:177,182) and are not built")
+        self._init_common(hyper)
+        self.history, self.edge_len = history, edge_len
+        self.gclstm_encoder = SeqGCLSTM(self.in_channels_dict, self.out_channels, self.num_layer,
+                                        self.metadata, self.device)
+        self.gclstm_decoder = SeqGCLSTM(self.in_channels_dict, self.out_channels, self.num_layer,
+                                        self.metadata, self.device)
+        self.linear = nn.ModuleDict({nt: nn.Linear(self.out_channels, len(t))
+                                     for nt, t in hyper.targets.items()})
+        for nt, t in hyper.targets.items():
+            if len(t) != 2:
+                raise NotImplementedError("regressor heads are Linear(96, 2) per node type")
+
+    @torch.no_grad()
+    def forward(self, x_dict, edge_index_dict, edge_attr):
+        be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
+        h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
+        w, b = self._packed_heads(pack_regressor_heads, self.linear)
+        dev = x_dict["joint"].device
+        y_joint = torch.empty(x_dict["joint"].size(0), 2, device=dev)
+        y_grain = torch.empty(x_dict["grain"].size(0), 2, device=dev)
+        area = torch.empty(x_dict["grain"].size(0), device=dev)
+        be.heads_regressor(h["joint"], h["grain"], x_dict["grain"], w, b, y_joint, y_grain, area)
+        return {"grain": y_grain, "joint": y_joint, "grain_area": area}
+
+    @torch.no_grad()
+    def update(self, x_dict, y_dict, geometry_scaling):
+        """Periodic / no-melt-pool branch of models.py:473-516, in place on x_dict."""
+        if geometry_scaling is not None and "melt_left" in geometry_scaling:
+            raise NotImplementedError("moving-melt-pool windowing (models.py:480-501) is out of scope")
+        be = default_backend()
+        if geometry_scaling is not None:
+            geometry_scaling["active_grains"] = (y_dict["grain"][:, 0] > -10).nonzero().view(-1)
+            geometry_scaling["active_joints"] = (y_dict["joint"][:, 0] > -10).nonzero().view(-1)
+        flags = torch.zeros(2, dtype=torch.int32, device=x_dict["joint"].device)
+        be.step_update(x_dict["joint"], x_dict["grain"], y_dict["joint"].contiguous(),
+                       y_dict["grain"].contiguous(), 0.0, float("inf"), flags)
+
+
+class GrainNN_classifier(_GrainNNBase):
+    """models.py:529-611.  With a regressor, encoder/decoder start as deep copies of its
+    (transfer learning, models.py:551-552)."""
+
+    def __init__(self, hyper, regressor=None, history=False):
+        super().__init__()
+        if history:
+            raise NotImplementedError("history branch is disabled in every shipped config")
+        self._init_common(hyper)
+        self.history = history
+        if regressor is not None:
+            self.gclstm_encoder = copy.deepcopy(regressor.gclstm_encoder)
+            self.gclstm_decoder = copy.deepcopy(regressor.gclstm_decoder)
+        else:
+            self.gclstm_encoder = SeqGCLSTM(self.in_channels_dict, self.out_channels,
+                                            self.num_layer, self.metadata, self.device)
+            self.gclstm_decoder = SeqGCLSTM(self.in_channels_dict, self.out_channels,
+                                            self.num_layer, self.metadata, self.device)
+        self.lin1 = nn.Linear(2 * self.out_channels + 1, 2)
+        self.lin2 = nn.Linear(2 * self.out_channels + 1, 1)
+        self._tmp = None
+
+    @torch.no_grad()
+    def forward(self, x_dict, edge_index_dict, edge_attr):
+        be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
+        h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
+        w_node, w_edge = self._packed_heads(pack_classifier_heads, self.lin1, self.lin2)
+        dev = x_dict["joint"].device
+        n_joint = x_dict["joint"].size(0)
+        ei = graph.edge_index[ET_JJ]
+        E = ei.size(1)
+        if self._tmp is None or self._tmp.size(0) != n_joint or self._tmp.device != dev:
+            self._tmp = torch.empty(n_joint, 8, device=dev)
+        edge_event = torch.empty(E, device=dev)
+        edge = torch.empty(E, 2, device=dev)
+        be.heads_classifier(h["joint"], ei, _edge_attr_1d(edge_attr[ET_JJ]), w_node, w_edge,
+                            self._tmp, edge_event, edge)
+        return {"edge_event": edge_event, "edge": edge}
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError(
+            "topology surgery (models.py:614-1053) is host-side, data-dependent code outside the "
+            "accelerated hot path (SURVEY.md section 8f-2); use the reference implementation on the "
+            "tensors returned by forward()")

@@ -1,0 +1,158 @@
+"""Parameter holders with the reference's module tree (so `.pt` state_dicts load unchanged)
+whose `forward` runs on the HIP kernels.
+
+Reference classes mirrored (constructor arguments, attribute names, forward signatures):
+  PeriodConv     periodGATconv.py:15-236   (heads=1, concat, edge_dim=1, no beta, dropout 0)
+  HeteroConv     torch_geometric 2.1.0 as used at heteropgclstm.py:49-82 (ModuleDict `convs`,
+                 keys '__'.join(edge_type), aggr='sum')
+  HeteroPGCLSTM  heteropgclstm.py:18-183
+  SeqGCLSTM      models.py:151-301 (layers == 1, seq_len == 1)
+"""
+import math
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .backend import default_backend
+from .engine import GraphCSR, Workspace, _check_x, _edge_attr_1d, graph_for, run_cell
+from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, pack_cell, pack_conv, roundup4
+
+
+def _param_version(module: nn.Module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+class PeriodConv(nn.Module):
+    """periodGATconv.py:90-154.  `in_channels` = (source width, destination width)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        if out_channels != C:
+            raise NotImplementedError(f"the HIP path is built for layer_size {C} (got {out_channels})")
+        self.in_channels = tuple(in_channels)
+        self.out_channels = out_channels
+        self.lin_key = nn.Linear(in_channels[0], out_channels)
+        self.lin_query = nn.Linear(in_channels[1], out_channels)
+        self.lin_value = nn.Linear(in_channels[0], out_channels)
+        self.lin_l2 = nn.Linear(out_channels, out_channels, bias=bias)
+        self.lin_edge = nn.Linear(1, out_channels, bias=False)
+        self.lin_skip = nn.Linear(in_channels[1], out_channels, bias=bias)
+
+    @torch.no_grad()
+    def forward(self, x, edge_index, edge_attr=None):
+        """x: Tensor or (x_src, x_dst), rows = cat[features, h] (width F + 96) or bare
+        features (width F <= 12); edge_index [2, E] int64; edge_attr [E, 1].  -> [N_dst, 96]."""
+        be = default_backend()
+        x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
+        Ds, Dd = self.in_channels
+        k2 = C if Ds > 12 else 0
+        Fs, Fd = Ds - k2, Dd - k2
+        wps, bps, wpd, bpd, ep, w2 = pack_conv(self, Fs, Fd, k2)
+        dev = x_src.device
+        xs, xd = x_src[:, :Fs].contiguous(), x_dst[:, :Fd].contiguous()
+        hs = x_src[:, Fs:].contiguous() if k2 else None
+        hd = x_dst[:, Fd:].contiguous() if k2 else None
+        ps = torch.empty(x_src.size(0), 2 * C, device=dev)
+        pd = torch.empty(x_dst.size(0), 2 * C, device=dev)
+        be.project(xs, Fs, hs, wps, bps, ps)
+        be.project(xd, Fd, hd, wpd, bpd, pd)
+        csr = be.build_csr(edge_index, x_src.size(0), x_dst.size(0))
+        agg = torch.zeros(x_dst.size(0), 100, device=dev)
+        be.aggregate(csr, _edge_attr_1d(edge_attr), xs, xd, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)
+        out = torch.empty(x_dst.size(0), C, device=dev)
+        be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW)
+        return out
+
+
+class HeteroConv(nn.Module):
+    def __init__(self, convs: Dict[tuple, nn.Module]):
+        super().__init__()
+        self.convs = nn.ModuleDict(OrderedDict((et_key(et), m) for et, m in convs.items()))
+
+
+class HeteroPGCLSTM(nn.Module):
+    """heteropgclstm.py:30-99: conv_{i,f,c,o} (HeteroConv of 3 PeriodConv on cat[x, h]) and
+    per-node-type gate biases b_{i,f,c,o} [1, C] (glorot)."""
+
+    def __init__(self, in_channels_dict, out_channels, metadata, bias=True, device="cpu"):
+        super().__init__()
+        if out_channels != C:
+            raise NotImplementedError(f"the HIP path is built for layer_size {C} (got {out_channels})")
+        self.in_channels_dict = dict(in_channels_dict)
+        self.out_channels = out_channels
+        self.metadata = metadata
+        edge_types = [tuple(et) for et in metadata[1]]
+        if sorted(edge_types) != sorted(EDGE_TYPES) or sorted(in_channels_dict) != sorted(NODE_TYPES):
+            raise NotImplementedError(
+                f"graph schema must be node types {NODE_TYPES} and edge types {EDGE_TYPES}")
+        for nt, F in in_channels_dict.items():
+            if not 3 <= F <= 12:
+                raise NotImplementedError(f"{nt}: feature width {F} outside the supported 3..12")
+        self.edge_types = edge_types
+        for g in "ifco":
+            setattr(self, "conv_" + g, HeteroConv({
+                et: PeriodConv((in_channels_dict[et[0]] + C, in_channels_dict[et[-1]] + C), C, bias)
+                for et in edge_types}))
+            b = nn.ParameterDict({nt: nn.Parameter(torch.empty(1, C)) for nt in in_channels_dict})
+            for p in b.values():
+                bound = math.sqrt(6.0 / (p.size(-2) + p.size(-1)))  # glorot, heteropgclstm.py:90-99
+                nn.init.uniform_(p, -bound, bound)
+            setattr(self, "b_" + g, b)
+        self._packed = {}
+
+    def packed(self, encoder: bool):
+        """Fused device weights, re-packed when parameters were replaced or updated."""
+        ver = _param_version(self)
+        hit = self._packed.get(encoder)
+        if hit is None or hit[0] != ver:
+            hit = (ver, pack_cell(self, self.in_channels_dict, encoder))
+            self._packed[encoder] = hit
+        return hit[1]
+
+    @torch.no_grad()
+    def forward(self, x_dict, edge_index_dict, edge_attr=None, h_dict=None, c_dict=None):
+        be = default_backend()
+        n_nodes = {nt: x_dict[nt].size(0) for nt in NODE_TYPES}
+        for nt in NODE_TYPES:
+            _check_x(x_dict[nt], self.in_channels_dict[nt], nt)
+        graph = graph_for(be, edge_index_dict, n_nodes)
+        encoder = h_dict is None
+        pc = self.packed(encoder)
+        dev = x_dict["joint"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        proj = {nt: torch.empty(n_nodes[nt], pc.layout[nt].ncols, **f32) for nt in NODE_TYPES}
+        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Ka, **f32) for nt in NODE_TYPES}
+        h_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
+        c_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
+        ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
+        if not encoder:
+            if c_dict is None:
+                c_dict = {nt: torch.zeros(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
+            h_dict = {nt: h_dict[nt].contiguous() for nt in NODE_TYPES}
+            c_dict = {nt: c_dict[nt].contiguous() for nt in NODE_TYPES}
+        run_cell(be, pc, graph, x_dict, ea, h_dict, c_dict, proj, agg, h_out, c_out)
+        return h_out, c_out
+
+
+class SeqGCLSTM(nn.Module):
+    """models.py:173-216 with layers == 1 (parameters.py:49,90,130)."""
+
+    def __init__(self, in_channels_dict, out_channels, num_layers, metadata, device,
+                 bias=True, return_all_layers=True):
+        super().__init__()
+        if num_layers != 1:
+            raise NotImplementedError("only layers == 1 is on the shipped path (parameters.py:49)")
+        self.in_channels_dict = dict(in_channels_dict)
+        self.num_layers = num_layers
+        self.cell_list = nn.ModuleList(
+            [HeteroPGCLSTM(in_channels_dict, out_channels, metadata, bias, device)])
+
+    def forward(self, x_dict, edge_index_dict, edge_attr, hidden_state):
+        h, c = (None, None) if hidden_state is None else hidden_state[0]
+        h, c = self.cell_list[0](x_dict, edge_index_dict, edge_attr, h, c)
+        return [[h, c]]

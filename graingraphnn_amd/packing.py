@@ -1,0 +1,217 @@
+"""Host-side weight packing: reference `state_dict` layout -> the fused device layouts the
+HIP kernels consume.  Pure tensor reshuffling (no arithmetic except summing the `lin_skip`
+weights of edge types that share a destination, which is what HeteroConv(aggr='sum') does to
+their outputs -- heteropgclstm.py:49-82 -- and folding the gate bias b_{i,f,c,o} in).
+
+Layouts (C = 96, G = number of gates, F = features of the node type, Fp = roundup4(F)):
+
+* projection weight of node type T, `Wp [ncols, Kp]`, Kp = Fp + (96 if the cell sees h else 0):
+    columns of the OUTPUT (rows of Wp), in blocks of 96:
+      for each edge type with source T (canonical order):  for g: [K_g | V_g]
+      for each edge type with destination T:               for g: [Q_g]
+      summed skip + gate bias:                             for g: [S_g]
+    K/V rows have their first three input columns zeroed: the aggregation kernel re-adds
+    `W[:, :3] . minimg(x_j - x_i)` per edge (periodGATconv.py:209-211).
+* edge parameters of an edge type, `EP [G][7][96]`: W_key[:, 0..2], W_value[:, 0..2], w_edge.
+* gate weight of node type T, `W2 [G][96][Ka]`, Ka = roundup4(98 * n_in):
+      [lin_l2.weight of incoming edge type 0 | ... | (b_l2, w_edge) of type 0 | ...]
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import torch
+
+C = 96
+NODE_TYPES = ("grain", "joint")
+EDGE_TYPES = (("grain", "push", "joint"), ("joint", "pull", "grain"), ("joint", "connect", "joint"))
+GATES_DEC = ("i", "f", "c", "o")
+GATES_ENC = ("i", "c", "o")  # h = c = 0: the forget gate multiplies c = 0 (heteropgclstm.py:132)
+
+
+def et_key(et) -> str:
+    return "__".join(et)
+
+
+def roundup4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+@dataclass
+class NodeLayout:
+    """Column offsets inside the projection buffer / aggregate buffer of one node type."""
+    F: int
+    G: int
+    src_ets: List[Tuple[str, str, str]]
+    dst_ets: List[Tuple[str, str, str]]
+    kv_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    q_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    a_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    sc_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    s_off: int = 0
+    ncols: int = 0
+    Ka: int = 0
+
+    @property
+    def Fp(self):
+        return roundup4(self.F)
+
+
+def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES) -> NodeLayout:
+    src_ets = [tuple(et) for et in edge_types if et[0] == node_type]
+    dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type]
+    lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets)
+    off = 0
+    for et in src_ets:
+        lay.kv_off[et] = off
+        off += G * 2 * C
+    for et in dst_ets:
+        lay.q_off[et] = off
+        off += G * C
+    lay.s_off = off
+    lay.ncols = off + G * C
+    n_in = len(dst_ets)
+    lay.Ka = roundup4(n_in * C + 2 * n_in)
+    for d, et in enumerate(dst_ets):
+        lay.a_off[et] = d * C
+        lay.sc_off[et] = n_in * C + 2 * d
+    return lay
+
+
+@dataclass
+class PackedCell:
+    """Device-resident fused parameters of one HeteroPGCLSTM cell."""
+    G: int
+    k2: int  # 96 (decoder: input is cat[x, h]) or 0 (encoder: h = 0)
+    layout: Dict[str, NodeLayout]
+    wp: Dict[str, torch.Tensor]     # node type -> [ncols, Kp]
+    bp: Dict[str, torch.Tensor]     # node type -> [ncols]
+    ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 7, 96]
+    w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
+
+
+def _conv(cell, gate, et):
+    return getattr(cell, "conv_" + gate).convs[et_key(et)]
+
+
+@torch.no_grad()
+def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_TYPES) -> PackedCell:
+    """`cell` is a HeteroPGCLSTM parameter holder (same attribute tree as heteropgclstm.py:30-99)."""
+    gates = GATES_ENC if encoder else GATES_DEC
+    G = len(gates)
+    k2 = 0 if encoder else C
+    some = _conv(cell, "i", edge_types[0]).lin_key.weight
+    dev, dt = some.device, torch.float32
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types) for nt in NODE_TYPES}
+    wp, bp, w2, ep = {}, {}, {}, {}
+
+    def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz):
+        """weight: [96, F + 96] reference layout -> rows row0..row0+95 of the packed matrix."""
+        w = weight.detach().to(dt)
+        blk = dst_w[row0:row0 + C]
+        blk[:, :F] = w[:, :F]
+        if zero_xyz:
+            blk[:, :3] = 0.0
+        if k2:
+            blk[:, Fp:Fp + C] = w[:, F:F + C]
+        dst_b[row0:row0 + C] += bias.detach().to(dt)
+
+    for nt in NODE_TYPES:
+        lay = layout[nt]
+        F, Fp = lay.F, lay.Fp
+        W = torch.zeros(lay.ncols, Fp + k2, dtype=dt, device=dev)
+        B = torch.zeros(lay.ncols, dtype=dt, device=dev)
+        for et in lay.src_ets:
+            for g, gate in enumerate(gates):
+                conv = _conv(cell, gate, et)
+                base = lay.kv_off[et] + g * 2 * C
+                put(W, B, base, F, Fp, conv.lin_key.weight, conv.lin_key.bias, True)
+                put(W, B, base + C, F, Fp, conv.lin_value.weight, conv.lin_value.bias, True)
+        for et in lay.dst_ets:
+            for g, gate in enumerate(gates):
+                conv = _conv(cell, gate, et)
+                put(W, B, lay.q_off[et] + g * C, F, Fp, conv.lin_query.weight, conv.lin_query.bias, False)
+        for g, gate in enumerate(gates):
+            row0 = lay.s_off + g * C
+            for et in lay.dst_ets:  # HeteroConv sums the outputs -> sum the skip weights
+                conv = _conv(cell, gate, et)
+                w = conv.lin_skip.weight.detach().to(dt)
+                W[row0:row0 + C, :F] += w[:, :F]
+                if k2:
+                    W[row0:row0 + C, Fp:Fp + C] += w[:, F:F + C]
+                B[row0:row0 + C] += conv.lin_skip.bias.detach().to(dt)
+            B[row0:row0 + C] += getattr(cell, "b_" + gate)[nt].detach().to(dt).view(-1)
+        wp[nt], bp[nt] = W.contiguous(), B.contiguous()
+
+        n_in = len(lay.dst_ets)
+        W2 = torch.zeros(G, C, lay.Ka, dtype=dt, device=dev)
+        for d, et in enumerate(lay.dst_ets):
+            for g, gate in enumerate(gates):
+                conv = _conv(cell, gate, et)
+                W2[g, :, d * C:(d + 1) * C] = conv.lin_l2.weight.detach().to(dt)
+                W2[g, :, n_in * C + 2 * d] = conv.lin_l2.bias.detach().to(dt)
+                W2[g, :, n_in * C + 2 * d + 1] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+        w2[nt] = W2.contiguous()
+
+    for et in edge_types:
+        et = tuple(et)
+        E = torch.zeros(G, 7, C, dtype=dt, device=dev)
+        for g, gate in enumerate(gates):
+            conv = _conv(cell, gate, et)
+            E[g, 0:3] = conv.lin_key.weight.detach().to(dt)[:, 0:3].t()
+            E[g, 3:6] = conv.lin_value.weight.detach().to(dt)[:, 0:3].t()
+            E[g, 6] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+        ep[et] = E.contiguous()
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2)
+
+
+@torch.no_grad()
+def pack_conv(conv, F_src: int, F_dst: int, k2: int):
+    """Single PeriodConv (one gate, one edge type) for op-level parity tests.  Returns
+    (wp_src [192, Kp_s], bp_src, wp_dst [192, Kp_d], bp_dst, ep [1,7,96], w2 [1,96,100]):
+    source projection = [K | V], destination projection = [Q | S]."""
+    dt = torch.float32
+    dev = conv.lin_key.weight.device
+
+    def pack(weight, F, zero_xyz):
+        Fp = roundup4(F)
+        w = weight.detach().to(dt)
+        out = torch.zeros(C, Fp + k2, dtype=dt, device=dev)
+        out[:, :F] = w[:, :F]
+        if zero_xyz:
+            out[:, :3] = 0.0
+        if k2:
+            out[:, Fp:Fp + C] = w[:, F:F + C]
+        return out
+
+    wp_src = torch.cat([pack(conv.lin_key.weight, F_src, True), pack(conv.lin_value.weight, F_src, True)])
+    bp_src = torch.cat([conv.lin_key.bias, conv.lin_value.bias]).detach().to(dt)
+    wp_dst = torch.cat([pack(conv.lin_query.weight, F_dst, False), pack(conv.lin_skip.weight, F_dst, False)])
+    bp_dst = torch.cat([conv.lin_query.bias, conv.lin_skip.bias]).detach().to(dt)
+    ep = torch.zeros(1, 7, C, dtype=dt, device=dev)
+    ep[0, 0:3] = conv.lin_key.weight.detach().to(dt)[:, 0:3].t()
+    ep[0, 3:6] = conv.lin_value.weight.detach().to(dt)[:, 0:3].t()
+    ep[0, 6] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+    w2 = torch.zeros(1, C, 100, dtype=dt, device=dev)
+    w2[0, :, :C] = conv.lin_l2.weight.detach().to(dt)
+    w2[0, :, C] = conv.lin_l2.bias.detach().to(dt)
+    w2[0, :, C + 1] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+    return (wp_src.contiguous(), bp_src.contiguous(), wp_dst.contiguous(), bp_dst.contiguous(),
+            ep.contiguous(), w2.contiguous())
+
+
+@torch.no_grad()
+def pack_regressor_heads(linear):
+    """`linear` = ModuleDict {'grain','joint'} of Linear(96, 2) (models.py:393-394)."""
+    w = torch.stack([linear["joint"].weight, linear["grain"].weight]).detach().float().contiguous()
+    b = torch.cat([linear["joint"].bias, linear["grain"].bias]).detach().float().contiguous()
+    return w, b  # [2, 2, 96], [4]
+
+
+@torch.no_grad()
+def pack_classifier_heads(lin1, lin2):
+    """lin1: Linear(193, 2), lin2: Linear(193, 1) (models.py:568-569)."""
+    w1, w2 = lin1.weight.detach().float(), lin2.weight.detach().float()
+    w_node = torch.stack([w1[0, :C], w1[1, :C], w2[0, :C], w1[0, C:2 * C], w1[1, C:2 * C], w2[0, C:2 * C]])
+    w_edge = torch.stack([w1[0, 2 * C], w1[1, 2 * C], w2[0, 2 * C], lin1.bias[0].detach().float(),
+                          lin1.bias[1].detach().float(), lin2.bias[0].detach().float()])
+    return w_node.contiguous(), w_edge.contiguous()  # [6, 96], [6]

@@ -1,0 +1,118 @@
+"""Static-topology rollout driver: the hot loop of test.py:353-577 with everything that
+runs per step kept on the device.
+
+One step = Rmodel.forward + Cmodel.forward (test.py:382-383) + Rmodel.update (:400)
++ z advance and clamp (:401-407) + edge-length refresh (:562-575).  Grain-event / edge-event
+topology surgery (Cmodel.update, :426) and the polygon geometry of traj.GNN_update (:478)
+are host code outside this path; the topology is therefore static here and the grain
+centres x_grain[:, :2] are not refreshed.
+
+The whole step is 34 kernel launches with no host synchronisation and no allocation, so it
+can be replayed from a hipGraph (`use_graph=True`) to remove launch overhead on small graphs.
+"""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .backend import default_backend
+from .engine import Workspace, _check_x, graph_for, run_encoder_decoder
+from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
+
+TRAIN_FRAMES = 120  # test.py:190
+ET_JJ = ("joint", "connect", "joint")
+
+
+class GrainRollout:
+    def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
+                 edge_attr_dict, span: int, use_graph: bool = False):
+        self.be = default_backend()
+        self.rmodel, self.cmodel = rmodel, cmodel
+        self.x = {nt: x_dict[nt] for nt in NODE_TYPES}  # mutated in place, like the reference
+        for nt in NODE_TYPES:
+            _check_x(self.x[nt], rmodel.in_channels_dict[nt], nt)
+            if not self.x[nt].is_contiguous():
+                raise _lib.GGNNError("x_dict tensors must be contiguous")
+        dev = self.x["joint"].device
+        self.n_nodes = {nt: self.x[nt].size(0) for nt in NODE_TYPES}
+        self.graph = graph_for(self.be, edge_index_dict, self.n_nodes)
+        # edge lengths live in our own [E] buffers (refreshed in place every step)
+        self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
+                          for et in EDGE_TYPES}
+        self.span = span
+        # test.py:401-406 computes in fp32: z += fp32(span/121); clamp at fp32(120/121)
+        self.dz = float(np.float32(span / (TRAIN_FRAMES + 1)))
+        self.zmax = float(np.float32(TRAIN_FRAMES / (TRAIN_FRAMES + 1)))
+        self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.packed = {}
+        self.ws = {}
+        for name, m in (("R", rmodel), ("C", cmodel)):
+            enc = m.gclstm_encoder.cell_list[0].packed(True)
+            dec = m.gclstm_decoder.cell_list[0].packed(False)
+            self.packed[name] = (enc, dec)
+            self.ws[name] = Workspace(enc, dec, self.n_nodes, dev)
+        self.w_reg = pack_regressor_heads(rmodel.linear)
+        self.w_cls = pack_classifier_heads(cmodel.lin1, cmodel.lin2)
+        nj, ng = self.n_nodes["joint"], self.n_nodes["grain"]
+        E = self.graph.edge_index[ET_JJ].size(1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.pred = {
+            "joint": torch.empty(nj, 2, **f32), "grain": torch.empty(ng, 2, **f32),
+            "grain_area": torch.empty(ng, **f32), "edge_event": torch.empty(E, **f32),
+            "edge": torch.empty(E, 2, **f32),
+        }
+        self._tmp = torch.empty(nj, 8, **f32)
+        self.steps_done = 0
+        self._graph_exec = None
+        if use_graph:
+            self._capture()
+
+    # -- one step, enqueued on the current stream --------------------------------------
+    def _enqueue_step(self):
+        be, x, ea, p = self.be, self.x, self.edge_attr, self.pred
+        enc, dec = self.packed["R"]
+        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea)
+        be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
+                           p["joint"], p["grain"], p["grain_area"])
+        enc, dec = self.packed["C"]
+        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea)
+        be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                            self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+        be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+        be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
+                        [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et]) for et in EDGE_TYPES])
+
+    def _capture(self):
+        """Record one step into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm); the
+        kernels are launched through the C ABI on the capturing stream."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            # the capture records, it does not execute: x / edge_attr are left untouched
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._enqueue_step()
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph_exec = g
+
+    def step(self):
+        """Advance one rollout step; returns the prediction dict (tensors are reused)."""
+        if self._graph_exec is not None:
+            self._graph_exec.replay()
+        else:
+            self._enqueue_step()
+        self.steps_done += 1
+        return self.pred
+
+    def run(self, n_steps: int):
+        for _ in range(n_steps):
+            self.step()
+        return self.pred
+
+    def state(self):
+        """Final state a caller gathers across ranks: joint xy and grain (area, extraV)."""
+        return {"joint_xy": self.x["joint"][:, :2].clone(), "grain_area_v": self.x["grain"][:, 3:5].clone()}
+
+    def edge_attr_dict(self):
+        return {et: self.edge_attr[et].view(-1, 1) for et in EDGE_TYPES}

@@ -1,0 +1,126 @@
+"""Graph inputs: the committed reference fixtures (`tests/golden/graph_*.npz`) and the
+synthetic periodic honeycomb of SURVEY.md section 8(d) (cfg3: 100 x 100 hexagonal grains on
+the unit torus = 10 000 grains / 20 000 junctions / 60 000 edges per type).
+
+Feature schema (graph_datastruct.py:827-831 + gradients :1000-1010):
+  grain: x, y, z, area, extraV, cosx, sinx, cosz, sinz, span, darea       (11)
+  joint: x, y, z, G, R, span, dx, dy                                      (8)
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+GJ = ("grain", "push", "joint")
+JG = ("joint", "pull", "grain")
+JJ = ("joint", "connect", "joint")
+EDGE_TYPES = (GJ, JG, JJ)
+FEATURES = {
+    "grain": ["x", "y", "z", "area", "extraV", "cosx", "sinx", "cosz", "sinz", "span", "darea"],
+    "joint": ["x", "y", "z", "G", "R", "span", "dx", "dy"],
+}
+TARGETS = {"grain": ["darea", "extraV"], "joint": ["dx", "dy"]}
+
+
+def default_hyper(device="cuda"):
+    """The `hyper` attribute bag of the shipped models (parameters.py:18-50, 97-134;
+    test.py:162-175): layer_size 96, layers 1, window 1."""
+    return SimpleNamespace(features=FEATURES, targets=TARGETS, layer_size=96, layers=1,
+                           metadata=(["grain", "joint"], [GJ, JG, JJ]), out_win=1, window=1,
+                           device=device)
+
+
+def _minimg(d):
+    return d - np.round(d)
+
+
+def edge_lengths(x_dict, edge_index_dict):
+    """numpy restatement of test.py:562-575 for building inputs (float64 in, float32 out)."""
+    out = {}
+    for et, ei in edge_index_dict.items():
+        rel = x_dict[et[0]][ei[0], :2] - x_dict[et[-1]][ei[1], :2]
+        rel = np.where(rel > 0.5, rel - 1.0, np.where(rel < -0.5, rel + 1.0, rel))
+        out[et] = np.sqrt((rel ** 2).sum(1)).astype(np.float32).reshape(-1, 1)
+    return out
+
+
+def honeycomb(n: int = 100, fold: int = 10, seed: int = 0, shuffle_edges: bool = True):
+    """Periodic honeycomb with n x n grains (n even).  Returns numpy dicts
+    (x_dict, edge_index_dict, edge_attr_dict) after integer patch folding by `fold`
+    (test.py:29-55: xy <- (xy * fold) mod 1), ready for torch.from_numpy."""
+    if n % 2 or n < 4:
+        raise ValueError("n must be even and >= 4")
+    rs = np.random.RandomState(seed)
+    dx = dy = 1.0 / n
+    r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    r, c = r.ravel(), c.ravel()
+    gid = r * n + c
+    odd = r & 1
+
+    def g(rr, cc):
+        return (rr % n) * n + (cc % n)
+
+    UR, UL = g(r + 1, c + odd), g(r + 1, c + odd - 1)
+    DR, DL = g(r - 1, c + odd), g(r - 1, c + odd - 1)
+    T, B = 2 * gid, 2 * gid + 1
+    cx, cy = (c + 0.5 * odd) * dx, r * dy
+    n_g, n_j = n * n, 2 * n * n
+    xj = np.zeros((n_j, 2))
+    xj[T] = np.stack([cx, cy + 2 * dy / 3], 1)
+    xj[B] = np.stack([cx, cy - 2 * dy / 3], 1)
+    xj += rs.normal(0.0, 0.1 * (2 * dy / 3), size=xj.shape)
+    xj %= 1.0
+    # the six junctions of every grain: N, NE, SE, S, SW, NW
+    hexj = np.stack([T, 2 * UR + 1, 2 * DR, B, 2 * DL, 2 * UL + 1], 1)  # [n_g, 6]
+    ref = xj[hexj[:, 0]]
+    xg = (ref + _minimg(xj[hexj] - ref[:, None, :]).mean(1)) % 1.0
+    # edges: joint -> grain (6 per grain), grain -> joint = flip, joint <-> joint (3 per joint)
+    jg = np.stack([hexj.ravel(), np.repeat(gid, 6)])
+    gj = jg[::-1].copy()
+    up2, dn2 = g(r + 2, c), g(r - 2, c)
+    jj_src = np.concatenate([T, T, T, B, B, B])
+    jj_dst = np.concatenate([2 * UR + 1, 2 * UL + 1, 2 * up2 + 1, 2 * DR, 2 * DL, 2 * dn2])
+    jj = np.stack([jj_src, jj_dst])
+    ei = {GJ: gj, JG: jg, JJ: jj}
+    if shuffle_edges:
+        for k, et in enumerate(EDGE_TYPES):
+            p = np.random.RandomState(seed + 1 + k).permutation(ei[et].shape[1])
+            ei[et] = ei[et][:, p]
+    ei = {et: np.ascontiguousarray(v.astype(np.int64)) for et, v in ei.items()}
+    # features
+    theta_x, theta_z = rs.uniform(0, np.pi / 2, n_g), rs.uniform(0, np.pi / 2, n_g)
+    area = np.clip(0.0087 * (1 + 0.1 * rs.normal(size=n_g)), 0.002, None)
+    fg = np.zeros((n_g, 11))
+    fg[:, :2] = (xg * fold) % 1.0
+    fg[:, 3] = area
+    fg[:, 5], fg[:, 6], fg[:, 7], fg[:, 8] = np.cos(theta_x), np.sin(theta_x), np.cos(theta_z), np.sin(theta_z)
+    fg[:, 9] = 6 / 120
+    fj = np.zeros((n_j, 8))
+    fj[:, :2] = (xj * fold) % 1.0
+    fj[:, 3], fj[:, 4], fj[:, 5] = 0.0, 1.0, 6 / 120
+    x = {"grain": fg.astype(np.float32), "joint": fj.astype(np.float32)}
+    ea = edge_lengths({k: v.astype(np.float64) for k, v in x.items()}, ei)
+    return x, ei, ea
+
+
+def load_fixture(path):
+    """tests/golden/graph_*.npz -> (x_dict, edge_index_dict, edge_attr_dict) of numpy arrays."""
+    z = np.load(path)
+    x = {"grain": z["x_grain"], "joint": z["x_joint"]}
+    ei = {et: z["ei_" + "__".join(et)] for et in EDGE_TYPES}
+    ea = {et: z["ea_" + "__".join(et)] for et in EDGE_TYPES}
+    return x, ei, ea
+
+
+def to_torch(x, ei, ea, device="cpu"):
+    return ({k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in x.items()},
+            {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in ei.items()},
+            {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in ea.items()})
+
+
+def perturbed_copy(x, sigma: float, seed: int):
+    """cfg4: weight-independent per-trajectory perturbation of the joint xy."""
+    rs = np.random.RandomState(seed)
+    out = {k: v.copy() for k, v in x.items()}
+    out["joint"][:, :2] += rs.normal(0.0, sigma, size=out["joint"][:, :2].shape).astype(np.float32)
+    return out

@@ -1,0 +1,186 @@
+/*
+ * ggnn.h -- C ABI of libggnn.so: the MI355X (gfx950) kernels behind the GrainGNN rollout
+ * hot path (GrainNN_regressor.forward + GrainNN_classifier.forward + rollout-step glue).
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers + sizes + a hipStream_t
+ * (passed as void*), never allocates, never synchronises, never throws, keeps no global
+ * state, and returns 0 or a negative GGNN_E* code.  All work is enqueued on `stream`, so
+ * a caller may capture any sequence of calls into a hipGraph.
+ *
+ * Citations (file:line) are into the reference repository YigongQin/GrainGraphNN.  The
+ * reference has no FFI of its own (it is pure Python on PyTorch + PyG); each entry point
+ * names the Python function(s) whose work it replaces.  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.
+ *
+ * Fixed by the shipped models (parameters.py:18-50, 97-134): hidden width C = 96, one
+ * attention head, fp32 everywhere.  Features per node <= 12 (grain 11, joint 8).
+ */
+#ifndef GGNN_H_
+#define GGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGNN_ABI_VERSION 1
+#define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
+#define GGNN_MAX_GATES 4       /* i, f, c, o */
+#define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
+
+#define GGNN_OK 0
+#define GGNN_EINVAL (-1)  /* bad argument (null pointer, size, alignment, unsupported width) */
+#define GGNN_ELAUNCH (-2) /* hipLaunch / hipMemsetAsync reported an error */
+
+typedef void* ggnn_stream_t; /* hipStream_t */
+
+/* Gate-epilogue modes of ggnn_lstm_epilogue */
+#define GGNN_MODE_LSTM 0    /* 4 gates (i,f,c,o), c_in given: c' = f*c + i*tanh(.), h' = o*tanh(c') */
+#define GGNN_MODE_LSTM_H0 1 /* 3 gates (i,c,o), h = c = 0 (encoder): c' = i*tanh(.), h' = o*tanh(c') */
+#define GGNN_MODE_RAW 2     /* no LSTM: write the n_gates pre-activations (used for PeriodConv parity) */
+
+int ggnn_version(void);
+const char* ggnn_error_string(int code);
+
+/* ------------------------------------------------------------------------------------
+ * CSR build.  Replaces the COO bookkeeping inside PyG MessagePassing.propagate as used at
+ * periodGATconv.py:174-175 (gather by edge_index[0]/[1], scatter-add by edge_index[1]):
+ * edges are grouped by destination once per topology, so aggregation needs no atomics.
+ *   edge_index : [2, E] int64, row 0 = source node, row 1 = destination node (device)
+ *   rowptr     : [n_dst + 1] int32 out
+ *   col        : [E] int32 out, source node of each CSR slot
+ *   perm       : [E] int32 out, original COO edge id of each CSR slot (ascending inside a
+ *                row => the result is deterministic and order-stable)
+ *   flags      : [1] int32 device word, bit 0 is OR-ed in when an index is out of range
+ *                (such edges are dropped; the host wrapper raises)
+ *   workspace  : ggnn_csr_workspace_bytes(E, n_dst) bytes of device scratch
+ */
+size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst);
+int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
+                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* flags,
+                   void* workspace, size_t workspace_bytes, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Node-level projection (fp32 MFMA): out[M, ncols] = [X[:, :F] | H] . Wp^T + bias.
+ * Replaces, for all gates and edge types at once, the per-edge lin_key / lin_value /
+ * lin_query (periodGATconv.py:216-218) and lin_skip (:186) applied to cat[x, h]
+ * (heteropgclstm.py:112,120,128,137), using linearity to hoist them from edges to nodes.
+ *   X  : [M, ldx] node features, first F columns used (F <= 12)
+ *   H  : [M, ldh] hidden state (k2 = 96) or NULL (k2 = 0, encoder: h = 0)
+ *   Wp : [ncols, Kp] packed weight rows, Kp = roundup4(F) + k2; columns [F, roundup4(F)) zero
+ *   ncols % 96 == 0; ldo % 4 == 0; H, Wp, bias, out 16-byte aligned.
+ */
+int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, int k2,
+                 const float* Wp, const float* bias, int64_t M, int ncols, float* out,
+                 int64_t ldo, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Periodic-boundary GAT aggregation for one edge type, all gates fused.  Replaces
+ * PeriodConv.message (periodGATconv.py:204-236) + PyG propagate's gather and scatter-add:
+ * min-image wrap of the first three coordinates, key/value 3-column corrections, rank-1
+ * lin_edge term, scaled dot, segment softmax (+1e-16), relu, alpha-weighted sum.
+ * Per destination i and gate g it writes
+ *   agg[i, g*a_gstride + a_off + 0..95] = sum_e alpha_e * relu(lin_value(x~_j))
+ *   agg[i, g*a_gstride + sc_off + 0]    = sum_e alpha_e            (1, or 0 if no in-edge)
+ *   agg[i, g*a_gstride + sc_off + 1]    = sum_e alpha_e * edge_attr_e
+ * (lin_l2, its bias, the value-side lin_edge term and lin_skip are applied afterwards by
+ * ggnn_lstm_epilogue, which is exact because they are linear in these sums.)
+ */
+typedef struct ggnn_aggregate_args {
+  const int32_t* rowptr;    /* [n_dst + 1] */
+  const int32_t* col;       /* [E] */
+  const int32_t* perm;      /* [E] */
+  const float* edge_attr;   /* [E] in the ORIGINAL COO order (edge_attr_dict[et][:, 0]) */
+  const float* x_src;       /* [n_src, ldx_src], columns 0..2 = x, y, z */
+  const float* x_dst;       /* [n_dst, ldx_dst] */
+  const float* p_src;       /* projection of the source type: K|V of gate g at column kv_off + g*192 */
+  const float* p_dst;       /* projection of the destination type: Q of gate g at column q_off + g*96 */
+  const float* edge_params; /* [n_gates][7][96]: W_key[:,0..2], W_value[:,0..2], lin_edge.weight[:,0] */
+  float* agg;               /* [n_dst, ld_agg] */
+  int64_t ldx_src, ldx_dst, ldp_src, ldp_dst, ld_agg;
+  int64_t n_src, n_dst, E;
+  int32_t kv_off, q_off, a_off, a_gstride, sc_off, n_gates; /* n_gates in {1, 3, 4} */
+} ggnn_aggregate_args;
+int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:
+ *   pre[g] = agg[:, g, 0:Ka] . W2[g]^T + p_dst[:, s_off + g*96 ...]
+ * where W2[g] = [lin_l2.weight of each incoming edge type | b_l2, w_edge per edge type]
+ * (periodGATconv.py:218, 231-235), the skip/bias term was produced by ggnn_project
+ * (lin_skip summed over incoming edge types = HeteroConv aggr 'sum', plus b_{i,f,c,o}),
+ * followed by the cell update of heteropgclstm.py:111-146.
+ *   mode GGNN_MODE_LSTM    : n_gates = 4, needs c_in, writes h_out, c_out   [N, 96]
+ *   mode GGNN_MODE_LSTM_H0 : n_gates = 3 (i, c, o), writes h_out, c_out
+ *   mode GGNN_MODE_RAW     : writes raw_out [N, n_gates*96] = pre
+ * Ka % 4 == 0, Ka <= 200; ld_agg = n_gates * Ka.
+ */
+typedef struct ggnn_epilogue_args {
+  const float* agg;   /* [N, n_gates*Ka] */
+  const float* w2;    /* [n_gates][96][Ka] */
+  const float* p_dst; /* [N, ldp] */
+  const float* c_in;  /* [N, 96] or NULL */
+  float* h_out;       /* [N, 96] */
+  float* c_out;       /* [N, 96] */
+  float* raw_out;     /* [N, n_gates*96] (GGNN_MODE_RAW) */
+  int64_t ldp, N;
+  int32_t Ka, s_off, n_gates, mode;
+} ggnn_epilogue_args;
+int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Output heads.
+ * Regressor (models.py:433-452): y_joint = tanh(W_j h_j + b_j); y_grain = W_g h_g + b_g;
+ * grain_area = tanh(y_grain[:,0])/20 + x_grain[:,3]; y_grain[:,0] = tanh; y_grain[:,1] = relu.
+ *   w : [2][2][96] (joint rows, then grain rows), b : [2][2].
+ */
+int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const float* h_grain,
+                         int64_t n_grain, const float* x_grain, int64_t ldx_grain,
+                         const float* w, const float* b, float* y_joint, float* y_grain,
+                         float* grain_area, ggnn_stream_t stream);
+/* Classifier (models.py:595-609): pair = [h_j[src] | h_j[dst] | edge_attr];
+ * edge_event = lin2(pair); edge = tanh(lin1(pair)).  Computed as per-node partial dots
+ * (node_tmp [n_joint, 8] scratch) + a per-edge combine in the original COO order.
+ *   w_node : [6][96] = lin1.w[0,0:96], lin1.w[1,0:96], lin2.w[0,0:96], lin1.w[0,96:192], lin1.w[1,96:192], lin2.w[0,96:192]
+ *   w_edge : [6]     = lin1.w[0,192], lin1.w[1,192], lin2.w[0,192], lin1.b[0], lin1.b[1], lin2.b[0]
+ */
+int ggnn_heads_classifier(const float* h_joint, int64_t n_joint, const int64_t* edge_index_jj,
+                          int64_t E, const float* edge_attr_jj, const float* w_node,
+                          const float* w_edge, float* node_tmp, float* edge_event, float* edge,
+                          ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Rollout-step glue on device.
+ * ggnn_step_update = GrainNN_regressor.update, periodic branch (models.py:503-516) + the z
+ * advance of test.py:401-402:  x_j[:, :2] += y_j/5; x_j[:, 6:8] = y_j; x_g[:, 3] += y_g0/20;
+ * x_g[:, 4] = y_g1; x_g[:, f_grain-1] = y_g0; z (column 2 of both) += dz.  flags[1] is set
+ * to (x_grain[0, 2] > zmax) after the advance.
+ * ggnn_step_refresh = the clamp of test.py:405-407 (if flags[1]: z = zmax on every node)
+ * + the edge-length refresh of test.py:562-575 for up to three edge types:
+ * edge_attr[e] = || min-image(src_xy - dst_xy) ||_2 in the original COO order.
+ */
+int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
+                     int64_t n_grain, int64_t ldx_grain, int f_grain, const float* y_joint,
+                     const float* y_grain, float dz, float zmax, int32_t* flags,
+                     ggnn_stream_t stream);
+typedef struct ggnn_refresh_edge {
+  const int64_t* edge_index; /* [2, E] */
+  const float* x_src;
+  const float* x_dst;
+  float* edge_attr; /* [E] out */
+  int64_t ldx_src, ldx_dst, n_src, n_dst, E;
+} ggnn_refresh_edge;
+int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
+                      int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
+                      const ggnn_refresh_edge* edges, int n_edge_types, ggnn_stream_t stream);
+
+/* Bytes of device scratch one model forward needs (projections + aggregates + h/c), so a
+ * caller can size a single arena; the Python host allocates the same amounts as tensors. */
+size_t ggnn_workspace_bytes(int64_t n_grain, int64_t n_joint, int64_t E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGNN_H_ */

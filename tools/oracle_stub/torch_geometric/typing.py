@@ -1,0 +1,9 @@
+from typing import Optional, Tuple, Union
+
+from torch import Tensor
+
+Adj = Union[Tensor, "SparseTensor"]
+OptTensor = Optional[Tensor]
+PairTensor = Tuple[Tensor, Tensor]
+OptPairTensor = Tuple[Tensor, Optional[Tensor]]
+Size = Optional[Tuple[int, int]]
