@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Rollout throughput of the GrainGNN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = Rmodel.forward + Cmodel.forward + Rmodel.update + z advance + edge-length
+refresh (test.py:382-407, 562-575) on the synthetic 10 000-grain / 20 000-junction periodic
+honeycomb of SURVEY.md 8(d) (BASELINE config "synthetic 10k-grain / 20k-junction periodic
+heterograph, 500-step rollout"), static topology, weights RandomState(0) x0.3, inputs resident
+in HBM before the timed region.  N > 1 runs one independent replica per GPU (weak scaling; a
+single 10k-grain graph does not shard) and all-gathers the final states over
+RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from graingraphnn_amd import GrainRollout, synthetic  # noqa: E402
+from graingraphnn_amd.dist import gather_states  # noqa: E402
+from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor  # noqa: E402
+from graingraphnn_amd.packing import EDGE_TYPES  # noqa: E402
+from graingraphnn_amd.seeding import load_seeded  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SPAN = 6
+
+
+def algorithmic_bytes(n_src, n_dst, E, G):
+    """each distinct operand row once + each output row once, fp32, int32 CSR."""
+    return 4 * (G * 96 * (2 * n_src + 2 * n_dst) + 3 * (n_src + n_dst) + E) + 4 * E + 4 * (n_dst + 1) + 8 * G * n_dst
+
+
+def build(device, n=100, fold=10, seed=0, scale=0.3):
+    x, ei, ea = synthetic.honeycomb(n, fold, seed)
+    hp = synthetic.default_hyper(device)
+    R = GrainNN_regressor(hp)
+    Cm = GrainNN_classifier(hp, R)
+    load_seeded(R, seed, scale).eval()
+    load_seeded(Cm, seed + 1, scale).eval()
+    X, EI, EA = synthetic.to_torch(x, ei, ea, device)
+    return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea)
+
+
+class EventTimedBackend:
+    """Wraps the HIP backend so that every aggregation launch of the decoder (G = 4, the
+    dominant kernel) is bracketed by HIP events recorded on the launch stream."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.events = []
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def aggregate(self, *args):
+        n_gates = args[-1]
+        if n_gates != 4:
+            return self.inner.aggregate(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.inner.aggregate(*args)
+        e1.record()
+        self.events.append((e0, e1))
+
+
+def measure_roofline(ro, n_steps):
+    """Average duration of aggregate_kernel<4> launches inside real rollout steps."""
+    timed = EventTimedBackend(ro.be)
+    ro.be = timed
+    try:
+        for _ in range(n_steps):
+            ro._enqueue_step()
+        torch.cuda.synchronize()
+    finally:
+        ro.be = timed.inner
+    ms = [a.elapsed_time(b) for a, b in timed.events]
+    nj, ng = ro.n_nodes["joint"], ro.n_nodes["grain"]
+    E = {et: ro.graph.edge_index[et].size(1) for et in EDGE_TYPES}
+    n = {"grain": ng, "joint": nj}
+    per_launch = [algorithmic_bytes(n[et[0]], n[et[-1]], E[et], 4) for et in EDGE_TYPES]
+    avg_bytes = float(np.mean(per_launch))  # each step issues the three edge types equally often
+    avg_s = float(np.mean(ms)) * 1e-3
+    achieved = avg_bytes / avg_s / 1e9
+    return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4>", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+            "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(ms)}
+
+
+def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=20.0):
+    """The oracle (reference formulation, plain PyTorch CPU) on the same workload, bounded."""
+    from oracle import grainnn_oracle as oracle
+    x, ei, ea = inputs
+    hp = synthetic.default_hyper("cpu")
+    R = oracle.GrainNN_regressor(hp)
+    Cm = oracle.GrainNN_classifier(hp, R)
+    load_seeded(R, seed, scale).eval()
+    load_seeded(Cm, seed + 1, scale).eval()
+    X, EI, EA = synthetic.to_torch(x, ei, ea, "cpu")
+    oracle.rollout_step(R, Cm, X, EI, EA, SPAN)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
+        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} steps of the same 10k-grain workload after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+
+    # every rank owns an independent replica (different seed of the junction noise per rank)
+    R, Cm, X, EI, EA, inputs = build(device, seed=0)
+    if rank:
+        xp = synthetic.perturbed_copy(inputs[0], 1e-4, 1000 + rank)
+        X = {k: torch.from_numpy(v).to(device) for k, v in xp.items()}
+    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph)
+
+    for _ in range(args.warmup):
+        ro.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.step()
+    gathered = gather_states(ro.state(), world)  # RCCL all-gather of the rollout results
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = all(bool(torch.isfinite(v).all()) for g in gathered for v in g.values())
+
+    if rank == 0:
+        roof = measure_roofline(ro, 10)
+        line = {
+            "metric": "rollout steps/sec (10k-grain heterograph)",
+            "value": round(world * args.steps / dt, 2),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg3: synthetic periodic honeycomb, 10000 grains / 20000 junctions / "
+                                   "60000 edges per type, fold 10, static topology, R+C forward + update + "
+                                   "edge refresh per step, weights RandomState(0) x0.3",
+                       "replicas": world, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "results_finite": finite},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(inputs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

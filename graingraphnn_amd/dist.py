@@ -1,0 +1,52 @@
+"""Multi-GPU: independent grain-graph trajectories shard across ranks (one process per GPU,
+`torch.distributed`, backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in CPU tests).  There is
+no exchange during a rollout; the only collective is one all-gather of the per-trajectory
+results at the end.  The reference's only parallel code is DDP training
+(dist_train.py:76-93); inference there is single-process."""
+from typing import Callable, Dict, List
+
+import torch
+import torch.distributed as dist
+
+
+def shard_trajectories(n_traj: int, rank: int, world: int) -> List[int]:
+    """Trajectory t runs on rank t mod world (round-robin keeps ranks within one of each other)."""
+    return [t for t in range(n_traj) if t % world == rank]
+
+
+def gather_states(state: Dict[str, torch.Tensor], world: int) -> List[Dict[str, torch.Tensor]]:
+    """All-gather a dict of equally-shaped tensors; returns one dict per rank (rank order)."""
+    if world <= 1 or not dist.is_initialized():
+        return [state]
+    out = [dict() for _ in range(world)]
+    for k in sorted(state):
+        t = state[k].contiguous()
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        for r in range(world):
+            out[r][k] = bufs[r]
+    return out
+
+
+def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, world: int,
+                device=None) -> torch.Tensor:
+    """Run `run_one(t)` (-> fixed-shape result tensor) for this rank's trajectories and
+    all-gather everything: returns [n_traj, ...] in trajectory order on every rank.
+    Ranks with fewer trajectories pad their shard so the collective stays regular."""
+    mine = shard_trajectories(n_traj, rank, world)
+    per_rank = (n_traj + world - 1) // world
+    results = [run_one(t) for t in mine]
+    if not results and n_traj:
+        raise ValueError("more ranks than trajectories")
+    proto = results[0]
+    local = torch.zeros((per_rank,) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
+    for i, r in enumerate(results):
+        local[i] = r
+    if world <= 1 or not dist.is_initialized():
+        return local[:n_traj]
+    bufs = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(bufs, local)
+    out = torch.empty((n_traj,) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
+    for t in range(n_traj):
+        out[t] = bufs[t % world][t // world]
+    return out

@@ -113,9 +113,9 @@ def load_fixture(path):
 
 
 def to_torch(x, ei, ea, device="cpu"):
-    return ({k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in x.items()},
-            {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in ei.items()},
-            {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in ea.items()})
+    def conv(d):  # private copies: rollouts mutate x_dict in place
+        return {k: torch.from_numpy(np.array(v, copy=True, order="C")).to(device) for k, v in d.items()}
+    return conv(x), conv(ei), conv(ea)
 
 
 def perturbed_copy(x, sigma: float, seed: int):

@@ -1,0 +1,117 @@
+"""Torch (CPU) emulation of the C-ABI calls in include/ggnn.h -- TEST INFRASTRUCTURE.
+
+It restates, call by call, what each `ggnn_*` entry point is documented to compute, so that
+the CPU test-suite can push the product's host logic (weight packing, column offsets, launch
+plan of graingraphnn_amd/engine.py) end-to-end against the oracle without a GPU.  It is not
+shipped, not importable from the package, and never used as a fallback: the product's only
+backend is `graingraphnn_amd.backend.HipBackend`.
+"""
+import math
+
+import torch
+
+C = 96
+
+
+class TorchEmulatorBackend:
+    name = "torch-emulator (tests only)"
+
+    def build_csr(self, edge_index, n_src, n_dst):
+        src, dst = edge_index[0], edge_index[1]
+        if ((src < 0) | (src >= n_src) | (dst < 0) | (dst >= n_dst)).any():
+            raise IndexError("edge_index out of range")
+        E = edge_index.size(1)
+        # stable sort by destination == ascending original edge id inside each row
+        perm = torch.sort(dst * (E + 1) + torch.arange(E), stable=True).indices
+        rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
+        rowptr[1:] = torch.bincount(dst, minlength=n_dst).cumsum(0)
+        return rowptr.int(), src[perm].int(), perm.int()
+
+    def project(self, x, F, h, wp, bp, out):
+        Fp = (F + 3) & ~3
+        k2 = 0 if h is None else h.size(1)
+        assert wp.size(1) == Fp + k2
+        xin = torch.zeros(x.size(0), Fp + k2)
+        xin[:, :F] = x[:, :F]
+        if k2:
+            xin[:, Fp:] = h
+        out[:, :wp.size(0)] = xin @ wp.t() + bp
+
+    def aggregate(self, csr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg, kv_off, q_off,
+                  a_off, a_gstride, sc_off, n_gates):
+        rowptr, col, perm = (t.long() for t in csr)
+        n_dst = x_dst.size(0)
+        E = int(rowptr[-1])
+        dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
+        j, a = col[:E], edge_attr[perm[:E]]
+        rel = x_src[j, :3] - x_dst[dst, :3]
+        reloc = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+        for g in range(n_gates):
+            K = p_src[j, kv_off + g * 2 * C: kv_off + g * 2 * C + C]
+            V = p_src[j, kv_off + g * 2 * C + C: kv_off + (g + 1) * 2 * C]
+            Q = p_dst[dst, q_off + g * C: q_off + (g + 1) * C]
+            wk3, wv3, we = ep[g, 0:3], ep[g, 3:6], ep[g, 6]
+            k = K + reloc @ wk3 + a[:, None] * we[None, :]
+            s = (Q * k).sum(-1) / math.sqrt(C)
+            smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
+            p = (s - smax[dst]).exp()
+            den = torch.zeros(n_dst).index_add_(0, dst, p)
+            alpha = p / (den[dst] + 1e-16)
+            r = torch.relu(V + reloc @ wv3)
+            base = g * a_gstride
+            agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add_(0, dst, alpha[:, None] * r)
+            agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
+            agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
+
+    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode):
+        Ka = w2.size(2)
+        pre = [agg[:, g * Ka:(g + 1) * Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]
+               for g in range(n_gates)]
+        if mode == 2:
+            raw_out.copy_(torch.cat(pre, 1))
+        elif mode == 0:
+            i, f, t, o = torch.sigmoid(pre[0]), torch.sigmoid(pre[1]), torch.tanh(pre[2]), torch.sigmoid(pre[3])
+            c = f * c_in + i * t
+            c_out.copy_(c)
+            h_out.copy_(o * torch.tanh(c))
+        else:
+            i, t, o = torch.sigmoid(pre[0]), torch.tanh(pre[1]), torch.sigmoid(pre[2])
+            c = i * t
+            c_out.copy_(c)
+            h_out.copy_(o * torch.tanh(c))
+
+    def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):
+        y_joint.copy_(torch.tanh(h_joint @ w[0].t() + b[0:2]))
+        yg = h_grain @ w[1].t() + b[2:4]
+        t0 = torch.tanh(yg[:, 0])
+        grain_area.copy_(t0 / 20 + x_grain[:, 3])
+        y_grain[:, 0] = t0
+        y_grain[:, 1] = torch.relu(yg[:, 1])
+
+    def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
+                         edge_event, edge):
+        node_tmp[:, :6] = h_joint @ w_node.t()
+        s, d, a = edge_index_jj[0], edge_index_jj[1], edge_attr_jj
+        edge[:, 0] = torch.tanh(node_tmp[s, 0] + node_tmp[d, 3] + w_edge[0] * a + w_edge[3])
+        edge[:, 1] = torch.tanh(node_tmp[s, 1] + node_tmp[d, 4] + w_edge[1] * a + w_edge[4])
+        edge_event.copy_(node_tmp[s, 2] + node_tmp[d, 5] + w_edge[2] * a + w_edge[5])
+
+    def step_update(self, x_joint, x_grain, y_joint, y_grain, dz, zmax, flags):
+        dz = torch.tensor(dz, dtype=torch.float32)
+        x_joint[:, :2] += y_joint / 5
+        x_joint[:, 6:8] = y_joint
+        x_joint[:, 2] += dz
+        x_grain[:, 3] += y_grain[:, 0] / 20
+        x_grain[:, 4] = y_grain[:, 1]
+        x_grain[:, -1] = y_grain[:, 0]
+        x_grain[:, 2] += dz
+        flags[1] = int(x_grain[0, 2] > torch.tensor(zmax, dtype=torch.float32))
+
+    def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
+        if int(flags[1]):
+            x_joint[:, 2] = zmax
+            x_grain[:, 2] = zmax
+        for ei, xs, xd, ea in edges:
+            rel = xs[ei[0], :2] - xd[ei[1], :2]
+            rel = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+            ea.copy_(torch.sqrt(rel[:, 0] ** 2 + rel[:, 1] ** 2))

@@ -1,0 +1,85 @@
+"""Shared test helpers: fixtures on disk, seeded oracle / product models, tolerances."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from graingraphnn_amd import synthetic  # noqa: E402
+from graingraphnn_amd.seeding import load_seeded  # noqa: E402
+from oracle import grainnn_oracle as oracle  # noqa: E402
+
+EDGE_TYPES = synthetic.EDGE_TYPES
+# north_star tolerance: regressor deltas / classifier logits within 1e-4 relative, fp32.
+# "relative" is taken per tensor against max|ref|.
+RTOL = 1e-4
+
+
+def etk(et):
+    return "__".join(et)
+
+
+def load_graph(name):
+    """name in {'40', '120'} -> numpy dicts (x, ei, ea)."""
+    return synthetic.load_fixture(os.path.join(GOLDEN, f"graph_{name}.npz"))
+
+
+def fold_120(x, ea):
+    """x3 patch folding of the 120 um graph (test.py:29-55 via the oracle restatement)."""
+    X = {k: torch.from_numpy(v.copy()) for k, v in x.items()}
+    EA = {k: torch.from_numpy(v.copy()) for k, v in ea.items()}
+    oracle.scale_feature_patchs(3.0, X, EA)
+    return {k: v.numpy() for k, v in X.items()}, {k: v.numpy() for k, v in EA.items()}
+
+
+def golden(tag):
+    return np.load(os.path.join(GOLDEN, f"golden_{tag}.npz"))
+
+
+def oracle_models(seed, scale=1.0):
+    hp = synthetic.default_hyper("cpu")
+    R = oracle.GrainNN_regressor(hp)
+    Cm = oracle.GrainNN_classifier(hp, R)
+    load_seeded(R, seed, scale).eval()
+    load_seeded(Cm, seed + 1, scale).eval()
+    return R, Cm
+
+
+def product_models(seed, scale=1.0, device="cpu"):
+    from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor
+    hp = synthetic.default_hyper(device)
+    R = GrainNN_regressor(hp)
+    Cm = GrainNN_classifier(hp, R)
+    load_seeded(R, seed, scale).eval()
+    load_seeded(Cm, seed + 1, scale).eval()
+    return R.to(device), Cm.to(device)
+
+
+def tt(d, device="cpu"):
+    """numpy dict -> torch dict; always a private copy (rollouts mutate x in place)."""
+    return {k: torch.from_numpy(np.array(v, copy=True, order="C")).to(device) for k, v in d.items()}
+
+
+def random_state(n_nodes, seed):
+    rs = np.random.RandomState(seed)
+    return {nt: rs.uniform(-1, 1, (n, 96)).astype(np.float32) for nt, n in sorted(n_nodes.items())}
+
+
+def rel_err(got, ref):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()
+                 / max(float(np.abs(ref).max()), 1e-30))
+
+
+def assert_close(got, ref, what, rtol=RTOL):
+    e = rel_err(got, ref)
+    assert np.isfinite(e) and e <= rtol, f"{what}: max|a-b|/max|b| = {e:.3e} > {rtol:g}"
+    return e

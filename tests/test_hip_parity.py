@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP path, called through the product API (-> C ABI, libggnn.so),
+against the CPU oracle and the committed golden vectors.  Tolerance: 1e-4 relative fp32
+(max|a-b| <= 1e-4 * max|ref| per tensor), the north_star bar."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (EDGE_TYPES, RTOL, assert_close, etk, fold_120, golden, load_graph,
+                     oracle_models, product_models, random_state, rel_err, tt)
+from graingraphnn_amd import _lib, synthetic
+from oracle import grainnn_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GJ, JG, JJ = EDGE_TYPES
+
+
+def backend():
+    from graingraphnn_amd.backend import default_backend
+    return default_backend()
+
+
+def test_library_is_loaded_from_the_tree():
+    be = backend()
+    assert be.lib.ggnn_version() == 1
+    assert _lib.LIB_PATH.endswith("graingraphnn_amd/libggnn.so")
+
+
+# ---------------------------------------------------------------------------------------
+# CSR build: bit-exact against numpy (integer work)
+# ---------------------------------------------------------------------------------------
+def _csr_numpy(ei, n_dst):
+    order = np.argsort(ei[1], kind="stable")
+    rowptr = np.zeros(n_dst + 1, np.int64)
+    rowptr[1:] = np.cumsum(np.bincount(ei[1], minlength=n_dst))
+    return rowptr, ei[0][order], order
+
+
+@pytest.mark.parametrize("n_src,n_dst,E,seed", [(7, 5, 0, 0), (1, 1, 1, 1), (236, 118, 708, 2),
+                                               (5000, 3000, 40000, 3), (100, 2500, 700, 4),
+                                               (50, 3, 5000, 5)])
+def test_build_csr_bit_exact(n_src, n_dst, E, seed):
+    rs = np.random.RandomState(seed)
+    ei = np.stack([rs.randint(0, n_src, E), rs.randint(0, n_dst, E)]).astype(np.int64)
+    rowptr, col, perm = backend().build_csr(torch.from_numpy(ei).to(DEV), n_src, n_dst)
+    r_ref, c_ref, p_ref = _csr_numpy(ei, n_dst)
+    assert np.array_equal(rowptr.cpu().numpy(), r_ref)
+    assert np.array_equal(col.cpu().numpy()[:E], c_ref)
+    assert np.array_equal(perm.cpu().numpy()[:E], p_ref)
+
+
+def test_build_csr_rejects_out_of_range_indices():
+    ei = torch.tensor([[0, 1, 9], [0, 1, 1]], dtype=torch.int64, device=DEV)
+    with pytest.raises(IndexError):
+        backend().build_csr(ei, 5, 3)
+    ei = torch.tensor([[0, 1, 2], [0, -1, 1]], dtype=torch.int64, device=DEV)
+    with pytest.raises(IndexError):
+        backend().build_csr(ei, 5, 3)
+
+
+# ---------------------------------------------------------------------------------------
+# projection GEMM (fp32 MFMA) against a plain fp32 torch reference
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,F,k2,ncols", [(1, 8, 0, 96), (63, 11, 96, 192), (64, 8, 96, 96),
+                                         (65, 11, 0, 288), (1000, 8, 96, 2688), (777, 11, 96, 1536),
+                                         (300, 3, 96, 96), (129, 12, 0, 96)])
+def test_project_matches_fp32_matmul(M, F, k2, ncols):
+    rs = np.random.RandomState(M + F)
+    Fp = (F + 3) & ~3
+    x = torch.from_numpy(rs.uniform(-1, 1, (M, F)).astype(np.float32))
+    h = torch.from_numpy(rs.uniform(-1, 1, (M, 96)).astype(np.float32)) if k2 else None
+    wp = torch.from_numpy(rs.uniform(-0.3, 0.3, (ncols, Fp + k2)).astype(np.float32))
+    wp[:, F:Fp] = 0
+    bp = torch.from_numpy(rs.uniform(-1, 1, ncols).astype(np.float32))
+    xin = torch.zeros(M, Fp + k2, dtype=torch.float64)
+    xin[:, :F] = x
+    if k2:
+        xin[:, Fp:] = h
+    ref = (xin @ wp.double().t() + bp.double()).float()
+    out = torch.full((M, ncols), float("nan"), device=DEV)
+    backend().project(x.to(DEV), F, None if h is None else h.to(DEV), wp.to(DEV), bp.to(DEV), out)
+    assert_close(out, ref, f"project M={M} F={F} k2={k2} ncols={ncols}", 2e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# op level: PeriodConv and HeteroPGCLSTM against the reference's golden vectors (cfg1)
+# ---------------------------------------------------------------------------------------
+@torch.no_grad()
+def test_periodconv_golden():
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_s1")
+    R, _ = product_models(10020, 1.0, DEV)
+    n_nodes = {nt: v.shape[0] for nt, v in x.items()}
+    h0 = tt(random_state(n_nodes, 7), DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    xh = {nt: torch.cat([X[nt], h0[nt]], 1) for nt in x}
+    for et in EDGE_TYPES:
+        conv = R.gclstm_decoder.cell_list[0].conv_i.convs[etk(et)]
+        arg = xh[et[0]] if et[0] == et[-1] else (xh[et[0]], xh[et[-1]])
+        assert_close(conv(arg, EI[et], EA[et]), g["conv_" + etk(et)], f"PeriodConv {et}")
+
+
+@torch.no_grad()
+def test_cell_golden_zero_and_nonzero_state():
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_s1")
+    R, _ = product_models(10020, 1.0, DEV)
+    n_nodes = {nt: v.shape[0] for nt, v in x.items()}
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    h, c = R.gclstm_encoder.cell_list[0](X, EI, EA, None, None)
+    for nt in x:
+        assert_close(h[nt], g[f"cell0_h_{nt}"], f"cell0 h {nt}")
+        assert_close(c[nt], g[f"cell0_c_{nt}"], f"cell0 c {nt}")
+    h0, c0 = tt(random_state(n_nodes, 7), DEV), tt(random_state(n_nodes, 8), DEV)
+    h, c = R.gclstm_decoder.cell_list[0](X, EI, EA, h0, c0)
+    for nt in x:
+        assert_close(h[nt], g[f"cell1_h_{nt}"], f"cell1 h {nt}")
+        assert_close(c[nt], g[f"cell1_c_{nt}"], f"cell1 c {nt}")
+    # generic (k2 = 96) path with an explicit zero state == the h = 0 fast path
+    z = {nt: torch.zeros(n_nodes[nt], 96, device=DEV) for nt in x}
+    h, c = R.gclstm_encoder.cell_list[0](X, EI, EA, z, z)
+    for nt in x:
+        assert_close(h[nt], g[f"cell0_h_{nt}"], f"cell0 (explicit zeros) h {nt}")
+        assert_close(c[nt], g[f"cell0_c_{nt}"], f"cell0 (explicit zeros) c {nt}")
+
+
+# ---------------------------------------------------------------------------------------
+# model level: regressor deltas and classifier logits against the goldens
+# ---------------------------------------------------------------------------------------
+def _inputs(tag):
+    if tag.startswith("cfg1"):
+        return load_graph("40")
+    x, ei, ea = load_graph("120")
+    x, ea = fold_120(x, ea)
+    return x, ei, ea
+
+
+CASES = [("cfg1_s1", 10020, 1.0), ("cfg1_s3", 10020, 3.0), ("cfg2_s1", 0, 1.0)]
+
+
+@pytest.mark.parametrize("tag,seed,scale", CASES)
+@torch.no_grad()
+def test_forward_golden(tag, seed, scale):
+    x, ei, ea = _inputs(tag)
+    g = golden(tag)
+    R, Cm = product_models(seed, scale, DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    yr, yc = R(X, EI, EA), Cm(X, EI, EA)
+    for k in ("joint", "grain", "grain_area"):
+        assert_close(yr[k], g["R_" + k], f"{tag} regressor {k}")
+    for k in ("edge_event", "edge"):
+        assert_close(yc[k], g["C_" + k], f"{tag} classifier {k}")
+    # drop-in update(): periodic branch of models.py:503-516, in place
+    Xo = tt(x)
+    oR, _ = oracle_models(seed, scale)
+    pred_o = {k: torch.from_numpy(g["R_" + k].copy()) for k in ("joint", "grain")}
+    oR.update(Xo, pred_o, {})
+    gs = {}
+    R.update(X, yr, gs)
+    for nt in x:
+        assert_close(X[nt], Xo[nt], f"{tag} update x {nt}")
+    assert gs["active_grains"].numel() == x["grain"].shape[0]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag,seed,scale", CASES)
+@torch.no_grad()
+def test_rollout_golden(tag, seed, scale, use_graph):
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = _inputs(tag)
+    g = golden(tag)
+    n_steps, span = int(g["meta"][2]), int(g["meta"][3])
+    R, Cm = product_models(seed, scale, DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    ro = GrainRollout(R, Cm, X, EI, EA, span, use_graph=use_graph)
+    for step in range(1, n_steps + 1):
+        pred = ro.step()
+        if step == 1:
+            for k in ("joint", "grain", "grain_area"):
+                assert_close(pred[k], g["R_" + k], f"{tag} step1 R {k}")
+            for k in ("edge_event", "edge"):
+                assert_close(pred[k], g["C_" + k], f"{tag} step1 C {k}")
+        if step in (1, n_steps):
+            for nt in x:
+                assert_close(X[nt], g[f"step{step}_x_{nt}"], f"{tag} step{step} x {nt}")
+            ead = ro.edge_attr_dict()
+            for et in EDGE_TYPES:
+                assert_close(ead[et], g[f"step{step}_ea_{etk(et)}"], f"{tag} step{step} edge_attr {et}")
+
+
+@torch.no_grad()
+def test_full_120_frame_rollout_against_oracle():
+    """BASELINE config 2: seed=0 lxd=120 graph, frames 6..120 in steps of span 6 = 20 steps."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = _inputs("cfg2_s1")
+    R, Cm = product_models(0, 1.0, DEV)
+    oR, oC = oracle_models(0, 1.0)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6)
+    for step in range(20):
+        ro.step()
+        _, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+    for nt in x:
+        assert_close(X[nt], oX[nt], f"20-step x {nt}")
+    assert float(X["grain"][0, 2]) == pytest.approx(120 / 121, abs=1e-6)  # z clamp reached
+    for et in EDGE_TYPES:
+        assert_close(ro.edge_attr_dict()[et], oEA[et], f"20-step edge_attr {et}")
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases: empty rows, ragged / large degrees (LDS window overflow path), odd sizes
+# ---------------------------------------------------------------------------------------
+def _ragged_graph(seed, n_g=37, n_j=75, hub_deg=0):
+    rs = np.random.RandomState(seed)
+    x = {"grain": rs.uniform(0, 1, (n_g, 11)).astype(np.float32),
+         "joint": rs.uniform(0, 1, (n_j, 8)).astype(np.float32)}
+
+    def rand_edges(n_s, n_d, E, skip_dst):
+        s, d = rs.randint(0, n_s, E), rs.randint(0, n_d, E)
+        keep = ~np.isin(d, skip_dst)
+        return np.stack([s[keep], d[keep]]).astype(np.int64)
+
+    ei = {GJ: rand_edges(n_g, n_j, 4 * n_j, [0, 5]),      # joints 0 and 5 get no grain edges
+          JG: rand_edges(n_j, n_g, 7 * n_g, [n_g - 1]),   # last grain has no in-edges at all
+          JJ: rand_edges(n_j, n_j, 3 * n_j, [0])}         # joint 0 has no in-edges of any type
+    if hub_deg:
+        hub = np.stack([rs.randint(0, n_j, hub_deg), np.full(hub_deg, 3)]).astype(np.int64)
+        ei[JG] = np.concatenate([ei[JG], hub], 1)[:, rs.permutation(ei[JG].shape[1] + hub_deg)]
+    ea = {et: rs.uniform(0.01, 0.1, (v.shape[1], 1)).astype(np.float32) for et, v in ei.items()}
+    return x, ei, ea
+
+
+@pytest.mark.parametrize("seed,hub_deg", [(0, 0), (1, 37), (2, 900)])
+@torch.no_grad()
+def test_ragged_graphs_against_oracle(seed, hub_deg):
+    """Zero in-degree rows (PyG leaves them at lin_skip only), multi-chunk softmax rows and a
+    900-neighbour hub that overflows the 512-slot LDS window of its workgroup."""
+    x, ei, ea = _ragged_graph(seed, hub_deg=hub_deg)
+    R, Cm = product_models(11 + seed, 1.0, DEV)
+    oR, oC = oracle_models(11 + seed, 1.0)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    yr, yc = R(X, EI, EA), Cm(X, EI, EA)
+    oyr, oyc = oR(tt(x), tt(ei), tt(ea)), oC(tt(x), tt(ei), tt(ea))
+    for k in ("joint", "grain", "grain_area"):
+        assert_close(yr[k], oyr[k], f"ragged regressor {k}")
+    for k in ("edge_event", "edge"):
+        assert_close(yc[k], oyc[k], f"ragged classifier {k}")
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE full size (cfg3): one oracle step + size-independent properties
+# ---------------------------------------------------------------------------------------
+@torch.no_grad()
+def test_cfg3_full_size_step_and_properties():
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = synthetic.honeycomb(100, 10, 0)
+    R, Cm = product_models(0, 0.3, DEV)
+    oR, oC = oracle_models(0, 0.3)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6)
+    pred = {k: v.clone() for k, v in ro.step().items()}
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+    for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+        assert_close(pred[k], opred[k], f"cfg3 {k}")
+    for nt in x:
+        assert_close(X[nt], oX[nt], f"cfg3 step1 x {nt}")
+    for et in EDGE_TYPES:
+        assert_close(ro.edge_attr_dict()[et], oEA[et], f"cfg3 step1 edge_attr {et}")
+    # (1) bitwise determinism (atomics-free CSR aggregation): same inputs -> same bits
+    X2 = tt(x, DEV)
+    ro2 = GrainRollout(R, Cm, X2, tt(ei, DEV), tt(ea, DEV), 6)
+    pred2 = ro2.step()
+    for k in pred:
+        assert torch.equal(pred[k], pred2[k]), f"cfg3 {k} differs between two identical runs"
+    # (2) COO order independence: permuting the edge list permutes per-edge outputs only
+    perm = {et: np.random.RandomState(9).permutation(ei[et].shape[1]) for et in EDGE_TYPES}
+    ei_p = {et: ei[et][:, perm[et]] for et in EDGE_TYPES}
+    ea_p = {et: ea[et][perm[et]] for et in EDGE_TYPES}
+    X3 = tt(x, DEV)
+    ro3 = GrainRollout(R, Cm, X3, tt(ei_p, DEV), tt(ea_p, DEV), 6)
+    pred3 = ro3.step()
+    for k in ("joint", "grain", "grain_area"):
+        assert_close(pred3[k], pred[k], f"cfg3 permuted-COO {k}", 1e-5)
+    assert_close(pred3["edge_event"], pred["edge_event"][torch.from_numpy(perm[JJ]).to(DEV)],
+                 "cfg3 permuted-COO edge_event", 1e-5)
+    # (3) softmax normalisation: sum of alpha is 1 on every row with an in-edge
+    Ka = 196
+    sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, Ka)[:, :, 192::2]
+    assert float((sa - 1).abs().max()) < 1e-5

@@ -1,0 +1,202 @@
+"""CPU tests of the product's host logic: state_dict layout, weight packing, column offsets
+and launch plan, checked end-to-end against the oracle through tests/emulator.py (a torch
+restatement of each C-ABI call -- test infrastructure, never a product fallback)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emulator import TorchEmulatorBackend
+from helpers import (EDGE_TYPES, GOLDEN, assert_close, etk, fold_120, golden, load_graph,
+                     oracle_models, product_models, random_state, tt)
+from graingraphnn_amd import _lib, engine, packing, synthetic
+from graingraphnn_amd.seeding import seeded_state_dict
+from oracle import grainnn_oracle as oracle
+
+TOL = 2e-5
+
+
+def test_state_dict_layout_matches_reference():
+    R, Cm = product_models(3)
+    keys = json.load(open(os.path.join(GOLDEN, "keys.json")))
+    for name, m in (("regressor", R), ("classifier", Cm)):
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys[name]
+    assert sum(p.numel() for p in R.parameters()) == 1204612
+    assert sum(p.numel() for p in Cm.parameters()) == 1204806
+    # a reference-layout checkpoint loads strictly, and round-trips through torch.save
+    oR, _ = oracle_models(3)
+    R.load_state_dict(oR.state_dict(), strict=True)
+
+
+def test_classifier_deepcopies_regressor_cells():
+    """models.py:551-552."""
+    from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor
+    hp = synthetic.default_hyper("cpu")
+    R = GrainNN_regressor(hp)
+    Cm = GrainNN_classifier(hp, R)
+    a = R.gclstm_encoder.cell_list[0].conv_i.convs["grain__push__joint"].lin_key.weight
+    b = Cm.gclstm_encoder.cell_list[0].conv_i.convs["grain__push__joint"].lin_key.weight
+    assert torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+
+
+def test_unsupported_configs_fail_loudly():
+    from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor
+    hp = synthetic.default_hyper("cpu")
+    with pytest.raises(NotImplementedError):
+        GrainNN_regressor(hp, history=True)
+    with pytest.raises(NotImplementedError):
+        GrainNN_classifier(hp, None, history=True)
+    hp.layer_size = 64
+    with pytest.raises(NotImplementedError):
+        GrainNN_regressor(hp)
+
+
+def test_no_cpu_fallback():
+    """The product refuses CPU tensors instead of silently computing on the host."""
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(1)
+    with pytest.raises(_lib.GGNNError):
+        R(tt(x), tt(ei), tt(ea))
+    with pytest.raises(_lib.GGNNError):
+        Cm(tt(x), tt(ei), tt(ea))
+
+
+def test_layout_offsets():
+    lj = packing.node_layout("joint", 8, 4)
+    lg = packing.node_layout("grain", 11, 4)
+    assert (lj.ncols, lg.ncols) == (2688, 1536)      # [20000,104]x[104,2688], [10000,107]x[107,1536]
+    assert (lj.Ka, lg.Ka) == (196, 100)
+    assert (packing.node_layout("joint", 8, 3).ncols, packing.node_layout("grain", 11, 3).ncols) == (2016, 1152)
+    assert lj.kv_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 768}
+    assert lj.q_off == {EDGE_TYPES[0]: 1536, EDGE_TYPES[2]: 1920} and lj.s_off == 2304
+
+
+def _run_model_emulated(model, x, ei, ea):
+    be = TorchEmulatorBackend()
+    n_nodes = {nt: v.shape[0] for nt, v in x.items()}
+    graph = engine.GraphCSR(be, ei, n_nodes)
+    enc = model.gclstm_encoder.cell_list[0].packed(True)
+    dec = model.gclstm_decoder.cell_list[0].packed(False)
+    ws = engine.Workspace(enc, dec, n_nodes, "cpu")
+    h, c = engine.run_encoder_decoder(be, enc, dec, graph, ws, x, ea)
+    return be, graph, h
+
+
+@pytest.mark.parametrize("tag,seed,scale", [("cfg1_s1", 10020, 1.0), ("cfg1_s3", 10020, 3.0),
+                                            ("cfg2_s1", 0, 1.0)])
+@torch.no_grad()
+def test_packing_and_plan_reproduce_golden_forward(tag, seed, scale):
+    if tag.startswith("cfg1"):
+        x, ei, ea = load_graph("40")
+    else:
+        x, ei, ea = load_graph("120")
+        x, ea = fold_120(x, ea)
+    g = golden(tag)
+    R, Cm = product_models(seed, scale)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    be, graph, h = _run_model_emulated(R, X, EI, EA)
+    w, b = packing.pack_regressor_heads(R.linear)
+    yj, yg, area = torch.empty(X["joint"].size(0), 2), torch.empty(X["grain"].size(0), 2), torch.empty(X["grain"].size(0))
+    be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
+    assert_close(yj, g["R_joint"], f"{tag} R joint", TOL)
+    assert_close(yg, g["R_grain"], f"{tag} R grain", TOL)
+    assert_close(area, g["R_grain_area"], f"{tag} R area", TOL)
+    be, graph, h = _run_model_emulated(Cm, X, EI, EA)
+    wn, we = packing.pack_classifier_heads(Cm.lin1, Cm.lin2)
+    E = EI[EDGE_TYPES[2]].size(1)
+    ev, ed, tmp = torch.empty(E), torch.empty(E, 2), torch.empty(X["joint"].size(0), 8)
+    be.heads_classifier(h["joint"], EI[EDGE_TYPES[2]], EA[EDGE_TYPES[2]].view(-1), wn, we, tmp, ev, ed)
+    assert_close(ev, g["C_edge_event"], f"{tag} C edge_event", TOL)
+    assert_close(ed, g["C_edge"], f"{tag} C edge", TOL)
+
+
+@torch.no_grad()
+def test_cell_with_state_and_single_conv_packing():
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_s1")
+    R, _ = product_models(10020)
+    be = TorchEmulatorBackend()
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    n_nodes = {nt: v.shape[0] for nt, v in x.items()}
+    h0, c0 = tt(random_state(n_nodes, 7)), tt(random_state(n_nodes, 8))
+    graph = engine.GraphCSR(be, EI, n_nodes)
+    ea1 = {et: EA[et].view(-1) for et in EDGE_TYPES}
+    for encoder, key in ((True, "cell0"), (False, "cell1")):
+        cell = (R.gclstm_encoder if encoder else R.gclstm_decoder).cell_list[0]
+        pc = cell.packed(encoder)
+        proj = {nt: torch.empty(n_nodes[nt], pc.layout[nt].ncols) for nt in n_nodes}
+        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Ka) for nt in n_nodes}
+        ho = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
+        co = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
+        engine.run_cell(be, pc, graph, X, ea1, None if encoder else h0, None if encoder else c0,
+                        proj, agg, ho, co)
+        for nt in n_nodes:
+            assert_close(ho[nt], g[f"{key}_h_{nt}"], f"{key} h {nt}", TOL)
+            assert_close(co[nt], g[f"{key}_c_{nt}"], f"{key} c {nt}", TOL)
+    # single PeriodConv through pack_conv + raw epilogue
+    for et in EDGE_TYPES:
+        conv = R.gclstm_decoder.cell_list[0].conv_i.convs[etk(et)]
+        Fs, Fd = X[et[0]].size(1), X[et[-1]].size(1)
+        wps, bps, wpd, bpd, ep, w2 = packing.pack_conv(conv, Fs, Fd, 96)
+        ps, pd = torch.empty(n_nodes[et[0]], 192), torch.empty(n_nodes[et[-1]], 192)
+        be.project(X[et[0]], Fs, h0[et[0]], wps, bps, ps)
+        be.project(X[et[-1]], Fd, h0[et[-1]], wpd, bpd, pd)
+        agg = torch.zeros(n_nodes[et[-1]], 100)
+        be.aggregate(graph.csr[et], ea1[et], X[et[0]], X[et[-1]], ps, pd, ep, agg, 0, 0, 0, 100, 96, 1)
+        out = torch.empty(n_nodes[et[-1]], 96)
+        be.lstm_epilogue(agg, w2, pd, 96, None, None, None, out, 1, 2)
+        assert_close(out, g["conv_" + etk(et)], f"conv {et}", TOL)
+
+
+@torch.no_grad()
+def test_step_glue_matches_golden():
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_s1")
+    be = TorchEmulatorBackend()
+    X = tt(x)
+    yj, yg = torch.from_numpy(g["R_joint"].copy()), torch.from_numpy(g["R_grain"].copy())
+    flags = torch.zeros(2, dtype=torch.int32)
+    dz, zmax = float(np.float32(6 / 121)), float(np.float32(120 / 121))
+    be.step_update(X["joint"], X["grain"], yj, yg, dz, zmax, flags)
+    EI = tt(ei)
+    EA = {et: torch.empty(EI[et].size(1)) for et in EDGE_TYPES}
+    be.step_refresh(X["joint"], X["grain"], zmax, flags,
+                    [(EI[et], X[et[0]], X[et[-1]], EA[et]) for et in EDGE_TYPES])
+    for nt in x:
+        assert_close(X[nt], g[f"step1_x_{nt}"], f"step1 x {nt}", TOL)
+    for et in EDGE_TYPES:
+        assert_close(EA[et].view(-1, 1), g["step1_ea_" + etk(et)], f"step1 ea {et}", TOL)
+
+
+def test_seeding_is_deterministic_and_order_free():
+    shapes = {"b": (4, 9), "a": (5,), "c.weight": (96, 1)}
+    s1 = seeded_state_dict(shapes, 5)
+    s2 = seeded_state_dict(dict(reversed(list(shapes.items()))), 5)
+    assert all(torch.equal(s1[k], s2[k]) for k in shapes)
+    assert float(s1["c.weight"].abs().max()) <= 1.0 and float(s1["b"].abs().max()) <= 1 / 3
+
+
+def test_honeycomb_invariants():
+    x, ei, ea = synthetic.honeycomb(20, 2, 0)
+    ng, nj = 400, 800
+    assert x["grain"].shape == (ng, 11) and x["joint"].shape == (nj, 8)
+    for et in EDGE_TYPES:
+        assert ei[et].shape == (2, 3 * nj) and ei[et].dtype == np.int64
+    assert (np.bincount(ei[EDGE_TYPES[0]][1], minlength=nj) == 3).all()   # 3 grains per junction
+    assert (np.bincount(ei[EDGE_TYPES[2]][1], minlength=nj) == 3).all()   # 3 junctions per junction
+    assert (np.bincount(ei[EDGE_TYPES[1]][1], minlength=ng) == 6).all()   # hexagons
+    jj = set(map(tuple, ei[EDGE_TYPES[2]].T))
+    assert all((b, a) in jj for a, b in jj) and all(a != b for a, b in jj)
+    gj = set(map(tuple, ei[EDGE_TYPES[0]].T))
+    assert all((b, a) in gj for a, b in map(tuple, ei[EDGE_TYPES[1]].T))
+    # edge lengths equal the min-image distances of the folded coordinates (test.py:562-575)
+    X, EI = tt(x), tt(ei)
+    EA = oracle.refresh_edge_attr(X, EI)
+    for et in EDGE_TYPES:
+        assert_close(torch.from_numpy(ea[et]), EA[et], f"honeycomb ea {et}", 1e-5)
+        assert float(ea[et].max()) < 0.25
+    x3, ei3, _ = synthetic.honeycomb(100, 10, 0)
+    assert x3["grain"].shape[0] == 10000 and x3["joint"].shape[0] == 20000
+    assert all(v.shape == (2, 60000) for v in ei3.values())
