@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AggregateArgs, EpilogueArgs, RefreshEdge, check, ptr
+from ._lib import AggregateArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
 
 
 def _require_cuda(*tensors):
@@ -32,8 +32,8 @@ class HipBackend:
 
     # -- CSR ---------------------------------------------------------------------------
     def build_csr(self, edge_index, n_src, n_dst):
-        """edge_index [2, E] int64 (cuda) -> (rowptr, col, perm) int32.  Raises IndexError on
-        out-of-range indices (one host sync, only when a topology is first seen)."""
+        """edge_index [2, E] int64 (cuda) -> (rowptr, col, perm, row) int32.  Raises IndexError
+        on out-of-range indices (one host sync, only when a topology is first seen)."""
         _require_cuda(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise _lib.GGNNError("edge_index must be int64 [2, E]")
@@ -43,15 +43,30 @@ class HipBackend:
         rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
         nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(self.lib.ggnn_build_csr(ptr(ei), E, n_src, n_dst, ptr(rowptr), ptr(col), ptr(perm),
-                                      ptr(flags), ptr(ws), nbytes, _lib.current_stream()),
+                                      ptr(row), ptr(flags), ptr(ws), nbytes, _lib.current_stream()),
               "ggnn_build_csr")
         if int(flags[0].item()) & 1:
             raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
-        return rowptr, col, perm
+        return rowptr, col, perm, row
+
+    # -- per-edge geometry -------------------------------------------------------------
+    def edge_prepare(self, items):
+        """items: list of (csr, edge_attr [E] COO order, x_src, x_dst, einfo_out [E, 4])."""
+        arr = (PrepareEdge * max(len(items), 1))()
+        for k, (csr, ea, xs, xd, einfo) in enumerate(items):
+            rowptr, col, perm, row = csr
+            _require_cuda(col, ea, xs, xd, einfo)
+            a = arr[k]
+            a.col, a.perm, a.row = col.data_ptr(), perm.data_ptr(), row.data_ptr()
+            a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
+            a.einfo = einfo.data_ptr()
+            a.ldx_src, a.ldx_dst, a.E = xs.stride(0), xd.stride(0), ea.numel()
+        check(self.lib.ggnn_edge_prepare(arr, len(items), _lib.current_stream()), "ggnn_edge_prepare")
 
     # -- projection --------------------------------------------------------------------
     def project(self, x, F, h, wp, bp, out):
@@ -63,19 +78,16 @@ class HipBackend:
                                     _lib.current_stream()), "ggnn_project")
 
     # -- aggregation -------------------------------------------------------------------
-    def aggregate(self, csr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg, kv_off, q_off,
-                  a_off, a_gstride, sc_off, n_gates):
-        rowptr, col, perm = csr
-        _require_cuda(rowptr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg)
+    def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
+                  sc_off, n_gates):
+        rowptr, col = csr[0], csr[1]
+        _require_cuda(rowptr, einfo, p_src, p_dst, ep, agg)
         a = AggregateArgs()
-        a.rowptr, a.col, a.perm = rowptr.data_ptr(), col.data_ptr(), perm.data_ptr()
-        a.edge_attr = edge_attr.data_ptr()
-        a.x_src, a.x_dst = x_src.data_ptr(), x_dst.data_ptr()
+        a.rowptr, a.col, a.einfo = rowptr.data_ptr(), col.data_ptr(), einfo.data_ptr()
         a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
         a.edge_params, a.agg = ep.data_ptr(), agg.data_ptr()
-        a.ldx_src, a.ldx_dst = x_src.stride(0), x_dst.stride(0)
         a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
-        a.n_src, a.n_dst, a.E = x_src.size(0), x_dst.size(0), edge_attr.numel()
+        a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), einfo.size(0)
         a.kv_off, a.q_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             kv_off, q_off, a_off, a_gstride, sc_off, n_gates)
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),

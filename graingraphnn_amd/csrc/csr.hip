@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict
 __global__ __launch_bounds__(256) void csr_sort_kernel(const int64_t* __restrict__ ei,
                                                        const int32_t* __restrict__ rowptr,
                                                        int64_t n_dst, int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ col) {
+                                                       int32_t* __restrict__ col,
+                                                       int32_t* __restrict__ row) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_dst) return;
   const int32_t beg = rowptr[i], end = rowptr[i + 1];
@@ -86,7 +87,10 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int64_t* __restrict
     }
     perm[b + 1] = key;
   }
-  for (int32_t a = beg; a < end; ++a) col[a] = (int32_t)ei[perm[a]];
+  for (int32_t a = beg; a < end; ++a) {
+    col[a] = (int32_t)ei[perm[a]];
+    row[a] = (int32_t)i;
+  }
 }
 
 }  // namespace ggnn
@@ -97,12 +101,12 @@ extern "C" size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst) {
 }
 
 extern "C" int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
-                              int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* flags,
-                              void* workspace, size_t workspace_bytes, ggnn_stream_t stream_) {
+                              int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row,
+                              int32_t* flags, void* workspace, size_t workspace_bytes, ggnn_stream_t stream_) {
   using namespace ggnn;
   hipStream_t stream = (hipStream_t)stream_;
   if (E < 0 || n_src < 0 || n_dst <= 0 || !rowptr || !flags || !workspace) return GGNN_EINVAL;
-  if (E > 0 && (!edge_index || !col || !perm)) return GGNN_EINVAL;
+  if (E > 0 && (!edge_index || !col || !perm || !row)) return GGNN_EINVAL;
   if (E >= INT32_MAX || n_dst >= INT32_MAX || n_src >= INT32_MAX) return GGNN_EINVAL;
   if (workspace_bytes < ggnn_csr_workspace_bytes(E, n_dst)) return GGNN_EINVAL;
   int32_t* counts = (int32_t*)workspace;
@@ -119,7 +123,7 @@ extern "C" int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_sr
     hipLaunchKernelGGL(csr_fill_kernel, dim3(eb), dim3(256), 0, stream, edge_index, E, n_src,
                        n_dst, cursor, perm);
     hipLaunchKernelGGL(csr_sort_kernel, dim3(nb), dim3(256), 0, stream, edge_index, rowptr,
-                       n_dst, perm, col);
+                       n_dst, perm, col, row);
   }
   return launch_status();
 }

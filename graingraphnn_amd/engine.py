@@ -2,8 +2,8 @@
 
 One HeteroPGCLSTM cell (heteropgclstm.py:148-183: 4 gates x 3 PeriodConv + LSTM update) is
 2 projection GEMMs + 3 aggregation sweeps + 2 gate-GEMM/LSTM epilogues = 7 launches; a
-model forward (encoder cell with h = c = 0, decoder cell, heads; models.py:422-452, 581-609)
-is 15-16 launches instead of the ~600 framework kernels the reference issues.
+model forward (edge geometry, encoder cell with h = c = 0, decoder cell, heads;
+models.py:422-452, 581-609) is 16-17 launches instead of the ~600 framework kernels the reference issues.
 """
 from typing import Dict, Optional, Tuple
 
@@ -28,6 +28,9 @@ class GraphCSR:
             ei = edge_index_dict[et]
             self.edge_index[et] = ei.contiguous()
             self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
+
+    def n_edges(self, et):
+        return self.edge_index[et].size(1)
 
 
 _graph_cache: Dict[tuple, GraphCSR] = {}
@@ -58,6 +61,7 @@ class Workspace:
         self.n_nodes = dict(n_nodes)
         f32 = dict(dtype=torch.float32, device=device)
         self.proj, self.agg_enc, self.agg_dec, self.h1, self.c1, self.h2, self.c2 = {}, {}, {}, {}, {}, {}, {}
+        self.einfo = None  # edge type -> [E, 4], (re)allocated by prepare_edges
         for nt in NODE_TYPES:
             n = n_nodes[nt]
             ncols = max(enc.layout[nt].ncols, dec.layout[nt].ncols)
@@ -81,8 +85,20 @@ def _check_x(x: torch.Tensor, F: int, name: str):
         raise _lib.GGNNError(f"x_dict['{name}'] must be float32 [N, {F}] with unit column stride")
 
 
+def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
+                  edge_attr: Dict[ET, torch.Tensor], einfo: Optional[Dict[ET, torch.Tensor]]):
+    """One launch: min-image offsets + edge lengths of all three edge types in CSR order."""
+    dev = x["joint"].device
+    if einfo is None or any(einfo[et].size(0) != max(graph.n_edges(et), 1) for et in EDGE_TYPES):
+        einfo = {et: torch.empty(max(graph.n_edges(et), 1), 4, dtype=torch.float32, device=dev)
+                 for et in EDGE_TYPES}
+    backend.edge_prepare([(graph.csr[et], edge_attr[et], x[et[0]], x[et[-1]], einfo[et])
+                          for et in EDGE_TYPES])
+    return einfo
+
+
 def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],
-             edge_attr: Dict[ET, torch.Tensor], h_in: Optional[Dict[str, torch.Tensor]],
+             einfo: Dict[ET, torch.Tensor], h_in: Optional[Dict[str, torch.Tensor]],
              c_in: Optional[Dict[str, torch.Tensor]], proj, agg, h_out, c_out):
     """One HeteroPGCLSTM.forward.  Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
     lay = pc.layout
@@ -91,9 +107,9 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
         backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
     for et in EDGE_TYPES:  # 3 aggregation sweeps
         s, d = et[0], et[-1]
-        backend.aggregate(graph.csr[et], edge_attr[et], x[s], x[d], proj[s], proj[d], pc.ep[et],
-                          agg[d], lay[s].kv_off[et], lay[d].q_off[et], lay[d].a_off[et],
-                          lay[d].Ka, lay[d].sc_off[et], pc.G)
+        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], pc.ep[et], agg[d],
+                          lay[s].kv_off[et], lay[d].q_off[et], lay[d].a_off[et], lay[d].Ka,
+                          lay[d].sc_off[et], pc.G)
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
     for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
         backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
@@ -101,10 +117,14 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
 
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,
-                        x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor]):
+                        x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor],
+                        einfo: Optional[Dict[ET, torch.Tensor]] = None):
     """models.py:422-426 / 581-585: encoder from zero state, decoder from the encoder's (h, c),
-    both on the same x_dict.  Returns the decoder's h dict (views into the workspace)."""
-    ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
-    run_cell(backend, enc, graph, x, ea, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1)
-    run_cell(backend, dec, graph, x, ea, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2)
+    both on the same x_dict.  `einfo` (from prepare_edges) may be shared by several models that
+    see the same x / edge_attr; when absent it is computed here.  Returns the decoder's (h, c)."""
+    if einfo is None:
+        ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
+        einfo = ws.einfo = prepare_edges(backend, graph, x, ea, ws.einfo)
+    run_cell(backend, enc, graph, x, einfo, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1)
+    run_cell(backend, dec, graph, x, einfo, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2)
     return ws.h2, ws.c2

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from .backend import default_backend
-from .engine import GraphCSR, Workspace, _check_x, _edge_attr_1d, graph_for, run_cell
+from .engine import _check_x, _edge_attr_1d, graph_for, prepare_edges, run_cell
 from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, pack_cell, pack_conv, roundup4
 
 
@@ -62,8 +62,10 @@ class PeriodConv(nn.Module):
         be.project(xs, Fs, hs, wps, bps, ps)
         be.project(xd, Fd, hd, wpd, bpd, pd)
         csr = be.build_csr(edge_index, x_src.size(0), x_dst.size(0))
+        einfo = torch.empty(max(edge_index.size(1), 1), 4, device=dev)
+        be.edge_prepare([(csr, _edge_attr_1d(edge_attr), xs, xd, einfo)])
         agg = torch.zeros(x_dst.size(0), 100, device=dev)
-        be.aggregate(csr, _edge_attr_1d(edge_attr), xs, xd, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)
+        be.aggregate(csr, einfo, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)
         out = torch.empty(x_dst.size(0), C, device=dev)
         be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW)
         return out
@@ -135,7 +137,8 @@ class HeteroPGCLSTM(nn.Module):
                 c_dict = {nt: torch.zeros(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
             h_dict = {nt: h_dict[nt].contiguous() for nt in NODE_TYPES}
             c_dict = {nt: c_dict[nt].contiguous() for nt in NODE_TYPES}
-        run_cell(be, pc, graph, x_dict, ea, h_dict, c_dict, proj, agg, h_out, c_out)
+        einfo = prepare_edges(be, graph, x_dict, ea, None)
+        run_cell(be, pc, graph, x_dict, einfo, h_dict, c_dict, proj, agg, h_out, c_out)
         return h_out, c_out
 
 

@@ -7,7 +7,7 @@ topology surgery (Cmodel.update, :426) and the polygon geometry of traj.GNN_upda
 are host code outside this path; the topology is therefore static here and the grain
 centres x_grain[:, :2] are not refreshed.
 
-The whole step is 34 kernel launches with no host synchronisation and no allocation, so it
+The whole step is 35 kernel launches with no host synchronisation and no allocation, so it
 can be replayed from a hipGraph (`use_graph=True`) to remove launch overhead on small graphs.
 """
 from typing import Dict, Optional
@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .backend import default_backend
-from .engine import Workspace, _check_x, graph_for, run_encoder_decoder
+from .engine import Workspace, _check_x, graph_for, prepare_edges, run_encoder_decoder
 from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
 TRAIN_FRAMES = 120  # test.py:190
@@ -63,6 +63,7 @@ class GrainRollout:
             "edge": torch.empty(E, 2, **f32),
         }
         self._tmp = torch.empty(nj, 8, **f32)
+        self.einfo = {et: torch.empty(max(self.graph.n_edges(et), 1), 4, **f32) for et in EDGE_TYPES}
         self.steps_done = 0
         self._graph_exec = None
         if use_graph:
@@ -71,12 +72,14 @@ class GrainRollout:
     # -- one step, enqueued on the current stream --------------------------------------
     def _enqueue_step(self):
         be, x, ea, p = self.be, self.x, self.edge_attr, self.pred
+        # edge geometry once per step, shared by both models and all four cells
+        einfo = prepare_edges(be, self.graph, x, ea, self.einfo)
         enc, dec = self.packed["R"]
-        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea)
+        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
         be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
                            p["joint"], p["grain"], p["grain_area"])
         enc, dec = self.packed["C"]
-        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea)
+        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo)
         be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                             self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
         be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)

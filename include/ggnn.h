@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 1
+#define GGNN_ABI_VERSION 2
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
@@ -53,14 +53,34 @@ const char* ggnn_error_string(int code);
  *   col        : [E] int32 out, source node of each CSR slot
  *   perm       : [E] int32 out, original COO edge id of each CSR slot (ascending inside a
  *                row => the result is deterministic and order-stable)
+ *   row        : [E] int32 out, destination node of each CSR slot
  *   flags      : [1] int32 device word, bit 0 is OR-ed in when an index is out of range
  *                (such edges are dropped; the host wrapper raises)
  *   workspace  : ggnn_csr_workspace_bytes(E, n_dst) bytes of device scratch
  */
 size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst);
 int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
-                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* flags,
+                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row, int32_t* flags,
                    void* workspace, size_t workspace_bytes, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-edge geometry in CSR order, computed once per forward and shared by every gate of the
+ * encoder and decoder cells:  einfo[p] = (reloc_x, reloc_y, reloc_z, edge_attr) with
+ * reloc = min-image(x_src[col[p], :3] - x_dst[row[p], :3]) exactly as periodGATconv.py:209-210
+ * (rel > 0.5 -> rel - 1, rel < -0.5 -> rel + 1) and edge_attr taken from the ORIGINAL COO
+ * order through perm (edge_attr_dict[et][:, 0]).  Up to three edge types per launch.
+ */
+typedef struct ggnn_prepare_edge {
+  const int32_t* col;     /* [E] */
+  const int32_t* perm;    /* [E] */
+  const int32_t* row;     /* [E] */
+  const float* edge_attr; /* [E] COO order */
+  const float* x_src;     /* [n_src, ldx_src] */
+  const float* x_dst;     /* [n_dst, ldx_dst] */
+  float* einfo;           /* [E, 4] out, 16-byte aligned */
+  int64_t ldx_src, ldx_dst, E;
+} ggnn_prepare_edge;
+int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Node-level projection (fp32 MFMA): out[M, ncols] = [X[:, :F] | H] . Wp^T + bias.
@@ -91,15 +111,12 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
 typedef struct ggnn_aggregate_args {
   const int32_t* rowptr;    /* [n_dst + 1] */
   const int32_t* col;       /* [E] */
-  const int32_t* perm;      /* [E] */
-  const float* edge_attr;   /* [E] in the ORIGINAL COO order (edge_attr_dict[et][:, 0]) */
-  const float* x_src;       /* [n_src, ldx_src], columns 0..2 = x, y, z */
-  const float* x_dst;       /* [n_dst, ldx_dst] */
+  const float* einfo;       /* [E, 4] from ggnn_edge_prepare */
   const float* p_src;       /* projection of the source type: K|V of gate g at column kv_off + g*192 */
   const float* p_dst;       /* projection of the destination type: Q of gate g at column q_off + g*96 */
   const float* edge_params; /* [n_gates][7][96]: W_key[:,0..2], W_value[:,0..2], lin_edge.weight[:,0] */
   float* agg;               /* [n_dst, ld_agg] */
-  int64_t ldx_src, ldx_dst, ldp_src, ldp_dst, ld_agg;
+  int64_t ldp_src, ldp_dst, ld_agg;
   int64_t n_src, n_dst, E;
   int32_t kv_off, q_off, a_off, a_gstride, sc_off, n_gates; /* n_gates in {1, 3, 4} */
 } ggnn_aggregate_args;

@@ -25,7 +25,15 @@ class TorchEmulatorBackend:
         perm = torch.sort(dst * (E + 1) + torch.arange(E), stable=True).indices
         rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
         rowptr[1:] = torch.bincount(dst, minlength=n_dst).cumsum(0)
-        return rowptr.int(), src[perm].int(), perm.int()
+        return rowptr.int(), src[perm].int(), perm.int(), dst[perm].int()
+
+    def edge_prepare(self, items):
+        for csr, ea, xs, xd, einfo in items:
+            rowptr, col, perm, row = (t.long() for t in csr)
+            E = ea.numel()
+            rel = xs[col[:E], :3] - xd[row[:E], :3]
+            einfo[:E, :3] = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+            einfo[:E, 3] = ea[perm[:E]]
 
     def project(self, x, F, h, wp, bp, out):
         Fp = (F + 3) & ~3
@@ -37,15 +45,13 @@ class TorchEmulatorBackend:
             xin[:, Fp:] = h
         out[:, :wp.size(0)] = xin @ wp.t() + bp
 
-    def aggregate(self, csr, edge_attr, x_src, x_dst, p_src, p_dst, ep, agg, kv_off, q_off,
-                  a_off, a_gstride, sc_off, n_gates):
-        rowptr, col, perm = (t.long() for t in csr)
-        n_dst = x_dst.size(0)
+    def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
+                  sc_off, n_gates):
+        rowptr, col = csr[0].long(), csr[1].long()
+        n_dst = p_dst.size(0)
         E = int(rowptr[-1])
         dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
-        j, a = col[:E], edge_attr[perm[:E]]
-        rel = x_src[j, :3] - x_dst[dst, :3]
-        reloc = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+        j, reloc, a = col[:E], einfo[:E, :3], einfo[:E, 3]
         for g in range(n_gates):
             K = p_src[j, kv_off + g * 2 * C: kv_off + g * 2 * C + C]
             V = p_src[j, kv_off + g * 2 * C + C: kv_off + (g + 1) * 2 * C]

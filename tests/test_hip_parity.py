@@ -22,7 +22,7 @@ def backend():
 
 def test_library_is_loaded_from_the_tree():
     be = backend()
-    assert be.lib.ggnn_version() == 1
+    assert be.lib.ggnn_version() == 2
     assert _lib.LIB_PATH.endswith("graingraphnn_amd/libggnn.so")
 
 
@@ -42,8 +42,9 @@ def _csr_numpy(ei, n_dst):
 def test_build_csr_bit_exact(n_src, n_dst, E, seed):
     rs = np.random.RandomState(seed)
     ei = np.stack([rs.randint(0, n_src, E), rs.randint(0, n_dst, E)]).astype(np.int64)
-    rowptr, col, perm = backend().build_csr(torch.from_numpy(ei).to(DEV), n_src, n_dst)
+    rowptr, col, perm, row = backend().build_csr(torch.from_numpy(ei).to(DEV), n_src, n_dst)
     r_ref, c_ref, p_ref = _csr_numpy(ei, n_dst)
+    assert np.array_equal(row.cpu().numpy()[:E], ei[1][p_ref])
     assert np.array_equal(rowptr.cpu().numpy(), r_ref)
     assert np.array_equal(col.cpu().numpy()[:E], c_ref)
     assert np.array_equal(perm.cpu().numpy()[:E], p_ref)

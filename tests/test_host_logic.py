@@ -130,7 +130,8 @@ def test_cell_with_state_and_single_conv_packing():
         agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Ka) for nt in n_nodes}
         ho = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
         co = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
-        engine.run_cell(be, pc, graph, X, ea1, None if encoder else h0, None if encoder else c0,
+        einfo = engine.prepare_edges(be, graph, X, ea1, None)
+        engine.run_cell(be, pc, graph, X, einfo, None if encoder else h0, None if encoder else c0,
                         proj, agg, ho, co)
         for nt in n_nodes:
             assert_close(ho[nt], g[f"{key}_h_{nt}"], f"{key} h {nt}", TOL)
@@ -144,7 +145,7 @@ def test_cell_with_state_and_single_conv_packing():
         be.project(X[et[0]], Fs, h0[et[0]], wps, bps, ps)
         be.project(X[et[-1]], Fd, h0[et[-1]], wpd, bpd, pd)
         agg = torch.zeros(n_nodes[et[-1]], 100)
-        be.aggregate(graph.csr[et], ea1[et], X[et[0]], X[et[-1]], ps, pd, ep, agg, 0, 0, 0, 100, 96, 1)
+        be.aggregate(graph.csr[et], einfo[et], ps, pd, ep, agg, 0, 0, 0, 100, 96, 1)
         out = torch.empty(n_nodes[et[-1]], 96)
         be.lstm_epilogue(agg, w2, pd, 96, None, None, None, out, 1, 2)
         assert_close(out, g["conv_" + etk(et)], f"conv {et}", TOL)
