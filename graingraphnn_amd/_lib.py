@@ -13,14 +13,16 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 2
+GGNN_ABI_VERSION = 3
+GGNN_UNIT_EDGES = 3
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 7
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
 EXPORTED_SYMBOLS = (
-    "ggnn_version", "ggnn_error_string", "ggnn_csr_workspace_bytes", "ggnn_build_csr",
+    "ggnn_version", "ggnn_error_string", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
+    "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_step_refresh", "ggnn_workspace_bytes",
 )
@@ -46,7 +48,7 @@ class PrepareEdge(Structure):
 class AggregateArgs(Structure):
     """Mirror of `ggnn_aggregate_args`."""
     _fields_ = [
-        ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p),
+        ("unit_ptr", c_void_p), ("units", c_void_p), ("einfo", c_void_p),
         ("p_src", c_void_p), ("p_dst", c_void_p), ("edge_params", c_void_p), ("agg", c_void_p),
         ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
         ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
@@ -85,8 +87,11 @@ def _declare(lib):
     lib.ggnn_csr_workspace_bytes.restype = c_size_t
     lib.ggnn_csr_workspace_bytes.argtypes = [c_int64, c_int64]
     lib.ggnn_build_csr.restype = c_int
+    lib.ggnn_csr_max_units.restype = c_int64
+    lib.ggnn_csr_max_units.argtypes = [c_int64, c_int64]
     lib.ggnn_build_csr.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]
     lib.ggnn_edge_prepare.restype = c_int
     lib.ggnn_edge_prepare.argtypes = [POINTER(PrepareEdge), c_int, c_void_p]
     lib.ggnn_project.restype = c_int

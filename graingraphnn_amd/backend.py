@@ -10,6 +10,15 @@ from . import _lib
 from ._lib import AggregateArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
 
 
+class CSR:
+    """Destination-grouped edge list of one edge type (all int32, device resident)."""
+    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E")
+
+    def __init__(self, rowptr, col, perm, row, unit_ptr, units, E):
+        self.rowptr, self.col, self.perm, self.row = rowptr, col, perm, row
+        self.unit_ptr, self.units, self.E = unit_ptr, units, E
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -32,8 +41,8 @@ class HipBackend:
 
     # -- CSR ---------------------------------------------------------------------------
     def build_csr(self, edge_index, n_src, n_dst):
-        """edge_index [2, E] int64 (cuda) -> (rowptr, col, perm, row) int32.  Raises IndexError
-        on out-of-range indices (one host sync, only when a topology is first seen)."""
+        """edge_index [2, E] int64 (cuda) -> CSR.  Raises IndexError on out-of-range indices
+        (one host sync, only when a topology is first seen)."""
         _require_cuda(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise _lib.GGNNError("edge_index must be int64 [2, E]")
@@ -44,25 +53,29 @@ class HipBackend:
         col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        unit_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+        units = torch.zeros(self.lib.ggnn_csr_max_units(E, n_dst), 8, dtype=torch.int32, device=dev)
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
         nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(self.lib.ggnn_build_csr(ptr(ei), E, n_src, n_dst, ptr(rowptr), ptr(col), ptr(perm),
-                                      ptr(row), ptr(flags), ptr(ws), nbytes, _lib.current_stream()),
+                                      ptr(row), ptr(unit_ptr), ptr(units), ptr(flags), ptr(ws), nbytes,
+                                      _lib.current_stream()),
               "ggnn_build_csr")
         if int(flags[0].item()) & 1:
             raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
-        return rowptr, col, perm, row
+        return CSR(rowptr, col, perm, row, unit_ptr, units, E)
 
     # -- per-edge geometry -------------------------------------------------------------
     def edge_prepare(self, items):
-        """items: list of (csr, edge_attr [E] COO order, x_src, x_dst, einfo_out [E, 4])."""
+        """items: list of (csr, edge_attr [E] COO order, x_src, x_dst, einfo_out [E + 3, 4])."""
         arr = (PrepareEdge * max(len(items), 1))()
         for k, (csr, ea, xs, xd, einfo) in enumerate(items):
-            rowptr, col, perm, row = csr
-            _require_cuda(col, ea, xs, xd, einfo)
+            _require_cuda(csr.col, ea, xs, xd, einfo)
+            if einfo.size(0) < ea.numel() + _lib.GGNN_UNIT_EDGES:
+                raise _lib.GGNNError("einfo needs E + GGNN_UNIT_EDGES rows")
             a = arr[k]
-            a.col, a.perm, a.row = col.data_ptr(), perm.data_ptr(), row.data_ptr()
+            a.col, a.perm, a.row = csr.col.data_ptr(), csr.perm.data_ptr(), csr.row.data_ptr()
             a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
             a.einfo = einfo.data_ptr()
             a.ldx_src, a.ldx_dst, a.E = xs.stride(0), xd.stride(0), ea.numel()
@@ -80,14 +93,13 @@ class HipBackend:
     # -- aggregation -------------------------------------------------------------------
     def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
                   sc_off, n_gates):
-        rowptr, col = csr[0], csr[1]
-        _require_cuda(rowptr, einfo, p_src, p_dst, ep, agg)
+        _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, ep, agg)
         a = AggregateArgs()
-        a.rowptr, a.col, a.einfo = rowptr.data_ptr(), col.data_ptr(), einfo.data_ptr()
+        a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
         a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
         a.edge_params, a.agg = ep.data_ptr(), agg.data_ptr()
         a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
-        a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), einfo.size(0)
+        a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), csr.E
         a.kv_off, a.q_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             kv_off, q_off, a_off, a_gstride, sc_off, n_gates)
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),

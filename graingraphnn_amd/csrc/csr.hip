@@ -1,4 +1,5 @@
-// CSR build: COO edge_index [2,E] int64 -> (rowptr, col, perm) grouped by destination.
+// CSR build: COO edge_index [2,E] int64 -> (rowptr, col, perm, row) grouped by destination,
+// plus the unit table (unit_ptr, units) the aggregation sweep walks.
 // Replaces the per-call COO gather/scatter bookkeeping of PyG MessagePassing.propagate as
 // used at periodGATconv.py:174-175.  Deterministic: inside a row the slots are ordered by
 // original edge id, whatever order the atomics happened to land in.
@@ -93,6 +94,48 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int64_t* __restrict
   }
 }
 
+// ---- unit table for the LDS-DMA aggregation sweep -------------------------------------
+// A unit is one destination row restricted to at most GGNN_UNIT_EDGES consecutive in-edges
+// (rows without edges still get one empty unit so that their output is written).  The
+// descriptor is 32 bytes: {i, p0, nact | first<<8 | last<<9, 0, j0, j1, j2, 0}; absent
+// edges repeat j0 (or 0) so that every unit issues the same number of row loads.
+__global__ __launch_bounds__(256) void csr_unit_count_kernel(const int32_t* __restrict__ rowptr,
+                                                             int64_t n_dst,
+                                                             int32_t* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_dst) return;
+  const int32_t deg = rowptr[i + 1] - rowptr[i];
+  cnt[i] = deg == 0 ? 1 : (deg + GGNN_UNIT_EDGES - 1) / GGNN_UNIT_EDGES;
+}
+
+__global__ __launch_bounds__(256) void csr_unit_fill_kernel(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ unit_ptr,
+                                                            int64_t n_dst,
+                                                            int32_t* __restrict__ units) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_dst) return;
+  const int32_t beg = rowptr[i], end = rowptr[i + 1];
+  int32_t u = unit_ptr[i];
+  int32_t p = beg;
+  do {
+    const int32_t nact = min(GGNN_UNIT_EDGES, end - p);
+    const int32_t first = p == beg, last = p + GGNN_UNIT_EDGES >= end;
+    int32_t* d = units + 8 * (int64_t)u;
+    const int32_t j0 = nact > 0 ? col[p] : 0;
+    d[0] = (int32_t)i;
+    d[1] = p;
+    d[2] = nact | (first << 8) | (last << 9);
+    d[3] = 0;
+    d[4] = j0;
+    d[5] = nact > 1 ? col[p + 1] : j0;
+    d[6] = nact > 2 ? col[p + 2] : j0;
+    d[7] = 0;
+    ++u;
+    p += GGNN_UNIT_EDGES;
+  } while (p < end);
+}
+
 }  // namespace ggnn
 
 extern "C" size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst) {
@@ -100,13 +143,18 @@ extern "C" size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst) {
   return (size_t)(2 * (n_dst > 0 ? n_dst : 0) + 2) * sizeof(int32_t);
 }
 
+extern "C" int64_t ggnn_csr_max_units(int64_t E, int64_t n_dst) {
+  return (n_dst > 0 ? n_dst : 0) + (E > 0 ? E : 0) / GGNN_UNIT_EDGES + 1;
+}
+
 extern "C" int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
                               int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row,
-                              int32_t* flags, void* workspace, size_t workspace_bytes, ggnn_stream_t stream_) {
+                              int32_t* unit_ptr, int32_t* units, int32_t* flags, void* workspace, size_t workspace_bytes, ggnn_stream_t stream_) {
   using namespace ggnn;
   hipStream_t stream = (hipStream_t)stream_;
   if (E < 0 || n_src < 0 || n_dst <= 0 || !rowptr || !flags || !workspace) return GGNN_EINVAL;
   if (E > 0 && (!edge_index || !col || !perm || !row)) return GGNN_EINVAL;
+  if (!unit_ptr || !units || !aligned16(units)) return GGNN_EINVAL;
   if (E >= INT32_MAX || n_dst >= INT32_MAX || n_src >= INT32_MAX) return GGNN_EINVAL;
   if (workspace_bytes < ggnn_csr_workspace_bytes(E, n_dst)) return GGNN_EINVAL;
   int32_t* counts = (int32_t*)workspace;
@@ -125,5 +173,11 @@ extern "C" int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_sr
     hipLaunchKernelGGL(csr_sort_kernel, dim3(nb), dim3(256), 0, stream, edge_index, rowptr,
                        n_dst, perm, col, row);
   }
+  // unit table: per-row unit counts -> exclusive scan (cursor is free again) -> descriptors
+  hipLaunchKernelGGL(csr_unit_count_kernel, dim3(nb), dim3(256), 0, stream, rowptr, n_dst, counts);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_dst, unit_ptr,
+                     cursor);
+  hipLaunchKernelGGL(csr_unit_fill_kernel, dim3(nb), dim3(256), 0, stream, rowptr, col, unit_ptr,
+                     n_dst, units);
   return launch_status();
 }

@@ -85,13 +85,18 @@ def _check_x(x: torch.Tensor, F: int, name: str):
         raise _lib.GGNNError(f"x_dict['{name}'] must be float32 [N, {F}] with unit column stride")
 
 
+def alloc_einfo(graph: GraphCSR, device):
+    """[E + GGNN_UNIT_EDGES, 4] per edge type: the tail rows pad the last unit's 48-byte read."""
+    return {et: torch.zeros(graph.n_edges(et) + _lib.GGNN_UNIT_EDGES, 4, dtype=torch.float32, device=device)
+            for et in EDGE_TYPES}
+
+
 def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
                   edge_attr: Dict[ET, torch.Tensor], einfo: Optional[Dict[ET, torch.Tensor]]):
     """One launch: min-image offsets + edge lengths of all three edge types in CSR order."""
     dev = x["joint"].device
-    if einfo is None or any(einfo[et].size(0) != max(graph.n_edges(et), 1) for et in EDGE_TYPES):
-        einfo = {et: torch.empty(max(graph.n_edges(et), 1), 4, dtype=torch.float32, device=dev)
-                 for et in EDGE_TYPES}
+    if einfo is None or any(einfo[et].size(0) != graph.n_edges(et) + _lib.GGNN_UNIT_EDGES for et in EDGE_TYPES):
+        einfo = alloc_einfo(graph, dev)
     backend.edge_prepare([(graph.csr[et], edge_attr[et], x[et[0]], x[et[-1]], einfo[et])
                           for et in EDGE_TYPES])
     return einfo

@@ -62,7 +62,7 @@ class PeriodConv(nn.Module):
         be.project(xs, Fs, hs, wps, bps, ps)
         be.project(xd, Fd, hd, wpd, bpd, pd)
         csr = be.build_csr(edge_index, x_src.size(0), x_dst.size(0))
-        einfo = torch.empty(max(edge_index.size(1), 1), 4, device=dev)
+        einfo = torch.zeros(edge_index.size(1) + _lib.GGNN_UNIT_EDGES, 4, device=dev)
         be.edge_prepare([(csr, _edge_attr_1d(edge_attr), xs, xd, einfo)])
         agg = torch.zeros(x_dst.size(0), 100, device=dev)
         be.aggregate(csr, einfo, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)

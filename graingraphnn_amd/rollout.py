@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .backend import default_backend
-from .engine import Workspace, _check_x, graph_for, prepare_edges, run_encoder_decoder
+from .engine import Workspace, _check_x, alloc_einfo, graph_for, prepare_edges, run_encoder_decoder
 from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
 TRAIN_FRAMES = 120  # test.py:190
@@ -63,7 +63,7 @@ class GrainRollout:
             "edge": torch.empty(E, 2, **f32),
         }
         self._tmp = torch.empty(nj, 8, **f32)
-        self.einfo = {et: torch.empty(max(self.graph.n_edges(et), 1), 4, **f32) for et in EDGE_TYPES}
+        self.einfo = alloc_einfo(self.graph, dev)
         self.steps_done = 0
         self._graph_exec = None
         if use_graph:

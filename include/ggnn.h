@@ -25,10 +25,11 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 2
+#define GGNN_ABI_VERSION 3
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
+#define GGNN_UNIT_EDGES 3      /* in-edges per aggregation unit (every junction has exactly 3) */
 
 #define GGNN_OK 0
 #define GGNN_EINVAL (-1)  /* bad argument (null pointer, size, alignment, unsupported width) */
@@ -54,14 +55,21 @@ const char* ggnn_error_string(int code);
  *   perm       : [E] int32 out, original COO edge id of each CSR slot (ascending inside a
  *                row => the result is deterministic and order-stable)
  *   row        : [E] int32 out, destination node of each CSR slot
+ *   unit_ptr   : [n_dst + 1] int32 out, first unit of every destination row
+ *   units      : [ggnn_csr_max_units(E, n_dst), 8] int32 out, 16-byte aligned.  A unit is a
+ *                destination row restricted to <= GGNN_UNIT_EDGES consecutive in-edges:
+ *                {i, p0, nact | first<<8 | last<<9, 0, j0, j1, j2, 0}; rows without edges
+ *                get one empty unit; absent edges repeat j0.  unit_ptr[n_dst] = #units.
  *   flags      : [1] int32 device word, bit 0 is OR-ed in when an index is out of range
  *                (such edges are dropped; the host wrapper raises)
  *   workspace  : ggnn_csr_workspace_bytes(E, n_dst) bytes of device scratch
  */
 size_t ggnn_csr_workspace_bytes(int64_t E, int64_t n_dst);
+int64_t ggnn_csr_max_units(int64_t E, int64_t n_dst); /* upper bound: n_dst + E / GGNN_UNIT_EDGES */
 int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
-                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row, int32_t* flags,
-                   void* workspace, size_t workspace_bytes, ggnn_stream_t stream);
+                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row, int32_t* unit_ptr,
+                   int32_t* units, int32_t* flags, void* workspace, size_t workspace_bytes,
+                   ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-edge geometry in CSR order, computed once per forward and shared by every gate of the
@@ -77,7 +85,7 @@ typedef struct ggnn_prepare_edge {
   const float* edge_attr; /* [E] COO order */
   const float* x_src;     /* [n_src, ldx_src] */
   const float* x_dst;     /* [n_dst, ldx_dst] */
-  float* einfo;           /* [E, 4] out, 16-byte aligned */
+  float* einfo;           /* [E + GGNN_UNIT_EDGES, 4] out, 16-byte aligned (tail rows are padding) */
   int64_t ldx_src, ldx_dst, E;
 } ggnn_prepare_edge;
 int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
@@ -109,9 +117,9 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
  * ggnn_lstm_epilogue, which is exact because they are linear in these sums.)
  */
 typedef struct ggnn_aggregate_args {
-  const int32_t* rowptr;    /* [n_dst + 1] */
-  const int32_t* col;       /* [E] */
-  const float* einfo;       /* [E, 4] from ggnn_edge_prepare */
+  const int32_t* unit_ptr;  /* [n_dst + 1] from ggnn_build_csr */
+  const int32_t* units;     /* [n_units, 8] from ggnn_build_csr */
+  const float* einfo;       /* [E + GGNN_UNIT_EDGES, 4] from ggnn_edge_prepare */
   const float* p_src;       /* projection of the source type: K|V of gate g at column kv_off + g*192 */
   const float* p_dst;       /* projection of the destination type: Q of gate g at column q_off + g*96 */
   const float* edge_params; /* [n_gates][7][96]: W_key[:,0..2], W_value[:,0..2], lin_edge.weight[:,0] */

@@ -25,11 +25,12 @@ class TorchEmulatorBackend:
         perm = torch.sort(dst * (E + 1) + torch.arange(E), stable=True).indices
         rowptr = torch.zeros(n_dst + 1, dtype=torch.int64)
         rowptr[1:] = torch.bincount(dst, minlength=n_dst).cumsum(0)
-        return rowptr.int(), src[perm].int(), perm.int(), dst[perm].int()
+        from graingraphnn_amd.backend import CSR
+        return CSR(rowptr.int(), src[perm].int(), perm.int(), dst[perm].int(), None, None, E)
 
     def edge_prepare(self, items):
         for csr, ea, xs, xd, einfo in items:
-            rowptr, col, perm, row = (t.long() for t in csr)
+            col, perm, row = csr.col.long(), csr.perm.long(), csr.row.long()
             E = ea.numel()
             rel = xs[col[:E], :3] - xd[row[:E], :3]
             einfo[:E, :3] = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
@@ -47,7 +48,7 @@ class TorchEmulatorBackend:
 
     def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
                   sc_off, n_gates):
-        rowptr, col = csr[0].long(), csr[1].long()
+        rowptr, col = csr.rowptr.long(), csr.col.long()
         n_dst = p_dst.size(0)
         E = int(rowptr[-1])
         dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])

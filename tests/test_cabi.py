@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 2
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 3
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4
@@ -47,7 +47,8 @@ def test_argument_validation_returns_einval_without_launching():
     assert lib.ggnn_period_gat_aggregate(ctypes.byref(a), None) == -1
     e = _lib.EpilogueArgs()
     assert lib.ggnn_lstm_epilogue(ctypes.byref(e), None) == -1
-    assert lib.ggnn_build_csr(None, 5, 3, 0, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ggnn_build_csr(None, 5, 3, 0, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ggnn_csr_max_units(60000, 20000) == 40001
     assert lib.ggnn_edge_prepare(None, 1, None) == -1
     assert lib.ggnn_heads_regressor(None, 1, None, 1, None, 11, None, None, None, None, None, None) == -1
     assert lib.ggnn_heads_classifier(None, 1, None, 0, None, None, None, None, None, None, None) == -1

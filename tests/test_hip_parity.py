@@ -22,7 +22,7 @@ def backend():
 
 def test_library_is_loaded_from_the_tree():
     be = backend()
-    assert be.lib.ggnn_version() == 2
+    assert be.lib.ggnn_version() == 3
     assert _lib.LIB_PATH.endswith("graingraphnn_amd/libggnn.so")
 
 
@@ -42,12 +42,27 @@ def _csr_numpy(ei, n_dst):
 def test_build_csr_bit_exact(n_src, n_dst, E, seed):
     rs = np.random.RandomState(seed)
     ei = np.stack([rs.randint(0, n_src, E), rs.randint(0, n_dst, E)]).astype(np.int64)
-    rowptr, col, perm, row = backend().build_csr(torch.from_numpy(ei).to(DEV), n_src, n_dst)
+    csr = backend().build_csr(torch.from_numpy(ei).to(DEV), n_src, n_dst)
     r_ref, c_ref, p_ref = _csr_numpy(ei, n_dst)
-    assert np.array_equal(row.cpu().numpy()[:E], ei[1][p_ref])
-    assert np.array_equal(rowptr.cpu().numpy(), r_ref)
-    assert np.array_equal(col.cpu().numpy()[:E], c_ref)
-    assert np.array_equal(perm.cpu().numpy()[:E], p_ref)
+    assert np.array_equal(csr.row.cpu().numpy()[:E], ei[1][p_ref])
+    assert np.array_equal(csr.rowptr.cpu().numpy(), r_ref)
+    assert np.array_equal(csr.col.cpu().numpy()[:E], c_ref)
+    assert np.array_equal(csr.perm.cpu().numpy()[:E], p_ref)
+    # unit table: rows cut into <= 3-edge units, empty rows keep one empty unit
+    deg = np.diff(r_ref)
+    cnt = np.where(deg == 0, 1, (deg + 2) // 3)
+    uptr = np.concatenate([[0], np.cumsum(cnt)])
+    assert np.array_equal(csr.unit_ptr.cpu().numpy(), uptr)
+    units = csr.units.cpu().numpy()[:uptr[-1]]
+    for i in np.random.RandomState(seed).randint(0, n_dst, 50):
+        for c in range(cnt[i]):
+            d = units[uptr[i] + c]
+            p0 = r_ref[i] + 3 * c
+            nact = int(min(3, max(0, r_ref[i + 1] - p0)))
+            assert d[0] == i and d[1] == p0
+            assert d[2] == (nact | (int(c == 0) << 8) | (int(c == cnt[i] - 1) << 9))
+            want = [c_ref[p0 + t] if t < nact else (c_ref[p0] if nact else 0) for t in range(3)]
+            assert list(d[4:7]) == want
 
 
 def test_build_csr_rejects_out_of_range_indices():
