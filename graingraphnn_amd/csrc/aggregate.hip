@@ -14,68 +14,38 @@
 // ggnn_edge_prepare computes (reloc_e, a_e) once per forward in CSR order (16 bytes per
 // edge, shared by the 7 gate sweeps of encoder + decoder).
 //
-// The sweep is a per-wave LDS-DMA gather ring.  Work is cut into *units* (one destination
-// row x up to 3 in-edges, descriptor table built with the CSR).  A wave owns a contiguous
-// range of destination rows and runs a 3-deep software pipeline over its units:
-//   issue  : 13 `global_load_lds_dwordx4` per unit copy the unit descriptor, its 3 edge
-//            records, the destination's Q fragments of all gates (G x 384 B) and the 3
-//            neighbour rows' K|V fragments of all gates (G x 768 B contiguous each) straight
-//            from HBM into the wave's LDS slot -- no VGPRs are held while they fly, so each
-//            wave keeps 2 units (~21 KB) in flight and a CU ~86 KB, 2x what 8 TB/s needs;
-//   wait   : a counted `s_waitcnt vmcnt(13 * units_issued_after)` (LDS-DMA completes in
-//            order), never vmcnt(0) in steady state, no workgroup barrier;
-//   compute: the two half-waves take gates {h, h+2}; each lane owns channels {l, l+32, l+64}
-//            (conflict-free ds_read_b32), scores its edges, folds them into an online-max
-//            softmax carried in registers across the units of one row, and stores the row
-//            when its last unit is done.
-// Unit descriptors are fetched with scalar loads (SMEM, lgkmcnt) one iteration ahead, so the
-// only vector-memory traffic in the loop is the DMA stream and the output stores.
-// No atomics, one owner per output row => bit-reproducible.  Rows of any degree work.
+// The sweep walks the *unit table* built with the CSR (a unit = one destination row x up to
+// 3 in-edges, 32-byte descriptor {i, p0, nact|first|last, -, j0, j1, j2, -}).  The workgroups
+// that share an XCD own one contiguous eighth of the destination rows and deal them
+// round-robin to their waves, so an XCD always works inside a short sliding window of
+// neighbouring rows and the 3-6 re-reads of a source row hit its L2 (rocprofv3: 63 % L2
+// misses and 2x the algorithmic bytes fetched with per-workgroup contiguous ranges).
+// A WAVE takes such a row stream and a pair of gates (one gate per half-wave: 32 lanes x 3 channels, so one
+// global_load_dwordx3 is one 384-byte row fragment) and streams through the sub-range's
+// units.  Both halves see the same units, so everything that describes a unit is
+// wave-uniform and lives on the scalar side:
+//   * descriptor and the 3 edge records (reloc, a_e) come through scalar loads (SMEM) into
+//     SGPRs; the scalar chain for unit u+1 (descriptor -> its edge records) runs while the
+//     vector loads of unit u are in flight, and does not touch the vector-memory counter;
+//   * the vector side of a unit is exactly 7 loads issued back to back: Q and the 3 x (K, V)
+//     fragments -- one exposed round trip per unit, ~21 VGPRs of load state, which keeps the
+//     kernel at 8 waves per SIMD (64 half-wave streams, ~170 KB requested per CU);
+//   * scores are folded into an online-max softmax carried in registers across the units
+//     of one row (any degree, bounded registers, nothing re-read); the row is stored once,
+//     when its last unit is done.  No atomics => bit-reproducible.
+// Only the 7 x 96 per-gate edge parameters go through LDS.  (Measured alternatives, in git
+// history and profiles/: v1 block-staged CSR 64 us; v2 per-half-wave CSR walk 53 us; v3
+// per-wave LDS-DMA gather ring 63 us -- 86 KB/CU in flight but issue-bound at one wave per
+// SIMD; v4 unit table + vector-side descriptor prefetch 41 us.)
 #include "common.h"
 
 namespace ggnn {
 
-constexpr int AG_WAVES = 4;   // waves per workgroup (one workgroup per CU: LDS-limited)
-constexpr int AG_DEPTH = 3;   // ring slots per wave
+constexpr int AG_BLOCKS_PER_CU = 7;  // resident workgroups per CU (68 VGPRs -> 7 waves per SIMD)
 constexpr int AG_NUM_CU = 256;
 constexpr int UE = GGNN_UNIT_EDGES;
 
-// LDS slot layout (bytes)
-constexpr int SL_DESC = 0;     // 32 B unit descriptor
-constexpr int SL_EINFO = 64;   // 3 x 16 B edge records
-constexpr int SL_Q = 128;      // G x 384 B
-template <int G> struct Slot {
-  static constexpr int q_bytes = G * C * 4;
-  static constexpr int row_bytes = G * 2 * C * 4;
-  static constexpr int rows_off = SL_Q + ((q_bytes + 63) / 64) * 64;
-  static constexpr int bytes = ((rows_off + UE * row_bytes + 127) / 128) * 128;
-  static constexpr int nq = (q_bytes + 1023) / 1024;     // DMA instructions for Q
-  static constexpr int nr = (row_bytes + 1023) / 1024;   // DMA instructions per neighbour row
-  static constexpr int dma_per_unit = 2 + nq + UE * nr;  // desc + einfo + Q + rows
-};
-
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef const i32x8 __attribute__((address_space(4))) * const_i32x8_ptr;  // -> s_load_dwordx8
-typedef const int __attribute__((address_space(4))) * const_i32_ptr;
-
-// One LDS-DMA instruction: every active lane copies 16 bytes from its own global address to
-// lds_base + lane * 16 (wave-uniform base in M0).  Not tracked by the compiler: completion is
-// awaited with dma_wait<N>() below.  (cdna_hip_programming.md 5.7: M0 is written and
-// restored inside the same statement.)
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_base)
-      : "memory");
-}
-
-template <int N> __device__ __forceinline__ void dma_wait() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Sum over the 32 lanes of a half-wave, result in every lane: four DPP row steps inside each
 // 16-lane row, then one ds_swizzle (xor 16) across the two rows.
@@ -122,172 +92,167 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
 // ---------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ void issue_unit(const ggnn_aggregate_args& A, int u, const i32x8 d,
-                                           uint32_t slot, int lane) {
-  using S = Slot<G>;
-  const int i = d[0], p0 = d[1];
-  // descriptor (2 lanes) and the three edge records (3 lanes)
-  if (lane < 2) dma16(reinterpret_cast<const char*>(A.units) + (int64_t)u * 32 + lane * 16, slot + SL_DESC);
-  if (lane < UE) dma16(reinterpret_cast<const char*>(A.einfo) + ((int64_t)p0 + lane) * 16, slot + SL_EINFO);
-  // Q fragments of all gates of destination i
-  const char* qsrc = reinterpret_cast<const char*>(A.p_dst + (int64_t)i * A.ldp_dst + A.q_off) + lane * 16;
-#pragma unroll
-  for (int m = 0; m < S::nq; ++m)
-    if (m * 1024 + lane * 16 < S::q_bytes) dma16(qsrc + m * 1024, slot + SL_Q + m * 1024);
-  // K|V fragments of all gates of the three neighbour rows
-#pragma unroll
-  for (int t = 0; t < UE; ++t) {
-    const char* rsrc = reinterpret_cast<const char*>(A.p_src + (int64_t)d[4 + t] * A.ldp_src + A.kv_off) + lane * 16;
-#pragma unroll
-    for (int m = 0; m < S::nr; ++m)
-      if (m * 1024 + lane * 16 < S::row_bytes)
-        dma16(rsrc + m * 1024, slot + S::rows_off + t * S::row_bytes + m * 1024);
-  }
-}
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef const i32x8 __attribute__((address_space(4))) * const_i32x8_ptr;  // uniform index -> s_load_dwordx8
+typedef const f32x4 __attribute__((address_space(4))) * const_f32x4_ptr;  // uniform index -> s_load_dwordx4
+typedef const int __attribute__((address_space(4))) * const_i32_ptr;
 
-struct GateState {
-  float mx, den, sae, a0, a1, a2;
+template <int G> struct Shape {
+  static constexpr int pairs = (G + 1) / 2;  // gate pairs; a wave sweeps one pair
+  static constexpr int waves = 4;
+  static constexpr int subs = waves / pairs;  // row sub-ranges per workgroup
 };
 
 template <int G>
-__global__ __launch_bounds__(AG_WAVES * 64, 1) void aggregate_kernel(const ggnn_aggregate_args A) {
-  using S = Slot<G>;
-  __shared__ float s_ep[G * GGNN_EDGE_PARAM_ROWS * C];
-  __shared__ __attribute__((aligned(128))) char s_ring[AG_WAVES * AG_DEPTH * S::bytes];
-
+__global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_args A) {
+  using SH = Shape<G>;
+  // [g][channel][8]: 7 parameters of one channel contiguous (32 B) -> two 16-byte LDS reads
+  __shared__ __attribute__((aligned(16))) float s_ep[G * C * 8];
   const int tid = threadIdx.x;
-  for (int t = tid; t < G * GGNN_EDGE_PARAM_ROWS * C; t += AG_WAVES * 64) s_ep[t] = A.edge_params[t];
-  __syncthreads();  // the only workgroup barrier; no DMA has been issued yet
+  for (int t = tid; t < G * GGNN_EDGE_PARAM_ROWS * C; t += 256) {
+    const int g = t / (GGNN_EDGE_PARAM_ROWS * C), r = (t / C) % GGNN_EDGE_PARAM_ROWS, c = t % C;
+    s_ep[(g * C + c) * 8 + r] = A.edge_params[t];
+  }
+  __syncthreads();
 
-  const int lane = tid & 63, l32 = tid & 31, half = (tid >> 5) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = gridDim.x;
-  const int b = xcd_remap(blockIdx.x, nblk);
-  // contiguous destination range of this wave
-  const int64_t n_waves = (int64_t)nblk * AG_WAVES;
-  const int64_t dpw = (A.n_dst + n_waves - 1) / n_waves;
-  const int64_t d_lo = ((int64_t)b * AG_WAVES + wave) * dpw;
-  if (d_lo >= A.n_dst) return;
-  const int64_t d_hi = min(A.n_dst, d_lo + dpw);
-  const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
-  const int u_lo = uptr[d_lo], u_hi = uptr[d_hi];
-  const int n_u = u_hi - u_lo;
-  const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
-
-  const uint32_t ring =
-      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_ring))) +
-      wave * (AG_DEPTH * S::bytes);
-  const char* ring_ptr = s_ring + wave * (AG_DEPTH * S::bytes);
+  const int pair = wave % SH::pairs, sub = wave / SH::pairs;
+  const int g = pair * 2 + ((tid >> 5) & 1);  // the gate of this half-wave
+  const bool active = g < G;                  // odd G: the last pair's upper half idles
+  const int gc = active ? g : 0;
+  const int ch = 3 * (tid & 31);              // first of this lane's three channels
   const float inv_sqrt_c = 0.10206207261596577f;  // 1/sqrt(96), periodGATconv.py:226
 
-  // gates owned by this half-wave: half, half + 2
-  GateState st[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) st[s] = {-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // Row assignment (all wave-uniform).  Workgroups with equal blockIdx % 8 share an XCD and
+  // its L2 (observed placement; speed only).  Each such group owns one contiguous eighth of
+  // the rows and its streams (one per wave pair-slot) take rows round-robin, so at any moment
+  // the whole group works inside one short sliding window of neighbouring rows: the 3-6
+  // readers of a source row then run close together in time and the re-reads hit that L2
+  // instead of going back to memory.
+  const int nblk = gridDim.x;
+  const int ngrp = min(nblk, 8);
+  const int grp = blockIdx.x % ngrp, lb = blockIdx.x / ngrp;
+  const int nb_grp = (nblk - grp + ngrp - 1) / ngrp;            // workgroups in this group
+  const int64_t x_lo = A.n_dst * grp / ngrp, x_hi = A.n_dst * (grp + 1) / ngrp;
+  const int64_t n_streams = (int64_t)nb_grp * SH::subs;
+  int64_t r = x_lo + (int64_t)lb * SH::subs + sub;
+  if (sub >= SH::subs || r >= x_hi) return;
+  const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
+  const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
+  const const_f32x4_ptr einfo = (const_f32x4_ptr)(uintptr_t)A.einfo;
 
-  // ---- prologue: AG_DEPTH-1 units in flight, descriptor of the next one on its way ----
-  i32x8 dnext = udesc[u_lo];
+  // this lane's 3 channels x 8 parameters: [wkx wky wkz wvx | wvy wvz we -]
+  const f32x4* epp = reinterpret_cast<const f32x4*>(&s_ep[(gc * C + ch) * 8]);
+  const f32x4 e0a = epp[0], e0b = epp[1], e1a = epp[2], e1b = epp[3], e2a = epp[4], e2b = epp[5];
+  const float* kvbase = A.p_src + A.kv_off + gc * 2 * C + ch;
+  const float* qbase = A.p_dst + A.q_off + gc * C + ch;
+  const uint32_t ldp_src = (uint32_t)A.ldp_src, ldp_dst = (uint32_t)A.ldp_dst;
+
+  float mx = -INFINITY, den = 0.f, sae = 0.f;
+  f3 acc = {0.f, 0.f, 0.f};
+
+  // scalar state of the current unit
+  int u = uptr[r], u_end = uptr[r + 1];
+  i32x8 d = udesc[u];
+  f32x4 ed[UE];
 #pragma unroll
-  for (int k = 0; k < AG_DEPTH - 1; ++k) {
-    if (k < n_u) {
-      const i32x8 d = dnext;
-      if (k + 1 < n_u) dnext = udesc[u_lo + k + 1];
-      issue_unit<G>(A, u_lo + k, d, ring + k * S::bytes, lane);
+  for (int t = 0; t < UE; ++t) ed[t] = einfo[(int64_t)d[1] + t];  // einfo is padded by UE records
+
+  while (true) {
+    const int i = d[0], nact = d[2] & 0xFF;
+    const bool first = (d[2] >> 8) & 1, last = (d[2] >> 9) & 1;
+    // ---- vector side: Q + 3 x (K, V), unconditional and back to back (absent edges repeat
+    // j0 in the descriptor, so every address is valid; they are masked when folded) ----
+    f3 q = {0.f, 0.f, 0.f}, kk[UE], vv[UE];
+#pragma unroll
+    for (int t = 0; t < UE; ++t) {
+      kk[t] = {0.f, 0.f, 0.f};
+      vv[t] = {0.f, 0.f, 0.f};
     }
-  }
-
-  int slot_c = 0;                 // slot of the unit being consumed
-  int slot_i = AG_DEPTH - 1;      // slot the next issue goes to
-  for (int k = 0; k < n_u; ++k) {
-    // ---- issue unit k + DEPTH - 1 into the slot freed in the previous iteration ----
-    const int ki = k + AG_DEPTH - 1;
-    if (ki < n_u) {
-      const i32x8 d = dnext;
-      if (ki + 1 < n_u) dnext = udesc[u_lo + ki + 1];
-      issue_unit<G>(A, u_lo + ki, d, ring + slot_i * S::bytes, lane);
-      slot_i = slot_i + 1 == AG_DEPTH ? 0 : slot_i + 1;
-    }
-    // ---- wait for unit k: everything but the DMAs of the units issued after it ----
-    const int younger = min(n_u - 1 - k, AG_DEPTH - 1);
-    if (younger >= 2) dma_wait<2 * S::dma_per_unit>();
-    else if (younger == 1) dma_wait<S::dma_per_unit>();
-    else dma_wait<0>();
-
-    // ---- compute unit k from LDS ----
-    const char* sl = ring_ptr + slot_c * S::bytes;
-    slot_c = slot_c + 1 == AG_DEPTH ? 0 : slot_c + 1;
-    const i32x4 dd = *reinterpret_cast<const i32x4*>(sl + SL_DESC);
-    const int i = dd.x, nact = dd.z & 0xFF;
-    const bool first = (dd.z >> 8) & 1, last = (dd.z >> 9) & 1;
-    f32x4 ed[UE];
+    if (active) {
+      q = ld3_nt(qbase + (uint32_t)i * ldp_dst);  // read once; host checked: n * ld < 2^31
 #pragma unroll
-    for (int t = 0; t < UE; ++t) ed[t] = *reinterpret_cast<const f32x4*>(sl + SL_EINFO + 16 * t);
-    const float* qf = reinterpret_cast<const float*>(sl + SL_Q);
-    const float* rows = reinterpret_cast<const float*>(sl + S::rows_off);
-
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int g = half + 2 * s;
-      if (g < G) {
-        GateState z = st[s];
-        if (first) z = {-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* ep = &s_ep[g * GGNN_EDGE_PARAM_ROWS * C + l32];
-        const float q0 = qf[g * C + l32], q1 = qf[g * C + l32 + 32], q2 = qf[g * C + l32 + 64];
-        float sc[UE];
-        float mnew = z.mx;
-#pragma unroll
-        for (int t = 0; t < UE; ++t) {
-          sc[t] = -INFINITY;
-          if (t < nact) {
-            const float* kr = rows + t * (S::row_bytes / 4) + g * 2 * C + l32;
-            const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z, a = ed[t].w;
-            float part = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float kc = kr[32 * c] + ep[32 * c] * rx + ep[C + 32 * c] * ry + ep[2 * C + 32 * c] * rz +
-                               ep[6 * C + 32 * c] * a;
-              part += (c == 0 ? q0 : (c == 1 ? q1 : q2)) * kc;
-            }
-            sc[t] = halfwave_sum(part) * inv_sqrt_c;
-            mnew = fmaxf(mnew, sc[t]);
-          }
-        }
-        // (empty rows have a single unit with nact == 0: nothing to fold, zeros are stored)
-        const float scale = nact > 0 ? __expf(z.mx - mnew) : 1.0f;  // exp(-inf) = 0 on a row's first unit
-        z.den *= scale;
-        z.sae *= scale;
-        z.a0 *= scale;
-        z.a1 *= scale;
-        z.a2 *= scale;
-#pragma unroll
-        for (int t = 0; t < UE; ++t) {
-          if (t < nact) {
-            const float* vr = rows + t * (S::row_bytes / 4) + g * 2 * C + C + l32;
-            const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z;
-            const float pe = __expf(sc[t] - mnew);
-            z.den += pe;
-            z.sae += pe * ed[t].w;
-            z.a0 += pe * fmaxf(vr[0] + ep[3 * C] * rx + ep[4 * C] * ry + ep[5 * C] * rz, 0.f);
-            z.a1 += pe * fmaxf(vr[32] + ep[3 * C + 32] * rx + ep[4 * C + 32] * ry + ep[5 * C + 32] * rz, 0.f);
-            z.a2 += pe * fmaxf(vr[64] + ep[3 * C + 64] * rx + ep[4 * C + 64] * ry + ep[5 * C + 64] * rz, 0.f);
-          }
-        }
-        if (nact > 0) z.mx = mnew;
-        st[s] = z;
-        if (last) {
-          const float inv = 1.0f / (z.den + 1e-16f);  // PyG softmax denominator
-          float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
-          orow[A.a_off + l32] = z.a0 * inv;
-          orow[A.a_off + l32 + 32] = z.a1 * inv;
-          orow[A.a_off + l32 + 64] = z.a2 * inv;
-          if (l32 == 0) {
-            orow[A.sc_off] = z.den * inv;
-            orow[A.sc_off + 1] = z.sae * inv;
-          }
-        }
+      for (int t = 0; t < UE; ++t) {
+        const float* row = kvbase + (uint32_t)d[4 + t] * ldp_src;
+        kk[t] = ld3(row);
+        vv[t] = ld3(row + C);
       }
     }
+    // ---- scalar side for the next unit (same row, or the first unit of this stream's next
+    // row), hidden under the vector round trip above ----
+    bool more = true;
+    int un = u + 1, un_end = u_end;
+    int64_t rn = r;
+    if (un >= u_end) {
+      rn = r + n_streams;
+      if (rn < x_hi) {
+        un = uptr[rn];
+        un_end = uptr[rn + 1];
+      } else {
+        more = false;
+        un = u;
+      }
+    }
+    const i32x8 dn = udesc[un];
+    f32x4 edn[UE];
+#pragma unroll
+    for (int t = 0; t < UE; ++t) edn[t] = einfo[(int64_t)dn[1] + t];
+
+    if (first) {
+      mx = -INFINITY;
+      den = 0.f;
+      sae = 0.f;
+      acc = {0.f, 0.f, 0.f};
+    }
+    if (active && nact > 0) {  // (empty rows have a single unit with nact == 0: zeros are stored)
+      float s[UE];
+      float mnew = mx;
+#pragma unroll
+      for (int t = 0; t < UE; ++t) {
+        s[t] = -INFINITY;
+        if (t < nact) {
+          const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z, a = ed[t].w;
+          const float k0 = kk[t].x + e0a.x * rx + e0a.y * ry + e0a.z * rz + e0b.z * a;
+          const float k1 = kk[t].y + e1a.x * rx + e1a.y * ry + e1a.z * rz + e1b.z * a;
+          const float k2 = kk[t].z + e2a.x * rx + e2a.y * ry + e2a.z * rz + e2b.z * a;
+          s[t] = halfwave_sum(q.x * k0 + q.y * k1 + q.z * k2) * inv_sqrt_c;
+          mnew = fmaxf(mnew, s[t]);
+        }
+      }
+      const float scale = __expf(mx - mnew);  // exp(-inf) = 0 on a row's first unit
+      den *= scale;
+      sae *= scale;
+      acc = {acc.x * scale, acc.y * scale, acc.z * scale};
+#pragma unroll
+      for (int t = 0; t < UE; ++t) {
+        if (t < nact) {
+          const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z;
+          const float pe = __expf(s[t] - mnew);
+          den += pe;
+          sae += pe * ed[t].w;
+          acc.x += pe * fmaxf(vv[t].x + e0a.w * rx + e0b.x * ry + e0b.y * rz, 0.f);
+          acc.y += pe * fmaxf(vv[t].y + e1a.w * rx + e1b.x * ry + e1b.y * rz, 0.f);
+          acc.z += pe * fmaxf(vv[t].z + e2a.w * rx + e2b.x * ry + e2b.y * rz, 0.f);
+        }
+      }
+      mx = mnew;
+    }
+    if (active && last) {
+      const float inv = 1.0f / (den + 1e-16f);  // PyG softmax denominator
+      float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
+      st3_nt(orow + A.a_off + ch, {acc.x * inv, acc.y * inv, acc.z * inv});
+      if ((tid & 31) == 0) {
+        __builtin_nontemporal_store(den * inv, orow + A.sc_off);
+        __builtin_nontemporal_store(sae * inv, orow + A.sc_off + 1);
+      }
+    }
+    if (!more) break;
+    u = un;
+    u_end = un_end;
+    r = rn;
+    d = dn;
+#pragma unroll
+    for (int t = 0; t < UE; ++t) ed[t] = edn[t];
   }
 }
 
@@ -326,25 +291,26 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
   const ggnn_aggregate_args& A = *args;
   if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.edge_params || !A.agg)
     return GGNN_EINVAL;
-  if (!aligned16(A.units) || !aligned16(A.einfo) || !aligned16(A.p_src) || !aligned16(A.p_dst))
-    return GGNN_EINVAL;
+  if (!aligned16(A.units) || !aligned16(A.einfo)) return GGNN_EINVAL;
   if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0) return GGNN_EINVAL;
   const int G = A.n_gates;
   if (G != 1 && G != 3 && G != 4) return GGNN_EINVAL;
   if (A.kv_off < 0 || A.q_off < 0 || A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
-  if ((A.kv_off & 3) || (A.q_off & 3) || (A.ldp_src & 3) || (A.ldp_dst & 3)) return GGNN_EINVAL;  // 16-byte DMA granules
+  if (A.ldp_src <= 0 || A.ldp_dst <= 0 || A.n_src * A.ldp_src >= INT32_MAX || A.n_dst * A.ldp_dst >= INT32_MAX)
+    return GGNN_EINVAL;  // the sweep forms row offsets in 32 bits
   if (A.kv_off + (int64_t)G * 2 * C > A.ldp_src || A.q_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
-  const int64_t want = (A.n_dst + AG_WAVES - 1) / AG_WAVES;  // at least one row per wave
-  const int64_t nblk = want < AG_NUM_CU ? want : AG_NUM_CU;
-  const dim3 grid((unsigned)nblk), block(AG_WAVES * 64);
+  // persistent grid: at least 4 rows per workgroup, at most the resident capacity
+  const int64_t want = (A.n_dst + 3) / 4;
+  const int64_t cap = (int64_t)AG_NUM_CU * AG_BLOCKS_PER_CU;
+  const dim3 grid((unsigned)(want < cap ? want : cap));
   hipStream_t s = (hipStream_t)stream;
   if (G == 4)
-    hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, 0, s, A);
+    hipLaunchKernelGGL(aggregate_kernel<4>, grid, dim3(256), 0, s, A);
   else if (G == 3)
-    hipLaunchKernelGGL(aggregate_kernel<3>, grid, block, 0, s, A);
+    hipLaunchKernelGGL(aggregate_kernel<3>, grid, dim3(256), 0, s, A);
   else
-    hipLaunchKernelGGL(aggregate_kernel<1>, grid, block, 0, s, A);
+    hipLaunchKernelGGL(aggregate_kernel<1>, grid, dim3(256), 0, s, A);
   return launch_status();
 }

@@ -40,4 +40,15 @@ __device__ __forceinline__ void st3(float* __restrict__ p, f3 v) {
   p[2] = v.z;
 }
 
+// Streaming (read-once / write-once) variants: the `nt` hint keeps these rows from evicting
+// the gathered rows that ARE re-read out of the XCD's L2.
+__device__ __forceinline__ f3 ld3_nt(const float* __restrict__ p) {
+  return {__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2)};
+}
+__device__ __forceinline__ void st3_nt(float* __restrict__ p, f3 v) {
+  __builtin_nontemporal_store(v.x, p);
+  __builtin_nontemporal_store(v.y, p + 1);
+  __builtin_nontemporal_store(v.z, p + 2);
+}
+
 }  // namespace ggnn
