@@ -1,5 +1,5 @@
 // Gate GEMM + LSTM cell update on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
-// For a block of 64 nodes and every gate g:
+// For a block of 32 nodes and every gate g:
 //   pre[g] = agg[:, g, 0:Ka] . W2[g]^T + skip[g]
 // W2[g] packs, per incoming edge type, lin_l2.weight (periodGATconv.py:218) and the two
 // rank-1 columns (lin_l2.bias x sum alpha, lin_edge.weight x sum alpha*a, :231-235); skip[g]
@@ -15,12 +15,12 @@
 
 namespace ggnn {
 
-constexpr int GT_BM = 64;    // nodes per workgroup
+constexpr int GT_BM = 32;    // nodes per workgroup (52 KB of LDS -> three workgroups per CU)
 constexpr int GT_KC = 100;   // K chunk staged per pass (Ka = 196 -> 100 + 96, Ka = 100 -> 100)
 constexpr int GT_LD = GT_KC + 2;
 
 template <int G, int MODE>
-__global__ __launch_bounds__(256, 2) void gates_kernel(const ggnn_epilogue_args A) {
+__global__ __launch_bounds__(256, 3) void gates_kernel(const ggnn_epilogue_args A) {
   __shared__ float s_a[GT_BM * GT_LD];
   __shared__ float s_w[C * GT_LD];
 
@@ -30,16 +30,14 @@ __global__ __launch_bounds__(256, 2) void gates_kernel(const ggnn_epilogue_args 
   const int64_t ld_agg = (int64_t)G * Ka;
 
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave & 1, wn = wave >> 1;  // wave tile: 16 nodes x 48 channels
   const int lr = lane & 15, lq = lane >> 4;
 
-  f32x4 acc[G][3][2];
+  f32x4 acc[G][3];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[g][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 3; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -67,20 +65,16 @@ __global__ __launch_bounds__(256, 2) void gates_kernel(const ggnn_epilogue_args 
       }
       __syncthreads();
       const float* pw = &s_w[(wn * 48 + lr) * ld + lq];
-      const float* px = &s_a[(wm * 32 + lr) * ld + lq];
+      const float* px = &s_a[(wm * 16 + lr) * ld + lq];
 #pragma unroll 2
       for (int k0 = 0; k0 < kc; k0 += 4) {
-        float wf[3], xf[2];
+        float wf[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) wf[a] = pw[a * 16 * ld + k0];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) xf[b] = px[b * 16 * ld + k0];
+        const float xf = px[k0];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[g][a][b] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a], xf[b], acc[g][a][b], 0, 0, 0);
+          acc[g][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a], xf, acc[g][a], 0, 0, 0);
       }
     }
   }
@@ -89,15 +83,14 @@ __global__ __launch_bounds__(256, 2) void gates_kernel(const ggnn_epilogue_args 
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int n = wn * 48 + a * 16 + 4 * lq;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t m = m0 + wm * 32 + b * 16 + lr;
+    {
+      const int64_t m = m0 + wm * 16 + lr;
       if (m >= A.N) continue;
       const float* srow = A.p_dst + m * A.ldp + A.s_off + n;
       f32x4 pre[G];
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        pre[g] = acc[g][a][b] + *reinterpret_cast<const f32x4*>(srow + g * C);
+        pre[g] = acc[g][a] + *reinterpret_cast<const f32x4*>(srow + g * C);
       if (MODE == GGNN_MODE_RAW) {
 #pragma unroll
         for (int g = 0; g < G; ++g)

@@ -2,9 +2,21 @@
 //   out[M, ncols] = [X[:, :F] | H] . Wp^T + bias
 // One launch per node type and cell produces, for every gate and edge type, the per-node
 // key/value (as source), query (as destination) and summed-skip pre-activations that the
-// reference computes per EDGE (periodGATconv.py:216-218, :186).  K = F + 96 <= 108 is so
-// short that a workgroup keeps its whole 64-node x K input tile and 96-column x K weight
-// tile in LDS (70 KB -> two workgroups per CU) and runs one barrier-free MFMA sweep.
+// reference computes per EDGE (periodGATconv.py:216-218, :186).
+//
+// K = roundup4(F) + 96 <= 108 is short and M is long, so the kernel is WEIGHT-STATIONARY and
+// persistent: one 8-wave workgroup per CU keeps a 96-column x K weight tile in LDS for its
+// whole life (read-only after the prologue), and every WAVE streams its own 16-node input
+// tiles past it through a wave-private LDS stage.  Nothing is shared between waves except
+// the constant weight tile, so the main loop has NO workgroup barrier: two waves per SIMD
+// run decoupled and one wave's staging / epilogue hides under the other's MFMA sweep:
+//   * while the sweep of tile t runs (26 k-steps x 6 MFMAs), the global loads of tile t+1
+//     are in flight into registers (6 x 16 B + <= 3 x 4 B per lane); they are written to the
+//     same LDS stage right after the sweep (LDS accesses of one wave execute in order);
+//   * the sweep is fully unrolled (K is a template parameter) so operand fragments are read
+//     from LDS well ahead of the MFMA that consumes them;
+//   * the 16-byte output stores of tile t drain while tile t+1 is swept.
+// The grid is (ncols / 96) column tiles x as many row splits as fit 256 CUs.
 //
 // Orientation: the WEIGHT tile is the MFMA A operand and the NODE tile the B operand, so
 // that each lane ends up with 4 consecutive output columns of one node -> 16-byte stores.
@@ -17,93 +29,119 @@
 
 namespace ggnn {
 
-constexpr int PJ_BM = 64;       // nodes per workgroup
-constexpr int PJ_BN = 96;       // output columns per workgroup
-constexpr int PJ_KP_MAX = 108;  // roundup4(F <= 12) + 96
-constexpr int PJ_LD_MAX = PJ_KP_MAX + 2;
+constexpr int PJ_BM = 16;      // nodes per wave tile
+constexpr int PJ_BN = 96;      // output columns per workgroup
+constexpr int PJ_WAVES = 8;    // waves per workgroup (two per SIMD)
+constexpr int PJ_NUM_CU = 256;
 
-__global__ __launch_bounds__(256, 2) void project_kernel(
-    const float* __restrict__ X, int64_t ldx, int F, int Fp, const float* __restrict__ H,
-    int64_t ldh, int K2, const float* __restrict__ Wp, const float* __restrict__ bias, int64_t M,
-    int ncols, float* __restrict__ out, int64_t ldo) {
-  __shared__ float s_x[PJ_BM * PJ_LD_MAX];
-  __shared__ float s_w[PJ_BN * PJ_LD_MAX];
+template <int FP, int K2>
+__global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
+    const float* __restrict__ X, int64_t ldx, int F, const float* __restrict__ H, int64_t ldh,
+    const float* __restrict__ Wp, const float* __restrict__ bias, int64_t M, int ncols,
+    float* __restrict__ out, int64_t ldo, int m_splits) {
+  constexpr int KP = FP + K2;
+  constexpr int LD = KP + 2;
+  constexpr int NVH = K2 > 0 ? K2 / 4 : 1;                   // 16-byte pieces per hidden row (24)
+  constexpr int NH = K2 > 0 ? (PJ_BM * NVH) / 64 : 0;        // hidden pieces per lane per tile (6 or 0)
+  constexpr int NX = (PJ_BM * FP) / 64;                      // feature floats per lane per tile (1..3)
+  static_assert((K2 == 0 || (PJ_BM * NVH) % 64 == 0) && (PJ_BM * FP) % 64 == 0, "tile / lane mismatch");
+  __shared__ float s_w[PJ_BN * LD];
+  __shared__ float s_x[PJ_WAVES][PJ_BM * LD];
 
-  const int Kp = Fp + K2;
-  const int ld = Kp + 2;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb_n = ncols / PJ_BN;
-  const int bn = blockIdx.x % nb_n;
-  const int64_t bm = blockIdx.x / nb_n;
+  const int bn = blockIdx.x % nb_n, ms = blockIdx.x / nb_n;
   const int n0 = bn * PJ_BN;
-  const int64_t m0 = bm * PJ_BM;
 
-  // ---- stage the node tile: feature columns (scalar, F is 8 or 11) then hidden (16 B) ----
-  for (int idx = tid; idx < PJ_BM * Fp; idx += 256) {
-    const int r = idx / Fp, k = idx - r * Fp;
-    const int64_t m = m0 + r;
-    s_x[r * ld + k] = (m < M && k < F) ? X[m * ldx + k] : 0.0f;
-  }
-  if (K2 > 0) {
-    const int nv = K2 >> 2;
-    for (int idx = tid; idx < PJ_BM * nv; idx += 256) {
-      const int r = idx / nv, c4 = idx - r * nv;
-      const int64_t m = m0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < M) v = *reinterpret_cast<const f32x4*>(H + m * ldh + 4 * c4);
-      float2* dst = reinterpret_cast<float2*>(&s_x[r * ld + Fp + 4 * c4]);
-      dst[0] = make_float2(v.x, v.y);
-      dst[1] = make_float2(v.z, v.w);
-    }
-  }
-  // ---- stage the weight tile (rows are Kp floats, 16-byte aligned, zero padded) ----
+  // ---- prologue: the weight tile, shared and constant from here on ----
   {
-    const int nv = Kp >> 2;
-    for (int idx = tid; idx < PJ_BN * nv; idx += 256) {
+    constexpr int nv = KP / 4;
+    for (int idx = tid; idx < PJ_BN * nv; idx += PJ_WAVES * 64) {
       const int r = idx / nv, c4 = idx - r * nv;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Wp + (int64_t)(n0 + r) * Kp + 4 * c4);
-      float2* dst = reinterpret_cast<float2*>(&s_w[r * ld + 4 * c4]);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Wp + (int64_t)(n0 + r) * KP + 4 * c4);
+      float2* dst = reinterpret_cast<float2*>(&s_w[r * LD + 4 * c4]);
       dst[0] = make_float2(v.x, v.y);
       dst[1] = make_float2(v.z, v.w);
     }
   }
-  __syncthreads();
+  __syncthreads();  // the only workgroup barrier
 
-  // ---- MFMA sweep: wave (wm, wn) owns 32 nodes x 48 columns = 2 x 3 tiles of 16x16 ----
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  // 16-node tiles of this workgroup's row split, dealt round-robin to its waves
+  const int64_t n_mt = (M + PJ_BM - 1) / PJ_BM;
+  const int64_t per = (n_mt + m_splits - 1) / m_splits;
+  const int64_t mt_lo = ms * per + wave, mt_hi = min(n_mt, (ms + 1) * per);
+  if (mt_lo >= mt_hi) return;
+  float* sx = s_x[wave];
+
+  // ---- global -> register stage of one node tile (issued early, written to LDS late) ----
+  f32x4 rh[NH > 0 ? NH : 1];
+  float rx[NX];
+  auto load_tile = [&](int64_t mt) {
+    const int64_t m0 = mt * PJ_BM;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = lane + it * 64, r = idx / FP, k = idx - r * FP;
+      const int64_t m = m0 + r;
+      rx[it] = (m < M && k < F) ? X[m * ldx + k] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = lane + it * 64, r = idx / NVH, c4 = idx - r * NVH;
+      const int64_t m = m0 + r;
+      rh[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) rh[it] = *reinterpret_cast<const f32x4*>(H + m * ldh + 4 * c4);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = lane + it * 64, r = idx / FP, k = idx - r * FP;
+      sx[r * LD + k] = rx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = lane + it * 64, r = idx / NVH, c4 = idx - r * NVH;
+      float2* dst = reinterpret_cast<float2*>(&sx[r * LD + FP + 4 * c4]);
+      dst[0] = make_float2(rh[it].x, rh[it].y);
+      dst[1] = make_float2(rh[it].z, rh[it].w);
+    }
+  };
+
   const int lr = lane & 15, lq = lane >> 4;
-  const float* pw = &s_w[(wn * 48 + lr) * ld + lq];
-  const float* px = &s_x[(wm * 32 + lr) * ld + lq];
-  f32x4 acc[3][2];
+  const float* pw = &s_w[lr * LD + lq];
+  const float* px = &sx[lr * LD + lq];
+  f32x4 bv[6];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 6; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + n0 + a * 16 + 4 * lq);
 
-#pragma unroll 2
-  for (int k0 = 0; k0 < Kp; k0 += 4) {
-    float wf[3], xf[2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) wf[a] = pw[a * 16 * ld + k0];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) xf[b] = px[b * 16 * ld + k0];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a], xf[b], acc[a][b], 0, 0, 0);
-  }
+  load_tile(mt_lo);
+  store_tile();
+  for (int64_t mt = mt_lo; mt < mt_hi; mt += PJ_WAVES) {
+    const bool has_next = mt + PJ_WAVES < mt_hi;
+    if (has_next) load_tile(mt + PJ_WAVES);  // in flight during the sweep below
+    __builtin_amdgcn_wave_barrier();         // (compiler only) keep the stage write above the reads
 
-  // ---- epilogue: + bias, 16-byte stores (4 consecutive columns of one node per lane) ----
+    // ---- sweep: 16 nodes x 96 columns = 6 accumulator tiles, K fully unrolled ----
+    f32x4 acc[6];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int n = n0 + wn * 48 + a * 16 + 4 * lq;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+    for (int a = 0; a < 6; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t m = m0 + wm * 32 + b * 16 + lr;
-      if (m < M) *reinterpret_cast<f32x4*>(out + m * ldo + n) = acc[a][b] + bv;
+    for (int k0 = 0; k0 < KP; k0 += 4) {
+      const float xf = px[k0];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[a * 16 * LD + k0], xf, acc[a], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (has_next) store_tile();  // same wave, in-order LDS: lands after the reads above
+
+    // ---- epilogue: + bias, 16-byte stores (4 consecutive columns of one node per lane) ----
+    const int64_t m = mt * PJ_BM + lr;
+    if (m < M) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        *reinterpret_cast<f32x4*>(out + m * ldo + n0 + a * 16 + 4 * lq) = acc[a] + bv[a];
     }
   }
 }
@@ -121,9 +159,27 @@ extern "C" int ggnn_project(const float* X, int64_t ldx, int F, const float* H, 
   if (ncols <= 0 || ncols % PJ_BN != 0 || ldo < ncols || (ldo & 3)) return GGNN_EINVAL;
   if (!aligned16(Wp) || !aligned16(bias) || !aligned16(out)) return GGNN_EINVAL;
   const int Fp = (F + 3) & ~3;
-  const int64_t nblk = (int64_t)(ncols / PJ_BN) * ((M + PJ_BM - 1) / PJ_BM);
-  if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  hipLaunchKernelGGL(project_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, X,
-                     ldx, F, Fp, H, ldh, k2, Wp, bias, M, ncols, out, ldo);
+  const int nb_n = ncols / PJ_BN;
+  const int64_t n_mt = (M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
+  // decoder (K ~ 104): MFMA-bound, one 95 KB workgroup per CU; encoder (K <= 12): store-bound
+  // with a tiny LDS footprint, so two workgroups per CU keep more stores in flight
+  int64_t m_splits = (k2 ? PJ_NUM_CU : 2 * PJ_NUM_CU) / nb_n;
+  if (m_splits < 1) m_splits = 1;
+  if (m_splits > n_mt) m_splits = n_mt;
+  const dim3 grid((unsigned)(nb_n * m_splits)), block(PJ_WAVES * 64);
+  hipStream_t s = (hipStream_t)stream;
+#define GGNN_PJ_LAUNCH(FP_, K2_)                                                                \
+  hipLaunchKernelGGL((project_kernel<FP_, K2_>), grid, block, 0, s, X, ldx, F, H, ldh, Wp, bias, \
+                     M, ncols, out, ldo, (int)m_splits)
+  if (k2 == 0) {
+    if (Fp == 4) GGNN_PJ_LAUNCH(4, 0);
+    else if (Fp == 8) GGNN_PJ_LAUNCH(8, 0);
+    else GGNN_PJ_LAUNCH(12, 0);
+  } else {
+    if (Fp == 4) GGNN_PJ_LAUNCH(4, 96);
+    else if (Fp == 8) GGNN_PJ_LAUNCH(8, 96);
+    else GGNN_PJ_LAUNCH(12, 96);
+  }
+#undef GGNN_PJ_LAUNCH
   return launch_status();
 }
