@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libggnn.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GGNN_ABI_VERSION = 3
 GGNN_UNIT_EDGES = 3

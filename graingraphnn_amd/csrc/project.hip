@@ -81,16 +81,17 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
     const int64_t m0 = mt * PJ_BM;
 #pragma unroll
     for (int it = 0; it < NX; ++it) {
-      const int idx = lane + it * 64, r = idx / FP, k = idx - r * FP;
-      const int64_t m = m0 + r;
-      rx[it] = (m < M && k < F) ? X[m * ldx + k] : 0.0f;
+      // unconditional (clamped) loads: rows past M are never stored, feature columns past F
+      // meet zero weight columns -- a load under `if` would drag a wait to the branch merge
+      const int idx = lane + it * 64, r = idx / FP, k = min(idx - r * FP, F - 1);
+      const int64_t m = min(m0 + r, M - 1);
+      rx[it] = X[m * ldx + k];
     }
 #pragma unroll
     for (int it = 0; it < NH; ++it) {
       const int idx = lane + it * 64, r = idx / NVH, c4 = idx - r * NVH;
-      const int64_t m = m0 + r;
-      rh[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) rh[it] = *reinterpret_cast<const f32x4*>(H + m * ldh + 4 * c4);
+      const int64_t m = min(m0 + r, M - 1);
+      rh[it] = *reinterpret_cast<const f32x4*>(H + m * ldh + 4 * c4);
     }
   };
   auto store_tile = [&]() {
