@@ -11,50 +11,55 @@
 // Structure (same operand orientation as project.hip: weight tile = MFMA A operand, node
 // tile = B operand, so a lane ends with 4 consecutive channels of one node; LDS rows are
 // (kc + 2) floats apart => conflict-free ds_read_b32):
-//   * a workgroup of W waves (4..8, chosen so that one round of workgroups covers the chip)
-//     owns 16 x W nodes; every wave keeps the accumulators of its own 16 nodes x 96 channels
-//     for ALL gates in registers (G x 6 tiles), so the LSTM update needs no exchange;
-//   * the K dimension is cut into passes (gate, <=100 columns); the 96 x kc weight chunk of a
-//     pass is shared through a double-buffered LDS tile, the 16 x kc node chunk is
-//     wave-private.  While a pass is swept (150 MFMAs per wave) the next pass's chunks are in
-//     flight into registers and are written to LDS right after the sweep: one workgroup
-//     barrier per pass, no exposed global latency after the prologue.
+//   * a wave owns 16 nodes x 32 channels and keeps their accumulators for ALL gates in
+//     registers (G x 2 tiles), so the LSTM update needs no exchange; three waves share a
+//     16-node row group;
+//   * ONE workgroup per CU and ONE round of workgroups: a workgroup takes NG = ceil(N / 16 /
+//     256) row groups (20 000 joints -> 5 groups = 15 waves, 250 workgroups; 10 000 grains ->
+//     3 groups = 9 waves, 209 workgroups).  Rounding the grid to the CU count matters more
+//     than anything else here: 313 equal workgroups on 256 CUs take as long as 512;
+//   * the K dimension is cut into passes (gate, <= 100 columns), fully unrolled; the 96 x kc
+//     weight chunk and the row groups' 16 x kc node chunks are double-buffered in LDS: while
+//     a pass is swept (50 MFMAs per wave) the next pass's chunks fly into registers and are
+//     written to the other buffer after the sweep -- one workgroup barrier per pass.  All
+//     global loads are unconditional (clamped indices; a load under `if` drags a wait to the
+//     branch merge and serialises the stage).
 #include "common.h"
 
 namespace ggnn {
 
-constexpr int GT_BM = 16;    // nodes per wave
-constexpr int GT_MAXW = 8;   // waves per workgroup (upper bound)
-constexpr int GT_MINW = 4;   // ... and lower bound (sizes the weight staging registers)
-constexpr int GT_KC = 100;   // K chunk per pass (Ka = 196 -> 100 + 96, Ka = 100 -> 100)
+constexpr int GT_BM = 16;     // nodes per row group (three waves per group)
+constexpr int GT_MAXG = 5;    // row groups per workgroup, upper bound (15 waves)
+constexpr int GT_MING = 2;    // ... lower bound (sizes the weight staging registers)
+constexpr int GT_KC = 100;    // K chunk per pass (Ka = 196 -> 100 + 96, Ka = 100 -> 100)
 constexpr int GT_LD = GT_KC + 2;
 constexpr int GT_NUM_CU = 256;
 
 template <int G, int MODE, int KA>
-__global__ __launch_bounds__(GT_MAXW * 64, 1) void gates_kernel(const ggnn_epilogue_args A) {
+__global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epilogue_args A) {
   __shared__ float s_w[2][C * GT_LD];
-  __shared__ float s_a[GT_MAXW][GT_BM * GT_LD];
+  __shared__ float s_a[2][GT_MAXG][GT_BM * GT_LD];
   constexpr int NCH = (KA + GT_KC - 1) / GT_KC;  // K chunks per gate (2 for Ka = 196, 1 for 100)
   constexpr int NPASS = G * NCH;
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave / 3, third = wave - 3 * rg;  // row group, channel third
+  const int ng = nthr / 192;                        // row groups in this workgroup
   constexpr int64_t ld_agg = (int64_t)G * KA;
-  const int64_t m0 = ((int64_t)blockIdx.x * (nthr >> 6) + wave) * GT_BM;  // first node of this wave
+  const int64_t m0 = ((int64_t)blockIdx.x * ng + rg) * GT_BM;  // first node of this row group
   const int lr = lane & 15, lq = lane >> 4;
-  float* sa = s_a[wave];
+  const int t192 = tid - rg * 192;  // index inside the row group's three waves
 
-  // Register stage of the next pass: node chunk (<= 7 pieces per lane) and weight chunk
-  // (96 x 25 pieces over the workgroup: <= 10 per lane at 4 waves, 5 at 8).  Every load is
-  // UNCONDITIONAL (indices clamped into range; only the LDS writes are predicated), so all of
-  // them are in flight together -- a load under `if` drags a wait to the branch merge.
-  constexpr int NA = (GT_BM * (GT_KC / 4) + 63) / 64;  // 7
-  constexpr int NW = (C * (GT_KC / 4) + GT_MINW * 64 - 1) / (GT_MINW * 64);  // 10
+  // register stage of the next pass: the row group's node chunk (16 x 25 pieces over 192
+  // lanes) and the weight chunk (96 x 25 pieces over the workgroup: 7 per lane at 2 groups)
+  constexpr int NA = (GT_BM * (GT_KC / 4) + 191) / 192;                      // 3
+  constexpr int NW = (C * (GT_KC / 4) + GT_MING * 192 - 1) / (GT_MING * 192);  // 7
   f32x4 ra[NA], rw[NW];
   auto load_pass = [&](int g, int kb, int kc) {
     const int nv = kc >> 2;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-      const int idx = min(lane + it * 64, GT_BM * nv - 1), r = idx / nv, c4 = idx - r * nv;
+      const int idx = min(t192 + it * 192, GT_BM * nv - 1), r = idx / nv, c4 = idx - r * nv;
       const int64_t m = min(m0 + r, A.N - 1);
       ra[it] = *reinterpret_cast<const f32x4*>(A.agg + m * ld_agg + g * KA + kb + 4 * c4);
     }
@@ -64,12 +69,13 @@ __global__ __launch_bounds__(GT_MAXW * 64, 1) void gates_kernel(const ggnn_epilo
       rw[it] = *reinterpret_cast<const f32x4*>(A.w2 + ((int64_t)g * C + r) * KA + kb + 4 * c4);
     }
   };
-  auto store_pass = [&](int p, int kc) {
+  auto store_pass = [&](int buf, int kc) {
     const int nv = kc >> 2, ld = kc + 2;
-    float* sw = s_w[p & 1];
+    float* sa = s_a[buf][rg];
+    float* sw = s_w[buf];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-      const int idx = lane + it * 64, r = idx / nv, c4 = idx - r * nv;
+      const int idx = t192 + it * 192, r = idx / nv, c4 = idx - r * nv;
       if (idx < GT_BM * nv) {
         float2* dst = reinterpret_cast<float2*>(&sa[r * ld + 4 * c4]);
         dst[0] = make_float2(ra[it].x, ra[it].y);
@@ -89,16 +95,16 @@ __global__ __launch_bounds__(GT_MAXW * 64, 1) void gates_kernel(const ggnn_epilo
   // chunk c of a gate covers columns [c * 100, min(KA, c * 100 + 100))
   auto kc_of = [](int c) { return (c + 1) * GT_KC <= KA ? GT_KC : KA - c * GT_KC; };
 
-  f32x4 acc[G][6];
+  f32x4 acc[G][2];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 2; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_pass(0, 0, kc_of(0));
   store_pass(0, kc_of(0));
   __syncthreads();
-  // passes are fully unrolled: gate index, chunk width and every stride are compile-time
+  // passes are fully unrolled: gate index, chunk width, buffer and every stride are compile-time
 #pragma unroll
   for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -108,30 +114,26 @@ __global__ __launch_bounds__(GT_MAXW * 64, 1) void gates_kernel(const ggnn_epilo
       const bool has_next = p + 1 < NPASS;
       const int gn = (p + 1) / NCH, cn = (p + 1) % NCH;
       if (has_next) load_pass(gn, cn * GT_KC, kc_of(cn));  // in flight during the sweep below
-      const float* pw = &s_w[p & 1][lr * ld + lq];
-      const float* px = &sa[lr * ld + lq];
-#ifndef GT_VAR_NO_MFMA
+      const float* pw = &s_w[p & 1][(third * 32 + lr) * ld + lq];
+      const float* px = &s_a[p & 1][rg][lr * ld + lq];
 #pragma unroll 5
       for (int k0 = 0; k0 < kc; k0 += 4) {
         const float xf = px[k0];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int a = 0; a < 2; ++a)
           acc[g][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[a * 16 * ld + k0], xf, acc[g][a], 0, 0, 0);
       }
-#else
-      acc[g][0][0] += pw[0] + px[0];
-#endif
-      if (has_next) store_pass(p + 1, kc_of(cn));  // node chunk: same wave, in-order LDS; weights: other buffer
+      if (has_next) store_pass((p + 1) & 1, kc_of(cn));  // the other buffer: last read in pass p - 1
       __syncthreads();
     }
   }
 
-  // ---- epilogue: lane holds channels n..n+3 (six times) of node m for every gate ----
+  // ---- epilogue: lane holds channels n..n+3 (twice) of node m for every gate ----
   const int64_t m = m0 + lr;
   if (m >= A.N) return;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const int n = a * 16 + 4 * lq;
+  for (int a = 0; a < 2; ++a) {
+    const int n = third * 32 + a * 16 + 4 * lq;
     const float* srow = A.p_dst + m * A.ldp + A.s_off + n;
     f32x4 pre[G];
 #pragma unroll
@@ -148,18 +150,13 @@ __global__ __launch_bounds__(GT_MAXW * 64, 1) void gates_kernel(const ggnn_epilo
       f32x4 hn, cn;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#ifdef GT_VAR_NO_LSTM
-        cn[r] = pre[GI][r] + pre[GC][r] + cold[r];
-        hn[r] = pre[GO][r] + pre[GF < G ? GF : 0][r];
-        continue;
-#endif
         const float ig = sigmoidf_(pre[GI][r]);
-        const float tg = tanhf(pre[GC][r]);
+        const float tg = tanhf_(pre[GC][r]);
         float cv = ig * tg;
         if (MODE == GGNN_MODE_LSTM) cv = sigmoidf_(pre[GF < G ? GF : 0][r]) * cold[r] + cv;
         const float og = sigmoidf_(pre[GO][r]);
         cn[r] = cv;
-        hn[r] = og * tanhf(cv);
+        hn[r] = og * tanhf_(cv);
       }
       *reinterpret_cast<f32x4*>(A.c_out + m * C + n) = cn;
       *reinterpret_cast<f32x4*>(A.h_out + m * C + n) = hn;
@@ -178,16 +175,13 @@ extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t 
   const int G = A.n_gates;
   if (A.s_off < 0 || (A.s_off & 3) || (A.ldp & 3) || A.s_off + (int64_t)G * C > A.ldp) return GGNN_EINVAL;
   if (!aligned16(A.agg) || !aligned16(A.w2) || !aligned16(A.p_dst)) return GGNN_EINVAL;
-  // waves per workgroup: as few as cover the chip in one round of workgroups (4..8)
+  // row groups per workgroup: one round of workgroups, at most one per CU (2..5 groups)
   const int64_t n16 = (A.N + GT_BM - 1) / GT_BM;
-  int64_t W = (n16 + GT_NUM_CU - 1) / GT_NUM_CU;
-  W = W < GT_MINW ? GT_MINW : (W > GT_MAXW ? GT_MAXW : W);
-#ifdef GT_VAR_W
-  W = GT_VAR_W;
-#endif
-  const int64_t nblk = (n16 + W - 1) / W;
+  int64_t ng = (n16 + GT_NUM_CU - 1) / GT_NUM_CU;
+  ng = ng < GT_MING ? GT_MING : (ng > GT_MAXG ? GT_MAXG : ng);
+  const int64_t nblk = (n16 + ng - 1) / ng;
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  const dim3 grid((unsigned)nblk), block((unsigned)(64 * W));
+  const dim3 grid((unsigned)nblk), block((unsigned)(192 * ng));
   hipStream_t s = (hipStream_t)stream;
   if (A.Ka != 196 && A.Ka != 100) return GGNN_EINVAL;  // two / one incoming edge types (packing.py)
   const bool wide = A.Ka == 196;
