@@ -75,15 +75,18 @@ class EventTimedBackend:
 
 
 def measure_roofline(ro, n_steps):
-    """Average duration of aggregate_kernel<4> launches inside real rollout steps."""
+    """Average duration of aggregate_kernel<4> launches inside real rollout steps (eager
+    launches, regressor and classifier serialised so that no other kernel shares the chip
+    with the launch being timed)."""
     timed = EventTimedBackend(ro.be)
-    ro.be = timed
+    ro.be, side = timed, ro._side
+    ro._side = None
     try:
         for _ in range(n_steps):
             ro._enqueue_step()
         torch.cuda.synchronize()
     finally:
-        ro.be = timed.inner
+        ro.be, ro._side = timed.inner, side
     ms = [a.elapsed_time(b) for a, b in timed.events]
     nj, ng = ro.n_nodes["joint"], ro.n_nodes["grain"]
     E = {et: ro.graph.edge_index[et].size(1) for et in EDGE_TYPES}
@@ -126,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,7 +150,7 @@ def main():
     if rank:
         xp = synthetic.perturbed_copy(inputs[0], 1e-4, 1000 + rank)
         X = {k: torch.from_numpy(v).to(device) for k, v in xp.items()}
-    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph)
+    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial)
 
     for _ in range(args.warmup):
         ro.step()
@@ -187,7 +191,7 @@ def main():
             "config": {"workload": "cfg3: synthetic periodic honeycomb, 10000 grains / 20000 junctions / "
                                    "60000 edges per type, fold 10, static topology, R+C forward + update + "
                                    "edge refresh per step, weights RandomState(0) x0.3",
-                       "replicas": world, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "replicas": world, "launch": ("eager" if args.no_graph else "hipGraph replay") + (", R|C serial" if args.serial else ", R|C on two streams"),
                        "results_finite": finite},
             "roofline": roof,
         }

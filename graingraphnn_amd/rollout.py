@@ -26,7 +26,7 @@ ET_JJ = ("joint", "connect", "joint")
 
 class GrainRollout:
     def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
-                 edge_attr_dict, span: int, use_graph: bool = False):
+                 edge_attr_dict, span: int, use_graph: bool = False, concurrent: bool = True):
         self.be = default_backend()
         self.rmodel, self.cmodel = rmodel, cmodel
         self.x = {nt: x_dict[nt] for nt in NODE_TYPES}  # mutated in place, like the reference
@@ -64,6 +64,10 @@ class GrainRollout:
         }
         self._tmp = torch.empty(nj, 8, **f32)
         self.einfo = alloc_einfo(self.graph, dev)
+        # the regressor and the classifier are independent given (x, edge geometry): run them
+        # on two HIP streams so one model's launch tails overlap the other's kernels
+        self.concurrent = concurrent
+        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if concurrent else None
         self.steps_done = 0
         self._graph_exec = None
         if use_graph:
@@ -74,14 +78,30 @@ class GrainRollout:
         be, x, ea, p = self.be, self.x, self.edge_attr, self.pred
         # edge geometry once per step, shared by both models and all four cells
         einfo = prepare_edges(be, self.graph, x, ea, self.einfo)
-        enc, dec = self.packed["R"]
-        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
-        be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
-                           p["joint"], p["grain"], p["grain_area"])
-        enc, dec = self.packed["C"]
-        h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo)
-        be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
-                            self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+
+        def regressor():
+            enc, dec = self.packed["R"]
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
+            be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
+                               p["joint"], p["grain"], p["grain_area"])
+
+        def classifier():
+            enc, dec = self.packed["C"]
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo)
+            be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+
+        if self._side is None:
+            regressor()
+            classifier()
+        else:
+            main = torch.cuda.current_stream()
+            for st, fn in zip(self._side, (regressor, classifier)):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    fn()
+            for st in self._side:
+                main.wait_stream(st)
         be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
         be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
                         [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et]) for et in EDGE_TYPES])

@@ -178,17 +178,17 @@ def test_forward_golden(tag, seed, scale):
     assert gs["active_grains"].numel() == x["grain"].shape[0]
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph,concurrent", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("tag,seed,scale", CASES)
 @torch.no_grad()
-def test_rollout_golden(tag, seed, scale, use_graph):
+def test_rollout_golden(tag, seed, scale, use_graph, concurrent):
     from graingraphnn_amd import GrainRollout
     x, ei, ea = _inputs(tag)
     g = golden(tag)
     n_steps, span = int(g["meta"][2]), int(g["meta"][3])
     R, Cm = product_models(seed, scale, DEV)
     X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
-    ro = GrainRollout(R, Cm, X, EI, EA, span, use_graph=use_graph)
+    ro = GrainRollout(R, Cm, X, EI, EA, span, use_graph=use_graph, concurrent=concurrent)
     for step in range(1, n_steps + 1):
         pred = ro.step()
         if step == 1:
