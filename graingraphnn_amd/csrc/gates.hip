@@ -30,7 +30,7 @@ namespace ggnn {
 
 constexpr int GT_BM = 16;     // nodes per row group (three waves per group)
 constexpr int GT_MAXG = 5;    // row groups per workgroup, upper bound (15 waves)
-constexpr int GT_MING = 2;    // ... lower bound (sizes the weight staging registers)
+constexpr int GT_MING = 3;    // ... lower bound (sizes the weight staging registers: 5 pieces per lane)
 constexpr int GT_KC = 100;    // K chunk per pass (Ka = 196 -> 100 + 96, Ka = 100 -> 100)
 constexpr int GT_LD = GT_KC + 2;
 constexpr int GT_NUM_CU = 256;
@@ -95,11 +95,24 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
   // chunk c of a gate covers columns [c * 100, min(KA, c * 100 + 100))
   auto kc_of = [](int c) { return (c + 1) * GT_KC <= KA ? GT_KC : KA - c * GT_KC; };
 
+  // The accumulators START from the skip / bias term written by ggnn_project (pre = skip +
+  // agg . W2^T): its loads fly together with the first chunk's, and the epilogue has nothing
+  // left to fetch but c.
+  const int64_t m = m0 + lr, m_c = min(m, A.N - 1);
   f32x4 acc[G][2];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 2; ++a)
+      acc[g][a] = *reinterpret_cast<const f32x4*>(A.p_dst + m_c * A.ldp + A.s_off + g * C + third * 32 +
+                                                  a * 16 + 4 * lq);
+  f32x4 cold[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    cold[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (MODE == GGNN_MODE_LSTM)
+      cold[a] = *reinterpret_cast<const f32x4*>(A.c_in + m_c * C + third * 32 + a * 16 + 4 * lq);
+  }
 
   load_pass(0, 0, kc_of(0));
   store_pass(0, kc_of(0));
@@ -113,9 +126,13 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
       const int kc = kc_of(c), ld = kc + 2;
       const bool has_next = p + 1 < NPASS;
       const int gn = (p + 1) / NCH, cn = (p + 1) % NCH;
+#ifndef GT_VAR_NO_STAGE
       if (has_next) load_pass(gn, cn * GT_KC, kc_of(cn));  // in flight during the sweep below
+#endif
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads above the sweep (hipcc sinks them otherwise)
       const float* pw = &s_w[p & 1][(third * 32 + lr) * ld + lq];
       const float* px = &s_a[p & 1][rg][lr * ld + lq];
+#ifndef GT_VAR_NO_MFMA
 #pragma unroll 5
       for (int k0 = 0; k0 < kc; k0 += 4) {
         const float xf = px[k0];
@@ -123,38 +140,36 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
         for (int a = 0; a < 2; ++a)
           acc[g][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[a * 16 * ld + k0], xf, acc[g][a], 0, 0, 0);
       }
+#else
+      acc[g][0][0] += pw[0] + px[0];
+#endif
+#ifndef GT_VAR_NO_STAGE
       if (has_next) store_pass((p + 1) & 1, kc_of(cn));  // the other buffer: last read in pass p - 1
+#endif
       __syncthreads();
     }
   }
 
   // ---- epilogue: lane holds channels n..n+3 (twice) of node m for every gate ----
-  const int64_t m = m0 + lr;
   if (m >= A.N) return;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int n = third * 32 + a * 16 + 4 * lq;
-    const float* srow = A.p_dst + m * A.ldp + A.s_off + n;
-    f32x4 pre[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) pre[g] = acc[g][a] + *reinterpret_cast<const f32x4*>(srow + g * C);
     if (MODE == GGNN_MODE_RAW) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        *reinterpret_cast<f32x4*>(A.raw_out + m * (int64_t)(G * C) + g * C + n) = pre[g];
+        *reinterpret_cast<f32x4*>(A.raw_out + m * (int64_t)(G * C) + g * C + n) = acc[g][a];
     } else {
       constexpr int GI = 0, GF = 1, GC = (MODE == GGNN_MODE_LSTM) ? 2 : 1,
                     GO = (MODE == GGNN_MODE_LSTM) ? 3 : 2;
-      f32x4 cold = {0.f, 0.f, 0.f, 0.f};
-      if (MODE == GGNN_MODE_LSTM) cold = *reinterpret_cast<const f32x4*>(A.c_in + m * C + n);
       f32x4 hn, cn;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = sigmoidf_(pre[GI][r]);
-        const float tg = tanhf_(pre[GC][r]);
+        const float ig = sigmoidf_(acc[GI][a][r]);
+        const float tg = tanhf_(acc[GC][a][r]);
         float cv = ig * tg;
-        if (MODE == GGNN_MODE_LSTM) cv = sigmoidf_(pre[GF < G ? GF : 0][r]) * cold[r] + cv;
-        const float og = sigmoidf_(pre[GO][r]);
+        if (MODE == GGNN_MODE_LSTM) cv = sigmoidf_(acc[GF < G ? GF : 0][a][r]) * cold[a][r] + cv;
+        const float og = sigmoidf_(acc[GO][a][r]);
         cn[r] = cv;
         hn[r] = og * tanhf_(cv);
       }

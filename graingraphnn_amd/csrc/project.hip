@@ -121,7 +121,7 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
   for (int64_t mt = mt_lo; mt < mt_hi; mt += PJ_WAVES) {
     const bool has_next = mt + PJ_WAVES < mt_hi;
     if (has_next) load_tile(mt + PJ_WAVES);  // in flight during the sweep below
-    __builtin_amdgcn_wave_barrier();         // (compiler only) keep the stage write above the reads
+    __builtin_amdgcn_sched_barrier(0);       // loads stay above the sweep, the stage write above the reads
 
     // ---- sweep: 16 nodes x 96 columns = 6 accumulator tiles, K fully unrolled ----
     f32x4 acc[6];
