@@ -67,11 +67,12 @@ class EventTimedBackend:
         n_gates = args[-1]
         if n_gates != 4:
             return self.inner.aggregate(*args)
+        csr, p_src, p_dst = args[0], args[2], args[3]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.inner.aggregate(*args)
         e1.record()
-        self.events.append((e0, e1))
+        self.events.append((e0, e1, algorithmic_bytes(p_src.size(0), p_dst.size(0), csr.E, 4)))
 
 
 def measure_roofline(ro, n_steps):
@@ -87,12 +88,8 @@ def measure_roofline(ro, n_steps):
         torch.cuda.synchronize()
     finally:
         ro.be, ro._side = timed.inner, side
-    ms = [a.elapsed_time(b) for a, b in timed.events]
-    nj, ng = ro.n_nodes["joint"], ro.n_nodes["grain"]
-    E = {et: ro.graph.edge_index[et].size(1) for et in EDGE_TYPES}
-    n = {"grain": ng, "joint": nj}
-    per_launch = [algorithmic_bytes(n[et[0]], n[et[-1]], E[et], 4) for et in EDGE_TYPES]
-    avg_bytes = float(np.mean(per_launch))  # each step issues the three edge types equally often
+    ms = [a.elapsed_time(b) for a, b, _ in timed.events]
+    avg_bytes = float(np.mean([nb for _, _, nb in timed.events]))  # per launch, as launched
     avg_s = float(np.mean(ms)) * 1e-3
     achieved = avg_bytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4>", "achieved": round(achieved, 1),

@@ -66,8 +66,8 @@ class Workspace:
             n = n_nodes[nt]
             ncols = max(enc.layout[nt].ncols, dec.layout[nt].ncols)
             self.proj[nt] = torch.empty(n, ncols, **f32)
-            self.agg_enc[nt] = torch.zeros(n, enc.G * enc.layout[nt].Ka, **f32)
-            self.agg_dec[nt] = torch.zeros(n, dec.G * dec.layout[nt].Ka, **f32)
+            self.agg_enc[nt] = torch.zeros(n, max(enc.G * enc.layout[nt].Ka, 4), **f32)
+            self.agg_dec[nt] = torch.zeros(n, max(dec.G * dec.layout[nt].Ka, 4), **f32)
             for d in (self.h1, self.c1, self.h2, self.c2):
                 d[nt] = torch.empty(n, C, **f32)
 
@@ -110,13 +110,17 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
     for nt in NODE_TYPES:  # 2 projection GEMMs
         P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
         backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
-    for et in EDGE_TYPES:  # 3 aggregation sweeps
+    for et in EDGE_TYPES:  # 3 aggregation sweeps (fewer when a destination type is dead)
         s, d = et[0], et[-1]
+        if not lay[d].live:
+            continue
         backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], pc.ep[et], agg[d],
                           lay[s].kv_off[et], lay[d].q_off[et], lay[d].a_off[et], lay[d].Ka,
                           lay[d].sc_off[et], pc.G)
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
     for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
+        if not lay[nt].live:
+            continue
         backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
                               c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode)
 

@@ -35,6 +35,8 @@ class _GrainNNBase(nn.Module):
         self.scaling = {"grain": 20, "joint": 5}
         self._ws = None
         self._heads = None
+        # node types whose decoder state the output heads read (all of them for the regressor)
+        self._live_out = NODE_TYPES
 
     def _prepare(self, x_dict, edge_index_dict, edge_attr):
         be = default_backend()
@@ -43,7 +45,7 @@ class _GrainNNBase(nn.Module):
         n_nodes = {nt: x_dict[nt].size(0) for nt in NODE_TYPES}
         graph = graph_for(be, edge_index_dict, n_nodes)
         enc = self.gclstm_encoder.cell_list[0].packed(True)
-        dec = self.gclstm_decoder.cell_list[0].packed(False)
+        dec = self.gclstm_decoder.cell_list[0].packed(False, self._live_out)
         dev = x_dict["joint"].device
         if self._ws is None or self._ws.n_nodes != n_nodes or self._ws.proj["joint"].device != dev:
             self._ws = Workspace(enc, dec, n_nodes, dev)
@@ -124,6 +126,8 @@ class GrainNN_classifier(_GrainNNBase):
         self.lin1 = nn.Linear(2 * self.out_channels + 1, 2)
         self.lin2 = nn.Linear(2 * self.out_channels + 1, 1)
         self._tmp = None
+        # the heads read h_joint only (models.py:595-609): the decoder's grain update is dead code
+        self._live_out = ("joint",)
 
     @torch.no_grad()
     def forward(self, x_dict, edge_index_dict, edge_attr):

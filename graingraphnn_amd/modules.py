@@ -107,13 +107,15 @@ class HeteroPGCLSTM(nn.Module):
             setattr(self, "b_" + g, b)
         self._packed = {}
 
-    def packed(self, encoder: bool):
-        """Fused device weights, re-packed when parameters were replaced or updated."""
+    def packed(self, encoder: bool, live=NODE_TYPES):
+        """Fused device weights, re-packed when parameters were replaced or updated.  `live`:
+        node types whose new (h, c) is read afterwards (dead ones are not computed)."""
         ver = _param_version(self)
-        hit = self._packed.get(encoder)
+        key = (encoder, tuple(live))
+        hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, pack_cell(self, self.in_channels_dict, encoder))
-            self._packed[encoder] = hit
+            hit = (ver, pack_cell(self, self.in_channels_dict, encoder, live=tuple(live)))
+            self._packed[key] = hit
         return hit[1]
 
     @torch.no_grad()

@@ -50,16 +50,20 @@ class NodeLayout:
     s_off: int = 0
     ncols: int = 0
     Ka: int = 0
+    live: bool = True
 
     @property
     def Fp(self):
         return roundup4(self.F)
 
 
-def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES) -> NodeLayout:
+def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True) -> NodeLayout:
+    """`live=False`: the new (h, c) of this node type is never read (the classifier's decoder only
+    feeds h_joint to its head, models.py:595-609), so the type keeps only its role as a message
+    SOURCE: no query / skip columns, no aggregation into it, no gate update."""
     src_ets = [tuple(et) for et in edge_types if et[0] == node_type]
-    dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type]
-    lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets)
+    dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type] if live else []
+    lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets, live=live)
     off = 0
     for et in src_ets:
         lay.kv_off[et] = off
@@ -68,7 +72,7 @@ def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES) -> NodeLa
         lay.q_off[et] = off
         off += G * C
     lay.s_off = off
-    lay.ncols = off + G * C
+    lay.ncols = off + (G * C if live else 0)
     n_in = len(dst_ets)
     lay.Ka = roundup4(n_in * C + 2 * n_in)
     for d, et in enumerate(dst_ets):
@@ -94,14 +98,16 @@ def _conv(cell, gate, et):
 
 
 @torch.no_grad()
-def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_TYPES) -> PackedCell:
-    """`cell` is a HeteroPGCLSTM parameter holder (same attribute tree as heteropgclstm.py:30-99)."""
+def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_TYPES,
+              live=NODE_TYPES) -> PackedCell:
+    """`cell` is a HeteroPGCLSTM parameter holder (same attribute tree as heteropgclstm.py:30-99).
+    `live`: node types whose new state is consumed downstream (see node_layout)."""
     gates = GATES_ENC if encoder else GATES_DEC
     G = len(gates)
     k2 = 0 if encoder else C
     some = _conv(cell, "i", edge_types[0]).lin_key.weight
     dev, dt = some.device, torch.float32
-    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types) for nt in NODE_TYPES}
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live) for nt in NODE_TYPES}
     wp, bp, w2, ep = {}, {}, {}, {}
 
     def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz):
@@ -130,7 +136,7 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
                 put(W, B, lay.q_off[et] + g * C, F, Fp, conv.lin_query.weight, conv.lin_query.bias, False)
-        for g, gate in enumerate(gates):
+        for g, gate in enumerate(gates if lay.live else ()):
             row0 = lay.s_off + g * C
             for et in lay.dst_ets:  # HeteroConv sums the outputs -> sum the skip weights
                 conv = _conv(cell, gate, et)
@@ -143,7 +149,7 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
         wp[nt], bp[nt] = W.contiguous(), B.contiguous()
 
         n_in = len(lay.dst_ets)
-        W2 = torch.zeros(G, C, lay.Ka, dtype=dt, device=dev)
+        W2 = torch.zeros(G, C, max(lay.Ka, 4), dtype=dt, device=dev)
         for d, et in enumerate(lay.dst_ets):
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
@@ -154,6 +160,8 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
 
     for et in edge_types:
         et = tuple(et)
+        if not layout[et[-1]].live:
+            continue
         E = torch.zeros(G, 7, C, dtype=dt, device=dev)
         for g, gate in enumerate(gates):
             conv = _conv(cell, gate, et)

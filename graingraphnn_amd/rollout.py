@@ -49,7 +49,7 @@ class GrainRollout:
         self.ws = {}
         for name, m in (("R", rmodel), ("C", cmodel)):
             enc = m.gclstm_encoder.cell_list[0].packed(True)
-            dec = m.gclstm_decoder.cell_list[0].packed(False)
+            dec = m.gclstm_decoder.cell_list[0].packed(False, m._live_out)
             self.packed[name] = (enc, dec)
             self.ws[name] = Workspace(enc, dec, self.n_nodes, dev)
         self.w_reg = pack_regressor_heads(rmodel.linear)

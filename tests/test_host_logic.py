@@ -71,6 +71,9 @@ def test_layout_offsets():
     assert (packing.node_layout("joint", 8, 3).ncols, packing.node_layout("grain", 11, 3).ncols) == (2016, 1152)
     assert lj.kv_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 768}
     assert lj.q_off == {EDGE_TYPES[0]: 1536, EDGE_TYPES[2]: 1920} and lj.s_off == 2304
+    # a dead destination type keeps only its key/value columns (classifier decoder, grain)
+    dead = packing.node_layout("grain", 11, 4, live=False)
+    assert dead.ncols == 768 and dead.dst_ets == [] and dead.kv_off == {EDGE_TYPES[0]: 0}
 
 
 def _run_model_emulated(model, x, ei, ea):
@@ -78,7 +81,7 @@ def _run_model_emulated(model, x, ei, ea):
     n_nodes = {nt: v.shape[0] for nt, v in x.items()}
     graph = engine.GraphCSR(be, ei, n_nodes)
     enc = model.gclstm_encoder.cell_list[0].packed(True)
-    dec = model.gclstm_decoder.cell_list[0].packed(False)
+    dec = model.gclstm_decoder.cell_list[0].packed(False, model._live_out)
     ws = engine.Workspace(enc, dec, n_nodes, "cpu")
     h, c = engine.run_encoder_decoder(be, enc, dec, graph, ws, x, ea)
     return be, graph, h
