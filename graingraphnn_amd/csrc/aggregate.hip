@@ -256,6 +256,183 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// encoder sweep: h = c = 0, so K0 / V0 / Q are affine maps of the 8- or 11-float feature rows.
+// Every input of a unit (descriptor, edge records, the destination's and the three sources'
+// feature rows) is wave-uniform and arrives through scalar loads; the lanes only hold the
+// 120 weights of their gate and three channels.  The inner loop has NO vector-memory load:
+// it is pure VALU (scalar x vector FMAs) plus the row store.
+// ---------------------------------------------------------------------------------------
+template <int FS, int FD>
+__global__ __launch_bounds__(256) void aggregate_enc_kernel(const ggnn_aggregate_enc_args A) {
+  constexpr int G = 3;
+  using SH = Shape<G>;
+  constexpr int KS = FS - 3;  // source features beyond xyz
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave % SH::pairs, sub = wave / SH::pairs;
+  const int g = pair * 2 + ((tid >> 5) & 1);
+  const bool active = g < G;
+  const int gc = active ? g : 0;
+  const int ch = 3 * (tid & 31);
+  const float inv_sqrt_c = 0.10206207261596577f;
+
+  // this lane's weights: 3 channels x 40 floats
+  f32x4 w[3][GGNN_ENC_W_ROW / 4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < GGNN_ENC_W_ROW / 4; ++k)
+      w[c][k] = *reinterpret_cast<const f32x4*>(A.enc_w + ((int64_t)(gc * C + ch + c)) * GGNN_ENC_W_ROW + 4 * k);
+  auto W = [&](int c, int idx) { return w[c][idx >> 2][idx & 3]; };
+
+  const int nblk = gridDim.x;
+  const int ngrp = min(nblk, 8);
+  const int grp = blockIdx.x % ngrp, lb = blockIdx.x / ngrp;
+  const int nb_grp = (nblk - grp + ngrp - 1) / ngrp;
+  const int64_t x_lo = A.n_dst * grp / ngrp, x_hi = A.n_dst * (grp + 1) / ngrp;
+  const int64_t n_streams = (int64_t)nb_grp * SH::subs;
+  int64_t r = x_lo + (int64_t)lb * SH::subs + sub;
+  if (sub >= SH::subs || r >= x_hi) return;
+  const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
+  const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
+  const const_f32x4_ptr einfo = (const_f32x4_ptr)(uintptr_t)A.einfo;
+  typedef const float __attribute__((address_space(4))) * const_f32_ptr;
+  const const_f32_ptr xs = (const_f32_ptr)(uintptr_t)A.x_src;
+  const const_f32_ptr xd = (const_f32_ptr)(uintptr_t)A.x_dst;
+
+  float mx = -INFINITY, den = 0.f, sae = 0.f;
+  f3 acc = {0.f, 0.f, 0.f};
+  f3 q = {0.f, 0.f, 0.f};
+
+  int u = uptr[r], u_end = uptr[r + 1];
+  i32x8 d = udesc[u];
+  f32x4 ed[UE];
+#pragma unroll
+  for (int t = 0; t < UE; ++t) ed[t] = einfo[(int64_t)d[1] + t];
+  // feature rows of a unit (scalar loads; absent edges repeat j0, so always valid)
+  float xi[FD], xj[UE][KS];
+#pragma unroll
+  for (int f = 0; f < FD; ++f) xi[f] = xd[(int64_t)d[0] * FD + f];
+#pragma unroll
+  for (int t = 0; t < UE; ++t)
+#pragma unroll
+    for (int f = 0; f < KS; ++f) xj[t][f] = xs[(int64_t)d[4 + t] * FS + 3 + f];
+
+  while (true) {
+    const int i = d[0], nact = d[2] & 0xFF;
+    const bool first = (d[2] >> 8) & 1, last = (d[2] >> 9) & 1;
+    // scalar side of the next unit
+    bool more = true;
+    int un = u + 1, un_end = u_end;
+    int64_t rn = r;
+    if (un >= u_end) {
+      rn = r + n_streams;
+      if (rn < x_hi) {
+        un = uptr[rn];
+        un_end = uptr[rn + 1];
+      } else {
+        more = false;
+        un = u;
+      }
+    }
+    const i32x8 dn = udesc[un];
+    f32x4 edn[UE];
+#pragma unroll
+    for (int t = 0; t < UE; ++t) edn[t] = einfo[(int64_t)dn[1] + t];
+    // ... including its feature rows: the whole scalar chain of unit u+1 runs under unit u's math
+    float xin[FD], xjn[UE][KS];
+#pragma unroll
+    for (int f = 0; f < FD; ++f) xin[f] = xd[(int64_t)dn[0] * FD + f];
+#pragma unroll
+    for (int t = 0; t < UE; ++t)
+#pragma unroll
+      for (int f = 0; f < KS; ++f) xjn[t][f] = xs[(int64_t)dn[4 + t] * FS + 3 + f];
+
+    if (first) {
+      mx = -INFINITY;
+      den = 0.f;
+      sae = 0.f;
+      acc = {0.f, 0.f, 0.f};
+      // query of this row: lin_query(x_i) (periodGATconv.py:216), x_i is NOT wrapped
+      float qq[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float a = W(c, 12);
+#pragma unroll
+        for (int f = 0; f < FD; ++f) a += W(c, f) * xi[f];
+        qq[c] = a;
+      }
+      q = {qq[0], qq[1], qq[2]};
+    }
+    if (active && nact > 0) {
+      float s[UE];
+      float vv[UE][3];
+      float mnew = mx;
+#pragma unroll
+      for (int t = 0; t < UE; ++t) {
+        s[t] = -INFINITY;
+        if (t < nact) {
+          const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z, a = ed[t].w;
+          float part = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float k = W(c, 21) + W(c, 31) * rx + W(c, 32) * ry + W(c, 33) * rz + W(c, 37) * a;
+            float v = W(c, 30) + W(c, 34) * rx + W(c, 35) * ry + W(c, 36) * rz;
+#pragma unroll
+            for (int f = 0; f < KS; ++f) {
+              k += W(c, 13 + f) * xj[t][f];
+              v += W(c, 22 + f) * xj[t][f];
+            }
+            vv[t][c] = fmaxf(v, 0.f);
+            part += (c == 0 ? q.x : (c == 1 ? q.y : q.z)) * k;
+          }
+          s[t] = halfwave_sum(part) * inv_sqrt_c;
+          mnew = fmaxf(mnew, s[t]);
+        }
+      }
+      const float scale = __expf(mx - mnew);
+      den *= scale;
+      sae *= scale;
+      acc = {acc.x * scale, acc.y * scale, acc.z * scale};
+#pragma unroll
+      for (int t = 0; t < UE; ++t) {
+        if (t < nact) {
+          const float pe = __expf(s[t] - mnew);
+          den += pe;
+          sae += pe * ed[t].w;
+          acc.x += pe * vv[t][0];
+          acc.y += pe * vv[t][1];
+          acc.z += pe * vv[t][2];
+        }
+      }
+      mx = mnew;
+    }
+    if (active && last) {
+      const float inv = 1.0f / (den + 1e-16f);
+      float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
+      st3_nt(orow + A.a_off + ch, {acc.x * inv, acc.y * inv, acc.z * inv});
+      if ((tid & 31) == 0) {
+        __builtin_nontemporal_store(den * inv, orow + A.sc_off);
+        __builtin_nontemporal_store(sae * inv, orow + A.sc_off + 1);
+      }
+    }
+    if (!more) break;
+    u = un;
+    u_end = un_end;
+    r = rn;
+    d = dn;
+#pragma unroll
+    for (int t = 0; t < UE; ++t) ed[t] = edn[t];
+#pragma unroll
+    for (int f = 0; f < FD; ++f) xi[f] = xin[f];
+#pragma unroll
+    for (int t = 0; t < UE; ++t)
+#pragma unroll
+      for (int f = 0; f < KS; ++f) xj[t][f] = xjn[t][f];
+  }
+}
+
 }  // namespace ggnn
 
 extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types,
@@ -312,5 +489,29 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
     hipLaunchKernelGGL(aggregate_kernel<3>, grid, dim3(256), 0, s, A);
   else
     hipLaunchKernelGGL(aggregate_kernel<1>, grid, dim3(256), 0, s, A);
+  return launch_status();
+}
+
+extern "C" int ggnn_period_gat_aggregate_enc(const ggnn_aggregate_enc_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  const ggnn_aggregate_enc_args& A = *args;
+  if (!A.unit_ptr || !A.units || !A.einfo || !A.x_src || !A.x_dst || !A.enc_w || !A.agg) return GGNN_EINVAL;
+  if (!aligned16(A.units) || !aligned16(A.einfo) || !aligned16(A.enc_w)) return GGNN_EINVAL;
+  if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0 || A.n_gates != 3) return GGNN_EINVAL;
+  if (A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
+  if (2LL * A.a_gstride + A.a_off + C > A.ld_agg || 2LL * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
+  const int64_t want = (A.n_dst + 3) / 4;
+  const int64_t cap = (int64_t)AG_NUM_CU * 3;  // ~150 VGPRs -> three workgroups per CU
+  const dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (A.f_src == 11 && A.f_dst == 8)
+    hipLaunchKernelGGL((aggregate_enc_kernel<11, 8>), grid, block, 0, s, A);
+  else if (A.f_src == 8 && A.f_dst == 11)
+    hipLaunchKernelGGL((aggregate_enc_kernel<8, 11>), grid, block, 0, s, A);
+  else if (A.f_src == 8 && A.f_dst == 8)
+    hipLaunchKernelGGL((aggregate_enc_kernel<8, 8>), grid, block, 0, s, A);
+  else
+    return GGNN_EINVAL;
   return launch_status();
 }

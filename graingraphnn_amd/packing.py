@@ -57,7 +57,18 @@ class NodeLayout:
         return roundup4(self.F)
 
 
-def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True) -> NodeLayout:
+ENC_W_ROW = 40  # floats per channel in the fused-encoder weight record (include/ggnn.h)
+# Fused encoder sweep (ggnn_period_gat_aggregate_enc): recompute K0/V0/Q per edge from the
+# feature rows instead of projecting them to HBM.  Parity-green, but measured SLOWER on cfg3
+# (r1: 3 sweeps 133 us + projection 21 us vs 84 us + 47 us for projection + gather): the sweep
+# is VALU-issue-bound at 150 VGPRs / 3 waves per SIMD.  Kept behind this switch for tuning.
+FUSE_ENCODER = False
+# (f_src, f_dst) pairs the fused encoder sweep is instantiated for
+ENC_FUSED_SHAPES = ((11, 8), (8, 11), (8, 8))
+
+
+def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True,
+                fused: bool = False) -> NodeLayout:
     """`live=False`: the new (h, c) of this node type is never read (the classifier's decoder only
     feeds h_joint to its head, models.py:595-609), so the type keeps only its role as a message
     SOURCE: no query / skip columns, no aggregation into it, no gate update."""
@@ -65,12 +76,13 @@ def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: boo
     dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type] if live else []
     lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets, live=live)
     off = 0
-    for et in src_ets:
-        lay.kv_off[et] = off
-        off += G * 2 * C
-    for et in dst_ets:
-        lay.q_off[et] = off
-        off += G * C
+    if not fused:  # fused encoder: key / value / query never leave the aggregation kernel
+        for et in src_ets:
+            lay.kv_off[et] = off
+            off += G * 2 * C
+        for et in dst_ets:
+            lay.q_off[et] = off
+            off += G * C
     lay.s_off = off
     lay.ncols = off + (G * C if live else 0)
     n_in = len(dst_ets)
@@ -91,6 +103,8 @@ class PackedCell:
     bp: Dict[str, torch.Tensor]     # node type -> [ncols]
     ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 7, 96]
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
+    enc_w: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # fused encoder: [G, 96, 40]
+    fused: bool = False
 
 
 def _conv(cell, gate, et):
@@ -107,8 +121,10 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
     k2 = 0 if encoder else C
     some = _conv(cell, "i", edge_types[0]).lin_key.weight
     dev, dt = some.device, torch.float32
-    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live) for nt in NODE_TYPES}
-    wp, bp, w2, ep = {}, {}, {}, {}
+    fused = (FUSE_ENCODER and encoder and
+             all((in_channels[et[0]], in_channels[et[-1]]) in ENC_FUSED_SHAPES for et in edge_types))
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, fused) for nt in NODE_TYPES}
+    wp, bp, w2, ep, enc_w = {}, {}, {}, {}, {}
 
     def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz):
         """weight: [96, F + 96] reference layout -> rows row0..row0+95 of the packed matrix."""
@@ -126,13 +142,13 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
         F, Fp = lay.F, lay.Fp
         W = torch.zeros(lay.ncols, Fp + k2, dtype=dt, device=dev)
         B = torch.zeros(lay.ncols, dtype=dt, device=dev)
-        for et in lay.src_ets:
+        for et in (() if fused else lay.src_ets):
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
                 base = lay.kv_off[et] + g * 2 * C
                 put(W, B, base, F, Fp, conv.lin_key.weight, conv.lin_key.bias, True)
                 put(W, B, base + C, F, Fp, conv.lin_value.weight, conv.lin_value.bias, True)
-        for et in lay.dst_ets:
+        for et in (() if fused else lay.dst_ets):
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
                 put(W, B, lay.q_off[et] + g * C, F, Fp, conv.lin_query.weight, conv.lin_query.bias, False)
@@ -169,7 +185,23 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             E[g, 3:6] = conv.lin_value.weight.detach().to(dt)[:, 0:3].t()
             E[g, 6] = conv.lin_edge.weight.detach().to(dt)[:, 0]
         ep[et] = E.contiguous()
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2)
+        if fused:
+            Fs, Fd = in_channels[et[0]], in_channels[et[-1]]
+            Wf = torch.zeros(G, C, ENC_W_ROW, dtype=dt, device=dev)
+            for g, gate in enumerate(gates):
+                conv = _conv(cell, gate, et)
+                wq, wk, wv = (m.weight.detach().to(dt) for m in (conv.lin_query, conv.lin_key, conv.lin_value))
+                Wf[g, :, 0:Fd] = wq[:, :Fd]
+                Wf[g, :, 12] = conv.lin_query.bias.detach().to(dt)
+                Wf[g, :, 13:13 + Fs - 3] = wk[:, 3:Fs]
+                Wf[g, :, 21] = conv.lin_key.bias.detach().to(dt)
+                Wf[g, :, 22:22 + Fs - 3] = wv[:, 3:Fs]
+                Wf[g, :, 30] = conv.lin_value.bias.detach().to(dt)
+                Wf[g, :, 31:34] = wk[:, 0:3]
+                Wf[g, :, 34:37] = wv[:, 0:3]
+                Wf[g, :, 37] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+            enc_w[et] = Wf.contiguous()
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, enc_w=enc_w, fused=fused)
 
 
 @torch.no_grad()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 3
+#define GGNN_ABI_VERSION 4
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
@@ -129,6 +129,35 @@ typedef struct ggnn_aggregate_args {
   int32_t kv_off, q_off, a_off, a_gstride, sc_off, n_gates; /* n_gates in {1, 3, 4} */
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Encoder variant of the aggregation (h = c = 0, SeqGCLSTM._init_hidden, models.py:282-289):
+ * the cell input is the bare feature row (8 or 11 floats), so the key / value / query
+ * projections are recomputed per edge from the 32..44-byte feature rows instead of being
+ * read back as 384-byte fragments -- same outputs as ggnn_project + ggnn_period_gat_aggregate,
+ * no [N, G*96] key/value/query buffers at all.
+ *   enc_w : [n_gates][96][GGNN_ENC_W_ROW] per channel c of gate g:
+ *           [0..11]  lin_query.weight[c, 0..f_dst-1] (zero padded)   [12] lin_query.bias[c]
+ *           [13..20] lin_key.weight[c, 3..f_src-1]   (zero padded)   [21] lin_key.bias[c]
+ *           [22..29] lin_value.weight[c, 3..f_src-1] (zero padded)   [30] lin_value.bias[c]
+ *           [31..33] lin_key.weight[c, 0..2]  [34..36] lin_value.weight[c, 0..2]
+ *           [37]     lin_edge.weight[c, 0]    [38..39] 0
+ *   x_src / x_dst : contiguous [n, f] feature rows (row stride = f); (f_src, f_dst) must be
+ *           one of (11, 8), (8, 11), (8, 8).
+ */
+#define GGNN_ENC_W_ROW 40
+typedef struct ggnn_aggregate_enc_args {
+  const int32_t* unit_ptr; /* [n_dst + 1] */
+  const int32_t* units;    /* [n_units, 8] */
+  const float* einfo;      /* [E + GGNN_UNIT_EDGES, 4] */
+  const float* x_src;      /* [n_src, f_src] */
+  const float* x_dst;      /* [n_dst, f_dst] */
+  const float* enc_w;      /* [n_gates][96][GGNN_ENC_W_ROW], 16-byte aligned */
+  float* agg;              /* [n_dst, ld_agg] */
+  int64_t ld_agg, n_src, n_dst, E;
+  int32_t f_src, f_dst, a_off, a_gstride, sc_off, n_gates; /* n_gates == 3 */
+} ggnn_aggregate_enc_args;
+int ggnn_period_gat_aggregate_enc(const ggnn_aggregate_enc_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:

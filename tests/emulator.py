@@ -70,6 +70,29 @@ class TorchEmulatorBackend:
             agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
             agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
 
+    def aggregate_enc(self, csr, einfo, x_src, x_dst, enc_w, agg, a_off, a_gstride, sc_off, n_gates):
+        rowptr, col = csr.rowptr.long(), csr.col.long()
+        n_dst, Fs, Fd = x_dst.size(0), x_src.size(1), x_dst.size(1)
+        E = int(rowptr[-1])
+        dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
+        j, reloc, a = col[:E], einfo[:E, :3], einfo[:E, 3]
+        for g in range(n_gates):
+            w = enc_w[g]
+            Q = x_dst[:, :Fd] @ w[:, 0:Fd].t() + w[:, 12]
+            K = x_src[:, 3:Fs] @ w[:, 13:13 + Fs - 3].t() + w[:, 21]
+            V = x_src[:, 3:Fs] @ w[:, 22:22 + Fs - 3].t() + w[:, 30]
+            k = K[j] + reloc @ w[:, 31:34].t() + a[:, None] * w[:, 37][None, :]
+            s = (Q[dst] * k).sum(-1) / math.sqrt(C)
+            smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
+            p = (s - smax[dst]).exp()
+            den = torch.zeros(n_dst).index_add_(0, dst, p)
+            alpha = p / (den[dst] + 1e-16)
+            r = torch.relu(V[j] + reloc @ w[:, 34:37].t())
+            base = g * a_gstride
+            agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add_(0, dst, alpha[:, None] * r)
+            agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
+            agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
+
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode):
         Ka = w2.size(2)
         pre = [agg[:, g * Ka:(g + 1) * Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]

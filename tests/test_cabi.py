@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 3
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 4
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4
@@ -43,6 +43,7 @@ def test_argument_validation_returns_einval_without_launching():
     assert lib.ggnn_project(None, 8, 8, None, 0, 0, None, None, 10, 96, None, 96, None) == -1
     assert lib.ggnn_period_gat_aggregate(None, None) == -1
     assert lib.ggnn_lstm_epilogue(None, None) == -1
+    assert lib.ggnn_period_gat_aggregate_enc(None, None) == -1
     a = _lib.AggregateArgs()
     assert lib.ggnn_period_gat_aggregate(ctypes.byref(a), None) == -1
     e = _lib.EpilogueArgs()

@@ -69,6 +69,8 @@ def test_layout_offsets():
     assert (lj.ncols, lg.ncols) == (2688, 1536)      # [20000,104]x[104,2688], [10000,107]x[107,1536]
     assert (lj.Ka, lg.Ka) == (196, 100)
     assert (packing.node_layout("joint", 8, 3).ncols, packing.node_layout("grain", 11, 3).ncols) == (2016, 1152)
+    # fused encoder: only the summed skip leaves the projection
+    assert packing.node_layout("joint", 8, 3, fused=True).ncols == 288
     assert lj.kv_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 768}
     assert lj.q_off == {EDGE_TYPES[0]: 1536, EDGE_TYPES[2]: 1920} and lj.s_off == 2304
     # a dead destination type keeps only its key/value columns (classifier decoder, grain)
@@ -152,6 +154,22 @@ def test_cell_with_state_and_single_conv_packing():
         out = torch.empty(n_nodes[et[-1]], 96)
         be.lstm_epilogue(agg, w2, pd, 96, None, None, None, out, 1, 2)
         assert_close(out, g["conv_" + etk(et)], f"conv {et}", TOL)
+
+
+@torch.no_grad()
+def test_fused_encoder_packing_reproduces_golden(monkeypatch):
+    monkeypatch.setattr(packing, "FUSE_ENCODER", True)
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_s1")
+    R, _ = product_models(10020)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    be, graph, h = _run_model_emulated(R, X, EI, EA)
+    assert R.gclstm_encoder.cell_list[0].packed(True).fused
+    w, b = packing.pack_regressor_heads(R.linear)
+    yj, yg, area = torch.empty(236, 2), torch.empty(118, 2), torch.empty(118)
+    be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
+    assert_close(yj, g["R_joint"], "fused encoder R joint", TOL)
+    assert_close(yg, g["R_grain"], "fused encoder R grain", TOL)
 
 
 @torch.no_grad()
