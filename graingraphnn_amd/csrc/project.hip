@@ -116,6 +116,13 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
 #pragma unroll
   for (int a = 0; a < 6; ++a) bv[a] = *reinterpret_cast<const f32x4*>(bias + n0 + a * 16 + 4 * lq);
 
+  // Waves w and w + 4 share a SIMD and run the same program: started together they would sweep
+  // together and reach their load / store phases together, leaving the matrix pipe idle.  A
+  // half-sweep head start for one of them makes the phases complementary for the whole kernel
+  // (there is no barrier to re-align them).  Speed only.
+#ifndef PJ_VAR_NO_STAGGER
+  if (K2 > 0 && wave >= 4) __builtin_amdgcn_s_sleep(40);  // 40 x 64 clocks ~ half a sweep
+#endif
   load_tile(mt_lo);
   store_tile();
   for (int64_t mt = mt_lo; mt < mt_hi; mt += PJ_WAVES) {
@@ -123,16 +130,40 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
     if (has_next) load_tile(mt + PJ_WAVES);  // in flight during the sweep below
     __builtin_amdgcn_sched_barrier(0);       // loads stay above the sweep, the stage write above the reads
 
-    // ---- sweep: 16 nodes x 96 columns = 6 accumulator tiles, K fully unrolled ----
+    // ---- sweep: 16 nodes x 96 columns = 6 accumulator tiles, K fully unrolled.  Operand
+    // fragments are double-buffered in registers: the 7 LDS reads of k-step s+1 are issued
+    // between the 6 MFMAs of k-step s (sched_group_barrier pins the interleave), so no MFMA
+    // waits on an LDS read issued right in front of it. ----
     f32x4 acc[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wf[2][6], xf[2];
 #pragma unroll
-    for (int k0 = 0; k0 < KP; k0 += 4) {
-      const float xf = px[k0];
+    for (int a = 0; a < 6; ++a) wf[0][a] = pw[a * 16 * LD];
+    xf[0] = px[0];
+#pragma unroll
+    for (int ks = 0; ks < KP / 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < KP / 4) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) wf[nxt][a] = pw[a * 16 * LD + 4 * (ks + 1)];
+        xf[nxt] = px[4 * (ks + 1)];
+      }
 #pragma unroll
       for (int a = 0; a < 6; ++a)
-        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[a * 16 * LD + k0], xf, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][a], xf[cur], acc[a], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // ... two DS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_wave_barrier();
     if (has_next) store_tile();  // same wave, in-order LDS: lands after the reads above
