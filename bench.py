@@ -94,8 +94,19 @@ def measure_roofline(ro, n_steps):
     achieved = avg_bytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4>", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+            "traffic": pmc_traffic(), "avg_launch_us": round(avg_s * 1e6, 2),
             "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(ms)}
+
+
+def pmc_traffic():
+    """HBM bytes per aggregate_kernel<4> launch from the rocprofv3 --pmc passes recorded in
+    profiles/r1_pmc_aggregate.json (PMC collection cannot run inside this process; the file
+    says how it was taken and corrected).  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_aggregate.json")) as f:
+            return int(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=20.0):
