@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"],
+                    help="cfg3 (default, the BASELINE metric): 10k-grain honeycomb; cfg2: the 120 um fixture "
+                         "(1043 grains); cfg4: 64 perturbed 40 um trajectories sharded over the ranks, each "
+                         "rank batching its shard as one disjoint-union graph (--steps = steps per trajectory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,11 +157,43 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
 
-    # every rank owns an independent replica (different seed of the junction noise per rank)
-    R, Cm, X, EI, EA, inputs = build(device, seed=0)
-    if rank:
-        xp = synthetic.perturbed_copy(inputs[0], 1e-4, 1000 + rank)
-        X = {k: torch.from_numpy(v).to(device) for k, v in xp.items()}
+    units_per_step = world  # graph-steps completed per ro.step() over the whole job
+    if args.workload == "cfg3":
+        # every rank owns an independent replica (different seed of the junction noise per rank)
+        R, Cm, X, EI, EA, inputs = build(device, seed=0)
+        if rank:
+            xp = synthetic.perturbed_copy(inputs[0], 1e-4, 1000 + rank)
+            X = {k: torch.from_numpy(v).to(device) for k, v in xp.items()}
+        workload = ("cfg3: synthetic periodic honeycomb, 10000 grains / 20000 junctions / 60000 edges per "
+                    "type, fold 10, static topology, R+C forward + update + edge refresh per step, weights "
+                    "RandomState(0) x0.3")
+    else:
+        from graingraphnn_amd.dist import shard_trajectories
+        from oracle import grainnn_oracle as _o  # only for the x3 patch folding of the 120 um fixture
+        gold = os.path.join(ROOT, "tests", "golden")
+        hp = synthetic.default_hyper(device)
+        R = GrainNN_regressor(hp)
+        Cm = GrainNN_classifier(hp, R)
+        if args.workload == "cfg2":
+            x, ei, ea = synthetic.load_fixture(os.path.join(gold, "graph_120.npz"))
+            Xc, _, EAc = synthetic.to_torch(x, ei, ea, "cpu")
+            _o.scale_feature_patchs(3.0, Xc, EAc)
+            x = {k: v.numpy() for k, v in Xc.items()}
+            ea = {k: v.numpy() for k, v in EAc.items()}
+            load_seeded(R, 0).eval(), load_seeded(Cm, 1).eval()
+            workload = "cfg2: 120 um fixture (1043 grains / 2086 junctions) after x3 patch folding, one replica per rank"
+        else:
+            x0, ei0, ea0 = synthetic.load_fixture(os.path.join(gold, "graph_40.npz"))
+            mine = shard_trajectories(64, rank, world)
+            x, ei, ea, _ = synthetic.disjoint_union(
+                [(synthetic.perturbed_copy(x0, 1e-3, 1000 + t), ei0, ea0) for t in mine])
+            load_seeded(R, 10020).eval(), load_seeded(Cm, 10021).eval()
+            units_per_step = 64
+            workload = (f"cfg4: 64 perturbed 40 um trajectories (118 grains each), {len(mine)} per rank batched "
+                        "as one disjoint-union graph")
+        inputs = (x, ei, ea)
+        R, Cm = R.to(device), Cm.to(device)
+        X, EI, EA = synthetic.to_torch(x, ei, ea, device)
     ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial)
 
     for _ in range(args.warmup):
@@ -185,7 +221,7 @@ def main():
         roof = measure_roofline(ro, 10)
         line = {
             "metric": "rollout steps/sec (10k-grain heterograph)",
-            "value": round(world * args.steps / dt, 2),
+            "value": round(units_per_step * args.steps / dt, 2),
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -196,14 +232,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg3: synthetic periodic honeycomb, 10000 grains / 20000 junctions / "
-                                   "60000 edges per type, fold 10, static topology, R+C forward + update + "
-                                   "edge refresh per step, weights RandomState(0) x0.3",
-                       "replicas": world, "launch": ("eager" if args.no_graph else "hipGraph replay") + (", R|C serial" if args.serial else ", R|C on two streams"),
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else "hipGraph replay") + (", R|C serial" if args.serial else ", R|C on two streams"),
                        "results_finite": finite},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "cfg3":
             line["cpu_baseline"] = cpu_baseline(inputs)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -50,3 +50,27 @@ def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, 
     for t in range(n_traj):
         out[t] = bufs[t % world][t // world]
     return out
+
+
+def rollout_trajectories(rmodel, cmodel, graphs, span: int, n_steps: int, rank: int = 0,
+                         world: int = 1, device="cuda", use_graph: bool = True):
+    """BASELINE config 4: `graphs[t]` = (x, ei, ea) numpy dicts of independent trajectories with
+    EQUAL node counts.  Rank r rolls out trajectories t = r (mod world) as ONE disjoint-union
+    graph on its GPU (one set of launches for the whole shard), then all ranks all-gather the
+    final joint coordinates and grain (area, extraV): returns {'joint_xy': [T, N_j, 2],
+    'grain_area_v': [T, N_g, 2]} in trajectory order on every rank."""
+    from . import synthetic
+    from .rollout import GrainRollout
+
+    mine = shard_trajectories(len(graphs), rank, world)
+    x, ei, ea, slices = synthetic.disjoint_union([graphs[t] for t in mine])
+    X, EI, EA = synthetic.to_torch(x, ei, ea, device)
+    ro = GrainRollout(rmodel, cmodel, X, EI, EA, span, use_graph=use_graph)
+    ro.run(n_steps)
+    local = {"joint_xy": torch.stack([X["joint"][lo:hi, :2] for lo, hi in (s["joint"] for s in slices)]),
+             "grain_area_v": torch.stack([X["grain"][lo:hi, 3:5] for lo, hi in (s["grain"] for s in slices)])}
+    out = {}
+    for k, v in local.items():
+        it = iter(range(len(mine)))
+        out[k] = run_sharded(len(graphs), lambda t, v=v, it=it: v[next(it)], rank, world)
+    return out

@@ -124,3 +124,27 @@ def perturbed_copy(x, sigma: float, seed: int):
     out = {k: v.copy() for k, v in x.items()}
     out["joint"][:, :2] += rs.normal(0.0, sigma, size=out["joint"][:, :2].shape).astype(np.float32)
     return out
+
+
+def disjoint_union(graphs):
+    """cfg4: batch independent graphs into one disjoint-union graph (what PyG DataLoader
+    collation does, train.py:365-366): node rows concatenated, edge indices offset.  Returns
+    (x, ei, ea, slices) with slices[t] = {'grain': (lo, hi), 'joint': (lo, hi)}."""
+    off = {"grain": 0, "joint": 0}
+    xs = {"grain": [], "joint": []}
+    eis = {et: [] for et in EDGE_TYPES}
+    eas = {et: [] for et in EDGE_TYPES}
+    slices = []
+    for x, ei, ea in graphs:
+        slices.append({nt: (off[nt], off[nt] + x[nt].shape[0]) for nt in xs})
+        for nt in xs:
+            xs[nt].append(x[nt])
+        for et in EDGE_TYPES:
+            shift = np.array([[off[et[0]]], [off[et[-1]]]], dtype=np.int64)
+            eis[et].append(ei[et] + shift)
+            eas[et].append(ea[et])
+        for nt in xs:
+            off[nt] += x[nt].shape[0]
+    return ({nt: np.concatenate(v, 0) for nt, v in xs.items()},
+            {et: np.ascontiguousarray(np.concatenate(v, 1)) for et, v in eis.items()},
+            {et: np.concatenate(v, 0) for et, v in eas.items()}, slices)

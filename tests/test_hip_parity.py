@@ -324,3 +324,31 @@ def test_cfg3_full_size_step_and_properties():
     Ka = 196
     sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, Ka)[:, :, 192::2]
     assert float((sa - 1).abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 4: independent trajectories batched as one disjoint-union graph
+# ---------------------------------------------------------------------------------------
+@torch.no_grad()
+def test_cfg4_batched_trajectories_match_individual_rollouts():
+    from graingraphnn_amd import GrainRollout
+    from graingraphnn_amd.dist import rollout_trajectories
+    x, ei, ea = load_graph("40")
+    graphs = [(synthetic.perturbed_copy(x, 1e-3, 1000 + t), ei, ea) for t in range(8)]
+    R, Cm = product_models(10020, 1.0, DEV)
+    got = rollout_trajectories(R, Cm, graphs, 6, 3, 0, 1, DEV)
+    assert got["joint_xy"].shape == (8, 236, 2) and got["grain_area_v"].shape == (8, 118, 2)
+    oR, oC = oracle_models(10020, 1.0)
+    for t in (0, 3, 7):
+        # (1) same bits as rolling the trajectory out alone: rows are independent, CSR order and
+        # the MFMA k-order do not depend on where a row sits in the batch
+        X, EI, EA = tt(graphs[t][0], DEV), tt(ei, DEV), tt(ea, DEV)
+        GrainRollout(R, Cm, X, EI, EA, 6).run(3)
+        assert torch.equal(got["joint_xy"][t], X["joint"][:, :2]), f"trajectory {t} joints"
+        assert torch.equal(got["grain_area_v"][t], X["grain"][:, 3:5]), f"trajectory {t} grains"
+        # (2) and the oracle within tolerance
+        oX, oEI, oEA = tt(graphs[t][0]), tt(ei), tt(ea)
+        for _ in range(3):
+            _, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+        assert_close(got["joint_xy"][t], oX["joint"][:, :2], f"cfg4 trajectory {t} joint xy")
+        assert_close(got["grain_area_v"][t], oX["grain"][:, 3:5], f"cfg4 trajectory {t} grain area/extraV")

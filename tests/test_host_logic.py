@@ -222,3 +222,17 @@ def test_honeycomb_invariants():
     x3, ei3, _ = synthetic.honeycomb(100, 10, 0)
     assert x3["grain"].shape[0] == 10000 and x3["joint"].shape[0] == 20000
     assert all(v.shape == (2, 60000) for v in ei3.values())
+
+
+def test_disjoint_union_offsets():
+    g1 = synthetic.honeycomb(4, 1, 0)
+    g2 = synthetic.honeycomb(6, 1, 1)
+    x, ei, ea, slices = synthetic.disjoint_union([g1, g2])
+    assert x["grain"].shape[0] == 16 + 36 and x["joint"].shape[0] == 32 + 72
+    assert slices[1] == {"grain": (16, 52), "joint": (32, 104)}
+    for et in EDGE_TYPES:
+        n1 = g1[1][et].shape[1]
+        assert np.array_equal(ei[et][:, :n1], g1[1][et])
+        shift = np.array([[slices[1][et[0]][0]], [slices[1][et[-1]][0]]])
+        assert np.array_equal(ei[et][:, n1:], g2[1][et] + shift)
+        assert ea[et].shape[0] == ei[et].shape[1]
