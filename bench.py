@@ -151,11 +151,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # GGNN_BENCH_BACKEND=gloo + fewer GPUs than ranks: single-GPU smoke run of the N > 1 code path
+    backend = os.environ.get("GGNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI on ROCm
+        else:
+            dist.init_process_group(backend)
 
     units_per_step = world  # graph-steps completed per ro.step() over the whole job
     if args.workload == "cfg3":
@@ -198,6 +204,7 @@ def main():
 
     for _ in range(args.warmup):
         ro.step()
+    gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -212,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = all(bool(torch.isfinite(v).all()) for g in gathered for v in g.values())

@@ -14,17 +14,23 @@ def shard_trajectories(n_traj: int, rank: int, world: int) -> List[int]:
     return [t for t in range(n_traj) if t % world == rank]
 
 
+def _staging(t: torch.Tensor) -> torch.Tensor:
+    """RCCL ('nccl') moves device buffers directly; the 'gloo' backend (CPU tests, single-GPU
+    smoke runs) needs host buffers."""
+    return t.contiguous().cpu() if dist.get_backend() == "gloo" else t.contiguous()
+
+
 def gather_states(state: Dict[str, torch.Tensor], world: int) -> List[Dict[str, torch.Tensor]]:
     """All-gather a dict of equally-shaped tensors; returns one dict per rank (rank order)."""
     if world <= 1 or not dist.is_initialized():
         return [state]
     out = [dict() for _ in range(world)]
     for k in sorted(state):
-        t = state[k].contiguous()
+        t = _staging(state[k])
         bufs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(bufs, t)
         for r in range(world):
-            out[r][k] = bufs[r]
+            out[r][k] = bufs[r].to(state[k].device)
     return out
 
 
@@ -44,11 +50,12 @@ def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, 
         local[i] = r
     if world <= 1 or not dist.is_initialized():
         return local[:n_traj]
-    bufs = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(bufs, local)
+    staged = _staging(local)
+    bufs = [torch.empty_like(staged) for _ in range(world)]
+    dist.all_gather(bufs, staged)
     out = torch.empty((n_traj,) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
     for t in range(n_traj):
-        out[t] = bufs[t % world][t // world]
+        out[t] = bufs[t % world][t // world].to(proto.device)
     return out
 
 
