@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
+    ap.add_argument("--phase-shift", action="store_true",
+                    help="start the classifier one kernel phase after the regressor (measured slower)")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"],
                     help="cfg3 (default, the BASELINE metric): 10k-grain honeycomb; cfg2: the 120 um fixture "
                          "(1043 grains); cfg4: 64 perturbed 40 um trajectories sharded over the ranks, each "
@@ -200,7 +202,8 @@ def main():
         inputs = (x, ei, ea)
         R, Cm = R.to(device), Cm.to(device)
         X, EI, EA = synthetic.to_torch(x, ei, ea, device)
-    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial)
+    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial,
+                      phase_shift=args.phase_shift)
 
     for _ in range(args.warmup):
         ro.step()

@@ -41,7 +41,10 @@
 
 namespace ggnn {
 
-constexpr int AG_BLOCKS_PER_CU = 7;  // resident workgroups per CU (68 VGPRs -> 7 waves per SIMD)
+#ifndef AG_VAR_BPC
+#define AG_VAR_BPC 7
+#endif
+constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;  // resident workgroups per CU (68 VGPRs -> 7 waves per SIMD)
 constexpr int AG_NUM_CU = 256;
 constexpr int UE = GGNN_UNIT_EDGES;
 
