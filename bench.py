@@ -42,14 +42,14 @@ def algorithmic_bytes(n_src, n_dst, E, G):
 
 
 def build(device, n=100, fold=10, seed=0, scale=0.3):
-    x, ei, ea = synthetic.honeycomb(n, fold, seed)
+    x, ei, ea, off = synthetic.honeycomb(n, fold, seed, return_offset=True)
     hp = synthetic.default_hyper(device)
     R = GrainNN_regressor(hp)
     Cm = GrainNN_classifier(hp, R)
     load_seeded(R, seed, scale).eval()
     load_seeded(Cm, seed + 1, scale).eval()
     X, EI, EA = synthetic.to_torch(x, ei, ea, device)
-    return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea)
+    return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea, float(fold), off)
 
 
 class EventTimedBackend:
@@ -112,18 +112,19 @@ def pmc_traffic():
 def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=20.0):
     """The oracle (reference formulation, plain PyTorch CPU) on the same workload, bounded."""
     from oracle import grainnn_oracle as oracle
-    x, ei, ea = inputs
+    x, ei, ea, factor, off = inputs
+    centres = (factor, torch.from_numpy(off))
     hp = synthetic.default_hyper("cpu")
     R = oracle.GrainNN_regressor(hp)
     Cm = oracle.GrainNN_classifier(hp, R)
     load_seeded(R, seed, scale).eval()
     load_seeded(Cm, seed + 1, scale).eval()
     X, EI, EA = synthetic.to_torch(x, ei, ea, "cpu")
-    oracle.rollout_step(R, Cm, X, EI, EA, SPAN)  # warm-up
+    oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)  # warm-up
     t0 = time.perf_counter()
     n = 0
     while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
-        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN)
+        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(),
@@ -173,24 +174,23 @@ def main():
             xp = synthetic.perturbed_copy(inputs[0], 1e-4, 1000 + rank)
             X = {k: torch.from_numpy(v).to(device) for k, v in xp.items()}
         workload = ("cfg3: synthetic periodic honeycomb, 10000 grains / 20000 junctions / 60000 edges per "
-                    "type, fold 10, static topology, R+C forward + update + edge refresh per step, weights "
+                    "type, fold 10, static topology, R+C forward + update + grain-centre refresh + edge "
+                    "refresh per step, weights "
                     "RandomState(0) x0.3")
     else:
         from graingraphnn_amd.dist import shard_trajectories
-        from oracle import grainnn_oracle as _o  # only for the x3 patch folding of the 120 um fixture
         gold = os.path.join(ROOT, "tests", "golden")
         hp = synthetic.default_hyper(device)
         R = GrainNN_regressor(hp)
         Cm = GrainNN_classifier(hp, R)
         if args.workload == "cfg2":
             x, ei, ea = synthetic.load_fixture(os.path.join(gold, "graph_120.npz"))
-            Xc, _, EAc = synthetic.to_torch(x, ei, ea, "cpu")
-            _o.scale_feature_patchs(3.0, Xc, EAc)
-            x = {k: v.numpy() for k, v in Xc.items()}
-            ea = {k: v.numpy() for k, v in EAc.items()}
+            x, ea = {k: v.copy() for k, v in x.items()}, {k: v.copy() for k, v in ea.items()}
+            factor, off = 3.0, synthetic.scale_feature_patchs(3.0, x, ea)
             load_seeded(R, 0).eval(), load_seeded(Cm, 1).eval()
             workload = "cfg2: 120 um fixture (1043 grains / 2086 junctions) after x3 patch folding, one replica per rank"
         else:
+            factor, off = 1.0, None
             x0, ei0, ea0 = synthetic.load_fixture(os.path.join(gold, "graph_40.npz"))
             mine = shard_trajectories(64, rank, world)
             x, ei, ea, _ = synthetic.disjoint_union(
@@ -199,11 +199,12 @@ def main():
             units_per_step = 64
             workload = (f"cfg4: 64 perturbed 40 um trajectories (118 grains each), {len(mine)} per rank batched "
                         "as one disjoint-union graph")
-        inputs = (x, ei, ea)
+        inputs = (x, ei, ea, factor, off)
         R, Cm = R.to(device), Cm.to(device)
         X, EI, EA = synthetic.to_torch(x, ei, ea, device)
     ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial,
-                      phase_shift=args.phase_shift)
+                      phase_shift=args.phase_shift, refresh_centres=True, domain_factor=inputs[3],
+                      domain_offset=None if inputs[4] is None else torch.from_numpy(inputs[4]))
 
     for _ in range(args.warmup):
         ro.step()

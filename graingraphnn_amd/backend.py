@@ -158,6 +158,25 @@ class HipBackend:
                                         x_grain.size(1), ptr(y_joint), ptr(y_grain), dz, zmax,
                                         ptr(flags), _lib.current_stream()), "ggnn_step_update")
 
+    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None):
+        """x_grain[:, :2] <- region centres of the grains' junction polygons (graph.update(),
+        graph_datastruct.py:681-708 + test.py:556-559).  csr_jg: CSR of (joint, pull, grain)."""
+        _require_cuda(x_joint, x_grain, csr_jg.rowptr, domain_offset)
+        if csr_jg.rowptr.numel() != x_grain.size(0) + 1:
+            raise _lib.GGNNError("csr_jg must have one row per grain")
+        if domain_offset is not None:
+            _f32c(domain_offset, "domain_offset")
+            if tuple(domain_offset.shape) != (x_joint.size(0), 2):
+                raise _lib.GGNNError("domain_offset must be [n_joint, 2]")
+        elif domain_factor > 1:
+            raise _lib.GGNNError("domain_factor > 1 needs the domain_offset of scale_feature_patchs")
+        check(self.lib.ggnn_grain_centres(ptr(csr_jg.rowptr), ptr(csr_jg.col), ptr(x_joint),
+                                          x_joint.size(0), x_joint.stride(0),
+                                          ptr(domain_offset) if domain_offset is not None else None,
+                                          float(domain_factor), ptr(x_grain), x_grain.size(0),
+                                          x_grain.stride(0), _lib.current_stream()),
+              "ggnn_grain_centres")
+
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
         """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E])."""
         _require_cuda(x_joint, x_grain, flags)

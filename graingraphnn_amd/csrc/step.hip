@@ -2,7 +2,9 @@
 //   ggnn_step_update  = GrainNN_regressor.update, periodic branch (models.py:503-516)
 //                       + z advance (test.py:401-402)
 //   ggnn_step_refresh = z clamp (test.py:405-407) + edge-length refresh (test.py:562-575)
-// Two launches because the refresh needs every node's updated coordinates.
+//   ggnn_grain_centres = region centres of graph.update() (graph_datastruct.py:681-708) written
+//                       to x_grain[:, :2] (test.py:468-478, 556-559), between the two
+// Separate launches because each stage needs every node's updated coordinates.
 #include "common.h"
 
 namespace ggnn {
@@ -30,6 +32,49 @@ __global__ __launch_bounds__(256) void step_update_kernel(
     x[4] = dv;           // :507
     x[f_grain - 1] = da;  // :511
     if (g == 0) flags[1] = z > zmax ? 1 : 0;  // test.py:405
+  }
+}
+
+// One thread per grain: walk the grain's junctions (CSR row of the joint->grain edge type),
+// min-image each to the previous moved one, shift by +1 where any vertex is below -eps, mean.
+// ~6 junctions x 8 B per grain: the launch is latency-, not bandwidth-bound.
+__global__ __launch_bounds__(256) void grain_centres_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ x_joint, int64_t ldxj, const float* __restrict__ offset,
+    float factor, float* __restrict__ x_grain, int64_t ldxg, int64_t n_grain, int64_t n_joint) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n_grain) return;
+  const int p0 = rowptr[g], p1 = rowptr[g + 1];
+  if (p1 - p0 <= 1) return;  // graph_datastruct.py:685: such a region keeps its centre
+  const bool folded = factor > 1.0f;
+  float prev[2], sum[2] = {0.f, 0.f}, lo[2] = {INFINITY, INFINITY};
+  for (int p = p0; p < p1; ++p) {
+    const int64_t j = min((int64_t)max(col[p], 0), n_joint - 1);
+    float v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t = x_joint[j * ldxj + c];
+      if (folded) t = (t + (offset ? offset[2 * j + c] : 0.f)) / factor;  // test.py:474
+      if (p > p0) {  // periodic_move, graph_datastruct.py:55-72
+        const float rel = t - prev[c];
+        t += rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
+      }
+      v[c] = t;
+      prev[c] = t;
+      sum[c] += t;
+      lo[c] = fminf(lo[c], t);
+    }
+  }
+  const float inv = 1.0f / (float)(p1 - p0);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float m = sum[c] * inv;
+    if (!(lo[c] > -1e-12f)) m += 1.0f;  // inbound test, graph_datastruct.py:696-704
+    if (folded) {                        // test.py:558-559
+      m *= factor;
+      m -= floorf(m);
+    }
+    x_grain[g * ldxg + c] = m;
   }
 }
 
@@ -92,6 +137,22 @@ extern "C" int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joi
   hipLaunchKernelGGL(step_update_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                      x_joint, n_joint, ldx_joint, x_grain, n_grain, ldx_grain, f_grain, y_joint,
                      y_grain, dz, zmax, flags);
+  return launch_status();
+}
+
+extern "C" int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x_joint,
+                                  int64_t n_joint, int64_t ldx_joint, const float* domain_offset,
+                                  float domain_factor, float* x_grain, int64_t n_grain,
+                                  int64_t ldx_grain, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!rowptr || !col || !x_joint || !x_grain) return GGNN_EINVAL;
+  if (n_joint <= 0 || n_grain <= 0 || ldx_joint < 2 || ldx_grain < 2) return GGNN_EINVAL;
+  if (!(domain_factor >= 1.0f)) return GGNN_EINVAL;
+  const int64_t nblk = (n_grain + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(grain_centres_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     rowptr, col, x_joint, ldx_joint, domain_offset, domain_factor, x_grain,
+                     ldx_grain, n_grain, n_joint);
   return launch_status();
 }
 

@@ -2,12 +2,12 @@
 runs per step kept on the device.
 
 One step = Rmodel.forward + Cmodel.forward (test.py:382-383) + Rmodel.update (:400)
-+ z advance and clamp (:401-407) + edge-length refresh (:562-575).  Grain-event / edge-event
-topology surgery (Cmodel.update, :426) and the polygon geometry of traj.GNN_update (:478)
-are host code outside this path; the topology is therefore static here and the grain
-centres x_grain[:, :2] are not refreshed.
++ z advance and clamp (:401-407) + [grain-centre refresh, :468-478 + :556-559 via
+graph.update(), when `refresh_centres=True`] + edge-length refresh (:562-575).  Grain-event /
+edge-event topology surgery (Cmodel.update, :426) is host code outside this path; the topology
+is therefore static here.
 
-The whole step is 35 kernel launches with no host synchronisation and no allocation, so it
+The whole step is ~35 kernel launches with no host synchronisation and no allocation, so it
 can be replayed from a hipGraph (`use_graph=True`) to remove launch overhead on small graphs.
 """
 from typing import Dict, Optional
@@ -27,7 +27,12 @@ ET_JJ = ("joint", "connect", "joint")
 class GrainRollout:
     def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
                  edge_attr_dict, span: int, use_graph: bool = False, concurrent: bool = True,
-                 phase_shift: bool = False):
+                 phase_shift: bool = False, refresh_centres: bool = False,
+                 domain_factor: float = 1.0, domain_offset: Optional[torch.Tensor] = None):
+        """refresh_centres: also recompute x_grain[:, :2] from the junction polygons every step,
+        like the reference's traj.GNN_update + test.py:556-559 (default off = the static-geometry
+        goldens).  domain_factor / domain_offset: `geometry_scaling` of test.py:310-312 when the
+        domain was folded by scale_feature_patchs (offset [n_joint, 2], floor of the scaled xy)."""
         self.be = default_backend()
         self.rmodel, self.cmodel = rmodel, cmodel
         self.x = {nt: x_dict[nt] for nt in NODE_TYPES}  # mutated in place, like the reference
@@ -70,6 +75,13 @@ class GrainRollout:
         self.concurrent = concurrent
         self.phase_shift = phase_shift
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if concurrent else None
+        self.refresh_centres = refresh_centres
+        self.domain_factor = float(domain_factor)
+        self.domain_offset = None
+        if refresh_centres and self.domain_factor > 1:
+            if domain_offset is None:
+                raise _lib.GGNNError("domain_factor > 1 needs domain_offset")
+            self.domain_offset = domain_offset.to(dev, torch.float32).contiguous()
         self.steps_done = 0
         self._graph_exec = None
         if use_graph:
@@ -112,6 +124,9 @@ class GrainRollout:
             for st in self._side:
                 main.wait_stream(st)
         be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+        if self.refresh_centres:
+            be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
+                             self.domain_factor, self.domain_offset)
         be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
                         [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et]) for et in EDGE_TYPES])
 

@@ -44,10 +44,27 @@ def edge_lengths(x_dict, edge_index_dict):
     return out
 
 
-def honeycomb(n: int = 100, fold: int = 10, seed: int = 0, shuffle_edges: bool = True):
+def scale_feature_patchs(factor: float, x, ea):
+    """Host-side data preparation of test.py:29-55 (periodic BC) on numpy fp32 dicts, in place:
+    fold a `factor`-times larger domain onto unit training-size patches.  Returns the
+    junctions' `domain_offset` [n_joint, 2] that the grain-centre refresh needs (test.py:474)."""
+    f = np.float32(factor)
+    for et in ea:
+        ea[et] *= f
+    x["grain"][:, :2] *= f
+    x["joint"][:, :2] *= f
+    domain_offset = np.floor(x["joint"][:, :2])
+    x["joint"][:, :2] -= domain_offset
+    x["grain"][:, :2] -= x["grain"][:, :2] - np.mod(x["grain"][:, :2], np.float32(1))
+    return domain_offset.astype(np.float32)
+
+
+def honeycomb(n: int = 100, fold: int = 10, seed: int = 0, shuffle_edges: bool = True,
+              return_offset: bool = False):
     """Periodic honeycomb with n x n grains (n even).  Returns numpy dicts
     (x_dict, edge_index_dict, edge_attr_dict) after integer patch folding by `fold`
-    (test.py:29-55: xy <- (xy * fold) mod 1), ready for torch.from_numpy."""
+    (test.py:29-55: xy <- (xy * fold) mod 1), ready for torch.from_numpy; with
+    `return_offset` also the junctions' domain_offset = floor(xy * fold) [n_joint, 2]."""
     if n % 2 or n < 4:
         raise ValueError("n must be even and >= 4")
     rs = np.random.RandomState(seed)
@@ -100,6 +117,8 @@ def honeycomb(n: int = 100, fold: int = 10, seed: int = 0, shuffle_edges: bool =
     fj[:, 3], fj[:, 4], fj[:, 5] = 0.0, 1.0, 6 / 120
     x = {"grain": fg.astype(np.float32), "joint": fj.astype(np.float32)}
     ea = edge_lengths({k: v.astype(np.float64) for k, v in x.items()}, ei)
+    if return_offset:
+        return x, ei, ea, np.floor(xj * fold).astype(np.float32)
     return x, ei, ea
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 4
+#define GGNN_ABI_VERSION 5
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
@@ -219,6 +219,20 @@ int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* 
                      int64_t n_grain, int64_t ldx_grain, int f_grain, const float* y_joint,
                      const float* y_grain, float dz, float zmax, int32_t* flags,
                      ggnn_stream_t stream);
+/* Grain-centre refresh: replaces traj.GNN_update -> graph.update()
+ * (graph_trajectory.py:1010-1085, graph_datastruct.py:681-708; periodic BC) + the write-back of
+ * test.py:556-559.  For every grain with >= 2 junctions (CSR row of the joint->grain edge type
+ * from ggnn_build_csr): junction xy, brought to the global frame ((x + domain_offset[j]) /
+ * domain_factor when domain_factor > 1, test.py:474), are chained by min-image to the previous
+ * junction, shifted by +1 in a coordinate where any of them is below -1e-12, and averaged;
+ * x_grain[g, 0:2] = centre, or frac(centre * domain_factor) when domain_factor > 1.
+ * fp32 (the reference's numpy scalars promote to fp64: differences are <= 1 ulp of fp32).
+ * domain_offset: [n_joint, 2] or NULL (= 0).  Runs between ggnn_step_update and
+ * ggnn_step_refresh so that the refreshed edge lengths see the new centres. */
+int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x_joint,
+                       int64_t n_joint, int64_t ldx_joint, const float* domain_offset,
+                       float domain_factor, float* x_grain, int64_t n_grain, int64_t ldx_grain,
+                       ggnn_stream_t stream);
 typedef struct ggnn_refresh_edge {
   const int64_t* edge_index; /* [2, E] */
   const float* x_src;

@@ -286,12 +286,68 @@ def scale_feature_patchs(factor, x_dict, edge_attr_dict):
     return domain_offset, grain_coor_offset
 
 
+def grain_centres(x_joint_global, gj_edge_index, n_grain):
+    """graph_datastruct.py:654-708 (`graph.update`, periodic BC) restated for tensors.  Junction
+    order inside a grain is the reference's: `joint2vertex` as `GNN_update(topo=True)` rebuilds it
+    (graph_trajectory.py:1066-1085) = junctions in order of first appearance in the grain->joint
+    edge list.  Each junction is min-imaged to the PREVIOUS (already moved) one (`periodic_move`,
+    :55-72), 1 is added to a coordinate if any vertex of the grain has it below -eps (:698-704),
+    then the mean.  Arithmetic types follow the reference's numpy scalars: the vertices are
+    float32 (rows of x_dict['joint'].numpy(), graph_trajectory.py:1021,1038); `periodic_move`
+    adds an int64 to them, which promotes every vertex but the first to float64, and np.mean of
+    the mixed list is float64.  Returns [n_grain, 2] float64; grains with <= 1 junction are NaN
+    (the reference skips them, :685)."""
+    import numpy as np
+    eps = 1e-12  # graph_datastruct.py:36
+    xj = x_joint_global.detach().numpy().astype(np.float32)
+    tri = {}
+    for g, j in zip(gj_edge_index[0].tolist(), gj_edge_index[1].tolist()):
+        tri.setdefault(j, set()).add(g)
+    members = [[] for _ in range(n_grain)]
+    for j in tri:                      # dict order = first appearance
+        for g in tri[j]:
+            members[g].append(j)
+    out = np.full((n_grain, 2), np.nan)
+    for g, js in enumerate(members):
+        if len(js) <= 1:
+            continue
+        verts = [[xj[js[0], 0], xj[js[0], 1]]]
+        for j in js[1:]:
+            p = []
+            for d in (0, 1):
+                rel = xj[j, d] - verts[-1][d]
+                p.append(xj[j, d] + np.int64(-1 * (rel > 0.5) + 1 * (rel < -0.5)))
+            verts.append(p)
+        inbound = [all(v[d] > -eps for v in verts) for d in (0, 1)]
+        moved = [[v[d] + 1 * (not inbound[d]) for d in (0, 1)] for v in verts]
+        out[g] = [np.mean([v[0] for v in moved]), np.mean([v[1] for v in moved])]
+    return torch.from_numpy(out)
+
+
+def refresh_grain_centres(x_dict, edge_index_dict, domain_factor=1.0, domain_offset=None):
+    """test.py:468-478 + 556-559: junction coordinates back to the global frame
+    ((x + domain_offset) / domain_factor when the domain was folded), region centres from
+    `graph.update`, written to x_grain[:, :2] ((c * domain_factor) % 1 when folded)."""
+    xj = x_dict["joint"][:, :2]
+    if domain_factor > 1:
+        xj = (xj + domain_offset) / domain_factor
+    c = grain_centres(xj, edge_index_dict[("grain", "push", "joint")], x_dict["grain"].size(0))
+    c = c.float()  # torch.FloatTensor(coor), test.py:557
+    if domain_factor > 1:
+        c = (c * domain_factor) % 1
+    ok = ~torch.isnan(c[:, 0])
+    x_dict["grain"][ok, :2] = c[ok]
+
+
 @torch.no_grad()
-def rollout_step(rmodel, cmodel, x_dict, edge_index_dict, edge_attr_dict, span):
+def rollout_step(rmodel, cmodel, x_dict, edge_index_dict, edge_attr_dict, span, centres=None):
     """One static-topology rollout step: R.forward + C.forward + R.update + z advance +
+    [grain-centre refresh when `centres` = (domain_factor, domain_offset) is given] +
     edge-length refresh.  Mutates x_dict in place; returns (pred, new edge_attr_dict)."""
     pred = rmodel(x_dict, edge_index_dict, edge_attr_dict)       # test.py:382
     pred.update(cmodel(x_dict, edge_index_dict, edge_attr_dict))  # :383-384
     rmodel.update(x_dict, pred, None)                             # :400
     advance_z(x_dict, span)                                       # :401-407
+    if centres is not None:                                       # :468-478, 556-559
+        refresh_grain_centres(x_dict, edge_index_dict, *centres)
     return pred, refresh_edge_attr(x_dict, edge_index_dict)       # :562-575

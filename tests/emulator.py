@@ -137,6 +137,27 @@ class TorchEmulatorBackend:
         x_grain[:, 2] += dz
         flags[1] = int(x_grain[0, 2] > torch.tensor(zmax, dtype=torch.float32))
 
+    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None):
+        rowptr, col = csr_jg.rowptr.tolist(), csr_jg.col.tolist()
+        f = torch.tensor(domain_factor, dtype=torch.float32)
+        xy = x_joint[:, :2].clone()
+        if domain_factor > 1:
+            xy = (xy + (domain_offset if domain_offset is not None else 0)) / f
+        for g in range(x_grain.size(0)):
+            js = col[rowptr[g]:rowptr[g + 1]]
+            if len(js) <= 1:
+                continue
+            v = [xy[js[0]]]
+            for j in js[1:]:
+                rel = xy[j] - v[-1]
+                v.append(xy[j] + torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)))
+            v = torch.stack(v)
+            m = v.sum(0) / len(js) + (~(v > -1e-12).all(0)).float()
+            if domain_factor > 1:
+                m = m * f
+                m = m - torch.floor(m)
+            x_grain[g, :2] = m
+
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
         if int(flags[1]):
             x_joint[:, 2] = zmax

@@ -201,6 +201,56 @@ def generate(tag, x, ei, ea, hp, seed, scale, full):
     return R, Cm
 
 
+@torch.no_grad()
+def generate_centres(x, ei, ea, mask, hp, seed, scale):
+    """f-1: the rollout loop of test.py INCLUDING traj.GNN_update -> graph.update() ->
+    region_center -> x_grain[:, :2] (test.py:468-478, 556-559), driven by the reference's own
+    graph_trajectory object (graphs/40_40/traj10020.pkl.gz).  Cmodel.update (topology surgery,
+    SURVEY 8f-2) is skipped like in `generate` (4): topo=False, static connectivity."""
+    import gzip
+    import __main__
+    import graph_trajectory as gt
+    __main__.graph_trajectory, __main__.graph = gt.graph_trajectory, gt.graph
+    with gzip.open(os.path.join(REF, "graphs/40_40/traj10020.pkl.gz"), "rb") as f:
+        traj = dill.load(f)
+    traj.raise_err = False
+    R, Cm = build_reference(hp, x, ei, ea, seed, scale)
+    oR, oC = build_oracle(hp, seed, scale)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    oX, oEA = tt(x), tt(ea)
+    M = {k: torch.from_numpy(v.copy()) for k, v in mask.items()}
+    M["joint"] = 1 + 0 * M["joint"]                               # test.py:258
+    traj.extraV_traj, traj.area_traj = [], traj.area_traj[:1]
+    traj.GNN_update(0, {k: v.clone() for k, v in X.items()}, M, True, EI, False)   # test.py:266
+    c0 = np.array([traj.region_center[g + 1] for g in range(x["grain"].shape[0])])
+    out = {"init_region_center": c0}
+    pin("centres/init", oracle.grain_centres(X["joint"][:, :2], EI[GJ], x["grain"].shape[0]).numpy(), c0, tol=0.0)
+    for step in range(1, 4):
+        pred = R(X, EI, EA)
+        pred.update(Cm(X, EI, EA))
+        R.update(X, pred, {})
+        X["grain"][:, 2] += SPAN / 121
+        X["joint"][:, 2] += SPAN / 121
+        traj.GNN_update(step * SPAN, {k: v.clone() for k, v in X.items()}, M, False, EI, False)  # :478
+        for grain, coor in traj.region_center.items():            # test.py:556-559
+            X["grain"][grain - 1, :2] = torch.FloatTensor(coor)
+        EA = {}
+        for edge_type, index in EI.items():                       # test.py:562-575
+            rel_loc = X[edge_type[0]][index[0], :2] - X[edge_type[-1]][index[-1], :2]
+            rel_loc = -1 * (rel_loc > 0.5) + 1 * (rel_loc < -0.5) + rel_loc
+            EA[edge_type] = torch.sqrt(rel_loc[:, 0] ** 2 + rel_loc[:, 1] ** 2).view(-1, 1)
+        _, oEA = oracle.rollout_step(oR, oC, oX, EI, oEA, SPAN, centres=(1.0, None))
+        if step in (1, 3):
+            for nt in x:
+                out[f"step{step}_x_{nt}"] = X[nt].numpy().copy()
+                pin(f"centres/step{step}/x/{nt}", oX[nt].numpy(), X[nt].numpy(), tol=1e-5)
+            for et in ETS:
+                out[f"step{step}_ea_" + "__".join(et)] = EA[et].numpy().copy()
+                pin(f"centres/step{step}/ea/{et}", oEA[et].numpy(), EA[et].numpy(), tol=1e-5)
+    out["meta"] = np.array([seed, scale, 3, SPAN], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "golden_cfg1_centres.npz"), **out)
+
+
 def main():
     g40, x40, ei40, ea40 = load_graph(os.path.join(REF, "graphs/40_40/seed10020_G1.904_R0.558_span6.pkl"))
     g120, x120, ei120, ea120 = load_graph(os.path.join(REF, "graphs/120_120/seed0_G10.0_R2.0_span6.pkl"))
@@ -221,6 +271,8 @@ def main():
         json.dump(keys, f, indent=0, sort_keys=True)
 
     generate("cfg1_s3", x40, ei40, ea40, hp, 10020, 3.0, full=False)
+    mask40 = {k: np.asarray(v).astype(np.int64) for k, v in g40.mask.items()}
+    generate_centres(x40, ei40, ea40, mask40, hp, 10020, 1.0)
 
     # cfg2: x3 patch folding with the reference's own function (test.py:29-55, 310-312)
     X, EA = tt(x120), tt(ea120)

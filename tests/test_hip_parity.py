@@ -22,7 +22,7 @@ def backend():
 
 def test_library_is_loaded_from_the_tree():
     be = backend()
-    assert be.lib.ggnn_version() == 4
+    assert be.lib.ggnn_version() == _lib.GGNN_ABI_VERSION
     assert _lib.LIB_PATH.endswith("graingraphnn_amd/libggnn.so")
 
 
@@ -324,6 +324,89 @@ def test_cfg3_full_size_step_and_properties():
     Ka = 196
     sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, Ka)[:, :, 192::2]
     assert float((sa - 1).abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# on-device grain-centre refresh (graph.update() + test.py:556-559)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_graph", [False, True])
+@torch.no_grad()
+def test_rollout_with_grain_centres_golden(use_graph):
+    """Against vectors the reference's own graph_trajectory.GNN_update produced."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_centres")
+    R, Cm = product_models(10020, 1.0, DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=use_graph, refresh_centres=True)
+    for step in range(1, 4):
+        ro.step()
+        if step in (1, 3):
+            for nt in x:
+                assert_close(X[nt], g[f"step{step}_x_{nt}"], f"centres step{step} x {nt}")
+            for et in EDGE_TYPES:
+                assert_close(ro.edge_attr_dict()[et], g[f"step{step}_ea_{etk(et)}"],
+                             f"centres step{step} edge_attr {et}")
+
+
+@torch.no_grad()
+def test_grain_centres_folded_domain_rollout_against_oracle():
+    """cfg2 (x3 folded domain): the centre refresh goes through the global frame
+    (test.py:474) and folds back with (c * 3) % 1 (test.py:558-559)."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("120")
+    oX, oEA, oEI = tt(x), tt(ea), tt(ei)
+    off, _ = oracle.scale_feature_patchs(3.0, oX, oEA)
+    X = {k: v.clone().to(DEV) for k, v in oX.items()}
+    EA = {k: v.clone().to(DEV) for k, v in oEA.items()}
+    R, Cm = product_models(0, 1.0, DEV)
+    oR, oC = oracle_models(0, 1.0)
+    ro = GrainRollout(R, Cm, X, tt(ei, DEV), EA, 6, refresh_centres=True, domain_factor=3.0,
+                      domain_offset=off)
+    for step in range(5):
+        ro.step()
+        _, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6, centres=(3.0, off))
+    assert_close(X["joint"], oX["joint"], "folded centres x joint")
+    assert_close(X["grain"][:, 2:], oX["grain"][:, 2:], "folded centres x grain[2:]")
+    d = (X["grain"][:, :2].cpu() - oX["grain"][:, :2]).abs()
+    assert float(torch.minimum(d, 1 - d).max()) < 1e-4   # frac() may land on either side of 0/1
+    for et in EDGE_TYPES:
+        assert_close(ro.edge_attr_dict()[et], oEA[et], f"folded centres edge_attr {et}")
+
+
+@torch.no_grad()
+def test_grain_centres_full_size_and_edge_cases():
+    """cfg3 size against the oracle, COO-order independence, straddling grains, rows with
+    0 / 1 junctions keep their centre, invalid arguments are refused."""
+    be = backend()
+    x, ei, _ = synthetic.honeycomb(100, 10, 0)
+    rs = np.random.RandomState(4)
+    xj = x["joint"].copy()
+    xj[:, :2] = (xj[:, :2] + rs.normal(0, 2e-3, (xj.shape[0], 2)) + [0.4031, 0.7717]) % 1
+    Xj, Xg = torch.from_numpy(xj).to(DEV), torch.from_numpy(x["grain"].copy()).to(DEV)
+    n_g, n_j = Xg.size(0), Xj.size(0)
+    csr = be.build_csr(torch.from_numpy(ei[JG]).to(DEV), n_j, n_g)
+    be.grain_centres(csr, Xj, Xg)
+    ref = oracle.grain_centres(torch.from_numpy(xj[:, :2]), torch.from_numpy(ei[GJ]), n_g)
+    assert_close(Xg[:, :2], ref.float(), "cfg3 grain centres", 1e-6)
+    assert torch.equal(Xg[:, 2:].cpu(), torch.from_numpy(x["grain"][:, 2:]))
+    perm = rs.permutation(ei[JG].shape[1])
+    Xg2 = torch.from_numpy(x["grain"].copy()).to(DEV)
+    be.grain_centres(be.build_csr(torch.from_numpy(ei[JG][:, perm]).to(DEV), n_j, n_g), Xj, Xg2)
+    assert_close(Xg2[:, :2], Xg[:, :2], "cfg3 grain centres, permuted COO", 1e-6)
+    # grains with 0 and 1 junctions keep their centre (graph_datastruct.py:685)
+    e = torch.tensor([[0, 1, 2, 3], [0, 0, 0, 2]], dtype=torch.int64, device=DEV)
+    xj3 = torch.tensor([[0.98, 0.5], [0.02, 0.52], [0.01, 0.47], [0.3, 0.3]], device=DEV)
+    xg3 = torch.full((3, 4), 7.0, device=DEV)
+    be.grain_centres(be.build_csr(e, 4, 3), xj3, xg3)
+    got = xg3.cpu()
+    assert torch.equal(got[1:], torch.full((2, 4), 7.0))
+    assert_close(got[0, :2], torch.tensor([(0.98 + 1.02 + 1.01) / 3, (0.5 + 0.52 + 0.47) / 3]),
+                 "straddling grain", 1e-6)
+    with pytest.raises(_lib.GGNNError):
+        be.grain_centres(csr, Xj, Xg, 3.0, None)
+    with pytest.raises(_lib.GGNNError):
+        be.grain_centres(csr, Xj.cpu(), Xg)
 
 
 # ---------------------------------------------------------------------------------------

@@ -192,6 +192,62 @@ def test_step_glue_matches_golden():
         assert_close(EA[et].view(-1, 1), g["step1_ea_" + etk(et)], f"step1 ea {et}", TOL)
 
 
+@torch.no_grad()
+def test_grain_centre_glue_matches_golden_and_oracle():
+    """SURVEY 8f-1 host contract: step_update -> grain_centres -> step_refresh reproduces the
+    reference-generated golden; the folded-domain (factor 3) variant matches the oracle."""
+    x, ei, ea = load_graph("40")
+    g, gc = golden("cfg1_s1"), golden("cfg1_centres")
+    be = TorchEmulatorBackend()
+    X, EI = tt(x), tt(ei)
+    yj, yg = torch.from_numpy(g["R_joint"].copy()), torch.from_numpy(g["R_grain"].copy())
+    flags = torch.zeros(2, dtype=torch.int32)
+    dz, zmax = float(np.float32(6 / 121)), float(np.float32(120 / 121))
+    be.step_update(X["joint"], X["grain"], yj, yg, dz, zmax, flags)
+    csr = be.build_csr(EI[EDGE_TYPES[1]], 236, 118)
+    be.grain_centres(csr, X["joint"], X["grain"])
+    EA = {et: torch.empty(EI[et].size(1)) for et in EDGE_TYPES}
+    be.step_refresh(X["joint"], X["grain"], zmax, flags,
+                    [(EI[et], X[et[0]], X[et[-1]], EA[et]) for et in EDGE_TYPES])
+    for nt in x:
+        assert_close(X[nt], gc[f"step1_x_{nt}"], f"centres step1 x {nt}", TOL)
+    for et in EDGE_TYPES:
+        assert_close(EA[et].view(-1, 1), gc["step1_ea_" + etk(et)], f"centres step1 ea {et}", TOL)
+
+    x, ei, ea = load_graph("120")
+    X, EA = tt(x), tt(ea)
+    off, _ = oracle.scale_feature_patchs(3.0, X, EA)
+    X["joint"][:, :2] += 0.01 * torch.randn(X["joint"].size(0), 2, generator=torch.Generator().manual_seed(1))
+    EI = tt(ei)
+    oX = {k: v.clone() for k, v in X.items()}
+    oracle.refresh_grain_centres(oX, EI, 3.0, off)
+    csr = be.build_csr(EI[EDGE_TYPES[1]], X["joint"].size(0), X["grain"].size(0))
+    be.grain_centres(csr, X["joint"], X["grain"], 3.0, off)
+    d = (X["grain"][:, :2] - oX["grain"][:, :2]).abs()
+    assert float(torch.minimum(d, 1 - d).max()) < 1e-5     # frac() may land on either side of 0/1
+
+
+def test_patch_folding_matches_oracle_and_honeycomb_offset():
+    """synthetic.scale_feature_patchs (host data prep, numpy) == the oracle's restatement of
+    test.py:29-55; honeycomb's domain_offset undoes its folding."""
+    x, ei, ea = load_graph("120")
+    oX, oEA = tt(x), tt(ea)
+    ooff, _ = oracle.scale_feature_patchs(3.0, oX, oEA)
+    x2, ea2 = {k: v.copy() for k, v in x.items()}, {k: v.copy() for k, v in ea.items()}
+    off = synthetic.scale_feature_patchs(3.0, x2, ea2)
+    assert np.array_equal(off, ooff.numpy())
+    for nt in x:
+        assert np.array_equal(x2[nt], oX[nt].numpy()), nt
+    for et in EDGE_TYPES:
+        assert np.array_equal(ea2[et], oEA[et].numpy()), et
+    xh, eih, _, offh = synthetic.honeycomb(8, 2, 0, return_offset=True)
+    assert set(np.unique(offh)) <= {0.0, 1.0}
+    xg = (xh["joint"][:, :2] + offh) / 2
+    c = oracle.grain_centres(torch.from_numpy(xg), torch.from_numpy(eih[EDGE_TYPES[0]]), 64).numpy()
+    d = np.abs((c * 2) % 1 - xh["grain"][:, :2])
+    assert np.minimum(d, 1 - d).max() < 1e-5    # honeycomb grain centres are the polygon means
+
+
 def test_seeding_is_deterministic_and_order_free():
     shapes = {"b": (4, 9), "a": (5,), "c.weight": (96, 1)}
     s1 = seeded_state_dict(shapes, 5)

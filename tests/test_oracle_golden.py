@@ -80,6 +80,44 @@ def test_forward_and_rollout(tag, seed, scale):
                 assert_close(EA[et], g[f"step{step}_ea_{etk(et)}"], f"{tag} step{step} ea {et}", 1e-4)
 
 
+@torch.no_grad()
+def test_rollout_with_grain_centres():
+    """vectors produced by the reference's own graph_trajectory.GNN_update /
+    graph.update() driven from graphs/40_40/traj10020.pkl.gz (make_golden.generate_centres)."""
+    x, ei, ea = load_graph("40")
+    g = golden("cfg1_centres")
+    R, Cm = oracle_models(10020, 1.0)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    c0 = oracle.grain_centres(X["joint"][:, :2], EI[EDGE_TYPES[0]], X["grain"].size(0)).numpy()
+    assert np.array_equal(c0, g["init_region_center"])          # float64, bit-exact
+    for step in range(1, 4):
+        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, 6, centres=(1.0, None))
+        if step in (1, 3):
+            for nt in x:
+                assert_close(X[nt], g[f"step{step}_x_{nt}"], f"centres step{step} x {nt}", 1e-4)
+            for et in EDGE_TYPES:
+                assert_close(EA[et], g[f"step{step}_ea_{etk(et)}"], f"centres step{step} ea {et}", 1e-4)
+    # the centres really moved (this golden is not the static-geometry one)
+    assert np.abs(g["step3_x_grain"][:, :2] - x["grain"][:, :2]).max() > 1e-3
+
+
+def test_grain_centres_order_and_wrap_properties():
+    """Centres do not depend on which junction starts the chain, land in (-eps, 2) and follow a
+    rigid periodic shift of the junctions (a grain straddling the boundary is handled by the
+    +1 rule of graph_datastruct.py:696-704)."""
+    x, ei, _ = load_graph("40")
+    gj = torch.from_numpy(ei[EDGE_TYPES[0]])
+    xy = torch.from_numpy(x["joint"][:, :2].copy())
+    c = oracle.grain_centres(xy, gj, 118).numpy()
+    perm = torch.randperm(gj.size(1), generator=torch.Generator().manual_seed(3))
+    assert np.abs(oracle.grain_centres(xy, gj[:, perm], 118).numpy() - c).max() < 1e-6
+    assert (c > -1e-12).all() and (c < 2).all()
+    shifted = (xy + torch.tensor([0.37, 0.61])) % 1
+    cs = oracle.grain_centres(shifted, gj, 118).numpy()
+    d = (cs - c - np.array([0.37, 0.61])) % 1
+    assert np.minimum(d, 1 - d).max() < 1e-6
+
+
 def test_fixture_invariants():
     """graph_trajectory.py:985-988: every junction has exactly 3 grain and 3 junction
     neighbours; E = 3 N_j for all three edge types; N_j = 2 N_g on the torus."""
