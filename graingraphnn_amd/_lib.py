@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 5
+GGNN_ABI_VERSION = 7
 GGNN_ENC_W_ROW = 40
 GGNN_UNIT_EDGES = 3
 GGNN_C = 96
@@ -22,7 +22,7 @@ MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
 EXPORTED_SYMBOLS = (
-    "ggnn_version", "ggnn_error_string", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
+    "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_period_gat_aggregate_enc", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_step_refresh",
@@ -77,6 +77,7 @@ class EpilogueArgs(Structure):
         ("h_out", c_void_p), ("c_out", c_void_p), ("raw_out", c_void_p),
         ("ldp", c_int64), ("N", c_int64),
         ("Ka", c_int32), ("s_off", c_int32), ("n_gates", c_int32), ("mode", c_int32),
+        ("w2_planes", c_void_p), ("ld_agg", c_int64), ("g_stride", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -95,6 +96,8 @@ _lib = None
 def _declare(lib):
     lib.ggnn_version.restype = c_int
     lib.ggnn_version.argtypes = []
+    lib.ggnn_gemm_mode.restype = c_int
+    lib.ggnn_gemm_mode.argtypes = []
     lib.ggnn_error_string.restype = c_char_p
     lib.ggnn_error_string.argtypes = [c_int]
     lib.ggnn_csr_workspace_bytes.restype = c_size_t

@@ -120,8 +120,10 @@ class HipBackend:
               "ggnn_period_gat_aggregate_enc")
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
-    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode):
-        _require_cuda(agg, w2, p_dst, c_in, h_out, c_out, raw_out)
+    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
+                      w2_planes=None, g_stride=0):
+        """w2_planes: packing.bf16_planes(w2) (selects the bf16x6 kernel unless GGNN_GEMM=fp32)."""
+        _require_cuda(agg, w2, p_dst, c_in, h_out, c_out, raw_out, w2_planes)
         a = EpilogueArgs()
         a.agg, a.w2, a.p_dst = agg.data_ptr(), w2.data_ptr(), p_dst.data_ptr()
         a.c_in = None if c_in is None else c_in.data_ptr()
@@ -130,6 +132,12 @@ class HipBackend:
         a.raw_out = None if raw_out is None else raw_out.data_ptr()
         a.ldp, a.N = p_dst.stride(0), agg.size(0)
         a.Ka, a.s_off, a.n_gates, a.mode = w2.size(2), s_off, n_gates, mode
+        if g_stride:  # agg gate stride (floats) when the rows are padded; 0 = packed [N, n_gates * Ka]
+            a.g_stride, a.ld_agg = g_stride, agg.stride(0)
+        if w2_planes is not None:
+            if w2_planes.dtype != torch.int16 or w2_planes.numel() != 3 * w2.size(0) * _lib.GGNN_C * (w2.size(2) - 4):
+                raise _lib.GGNNError("w2_planes does not match w2 (see packing.bf16_planes)")
+            a.w2_planes = w2_planes.data_ptr()
         check(self.lib.ggnn_lstm_epilogue(ctypes.byref(a), _lib.current_stream()),
               "ggnn_lstm_epilogue")
 

@@ -1,7 +1,19 @@
 // Version / error strings / workspace sizing of libggnn.
 #include "common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 extern "C" int ggnn_version(void) { return GGNN_ABI_VERSION; }
+
+int ggnn::gemm_mode() {
+  static const int mode = [] {
+    const char* e = std::getenv("GGNN_GEMM");
+    return (e && std::strcmp(e, "fp32") == 0) ? GGNN_GEMM_FP32 : GGNN_GEMM_BF16X6;
+  }();
+  return mode;
+}
+extern "C" int ggnn_gemm_mode(void) { return ggnn::gemm_mode(); }
 
 extern "C" const char* ggnn_error_string(int code) {
   switch (code) {

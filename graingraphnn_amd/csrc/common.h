@@ -11,6 +11,11 @@ constexpr int C = GGNN_C;  // 96 hidden channels
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// How the K >= 100 GEMMs (decoder projection, gate epilogue) run: GGNN_GEMM=fp32 in the
+// environment selects the native v_mfma_f32_16x16x4_f32 kernels, anything else (default) the
+// 3 x bf16 split kernels.  Read once per process.
+int gemm_mode();
+
 static inline int launch_status() {
   return hipGetLastError() == hipSuccess ? GGNN_OK : GGNN_ELAUNCH;
 }
@@ -34,6 +39,47 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2 / (1 + exp(2x)); exp overflow -> rcp(inf) = 0 -> 1, underflow -> -1
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+
+// ---- fp32 GEMMs on the bf16 matrix cores: exact 3-way split + 6 products ----------------
+// x = hi + mid + lo EXACTLY (three round-to-nearest bf16 pieces hold the 24-bit significand),
+// and  x*w = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi  up to the three dropped
+// products mid*lo, lo*mid, lo*lo <= 2^-25 |x*w|: below one fp32 rounding of the product.  Every
+// kept product of two 8-bit significands is exact in the fp32 accumulator, so the result is
+// fp32-equivalent (tests compare both GEMM modes with an fp64 product) at 6/16 of the MFMA
+// cycles of v_mfma_f32_16x16x4_f32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+  const f32x2_ v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+// two fp32 values -> three dwords of packed (a, b) bf16 pieces
+__device__ __forceinline__ void split_bf16x3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = pack_bf16(a, b);
+  a -= __uint_as_float(hi << 16);
+  b -= __uint_as_float(hi & 0xffff0000u);
+  mid = pack_bf16(a, b);
+  a -= __uint_as_float(mid << 16);
+  b -= __uint_as_float(mid & 0xffff0000u);
+  lo = pack_bf16(a, b);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// all six kept products of one k-step, smallest first
+__device__ __forceinline__ f32x4 mfma_x6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x4 c) {
+  c = mfma_bf16(w[0], x[2], c);
+  c = mfma_bf16(w[2], x[0], c);
+  c = mfma_bf16(w[1], x[1], c);
+  c = mfma_bf16(w[0], x[1], c);
+  c = mfma_bf16(w[1], x[0], c);
+  c = mfma_bf16(w[0], x[0], c);
+  return c;
 }
 
 struct f3 {

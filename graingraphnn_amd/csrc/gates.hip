@@ -45,7 +45,7 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave / 3, third = wave - 3 * rg;  // row group, channel third
   const int ng = nthr / 192;                        // row groups in this workgroup
-  constexpr int64_t ld_agg = (int64_t)G * KA;
+  const int64_t ld_agg = A.ld_agg;
   const int64_t m0 = ((int64_t)blockIdx.x * ng + rg) * GT_BM;  // first node of this row group
   const int lr = lane & 15, lq = lane >> 4;
   const int t192 = tid - rg * 192;  // index inside the row group's three waves
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
     for (int it = 0; it < NA; ++it) {
       const int idx = min(t192 + it * 192, GT_BM * nv - 1), r = idx / nv, c4 = idx - r * nv;
       const int64_t m = min(m0 + r, A.N - 1);
-      ra[it] = *reinterpret_cast<const f32x4*>(A.agg + m * ld_agg + g * KA + kb + 4 * c4);
+      ra[it] = *reinterpret_cast<const f32x4*>(A.agg + m * ld_agg + g * A.g_stride + kb + 4 * c4);
     }
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
@@ -181,11 +181,19 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
 
 }  // namespace ggnn
 
+int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args& A, hipStream_t s);
+
 extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!args) return GGNN_EINVAL;
-  const ggnn_epilogue_args& A = *args;
+  ggnn_epilogue_args A = *args;
   if (!A.agg || !A.w2 || !A.p_dst || A.N <= 0) return GGNN_EINVAL;
+  if (A.g_stride == 0 && A.ld_agg == 0) {  // packed layout
+    A.g_stride = A.Ka;
+    A.ld_agg = (int64_t)A.n_gates * A.Ka;
+  }
+  if (A.g_stride < A.Ka || (A.g_stride & 3) || (A.ld_agg & 3) || A.ld_agg < (int64_t)A.n_gates * A.g_stride)
+    return GGNN_EINVAL;
   if (A.Ka < 4 || (A.Ka & 3) || A.Ka > 2 * GT_KC) return GGNN_EINVAL;
   const int G = A.n_gates;
   if (A.s_off < 0 || (A.s_off & 3) || (A.ldp & 3) || A.s_off + (int64_t)G * C > A.ldp) return GGNN_EINVAL;
@@ -200,6 +208,8 @@ extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t 
   hipStream_t s = (hipStream_t)stream;
   if (A.Ka != 196 && A.Ka != 100) return GGNN_EINVAL;  // two / one incoming edge types (packing.py)
   const bool wide = A.Ka == 196;
+  const bool x6 = A.w2_planes && gemm_mode() == GGNN_GEMM_BF16X6;
+  if (x6 && !aligned16(A.w2_planes)) return GGNN_EINVAL;
 #define GGNN_GT_LAUNCH(G_, MODE_)                                                         \
   do {                                                                                    \
     if (wide) hipLaunchKernelGGL((gates_kernel<G_, MODE_, 196>), grid, block, 0, s, A);   \
@@ -208,13 +218,17 @@ extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t 
   if (A.mode == GGNN_MODE_LSTM) {
     if (G != 4 || !A.c_in || !A.h_out || !A.c_out) return GGNN_EINVAL;
     if (!aligned16(A.c_in) || !aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
+    if (x6) return ggnn_lstm_epilogue_x6(A, s);
     GGNN_GT_LAUNCH(4, GGNN_MODE_LSTM);
   } else if (A.mode == GGNN_MODE_LSTM_H0) {
     if (G != 3 || !A.h_out || !A.c_out) return GGNN_EINVAL;
     if (!aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
+    if (x6) return ggnn_lstm_epilogue_x6(A, s);
     GGNN_GT_LAUNCH(3, GGNN_MODE_LSTM_H0);
   } else if (A.mode == GGNN_MODE_RAW) {
     if (!A.raw_out || !aligned16(A.raw_out)) return GGNN_EINVAL;
+    if (G != 4 && G != 3 && G != 1) return GGNN_EINVAL;
+    if (x6) return ggnn_lstm_epilogue_x6(A, s);
     if (G == 4) GGNN_GT_LAUNCH(4, GGNN_MODE_RAW);
     else if (G == 3) GGNN_GT_LAUNCH(3, GGNN_MODE_RAW);
     else if (G == 1) GGNN_GT_LAUNCH(1, GGNN_MODE_RAW);

@@ -180,6 +180,10 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
 
 }  // namespace ggnn
 
+int ggnn_project_x6(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, const float* Wp,
+                    const float* bias, int64_t M, int ncols, float* out, int64_t ldo,
+                    int m_splits, hipStream_t s);
+
 extern "C" int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh,
                             int k2, const float* Wp, const float* bias, int64_t M, int ncols,
                             float* out, int64_t ldo, ggnn_stream_t stream) {
@@ -200,6 +204,8 @@ extern "C" int ggnn_project(const float* X, int64_t ldx, int F, const float* H, 
   if (m_splits > n_mt) m_splits = n_mt;
   const dim3 grid((unsigned)(nb_n * m_splits)), block(PJ_WAVES * 64);
   hipStream_t s = (hipStream_t)stream;
+  if (k2 != 0 && gemm_mode() == GGNN_GEMM_BF16X6)
+    return ggnn_project_x6(X, ldx, F, H, ldh, Wp, bias, M, ncols, out, ldo, (int)m_splits, s);
 #define GGNN_PJ_LAUNCH(FP_, K2_)                                                                \
   hipLaunchKernelGGL((project_kernel<FP_, K2_>), grid, block, 0, s, X, ldx, F, H, ldh, Wp, bias, \
                      M, ncols, out, ldo, (int)m_splits)

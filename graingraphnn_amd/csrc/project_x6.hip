@@ -1,0 +1,257 @@
+// Decoder projection GEMM (K = F + 96) on the bf16 matrix cores with fp32-equivalent numerics:
+//   out[M, ncols] = [X[:, :F] | H] . Wp^T + bias
+// Same contract and launch geometry as project_kernel (project.hip); the arithmetic is the exact
+// 3 x bf16 split of common.h (6 products per k-step, fp32 accumulate), which needs 4 k-steps of
+// v_mfma_f32_16x16x32_bf16 x 6 = 384 matrix-pipe cycles per 16x16 output tile instead of
+// 26 x 32 = 832 for v_mfma_f32_16x16x4_f32.  With the MFMA time more than halved the kernel sits
+// at the HBM write roofline of its 215 MB output.
+//
+// Layout of a k-step: the reduction index is re-ordered to [H 0..95 | X 0..FP-1 | zeros] so
+// that k-steps 0..2 are pure hidden state and k-step 3 holds the <= 12 features.
+//   * WEIGHTS (A operand): split once per workgroup in the prologue into three bf16 planes
+//     [96 columns][128 k] in LDS (72 KB), 256-byte rows with the 16-byte slot XOR-swizzled by
+//     (row & 15): the ds_read_b128 fragment reads (lane: row l&15, k = 32 ks + 8 (l>>4) ..+8)
+//     are bank-conflict-free.
+//   * NODES (B operand): every wave streams its own 16-node tiles: coalesced 16-byte row loads
+//     (in flight during the previous sweep) -> a wave-private fp32 LDS stage -> per-lane fragment
+//     reads (node l&15, the 8 consecutive k = 32 ks + 8 (l>>4)..) -> split into three planes in
+//     registers, where they stay for the whole 96-column sweep.  No workgroup barrier in the loop.
+#include "common.h"
+
+namespace ggnn {
+
+#ifndef PX_NWAVES
+#define PX_NWAVES 12
+#endif
+#ifndef PX_LDF
+#define PX_LDF 112
+#endif
+constexpr int PX_BM = 16, PX_BN = 96, PX_WAVES = PX_NWAVES, PX_KS = 4;
+constexpr int PX_LD = PX_LDF;  // floats per staged node row (96 + 16); 12 stages + weights = 160 128 B of LDS
+
+template <int FP>
+__global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
+    const float* __restrict__ X, int64_t ldx, int F, const float* __restrict__ H, int64_t ldh,
+    const float* __restrict__ Wp, const float* __restrict__ bias, int64_t M, int ncols,
+    float* __restrict__ out, int64_t ldo, int m_splits) {
+  constexpr int KP = FP + 96;  // row length of Wp: [X(FP) | H(96)]
+  __shared__ u32x4 s_w[3][PX_BN][16];
+  __shared__ f32x4 s_b[PX_BN / 4];
+  __shared__ int s_next;  // tile queue of the workgroup: waves take the next 16-node tile when free
+  __shared__ __attribute__((aligned(16))) float s_x[PX_WAVES][PX_BM * PX_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb_n = ncols / PX_BN;
+  const int bn = blockIdx.x % nb_n, ms = blockIdx.x / nb_n;
+  const int n0 = bn * PX_BN;
+
+#ifdef PX_VAR_CLOCK
+  const uint64_t t_p0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- prologue: split the weight tile into its three planes ----
+#pragma unroll
+  for (int it = 0; it < PX_BN * 64 / (PX_WAVES * 64); ++it) {  // 12 independent load->split->write chains
+    const int idx = tid + it * PX_WAVES * 64;
+    const int r = idx >> 6, kp = idx & 63, k = 2 * kp;  // k, k+1 never straddle a segment (96, FP even)
+    float a = 0.f, b = 0.f;
+    if (k < 96 + FP) {
+      const float* w = Wp + (int64_t)(n0 + r) * KP + (k < 96 ? FP + k : k - 96);
+      a = w[0];
+      b = w[1];
+    }
+    uint32_t p0, p1, p2;
+    split_bf16x3(a, b, p0, p1, p2);
+    const int slot = (kp >> 2) ^ (r & 15), d = kp & 3;
+    reinterpret_cast<uint32_t*>(&s_w[0][r][slot])[d] = p0;
+    reinterpret_cast<uint32_t*>(&s_w[1][r][slot])[d] = p1;
+    reinterpret_cast<uint32_t*>(&s_w[2][r][slot])[d] = p2;
+  }
+  if (tid < PX_BN / 4) s_b[tid] = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * tid);
+  if (tid == 0) s_next = PX_WAVES;
+  __syncthreads();  // the only workgroup barrier
+
+#ifdef PX_VAR_CLOCK
+  const uint64_t t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int64_t n_mt = (M + PX_BM - 1) / PX_BM;
+  const int64_t per = (n_mt + m_splits - 1) / m_splits;
+  const int64_t mt_lo = ms * per, mt_hi = min(n_mt, (ms + 1) * per);
+  if (mt_lo + wave >= mt_hi) return;
+  auto grab = [&]() {  // wave-uniform ticket
+    int v = 0;
+    if (lane == 0) v = atomicAdd(&s_next, 1);
+    return (int64_t)__builtin_amdgcn_readfirstlane(v);
+  };
+
+  // ---- node tiles: coalesced row loads -> wave-private LDS stage -> fragment reads ----
+  // (Fragment-shaped global loads -- 16 rows x 16 B per quarter-wave -- touch 64 cache lines
+  // per instruction and made the L1 tag pipe the bottleneck of the whole kernel.)
+  const int lr = lane & 15, kq = lane >> 4;
+  float* sx = s_x[wave];
+  constexpr int NH = (PX_BM * 24) / 64;        // 16-byte hidden pieces per lane per tile (6)
+  constexpr int NX = (PX_BM * FP) / 64;        // feature floats per lane per tile (1..3)
+  static_assert((PX_BM * FP) % 64 == 0, "tile / lane mismatch");
+  f32x4 gh[NH];
+  float gx[NX];
+  // Addressing: a tile's first row is wave-uniform -- min(16 mt, M - 16), so a ragged last tile
+  // slides back over rows the previous tile also produced (identical values, benign duplicate
+  // stores) -- and every lane adds a constant 32-bit offset: no per-tile vector address math.
+  // (M < 16: one tile at row 0 whose lanes clamp their constant row to M - 1.)
+  const int64_t m_last = max(M - PX_BM, (int64_t)0);
+  int oh[NH], ox[NX];
+#pragma unroll
+  for (int it = 0; it < NH; ++it) {
+    const int idx = lane + it * 64, r = idx / 24, c4 = idx - r * 24;
+    oh[it] = (int)min((int64_t)r, M - 1) * (int)ldh + 4 * c4;
+  }
+#pragma unroll
+  for (int it = 0; it < NX; ++it) {
+    const int idx = lane + it * 64, r = idx / FP, k = min(idx - r * FP, F - 1);
+    ox[it] = (int)min((int64_t)r, M - 1) * (int)ldx + k;
+  }
+  const int oo = (int)min((int64_t)lr, M - 1) * (int)ldo + n0 + 4 * kq;
+  auto load_tile = [&](int64_t mt) {  // unconditional: nothing here uses a loaded value
+    const int64_t m0 = min(mt * PX_BM, m_last);
+    const float* hb = H + m0 * ldh;
+    const float* xb0 = X + m0 * ldx;
+#pragma unroll
+    for (int it = 0; it < NH; ++it) gh[it] = *reinterpret_cast<const f32x4*>(hb + oh[it]);
+#pragma unroll
+    for (int it = 0; it < NX; ++it) gx[it] = xb0[ox[it]];
+  };
+  auto stage_tile = [&]() {  // columns [96 + F, PX_LD) of the stage stay zero for the whole kernel
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = lane + it * 64, r = idx / 24, c4 = idx - r * 24;
+      *reinterpret_cast<f32x4*>(&sx[r * PX_LD + 4 * c4]) = gh[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = lane + it * 64, r = idx / FP, k = idx - r * FP;
+      sx[r * PX_LD + 96 + k] = k < F ? gx[it] : 0.f;  // a select, not a branch: keeps the wait exact
+    }
+  };
+  u32x4 xb[PX_KS][3];
+  auto split_tile = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < PX_KS; ++ks) {
+      // k-step 3 holds the features in k = 96 .. 96+F-1 <= 107: quarter-waves 2, 3 see zeros
+      const float* src = &sx[lr * PX_LD + (ks < 3 ? 32 * ks + 8 * kq : 96 + 8 * (kq & 1))];
+      f32x4 v[2] = {*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4)};
+      if (ks == 3 && kq >= 2) v[0] = v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t p0, p1, p2;
+        split_bf16x3(v[d >> 1][2 * (d & 1)], v[d >> 1][2 * (d & 1) + 1], p0, p1, p2);
+        xb[ks][0][d] = p0;
+        xb[ks][1][d] = p1;
+        xb[ks][2][d] = p2;
+      }
+    }
+  };
+  for (int i = lane; i < PX_BM * (PX_LD - 96); i += 64) {
+    const int r = i / (PX_LD - 96);
+    sx[r * PX_LD + 96 + (i - r * (PX_LD - 96))] = 0.f;
+  }
+  // waves w and w + 4 share a SIMD: a head start for one of them keeps their split / store
+  // phases out of step so the matrix pipe always has a sweep to run (speed only)
+  if (wave >= 8) __builtin_amdgcn_s_sleep(32);
+  else if (wave >= 4) __builtin_amdgcn_s_sleep(16);
+  const u32x4* pw = &s_w[0][lr][0];
+  int64_t mt = mt_lo + wave;
+  load_tile(mt);
+  stage_tile();
+  for (;;) {
+    split_tile();  // LDS stage -> register planes
+    // the next tile's rows are in flight during the sweep and are written to the stage right
+    // after it: that wait sits in straight-line code behind the sweep's stores, so it is an exact
+    // vmcnt(#stores) and the stores keep draining into the next tile
+    __builtin_amdgcn_sched_barrier(0);
+    const int64_t mt_next = mt_lo + grab();
+    const bool has_next = mt_next < mt_hi;
+    load_tile(has_next ? mt_next : mt);  // the last iteration re-reads a resident tile
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- sweep: 6 column tiles x 4 k-steps, one flat software pipeline.  The three weight
+    // fragments of step s+1 are read from LDS between the six MFMAs of step s; the accumulator
+    // starts from the bias; a finished column tile is stored while the next one is swept. ----
+    // no store predicate: see "Addressing" above
+    float* orow = out + min(mt * PX_BM, m_last) * ldo + oo;
+    constexpr int NSTEP = (PX_BN / 16) * PX_KS;
+    u32x4 wf[2][3];
+    f32x4 acc = s_b[kq];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wf[0][p] = pw[p * PX_BN * 16 + (kq ^ lr)];
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int ct = st / PX_KS, ks = st % PX_KS, cur = st & 1, nxt = cur ^ 1;
+      f32x4 acc_next = acc;
+      if (st + 1 < NSTEP) {
+        const int ct1 = (st + 1) / PX_KS, ks1 = (st + 1) % PX_KS;
+#ifndef PX_VAR_NO_LDS
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          wf[nxt][p] = pw[(p * PX_BN + ct1 * 16) * 16 + ((4 * ks1 + kq) ^ lr)];
+#else
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[nxt][p] = wf[cur][p] + (u32x4){1u, 2u, 3u, 4u};
+#endif
+        if (ks1 == 0) acc_next = s_b[ct1 * 4 + kq];
+      }
+#ifdef PX_VAR_NO_MFMA
+      acc[0] += __uint_as_float(wf[cur][0][0] ^ wf[cur][1][1] ^ wf[cur][2][2] ^ xb[ks][0][0]);
+#else
+      acc = mfma_x6(wf[cur], xb[ks], acc);
+#endif
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      if (ks == PX_KS - 1) {
+#ifdef PX_VAR_NO_STORE
+        if (acc[0] == 1.2345f) *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
+#else
+        *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
+#endif
+        acc = acc_next;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_tile();
+    if (!has_next) break;
+    mt = mt_next;
+  }
+#ifdef PX_VAR_CLOCK  // diagnostic build only: wave 0 of block 0 overwrites out[0, 0:4]
+  if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+    const uint64_t dc = __builtin_amdgcn_s_memtime() - t_c0, dr = __builtin_amdgcn_s_memrealtime() - t_r0;
+    __builtin_amdgcn_s_waitcnt(0);
+    out[0] = (float)dc;
+    out[1] = (float)dr;
+    out[2] = (float)(mt_hi - mt_lo);
+    out[3] = (float)(t_r0 - t_p0);
+  }
+#endif
+}
+
+}  // namespace ggnn
+
+// Called by ggnn_project (project.hip) for k2 == 96 unless GGNN_GEMM=fp32.
+int ggnn_project_x6(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, const float* Wp,
+                    const float* bias, int64_t M, int ncols, float* out, int64_t ldo,
+                    int m_splits, hipStream_t s) {
+  using namespace ggnn;
+  const int Fp = (F + 3) & ~3;
+  const dim3 grid((unsigned)((ncols / PX_BN) * m_splits)), block(PX_WAVES * 64);
+#define GGNN_PX_LAUNCH(FP_)                                                                     \
+  hipLaunchKernelGGL((project_x6_kernel<FP_>), grid, block, 0, s, X, ldx, F, H, ldh, Wp, bias, M, \
+                     ncols, out, ldo, m_splits)
+  if (Fp == 4) GGNN_PX_LAUNCH(4);
+  else if (Fp == 8) GGNN_PX_LAUNCH(8);
+  else GGNN_PX_LAUNCH(12);
+#undef GGNN_PX_LAUNCH
+  return launch_status();
+}

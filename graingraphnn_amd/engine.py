@@ -129,7 +129,8 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
         if not lay[nt].live:
             continue
         backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
-                              c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode)
+                              c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode,
+                              pc.w2p.get(nt))
 
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,

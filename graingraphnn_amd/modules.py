@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, graph_for, prepare_edges, run_cell
-from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, pack_cell, pack_conv, roundup4
+from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, pack_conv, roundup4
 
 
 def _param_version(module: nn.Module):
@@ -67,7 +67,7 @@ class PeriodConv(nn.Module):
         agg = torch.zeros(x_dst.size(0), 100, device=dev)
         be.aggregate(csr, einfo, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)
         out = torch.empty(x_dst.size(0), C, device=dev)
-        be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW)
+        be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW, bf16_planes(w2))
         return out
 
 

@@ -103,8 +103,29 @@ class PackedCell:
     bp: Dict[str, torch.Tensor]     # node type -> [ncols]
     ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 7, 96]
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
+    w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> bf16 planes of w2 (bf16_planes)
     enc_w: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # fused encoder: [G, 96, 40]
     fused: bool = False
+
+
+@torch.no_grad()
+def bf16_planes(w2: torch.Tensor) -> torch.Tensor:
+    """`ggnn_epilogue_args.w2_planes` (include/ggnn.h): w2[:, :, :Ka-4] split exactly into three
+    bf16 pieces (hi = rne(w), mid = rne(w - hi), lo = rne(w - hi - mid); hi + mid + lo == w) and
+    laid out in MFMA fragment order [G][(Ka-4)/32][3][6][64][8] as int16 bit patterns."""
+    G, nch, Ka = w2.shape
+    KM = Ka - 4
+    assert nch == C and KM % 32 == 0
+    w = w2[:, :, :KM].float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    r2 = r1 - mid.float()
+    lo = r2.to(torch.bfloat16)
+    assert torch.equal(hi.float() + mid.float() + lo.float(), w)
+    pl = torch.stack([hi, mid, lo], 0).view(3, G, 6, 16, KM // 32, 4, 8)   # p g ct i ks kq j
+    pl = pl.permute(1, 4, 0, 2, 5, 3, 6).contiguous()                      # g ks p ct kq i j
+    return pl.view(torch.int16).view(-1)
 
 
 def _conv(cell, gate, et):
@@ -201,7 +222,9 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
                 Wf[g, :, 34:37] = wv[:, 0:3]
                 Wf[g, :, 37] = conv.lin_edge.weight.detach().to(dt)[:, 0]
             enc_w[et] = Wf.contiguous()
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, enc_w=enc_w, fused=fused)
+    w2p = {nt: bf16_planes(t) for nt, t in w2.items()}
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, enc_w=enc_w, fused=fused,
+                      w2p=w2p)
 
 
 @torch.no_grad()

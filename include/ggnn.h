@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 5
+#define GGNN_ABI_VERSION 7
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
@@ -44,6 +44,13 @@ typedef void* ggnn_stream_t; /* hipStream_t */
 
 int ggnn_version(void);
 const char* ggnn_error_string(int code);
+/* Arithmetic of the K >= 100 GEMMs (decoder ggnn_project, ggnn_lstm_epilogue), fixed per process
+ * by the environment variable GGNN_GEMM: GGNN_GEMM_BF16X6 (default) = every fp32 operand split
+ * exactly into three bf16 pieces, six bf16 MFMA products per k-step, fp32 accumulate (dropped
+ * terms <= 2^-25 of a product: fp32-equivalent); GGNN_GEMM_FP32 ("fp32") = native fp32 MFMA. */
+#define GGNN_GEMM_FP32 0
+#define GGNN_GEMM_BF16X6 1
+int ggnn_gemm_mode(void);
 
 /* ------------------------------------------------------------------------------------
  * CSR build.  Replaces the COO bookkeeping inside PyG MessagePassing.propagate as used at
@@ -169,7 +176,7 @@ int ggnn_period_gat_aggregate_enc(const ggnn_aggregate_enc_args* args, ggnn_stre
  *   mode GGNN_MODE_LSTM    : n_gates = 4, needs c_in, writes h_out, c_out   [N, 96]
  *   mode GGNN_MODE_LSTM_H0 : n_gates = 3 (i, c, o), writes h_out, c_out
  *   mode GGNN_MODE_RAW     : writes raw_out [N, n_gates*96] = pre
- * Ka % 4 == 0, Ka <= 200; ld_agg = n_gates * Ka.
+ * Ka % 4 == 0, Ka <= 200.
  */
 typedef struct ggnn_epilogue_args {
   const float* agg;   /* [N, n_gates*Ka] */
@@ -181,6 +188,18 @@ typedef struct ggnn_epilogue_args {
   float* raw_out;     /* [N, n_gates*96] (GGNN_MODE_RAW) */
   int64_t ldp, N;
   int32_t Ka, s_off, n_gates, mode;
+  /* Optional (NULL = native fp32 MFMA kernel): w2[:, :, 0:Ka-4] split into three bf16 planes in
+   * MFMA fragment order, uint16 [n_gates][(Ka-4)/32][3][6][64][8]: element [g][ks][p][ct][l][j] is
+   * piece p (0 = hi, 1 = mid, 2 = lo; x = hi + mid + lo exactly, each the bf16 round-to-nearest of
+   * what is left) of w2[g][16 ct + (l & 15)][32 ks + 8 (l >> 4) + j].  16-byte aligned.  Used
+   * when ggnn_gemm_mode() == GGNN_GEMM_BF16X6; Ka - 4 must be a multiple of 32. */
+  const uint16_t* w2_planes;
+  /* Layout of agg: row stride ld_agg and gate stride g_stride, in floats (0, 0 = packed:
+   * g_stride = Ka, ld_agg = n_gates * Ka).  Both multiples of 4, g_stride >= Ka,
+   * ld_agg >= n_gates * g_stride.  Multiples of 32 (128-byte aligned k-steps) are what the
+   * workspace uses: the fragment loads of the bf16x6 kernel then touch one cache line each. */
+  int64_t ld_agg;
+  int32_t g_stride, reserved;
 } ggnn_epilogue_args;
 int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream);
 

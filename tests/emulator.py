@@ -93,8 +93,14 @@ class TorchEmulatorBackend:
             agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
             agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
 
-    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode):
+    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
+                      w2_planes=None):
         Ka = w2.size(2)
+        if w2_planes is not None:  # the planes must reassemble to w2[:, :, :Ka-4] exactly (ggnn.h layout)
+            G, KM = w2.size(0), Ka - 4
+            pl = w2_planes.view(torch.bfloat16).view(G, KM // 32, 3, 6, 4, 16, 8).float().sum(2)  # g ks ct kq i j
+            back = pl.permute(0, 2, 4, 1, 3, 5).reshape(G, 96, KM)
+            assert torch.equal(back, w2[:, :, :KM])
         pre = [agg[:, g * Ka:(g + 1) * Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]
                for g in range(n_gates)]
         if mode == 2:

@@ -98,6 +98,45 @@ def test_project_matches_fp32_matmul(M, F, k2, ncols):
     assert_close(out, ref, f"project M={M} F={F} k2={k2} ncols={ncols}", 2e-6)
 
 
+def test_gemm_arithmetic_is_fp32_equivalent():
+    """The decoder GEMMs run by default as 3 x bf16 split / 6 MFMA products (GGNN_GEMM_BF16X6).
+    Their error against an fp64 product, normalised by sum_k |x_k||w_k| (the quantity fp32
+    rounding scales with), must stay at the fp32 level.  Measured on MI355X with these inputs:
+    2.7e-7 for the split kernels, 7.0e-7 for the native fp32 MFMA chain (GGNN_GEMM=fp32), whose
+    104 sequential fp32 roundings the split path replaces by 24."""
+    rs = np.random.RandomState(5)
+    M, F, ncols = 4096, 8, 2688
+    x = torch.from_numpy((rs.standard_normal((M, F)) * 10 ** rs.uniform(-3, 1, (M, 1))).astype(np.float32))
+    h = torch.from_numpy(np.tanh(rs.standard_normal((M, 96))).astype(np.float32))
+    wp = torch.from_numpy((rs.standard_normal((ncols, 104)) * 10 ** rs.uniform(-2, 0, (ncols, 1))).astype(np.float32))
+    bp = torch.zeros(ncols)
+    xin = torch.cat([x, h], 1).double()
+    ref = xin @ wp.double().t()
+    scale = xin.abs() @ wp.double().abs().t()
+    out = torch.empty(M, ncols, device=DEV)
+    backend().project(x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV), out)
+    err = float(((out.cpu().double() - ref).abs() / scale).max())
+    bound = 4e-7 if backend().lib.ggnn_gemm_mode() == 1 else 1e-6
+    assert err < bound, f"decoder projection error {err:.2e} of sum|x||w| (mode {backend().lib.ggnn_gemm_mode()})"
+
+
+def test_native_fp32_gemm_mode_in_a_subprocess():
+    """GGNN_GEMM=fp32 (native v_mfma_f32_16x16x4_f32 kernels) is fixed per process: run the GEMM,
+    cell and forward parity tests once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GGNN_GEMM") == "fp32":
+        assert backend().lib.ggnn_gemm_mode() == 0
+        return
+    assert backend().lib.ggnn_gemm_mode() == 1
+    env = dict(os.environ, GGNN_GEMM="fp32")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "project or gemm or periodconv or cell_golden or forward_golden"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------
 # op level: PeriodConv and HeteroPGCLSTM against the reference's golden vectors (cfg1)
 # ---------------------------------------------------------------------------------------

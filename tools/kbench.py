@@ -52,7 +52,7 @@ class Timed:
         if name == "aggregate":
             return f"n_dst={a[3].size(0)} n_src={a[2].size(0)} G={a[-1]}"
         if name == "lstm_epilogue":
-            return f"N={a[0].size(0)} Ka={a[1].size(2)} G={a[-2]}"
+            return f"N={a[0].size(0)} Ka={a[1].size(2)} G={a[8]}"
         return ""
 
 
