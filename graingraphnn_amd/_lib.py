@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 7
+GGNN_ABI_VERSION = 8
 GGNN_ENC_W_ROW = 40
 GGNN_UNIT_EDGES = 3
 GGNN_C = 96
@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_period_gat_aggregate_enc", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
-    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_step_refresh",
+    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
 
@@ -134,6 +134,9 @@ def _declare(lib):
     lib.ggnn_grain_centres.restype = c_int
     lib.ggnn_grain_centres.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                        c_float, c_void_p, c_int64, c_int64, c_void_p]
+    lib.ggnn_detect_events.restype = c_int
+    lib.ggnn_detect_events.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64,
+                                       c_float, c_void_p, c_void_p]
     lib.ggnn_workspace_bytes.restype = c_size_t
     lib.ggnn_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
 

@@ -185,6 +185,17 @@ class HipBackend:
                                           x_grain.stride(0), _lib.current_stream()),
               "ggnn_grain_centres")
 
+    def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,
+                      logit_threshold, flags):
+        """flags[0:2] (int32, device) <- (#grain events, #switch candidates); see ggnn.h."""
+        _require_cuda(grain_area, live_grain, edge_event, edge_index_jj, flags)
+        if live_grain.dtype != torch.int32 or flags.dtype != torch.int32 or flags.numel() < 2:
+            raise _lib.GGNNError("live_grain / flags must be int32")
+        check(self.lib.ggnn_detect_events(ptr(grain_area), ptr(live_grain), grain_area.numel(),
+                                          float(area_threshold), ptr(edge_event), ptr(edge_index_jj),
+                                          edge_index_jj.size(1), float(logit_threshold), ptr(flags),
+                                          _lib.current_stream()), "ggnn_detect_events")
+
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
         """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E])."""
         _require_cuda(x_joint, x_grain, flags)

@@ -78,6 +78,28 @@ __global__ __launch_bounds__(256) void grain_centres_kernel(
   }
 }
 
+// Counts the events the host-side topology update would act on (test.py:418, models.py:624-626):
+// flags[0] += #live grains with grain_area < area_threshold, flags[1] += #directed junction edges
+// (src < dst) with edge_event > logit_threshold.  One pass over 10k + 60k values; the rollout reads
+// the two words back once per step and only touches the host path when one is non-zero.
+__global__ __launch_bounds__(256) void detect_events_kernel(
+    const float* __restrict__ grain_area, const int32_t* __restrict__ live_grain, int64_t n_grain,
+    float area_threshold, const float* __restrict__ edge_event, const int64_t* __restrict__ ei_jj,
+    int64_t E, float logit_threshold, int32_t* __restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool g = false, e = false;
+  if (t < n_grain) g = live_grain[t] > 0 && grain_area[t] < area_threshold;
+  else if (t - n_grain < E) {
+    const int64_t k = t - n_grain;
+    e = edge_event[k] > logit_threshold && ei_jj[k] < ei_jj[E + k];
+  }
+  const int ng = __popcll(__ballot(g)), ne = __popcll(__ballot(e));
+  if ((threadIdx.x & 63) == 0) {
+    if (ng) atomicAdd(&flags[0], ng);
+    if (ne) atomicAdd(&flags[1], ne);
+  }
+}
+
 struct RefreshArgs {
   ggnn_refresh_edge et[3];
   int64_t e_off[4];  // prefix sums of E over the edge types
@@ -153,6 +175,22 @@ extern "C" int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, con
   hipLaunchKernelGGL(grain_centres_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                      rowptr, col, x_joint, ldx_joint, domain_offset, domain_factor, x_grain,
                      ldx_grain, n_grain, n_joint);
+  return launch_status();
+}
+
+extern "C" int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
+                                  float area_threshold, const float* edge_event,
+                                  const int64_t* edge_index_jj, int64_t E, float logit_threshold,
+                                  int32_t* flags, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!grain_area || !live_grain || !flags || n_grain <= 0 || E < 0) return GGNN_EINVAL;
+  if (E > 0 && (!edge_event || !edge_index_jj)) return GGNN_EINVAL;
+  const int64_t nblk = (n_grain + E + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return GGNN_ELAUNCH;
+  hipLaunchKernelGGL(detect_events_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     grain_area, live_grain, n_grain, area_threshold, edge_event, edge_index_jj, E,
+                     logit_threshold, flags);
   return launch_status();
 }
 

@@ -146,8 +146,40 @@ class GrainNN_classifier(_GrainNNBase):
                             self._tmp, edge_event, edge)
         return {"edge_event": edge_event, "edge": edge}
 
-    def update(self, *args, **kwargs):
-        raise NotImplementedError(
-            "topology surgery (models.py:614-1053) is host-side, data-dependent code outside the "
-            "accelerated hot path (SURVEY.md section 8f-2); use the reference implementation on the "
-            "tensors returned by forward()")
+    threshold = 0.6  # test.py:188 sets Cmodel.threshold after construction; same default
+
+    @torch.no_grad()
+    def update(self, x_dict, edge_index_dict, edge_attr, y_dict, mask, geometry_scaling, nucleation_prob=0.0):
+        """models.py:612-842 (grain elimination + neighbour switching; nucleation off).  Same
+        in/out contract as the reference: `x_dict['joint']`, `y_dict['joint']`, `mask` are
+        updated in place, `y_dict['grain_event']` gains the force-eliminated grains,
+        `edge_index_dict` gets three NEW tensors (the CSR cache then rebuilds on the next forward);
+        returns (x_dict, edge_index_dict, switching_list).  The rewiring itself is sequential index
+        work and runs on the host (`graingraphnn_amd/topology.py`)."""
+        from .topology import GJ, JG, JJ, update_topology
+        if nucleation_prob is not None and float(nucleation_prob) > 1e-6:
+            raise NotImplementedError("nucleation (models.py:770-835) draws from torch's global RNG "
+                                      "stream and is off in every shipped script (test.py:88)")
+        dev = x_dict["joint"].device
+        to_np = lambda t: torch.as_tensor(t).detach().cpu().numpy()
+        xj = to_np(x_dict["joint"]).astype("float32", copy=True)
+        yj = to_np(y_dict["joint"]).astype("float32", copy=True)
+        mg = to_np(mask["grain"]).copy().reshape(-1, 1)
+        mj = to_np(mask["joint"]).copy().reshape(-1, 1)
+        prob = torch.sigmoid(y_dict["edge_event"]).cpu().numpy()
+        gs = geometry_scaling or {}
+        pp, pq, qp, switches, events = update_topology(
+            xj, to_np(edge_index_dict[JJ]), to_np(edge_index_dict[JG]), yj, to_np(y_dict["grain"]), prob,
+            to_np(y_dict["grain_event"]).reshape(-1), mg, mj, float(self.threshold),
+            None if "active_grains" not in gs else to_np(gs["active_grains"]),
+            None if "active_joints" not in gs else to_np(gs["active_joints"]))
+        x_dict["joint"].copy_(torch.from_numpy(xj))
+        y_dict["joint"].copy_(torch.from_numpy(yj))
+        for key, arr in (("grain", mg), ("joint", mj)):
+            mask[key].copy_(torch.from_numpy(arr).view_as(mask[key]).to(mask[key].dtype))
+        y_dict["grain_event"] = torch.from_numpy(events).to(y_dict["grain_event"].device)
+        import numpy as _np
+        edge_index_dict[JJ] = torch.from_numpy(pp).to(dev)
+        edge_index_dict[JG] = torch.from_numpy(pq).to(dev)
+        edge_index_dict[GJ] = torch.from_numpy(_np.ascontiguousarray(qp)).to(dev)
+        return x_dict, edge_index_dict, torch.from_numpy(switches)

@@ -42,10 +42,7 @@ class GrainRollout:
                 raise _lib.GGNNError("x_dict tensors must be contiguous")
         dev = self.x["joint"].device
         self.n_nodes = {nt: self.x[nt].size(0) for nt in NODE_TYPES}
-        self.graph = graph_for(self.be, edge_index_dict, self.n_nodes)
-        # edge lengths live in our own [E] buffers (refreshed in place every step)
-        self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
-                          for et in EDGE_TYPES}
+        self._set_topology(edge_index_dict, edge_attr_dict)
         self.span = span
         # test.py:401-406 computes in fp32: z += fp32(span/121); clamp at fp32(120/121)
         self.dz = float(np.float32(span / (TRAIN_FRAMES + 1)))
@@ -61,15 +58,10 @@ class GrainRollout:
         self.w_reg = pack_regressor_heads(rmodel.linear)
         self.w_cls = pack_classifier_heads(cmodel.lin1, cmodel.lin2)
         nj, ng = self.n_nodes["joint"], self.n_nodes["grain"]
-        E = self.graph.edge_index[ET_JJ].size(1)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.pred = {
-            "joint": torch.empty(nj, 2, **f32), "grain": torch.empty(ng, 2, **f32),
-            "grain_area": torch.empty(ng, **f32), "edge_event": torch.empty(E, **f32),
-            "edge": torch.empty(E, 2, **f32),
-        }
+        self.pred.update({"joint": torch.empty(nj, 2, **f32), "grain": torch.empty(ng, 2, **f32),
+                          "grain_area": torch.empty(ng, **f32)})
         self._tmp = torch.empty(nj, 8, **f32)
-        self.einfo = alloc_einfo(self.graph, dev)
         # the regressor and the classifier are independent given (x, edge geometry): run them
         # on two HIP streams so one model's launch tails overlap the other's kernels
         self.concurrent = concurrent
@@ -83,12 +75,37 @@ class GrainRollout:
                 raise _lib.GGNNError("domain_factor > 1 needs domain_offset")
             self.domain_offset = domain_offset.to(dev, torch.float32).contiguous()
         self.steps_done = 0
-        self._graph_exec = None
+        self.use_graph = use_graph
         if use_graph:
             self._capture()
 
+    def _set_topology(self, edge_index_dict, edge_attr_dict=None):
+        """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
+        buffers (refreshed in place every step), the per-edge geometry records and the per-edge
+        outputs.  Called once at construction and after every topological event."""
+        dev = self.x["joint"].device
+        self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
+        self.graph = graph_for(self.be, self.edge_index, self.n_nodes)
+        if edge_attr_dict is not None:
+            self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
+                              for et in EDGE_TYPES}
+        else:  # lengths are recomputed by the refresh that follows an event
+            self.edge_attr = {et: torch.zeros(self.edge_index[et].size(1), device=dev) for et in EDGE_TYPES}
+        E = self.graph.edge_index[ET_JJ].size(1)
+        if not hasattr(self, "pred"):
+            self.pred = {}
+        self.pred["edge_event"] = torch.empty(E, dtype=torch.float32, device=dev)
+        self.pred["edge"] = torch.empty(E, 2, dtype=torch.float32, device=dev)
+        self.einfo = alloc_einfo(self.graph, dev)
+        self._graph_exec = None
+
     # -- one step, enqueued on the current stream --------------------------------------
     def _enqueue_step(self):
+        self._enqueue_forward_update()
+        self._enqueue_refresh()
+
+    def _enqueue_forward_update(self):
+        """test.py:382-402: both forwards, Rmodel.update, z advance."""
         be, x, ea, p = self.be, self.x, self.edge_attr, self.pred
         # edge geometry once per step, shared by both models and all four cells
         einfo = prepare_edges(be, self.graph, x, ea, self.einfo)
@@ -124,6 +141,10 @@ class GrainRollout:
             for st in self._side:
                 main.wait_stream(st)
         be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+
+    def _enqueue_refresh(self):
+        """test.py:405-407, 468-478 + 556-559, 562-575: z clamp, grain centres, edge lengths."""
+        be, x, ea = self.be, self.x, self.edge_attr
         if self.refresh_centres:
             be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
                              self.domain_factor, self.domain_offset)
@@ -143,8 +164,103 @@ class GrainRollout:
         torch.cuda.current_stream().wait_stream(s)
         self._graph_exec = g
 
+    # -- event-driven mode ------------------------------------------------
+    def enable_events(self, mask, area_threshold: float = 1e-4, edge_threshold: float = 0.6):
+        """Switch to the full loop of test.py:382-575: after the device forwards + Rmodel.update,
+        grains whose predicted area fell below `area_threshold` (Rmodel.threshold, test.py:187,
+        418) are eliminated and junction edges with sigmoid(edge_event) above `edge_threshold`
+        (Cmodel.threshold, :188) are switched by the host-side `topology.update_topology`; then
+        grain centres and edge lengths are refreshed on the NEW topology.  `mask` = the
+        reference's `data['mask']` ({'grain': [N_g, 1], 'joint': [N_j, 1]}, any integer dtype)."""
+        self.mask = {k: np.array(torch.as_tensor(mask[k]).cpu().numpy(), dtype=np.int64, copy=True).reshape(-1, 1)
+                     for k in ("grain", "joint")}
+        dev = self.x["joint"].device
+        self._live_grain = torch.from_numpy(self.mask["grain"][:, 0].astype(np.int32)).to(dev)
+        self.area_threshold, self.edge_threshold = float(area_threshold), float(edge_threshold)
+        # device-side trigger: slightly wider than the host's exact sigmoid(x) > threshold test,
+        # so a borderline edge always reaches the host, which then decides exactly
+        self._logit_trigger = float(np.log(edge_threshold / (1.0 - edge_threshold)) - 1e-4)
+        self._ev_flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._ev_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._quiet_steps = 0
+        self._graph_fwd = self._graph_ref = None
+        self.grain_events, self.switched = [], []
+
+    def _run_segment(self, which):
+        """The two halves of a step, replayed from their own hipGraphs once the topology has been
+        quiet for two steps (a capture is not worth it while events fire every step)."""
+        fn = self._enqueue_forward_update if which == "fwd" else self._enqueue_refresh
+        attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
+        if self.use_graph and self._quiet_steps >= 2:
+            if getattr(self, attr) is None:
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        fn()
+                torch.cuda.current_stream().wait_stream(st)
+                setattr(self, attr, g)
+            getattr(self, attr).replay()
+        else:
+            fn()
+
+    def step_events(self):
+        """One step with topological events.  Returns (pred, grain_events, switching_list); the
+        last two are empty numpy arrays on a quiet step.  One 8-byte read-back per step is the only
+        host synchronisation unless an event fires."""
+        if not hasattr(self, "mask"):
+            raise _lib.GGNNError("call enable_events(mask, ...) first")
+        self._run_segment("fwd")
+        p = self.pred
+        self.be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
+                              self.graph.edge_index[ET_JJ], self._logit_trigger, self._ev_flags)
+        self._ev_host.copy_(self._ev_flags, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        events, switches = np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
+        if int(self._ev_host[0]) or int(self._ev_host[1]):
+            events, switches = self._apply_events()
+        if len(events) or len(switches):
+            self._quiet_steps = 0
+        else:
+            self._quiet_steps += 1
+        self._run_segment("ref")
+        self.steps_done += 1
+        self.grain_events.append(events)
+        self.switched.append(switches)
+        return self.pred, events, switches
+
+    def _apply_events(self):
+        """Host round trip: read the predictions back, rewire, upload the new lists."""
+        from .topology import update_topology
+        p, dev = self.pred, self.x["joint"].device
+        area = p["grain_area"].cpu().numpy()
+        live = self.mask["grain"][:, 0] > 0
+        ge = np.flatnonzero(live & (area < np.float32(self.area_threshold)))
+        ge = ge[np.argsort(area[ge], kind="stable")]                         # test.py:418-420
+        prob = torch.sigmoid(p["edge_event"]).cpu().numpy()
+        if len(ge) == 0 and not np.any((prob > self.edge_threshold) &
+                                       (self.edge_index[ET_JJ][0].cpu().numpy() < self.edge_index[ET_JJ][1].cpu().numpy())):
+            return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)         # the trigger was conservative
+        xj = self.x["joint"].cpu().numpy()
+        yj, yg = p["joint"].cpu().numpy(), p["grain"].cpu().numpy()
+        ei_jj = self.edge_index[ET_JJ].cpu().numpy()
+        ei_jg = self.edge_index[("joint", "pull", "grain")].cpu().numpy()
+        pp, pq, qp, switches, events = update_topology(
+            xj, ei_jj, ei_jg, yj, yg, prob, ge, self.mask["grain"], self.mask["joint"], self.edge_threshold)
+        self.x["joint"].copy_(torch.from_numpy(xj))
+        p["joint"].copy_(torch.from_numpy(yj))
+        self._live_grain.copy_(torch.from_numpy(self.mask["grain"][:, 0].astype(np.int32)))
+        new_ei = {ET_JJ: torch.from_numpy(pp).to(dev), ("joint", "pull", "grain"): torch.from_numpy(pq).to(dev),
+                  ("grain", "push", "joint"): torch.from_numpy(np.ascontiguousarray(qp)).to(dev)}
+        self._set_topology(new_ei)
+        self._graph_fwd = self._graph_ref = None
+        return events, switches
+
     def step(self):
         """Advance one rollout step; returns the prediction dict (tensors are reused)."""
+        if self.use_graph and self._graph_exec is None:
+            self._capture()
         if self._graph_exec is not None:
             self._graph_exec.replay()
         else:

@@ -1,0 +1,255 @@
+"""Event-driven topology update of the grain graph, host side.
+
+Restates `GrainNN_classifier.update` of the reference (models.py:612-842 with its helpers
+`delete_grain_index` :861-893, `switching_edge_index` :896-1051, `point_in_triangle` :1055-1070,
+`periodic_move` :1103-1106) for the periodic, nucleation-free configuration every shipped script
+runs (test.py:88 `--nucleation_density 0`).  It is integer / index work on a few hundred edges
+per event and inherently sequential (every event rewires the lists the next one reads), so it
+runs on the host on numpy arrays between device steps; the device side only sees new
+`edge_index` tensors, for which `engine.graph_for` rebuilds the CSR.
+
+Bit-exactness contract (tests/golden/golden_cfg1_events.npz, produced by the unmodified
+reference): identical `edge_index` COLUMN ORDER (edges are rewritten in place, new edges are
+appended, dead columns are dropped at the end -- never re-sorted), identical masks, identical
+fp32 junction coordinates.  Reference behaviours that look accidental are kept because the
+trained models were run with them, each marked KEEP below.
+"""
+from itertools import combinations
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+GJ, JG, JJ = ("grain", "push", "joint"), ("joint", "pull", "grain"), ("joint", "connect", "joint")
+JOINT_SCALING = np.float32(5.0)  # models.py:398 scaling['joint']
+DEAD = -1                        # marker of a removed column until the final clean-up
+
+
+def _wrap_to(p: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """Periodic image of p nearest to ref (models.py:1103-1106), fp32."""
+    rel = p - ref
+    return p - (rel > 0.5).astype(np.float32) + (rel < -0.5).astype(np.float32)
+
+
+def _inside_triangle(t, v1, v2, v3) -> bool:
+    """models.py:1055-1070, evaluated in fp32 in the reference's operation order."""
+    a, b, c = _wrap_to(v1, t), _wrap_to(v2, t), _wrap_to(v3, t)
+
+    def side(p, q, r):
+        return (p[0] - r[0]) * (q[1] - r[1]) - (q[0] - r[0]) * (p[1] - r[1])
+
+    d = (side(t, a, b), side(t, b, c), side(t, c, a))
+    return not (any(v < 0 for v in d) and any(v > 0 for v in d))
+
+
+class TopologyError(RuntimeError):
+    """The lists are not a valid grain graph (the reference asserts / raises KeyError here)."""
+
+
+class GrainTopology:
+    """Mutable junction-junction (`pp`) and junction-grain (`pq`) edge lists of one graph."""
+
+    def __init__(self, ei_jj: np.ndarray, ei_jg: np.ndarray, x_joint: np.ndarray, y_joint: np.ndarray,
+                 mask_grain: np.ndarray, mask_joint: np.ndarray, active_joints: Optional[np.ndarray] = None):
+        self.pp = np.array(ei_jj, dtype=np.int64, copy=True)
+        self.pq = np.array(ei_jg, dtype=np.int64, copy=True)
+        self.xj, self.yj = x_joint, y_joint          # fp32, modified in place
+        self.mask_grain, self.mask_joint = mask_grain, mask_joint
+        self.active = None if active_joints is None else set(int(v) for v in active_joints)
+
+    # -- lookups (column order is the reference's `.nonzero()` order) -------------------------
+    def joints_of(self, grain: int) -> np.ndarray:
+        return self.pq[0, self.pq[1] == grain]
+
+    def pq_cols_of_joint(self, joint: int) -> np.ndarray:
+        return np.flatnonzero(self.pq[0] == joint)
+
+    def has_pq(self, joint: int, grain: int) -> bool:
+        return bool(np.any((self.pq[0] == joint) & (self.pq[1] == grain)))
+
+    def is_active(self, joint: int) -> bool:
+        return self.active is None or int(joint) in self.active
+
+    # -- models.py:861-893 -------------------------------------------------------------------
+    def remove_two_sided_grain(self, grain: int) -> None:
+        """A grain reduced to two junctions disappears: its junctions p1, p2 die and their two
+        outer neighbours are joined by a new edge pair appended at the end."""
+        corners = self.joints_of(grain)
+        if len(corners) != 2:
+            raise TopologyError(f"grain {grain} has {len(corners)} junctions, expected 2")
+        p1, p2 = int(corners[0]), int(corners[1])
+        pp = self.pp
+        n1 = int(pp[1, (pp[0] == p1) & (pp[1] != p2)][0])
+        n2 = int(pp[1, (pp[0] == p2) & (pp[1] != p1)][0])
+        self.pp = pp = np.concatenate([pp, np.array([[n1, n2], [n2, n1]], dtype=np.int64)], axis=1)
+        self.mask_grain[grain] = 0
+        self.mask_joint[p1] = 0
+        self.mask_joint[p2] = 0
+        self.pq[:, self.pq[1] == grain] = DEAD
+        for j in (p1, p2):
+            self.pq[:, self.pq[0] == j] = DEAD
+            pp[:, pp[0] == j] = DEAD
+            pp[:, pp[1] == j] = DEAD
+
+    def remove_all_two_sided(self) -> List[int]:
+        """models.py:708-717 / 741-750.  KEEP: the DEAD marker itself takes part in the count
+        (it never has <= 2 columns once a grain has been removed)."""
+        grains, counts = np.unique(self.pq[1], return_counts=True)
+        found = [int(g) for g in grains[counts <= 2]]
+        for g in found:
+            self.remove_two_sided_grain(g)
+        return found
+
+    # -- models.py:896-1051 ------------------------------------------------------------------
+    def switch_edges(self, cols: Sequence[int], vanishing_grain: Optional[int]) -> List[int]:
+        """Neighbour switching (T1) of the junction-junction columns `cols`, in order.  Returns
+        grains that turn out to be squeezed between the switching junctions (forced eliminations)."""
+        cols = np.asarray(cols, dtype=np.int64)
+        forced: List[int] = []
+        touched = np.unique(self.pp[:, cols].T.reshape(-1)) if len(cols) else np.zeros(0, np.int64)
+        for p in touched:
+            self.xj[p, :2] -= self.yj[p] / JOINT_SCALING     # back to the position before this step
+        pp, pq, xj = self.pp, self.pq, self.xj
+        for k in range(len(cols)):
+            p1, p2 = int(pp[0, cols[k]]), int(pp[1, cols[k]])
+            if not (self.is_active(p1) and self.is_active(p2)):
+                continue
+            c1, c2 = self.pq_cols_of_joint(p1), self.pq_cols_of_joint(p2)
+            g1, g2 = pq[1, c1], pq[1, c2]
+            e1 = np.flatnonzero((pp[0] == p1) & (pp[1] != p2))   # columns p1 -> its other neighbours
+            e2 = np.flatnonzero((pp[0] == p2) & (pp[1] != p1))
+            n1, n2 = pp[1, e1], pp[1, e2]
+            shared1 = np.isin(g1, g2)
+            grow_from_1 = g1[~shared1]            # grain of p1 only: becomes a neighbour of p2
+            grow_from_2 = g2[~np.isin(g2, g1)]    # grain of p2 only: becomes a neighbour of p1
+            shrink = g1[shared1]
+            if len(shrink) != 2 or len(grow_from_1) != 1 or len(grow_from_2) != 1:
+                raise TopologyError(f"junctions {p1}, {p2} do not share exactly two grains")
+            sa, sb = int(shrink[0]), int(shrink[1])
+            c1 = [int(c1[i]) for i in range(3) if g1[i] == sa] + [int(c1[i]) for i in range(3) if g1[i] == sb]
+            c2 = [int(c2[i]) for i in range(3) if g2[i] == sa] + [int(c2[i]) for i in range(3) if g2[i] == sb]
+            # order each junction's two outer neighbours as (the one on grain sa, the one on sb)
+            e1, n1 = [int(v) for v in e1], [int(v) for v in n1]
+            e2, n2 = [int(v) for v in e2], [int(v) for v in n2]
+            if not self.has_pq(n1[0], sa):
+                e1.reverse(), n1.reverse()
+            if not self.has_pq(n2[0], sa):
+                e2.reverse(), n2.reverse()
+            a1, b1 = n1
+            a2, b2 = n2
+            if vanishing_grain is None and (a1 == a2 or b1 == b2):
+                continue                          # a triangle would collapse: not a pure switch
+            if a1 == a2 and sa != vanishing_grain:
+                forced.append(sa)
+            if b1 == b2 and sb != vanishing_grain:
+                forced.append(sb)
+            # both junctions move to the (periodic) mid point of the edge
+            x2_near = _wrap_to(xj[p2, :2], xj[p1, :2])
+            mid = np.float32(0.5) * (xj[p1, :2] + x2_near)
+            new_p2 = _wrap_to(mid, xj[p2, :2])
+            xj[p1, :2], xj[p2, :2] = mid, new_p2
+            flip = _inside_triangle(xj[p2, :2], xj[p1, :2], xj[a1, :2], xj[a2, :2])
+            # look ahead: junctions that later switches of this call still need keep their side
+            later = set(int(v) for v in pp[:, cols[k:]].reshape(-1))
+            if a2 in later and b2 not in later:
+                flip = False
+            if b2 in later and a2 not in later:
+                flip = True
+            if a1 in later and b1 not in later:
+                flip = True
+            if b1 in later and a1 not in later:
+                flip = False
+            if flip:
+                c1.reverse(), c2.reverse(), e1.reverse(), e2.reverse()
+                a1, b1, a2, b2 = b1, a1, b2, a2
+            pq[1, c1[1]] = grow_from_2[0]
+            pq[1, c2[0]] = grow_from_1[0]
+            pp[0, e1[1]] = p2
+            pp[0, e2[0]] = p1
+            pp[1, (pp[0] == a2) & (pp[1] == p2)] = p1
+            pp[1, (pp[0] == b1) & (pp[1] == p1)] = p2
+        for p in touched:
+            # KEEP (models.py:903, 1045-1047): the reference remembers a VIEW of the rewound
+            # position, so the displacement feature of every touched junction comes out as 0.
+            self.yj[p] = JOINT_SCALING * (xj[p, :2] - xj[p, :2])
+            xj[p, 6:8] = self.yj[p]
+        return forced
+
+    # -- models.py:628-717 -------------------------------------------------------------------
+    def eliminate_grain(self, grain: int, y_grain_area: np.ndarray, pending_switches: List[int]) -> Optional[List[int]]:
+        """Shrink `grain` to two sides by switching all but two of its edges (those towards the
+        neighbours with the smallest predicted area change go first), then remove it.  Returns the
+        force-eliminated grains, or None if the grain was skipped."""
+        corners = self.joints_of(grain)
+        if len(corners) == 0 or not all(self.is_active(int(p)) for p in corners):
+            return None
+        pp, pq = self.pp, self.pq
+        edge_cols, across = [], []
+        for p, q in combinations([int(v) for v in corners], 2):
+            lo, hi = min(p, q), max(p, q)
+            hit = np.flatnonzero((pp[0] == lo) & (pp[1] == hi))
+            if len(hit) == 0:
+                continue
+            edge_cols.append(hit)
+            other_lo = pq[1, (pq[0] == lo) & (pq[1] != grain)]
+            other_hi = pq[1, (pq[0] == hi) & (pq[1] != grain)]
+            if other_lo[0] in other_hi:
+                across.append(int(other_lo[0]))
+            elif other_lo[1] in other_hi:
+                across.append(int(other_lo[1]))
+            else:
+                raise TopologyError(f"edge ({lo}, {hi}) of grain {grain} has no grain on its other side")
+        edge_cols = np.concatenate(edge_cols) if edge_cols else np.zeros(0, np.int64)
+        if len(across) != len(corners):
+            raise TopologyError(f"grain {grain}: {len(corners)} junctions but {len(across)} edges")
+        if len(set(across)) != len(across):
+            return None
+        order = np.argsort(y_grain_area[np.asarray(across, dtype=np.int64)], kind="stable")
+        cols = edge_cols[order[:-2]]
+        forced = self.switch_edges(cols, vanishing_grain=grain)
+        for g in [grain] + forced:
+            self.remove_two_sided_grain(g)
+        for c in cols:
+            if int(c) in pending_switches:
+                pending_switches.remove(int(c))
+        self.remove_all_two_sided()
+        return forced
+
+    def finish(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """models.py:845-858 + :837: drop dead columns (order kept); grain->joint = flipped joint->grain."""
+        pq = self.pq[:, self.pq[0] != DEAD]
+        pp = self.pp[:, self.pp[0] != DEAD]
+        return pp, pq, pq[::-1].copy()
+
+
+def update_topology(x_joint: np.ndarray, ei_jj: np.ndarray, ei_jg: np.ndarray, y_joint: np.ndarray,
+                    y_grain: np.ndarray, edge_prob: np.ndarray, grain_event: Sequence[int],
+                    mask_grain: np.ndarray, mask_joint: np.ndarray, threshold: float,
+                    active_grains: Optional[np.ndarray] = None, active_joints: Optional[np.ndarray] = None):
+    """One call of the reference's `Cmodel.update` (nucleation off).  `x_joint` [N_j, 8] fp32,
+    `y_joint` [N_j, 2] fp32 and the masks are modified in place.  `edge_prob` = sigmoid of the
+    classifier's `edge_event` logits, `grain_event` = grains below the area threshold, smallest
+    first (test.py:418-420).  Returns (ei_jj, ei_jg, ei_gj, switching_list [S, 2], grain_event')."""
+    topo = GrainTopology(ei_jj, ei_jg, x_joint, y_joint, mask_grain, mask_joint, active_joints)
+    src, dst = topo.pp[0], topo.pp[1]
+    pending = [int(c) for c in np.flatnonzero((edge_prob > threshold) & (src < dst))]
+    active_g = None if active_grains is None else set(int(v) for v in active_grains)
+    extra: List[int] = []
+    for grain in [int(g) for g in grain_event]:
+        if active_g is not None and grain not in active_g:
+            continue
+        forced = topo.eliminate_grain(grain, y_grain[:, 0], pending)
+        if forced:
+            extra.extend(forced)
+    # neighbour switching, most probable edge first (ties: lower column first)
+    pending = [pending[i] for i in np.argsort(-edge_prob[np.asarray(pending, dtype=np.int64)], kind="stable")] \
+        if pending else []
+    pending = [c for c in pending if topo.pp[0, c] != DEAD]
+    topo.switch_edges(pending, vanishing_grain=None)
+    switching_list = topo.pp[:, np.asarray(pending, dtype=np.int64)].T.copy() if pending \
+        else np.zeros((0, 2), np.int64)
+    extra.extend(topo.remove_all_two_sided())
+    events = np.concatenate([np.asarray(grain_event, dtype=np.int64).reshape(-1),
+                             np.asarray(extra, dtype=np.int64)]) if extra \
+        else np.asarray(grain_event, dtype=np.int64).reshape(-1)
+    pp, pq, qp = topo.finish()
+    return pp, pq, qp, switching_list, events

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 7
+#define GGNN_ABI_VERSION 8
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
@@ -252,6 +252,13 @@ int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x
                        int64_t n_joint, int64_t ldx_joint, const float* domain_offset,
                        float domain_factor, float* x_grain, int64_t n_grain, int64_t ldx_grain,
                        ggnn_stream_t stream);
+/* Event detection for the host-side topology update (test.py:418, models.py:624-626):
+ * flags[0] = number of grains with live_grain > 0 and grain_area < area_threshold,
+ * flags[1] = number of junction-junction edges with src < dst and edge_event (a logit) >
+ * logit_threshold.  flags: [2] int32 device words (zeroed by the call). */
+int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
+                       float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
+                       int64_t E, float logit_threshold, int32_t* flags, ggnn_stream_t stream);
 typedef struct ggnn_refresh_edge {
   const int64_t* edge_index; /* [2, E] */
   const float* x_src;

@@ -164,6 +164,11 @@ class TorchEmulatorBackend:
                 m = m - torch.floor(m)
             x_grain[g, :2] = m
 
+    def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,
+                      logit_threshold, flags):
+        flags[0] = int(((live_grain > 0) & (grain_area < area_threshold)).sum())
+        flags[1] = int(((edge_event > logit_threshold) & (edge_index_jj[0] < edge_index_jj[1])).sum())
+
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
         if int(flags[1]):
             x_joint[:, 2] = zmax

@@ -449,6 +449,61 @@ def test_grain_centres_full_size_and_edge_cases():
 
 
 # ---------------------------------------------------------------------------------------
+# event-driven rollout (device steps + host topology update + CSR rebuild)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_graph", [False, True])
+@torch.no_grad()
+def test_event_rollout_reproduces_reference_trajectory(use_graph):
+    """Free-running rollout of the 40 um graph with seeded weights, events ON: steps 1-2 are quiet,
+    step 3 eliminates 22 grains, step 4 another 75 (9 of them force-eliminated).  The reference's
+    own loop (forward, Rmodel.update, Cmodel.update, GNN_update, centre + edge refresh) produced
+    tests/golden/golden_cfg1_events.npz; the edge lists must come out identical, column for
+    column, and the refreshed grain centres within the fp32 tolerance."""
+    import os
+    from helpers import GOLDEN
+    from graingraphnn_amd import GrainRollout
+    ev = np.load(os.path.join(GOLDEN, "golden_cfg1_events.npz"))
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=use_graph, refresh_centres=True)
+    ro.enable_events({"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}, 1e-4, 0.6)
+    for step in range(1, 5):
+        pred, events, switches = ro.step_events()
+        if step < 3:
+            assert len(events) == 0 and len(switches) == 0
+            continue
+        name = f"mass{step}"
+        assert events.tolist() == ev[name + "__out_grain_event"].tolist()
+        for et in EDGE_TYPES:
+            assert np.array_equal(ro.edge_index[et].cpu().numpy(), ev[name + "__out_ei_" + etk(et)]), (step, et)
+        assert np.array_equal(ro.mask["grain"], ev[name + "__out_mask_grain"])
+        assert np.array_equal(ro.mask["joint"], ev[name + "__out_mask_joint"])
+        assert_close(X["grain"], ev[name + "__next_x_grain"], f"step {step} grains after the centre refresh")
+        live = ro.mask["joint"][:, 0] > 0
+        assert_close(X["joint"][torch.from_numpy(live).to(DEV)], ev[name + "__out_x_joint"][live],
+                     f"step {step} live junctions")
+    assert ro.edge_index[JJ].size(1) == 156 and int(ro.mask["grain"].sum()) == 26
+    # the rollout keeps running on the shrunken graph
+    ro.step_events()
+    assert bool(torch.isfinite(X["joint"]).all())
+
+
+@torch.no_grad()
+def test_detect_events_counts():
+    be = backend()
+    rs = np.random.RandomState(2)
+    area = torch.from_numpy(rs.uniform(0, 2e-4, 5000).astype(np.float32)).to(DEV)
+    live = torch.from_numpy((rs.uniform(size=5000) > 0.3).astype(np.int32)).to(DEV)
+    logit = torch.from_numpy(rs.normal(0, 1, 7001).astype(np.float32)).to(DEV)
+    ei = torch.from_numpy(rs.randint(0, 3000, (2, 7001))).to(DEV)
+    flags = torch.full((2,), 77, dtype=torch.int32, device=DEV)
+    be.detect_events(area, live, 1e-4, logit, ei, 0.405, flags)
+    assert int(flags[0]) == int(((live > 0) & (area < 1e-4)).sum())
+    assert int(flags[1]) == int(((logit > 0.405) & (ei[0] < ei[1])).sum())
+
+
+# ---------------------------------------------------------------------------------------
 # BASELINE config 4: independent trajectories batched as one disjoint-union graph
 # ---------------------------------------------------------------------------------------
 @torch.no_grad()

@@ -1,0 +1,115 @@
+"""the host-side topology update against vectors produced by the unmodified
+reference `GrainNN_classifier.update` (tests/golden/make_golden_events.py).  Integer work:
+bit-exact, including the COLUMN ORDER of every edge list."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from graingraphnn_amd.topology import GJ, JG, JJ, TopologyError, update_topology
+
+EV = np.load(os.path.join(GOLDEN, "golden_cfg1_events.npz"))
+SCENARIOS = ["elim1", "switch1", "switch3", "mixed", "mass3", "mass4"]
+
+
+def k(et):
+    return "ei_" + "__".join(et)
+
+
+def run(name):
+    i, o = name + "__in_", name + "__out_"
+    xj = EV[i + "x_joint"].copy()
+    yj = EV[i + "y_joint"].copy()
+    mg, mj = EV[i + "mask_grain"].copy(), EV[i + "mask_joint"].copy()
+    prob = torch.sigmoid(torch.from_numpy(EV[i + "edge_event"])).numpy()
+    res = update_topology(xj, EV[i + k(JJ)], EV[i + k(JG)], yj, EV[i + "y_grain"], prob,
+                          EV[i + "grain_event"], mg, mj, 0.6)
+    return res, xj, yj, mg, mj, o
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_update_matches_reference_bit_for_bit(name):
+    (pp, pq, qp, sw, events), xj, yj, mg, mj, o = run(name)
+    assert np.array_equal(pp, EV[o + k(JJ)]), "joint-joint edge list (values or column order)"
+    assert np.array_equal(pq, EV[o + k(JG)]), "joint-grain edge list"
+    assert np.array_equal(qp, EV[o + k(GJ)]), "grain-joint edge list"
+    assert np.array_equal(sw, EV[o + "switching_list"])
+    assert np.array_equal(events, EV[o + "grain_event"])
+    assert np.array_equal(mg, EV[o + "mask_grain"]) and np.array_equal(mj, EV[o + "mask_joint"])
+    assert np.array_equal(xj, EV[o + "x_joint"]), "junction features (fp32, bit-exact)"
+    assert np.array_equal(yj, EV[o + "y_joint"])
+    assert np.array_equal(EV[name + "__in_x_grain"], EV[o + "x_grain"])     # grains are not touched here
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_result_is_a_valid_grain_graph(name):
+    """graph_trajectory.py:985-988 invariants survive every update: live junctions have exactly
+    three grain and three junction neighbours, edge lists are symmetric, E = 3 N_live."""
+    (pp, pq, qp, sw, events), xj, yj, mg, mj, o = run(name)
+    live_j = np.flatnonzero(mj[:, 0] > 0)
+    assert pp.shape[1] == pq.shape[1] == 3 * len(live_j)
+    assert (np.bincount(pp[0], minlength=len(mj))[live_j] == 3).all()
+    assert (np.bincount(pq[0], minlength=len(mj))[live_j] == 3).all()
+    assert set(map(tuple, pp.T)) == set(map(tuple, pp[::-1].T))
+    dead_g = np.flatnonzero(mg[:, 0] == 0)
+    assert not np.isin(pq[1], dead_g).any() and set(events.tolist()) <= set(dead_g.tolist())
+    # Euler on the torus: junctions = 2 x grains
+    assert len(live_j) == 2 * int((mg[:, 0] > 0).sum())
+
+
+def test_quiet_step_is_the_identity():
+    i = "elim1__in_"
+    xj, yj = EV[i + "x_joint"].copy(), EV[i + "y_joint"].copy()
+    mg, mj = EV[i + "mask_grain"].copy(), EV[i + "mask_joint"].copy()
+    pp, pq, qp, sw, ev = update_topology(xj, EV[i + k(JJ)], EV[i + k(JG)], yj, EV[i + "y_grain"],
+                                         np.zeros(EV[i + k(JJ)].shape[1], np.float32), [], mg, mj, 0.6)
+    assert np.array_equal(pp, EV[i + k(JJ)]) and np.array_equal(pq, EV[i + k(JG)])
+    assert np.array_equal(xj, EV[i + "x_joint"]) and len(sw) == 0 and len(ev) == 0
+
+
+def test_invalid_lists_fail_loudly():
+    i = "elim1__in_"
+    pq = EV[i + k(JG)].copy()
+    pq[1, np.flatnonzero(pq[1] == 44)[0]] = 45          # grain 44 loses a corner: no longer a polygon
+    with pytest.raises((TopologyError, IndexError, ValueError)):
+        update_topology(EV[i + "x_joint"].copy(), EV[i + k(JJ)], pq, EV[i + "y_joint"].copy(),
+                        EV[i + "y_grain"], np.zeros(708, np.float32), [44],
+                        EV[i + "mask_grain"].copy(), EV[i + "mask_joint"].copy(), 0.6)
+
+
+def test_classifier_update_is_a_drop_in():
+    """The reference call of test.py:426 on torch tensors: same argument list, same in-place
+    effects, same return values as `GrainNN_classifier.update` of the reference."""
+    from helpers import product_models
+    _, Cm = product_models(10020)
+    Cm.threshold = 0.6
+    i, o = "mixed__in_", "mixed__out_"
+    t = lambda a: torch.from_numpy(np.array(a, copy=True))
+    x = {"joint": t(EV[i + "x_joint"]), "grain": t(EV[i + "x_grain"])}
+    ei = {et: t(EV[i + k(et)]) for et in (GJ, JG, JJ)}
+    y = {"joint": t(EV[i + "y_joint"]), "grain": t(EV[i + "y_grain"]), "edge_event": t(EV[i + "edge_event"]),
+         "grain_event": t(EV[i + "grain_event"])}
+    mask = {"grain": t(EV[i + "mask_grain"]), "joint": t(EV[i + "mask_joint"])}
+    gs = {"active_grains": torch.arange(118), "active_joints": torch.arange(236)}
+    old_jj = ei[JJ]
+    x2, ei2, sw = Cm.update(x, ei, None, y, mask, gs, 0.0)
+    assert x2 is x and ei2 is ei and ei[JJ] is not old_jj
+    for et in (GJ, JG, JJ):
+        assert torch.equal(ei[et], t(EV[o + k(et)]))
+    assert torch.equal(x["joint"], t(EV[o + "x_joint"])) and torch.equal(y["joint"], t(EV[o + "y_joint"]))
+    assert torch.equal(y["grain_event"], t(EV[o + "grain_event"])) and torch.equal(sw, t(EV[o + "switching_list"]))
+    assert torch.equal(mask["grain"], t(EV[o + "mask_grain"])) and torch.equal(mask["joint"], t(EV[o + "mask_joint"]))
+    with pytest.raises(NotImplementedError):
+        Cm.update(x, ei, None, y, mask, gs, 0.01)      # nucleation is out of scope
+    # a junction outside the active window freezes its events (models.py:640-645, 911)
+    x = {"joint": t(EV[i + "x_joint"]), "grain": t(EV[i + "x_grain"])}
+    ei = {et: t(EV[i + k(et)]) for et in (GJ, JG, JJ)}
+    y = {"joint": t(EV[i + "y_joint"]), "grain": t(EV[i + "y_grain"]),
+         "edge_event": torch.full((708,), -8.0), "grain_event": torch.tensor([60])}
+    mask = {"grain": t(EV[i + "mask_grain"]), "joint": t(EV[i + "mask_joint"])}
+    corner = int(ei[JG][0][ei[JG][1] == 60][0])
+    gs = {"active_grains": torch.arange(118), "active_joints": torch.tensor([j for j in range(236) if j != corner])}
+    Cm.update(x, ei, None, y, mask, gs, 0.0)
+    assert torch.equal(ei[JJ], t(EV[i + k(JJ)])) and int(mask["grain"].sum()) == 118
