@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
     ap.add_argument("--phase-shift", action="store_true",
                     help="start the classifier one kernel phase after the regressor (measured slower)")
+    ap.add_argument("--events", action="store_true",
+                    help="event-driven mode (SURVEY 8f-2): per-step event detection + host topology update when "
+                         "one fires; not the headline metric")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"],
                     help="cfg3 (default, the BASELINE metric): 10k-grain honeycomb; cfg2: the 120 um fixture "
                          "(1043 grains); cfg4: 64 perturbed 40 um trajectories sharded over the ranks, each "
@@ -207,8 +210,26 @@ def main():
                       phase_shift=args.phase_shift, refresh_centres=True, domain_factor=inputs[3],
                       domain_offset=None if inputs[4] is None else torch.from_numpy(inputs[4]))
 
+    step = ro.step
+    if args.events:
+        n_g, n_j = X["grain"].size(0), X["joint"].size(0)
+        ro.enable_events({"grain": np.ones((n_g, 1)), "joint": np.ones((n_j, 1))}, 1e-4, 0.6)
+        from graingraphnn_amd.topology import TopologyError
+        ev_state = {"stopped": None, "n": 0}
+
+        def step():
+            # random (untrained) weights eventually drive the graph into states the reference itself
+            # asserts on (models.py:673); from then on the run continues with the events switched off
+            ev_state["n"] += 1
+            if ev_state["stopped"] is None:
+                try:
+                    return ro.step_events()
+                except (TopologyError, IndexError, ValueError) as exc:
+                    ev_state["stopped"] = f"step {ev_state['n']}: {type(exc).__name__}: {exc}"
+                    ro.area_threshold, ro.edge_threshold, ro._logit_trigger = -1.0, 2.0, 1e30
+            return ro.step_events()
     for _ in range(args.warmup):
-        ro.step()
+        step()
     gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
     torch.cuda.synchronize()
     if world > 1:
@@ -216,7 +237,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ro.step()
+        step()
     gathered = gather_states(ro.state(), world)  # RCCL all-gather of the rollout results
     torch.cuda.synchronize()
     if world > 1:
@@ -248,7 +269,12 @@ def main():
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
-                       "results_finite": finite},
+                       "results_finite": finite,
+                       **({"events": {"grains_eliminated": int(sum(len(e) for e in ro.grain_events)),
+                                      "edges_switched": int(sum(len(e) for e in ro.switched)),
+                                      "edges_left": int(ro.edge_index[("joint", "connect", "joint")].size(1)),
+                                      "stopped": ev_state["stopped"]}}
+                          if args.events else {})},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and args.workload == "cfg3":
