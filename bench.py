@@ -69,17 +69,24 @@ class EventTimedBackend:
         if n_gates != 4:
             return self.inner.aggregate(*args)
         csr, p_src, p_dst = args[0], args[2], args[3]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # An event bracket also contains the dispatch latency of the launch (3-5 us in eager mode),
+        # which rocprofv3's kernel durations do not.  The sweep overwrites its outputs, so it can be
+        # repeated: [1 launch] and [2 launches] brackets differ by exactly one kernel duration.
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         self.inner.aggregate(*args)
         e1.record()
-        self.events.append((e0, e1, algorithmic_bytes(p_src.size(0), p_dst.size(0), csr.E, 4)))
+        self.inner.aggregate(*args)
+        self.inner.aggregate(*args)
+        e2.record()
+        self.events.append((e0, e1, e2, algorithmic_bytes(p_src.size(0), p_dst.size(0), csr.E, 4)))
 
 
 def measure_roofline(ro, n_steps):
     """Average duration of aggregate_kernel<4> launches inside real rollout steps (eager
     launches, regressor and classifier serialised so that no other kernel shares the chip
-    with the launch being timed)."""
+    with the launch being timed; HIP events on the launch stream, dispatch latency removed by
+    differencing a one-launch and a two-launch bracket)."""
     timed = EventTimedBackend(ro.be)
     ro.be, side = timed, ro._side
     ro._side = None
@@ -89,13 +96,15 @@ def measure_roofline(ro, n_steps):
         torch.cuda.synchronize()
     finally:
         ro.be, ro._side = timed.inner, side
-    ms = [a.elapsed_time(b) for a, b, _ in timed.events]
-    avg_bytes = float(np.mean([nb for _, _, nb in timed.events]))  # per launch, as launched
+    ms = [b.elapsed_time(c) - a.elapsed_time(b) for a, b, c, _ in timed.events]
+    bracket = float(np.mean([a.elapsed_time(b) for a, b, _, _ in timed.events])) * 1e3
+    avg_bytes = float(np.mean([ev[3] for ev in timed.events]))  # per launch, as launched
     avg_s = float(np.mean(ms)) * 1e-3
     achieved = avg_bytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4>", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic(), "avg_launch_us": round(avg_s * 1e6, 2),
+            "single_launch_event_bracket_us": round(bracket, 2),
             "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(ms)}
 
 
