@@ -13,18 +13,17 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 8
-GGNN_ENC_W_ROW = 40
+GGNN_ABI_VERSION = 9
 GGNN_UNIT_EDGES = 3
 GGNN_C = 96
-GGNN_EDGE_PARAM_ROWS = 7
+GGNN_EDGE_PARAM_ROWS = 3
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
 EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
-    "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_period_gat_aggregate_enc", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
+    "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -51,22 +50,12 @@ class AggregateArgs(Structure):
     """Mirror of `ggnn_aggregate_args`."""
     _fields_ = [
         ("unit_ptr", c_void_p), ("units", c_void_p), ("einfo", c_void_p),
-        ("p_src", c_void_p), ("p_dst", c_void_p), ("edge_params", c_void_p), ("agg", c_void_p),
-        ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
-        ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
-        ("kv_off", c_int32), ("q_off", c_int32), ("a_off", c_int32), ("a_gstride", c_int32),
-        ("sc_off", c_int32), ("n_gates", c_int32),
-    ]
-
-
-class AggregateEncArgs(Structure):
-    """Mirror of `ggnn_aggregate_enc_args`."""
-    _fields_ = [
-        ("unit_ptr", c_void_p), ("units", c_void_p), ("einfo", c_void_p), ("x_src", c_void_p),
-        ("x_dst", c_void_p), ("enc_w", c_void_p), ("agg", c_void_p),
-        ("ld_agg", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
-        ("f_src", c_int32), ("f_dst", c_int32), ("a_off", c_int32), ("a_gstride", c_int32),
-        ("sc_off", c_int32), ("n_gates", c_int32),
+        ("p_src", c_void_p), ("p_dst", c_void_p), ("x_src", c_void_p), ("h_src", c_void_p),
+        ("edge_params", c_void_p), ("agg", c_void_p),
+        ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64), ("ldx_src", c_int64),
+        ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
+        ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
+        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("f_src", c_int32),
     ]
 
 
@@ -115,8 +104,6 @@ def _declare(lib):
                                  c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
     lib.ggnn_period_gat_aggregate.restype = c_int
     lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
-    lib.ggnn_period_gat_aggregate_enc.restype = c_int
-    lib.ggnn_period_gat_aggregate_enc.argtypes = [POINTER(AggregateEncArgs), c_void_p]
     lib.ggnn_lstm_epilogue.restype = c_int
     lib.ggnn_lstm_epilogue.argtypes = [POINTER(EpilogueArgs), c_void_p]
     lib.ggnn_heads_regressor.restype = c_int

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AggregateArgs, AggregateEncArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
+from ._lib import AggregateArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
 
 
 class CSR:
@@ -91,33 +91,24 @@ class HipBackend:
                                     _lib.current_stream()), "ggnn_project")
 
     # -- aggregation -------------------------------------------------------------------
-    def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
-                  sc_off, n_gates):
-        _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, ep, agg)
+    def aggregate(self, csr, einfo, p_src, p_dst, x_src, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+                  a_gstride, sc_off, n_gates):
+        """One sweep of ggnn_period_gat_aggregate (include/ggnn.h).  x_src: the source node type's
+        feature tensor [n_src, F] (row-strided views allowed), h_src: its hidden state [n_src, 96]
+        or None (encoder)."""
+        _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, x_src, h_src, ep, agg)
         a = AggregateArgs()
         a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
-        a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
+        a.p_src, a.p_dst, a.x_src = p_src.data_ptr(), p_dst.data_ptr(), x_src.data_ptr()
+        a.h_src = None if h_src is None else h_src.data_ptr()
         a.edge_params, a.agg = ep.data_ptr(), agg.data_ptr()
         a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
+        a.ldx_src, a.ldh_src = x_src.stride(0), 0 if h_src is None else h_src.stride(0)
         a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), csr.E
-        a.kv_off, a.q_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
-            kv_off, q_off, a_off, a_gstride, sc_off, n_gates)
+        a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates, a.f_src = (
+            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, x_src.size(1))
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),
               "ggnn_period_gat_aggregate")
-
-    def aggregate_enc(self, csr, einfo, x_src, x_dst, enc_w, agg, a_off, a_gstride, sc_off, n_gates):
-        """Encoder cell (h = c = 0): key / value / query recomputed per edge from feature rows."""
-        _require_cuda(csr.unit_ptr, einfo, x_src, x_dst, enc_w, agg)
-        if not (x_src.is_contiguous() and x_dst.is_contiguous()):
-            raise _lib.GGNNError("aggregate_enc needs contiguous [n, f] feature rows")
-        a = AggregateEncArgs()
-        a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
-        a.x_src, a.x_dst, a.enc_w, a.agg = x_src.data_ptr(), x_dst.data_ptr(), enc_w.data_ptr(), agg.data_ptr()
-        a.ld_agg, a.n_src, a.n_dst, a.E = agg.stride(0), x_src.size(0), x_dst.size(0), csr.E
-        a.f_src, a.f_dst = x_src.size(1), x_dst.size(1)
-        a.a_off, a.a_gstride, a.sc_off, a.n_gates = a_off, a_gstride, sc_off, n_gates
-        check(self.lib.ggnn_period_gat_aggregate_enc(ctypes.byref(a), _lib.current_stream()),
-              "ggnn_period_gat_aggregate_enc")
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,

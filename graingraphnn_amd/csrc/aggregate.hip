@@ -2,14 +2,23 @@
 // Replaces PeriodConv.message (periodGATconv.py:204-236) and the gather / scatter-add of
 // PyG MessagePassing.propagate (periodGATconv.py:174-175) with an atomics-free CSR sweep.
 //
-// Per edge e = (j -> i) and gate g, with reloc_e = minimg(x_j[:3] - x_i[:3]) computed
-// exactly as periodGATconv.py:209-210 does, a_e = edge_attr_e, and the node-level
-// projections K0_j, V0_j (key/value WITHOUT their first three input columns) and Q_i:
-//   k_e   = K0_j + Wk3 . reloc_e + w_edge * a_e
-//   s_e   = (Q_i . k_e) / sqrt(96)
-//   alpha = exp(s_e - max_i) / (sum_i exp(.) + 1e-16)            (PyG softmax)
-//   r_e   = relu(V0_j + Wv3 . reloc_e)
+// Per edge e = (j -> i) and gate g, with reloc_e = minimg(x_j[:3] - x_i[:3]) computed exactly as
+// periodGATconv.py:209-210 does, a_e = edge_attr_e and x~_j = [reloc_e, x_j[3:F], h_j]:
+//   s_e   = q_i . (W_k x~_j + b_k + w_edge a_e) / sqrt(96)                       (:216-226)
+//         = u_i . x~_j + s1_i + a_e s2_i       with  u_i = W_k^T q_i / sqrt(96),
+//                                                    s1_i = b_k . q_i / sqrt(96), s2_i = w_edge . q_i / sqrt(96)
+//   alpha = exp(s_e - max_i) / (sum_i exp(.) + 1e-16)                            (PyG softmax)
+//   r_e   = relu(V0_j + Wv3 . reloc_e)          V0 = value WITHOUT its first three input columns
 //   agg_i = sum_e alpha_e r_e,  sa_i = sum_e alpha_e,  sae_i = sum_e alpha_e a_e
+// The KEY never exists: the destination-side projection (ggnn_project) delivers u_i, s1_i, s2_i
+// (all affine in the destination's [x_i | h_i]: one row of W_k^T W_q per source feature), and
+// the sweep dots u_i with the source's RAW [x_j | h_j] row.  Against gathering a projected key
+// this removes a quarter of the projection's output columns, and the 384-byte h_j row is shared
+// by all gates where the four 384-byte key fragments were not; in the encoder (h = 0) the key
+// side shrinks to the 8 / 11 feature floats.
+//   per (destination, gate):  u_h [96] | u4 [16] = (u_x[0..F), 0.., s1 @12, s2 @13, 0, 0)
+//   per edge:                 h_j [96] | x4 [16] = (reloc, x_j[3..F), 0.., 1 @12, a_e @13, 0, 0)
+//   s_e = sum over the half-wave of  u_h . h_j (3 channels per lane) + u4 * x4 (lanes 0..15)
 //
 // ggnn_edge_prepare computes (reloc_e, a_e) once per forward in CSR order (16 bytes per
 // edge, shared by the 7 gate sweeps of encoder + decoder).
@@ -20,23 +29,21 @@
 // round-robin to their waves, so an XCD always works inside a short sliding window of
 // neighbouring rows and the 3-6 re-reads of a source row hit its L2 (rocprofv3: 63 % L2
 // misses and 2x the algorithmic bytes fetched with per-workgroup contiguous ranges).
-// A WAVE takes such a row stream and a pair of gates (one gate per half-wave: 32 lanes x 3 channels, so one
-// global_load_dwordx3 is one 384-byte row fragment) and streams through the sub-range's
-// units.  Both halves see the same units, so everything that describes a unit is
-// wave-uniform and lives on the scalar side:
+// A WAVE takes such a row stream and a pair of gates (one gate per half-wave: 32 lanes x 3
+// channels, so one global_load_dwordx3 is one 384-byte row fragment).  Both halves see the same
+// units, so everything that describes a unit is wave-uniform and lives on the scalar side:
 //   * descriptor and the 3 edge records (reloc, a_e) come through scalar loads (SMEM) into
-//     SGPRs; the scalar chain for unit u+1 (descriptor -> its edge records) runs while the
-//     vector loads of unit u are in flight, and does not touch the vector-memory counter;
-//   * the vector side of a unit is exactly 7 loads issued back to back: Q and the 3 x (K, V)
-//     fragments -- one exposed round trip per unit, ~21 VGPRs of load state, which keeps the
-//     kernel at 8 waves per SIMD (64 half-wave streams, ~170 KB requested per CU);
-//   * scores are folded into an online-max softmax carried in registers across the units
-//     of one row (any degree, bounded registers, nothing re-read); the row is stored once,
-//     when its last unit is done.  No atomics => bit-reproducible.
-// Only the 7 x 96 per-gate edge parameters go through LDS.  (Measured alternatives, in git
-// history and profiles/: v1 block-staged CSR 64 us; v2 per-half-wave CSR walk 53 us; v3
-// per-wave LDS-DMA gather ring 63 us -- 86 KB/CU in flight but issue-bound at one wave per
-// SIMD; v4 unit table + vector-side descriptor prefetch 41 us.)
+//     SGPRs; the scalar chain for unit u+1 runs while the vector loads of unit u are in flight;
+//   * the vector side of a unit is issued back to back and unconditionally (absent edges repeat
+//     j0; a load under `if` would drag a wait to the branch merge): u_h, u4 and per edge h_j, x4,
+//     V -- one exposed round trip per unit;
+//   * scores are folded into an online-max softmax carried in registers across the units of one
+//     row (any degree, bounded registers, nothing re-read); the row is stored once, when its last
+//     unit is done.  No atomics => bit-reproducible.
+// (Measured alternatives, in git history and profiles/: v1 block-staged CSR 64 us; v2
+// per-half-wave CSR walk 53 us; v3 per-wave LDS-DMA gather ring 63 us; v4 unit table + vector-side
+// descriptor prefetch 41 us; v7 projected keys gathered per gate 31 us; a fused encoder sweep
+// recomputing K0 / V0 / Q per edge from feature rows: VALU-bound, slower.)
 #include "common.h"
 
 namespace ggnn {
@@ -106,15 +113,15 @@ template <int G> struct Shape {
   static constexpr int subs = waves / pairs;  // row sub-ranges per workgroup
 };
 
-template <int G>
+template <int G, bool HAS_H>
 __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_args A) {
   using SH = Shape<G>;
-  // [g][channel][8]: 7 parameters of one channel contiguous (32 B) -> two 16-byte LDS reads
-  __shared__ __attribute__((aligned(16))) float s_ep[G * C * 8];
+  // [g][channel][4]: W_value[:, 0..2] of one channel (16 B) -> one 16-byte LDS read per channel
+  __shared__ __attribute__((aligned(16))) float s_ep[G * C * 4];
   const int tid = threadIdx.x;
   for (int t = tid; t < G * GGNN_EDGE_PARAM_ROWS * C; t += 256) {
     const int g = t / (GGNN_EDGE_PARAM_ROWS * C), r = (t / C) % GGNN_EDGE_PARAM_ROWS, c = t % C;
-    s_ep[(g * C + c) * 8 + r] = A.edge_params[t];
+    s_ep[(g * C + c) * 4 + r] = A.edge_params[t];
   }
   __syncthreads();
 
@@ -124,7 +131,12 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
   const bool active = g < G;                  // odd G: the last pair's upper half idles
   const int gc = active ? g : 0;
   const int ch = 3 * (tid & 31);              // first of this lane's three channels
-  const float inv_sqrt_c = 0.10206207261596577f;  // 1/sqrt(96), periodGATconv.py:226
+  // lanes 0..15 of the half-wave also carry one element of the 16-wide tail (see the header)
+  const int l16 = tid & 15;
+  const bool tail = (tid & 16) == 0;
+  const float c_rx = tail && l16 == 0, c_ry = tail && l16 == 1, c_rz = tail && l16 == 2;
+  const float c_x = tail && l16 >= 3 && l16 < A.f_src, c_one = tail && l16 == 12, c_a = tail && l16 == 13;
+  const int xi = min(l16, A.f_src - 1);
 
   // Row assignment (all wave-uniform).  Workgroups with equal blockIdx % 8 share an XCD and
   // its L2 (observed placement; speed only).  Each such group owns one contiguous eighth of
@@ -144,12 +156,16 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
   const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
   const const_f32x4_ptr einfo = (const_f32x4_ptr)(uintptr_t)A.einfo;
 
-  // this lane's 3 channels x 8 parameters: [wkx wky wkz wvx | wvy wvz we -]
-  const f32x4* epp = reinterpret_cast<const f32x4*>(&s_ep[(gc * C + ch) * 8]);
-  const f32x4 e0a = epp[0], e0b = epp[1], e1a = epp[2], e1b = epp[3], e2a = epp[4], e2b = epp[5];
-  const float* kvbase = A.p_src + A.kv_off + gc * 2 * C + ch;
-  const float* qbase = A.p_dst + A.q_off + gc * C + ch;
+  // this lane's 3 channels x (wvx, wvy, wvz)
+  const f32x4* epp = reinterpret_cast<const f32x4*>(&s_ep[(gc * C + ch) * 4]);
+  const f32x4 w0 = epp[0], w1 = epp[1], w2 = epp[2];
+  const float* vbase = A.p_src + A.v_off + gc * C + ch;
+  const float* uhbase = A.p_dst + A.u_off + gc * C + ch;
+  const float* u4base = A.p_dst + A.u4_off + gc * 16 + l16;
+  const float* hbase = A.h_src + ch;
+  const float* xbase = A.x_src + xi;
   const uint32_t ldp_src = (uint32_t)A.ldp_src, ldp_dst = (uint32_t)A.ldp_dst;
+  const uint32_t ldh = (uint32_t)A.ldh_src, ldx = (uint32_t)A.ldx_src;
 
   float mx = -INFINITY, den = 0.f, sae = 0.f;
   f3 acc = {0.f, 0.f, 0.f};
@@ -164,21 +180,24 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
   while (true) {
     const int i = d[0], nact = d[2] & 0xFF;
     const bool first = (d[2] >> 8) & 1, last = (d[2] >> 9) & 1;
-    // ---- vector side: Q + 3 x (K, V), unconditional and back to back (absent edges repeat
-    // j0 in the descriptor, so every address is valid; they are masked when folded) ----
-    f3 q = {0.f, 0.f, 0.f}, kk[UE], vv[UE];
+    // ---- vector side, unconditional and back to back (host checked: n * ld < 2^31) ----
+    f3 uh = {0.f, 0.f, 0.f}, hh[UE], vv[UE];
+    float u4 = 0.f, x4[UE];
 #pragma unroll
     for (int t = 0; t < UE; ++t) {
-      kk[t] = {0.f, 0.f, 0.f};
+      hh[t] = {0.f, 0.f, 0.f};
       vv[t] = {0.f, 0.f, 0.f};
+      x4[t] = 0.f;
     }
     if (active) {
-      q = ld3_nt(qbase + (uint32_t)i * ldp_dst);  // read once; host checked: n * ld < 2^31
+      if (HAS_H) uh = ld3_nt(uhbase + (uint32_t)i * ldp_dst);  // read once
+      u4 = __builtin_nontemporal_load(u4base + (uint32_t)i * ldp_dst);
 #pragma unroll
       for (int t = 0; t < UE; ++t) {
-        const float* row = kvbase + (uint32_t)d[4 + t] * ldp_src;
-        kk[t] = ld3(row);
-        vv[t] = ld3(row + C);
+        const uint32_t j = (uint32_t)d[4 + t];
+        if (HAS_H) hh[t] = ld3(hbase + j * ldh);
+        x4[t] = xbase[j * ldx];
+        vv[t] = ld3(vbase + j * ldp_src);
       }
     }
     // ---- scalar side for the next unit (same row, or the first unit of this stream's next
@@ -214,11 +233,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
       for (int t = 0; t < UE; ++t) {
         s[t] = -INFINITY;
         if (t < nact) {
-          const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z, a = ed[t].w;
-          const float k0 = kk[t].x + e0a.x * rx + e0a.y * ry + e0a.z * rz + e0b.z * a;
-          const float k1 = kk[t].y + e1a.x * rx + e1a.y * ry + e1a.z * rz + e1b.z * a;
-          const float k2 = kk[t].z + e2a.x * rx + e2a.y * ry + e2a.z * rz + e2b.z * a;
-          s[t] = halfwave_sum(q.x * k0 + q.y * k1 + q.z * k2) * inv_sqrt_c;
+          // this lane's element of the tail: reloc / raw feature / 1 / a_e / 0
+          const float xe = c_x * x4[t] + c_rx * ed[t].x + c_ry * ed[t].y + c_rz * ed[t].z + c_a * ed[t].w + c_one;
+          float part = u4 * xe;
+          if (HAS_H) part += uh.x * hh[t].x + uh.y * hh[t].y + uh.z * hh[t].z;
+          s[t] = halfwave_sum(part);  // 1/sqrt(96) is folded into u
           mnew = fmaxf(mnew, s[t]);
         }
       }
@@ -233,9 +252,9 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
           const float pe = __expf(s[t] - mnew);
           den += pe;
           sae += pe * ed[t].w;
-          acc.x += pe * fmaxf(vv[t].x + e0a.w * rx + e0b.x * ry + e0b.y * rz, 0.f);
-          acc.y += pe * fmaxf(vv[t].y + e1a.w * rx + e1b.x * ry + e1b.y * rz, 0.f);
-          acc.z += pe * fmaxf(vv[t].z + e2a.w * rx + e2b.x * ry + e2b.y * rz, 0.f);
+          acc.x += pe * fmaxf(vv[t].x + w0.x * rx + w0.y * ry + w0.z * rz, 0.f);
+          acc.y += pe * fmaxf(vv[t].y + w1.x * rx + w1.y * ry + w1.z * rz, 0.f);
+          acc.z += pe * fmaxf(vv[t].z + w2.x * rx + w2.y * ry + w2.z * rz, 0.f);
         }
       }
       mx = mnew;
@@ -256,183 +275,6 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
     d = dn;
 #pragma unroll
     for (int t = 0; t < UE; ++t) ed[t] = edn[t];
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// encoder sweep: h = c = 0, so K0 / V0 / Q are affine maps of the 8- or 11-float feature rows.
-// Every input of a unit (descriptor, edge records, the destination's and the three sources'
-// feature rows) is wave-uniform and arrives through scalar loads; the lanes only hold the
-// 120 weights of their gate and three channels.  The inner loop has NO vector-memory load:
-// it is pure VALU (scalar x vector FMAs) plus the row store.
-// ---------------------------------------------------------------------------------------
-template <int FS, int FD>
-__global__ __launch_bounds__(256) void aggregate_enc_kernel(const ggnn_aggregate_enc_args A) {
-  constexpr int G = 3;
-  using SH = Shape<G>;
-  constexpr int KS = FS - 3;  // source features beyond xyz
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pair = wave % SH::pairs, sub = wave / SH::pairs;
-  const int g = pair * 2 + ((tid >> 5) & 1);
-  const bool active = g < G;
-  const int gc = active ? g : 0;
-  const int ch = 3 * (tid & 31);
-  const float inv_sqrt_c = 0.10206207261596577f;
-
-  // this lane's weights: 3 channels x 40 floats
-  f32x4 w[3][GGNN_ENC_W_ROW / 4];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int k = 0; k < GGNN_ENC_W_ROW / 4; ++k)
-      w[c][k] = *reinterpret_cast<const f32x4*>(A.enc_w + ((int64_t)(gc * C + ch + c)) * GGNN_ENC_W_ROW + 4 * k);
-  auto W = [&](int c, int idx) { return w[c][idx >> 2][idx & 3]; };
-
-  const int nblk = gridDim.x;
-  const int ngrp = min(nblk, 8);
-  const int grp = blockIdx.x % ngrp, lb = blockIdx.x / ngrp;
-  const int nb_grp = (nblk - grp + ngrp - 1) / ngrp;
-  const int64_t x_lo = A.n_dst * grp / ngrp, x_hi = A.n_dst * (grp + 1) / ngrp;
-  const int64_t n_streams = (int64_t)nb_grp * SH::subs;
-  int64_t r = x_lo + (int64_t)lb * SH::subs + sub;
-  if (sub >= SH::subs || r >= x_hi) return;
-  const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
-  const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
-  const const_f32x4_ptr einfo = (const_f32x4_ptr)(uintptr_t)A.einfo;
-  typedef const float __attribute__((address_space(4))) * const_f32_ptr;
-  const const_f32_ptr xs = (const_f32_ptr)(uintptr_t)A.x_src;
-  const const_f32_ptr xd = (const_f32_ptr)(uintptr_t)A.x_dst;
-
-  float mx = -INFINITY, den = 0.f, sae = 0.f;
-  f3 acc = {0.f, 0.f, 0.f};
-  f3 q = {0.f, 0.f, 0.f};
-
-  int u = uptr[r], u_end = uptr[r + 1];
-  i32x8 d = udesc[u];
-  f32x4 ed[UE];
-#pragma unroll
-  for (int t = 0; t < UE; ++t) ed[t] = einfo[(int64_t)d[1] + t];
-  // feature rows of a unit (scalar loads; absent edges repeat j0, so always valid)
-  float xi[FD], xj[UE][KS];
-#pragma unroll
-  for (int f = 0; f < FD; ++f) xi[f] = xd[(int64_t)d[0] * FD + f];
-#pragma unroll
-  for (int t = 0; t < UE; ++t)
-#pragma unroll
-    for (int f = 0; f < KS; ++f) xj[t][f] = xs[(int64_t)d[4 + t] * FS + 3 + f];
-
-  while (true) {
-    const int i = d[0], nact = d[2] & 0xFF;
-    const bool first = (d[2] >> 8) & 1, last = (d[2] >> 9) & 1;
-    // scalar side of the next unit
-    bool more = true;
-    int un = u + 1, un_end = u_end;
-    int64_t rn = r;
-    if (un >= u_end) {
-      rn = r + n_streams;
-      if (rn < x_hi) {
-        un = uptr[rn];
-        un_end = uptr[rn + 1];
-      } else {
-        more = false;
-        un = u;
-      }
-    }
-    const i32x8 dn = udesc[un];
-    f32x4 edn[UE];
-#pragma unroll
-    for (int t = 0; t < UE; ++t) edn[t] = einfo[(int64_t)dn[1] + t];
-    // ... including its feature rows: the whole scalar chain of unit u+1 runs under unit u's math
-    float xin[FD], xjn[UE][KS];
-#pragma unroll
-    for (int f = 0; f < FD; ++f) xin[f] = xd[(int64_t)dn[0] * FD + f];
-#pragma unroll
-    for (int t = 0; t < UE; ++t)
-#pragma unroll
-      for (int f = 0; f < KS; ++f) xjn[t][f] = xs[(int64_t)dn[4 + t] * FS + 3 + f];
-
-    if (first) {
-      mx = -INFINITY;
-      den = 0.f;
-      sae = 0.f;
-      acc = {0.f, 0.f, 0.f};
-      // query of this row: lin_query(x_i) (periodGATconv.py:216), x_i is NOT wrapped
-      float qq[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float a = W(c, 12);
-#pragma unroll
-        for (int f = 0; f < FD; ++f) a += W(c, f) * xi[f];
-        qq[c] = a;
-      }
-      q = {qq[0], qq[1], qq[2]};
-    }
-    if (active && nact > 0) {
-      float s[UE];
-      float vv[UE][3];
-      float mnew = mx;
-#pragma unroll
-      for (int t = 0; t < UE; ++t) {
-        s[t] = -INFINITY;
-        if (t < nact) {
-          const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z, a = ed[t].w;
-          float part = 0.f;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            float k = W(c, 21) + W(c, 31) * rx + W(c, 32) * ry + W(c, 33) * rz + W(c, 37) * a;
-            float v = W(c, 30) + W(c, 34) * rx + W(c, 35) * ry + W(c, 36) * rz;
-#pragma unroll
-            for (int f = 0; f < KS; ++f) {
-              k += W(c, 13 + f) * xj[t][f];
-              v += W(c, 22 + f) * xj[t][f];
-            }
-            vv[t][c] = fmaxf(v, 0.f);
-            part += (c == 0 ? q.x : (c == 1 ? q.y : q.z)) * k;
-          }
-          s[t] = halfwave_sum(part) * inv_sqrt_c;
-          mnew = fmaxf(mnew, s[t]);
-        }
-      }
-      const float scale = __expf(mx - mnew);
-      den *= scale;
-      sae *= scale;
-      acc = {acc.x * scale, acc.y * scale, acc.z * scale};
-#pragma unroll
-      for (int t = 0; t < UE; ++t) {
-        if (t < nact) {
-          const float pe = __expf(s[t] - mnew);
-          den += pe;
-          sae += pe * ed[t].w;
-          acc.x += pe * vv[t][0];
-          acc.y += pe * vv[t][1];
-          acc.z += pe * vv[t][2];
-        }
-      }
-      mx = mnew;
-    }
-    if (active && last) {
-      const float inv = 1.0f / (den + 1e-16f);
-      float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
-      st3_nt(orow + A.a_off + ch, {acc.x * inv, acc.y * inv, acc.z * inv});
-      if ((tid & 31) == 0) {
-        __builtin_nontemporal_store(den * inv, orow + A.sc_off);
-        __builtin_nontemporal_store(sae * inv, orow + A.sc_off + 1);
-      }
-    }
-    if (!more) break;
-    u = un;
-    u_end = un_end;
-    r = rn;
-    d = dn;
-#pragma unroll
-    for (int t = 0; t < UE; ++t) ed[t] = edn[t];
-#pragma unroll
-    for (int f = 0; f < FD; ++f) xi[f] = xin[f];
-#pragma unroll
-    for (int t = 0; t < UE; ++t)
-#pragma unroll
-      for (int f = 0; f < KS; ++f) xj[t][f] = xjn[t][f];
   }
 }
 
@@ -468,17 +310,27 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
 extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!args) return GGNN_EINVAL;
-  const ggnn_aggregate_args& A = *args;
-  if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.edge_params || !A.agg)
+  ggnn_aggregate_args A = *args;
+  if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.x_src || !A.edge_params || !A.agg)
     return GGNN_EINVAL;
   if (!aligned16(A.units) || !aligned16(A.einfo)) return GGNN_EINVAL;
   if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0) return GGNN_EINVAL;
   const int G = A.n_gates;
   if (G != 1 && G != 3 && G != 4) return GGNN_EINVAL;
-  if (A.kv_off < 0 || A.q_off < 0 || A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
-  if (A.ldp_src <= 0 || A.ldp_dst <= 0 || A.n_src * A.ldp_src >= INT32_MAX || A.n_dst * A.ldp_dst >= INT32_MAX)
+  if (A.f_src < 3 || A.f_src > 12 || A.ldx_src < A.f_src) return GGNN_EINVAL;
+  const bool has_h = A.h_src != nullptr;
+  if (has_h && (A.ldh_src < C || A.u_off < 0)) return GGNN_EINVAL;
+  if (!has_h) {  // never dereferenced, but the address arithmetic must stay in range
+    A.h_src = A.x_src;
+    A.ldh_src = 0;
+    A.u_off = 0;
+  }
+  if (A.v_off < 0 || A.u4_off < 0 || A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
+  if (A.ldp_src <= 0 || A.ldp_dst <= 0 || A.n_src * A.ldp_src >= INT32_MAX || A.n_dst * A.ldp_dst >= INT32_MAX ||
+      A.n_src * A.ldx_src >= INT32_MAX || A.n_src * A.ldh_src >= INT32_MAX)
     return GGNN_EINVAL;  // the sweep forms row offsets in 32 bits
-  if (A.kv_off + (int64_t)G * 2 * C > A.ldp_src || A.q_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
+  if (A.v_off + (int64_t)G * C > A.ldp_src || A.u4_off + (int64_t)G * 16 > A.ldp_dst) return GGNN_EINVAL;
+  if (has_h && A.u_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
   // persistent grid: at least 4 rows per workgroup, at most the resident capacity
@@ -486,35 +338,14 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
   const int64_t cap = (int64_t)AG_NUM_CU * AG_BLOCKS_PER_CU;
   const dim3 grid((unsigned)(want < cap ? want : cap));
   hipStream_t s = (hipStream_t)stream;
-  if (G == 4)
-    hipLaunchKernelGGL(aggregate_kernel<4>, grid, dim3(256), 0, s, A);
-  else if (G == 3)
-    hipLaunchKernelGGL(aggregate_kernel<3>, grid, dim3(256), 0, s, A);
-  else
-    hipLaunchKernelGGL(aggregate_kernel<1>, grid, dim3(256), 0, s, A);
-  return launch_status();
-}
-
-extern "C" int ggnn_period_gat_aggregate_enc(const ggnn_aggregate_enc_args* args, ggnn_stream_t stream) {
-  using namespace ggnn;
-  if (!args) return GGNN_EINVAL;
-  const ggnn_aggregate_enc_args& A = *args;
-  if (!A.unit_ptr || !A.units || !A.einfo || !A.x_src || !A.x_dst || !A.enc_w || !A.agg) return GGNN_EINVAL;
-  if (!aligned16(A.units) || !aligned16(A.einfo) || !aligned16(A.enc_w)) return GGNN_EINVAL;
-  if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0 || A.n_gates != 3) return GGNN_EINVAL;
-  if (A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
-  if (2LL * A.a_gstride + A.a_off + C > A.ld_agg || 2LL * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
-  const int64_t want = (A.n_dst + 3) / 4;
-  const int64_t cap = (int64_t)AG_NUM_CU * 3;  // ~150 VGPRs -> three workgroups per CU
-  const dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (A.f_src == 11 && A.f_dst == 8)
-    hipLaunchKernelGGL((aggregate_enc_kernel<11, 8>), grid, block, 0, s, A);
-  else if (A.f_src == 8 && A.f_dst == 11)
-    hipLaunchKernelGGL((aggregate_enc_kernel<8, 11>), grid, block, 0, s, A);
-  else if (A.f_src == 8 && A.f_dst == 8)
-    hipLaunchKernelGGL((aggregate_enc_kernel<8, 8>), grid, block, 0, s, A);
-  else
-    return GGNN_EINVAL;
+#define GGNN_AG_LAUNCH(G_)                                                                   \
+  do {                                                                                       \
+    if (has_h) hipLaunchKernelGGL((aggregate_kernel<G_, true>), grid, dim3(256), 0, s, A);   \
+    else hipLaunchKernelGGL((aggregate_kernel<G_, false>), grid, dim3(256), 0, s, A);        \
+  } while (0)
+  if (G == 4) GGNN_AG_LAUNCH(4);
+  else if (G == 3) GGNN_AG_LAUNCH(3);
+  else GGNN_AG_LAUNCH(1);
+#undef GGNN_AG_LAUNCH
   return launch_status();
 }

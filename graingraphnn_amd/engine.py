@@ -117,13 +117,9 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
         s, d = et[0], et[-1]
         if not lay[d].live:
             continue
-        if pc.fused:  # encoder: key / value / query recomputed in the sweep from feature rows
-            backend.aggregate_enc(graph.csr[et], einfo[et], x[s], x[d], pc.enc_w[et], agg[d],
-                                  lay[d].a_off[et], lay[d].Ka, lay[d].sc_off[et], pc.G)
-            continue
-        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], pc.ep[et], agg[d],
-                          lay[s].kv_off[et], lay[d].q_off[et], lay[d].a_off[et], lay[d].Ka,
-                          lay[d].sc_off[et], pc.G)
+        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], x[s], h_in[s] if pc.k2 else None,
+                          pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
+                          lay[d].a_off[et], lay[d].Ka, lay[d].sc_off[et], pc.G)
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
     for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
         if not lay[nt].live:

@@ -57,15 +57,15 @@ class PeriodConv(nn.Module):
         xs, xd = x_src[:, :Fs].contiguous(), x_dst[:, :Fd].contiguous()
         hs = x_src[:, Fs:].contiguous() if k2 else None
         hd = x_dst[:, Fd:].contiguous() if k2 else None
-        ps = torch.empty(x_src.size(0), 2 * C, device=dev)
-        pd = torch.empty(x_dst.size(0), 2 * C, device=dev)
+        ps = torch.empty(x_src.size(0), C, device=dev)          # [V]
+        pd = torch.empty(x_dst.size(0), 3 * C, device=dev)      # [u_h | S | u4, zero rows]
         be.project(xs, Fs, hs, wps, bps, ps)
         be.project(xd, Fd, hd, wpd, bpd, pd)
         csr = be.build_csr(edge_index, x_src.size(0), x_dst.size(0))
         einfo = torch.zeros(edge_index.size(1) + _lib.GGNN_UNIT_EDGES, 4, device=dev)
         be.edge_prepare([(csr, _edge_attr_1d(edge_attr), xs, xd, einfo)])
         agg = torch.zeros(x_dst.size(0), 100, device=dev)
-        be.aggregate(csr, einfo, ps, pd, ep, agg, 0, 0, 0, 100, C, 1)
+        be.aggregate(csr, einfo, ps, pd, xs, hs, ep, agg, 0, 0, 2 * C, 0, 100, C, 1)
         out = torch.empty(x_dst.size(0), C, device=dev)
         be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW, bf16_planes(w2))
         return out

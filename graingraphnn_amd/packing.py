@@ -1,21 +1,28 @@
 """Host-side weight packing: reference `state_dict` layout -> the fused device layouts the
-HIP kernels consume.  Pure tensor reshuffling (no arithmetic except summing the `lin_skip`
-weights of edge types that share a destination, which is what HeteroConv(aggr='sum') does to
-their outputs -- heteropgclstm.py:49-82 -- and folding the gate bias b_{i,f,c,o} in).
+HIP kernels consume.
 
 Layouts (C = 96, G = number of gates, F = features of the node type, Fp = roundup4(F)):
 
-* projection weight of node type T, `Wp [ncols, Kp]`, Kp = Fp + (96 if the cell sees h else 0):
-    columns of the OUTPUT (rows of Wp), in blocks of 96:
-      for each edge type with source T (canonical order):  for g: [K_g | V_g]
-      for each edge type with destination T:               for g: [Q_g]
-      summed skip + gate bias:                             for g: [S_g]
-    K/V rows have their first three input columns zeroed: the aggregation kernel re-adds
-    `W[:, :3] . minimg(x_j - x_i)` per edge (periodGATconv.py:209-211).
-* edge parameters of an edge type, `EP [G][7][96]`: W_key[:, 0..2], W_value[:, 0..2], w_edge.
+* projection weight of node type T, `Wp [ncols, Kp]`, Kp = Fp + (96 if the cell sees h else 0).
+  Rows of Wp = columns of the projection output, in this order:
+      for each edge type with source T:       for g: V_g   [96]  lin_value, first three input
+                                              columns zeroed (the sweep re-adds W[:, :3] . reloc)
+      for each edge type with destination T:  for g: u_h_g [96]  (only when the cell sees h)
+      summed skip + gate bias:                for g: S_g   [96]  (lin_skip summed over incoming
+                                              edge types = HeteroConv aggr 'sum', + b_{i,f,c,o})
+      for each edge type with destination T:  for g: u4_g  [16]
+      zero rows up to a multiple of 96
+  u_h / u4 replace the reference's query AND key (periodGATconv.py:216-217, 226): with
+  x~_j = [reloc, x_j[3:], h_j] the score q_i . (W_k x~_j + b_k + w_e a_e) / sqrt(96) equals
+  u_i . x~_j + s1_i + a_e s2_i for u_i = W_k^T q_i / sqrt(96), s1_i = b_k . q_i / sqrt(96),
+  s2_i = w_e . q_i / sqrt(96); all three are affine in [x_i | h_i], i.e. rows of the destination's
+  projection: u_h = the 96 hidden-state components of u, u4 = (u[0:F_src], 0.., s1 @12, s2 @13).
+  The products W_k^T W_q are formed in float64 and rounded once.
+* edge parameters of an edge type, `EP [G][3][96]`: W_value[:, 0..2].
 * gate weight of node type T, `W2 [G][96][Ka]`, Ka = roundup4(98 * n_in):
       [lin_l2.weight of incoming edge type 0 | ... | (b_l2, w_edge) of type 0 | ...]
 """
+import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Tuple
 
@@ -43,8 +50,9 @@ class NodeLayout:
     G: int
     src_ets: List[Tuple[str, str, str]]
     dst_ets: List[Tuple[str, str, str]]
-    kv_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
-    q_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    v_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    u_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
+    u4_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
     a_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
     sc_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
     s_off: int = 0
@@ -57,34 +65,32 @@ class NodeLayout:
         return roundup4(self.F)
 
 
-ENC_W_ROW = 40  # floats per channel in the fused-encoder weight record (include/ggnn.h)
-# Fused encoder sweep (ggnn_period_gat_aggregate_enc): recompute K0/V0/Q per edge from the
-# feature rows instead of projecting them to HBM.  Parity-green, but measured SLOWER on cfg3
-# (r1: 3 sweeps 133 us + projection 21 us vs 84 us + 47 us for projection + gather): the sweep
-# is VALU-issue-bound at 150 VGPRs / 3 waves per SIMD.  Kept behind this switch for tuning.
-FUSE_ENCODER = False
-# (f_src, f_dst) pairs the fused encoder sweep is instantiated for
-ENC_FUSED_SHAPES = ((11, 8), (8, 11), (8, 8))
+U4 = 16  # width of the per-(destination, gate) tail record: u[0:F_src], s1 @12, s2 @13
 
 
 def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True,
-                fused: bool = False) -> NodeLayout:
+                sees_h: bool = True) -> NodeLayout:
     """`live=False`: the new (h, c) of this node type is never read (the classifier's decoder only
     feeds h_joint to its head, models.py:595-609), so the type keeps only its role as a message
-    SOURCE: no query / skip columns, no aggregation into it, no gate update."""
+    SOURCE: no score / skip columns, no aggregation into it, no gate update.
+    `sees_h=False` (encoder, h = 0): the hidden-state part of u is not needed."""
     src_ets = [tuple(et) for et in edge_types if et[0] == node_type]
     dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type] if live else []
     lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets, live=live)
     off = 0
-    if not fused:  # fused encoder: key / value / query never leave the aggregation kernel
-        for et in src_ets:
-            lay.kv_off[et] = off
-            off += G * 2 * C
+    for et in src_ets:
+        lay.v_off[et] = off
+        off += G * C
+    if sees_h:
         for et in dst_ets:
-            lay.q_off[et] = off
+            lay.u_off[et] = off
             off += G * C
     lay.s_off = off
-    lay.ncols = off + (G * C if live else 0)
+    off += G * C if live else 0
+    for et in dst_ets:
+        lay.u4_off[et] = off
+        off += G * U4
+    lay.ncols = (off + C - 1) // C * C
     n_in = len(dst_ets)
     lay.Ka = roundup4(n_in * C + 2 * n_in)
     for d, et in enumerate(dst_ets):
@@ -101,11 +107,9 @@ class PackedCell:
     layout: Dict[str, NodeLayout]
     wp: Dict[str, torch.Tensor]     # node type -> [ncols, Kp]
     bp: Dict[str, torch.Tensor]     # node type -> [ncols]
-    ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 7, 96]
+    ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 3, 96]
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
     w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> bf16 planes of w2 (bf16_planes)
-    enc_w: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # fused encoder: [G, 96, 40]
-    fused: bool = False
 
 
 @torch.no_grad()
@@ -142,46 +146,56 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
     k2 = 0 if encoder else C
     some = _conv(cell, "i", edge_types[0]).lin_key.weight
     dev, dt = some.device, torch.float32
-    fused = (FUSE_ENCODER and encoder and
-             all((in_channels[et[0]], in_channels[et[-1]]) in ENC_FUSED_SHAPES for et in edge_types))
-    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, fused) for nt in NODE_TYPES}
-    wp, bp, w2, ep, enc_w = {}, {}, {}, {}, {}
+    F_of = dict(in_channels)
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, not encoder) for nt in NODE_TYPES}
+    wp, bp, w2, ep = {}, {}, {}, {}
 
-    def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz):
-        """weight: [96, F + 96] reference layout -> rows row0..row0+95 of the packed matrix."""
+    def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz=False):
+        """weight: [n, F + 96] in the reference's input order [x | h] -> n rows of the packed matrix
+        from row0 on (input order [x, pad to Fp | h]); bias is ADDED to the packed bias."""
         w = weight.detach().to(dt)
-        blk = dst_w[row0:row0 + C]
-        blk[:, :F] = w[:, :F]
+        n = w.size(0)
+        blk = dst_w[row0:row0 + n]
+        blk[:, :F] += w[:, :F]
         if zero_xyz:
             blk[:, :3] = 0.0
         if k2:
-            blk[:, Fp:Fp + C] = w[:, F:F + C]
-        dst_b[row0:row0 + C] += bias.detach().to(dt)
+            blk[:, Fp:Fp + C] += w[:, F:F + C]
+        dst_b[row0:row0 + n] += bias.detach().to(dt)
 
+    scale = 1.0 / math.sqrt(C)  # periodGATconv.py:226
     for nt in NODE_TYPES:
         lay = layout[nt]
         F, Fp = lay.F, lay.Fp
         W = torch.zeros(lay.ncols, Fp + k2, dtype=dt, device=dev)
         B = torch.zeros(lay.ncols, dtype=dt, device=dev)
-        for et in (() if fused else lay.src_ets):
+        for et in lay.src_ets:
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
-                base = lay.kv_off[et] + g * 2 * C
-                put(W, B, base, F, Fp, conv.lin_key.weight, conv.lin_key.bias, True)
-                put(W, B, base + C, F, Fp, conv.lin_value.weight, conv.lin_value.bias, True)
-        for et in (() if fused else lay.dst_ets):
+                put(W, B, lay.v_off[et] + g * C, F, Fp, conv.lin_value.weight, conv.lin_value.bias, True)
+        for et in lay.dst_ets:
+            Fs = F_of[et[0]]
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
-                put(W, B, lay.q_off[et] + g * C, F, Fp, conv.lin_query.weight, conv.lin_query.bias, False)
+                wq, bq = conv.lin_query.weight.detach().double(), conv.lin_query.bias.detach().double()
+                wk, bk = conv.lin_key.weight.detach().double(), conv.lin_key.bias.detach().double()
+                we = conv.lin_edge.weight.detach().double()[:, 0]
+                if not k2:  # encoder: both sides see the bare feature row
+                    wq, wk = wq[:, :F], wk[:, :Fs]
+                M, mb = (wk.t() @ wq) * scale, (wk.t() @ bq) * scale         # [Fs (+96), F (+96)], [Fs (+96)]
+                tail_w = torch.zeros(U4, wq.size(1), dtype=torch.float64, device=dev)
+                tail_b = torch.zeros(U4, dtype=torch.float64, device=dev)
+                tail_w[:Fs], tail_b[:Fs] = M[:Fs], mb[:Fs]
+                tail_w[12], tail_b[12] = (bk @ wq) * scale, (bk @ bq) * scale
+                tail_w[13], tail_b[13] = (we @ wq) * scale, (we @ bq) * scale
+                put(W, B, lay.u4_off[et] + g * U4, F, Fp, tail_w, tail_b)
+                if k2:
+                    put(W, B, lay.u_off[et] + g * C, F, Fp, M[Fs:], mb[Fs:])
         for g, gate in enumerate(gates if lay.live else ()):
             row0 = lay.s_off + g * C
             for et in lay.dst_ets:  # HeteroConv sums the outputs -> sum the skip weights
                 conv = _conv(cell, gate, et)
-                w = conv.lin_skip.weight.detach().to(dt)
-                W[row0:row0 + C, :F] += w[:, :F]
-                if k2:
-                    W[row0:row0 + C, Fp:Fp + C] += w[:, F:F + C]
-                B[row0:row0 + C] += conv.lin_skip.bias.detach().to(dt)
+                put(W, B, row0, F, Fp, conv.lin_skip.weight, conv.lin_skip.bias)
             B[row0:row0 + C] += getattr(cell, "b_" + gate)[nt].detach().to(dt).view(-1)
         wp[nt], bp[nt] = W.contiguous(), B.contiguous()
 
@@ -199,46 +213,28 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
         et = tuple(et)
         if not layout[et[-1]].live:
             continue
-        E = torch.zeros(G, 7, C, dtype=dt, device=dev)
+        E = torch.zeros(G, 3, C, dtype=dt, device=dev)
         for g, gate in enumerate(gates):
-            conv = _conv(cell, gate, et)
-            E[g, 0:3] = conv.lin_key.weight.detach().to(dt)[:, 0:3].t()
-            E[g, 3:6] = conv.lin_value.weight.detach().to(dt)[:, 0:3].t()
-            E[g, 6] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+            E[g] = _conv(cell, gate, et).lin_value.weight.detach().to(dt)[:, 0:3].t()
         ep[et] = E.contiguous()
-        if fused:
-            Fs, Fd = in_channels[et[0]], in_channels[et[-1]]
-            Wf = torch.zeros(G, C, ENC_W_ROW, dtype=dt, device=dev)
-            for g, gate in enumerate(gates):
-                conv = _conv(cell, gate, et)
-                wq, wk, wv = (m.weight.detach().to(dt) for m in (conv.lin_query, conv.lin_key, conv.lin_value))
-                Wf[g, :, 0:Fd] = wq[:, :Fd]
-                Wf[g, :, 12] = conv.lin_query.bias.detach().to(dt)
-                Wf[g, :, 13:13 + Fs - 3] = wk[:, 3:Fs]
-                Wf[g, :, 21] = conv.lin_key.bias.detach().to(dt)
-                Wf[g, :, 22:22 + Fs - 3] = wv[:, 3:Fs]
-                Wf[g, :, 30] = conv.lin_value.bias.detach().to(dt)
-                Wf[g, :, 31:34] = wk[:, 0:3]
-                Wf[g, :, 34:37] = wv[:, 0:3]
-                Wf[g, :, 37] = conv.lin_edge.weight.detach().to(dt)[:, 0]
-            enc_w[et] = Wf.contiguous()
     w2p = {nt: bf16_planes(t) for nt, t in w2.items()}
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, enc_w=enc_w, fused=fused,
-                      w2p=w2p)
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p)
 
 
 @torch.no_grad()
 def pack_conv(conv, F_src: int, F_dst: int, k2: int):
     """Single PeriodConv (one gate, one edge type) for op-level parity tests.  Returns
-    (wp_src [192, Kp_s], bp_src, wp_dst [192, Kp_d], bp_dst, ep [1,7,96], w2 [1,96,100]):
-    source projection = [K | V], destination projection = [Q | S]."""
+    (wp_src [96, Kp_s], bp_src, wp_dst [288, Kp_d], bp_dst, ep [1,3,96], w2 [1,96,100]):
+    source projection = [V]; destination projection = [u_h | S | u4, zero rows] (u_h unused and
+    zero when k2 == 0)."""
     dt = torch.float32
     dev = conv.lin_key.weight.device
 
     def pack(weight, F, zero_xyz):
+        """[n, F (+96)] reference input order -> [n, roundup4(F) + k2]."""
         Fp = roundup4(F)
         w = weight.detach().to(dt)
-        out = torch.zeros(C, Fp + k2, dtype=dt, device=dev)
+        out = torch.zeros(w.size(0), Fp + k2, dtype=dt, device=dev)
         out[:, :F] = w[:, :F]
         if zero_xyz:
             out[:, :3] = 0.0
@@ -246,20 +242,33 @@ def pack_conv(conv, F_src: int, F_dst: int, k2: int):
             out[:, Fp:Fp + C] = w[:, F:F + C]
         return out
 
-    wp_src = torch.cat([pack(conv.lin_key.weight, F_src, True), pack(conv.lin_value.weight, F_src, True)])
-    bp_src = torch.cat([conv.lin_key.bias, conv.lin_value.bias]).detach().to(dt)
-    wp_dst = torch.cat([pack(conv.lin_query.weight, F_dst, False), pack(conv.lin_skip.weight, F_dst, False)])
-    bp_dst = torch.cat([conv.lin_query.bias, conv.lin_skip.bias]).detach().to(dt)
-    ep = torch.zeros(1, 7, C, dtype=dt, device=dev)
-    ep[0, 0:3] = conv.lin_key.weight.detach().to(dt)[:, 0:3].t()
-    ep[0, 3:6] = conv.lin_value.weight.detach().to(dt)[:, 0:3].t()
-    ep[0, 6] = conv.lin_edge.weight.detach().to(dt)[:, 0]
+    wp_src = pack(conv.lin_value.weight, F_src, True)
+    bp_src = conv.lin_value.bias.detach().to(dt)
+    scale = 1.0 / math.sqrt(C)
+    wq, bq = conv.lin_query.weight.detach().double(), conv.lin_query.bias.detach().double()
+    wk, bk = conv.lin_key.weight.detach().double(), conv.lin_key.bias.detach().double()
+    we = conv.lin_edge.weight.detach().double()[:, 0]
+    if not k2:
+        wq, wk = wq[:, :F_dst], wk[:, :F_src]
+    M, mb = (wk.t() @ wq) * scale, (wk.t() @ bq) * scale
+    tail_w = torch.zeros(U4, wq.size(1), dtype=torch.float64, device=dev)
+    tail_b = torch.zeros(U4, dtype=torch.float64, device=dev)
+    tail_w[:F_src], tail_b[:F_src] = M[:F_src], mb[:F_src]
+    tail_w[12], tail_b[12] = (bk @ wq) * scale, (bk @ bq) * scale
+    tail_w[13], tail_b[13] = (we @ wq) * scale, (we @ bq) * scale
+    uh_w = M[F_src:] if k2 else torch.zeros(C, wq.size(1), dtype=torch.float64, device=dev)
+    uh_b = mb[F_src:] if k2 else torch.zeros(C, dtype=torch.float64, device=dev)
+    wp_dst = torch.cat([pack(uh_w, F_dst, False), pack(conv.lin_skip.weight, F_dst, False),
+                        pack(tail_w, F_dst, False),
+                        torch.zeros(C - U4, roundup4(F_dst) + k2, dtype=dt, device=dev)])
+    bp_dst = torch.cat([uh_b.to(dt), conv.lin_skip.bias.detach().to(dt), tail_b.to(dt),
+                        torch.zeros(C - U4, dtype=dt, device=dev)])
+    ep = conv.lin_value.weight.detach().to(dt)[:, 0:3].t().reshape(1, 3, C).contiguous()
     w2 = torch.zeros(1, C, 100, dtype=dt, device=dev)
     w2[0, :, :C] = conv.lin_l2.weight.detach().to(dt)
     w2[0, :, C] = conv.lin_l2.bias.detach().to(dt)
     w2[0, :, C + 1] = conv.lin_edge.weight.detach().to(dt)[:, 0]
-    return (wp_src.contiguous(), bp_src.contiguous(), wp_dst.contiguous(), bp_dst.contiguous(),
-            ep.contiguous(), w2.contiguous())
+    return (wp_src.contiguous(), bp_src.contiguous(), wp_dst.contiguous(), bp_dst.contiguous(), ep, w2.contiguous())
 
 
 @torch.no_grad()

@@ -25,10 +25,10 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 8
+#define GGNN_ABI_VERSION 9
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
-#define GGNN_EDGE_PARAM_ROWS 7 /* per gate: W_key[:,0:3], W_value[:,0:3], lin_edge.weight[:,0] */
+#define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
 #define GGNN_UNIT_EDGES 3      /* in-edges per aggregation unit (every junction has exactly 3) */
 
 #define GGNN_OK 0
@@ -98,10 +98,13 @@ typedef struct ggnn_prepare_edge {
 int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Node-level projection (fp32 MFMA): out[M, ncols] = [X[:, :F] | H] . Wp^T + bias.
- * Replaces, for all gates and edge types at once, the per-edge lin_key / lin_value /
- * lin_query (periodGATconv.py:216-218) and lin_skip (:186) applied to cat[x, h]
- * (heteropgclstm.py:112,120,128,137), using linearity to hoist them from edges to nodes.
+ * Node-level projection: out[M, ncols] = [X[:, :F] | H] . Wp^T + bias.
+ * Replaces, for all gates and edge types at once, the per-edge lin_query / lin_key /
+ * lin_value (periodGATconv.py:216-218) and lin_skip (:186) applied to cat[x, h]
+ * (heteropgclstm.py:112,120,128,137), using linearity to hoist them from edges to nodes.  What
+ * the rows of Wp hold is the caller's business (graingraphnn_amd/packing.py: value rows for the
+ * node as a source; W_k^T W_q / sqrt(96) rows for it as a destination, see
+ * ggnn_period_gat_aggregate; summed skip rows).
  *   X  : [M, ldx] node features, first F columns used (F <= 12)
  *   H  : [M, ldh] hidden state (k2 = 96) or NULL (k2 = 0, encoder: h = 0)
  *   Wp : [ncols, Kp] packed weight rows, Kp = roundup4(F) + k2; columns [F, roundup4(F)) zero
@@ -114,9 +117,16 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
 /* ------------------------------------------------------------------------------------
  * Periodic-boundary GAT aggregation for one edge type, all gates fused.  Replaces
  * PeriodConv.message (periodGATconv.py:204-236) + PyG propagate's gather and scatter-add:
- * min-image wrap of the first three coordinates, key/value 3-column corrections, rank-1
- * lin_edge term, scaled dot, segment softmax (+1e-16), relu, alpha-weighted sum.
- * Per destination i and gate g it writes
+ * min-image wrap of the first three coordinates, scaled dot of query and key, segment softmax
+ * (+1e-16), relu of the value, alpha-weighted sum.  The key is never formed: with
+ * x~_j = [reloc_e, x_j[3:F], h_j] the score q_i.(W_k x~_j + b_k + w_edge a_e)/sqrt(96) equals
+ * u_i . x~_j + s1_i + a_e s2_i, where u_i = W_k^T q_i/sqrt(96), s1_i = b_k.q_i/sqrt(96) and
+ * s2_i = w_edge.q_i/sqrt(96) are affine in the destination's [x_i | h_i] and come from
+ * ggnn_project.  Per destination i and gate g the projections hold
+ *   p_dst[i, u_off  + g*96 + 0..95] = u_i[F ..]   (hidden-state part; absent when h_src == NULL)
+ *   p_dst[i, u4_off + g*16 + 0..15] = (u_i[0..F-1], 0.., s1_i at 12, s2_i at 13, 0, 0)
+ *   p_src[j, v_off  + g*96 + 0..95] = lin_value(x_j with its first three columns zeroed, h_j)
+ * and the sweep writes
  *   agg[i, g*a_gstride + a_off + 0..95] = sum_e alpha_e * relu(lin_value(x~_j))
  *   agg[i, g*a_gstride + sc_off + 0]    = sum_e alpha_e            (1, or 0 if no in-edge)
  *   agg[i, g*a_gstride + sc_off + 1]    = sum_e alpha_e * edge_attr_e
@@ -127,44 +137,16 @@ typedef struct ggnn_aggregate_args {
   const int32_t* unit_ptr;  /* [n_dst + 1] from ggnn_build_csr */
   const int32_t* units;     /* [n_units, 8] from ggnn_build_csr */
   const float* einfo;       /* [E + GGNN_UNIT_EDGES, 4] from ggnn_edge_prepare */
-  const float* p_src;       /* projection of the source type: K|V of gate g at column kv_off + g*192 */
-  const float* p_dst;       /* projection of the destination type: Q of gate g at column q_off + g*96 */
-  const float* edge_params; /* [n_gates][7][96]: W_key[:,0..2], W_value[:,0..2], lin_edge.weight[:,0] */
+  const float* p_src;       /* [n_src, ldp_src] projections of the source node type */
+  const float* p_dst;       /* [n_dst, ldp_dst] projections of the destination node type */
+  const float* x_src;       /* [n_src, ldx_src] source features, first f_src columns used */
+  const float* h_src;       /* [n_src, ldh_src] source hidden state, or NULL (encoder: h = 0) */
+  const float* edge_params; /* [n_gates][GGNN_EDGE_PARAM_ROWS][96] = W_value[:, 0..2] */
   float* agg;               /* [n_dst, ld_agg] */
-  int64_t ldp_src, ldp_dst, ld_agg;
-  int64_t n_src, n_dst, E;
-  int32_t kv_off, q_off, a_off, a_gstride, sc_off, n_gates; /* n_gates in {1, 3, 4} */
+  int64_t ldp_src, ldp_dst, ld_agg, ldx_src, ldh_src, n_src, n_dst, E;
+  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, f_src; /* 3 <= f_src <= 12 */
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
-
-/* ------------------------------------------------------------------------------------
- * Encoder variant of the aggregation (h = c = 0, SeqGCLSTM._init_hidden, models.py:282-289):
- * the cell input is the bare feature row (8 or 11 floats), so the key / value / query
- * projections are recomputed per edge from the 32..44-byte feature rows instead of being
- * read back as 384-byte fragments -- same outputs as ggnn_project + ggnn_period_gat_aggregate,
- * no [N, G*96] key/value/query buffers at all.
- *   enc_w : [n_gates][96][GGNN_ENC_W_ROW] per channel c of gate g:
- *           [0..11]  lin_query.weight[c, 0..f_dst-1] (zero padded)   [12] lin_query.bias[c]
- *           [13..20] lin_key.weight[c, 3..f_src-1]   (zero padded)   [21] lin_key.bias[c]
- *           [22..29] lin_value.weight[c, 3..f_src-1] (zero padded)   [30] lin_value.bias[c]
- *           [31..33] lin_key.weight[c, 0..2]  [34..36] lin_value.weight[c, 0..2]
- *           [37]     lin_edge.weight[c, 0]    [38..39] 0
- *   x_src / x_dst : contiguous [n, f] feature rows (row stride = f); (f_src, f_dst) must be
- *           one of (11, 8), (8, 11), (8, 8).
- */
-#define GGNN_ENC_W_ROW 40
-typedef struct ggnn_aggregate_enc_args {
-  const int32_t* unit_ptr; /* [n_dst + 1] */
-  const int32_t* units;    /* [n_units, 8] */
-  const float* einfo;      /* [E + GGNN_UNIT_EDGES, 4] */
-  const float* x_src;      /* [n_src, f_src] */
-  const float* x_dst;      /* [n_dst, f_dst] */
-  const float* enc_w;      /* [n_gates][96][GGNN_ENC_W_ROW], 16-byte aligned */
-  float* agg;              /* [n_dst, ld_agg] */
-  int64_t ld_agg, n_src, n_dst, E;
-  int32_t f_src, f_dst, a_off, a_gstride, sc_off, n_gates; /* n_gates == 3 */
-} ggnn_aggregate_enc_args;
-int ggnn_period_gat_aggregate_enc(const ggnn_aggregate_enc_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:

@@ -46,48 +46,30 @@ class TorchEmulatorBackend:
             xin[:, Fp:] = h
         out[:, :wp.size(0)] = xin @ wp.t() + bp
 
-    def aggregate(self, csr, einfo, p_src, p_dst, ep, agg, kv_off, q_off, a_off, a_gstride,
-                  sc_off, n_gates):
+    def aggregate(self, csr, einfo, p_src, p_dst, x_src, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+                  a_gstride, sc_off, n_gates):
         rowptr, col = csr.rowptr.long(), csr.col.long()
         n_dst = p_dst.size(0)
         E = int(rowptr[-1])
+        Fs = x_src.size(1)
         dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
         j, reloc, a = col[:E], einfo[:E, :3], einfo[:E, 3]
+        # the per-edge 16-wide tail: reloc, raw features 3..F-1, zeros, 1 @12, a_e @13
+        x4 = torch.zeros(E, 16)
+        x4[:, :3] = reloc
+        x4[:, 3:Fs] = x_src[j, 3:Fs]
+        x4[:, 12] = 1.0
+        x4[:, 13] = a
         for g in range(n_gates):
-            K = p_src[j, kv_off + g * 2 * C: kv_off + g * 2 * C + C]
-            V = p_src[j, kv_off + g * 2 * C + C: kv_off + (g + 1) * 2 * C]
-            Q = p_dst[dst, q_off + g * C: q_off + (g + 1) * C]
-            wk3, wv3, we = ep[g, 0:3], ep[g, 3:6], ep[g, 6]
-            k = K + reloc @ wk3 + a[:, None] * we[None, :]
-            s = (Q * k).sum(-1) / math.sqrt(C)
+            V = p_src[j, v_off + g * C: v_off + (g + 1) * C]
+            s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
+            if h_src is not None:
+                s = s + (p_dst[dst, u_off + g * C: u_off + (g + 1) * C] * h_src[j]).sum(-1)
             smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
             p = (s - smax[dst]).exp()
             den = torch.zeros(n_dst).index_add_(0, dst, p)
             alpha = p / (den[dst] + 1e-16)
-            r = torch.relu(V + reloc @ wv3)
-            base = g * a_gstride
-            agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add_(0, dst, alpha[:, None] * r)
-            agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
-            agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
-
-    def aggregate_enc(self, csr, einfo, x_src, x_dst, enc_w, agg, a_off, a_gstride, sc_off, n_gates):
-        rowptr, col = csr.rowptr.long(), csr.col.long()
-        n_dst, Fs, Fd = x_dst.size(0), x_src.size(1), x_dst.size(1)
-        E = int(rowptr[-1])
-        dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
-        j, reloc, a = col[:E], einfo[:E, :3], einfo[:E, 3]
-        for g in range(n_gates):
-            w = enc_w[g]
-            Q = x_dst[:, :Fd] @ w[:, 0:Fd].t() + w[:, 12]
-            K = x_src[:, 3:Fs] @ w[:, 13:13 + Fs - 3].t() + w[:, 21]
-            V = x_src[:, 3:Fs] @ w[:, 22:22 + Fs - 3].t() + w[:, 30]
-            k = K[j] + reloc @ w[:, 31:34].t() + a[:, None] * w[:, 37][None, :]
-            s = (Q[dst] * k).sum(-1) / math.sqrt(C)
-            smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
-            p = (s - smax[dst]).exp()
-            den = torch.zeros(n_dst).index_add_(0, dst, p)
-            alpha = p / (den[dst] + 1e-16)
-            r = torch.relu(V[j] + reloc @ w[:, 34:37].t())
+            r = torch.relu(V + reloc @ ep[g])
             base = g * a_gstride
             agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add_(0, dst, alpha[:, None] * r)
             agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 8
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 9
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4
@@ -43,7 +43,6 @@ def test_argument_validation_returns_einval_without_launching():
     assert lib.ggnn_project(None, 8, 8, None, 0, 0, None, None, 10, 96, None, 96, None) == -1
     assert lib.ggnn_period_gat_aggregate(None, None) == -1
     assert lib.ggnn_lstm_epilogue(None, None) == -1
-    assert lib.ggnn_period_gat_aggregate_enc(None, None) == -1
     a = _lib.AggregateArgs()
     assert lib.ggnn_period_gat_aggregate(ctypes.byref(a), None) == -1
     e = _lib.EpilogueArgs()
@@ -61,7 +60,7 @@ def test_argument_validation_returns_einval_without_launching():
 
 def test_struct_sizes_match_the_header():
     """ctypes mirrors of the POD argument blocks (natural alignment, no packing)."""
-    assert ctypes.sizeof(_lib.AggregateArgs) == 7 * 8 + 6 * 8 + 6 * 4
+    assert ctypes.sizeof(_lib.AggregateArgs) == 9 * 8 + 8 * 8 + 8 * 4
     assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 3 * 8
     assert ctypes.sizeof(_lib.EpilogueArgs) == 7 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4
     assert ctypes.sizeof(_lib.RefreshEdge) == 4 * 8 + 5 * 8

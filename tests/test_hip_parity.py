@@ -217,25 +217,6 @@ def test_forward_golden(tag, seed, scale):
     assert gs["active_grains"].numel() == x["grain"].shape[0]
 
 
-@torch.no_grad()
-def test_fused_encoder_sweep_golden(monkeypatch):
-    """ggnn_period_gat_aggregate_enc (K0/V0/Q recomputed per edge; off by default) gives the
-    same forward as projection + gather."""
-    from graingraphnn_amd import packing
-    monkeypatch.setattr(packing, "FUSE_ENCODER", True)
-    for tag, seed, scale in CASES:
-        x, ei, ea = _inputs(tag)
-        g = golden(tag)
-        R, Cm = product_models(seed, scale, DEV)
-        assert R.gclstm_encoder.cell_list[0].packed(True).fused
-        X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
-        yr, yc = R(X, EI, EA), Cm(X, EI, EA)
-        for k in ("joint", "grain", "grain_area"):
-            assert_close(yr[k], g["R_" + k], f"{tag} fused-encoder regressor {k}")
-        for k in ("edge_event", "edge"):
-            assert_close(yc[k], g["C_" + k], f"{tag} fused-encoder classifier {k}")
-
-
 @pytest.mark.parametrize("use_graph,concurrent", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("tag,seed,scale", CASES)
 @torch.no_grad()

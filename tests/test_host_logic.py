@@ -66,16 +66,19 @@ def test_no_cpu_fallback():
 def test_layout_offsets():
     lj = packing.node_layout("joint", 8, 4)
     lg = packing.node_layout("grain", 11, 4)
-    assert (lj.ncols, lg.ncols) == (2688, 1536)      # [20000,104]x[104,2688], [10000,107]x[107,1536]
+    # joint: V for j->g, j->j (768) | u_h for g->j, j->j (768) | S (384) | u4 (2 x 64), padded to 96s
+    assert (lj.ncols, lg.ncols) == (2112, 1248)
     assert (lj.Ka, lg.Ka) == (196, 100)
-    assert (packing.node_layout("joint", 8, 3).ncols, packing.node_layout("grain", 11, 3).ncols) == (2016, 1152)
-    # fused encoder: only the summed skip leaves the projection
-    assert packing.node_layout("joint", 8, 3, fused=True).ncols == 288
-    assert lj.kv_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 768}
-    assert lj.q_off == {EDGE_TYPES[0]: 1536, EDGE_TYPES[2]: 1920} and lj.s_off == 2304
-    # a dead destination type keeps only its key/value columns (classifier decoder, grain)
+    assert lj.v_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 384}
+    assert lj.u_off == {EDGE_TYPES[0]: 768, EDGE_TYPES[2]: 1152} and lj.s_off == 1536
+    assert lj.u4_off == {EDGE_TYPES[0]: 1920, EDGE_TYPES[2]: 1984}
+    # encoder (h = 0): no hidden-state part of u
+    le = packing.node_layout("joint", 8, 3, sees_h=False)
+    assert le.u_off == {} and le.s_off == 576 and le.u4_off == {EDGE_TYPES[0]: 864, EDGE_TYPES[2]: 912}
+    assert (le.ncols, packing.node_layout("grain", 11, 3, sees_h=False).ncols) == (960, 672)
+    # a dead destination type keeps only its value columns (classifier decoder, grain)
     dead = packing.node_layout("grain", 11, 4, live=False)
-    assert dead.ncols == 768 and dead.dst_ets == [] and dead.kv_off == {EDGE_TYPES[0]: 0}
+    assert dead.ncols == 384 and dead.dst_ets == [] and dead.v_off == {EDGE_TYPES[0]: 0}
 
 
 def _run_model_emulated(model, x, ei, ea):
@@ -146,30 +149,14 @@ def test_cell_with_state_and_single_conv_packing():
         conv = R.gclstm_decoder.cell_list[0].conv_i.convs[etk(et)]
         Fs, Fd = X[et[0]].size(1), X[et[-1]].size(1)
         wps, bps, wpd, bpd, ep, w2 = packing.pack_conv(conv, Fs, Fd, 96)
-        ps, pd = torch.empty(n_nodes[et[0]], 192), torch.empty(n_nodes[et[-1]], 192)
+        ps, pd = torch.empty(n_nodes[et[0]], 96), torch.empty(n_nodes[et[-1]], 288)
         be.project(X[et[0]], Fs, h0[et[0]], wps, bps, ps)
         be.project(X[et[-1]], Fd, h0[et[-1]], wpd, bpd, pd)
         agg = torch.zeros(n_nodes[et[-1]], 100)
-        be.aggregate(graph.csr[et], einfo[et], ps, pd, ep, agg, 0, 0, 0, 100, 96, 1)
+        be.aggregate(graph.csr[et], einfo[et], ps, pd, X[et[0]], h0[et[0]], ep, agg, 0, 0, 192, 0, 100, 96, 1)
         out = torch.empty(n_nodes[et[-1]], 96)
         be.lstm_epilogue(agg, w2, pd, 96, None, None, None, out, 1, 2)
         assert_close(out, g["conv_" + etk(et)], f"conv {et}", TOL)
-
-
-@torch.no_grad()
-def test_fused_encoder_packing_reproduces_golden(monkeypatch):
-    monkeypatch.setattr(packing, "FUSE_ENCODER", True)
-    x, ei, ea = load_graph("40")
-    g = golden("cfg1_s1")
-    R, _ = product_models(10020)
-    X, EI, EA = tt(x), tt(ei), tt(ea)
-    be, graph, h = _run_model_emulated(R, X, EI, EA)
-    assert R.gclstm_encoder.cell_list[0].packed(True).fused
-    w, b = packing.pack_regressor_heads(R.linear)
-    yj, yg, area = torch.empty(236, 2), torch.empty(118, 2), torch.empty(118)
-    be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
-    assert_close(yj, g["R_joint"], "fused encoder R joint", TOL)
-    assert_close(yg, g["R_grain"], "fused encoder R grain", TOL)
 
 
 @torch.no_grad()
