@@ -83,7 +83,7 @@ class EventTimedBackend:
 
 
 def measure_roofline(ro, n_steps):
-    """Average duration of aggregate_kernel<4> launches inside real rollout steps (eager
+    """Average duration of aggregate_kernel<4, true> launches inside real rollout steps (eager
     launches, regressor and classifier serialised so that no other kernel shares the chip
     with the launch being timed; HIP events on the launch stream, dispatch latency removed by
     differencing a one-launch and a two-launch bracket)."""
@@ -101,7 +101,7 @@ def measure_roofline(ro, n_steps):
     avg_bytes = float(np.mean([ev[3] for ev in timed.events]))  # per launch, as launched
     avg_s = float(np.mean(ms)) * 1e-3
     achieved = avg_bytes / avg_s / 1e9
-    return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4>", "achieved": round(achieved, 1),
+    return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic(), "avg_launch_us": round(avg_s * 1e6, 2),
             "single_launch_event_bracket_us": round(bracket, 2),
@@ -109,7 +109,7 @@ def measure_roofline(ro, n_steps):
 
 
 def pmc_traffic():
-    """HBM bytes per aggregate_kernel<4> launch from the rocprofv3 --pmc passes recorded in
+    """HBM bytes per aggregate_kernel<4, true> launch from the rocprofv3 --pmc passes recorded in
     profiles/r1_pmc_aggregate.json (PMC collection cannot run inside this process; the file
     says how it was taken and corrected).  None when the file is absent."""
     try:

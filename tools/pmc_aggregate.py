@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Derive the memory-side traffic of the decoder aggregation sweep from rocprofv3 PMC passes.
+
+On the GPU box (one counter group per pass; rocprofv3 must be followed directly by the program):
+    for g in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+             "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+        rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/pmc/$i -- python3 tools/kbench.py --reps 5
+    done
+then here:  python tools/pmc_aggregate.py gpurun_out/pmc profiles/r1_pmc_aggregate.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL = "aggregate_kernel<4, true>"
+
+
+def main(root, out):
+    sums, counts = {}, {}
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if KERNEL not in row["Kernel_Name"]:
+                    continue
+                k = row["Counter_Name"]
+                sums[k] = sums.get(k, 0.0) + float(row["Counter_Value"])
+                counts[k] = counts.get(k, 0) + 1
+    c = {k: {"mean_per_launch": sums[k] / counts[k], "launches": counts[k]} for k in sorted(sums)}
+    m = lambda k: c[k]["mean_per_launch"]
+    reads = 128 * m("TCC_EA0_RDREQ_128B_sum") + 64 * m("TCC_EA0_RDREQ_64B_sum") + 32 * m("TCC_EA0_RDREQ_32B_sum")
+    writes = 64 * m("TCC_EA0_WRREQ_64B_sum") + 32 * (m("TCC_EA0_WRREQ_sum") - m("TCC_EA0_WRREQ_64B_sum"))
+    doc = {
+        "kernel": "ggnn::" + KERNEL,
+        "workload": "cfg3 decoder sweeps (g->j, j->g, j->j averaged), tools/kbench.py --reps 5 under rocprofv3 "
+                    "--kernel-trace --pmc <one group per pass>",
+        "counters": c,
+        "read_bytes_per_launch": reads, "write_bytes_per_launch": writes,
+        "traffic_bytes_per_launch": reads + writes,
+        "cross_check": {"FETCH_SIZE_KB_x2_gfx950_rule": 2 * 1024 * m("FETCH_SIZE") if "FETCH_SIZE" in c else None,
+                        "WRITE_SIZE_KB": 1024 * m("WRITE_SIZE") if "WRITE_SIZE" in c else None},
+        "method": "HBM-side bytes = 128*TCC_EA0_RDREQ_128B + 64*TCC_EA0_RDREQ_64B + 32*TCC_EA0_RDREQ_32B (reads) + "
+                  "64*TCC_EA0_WRREQ_64B + 32*(TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) (writes); FETCH_SIZE doubled per "
+                  "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B) is the cross-check",
+        "algorithmic_bytes_per_launch": (93720004 + 93360004 + 124560004) / 3,
+    }
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps({k: doc[k] for k in ("read_bytes_per_launch", "write_bytes_per_launch",
+                                           "traffic_bytes_per_launch", "cross_check")}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
