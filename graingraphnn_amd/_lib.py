@@ -13,8 +13,9 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 9
+GGNN_ABI_VERSION = 10
 GGNN_UNIT_EDGES = 3
+GGNN_EINFO_ROW = 20
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 3
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
@@ -42,7 +43,7 @@ class PrepareEdge(Structure):
     _fields_ = [
         ("col", c_void_p), ("perm", c_void_p), ("row", c_void_p), ("edge_attr", c_void_p),
         ("x_src", c_void_p), ("x_dst", c_void_p), ("einfo", c_void_p),
-        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("E", c_int64),
+        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("E", c_int64), ("f_src", c_int64),
     ]
 
 
@@ -50,12 +51,12 @@ class AggregateArgs(Structure):
     """Mirror of `ggnn_aggregate_args`."""
     _fields_ = [
         ("unit_ptr", c_void_p), ("units", c_void_p), ("einfo", c_void_p),
-        ("p_src", c_void_p), ("p_dst", c_void_p), ("x_src", c_void_p), ("h_src", c_void_p),
+        ("p_src", c_void_p), ("p_dst", c_void_p), ("h_src", c_void_p),
         ("edge_params", c_void_p), ("agg", c_void_p),
-        ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64), ("ldx_src", c_int64),
+        ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
         ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
         ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
-        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("f_src", c_int32),
+        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
     ]
 
 

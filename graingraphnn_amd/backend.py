@@ -68,17 +68,17 @@ class HipBackend:
 
     # -- per-edge geometry -------------------------------------------------------------
     def edge_prepare(self, items):
-        """items: list of (csr, edge_attr [E] COO order, x_src, x_dst, einfo_out [E + 3, 4])."""
+        """items: list of (csr, edge_attr [E] COO order, x_src, x_dst, einfo_out [E + 3, GGNN_EINFO_ROW])."""
         arr = (PrepareEdge * max(len(items), 1))()
         for k, (csr, ea, xs, xd, einfo) in enumerate(items):
             _require_cuda(csr.col, ea, xs, xd, einfo)
-            if einfo.size(0) < ea.numel() + _lib.GGNN_UNIT_EDGES:
-                raise _lib.GGNNError("einfo needs E + GGNN_UNIT_EDGES rows")
+            if einfo.size(0) < ea.numel() + _lib.GGNN_UNIT_EDGES or einfo.size(1) != _lib.GGNN_EINFO_ROW:
+                raise _lib.GGNNError("einfo must be [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
             a = arr[k]
             a.col, a.perm, a.row = csr.col.data_ptr(), csr.perm.data_ptr(), csr.row.data_ptr()
             a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
             a.einfo = einfo.data_ptr()
-            a.ldx_src, a.ldx_dst, a.E = xs.stride(0), xd.stride(0), ea.numel()
+            a.ldx_src, a.ldx_dst, a.E, a.f_src = xs.stride(0), xd.stride(0), ea.numel(), xs.size(1)
         check(self.lib.ggnn_edge_prepare(arr, len(items), _lib.current_stream()), "ggnn_edge_prepare")
 
     # -- projection --------------------------------------------------------------------
@@ -91,22 +91,21 @@ class HipBackend:
                                     _lib.current_stream()), "ggnn_project")
 
     # -- aggregation -------------------------------------------------------------------
-    def aggregate(self, csr, einfo, p_src, p_dst, x_src, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+    def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
                   a_gstride, sc_off, n_gates):
-        """One sweep of ggnn_period_gat_aggregate (include/ggnn.h).  x_src: the source node type's
-        feature tensor [n_src, F] (row-strided views allowed), h_src: its hidden state [n_src, 96]
-        or None (encoder)."""
-        _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, x_src, h_src, ep, agg)
+        """One sweep of ggnn_period_gat_aggregate (include/ggnn.h).  h_src: the source node type's
+        hidden state [n_src, 96] or None (encoder)."""
+        _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, h_src, ep, agg)
         a = AggregateArgs()
         a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
-        a.p_src, a.p_dst, a.x_src = p_src.data_ptr(), p_dst.data_ptr(), x_src.data_ptr()
+        a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
         a.h_src = None if h_src is None else h_src.data_ptr()
         a.edge_params, a.agg = ep.data_ptr(), agg.data_ptr()
         a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
-        a.ldx_src, a.ldh_src = x_src.stride(0), 0 if h_src is None else h_src.stride(0)
+        a.ldh_src = 0 if h_src is None else h_src.stride(0)
         a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), csr.E
-        a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates, a.f_src = (
-            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, x_src.size(1))
+        a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
+            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),
               "ggnn_period_gat_aggregate")
 

@@ -18,10 +18,11 @@
 // side shrinks to the 8 / 11 feature floats.
 //   per (destination, gate):  u_h [96] | u4 [16] = (u_x[0..F), 0.., s1 @12, s2 @13, 0, 0)
 //   per edge:                 h_j [96] | x4 [16] = (reloc, x_j[3..F), 0.., 1 @12, a_e @13, 0, 0)
-//   s_e = sum over the half-wave of  u_h . h_j (3 channels per lane) + u4 * x4 (lanes 0..15)
+//   s_e = sum over a 16-lane row of  u_h . h_j (6 channels per lane) + u4 * x4 (1 element per lane)
 //
-// ggnn_edge_prepare computes (reloc_e, a_e) once per forward in CSR order (16 bytes per
-// edge, shared by the 7 gate sweeps of encoder + decoder).
+// ggnn_edge_prepare writes, once per forward and in CSR order, the 80-byte record of every edge:
+// the 16-float tail x4 above and (reloc_e, a_e) again as one aligned float4 for the scalar side;
+// it is shared by the 7 gate sweeps of encoder + decoder of both models.
 //
 // The sweep walks the *unit table* built with the CSR (a unit = one destination row x up to
 // 3 in-edges, 32-byte descriptor {i, p0, nact|first|last, -, j0, j1, j2, -}).  The workgroups
@@ -29,47 +30,57 @@
 // round-robin to their waves, so an XCD always works inside a short sliding window of
 // neighbouring rows and the 3-6 re-reads of a source row hit its L2 (rocprofv3: 63 % L2
 // misses and 2x the algorithmic bytes fetched with per-workgroup contiguous ranges).
-// A WAVE takes such a row stream and a pair of gates (one gate per half-wave: 32 lanes x 3
-// channels, so one global_load_dwordx3 is one 384-byte row fragment).  Both halves see the same
-// units, so everything that describes a unit is wave-uniform and lives on the scalar side:
+// A WAVE takes such a row stream and ALL gates of its units: one gate per 16-lane row, 6 channels
+// per lane (a 384-byte fragment is two global_load_dwordx3 per lane; a row's dot product closes with
+// four DPP steps inside the row -- no cross-row traffic; the 16-wide tail is one element per lane).
+// Everything that describes a unit is wave-uniform and lives on the scalar side:
 //   * descriptor and the 3 edge records (reloc, a_e) come through scalar loads (SMEM) into
 //     SGPRs; the scalar chain for unit u+1 runs while the vector loads of unit u are in flight;
 //   * the vector side of a unit is issued back to back and unconditionally (absent edges repeat
-//     j0; a load under `if` would drag a wait to the branch merge): u_h, u4 and per edge h_j, x4,
-//     V -- one exposed round trip per unit;
+//     j0; a load under `if` would drag a wait to the branch merge): u_h, u4 and per edge h_j (the
+//     SAME 384 bytes for every gate row), the edge's tail record, V -- one exposed round trip;
 //   * scores are folded into an online-max softmax carried in registers across the units of one
 //     row (any degree, bounded registers, nothing re-read); the row is stored once, when its last
 //     unit is done.  No atomics => bit-reproducible.
+// The kernel is VALU-issue-bound, not bandwidth-bound (with every vector load AND store removed
+// the previous two-gates-per-wave version still took 60 % of its time): what made it faster was
+// fewer instructions per (edge, gate) -- the scalar work of a unit is now shared by four gates
+// instead of two, the tail arrives ready-made from ggnn_edge_prepare, no half-wave swizzles.
 // (Measured alternatives, in git history and profiles/: v1 block-staged CSR 64 us; v2
 // per-half-wave CSR walk 53 us; v3 per-wave LDS-DMA gather ring 63 us; v4 unit table + vector-side
-// descriptor prefetch 41 us; v7 projected keys gathered per gate 31 us; a fused encoder sweep
-// recomputing K0 / V0 / Q per edge from feature rows: VALU-bound, slower.)
+// descriptor prefetch 41 us; v7 projected keys gathered per gate 31 us; v12 key-free, two gates per
+// wave 31 us, the same with two units in flight 32 us; a fused encoder sweep recomputing
+// K0 / V0 / Q per edge from feature rows: VALU-bound, slower.)
 #include "common.h"
 
 namespace ggnn {
 
 #ifndef AG_VAR_BPC
-#define AG_VAR_BPC 7
+#define AG_VAR_BPC 5
 #endif
-constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;  // resident workgroups per CU (68 VGPRs -> 7 waves per SIMD)
+constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;  // resident workgroups per CU (98 VGPRs -> 5 waves per SIMD)
+#ifndef AG_VAR_BPC_NOH
+#define AG_VAR_BPC_NOH 7
+#endif
+constexpr int AG_BLOCKS_PER_CU_NOH = AG_VAR_BPC_NOH;  // encoder sweep (no hidden rows): ~72 VGPRs
 constexpr int AG_NUM_CU = 256;
 constexpr int UE = GGNN_UNIT_EDGES;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// Sum over the 32 lanes of a half-wave, result in every lane: four DPP row steps inside each
-// 16-lane row, then one ds_swizzle (xor 16) across the two rows.
-__device__ __forceinline__ float halfwave_sum(float v) {
+// Sum over the 16 lanes of a DPP row, result in every lane of the row (four v_add_f32 with DPP).
+__device__ __forceinline__ float row_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                    // lane ^ 16
   return v;
 }
 
 // ---------------------------------------------------------------------------------------
-// edge_prepare: einfo[p] = (reloc_x, reloc_y, reloc_z, edge_attr[perm[p]]) in CSR order
+// edge_prepare: the 20-float record of every edge, in CSR order (GGNN_EINFO_ROW floats):
+//   [0..15]  tail of the score dot product: reloc_xyz, x_src[3 .. f_src), 0.., 1 @12, a_e @13, 0, 0
+//   [16..19] (reloc_x, reloc_y, reloc_z, a_e) for the scalar side, a_e = edge_attr[perm[p]]
 // ---------------------------------------------------------------------------------------
 struct PrepareArgs {
   ggnn_prepare_edge et[3];
@@ -84,7 +95,9 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
   while (k + 1 < P.n_et && t >= P.e_off[k + 1]) ++k;
   const ggnn_prepare_edge& T = P.et[k];
   const int64_t p = t - P.e_off[k];
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  float rec[GGNN_EINFO_ROW];
+#pragma unroll
+  for (int c = 0; c < GGNN_EINFO_ROW; ++c) rec[c] = 0.f;
   if (p < T.E) {  // the last GGNN_UNIT_EDGES records are zero padding
     const float* xs = T.x_src + (int64_t)T.col[p] * T.ldx_src;
     const float* xd = T.x_dst + (int64_t)T.row[p] * T.ldx_dst;
@@ -92,11 +105,17 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
     for (int c = 0; c < 3; ++c) {
       const float rel = xs[c] - xd[c];
       const float w = rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
-      o[c] = w + rel;  // periodGATconv.py:210
+      rec[c] = rec[16 + c] = w + rel;  // periodGATconv.py:210
     }
-    o[3] = T.edge_attr[T.perm[p]];
+#pragma unroll
+    for (int c = 3; c < 12; ++c)
+      if (c < T.f_src) rec[c] = xs[c];
+    rec[12] = 1.0f;
+    rec[13] = rec[19] = T.edge_attr[T.perm[p]];
   }
-  *reinterpret_cast<f32x4*>(T.einfo + 4 * p) = o;
+  f32x4* o = reinterpret_cast<f32x4*>(T.einfo + GGNN_EINFO_ROW * p);
+#pragma unroll
+  for (int c = 0; c < GGNN_EINFO_ROW / 4; ++c) o[c] = (f32x4){rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -107,97 +126,106 @@ typedef const i32x8 __attribute__((address_space(4))) * const_i32x8_ptr;  // uni
 typedef const f32x4 __attribute__((address_space(4))) * const_f32x4_ptr;  // uniform index -> s_load_dwordx4
 typedef const int __attribute__((address_space(4))) * const_i32_ptr;
 
-template <int G> struct Shape {
-  static constexpr int pairs = (G + 1) / 2;  // gate pairs; a wave sweeps one pair
-  static constexpr int waves = 4;
-  static constexpr int subs = waves / pairs;  // row sub-ranges per workgroup
-};
+constexpr int AG_WAVES = 4;  // independent row streams per workgroup
 
 template <int G, bool HAS_H>
 __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_args A) {
-  using SH = Shape<G>;
-  // [g][channel][4]: W_value[:, 0..2] of one channel (16 B) -> one 16-byte LDS read per channel
-  __shared__ __attribute__((aligned(16))) float s_ep[G * C * 4];
   const int tid = threadIdx.x;
-  for (int t = tid; t < G * GGNN_EDGE_PARAM_ROWS * C; t += 256) {
-    const int g = t / (GGNN_EDGE_PARAM_ROWS * C), r = (t / C) % GGNN_EDGE_PARAM_ROWS, c = t % C;
-    s_ep[(g * C + c) * 4 + r] = A.edge_params[t];
-  }
-  __syncthreads();
-
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pair = wave % SH::pairs, sub = wave / SH::pairs;
-  const int g = pair * 2 + ((tid >> 5) & 1);  // the gate of this half-wave
-  const bool active = g < G;                  // odd G: the last pair's upper half idles
+  const int g = (tid >> 4) & 3;     // the gate of this 16-lane row
+  constexpr bool ALL = G == 4;      // every row of the wave has a gate
+  const bool active = ALL || g < G;
   const int gc = active ? g : 0;
-  const int ch = 3 * (tid & 31);              // first of this lane's three channels
-  // lanes 0..15 of the half-wave also carry one element of the 16-wide tail (see the header)
   const int l16 = tid & 15;
-  const bool tail = (tid & 16) == 0;
-  const float c_rx = tail && l16 == 0, c_ry = tail && l16 == 1, c_rz = tail && l16 == 2;
-  const float c_x = tail && l16 >= 3 && l16 < A.f_src, c_one = tail && l16 == 12, c_a = tail && l16 == 13;
-  const int xi = min(l16, A.f_src - 1);
+  // this lane's six channels: ch..ch+2 and 48+ch..48+ch+2, so that each of the two dwordx3
+  // accesses of a fragment covers a CONTIGUOUS 192-byte span per row (6 consecutive channels per
+  // lane would leave 12-byte holes in every instruction: half-filled lines on loads and stores)
+  const int ch = 3 * l16;
+  constexpr int CH2 = C / 2;
 
   // Row assignment (all wave-uniform).  Workgroups with equal blockIdx % 8 share an XCD and
   // its L2 (observed placement; speed only).  Each such group owns one contiguous eighth of
-  // the rows and its streams (one per wave pair-slot) take rows round-robin, so at any moment
-  // the whole group works inside one short sliding window of neighbouring rows: the 3-6
-  // readers of a source row then run close together in time and the re-reads hit that L2
-  // instead of going back to memory.
+  // the rows and its streams (one per wave) take rows round-robin, so at any moment the whole
+  // group works inside one short sliding window of neighbouring rows: the 3-6 readers of a
+  // source row then run close together in time and the re-reads hit that L2 instead of going
+  // back to memory.
   const int nblk = gridDim.x;
   const int ngrp = min(nblk, 8);
   const int grp = blockIdx.x % ngrp, lb = blockIdx.x / ngrp;
   const int nb_grp = (nblk - grp + ngrp - 1) / ngrp;            // workgroups in this group
   const int64_t x_lo = A.n_dst * grp / ngrp, x_hi = A.n_dst * (grp + 1) / ngrp;
-  const int64_t n_streams = (int64_t)nb_grp * SH::subs;
-  int64_t r = x_lo + (int64_t)lb * SH::subs + sub;
-  if (sub >= SH::subs || r >= x_hi) return;
+  const int64_t n_streams = (int64_t)nb_grp * AG_WAVES;
+  int64_t r = x_lo + (int64_t)lb * AG_WAVES + wave;
+  if (r >= x_hi) return;
+#ifdef AG_VAR_EXIT_EARLY
+  if (A.n_gates > 0) return;
+#endif
   const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
   const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
-  const const_f32x4_ptr einfo = (const_f32x4_ptr)(uintptr_t)A.einfo;
+  const const_f32x4_ptr erec = (const_f32x4_ptr)(uintptr_t)A.einfo;  // 5 float4 per edge; [4] = (reloc, a)
 
-  // this lane's 3 channels x (wvx, wvy, wvz)
-  const f32x4* epp = reinterpret_cast<const f32x4*>(&s_ep[(gc * C + ch) * 4]);
-  const f32x4 w0 = epp[0], w1 = epp[1], w2 = epp[2];
+  // this lane's 6 channels x W_value[:, 0..2] (edge_params [G][3][96], L2-resident, read once)
+  f3 wv[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const float* e = A.edge_params + gc * GGNN_EDGE_PARAM_ROWS * C + ch + (c < 3 ? c : CH2 + c - 3);
+    wv[c] = {e[0], e[C], e[2 * C]};
+  }
   const float* vbase = A.p_src + A.v_off + gc * C + ch;
   const float* uhbase = A.p_dst + A.u_off + gc * C + ch;
   const float* u4base = A.p_dst + A.u4_off + gc * 16 + l16;
   const float* hbase = A.h_src + ch;
-  const float* xbase = A.x_src + xi;
-  const uint32_t ldp_src = (uint32_t)A.ldp_src, ldp_dst = (uint32_t)A.ldp_dst;
-  const uint32_t ldh = (uint32_t)A.ldh_src, ldx = (uint32_t)A.ldx_src;
+  const float* tbase = A.einfo + l16;
+  const uint32_t ldp_src = (uint32_t)A.ldp_src, ldp_dst = (uint32_t)A.ldp_dst, ldh = (uint32_t)A.ldh_src;
 
   float mx = -INFINITY, den = 0.f, sae = 0.f;
-  f3 acc = {0.f, 0.f, 0.f};
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // scalar state of the current unit
   int u = uptr[r], u_end = uptr[r + 1];
   i32x8 d = udesc[u];
   f32x4 ed[UE];
 #pragma unroll
-  for (int t = 0; t < UE; ++t) ed[t] = einfo[(int64_t)d[1] + t];  // einfo is padded by UE records
+  for (int t = 0; t < UE; ++t) ed[t] = erec[((int64_t)d[1] + t) * (GGNN_EINFO_ROW / 4) + 4];  // padded by UE records
 
   while (true) {
     const int i = d[0], nact = d[2] & 0xFF;
     const bool first = (d[2] >> 8) & 1, last = (d[2] >> 9) & 1;
     // ---- vector side, unconditional and back to back (host checked: n * ld < 2^31) ----
-    f3 uh = {0.f, 0.f, 0.f}, hh[UE], vv[UE];
+    f3 uh[2], hh[UE][2], vv[UE][2];
     float u4 = 0.f, x4[UE];
+    if (!ALL) {
+      uh[0] = uh[1] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < UE; ++t) {
-      hh[t] = {0.f, 0.f, 0.f};
-      vv[t] = {0.f, 0.f, 0.f};
-      x4[t] = 0.f;
+      for (int t = 0; t < UE; ++t) {
+        hh[t][0] = hh[t][1] = vv[t][0] = vv[t][1] = {0.f, 0.f, 0.f};
+        x4[t] = 0.f;
+      }
     }
-    if (active) {
-      if (HAS_H) uh = ld3_nt(uhbase + (uint32_t)i * ldp_dst);  // read once
+    if (ALL || active) {
+#ifndef AG_VAR_NO_U
+      if (HAS_H) {
+        uh[0] = ld3_nt(uhbase + (uint32_t)i * ldp_dst);  // read once
+        uh[1] = ld3_nt(uhbase + (uint32_t)i * ldp_dst + CH2);
+      }
       u4 = __builtin_nontemporal_load(u4base + (uint32_t)i * ldp_dst);
+#endif
 #pragma unroll
       for (int t = 0; t < UE; ++t) {
         const uint32_t j = (uint32_t)d[4 + t];
-        if (HAS_H) hh[t] = ld3(hbase + j * ldh);
-        x4[t] = xbase[j * ldx];
-        vv[t] = ld3(vbase + j * ldp_src);
+#ifndef AG_VAR_NO_H
+        if (HAS_H) {
+          hh[t][0] = ld3(hbase + j * ldh);
+          hh[t][1] = ld3(hbase + j * ldh + CH2);
+        }
+#endif
+#ifndef AG_VAR_NO_X
+        x4[t] = tbase[((uint32_t)d[1] + t) * GGNN_EINFO_ROW];
+#endif
+#ifndef AG_VAR_NO_V
+        vv[t][0] = ld3(vbase + j * ldp_src);
+        vv[t][1] = ld3(vbase + j * ldp_src + CH2);
+#endif
       }
     }
     // ---- scalar side for the next unit (same row, or the first unit of this stream's next
@@ -218,33 +246,35 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
     const i32x8 dn = udesc[un];
     f32x4 edn[UE];
 #pragma unroll
-    for (int t = 0; t < UE; ++t) edn[t] = einfo[(int64_t)dn[1] + t];
+    for (int t = 0; t < UE; ++t) edn[t] = erec[((int64_t)dn[1] + t) * (GGNN_EINFO_ROW / 4) + 4];
 
     if (first) {
       mx = -INFINITY;
       den = 0.f;
       sae = 0.f;
-      acc = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] = 0.f;
     }
-    if (active && nact > 0) {  // (empty rows have a single unit with nact == 0: zeros are stored)
+    if ((ALL || active) && nact > 0) {  // (empty rows have a single unit with nact == 0: zeros are stored)
       float s[UE];
       float mnew = mx;
 #pragma unroll
       for (int t = 0; t < UE; ++t) {
         s[t] = -INFINITY;
         if (t < nact) {
-          // this lane's element of the tail: reloc / raw feature / 1 / a_e / 0
-          const float xe = c_x * x4[t] + c_rx * ed[t].x + c_ry * ed[t].y + c_rz * ed[t].z + c_a * ed[t].w + c_one;
-          float part = u4 * xe;
-          if (HAS_H) part += uh.x * hh[t].x + uh.y * hh[t].y + uh.z * hh[t].z;
-          s[t] = halfwave_sum(part);  // 1/sqrt(96) is folded into u
+          float part = u4 * x4[t];
+          if (HAS_H)
+            part += uh[0].x * hh[t][0].x + uh[0].y * hh[t][0].y + uh[0].z * hh[t][0].z +
+                    uh[1].x * hh[t][1].x + uh[1].y * hh[t][1].y + uh[1].z * hh[t][1].z;
+          s[t] = row_sum(part);  // 1/sqrt(96) is folded into u
           mnew = fmaxf(mnew, s[t]);
         }
       }
       const float scale = __expf(mx - mnew);  // exp(-inf) = 0 on a row's first unit
       den *= scale;
       sae *= scale;
-      acc = {acc.x * scale, acc.y * scale, acc.z * scale};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] *= scale;
 #pragma unroll
       for (int t = 0; t < UE; ++t) {
         if (t < nact) {
@@ -252,20 +282,31 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
           const float pe = __expf(s[t] - mnew);
           den += pe;
           sae += pe * ed[t].w;
-          acc.x += pe * fmaxf(vv[t].x + w0.x * rx + w0.y * ry + w0.z * rz, 0.f);
-          acc.y += pe * fmaxf(vv[t].y + w1.x * rx + w1.y * ry + w1.z * rz, 0.f);
-          acc.z += pe * fmaxf(vv[t].z + w2.x * rx + w2.y * ry + w2.z * rz, 0.f);
+          const float v[6] = {vv[t][0].x, vv[t][0].y, vv[t][0].z, vv[t][1].x, vv[t][1].y, vv[t][1].z};
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            acc[c] += pe * fmaxf(v[c] + wv[c].x * rx + wv[c].y * ry + wv[c].z * rz, 0.f);
         }
       }
       mx = mnew;
     }
-    if (active && last) {
+#ifdef AG_VAR_NO_STORE
+    if ((ALL || active) && last && den == 1.2345f) {
+#else
+    if ((ALL || active) && last) {
+#endif
       const float inv = 1.0f / (den + 1e-16f);  // PyG softmax denominator
       float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
-      st3_nt(orow + A.a_off + ch, {acc.x * inv, acc.y * inv, acc.z * inv});
-      if ((tid & 31) == 0) {
-        __builtin_nontemporal_store(den * inv, orow + A.sc_off);
-        __builtin_nontemporal_store(sae * inv, orow + A.sc_off + 1);
+#ifdef AG_VAR_PLAIN_STORE
+      st3(orow + A.a_off + ch, {acc[0] * inv, acc[1] * inv, acc[2] * inv});
+      st3(orow + A.a_off + ch + CH2, {acc[3] * inv, acc[4] * inv, acc[5] * inv});
+#else
+      st3_nt(orow + A.a_off + ch, {acc[0] * inv, acc[1] * inv, acc[2] * inv});
+      st3_nt(orow + A.a_off + ch + CH2, {acc[3] * inv, acc[4] * inv, acc[5] * inv});
+#endif
+      if (l16 == 0) {  // 8 bytes of a line the other edge type's sweep also writes into: through L2
+        orow[A.sc_off] = den * inv;
+        orow[A.sc_off + 1] = sae * inv;
       }
     }
     if (!more) break;
@@ -291,12 +332,13 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
     if (k < n_edge_types) {
       const ggnn_prepare_edge& T = edges[k];
       if (T.E < 0 || T.ldx_src < 3 || T.ldx_dst < 3 || !T.einfo || !aligned16(T.einfo)) return GGNN_EINVAL;
+      if (T.f_src < 3 || T.f_src > 12 || T.ldx_src < T.f_src) return GGNN_EINVAL;
       if (T.E > 0 && (!T.col || !T.perm || !T.row || !T.edge_attr || !T.x_src || !T.x_dst))
         return GGNN_EINVAL;
       P.et[k] = T;
       P.e_off[k + 1] = P.e_off[k] + T.E + GGNN_UNIT_EDGES;  // + zero padding records
     } else {
-      P.et[k] = ggnn_prepare_edge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+      P.et[k] = ggnn_prepare_edge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
       P.e_off[k + 1] = P.e_off[k];
     }
   }
@@ -311,23 +353,22 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
   using namespace ggnn;
   if (!args) return GGNN_EINVAL;
   ggnn_aggregate_args A = *args;
-  if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.x_src || !A.edge_params || !A.agg)
+  if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.edge_params || !A.agg)
     return GGNN_EINVAL;
   if (!aligned16(A.units) || !aligned16(A.einfo)) return GGNN_EINVAL;
   if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0) return GGNN_EINVAL;
   const int G = A.n_gates;
   if (G != 1 && G != 3 && G != 4) return GGNN_EINVAL;
-  if (A.f_src < 3 || A.f_src > 12 || A.ldx_src < A.f_src) return GGNN_EINVAL;
   const bool has_h = A.h_src != nullptr;
   if (has_h && (A.ldh_src < C || A.u_off < 0)) return GGNN_EINVAL;
   if (!has_h) {  // never dereferenced, but the address arithmetic must stay in range
-    A.h_src = A.x_src;
+    A.h_src = A.p_src;
     A.ldh_src = 0;
     A.u_off = 0;
   }
   if (A.v_off < 0 || A.u4_off < 0 || A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
   if (A.ldp_src <= 0 || A.ldp_dst <= 0 || A.n_src * A.ldp_src >= INT32_MAX || A.n_dst * A.ldp_dst >= INT32_MAX ||
-      A.n_src * A.ldx_src >= INT32_MAX || A.n_src * A.ldh_src >= INT32_MAX)
+      A.n_src * A.ldh_src >= INT32_MAX || (A.E + GGNN_UNIT_EDGES) * GGNN_EINFO_ROW >= INT32_MAX)
     return GGNN_EINVAL;  // the sweep forms row offsets in 32 bits
   if (A.v_off + (int64_t)G * C > A.ldp_src || A.u4_off + (int64_t)G * 16 > A.ldp_dst) return GGNN_EINVAL;
   if (has_h && A.u_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
@@ -335,7 +376,7 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
   // persistent grid: at least 4 rows per workgroup, at most the resident capacity
   const int64_t want = (A.n_dst + 3) / 4;
-  const int64_t cap = (int64_t)AG_NUM_CU * AG_BLOCKS_PER_CU;
+  const int64_t cap = (int64_t)AG_NUM_CU * (has_h ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH);
   const dim3 grid((unsigned)(want < cap ? want : cap));
   hipStream_t s = (hipStream_t)stream;
 #define GGNN_AG_LAUNCH(G_)                                                                   \

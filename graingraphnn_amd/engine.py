@@ -66,8 +66,8 @@ class Workspace:
             n = n_nodes[nt]
             ncols = max(enc.layout[nt].ncols, dec.layout[nt].ncols)
             self.proj[nt] = torch.empty(n, ncols, **f32)
-            self.agg_enc[nt] = torch.zeros(n, max(enc.G * enc.layout[nt].Ka, 4), **f32)
-            self.agg_dec[nt] = torch.zeros(n, max(dec.G * dec.layout[nt].Ka, 4), **f32)
+            self.agg_enc[nt] = torch.zeros(n, enc.G * enc.layout[nt].Kg, **f32)
+            self.agg_dec[nt] = torch.zeros(n, dec.G * dec.layout[nt].Kg, **f32)
             for d in (self.h1, self.c1, self.h2, self.c2):
                 d[nt] = torch.empty(n, C, **f32)
 
@@ -86,8 +86,9 @@ def _check_x(x: torch.Tensor, F: int, name: str):
 
 
 def alloc_einfo(graph: GraphCSR, device):
-    """[E + GGNN_UNIT_EDGES, 4] per edge type: the tail rows pad the last unit's 48-byte read."""
-    return {et: torch.zeros(graph.n_edges(et) + _lib.GGNN_UNIT_EDGES, 4, dtype=torch.float32, device=device)
+    """[E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] per edge type: the tail rows pad the last unit's reads."""
+    return {et: torch.zeros(graph.n_edges(et) + _lib.GGNN_UNIT_EDGES, _lib.GGNN_EINFO_ROW, dtype=torch.float32,
+                            device=device)
             for et in EDGE_TYPES}
 
 
@@ -117,16 +118,16 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
         s, d = et[0], et[-1]
         if not lay[d].live:
             continue
-        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], x[s], h_in[s] if pc.k2 else None,
+        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
                           pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
-                          lay[d].a_off[et], lay[d].Ka, lay[d].sc_off[et], pc.G)
+                          lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G)
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
     for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
         if not lay[nt].live:
             continue
         backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
                               c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode,
-                              pc.w2p.get(nt))
+                              pc.w2p.get(nt), lay[nt].Kg)
 
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,

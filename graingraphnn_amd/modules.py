@@ -62,10 +62,10 @@ class PeriodConv(nn.Module):
         be.project(xs, Fs, hs, wps, bps, ps)
         be.project(xd, Fd, hd, wpd, bpd, pd)
         csr = be.build_csr(edge_index, x_src.size(0), x_dst.size(0))
-        einfo = torch.zeros(edge_index.size(1) + _lib.GGNN_UNIT_EDGES, 4, device=dev)
+        einfo = torch.zeros(edge_index.size(1) + _lib.GGNN_UNIT_EDGES, _lib.GGNN_EINFO_ROW, device=dev)
         be.edge_prepare([(csr, _edge_attr_1d(edge_attr), xs, xd, einfo)])
         agg = torch.zeros(x_dst.size(0), 100, device=dev)
-        be.aggregate(csr, einfo, ps, pd, xs, hs, ep, agg, 0, 0, 2 * C, 0, 100, C, 1)
+        be.aggregate(csr, einfo, ps, pd, hs, ep, agg, 0, 0, 2 * C, 0, 100, C, 1)
         out = torch.empty(x_dst.size(0), C, device=dev)
         be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW, bf16_planes(w2))
         return out
@@ -130,7 +130,7 @@ class HeteroPGCLSTM(nn.Module):
         dev = x_dict["joint"].device
         f32 = dict(dtype=torch.float32, device=dev)
         proj = {nt: torch.empty(n_nodes[nt], pc.layout[nt].ncols, **f32) for nt in NODE_TYPES}
-        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Ka, **f32) for nt in NODE_TYPES}
+        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Kg, **f32) for nt in NODE_TYPES}
         h_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
         c_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}

@@ -57,7 +57,9 @@ class NodeLayout:
     sc_off: Dict[Tuple[str, str, str], int] = field(default_factory=dict)
     s_off: int = 0
     ncols: int = 0
-    Ka: int = 0
+    Ka: int = 0   # width of the gate weight W2 (aggregate columns the gate GEMM reads)
+    Kg: int = 0   # gate stride inside an aggregate row: Ka rounded up to 32 floats, so that every
+                  # 384-byte block the sweep stores is three whole 128-byte lines
     live: bool = True
 
     @property
@@ -93,6 +95,7 @@ def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: boo
     lay.ncols = (off + C - 1) // C * C
     n_in = len(dst_ets)
     lay.Ka = roundup4(n_in * C + 2 * n_in)
+    lay.Kg = (max(lay.Ka, 4) + 31) // 32 * 32
     for d, et in enumerate(dst_ets):
         lay.a_off[et] = d * C
         lay.sc_off[et] = n_in * C + 2 * d

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 9
+#define GGNN_ABI_VERSION 10
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -79,12 +79,16 @@ int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t 
                    ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Per-edge geometry in CSR order, computed once per forward and shared by every gate of the
- * encoder and decoder cells:  einfo[p] = (reloc_x, reloc_y, reloc_z, edge_attr) with
- * reloc = min-image(x_src[col[p], :3] - x_dst[row[p], :3]) exactly as periodGATconv.py:209-210
+ * Per-edge record in CSR order, computed once per forward and shared by every gate of the
+ * encoder and decoder cells (GGNN_EINFO_ROW = 20 floats per edge):
+ *   einfo[p, 0..15]  = (reloc_xyz, x_src[col[p], 3 .. f_src), 0.., 1 at 12, edge_attr at 13, 0, 0)
+ *                      -- the non-hidden part of the source row the attention score is taken with
+ *   einfo[p, 16..19] = (reloc_x, reloc_y, reloc_z, edge_attr)
+ * with reloc = min-image(x_src[col[p], :3] - x_dst[row[p], :3]) exactly as periodGATconv.py:209-210
  * (rel > 0.5 -> rel - 1, rel < -0.5 -> rel + 1) and edge_attr taken from the ORIGINAL COO
  * order through perm (edge_attr_dict[et][:, 0]).  Up to three edge types per launch.
  */
+#define GGNN_EINFO_ROW 20
 typedef struct ggnn_prepare_edge {
   const int32_t* col;     /* [E] */
   const int32_t* perm;    /* [E] */
@@ -92,8 +96,8 @@ typedef struct ggnn_prepare_edge {
   const float* edge_attr; /* [E] COO order */
   const float* x_src;     /* [n_src, ldx_src] */
   const float* x_dst;     /* [n_dst, ldx_dst] */
-  float* einfo;           /* [E + GGNN_UNIT_EDGES, 4] out, 16-byte aligned (tail rows are padding) */
-  int64_t ldx_src, ldx_dst, E;
+  float* einfo;           /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] out, 16-byte aligned (tail rows are padding) */
+  int64_t ldx_src, ldx_dst, E, f_src; /* 3 <= f_src <= 12 source features */
 } ggnn_prepare_edge;
 int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
 
@@ -124,7 +128,8 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
  * s2_i = w_edge.q_i/sqrt(96) are affine in the destination's [x_i | h_i] and come from
  * ggnn_project.  Per destination i and gate g the projections hold
  *   p_dst[i, u_off  + g*96 + 0..95] = u_i[F ..]   (hidden-state part; absent when h_src == NULL)
- *   p_dst[i, u4_off + g*16 + 0..15] = (u_i[0..F-1], 0.., s1_i at 12, s2_i at 13, 0, 0)
+ *   p_dst[i, u4_off + g*16 + 0..15] = (u_i[0..F-1], 0.., s1_i at 12, s2_i at 13, 0, 0), dotted
+ *                                     with einfo[e, 0..15]
  *   p_src[j, v_off  + g*96 + 0..95] = lin_value(x_j with its first three columns zeroed, h_j)
  * and the sweep writes
  *   agg[i, g*a_gstride + a_off + 0..95] = sum_e alpha_e * relu(lin_value(x~_j))
@@ -136,15 +141,14 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
 typedef struct ggnn_aggregate_args {
   const int32_t* unit_ptr;  /* [n_dst + 1] from ggnn_build_csr */
   const int32_t* units;     /* [n_units, 8] from ggnn_build_csr */
-  const float* einfo;       /* [E + GGNN_UNIT_EDGES, 4] from ggnn_edge_prepare */
+  const float* einfo;       /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] from ggnn_edge_prepare */
   const float* p_src;       /* [n_src, ldp_src] projections of the source node type */
   const float* p_dst;       /* [n_dst, ldp_dst] projections of the destination node type */
-  const float* x_src;       /* [n_src, ldx_src] source features, first f_src columns used */
   const float* h_src;       /* [n_src, ldh_src] source hidden state, or NULL (encoder: h = 0) */
   const float* edge_params; /* [n_gates][GGNN_EDGE_PARAM_ROWS][96] = W_value[:, 0..2] */
   float* agg;               /* [n_dst, ld_agg] */
-  int64_t ldp_src, ldp_dst, ld_agg, ldx_src, ldh_src, n_src, n_dst, E;
-  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, f_src; /* 3 <= f_src <= 12 */
+  int64_t ldp_src, ldp_dst, ld_agg, ldh_src, n_src, n_dst, E;
+  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
 

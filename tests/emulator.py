@@ -33,8 +33,13 @@ class TorchEmulatorBackend:
             col, perm, row = csr.col.long(), csr.perm.long(), csr.row.long()
             E = ea.numel()
             rel = xs[col[:E], :3] - xd[row[:E], :3]
-            einfo[:E, :3] = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
-            einfo[:E, 3] = ea[perm[:E]]
+            reloc = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+            Fs = xs.size(1)
+            einfo[:E] = 0.0
+            einfo[:E, 0:3] = einfo[:E, 16:19] = reloc
+            einfo[:E, 3:Fs] = xs[col[:E], 3:Fs]
+            einfo[:E, 12] = 1.0
+            einfo[:E, 13] = einfo[:E, 19] = ea[perm[:E]]
 
     def project(self, x, F, h, wp, bp, out):
         Fp = (F + 3) & ~3
@@ -46,20 +51,14 @@ class TorchEmulatorBackend:
             xin[:, Fp:] = h
         out[:, :wp.size(0)] = xin @ wp.t() + bp
 
-    def aggregate(self, csr, einfo, p_src, p_dst, x_src, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+    def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
                   a_gstride, sc_off, n_gates):
         rowptr, col = csr.rowptr.long(), csr.col.long()
         n_dst = p_dst.size(0)
         E = int(rowptr[-1])
-        Fs = x_src.size(1)
         dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
-        j, reloc, a = col[:E], einfo[:E, :3], einfo[:E, 3]
-        # the per-edge 16-wide tail: reloc, raw features 3..F-1, zeros, 1 @12, a_e @13
-        x4 = torch.zeros(E, 16)
-        x4[:, :3] = reloc
-        x4[:, 3:Fs] = x_src[j, 3:Fs]
-        x4[:, 12] = 1.0
-        x4[:, 13] = a
+        j, reloc, a = col[:E], einfo[:E, 16:19], einfo[:E, 19]
+        x4 = einfo[:E, :16]  # the per-edge 16-wide tail: reloc, raw features 3..F-1, zeros, 1 @12, a_e @13
         for g in range(n_gates):
             V = p_src[j, v_off + g * C: v_off + (g + 1) * C]
             s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
@@ -76,14 +75,15 @@ class TorchEmulatorBackend:
             agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
 
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
-                      w2_planes=None):
+                      w2_planes=None, g_stride=0):
         Ka = w2.size(2)
+        gs = g_stride or Ka
         if w2_planes is not None:  # the planes must reassemble to w2[:, :, :Ka-4] exactly (ggnn.h layout)
             G, KM = w2.size(0), Ka - 4
             pl = w2_planes.view(torch.bfloat16).view(G, KM // 32, 3, 6, 4, 16, 8).float().sum(2)  # g ks ct kq i j
             back = pl.permute(0, 2, 4, 1, 3, 5).reshape(G, 96, KM)
             assert torch.equal(back, w2[:, :, :KM])
-        pre = [agg[:, g * Ka:(g + 1) * Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]
+        pre = [agg[:, g * gs:g * gs + Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]
                for g in range(n_gates)]
         if mode == 2:
             raw_out.copy_(torch.cat(pre, 1))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 9
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 10
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4
@@ -60,7 +60,7 @@ def test_argument_validation_returns_einval_without_launching():
 
 def test_struct_sizes_match_the_header():
     """ctypes mirrors of the POD argument blocks (natural alignment, no packing)."""
-    assert ctypes.sizeof(_lib.AggregateArgs) == 9 * 8 + 8 * 8 + 8 * 4
-    assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 3 * 8
+    assert ctypes.sizeof(_lib.AggregateArgs) == 8 * 8 + 7 * 8 + 8 * 4
+    assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 4 * 8
     assert ctypes.sizeof(_lib.EpilogueArgs) == 7 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4
     assert ctypes.sizeof(_lib.RefreshEdge) == 4 * 8 + 5 * 8

@@ -341,8 +341,7 @@ def test_cfg3_full_size_step_and_properties():
     assert_close(pred3["edge_event"], pred["edge_event"][torch.from_numpy(perm[JJ]).to(DEV)],
                  "cfg3 permuted-COO edge_event", 1e-5)
     # (3) softmax normalisation: sum of alpha is 1 on every row with an in-edge
-    Ka = 196
-    sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, Ka)[:, :, 192::2]
+    sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, 224)[:, :, 192:196:2]
     assert float((sa - 1).abs().max()) < 1e-5
 
 

@@ -68,7 +68,7 @@ def test_layout_offsets():
     lg = packing.node_layout("grain", 11, 4)
     # joint: V for j->g, j->j (768) | u_h for g->j, j->j (768) | S (384) | u4 (2 x 64), padded to 96s
     assert (lj.ncols, lg.ncols) == (2112, 1248)
-    assert (lj.Ka, lg.Ka) == (196, 100)
+    assert (lj.Ka, lg.Ka) == (196, 100) and (lj.Kg, lg.Kg) == (224, 128)
     assert lj.v_off == {EDGE_TYPES[1]: 0, EDGE_TYPES[2]: 384}
     assert lj.u_off == {EDGE_TYPES[0]: 768, EDGE_TYPES[2]: 1152} and lj.s_off == 1536
     assert lj.u4_off == {EDGE_TYPES[0]: 1920, EDGE_TYPES[2]: 1984}
@@ -135,7 +135,7 @@ def test_cell_with_state_and_single_conv_packing():
         cell = (R.gclstm_encoder if encoder else R.gclstm_decoder).cell_list[0]
         pc = cell.packed(encoder)
         proj = {nt: torch.empty(n_nodes[nt], pc.layout[nt].ncols) for nt in n_nodes}
-        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Ka) for nt in n_nodes}
+        agg = {nt: torch.zeros(n_nodes[nt], pc.G * pc.layout[nt].Kg) for nt in n_nodes}
         ho = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
         co = {nt: torch.empty(n_nodes[nt], 96) for nt in n_nodes}
         einfo = engine.prepare_edges(be, graph, X, ea1, None)
@@ -153,7 +153,7 @@ def test_cell_with_state_and_single_conv_packing():
         be.project(X[et[0]], Fs, h0[et[0]], wps, bps, ps)
         be.project(X[et[-1]], Fd, h0[et[-1]], wpd, bpd, pd)
         agg = torch.zeros(n_nodes[et[-1]], 100)
-        be.aggregate(graph.csr[et], einfo[et], ps, pd, X[et[0]], h0[et[0]], ep, agg, 0, 0, 192, 0, 100, 96, 1)
+        be.aggregate(graph.csr[et], einfo[et], ps, pd, h0[et[0]], ep, agg, 0, 0, 192, 0, 100, 96, 1)
         out = torch.empty(n_nodes[et[-1]], 96)
         be.lstm_epilogue(agg, w2, pd, 96, None, None, None, out, 1, 2)
         assert_close(out, g["conv_" + etk(et)], f"conv {et}", TOL)
