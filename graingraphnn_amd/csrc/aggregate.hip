@@ -84,17 +84,19 @@ __device__ __forceinline__ float row_sum(float v) {
 // ---------------------------------------------------------------------------------------
 struct PrepareArgs {
   ggnn_prepare_edge et[3];
-  int64_t e_off[4];
+  int b_off[4];  // first workgroup of every edge type (256 records per workgroup)
   int n_et;
 };
 
 __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= P.e_off[P.n_et]) return;
+  // One thread builds one record (one gather of the source row, the destination xyz and the edge
+  // length); the workgroup's 256 records are contiguous in memory and leave through LDS as 1 280
+  // consecutive 16-byte pieces, so every store instruction covers 1 KB.
+  __shared__ __attribute__((aligned(16))) float s_rec[256 * GGNN_EINFO_ROW];
   int k = 0;
-  while (k + 1 < P.n_et && t >= P.e_off[k + 1]) ++k;
+  while (k + 1 < P.n_et && (int)blockIdx.x >= P.b_off[k + 1]) ++k;
   const ggnn_prepare_edge& T = P.et[k];
-  const int64_t p = t - P.e_off[k];
+  const int64_t p0 = (int64_t)((int)blockIdx.x - P.b_off[k]) * 256, p = p0 + threadIdx.x;
   float rec[GGNN_EINFO_ROW];
 #pragma unroll
   for (int c = 0; c < GGNN_EINFO_ROW; ++c) rec[c] = 0.f;
@@ -113,9 +115,18 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
     rec[12] = 1.0f;
     rec[13] = rec[19] = T.edge_attr[T.perm[p]];
   }
-  f32x4* o = reinterpret_cast<f32x4*>(T.einfo + GGNN_EINFO_ROW * p);
+  f32x4* mine = reinterpret_cast<f32x4*>(&s_rec[threadIdx.x * GGNN_EINFO_ROW]);
 #pragma unroll
-  for (int c = 0; c < GGNN_EINFO_ROW / 4; ++c) o[c] = (f32x4){rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]};
+  for (int c = 0; c < GGNN_EINFO_ROW / 4; ++c) mine[c] = (f32x4){rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]};
+  __syncthreads();
+  const int64_t n_rec = min((int64_t)256, T.E + GGNN_UNIT_EDGES - p0);  // records of this workgroup
+  const f32x4* src = reinterpret_cast<const f32x4*>(s_rec);
+  f32x4* dst = reinterpret_cast<f32x4*>(T.einfo + p0 * GGNN_EINFO_ROW);
+#pragma unroll
+  for (int c = 0; c < GGNN_EINFO_ROW / 4; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < n_rec * (GGNN_EINFO_ROW / 4)) dst[i] = src[i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -327,7 +338,7 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
   if (!edges || n_edge_types < 1 || n_edge_types > 3) return GGNN_EINVAL;
   PrepareArgs P;
   P.n_et = n_edge_types;
-  P.e_off[0] = 0;
+  P.b_off[0] = 0;
   for (int k = 0; k < 3; ++k) {
     if (k < n_edge_types) {
       const ggnn_prepare_edge& T = edges[k];
@@ -335,17 +346,16 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
       if (T.f_src < 3 || T.f_src > 12 || T.ldx_src < T.f_src) return GGNN_EINVAL;
       if (T.E > 0 && (!T.col || !T.perm || !T.row || !T.edge_attr || !T.x_src || !T.x_dst))
         return GGNN_EINVAL;
+      const int64_t nb = (T.E + GGNN_UNIT_EDGES + 255) / 256;  // + zero padding records
+      if (P.b_off[k] + nb >= INT32_MAX) return GGNN_EINVAL;
       P.et[k] = T;
-      P.e_off[k + 1] = P.e_off[k] + T.E + GGNN_UNIT_EDGES;  // + zero padding records
+      P.b_off[k + 1] = P.b_off[k] + (int)nb;
     } else {
       P.et[k] = ggnn_prepare_edge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-      P.e_off[k + 1] = P.e_off[k];
+      P.b_off[k + 1] = P.b_off[k];
     }
   }
-  const int64_t total = P.e_off[n_edge_types];
-  const int64_t nblk = (total + 255) / 256;
-  if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  hipLaunchKernelGGL(edge_prepare_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(edge_prepare_kernel, dim3((unsigned)P.b_off[n_edge_types]), dim3(256), 0, (hipStream_t)stream, P);
   return launch_status();
 }
 

@@ -37,14 +37,14 @@ __global__ __launch_bounds__(256) void heads_regressor_kernel(
   if (node < n_joint) {
     node_dots<2>(h_joint + node * C, w, l16, d);
     if (l16 == 0) {  // models.py:443
-      y_joint[2 * node] = tanhf(d[0] + b[0]);
-      y_joint[2 * node + 1] = tanhf(d[1] + b[1]);
+      y_joint[2 * node] = tanhf_(d[0] + b[0]);  // v_exp / v_rcp form: libm tanhf on one lane in 16 cost 15 us
+      y_joint[2 * node + 1] = tanhf_(d[1] + b[1]);
     }
   } else {
     const int64_t g = node - n_joint;
     node_dots<2>(h_grain + g * C, w + 2 * C, l16, d);
     if (l16 == 0) {
-      const float t0 = tanhf(d[0] + b[2]);
+      const float t0 = tanhf_(d[0] + b[2]);
       grain_area[g] = t0 / 20.0f + x_grain[g * ldx_grain + 3];  // models.py:445
       y_grain[2 * g] = t0;                                      // :450
       y_grain[2 * g + 1] = fmaxf(d[1] + b[3], 0.f);             // :452

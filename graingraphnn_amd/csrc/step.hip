@@ -48,21 +48,35 @@ __global__ __launch_bounds__(256) void grain_centres_kernel(
   if (p1 - p0 <= 1) return;  // graph_datastruct.py:685: such a region keeps its centre
   const bool folded = factor > 1.0f;
   float prev[2], sum[2] = {0.f, 0.f}, lo[2] = {INFINITY, INFINITY};
-  for (int p = p0; p < p1; ++p) {
-    const int64_t j = min((int64_t)max(col[p], 0), n_joint - 1);
-    float v[2];
+  // batches of 8 junctions: the index loads, then the coordinate loads, are issued together; only
+  // the min-image chain itself is sequential
+  for (int q0 = p0; q0 < p1; q0 += 8) {
+    int64_t js[8];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float t = x_joint[j * ldxj + c];
-      if (folded) t = (t + (offset ? offset[2 * j + c] : 0.f)) / factor;  // test.py:474
-      if (p > p0) {  // periodic_move, graph_datastruct.py:55-72
-        const float rel = t - prev[c];
-        t += rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
+    for (int k = 0; k < 8; ++k) js[k] = min((int64_t)max(col[min(q0 + k, p1 - 1)], 0), n_joint - 1);
+    float raw[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t = x_joint[js[k] * ldxj + c];
+        if (folded) t = (t + (offset ? offset[2 * js[k] + c] : 0.f)) / factor;  // test.py:474
+        raw[k][c] = t;
       }
-      v[c] = t;
-      prev[c] = t;
-      sum[c] += t;
-      lo[c] = fminf(lo[c], t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (q0 + k >= p1) break;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t = raw[k][c];
+        if (q0 + k > p0) {  // periodic_move, graph_datastruct.py:55-72
+          const float rel = t - prev[c];
+          t += rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
+        }
+        prev[c] = t;
+        sum[c] += t;
+        lo[c] = fminf(lo[c], t);
+      }
     }
   }
   const float inv = 1.0f / (float)(p1 - p0);
