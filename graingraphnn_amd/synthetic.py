@@ -122,6 +122,96 @@ def honeycomb(n: int = 100, fold: int = 10, seed: int = 0, shuffle_edges: bool =
     return x, ei, ea
 
 
+def voronoi(n_grains: int = 400, seed: int = 0, fold: int = 1, lattice_noise: float = None,
+            shuffle_edges: bool = True, return_offset: bool = False):
+    """Random periodic grain structure: the Voronoi tessellation of `n_grains` seed points on the
+    unit torus (what graph_datastruct.py:350-464 builds from its 3 x 3 mirrored seeds with
+    scipy.spatial.Voronoi: grains = cells, junctions = Voronoi vertices, every junction touches
+    exactly three grains and three junctions).  `lattice_noise=None`: uniformly random seeds (grain
+    degrees 3..11); a float: a hexagonal lattice with that relative jitter, the reference's default
+    initial condition (graph_datastruct.py:118-160).  Returns numpy dicts like `honeycomb`, after
+    integer patch folding by `fold` (test.py:29-55)."""
+    from scipy.spatial import Voronoi
+    rs = np.random.RandomState(seed)
+    if lattice_noise is None:
+        pts = rs.uniform(0, 1, (n_grains, 2))
+    else:
+        n = int(round(np.sqrt(n_grains)))
+        n += n % 2
+        r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        pts = np.stack([(c.ravel() + 0.5 * (r.ravel() & 1)) / n, r.ravel() / n], 1)
+        pts = (pts + rs.normal(0, lattice_noise / n, pts.shape)) % 1.0
+    n_g = len(pts)
+    shifts = np.array([[dx, dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1)], dtype=np.float64)
+    tiled = (pts[None, :, :] + shifts[:, None, :]).reshape(-1, 2)      # copy k of seed g = row k * n_g + g
+    vor = Voronoi(tiled)
+    # junctions = Voronoi vertices inside the unit cell; vertex -> canonical junction id by position
+    V = vor.vertices
+    inside = np.all((V >= 0) & (V < 1), axis=1)
+    jid = -np.ones(len(V), dtype=np.int64)
+    jid[inside] = np.arange(int(inside.sum()))
+    xj = V[inside]
+    n_j = len(xj)
+    key = {tuple(np.round(p, 9)): k for k, p in enumerate(xj)}
+
+    def canon(v):  # any copy of a vertex -> its junction id (or -1 far outside the 3 x 3 tiling's core)
+        if jid[v] >= 0:
+            return int(jid[v])
+        return key.get(tuple(np.round(V[v] % 1.0, 9)), -1)
+
+    jj, jg = set(), set()
+    for (a, b), (p, q) in zip(vor.ridge_vertices, vor.ridge_points):
+        if a < 0 or b < 0 or not (inside[a] or inside[b]):
+            continue
+        ca, cb = canon(a), canon(b)
+        if ca < 0 or cb < 0:
+            raise RuntimeError("Voronoi vertex without a periodic image: increase n_grains")
+        jj.add((ca, cb))
+        jj.add((cb, ca))
+        for v, cv in ((a, ca), (b, cb)):
+            if inside[v]:
+                jg.add((cv, int(p % n_g)))
+                jg.add((cv, int(q % n_g)))
+    jj = np.array(sorted(jj), dtype=np.int64).T
+    jg = np.array(sorted(jg), dtype=np.int64).T
+    if n_j != 2 * n_g or jj.shape[1] != 3 * n_j or jg.shape[1] != 3 * n_j:
+        raise RuntimeError(f"degenerate tessellation (N_j={n_j}, N_g={n_g}, E_jj={jj.shape[1]}, E_jg={jg.shape[1]})")
+    gj = jg[::-1].copy()
+    ei = {GJ: gj, JG: jg, JJ: jj}
+    if shuffle_edges:
+        for k, et in enumerate(EDGE_TYPES):
+            p = np.random.RandomState(seed + 1 + k).permutation(ei[et].shape[1])
+            ei[et] = ei[et][:, p]
+        ei[GJ] = ei[JG][::-1].copy()      # grain->joint stays the flip of joint->grain (models.py:837)
+    ei = {et: np.ascontiguousarray(v.astype(np.int64)) for et, v in ei.items()}
+    # grain centre = mean of its (min-imaged) junctions; area = shoelace of the polygon around it
+    xg, area = np.zeros((n_g, 2)), np.zeros(n_g)
+    order = np.argsort(jg[1], kind="stable")
+    bounds = np.searchsorted(jg[1][order], np.arange(n_g + 1))
+    for g in range(n_g):
+        js = jg[0][order[bounds[g]:bounds[g + 1]]]
+        rel = _minimg(xj[js] - xj[js[0]])
+        ctr = rel.mean(0)
+        ang = np.argsort(np.arctan2(rel[:, 1] - ctr[1], rel[:, 0] - ctr[0]))
+        poly = rel[ang]
+        area[g] = 0.5 * abs(np.dot(poly[:, 0], np.roll(poly[:, 1], -1)) - np.dot(poly[:, 1], np.roll(poly[:, 0], -1)))
+        xg[g] = (xj[js[0]] + ctr) % 1.0
+    theta_x, theta_z = rs.uniform(0, np.pi / 2, n_g), rs.uniform(0, np.pi / 2, n_g)
+    fg = np.zeros((n_g, 11))
+    fg[:, :2] = (xg * fold) % 1.0
+    fg[:, 3] = area * fold * fold          # area as a fraction of one training-size patch
+    fg[:, 5], fg[:, 6], fg[:, 7], fg[:, 8] = np.cos(theta_x), np.sin(theta_x), np.cos(theta_z), np.sin(theta_z)
+    fg[:, 9] = 6 / 120
+    fj = np.zeros((n_j, 8))
+    fj[:, :2] = (xj * fold) % 1.0
+    fj[:, 3], fj[:, 4], fj[:, 5] = 0.0, 1.0, 6 / 120
+    x = {"grain": fg.astype(np.float32), "joint": fj.astype(np.float32)}
+    ea = edge_lengths({k: v.astype(np.float64) for k, v in x.items()}, ei)
+    if return_offset:
+        return x, ei, ea, np.floor(xj * fold).astype(np.float32)
+    return x, ei, ea
+
+
 def load_fixture(path):
     """tests/golden/graph_*.npz -> (x_dict, edge_index_dict, edge_attr_dict) of numpy arrays."""
     z = np.load(path)

@@ -303,6 +303,30 @@ def test_ragged_graphs_against_oracle(seed, hub_deg):
         assert_close(yc[k], oyc[k], f"ragged classifier {k}")
 
 
+@torch.no_grad()
+def test_voronoi_graph_rollout_against_oracle():
+    """A random Voronoi structure (grain degrees 3..11: rows of up to four units, triangles) through
+    three full steps incl. the centre refresh."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = synthetic.voronoi(500, seed=11)
+    deg = np.bincount(ei[JG][1])
+    assert deg.min() == 3 and deg.max() >= 9
+    # small weights: junctions must move by less than a grain per step, or the polygons fold over
+    # themselves and the chained min-image of the centre refresh depends on the junction order
+    R, Cm = product_models(3, 0.1, DEV)
+    oR, oC = oracle_models(3, 0.1)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, refresh_centres=True)
+    for step in range(3):
+        pred = {k: v.clone() for k, v in ro.step().items()}
+        opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6, centres=(1.0, None))
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert_close(pred[k], opred[k], f"voronoi step {step} {k}")
+    for nt in x:
+        assert_close(X[nt], oX[nt], f"voronoi x {nt}")
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE full size (cfg3): one oracle step + size-independent properties
 # ---------------------------------------------------------------------------------------

@@ -267,6 +267,27 @@ def test_honeycomb_invariants():
     assert all(v.shape == (2, 60000) for v in ei3.values())
 
 
+def test_voronoi_generator_invariants():
+    """the scipy-Voronoi initial-structure generator gives a valid grain graph
+    (graph_trajectory.py:985-988): 3 + 3 neighbours per junction, N_j = 2 N_g, mutual edge lists,
+    unit total area; its grain centres are the junction-polygon means the centre refresh computes."""
+    for kw in (dict(n_grains=300, seed=2), dict(n_grains=256, seed=5, lattice_noise=0.2)):
+        x, ei, ea = synthetic.voronoi(**kw)
+        ng, nj = x["grain"].shape[0], x["joint"].shape[0]
+        assert nj == 2 * ng and all(ei[et].shape == (2, 3 * nj) for et in EDGE_TYPES)
+        assert (np.bincount(ei[EDGE_TYPES[0]][1], minlength=nj) == 3).all()
+        assert (np.bincount(ei[EDGE_TYPES[2]][1], minlength=nj) == 3).all()
+        assert set(map(tuple, ei[EDGE_TYPES[2]].T)) == set(map(tuple, ei[EDGE_TYPES[2]][::-1].T))
+        assert np.array_equal(ei[EDGE_TYPES[0]], ei[EDGE_TYPES[1]][::-1])
+        assert abs(float(x["grain"][:, 3].sum()) - 1.0) < 1e-5
+        deg = np.bincount(ei[EDGE_TYPES[1]][1], minlength=ng)
+        assert deg.min() >= 3 and deg.sum() == 3 * nj
+        c = oracle.grain_centres(torch.from_numpy(x["joint"][:, :2]), torch.from_numpy(ei[EDGE_TYPES[0]]), ng).numpy()
+        d = np.abs(c % 1 - x["grain"][:, :2])
+        assert np.minimum(d, 1 - d).max() < 1e-5
+        assert float(ea[EDGE_TYPES[2]].max()) < 0.5
+
+
 def test_disjoint_union_offsets():
     g1 = synthetic.honeycomb(4, 1, 0)
     g2 = synthetic.honeycomb(6, 1, 1)
