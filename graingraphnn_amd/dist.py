@@ -60,19 +60,21 @@ def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, 
 
 
 def rollout_trajectories(rmodel, cmodel, graphs, span: int, n_steps: int, rank: int = 0,
-                         world: int = 1, device="cuda", use_graph: bool = True):
+                         world: int = 1, device="cuda", use_graph: bool = True,
+                         refresh_centres: bool = False):
     """BASELINE config 4: `graphs[t]` = (x, ei, ea) numpy dicts of independent trajectories with
     EQUAL node counts.  Rank r rolls out trajectories t = r (mod world) as ONE disjoint-union
     graph on its GPU (one set of launches for the whole shard), then all ranks all-gather the
     final joint coordinates and grain (area, extraV): returns {'joint_xy': [T, N_j, 2],
-    'grain_area_v': [T, N_g, 2]} in trajectory order on every rank."""
+'grain_area_v': [T, N_g, 2]} in trajectory order on every rank.  `refresh_centres`: also
+    recompute the grain centres every step (unfolded domains: factor 1), as `GrainRollout` does."""
     from . import synthetic
     from .rollout import GrainRollout
 
     mine = shard_trajectories(len(graphs), rank, world)
     x, ei, ea, slices = synthetic.disjoint_union([graphs[t] for t in mine])
     X, EI, EA = synthetic.to_torch(x, ei, ea, device)
-    ro = GrainRollout(rmodel, cmodel, X, EI, EA, span, use_graph=use_graph)
+    ro = GrainRollout(rmodel, cmodel, X, EI, EA, span, use_graph=use_graph, refresh_centres=refresh_centres)
     ro.run(n_steps)
     local = {"joint_xy": torch.stack([X["joint"][lo:hi, :2] for lo, hi in (s["joint"] for s in slices)]),
              "grain_area_v": torch.stack([X["grain"][lo:hi, 3:5] for lo, hi in (s["grain"] for s in slices)])}
