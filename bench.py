@@ -288,6 +288,17 @@ def main():
         }
         if not args.no_cpu_baseline and args.workload == "cfg3":
             line["cpu_baseline"] = cpu_baseline(inputs)
+            if world == 1 and default_backend().lib.ggnn_gemm_mode() == 1 and not args.events:
+                # the same workload with the decoder GEMMs on the native fp32 matrix path, in a child
+                # process (the mode is fixed per process), so both arithmetic paths sit in one line
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "200", "--warmup", "10",
+                                    "--no-cpu-baseline"], env=dict(os.environ, GGNN_GEMM="fp32"),
+                                   capture_output=True, text=True, timeout=600)
+                try:
+                    line["config"]["native_fp32_gemm_steps_per_s"] = json.loads(r.stdout.strip().splitlines()[-1])["value"]
+                except (ValueError, IndexError, KeyError):
+                    line["config"]["native_fp32_gemm_steps_per_s"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
