@@ -303,6 +303,28 @@ def test_ragged_graphs_against_oracle(seed, hub_deg):
         assert_close(yc[k], oyc[k], f"ragged classifier {k}")
 
 
+@pytest.mark.parametrize("n_g,n_j", [(3, 7), (9, 15), (16, 17), (23, 33)])
+@torch.no_grad()
+def test_tiny_graphs_against_oracle(n_g, n_j):
+    """Fewer nodes than one 16-row tile, exactly one tile, and ragged last tiles: the GEMM kernels'
+    sliding / clamped tile addressing."""
+    rs = np.random.RandomState(n_g * 100 + n_j)
+    x = {"grain": rs.uniform(0, 1, (n_g, 11)).astype(np.float32), "joint": rs.uniform(0, 1, (n_j, 8)).astype(np.float32)}
+    ei = {GJ: np.stack([rs.randint(0, n_g, 3 * n_j), np.repeat(np.arange(n_j), 3)]).astype(np.int64),
+          JG: np.stack([rs.randint(0, n_j, 5 * n_g), rs.randint(0, n_g, 5 * n_g)]).astype(np.int64),
+          JJ: np.stack([rs.randint(0, n_j, 3 * n_j), rs.randint(0, n_j, 3 * n_j)]).astype(np.int64)}
+    ea = {et: rs.uniform(0.01, 0.1, (v.shape[1], 1)).astype(np.float32) for et, v in ei.items()}
+    R, Cm = product_models(5, 1.0, DEV)
+    oR, oC = oracle_models(5, 1.0)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    yr, yc = R(X, EI, EA), Cm(X, EI, EA)
+    oyr, oyc = oR(tt(x), tt(ei), tt(ea)), oC(tt(x), tt(ei), tt(ea))
+    for k in ("joint", "grain", "grain_area"):
+        assert_close(yr[k], oyr[k], f"tiny ({n_g}, {n_j}) regressor {k}")
+    for k in ("edge_event", "edge"):
+        assert_close(yc[k], oyc[k], f"tiny ({n_g}, {n_j}) classifier {k}")
+
+
 @torch.no_grad()
 def test_voronoi_graph_rollout_against_oracle():
     """A random Voronoi structure (grain degrees 3..11: rows of up to four units, triangles) through
