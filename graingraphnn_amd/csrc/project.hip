@@ -1,8 +1,9 @@
 // Node-level projection GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
 //   out[M, ncols] = [X[:, :F] | H] . Wp^T + bias
 // One launch per node type and cell produces, for every gate and edge type, the per-node
-// key/value (as source), query (as destination) and summed-skip pre-activations that the
-// reference computes per EDGE (periodGATconv.py:216-218, :186).
+// value (as source), key-free score operands u = W_k^T q / sqrt(96) (as destination) and summed-skip
+// pre-activations that replace the reference's per-EDGE linears (periodGATconv.py:216-218, :186;
+// what the rows of Wp hold: graingraphnn_amd/packing.py).
 //
 // K = roundup4(F) + 96 <= 108 is short and M is long, so the kernel is WEIGHT-STATIONARY and
 // persistent: one 8-wave workgroup per CU keeps a 96-column x K weight tile in LDS for its
