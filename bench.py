@@ -54,8 +54,9 @@ def build(device, n=100, fold=10, seed=0, scale=0.3):
 
 
 class EventTimedBackend:
-    """Wraps the HIP backend so that every aggregation launch of the decoder (G = 4, the
-    dominant kernel) is bracketed by HIP events recorded on the launch stream."""
+    """Wraps the HIP backend so that every aggregation launch of the decoder cells (G = 4, the
+    dominant kernel: all sweeps of the cell in one launch, 3 for the regressor and 2 for the
+    classifier) is bracketed by HIP events recorded on the launch stream."""
 
     def __init__(self, inner):
         self.inner = inner
@@ -64,30 +65,36 @@ class EventTimedBackend:
     def __getattr__(self, name):
         return getattr(self.inner, name)
 
-    def aggregate(self, *args):
-        n_gates = args[-1]
-        if n_gates != 4:
-            return self.inner.aggregate(*args)
-        csr, p_src, p_dst = args[0], args[2], args[3]
-        # An event bracket also contains the dispatch latency of the launch (3-5 us in eager mode),
-        # which rocprofv3's kernel durations do not.  The sweep overwrites its outputs, so it can be
-        # repeated: [1 launch] and [2 launches] brackets differ by exactly one kernel duration.
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    def aggregate_batch(self, sweeps):
+        if sweeps[0][-1] != 4:  # n_gates
+            return self.inner.aggregate_batch(sweeps)
+        # An event bracket also contains the dispatch/event overhead of the launch (3-6 us in eager
+        # mode), which rocprofv3's kernel durations do not.  It is calibrated right behind the
+        # sweep on a kernel that is too small to care about cache state: a [1 launch] and a
+        # [2 launches] bracket of it differ by exactly its duration, what is left of the first
+        # bracket is the overhead.  (Differencing the sweep itself would time a re-run whose
+        # operands the first run left in the 256 MB MALL.)
+        e0, e1, c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
         e0.record()
-        self.inner.aggregate(*args)
+        self.inner.aggregate_batch(sweeps)
         e1.record()
-        self.inner.aggregate(*args)
-        self.inner.aggregate(*args)
-        e2.record()
-        self.events.append((e0, e1, e2, algorithmic_bytes(p_src.size(0), p_dst.size(0), csr.E, 4)))
+        c0.record()
+        self.null.zero_()
+        c1.record()
+        self.null.zero_()
+        self.null.zero_()
+        c2.record()
+        nbytes = sum(algorithmic_bytes(sw[2].size(0), sw[3].size(0), sw[0].E, 4) for sw in sweeps)
+        self.events.append((e0, e1, c0, c1, c2, nbytes, len(sweeps)))
 
 
 def measure_roofline(ro, n_steps):
-    """Average duration of aggregate_kernel<4, true> launches inside real rollout steps (eager
-    launches, regressor and classifier serialised so that no other kernel shares the chip
-    with the launch being timed; HIP events on the launch stream, dispatch latency removed by
-    differencing a one-launch and a two-launch bracket)."""
+    """Average duration of the aggregate_kernel<4, true> launches inside real rollout steps
+    (eager launches, regressor and classifier serialised so that no other kernel shares the chip
+    with the launch being timed; HIP events on the launch stream, minus the bracket overhead
+    calibrated on a null kernel)."""
     timed = EventTimedBackend(ro.be)
+    timed.null = torch.zeros(64, device="cuda")
     ro.be, side = timed, ro._side
     ro._side = None
     try:
@@ -96,16 +103,21 @@ def measure_roofline(ro, n_steps):
         torch.cuda.synchronize()
     finally:
         ro.be, ro._side = timed.inner, side
-    ms = [b.elapsed_time(c) - a.elapsed_time(b) for a, b, c, _ in timed.events]
-    bracket = float(np.mean([a.elapsed_time(b) for a, b, _, _ in timed.events])) * 1e3
-    avg_bytes = float(np.mean([ev[3] for ev in timed.events]))  # per launch, as launched
-    avg_s = float(np.mean(ms)) * 1e-3
-    achieved = avg_bytes / avg_s / 1e9
+    if not timed.events:
+        return None
+    bracket = np.array([ev[0].elapsed_time(ev[1]) for ev in timed.events]) * 1e3
+    null1 = np.array([ev[2].elapsed_time(ev[3]) for ev in timed.events]) * 1e3
+    null2 = np.array([ev[3].elapsed_time(ev[4]) for ev in timed.events]) * 1e3
+    overhead = float(np.median(null1 - (null2 - null1)))     # bracket minus the null kernel itself
+    avg_us = float(np.mean(bracket)) - overhead
+    avg_bytes = float(np.mean([ev[5] for ev in timed.events]))  # per launch, as launched
+    achieved = avg_bytes / avg_us / 1e3
     return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(), "avg_launch_us": round(avg_s * 1e6, 2),
-            "single_launch_event_bracket_us": round(bracket, 2),
-            "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(ms)}
+            "traffic": pmc_traffic(), "avg_launch_us": round(avg_us, 2),
+            "event_bracket_us": round(float(np.mean(bracket)), 2), "bracket_overhead_us": round(overhead, 2),
+            "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(bracket),
+            "sweeps_per_launch": round(float(np.mean([ev[6] for ev in timed.events])), 2)}
 
 
 def pmc_traffic():

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 10
+GGNN_ABI_VERSION = 11
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -24,7 +24,8 @@ MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
-    "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
+    "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate",
+    "ggnn_period_gat_aggregate_batch", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -105,6 +106,8 @@ def _declare(lib):
                                  c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
     lib.ggnn_period_gat_aggregate.restype = c_int
     lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
+    lib.ggnn_period_gat_aggregate_batch.restype = c_int
+    lib.ggnn_period_gat_aggregate_batch.argtypes = [POINTER(AggregateArgs), c_int, c_void_p]
     lib.ggnn_lstm_epilogue.restype = c_int
     lib.ggnn_lstm_epilogue.argtypes = [POINTER(EpilogueArgs), c_void_p]
     lib.ggnn_heads_regressor.restype = c_int

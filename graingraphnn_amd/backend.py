@@ -91,12 +91,10 @@ class HipBackend:
                                     _lib.current_stream()), "ggnn_project")
 
     # -- aggregation -------------------------------------------------------------------
-    def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
-                  a_gstride, sc_off, n_gates):
-        """One sweep of ggnn_period_gat_aggregate (include/ggnn.h).  h_src: the source node type's
-        hidden state [n_src, 96] or None (encoder)."""
+    @staticmethod
+    def _sweep_args(a, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+                    a_gstride, sc_off, n_gates):
         _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, h_src, ep, agg)
-        a = AggregateArgs()
         a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
         a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
         a.h_src = None if h_src is None else h_src.data_ptr()
@@ -106,8 +104,24 @@ class HipBackend:
         a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), csr.E
         a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
+
+    def aggregate(self, *sweep):
+        """One sweep of ggnn_period_gat_aggregate (include/ggnn.h): (csr, einfo, p_src, p_dst, h_src,
+        ep, agg, v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates).  h_src: the source node
+        type's hidden state [n_src, 96] or None (encoder)."""
+        a = AggregateArgs()
+        self._sweep_args(a, *sweep)
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),
               "ggnn_period_gat_aggregate")
+
+    def aggregate_batch(self, sweeps):
+        """The 1..3 sweeps of one cell in one launch (ggnn_period_gat_aggregate_batch); each item
+        is the argument tuple of `aggregate`."""
+        arr = (AggregateArgs * len(sweeps))()
+        for a, sweep in zip(arr, sweeps):
+            self._sweep_args(a, *sweep)
+        check(self.lib.ggnn_period_gat_aggregate_batch(arr, len(sweeps), _lib.current_stream()),
+              "ggnn_period_gat_aggregate_batch")
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,

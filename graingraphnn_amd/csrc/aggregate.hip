@@ -51,18 +51,23 @@
 // descriptor prefetch 41 us; v7 projected keys gathered per gate 31 us; v12 key-free, two gates per
 // wave 31 us, the same with two units in flight 32 us; a fused encoder sweep recomputing
 // K0 / V0 / Q per edge from feature rows: VALU-bound, slower.)
+#include <algorithm>
+
 #include "common.h"
 
 namespace ggnn {
 
 #ifndef AG_VAR_BPC
-#define AG_VAR_BPC 5
+#define AG_VAR_BPC 3
 #endif
-constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;  // resident workgroups per CU (98 VGPRs -> 5 waves per SIMD)
+// Workgroups per CU of the persistent grid (measured on the batched launch, cfg3: 2 -> 80 us,
+// 3 -> 70, 4 -> 72, 5 -> 76: fewer streams keep the sliding window of rows, and with it the
+// re-reads of source rows, inside the XCD's L2; 116 VGPRs allow 4 waves per SIMD)
+constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;
 #ifndef AG_VAR_BPC_NOH
-#define AG_VAR_BPC_NOH 7
+#define AG_VAR_BPC_NOH 6
 #endif
-constexpr int AG_BLOCKS_PER_CU_NOH = AG_VAR_BPC_NOH;  // encoder sweep (no hidden rows): ~72 VGPRs
+constexpr int AG_BLOCKS_PER_CU_NOH = AG_VAR_BPC_NOH;  // encoder sweep (no hidden rows, 78 VGPRs): 4 -> 47.5 us, 5 -> 46.5, 6 -> 46, 7 -> 51
 constexpr int AG_NUM_CU = 256;
 constexpr int UE = GGNN_UNIT_EDGES;
 
@@ -139,8 +144,21 @@ typedef const int __attribute__((address_space(4))) * const_i32_ptr;
 
 constexpr int AG_WAVES = 4;  // independent row streams per workgroup
 
+// Up to three sweeps of one cell in one launch: every workgroup walks its rows of sweep 0, then
+// of sweep 1, ... (no barrier in between: a stream that runs out of rows moves on, so the tail
+// of one sweep is filled by the head of the next, and a cell pays one launch instead of three).
+struct AggregateBatch {
+  ggnn_aggregate_args a[3];
+  int n;
+};
+
 template <int G, bool HAS_H>
-__global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_args A) {
+#ifdef AG_VAR_LB
+__global__ __launch_bounds__(256, HAS_H ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH)
+#else
+__global__ __launch_bounds__(256)
+#endif
+void aggregate_kernel(const AggregateBatch B) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = (tid >> 4) & 3;     // the gate of this 16-lane row
@@ -164,10 +182,12 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
   const int ngrp = min(nblk, 8);
   const int grp = blockIdx.x % ngrp, lb = blockIdx.x / ngrp;
   const int nb_grp = (nblk - grp + ngrp - 1) / ngrp;            // workgroups in this group
+  for (int k = 0; k < B.n; ++k) {
+  const ggnn_aggregate_args& A = B.a[k];
   const int64_t x_lo = A.n_dst * grp / ngrp, x_hi = A.n_dst * (grp + 1) / ngrp;
   const int64_t n_streams = (int64_t)nb_grp * AG_WAVES;
   int64_t r = x_lo + (int64_t)lb * AG_WAVES + wave;
-  if (r >= x_hi) return;
+  if (r >= x_hi) continue;
 #ifdef AG_VAR_EXIT_EARLY
   if (A.n_gates > 0) return;
 #endif
@@ -328,6 +348,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const ggnn_aggregate_arg
 #pragma unroll
     for (int t = 0; t < UE; ++t) ed[t] = edn[t];
   }
+  }  // sweeps of the batch
 }
 
 }  // namespace ggnn
@@ -359,10 +380,9 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
   return launch_status();
 }
 
-extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream) {
-  using namespace ggnn;
-  if (!args) return GGNN_EINVAL;
-  ggnn_aggregate_args A = *args;
+namespace ggnn {
+// Argument checks of one sweep; normalises the encoder form (h_src == NULL).
+static int check_sweep(ggnn_aggregate_args& A) {
   if (!A.unit_ptr || !A.units || !A.einfo || !A.p_src || !A.p_dst || !A.edge_params || !A.agg)
     return GGNN_EINVAL;
   if (!aligned16(A.units) || !aligned16(A.einfo)) return GGNN_EINVAL;
@@ -384,19 +404,42 @@ extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_s
   if (has_h && A.u_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
+  return GGNN_OK;
+}
+}  // namespace ggnn
+
+extern "C" int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,
+                                               ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_sweeps < 1 || n_sweeps > 3) return GGNN_EINVAL;
+  AggregateBatch B;
+  B.n = n_sweeps;
+  const int G = args[0].n_gates;
+  const bool has_h = args[0].h_src != nullptr;
+  int64_t want = 1;
+  for (int k = 0; k < 3; ++k) {
+    B.a[k] = args[k < n_sweeps ? k : 0];
+    if (B.a[k].n_gates != G || (B.a[k].h_src != nullptr) != has_h) return GGNN_EINVAL;
+    const int rc = check_sweep(B.a[k]);
+    if (rc != GGNN_OK) return rc;
+    want = std::max<int64_t>(want, (B.a[k].n_dst + 3) / 4);
+  }
   // persistent grid: at least 4 rows per workgroup, at most the resident capacity
-  const int64_t want = (A.n_dst + 3) / 4;
   const int64_t cap = (int64_t)AG_NUM_CU * (has_h ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH);
   const dim3 grid((unsigned)(want < cap ? want : cap));
   hipStream_t s = (hipStream_t)stream;
 #define GGNN_AG_LAUNCH(G_)                                                                   \
   do {                                                                                       \
-    if (has_h) hipLaunchKernelGGL((aggregate_kernel<G_, true>), grid, dim3(256), 0, s, A);   \
-    else hipLaunchKernelGGL((aggregate_kernel<G_, false>), grid, dim3(256), 0, s, A);        \
+    if (has_h) hipLaunchKernelGGL((aggregate_kernel<G_, true>), grid, dim3(256), 0, s, B);   \
+    else hipLaunchKernelGGL((aggregate_kernel<G_, false>), grid, dim3(256), 0, s, B);        \
   } while (0)
   if (G == 4) GGNN_AG_LAUNCH(4);
   else if (G == 3) GGNN_AG_LAUNCH(3);
   else GGNN_AG_LAUNCH(1);
 #undef GGNN_AG_LAUNCH
   return launch_status();
+}
+
+extern "C" int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream) {
+  return ggnn_period_gat_aggregate_batch(args, 1, stream);
 }

@@ -1,9 +1,9 @@
 """Launch plan of one model forward on the HIP kernels.
 
 One HeteroPGCLSTM cell (heteropgclstm.py:148-183: 4 gates x 3 PeriodConv + LSTM update) is
-2 projection GEMMs + 3 aggregation sweeps + 2 gate-GEMM/LSTM epilogues = 7 launches; a
+2 projection GEMMs + 1 launch of 3 aggregation sweeps + 2 gate-GEMM/LSTM epilogues = 5 launches; a
 model forward (edge geometry, encoder cell with h = c = 0, decoder cell, heads;
-models.py:422-452, 581-609) is 16-17 launches instead of the ~600 framework kernels the reference issues.
+models.py:422-452, 581-609) is 12-13 launches instead of the ~600 framework kernels the reference issues.
 """
 from typing import Dict, Optional, Tuple
 
@@ -114,13 +114,15 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
         backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
     if after_project is not None:
         after_project()
-    for et in EDGE_TYPES:  # 3 aggregation sweeps (fewer when a destination type is dead)
+    sweeps = []  # 3 aggregation sweeps (fewer when a destination type is dead), one launch
+    for et in EDGE_TYPES:
         s, d = et[0], et[-1]
         if not lay[d].live:
             continue
-        backend.aggregate(graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
-                          pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
-                          lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G)
+        sweeps.append((graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
+                       pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
+                       lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
+    backend.aggregate_batch(sweeps)
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
     for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
         if not lay[nt].live:

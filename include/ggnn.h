@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 10
+#define GGNN_ABI_VERSION 11
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -151,6 +151,11 @@ typedef struct ggnn_aggregate_args {
   int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
+/* The 1..3 sweeps of one cell (HeteroConv over the edge types, heteropgclstm.py:148-183) in ONE
+ * launch: args[0..n_sweeps).  All must have the same n_gates and agree on h_src == NULL; they may
+ * write disjoint columns of the same agg rows.  Same result as n_sweeps single calls. */
+int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,
+                                    ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:

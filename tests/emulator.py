@@ -51,6 +51,10 @@ class TorchEmulatorBackend:
             xin[:, Fp:] = h
         out[:, :wp.size(0)] = xin @ wp.t() + bp
 
+    def aggregate_batch(self, sweeps):
+        for sweep in sweeps:
+            self.aggregate(*sweep)
+
     def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
                   a_gstride, sc_off, n_gates):
         rowptr, col = csr.rowptr.long(), csr.col.long()

@@ -51,6 +51,9 @@ class Timed:
             return f"M={a[0].size(0)} K={a[3].size(1)} N={a[3].size(0)}"
         if name == "aggregate":
             return f"n_dst={a[3].size(0)} n_src={a[2].size(0)} G={a[-1]}"
+        if name == "aggregate_batch":
+            return f"sweeps={len(a[0])} G={a[0][0][-1]} bytes=" + str(sum(
+                alg_bytes(sw[2].size(0), sw[3].size(0), sw[0].E, sw[-1]) for sw in a[0]))
         if name == "lstm_epilogue":
             return f"N={a[0].size(0)} Ka={a[1].size(2)} G={a[8]}"
         return ""
@@ -60,9 +63,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--tile", type=int, default=0, help="renumber the nodes in tiles of this many cells (experiment)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     x, ei, ea = synthetic.honeycomb(args.n, 10, 0)
+    if args.tile:
+        inv = {}
+        for nt in NODE_TYPES:
+            xy = x[nt][:, :2]
+            g = 1.0 / args.tile  # tiles of g x g of the unit square, row-major inside a tile
+            tx, ty = np.floor(xy[:, 0] / g).astype(np.int64), np.floor(xy[:, 1] / g).astype(np.int64)
+            key = np.lexsort((xy[:, 0], xy[:, 1], tx, ty))
+            inv[nt] = np.empty(len(key), np.int64)
+            inv[nt][key] = np.arange(len(key))
+            x[nt] = x[nt][key]
+        for et in list(ei):
+            ei[et] = np.stack([inv[et[0]][ei[et][0]], inv[et[-1]][ei[et][1]]])
     R = load_seeded(GrainNN_regressor(synthetic.default_hyper(dev)), 0, 0.3).eval().to(dev)
     X, EI, EA = synthetic.to_torch(x, ei, ea, dev)
     be = Timed(default_backend())
@@ -94,6 +110,9 @@ def main():
                 G = int(tag.split("G=")[1])
                 b = alg_bytes(n_nodes[et[0]], n_nodes[et[-1]], E[et], G)
                 rate = f"{b / med / 1e3:8.0f} GB/s algorithmic ({b / 1e6:.1f} MB) {et[0][0]}->{et[-1][0]}"
+            elif name == "aggregate_batch":
+                b = int(tag.split("bytes=")[1])
+                rate = f"{b / med / 1e3:8.0f} GB/s algorithmic ({b / 1e6:.1f} MB)"
             elif name == "project":
                 M, K, N = (int(s.split("=")[1]) for s in tag.split())
                 rate = f"{2 * M * K * N / med / 1e6:8.1f} TFLOP/s, {4 * M * N / med / 1e3:6.0f} GB/s written"

@@ -4,7 +4,8 @@
 On the GPU box (one counter group per pass; rocprofv3 must be followed directly by the program):
     for g in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
              "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-        rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/pmc/$i -- python3 tools/kbench.py --reps 5
+        rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/pmc/$i -- \
+            python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --serial
     done
 then here:  python tools/pmc_aggregate.py gpurun_out/pmc profiles/r1_pmc_aggregate.json
 """
@@ -33,7 +34,9 @@ def main(root, out):
     writes = 64 * m("TCC_EA0_WRREQ_64B_sum") + 32 * (m("TCC_EA0_WRREQ_sum") - m("TCC_EA0_WRREQ_64B_sum"))
     doc = {
         "kernel": "ggnn::" + KERNEL,
-        "workload": "cfg3 decoder sweeps (g->j, j->g, j->j averaged), tools/kbench.py --reps 5 under rocprofv3 "
+        "workload": "cfg3 decoder-cell sweep launches of bench.py (regressor: g->j, j->g, j->j in one launch; "
+                    "classifier: g->j, j->j; averaged over the launches as bench.py's roofline does), "
+                    "bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --serial under rocprofv3 "
                     "--kernel-trace --pmc <one group per pass>",
         "counters": c,
         "read_bytes_per_launch": reads, "write_bytes_per_launch": writes,
@@ -43,7 +46,7 @@ def main(root, out):
         "method": "HBM-side bytes = 128*TCC_EA0_RDREQ_128B + 64*TCC_EA0_RDREQ_64B + 32*TCC_EA0_RDREQ_32B (reads) + "
                   "64*TCC_EA0_WRREQ_64B + 32*(TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) (writes); FETCH_SIZE doubled per "
                   "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B) is the cross-check",
-        "algorithmic_bytes_per_launch": (93720004 + 93360004 + 124560004) / 3,
+        "algorithmic_bytes_per_launch": ((93720004 + 93360004 + 124560004) + (93720004 + 124560004)) / 2,
     }
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
