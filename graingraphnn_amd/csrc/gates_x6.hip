@@ -89,7 +89,11 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
   for (int t = 0; t < T; ++t)
     m0[t] = min(min(((int64_t)range * T + t) * GX_WAVES + wave, n_mt - 1) * GX_BM, m_last);
 
+#ifdef GX_VAR_NOSPLIT  // timing experiment only: `agg` taken as if it already were three bf16 planes
+  f32x4 raw[GX_DEPTH][3];
+#else
   f32x4 raw[GX_DEPTH][2];
+#endif
   auto load_step = [&](int gs) {  // global step -> (tile, gate, k-step); nothing here uses a loaded value
     const int t = gs / NSTEP, st = gs % NSTEP, g = st / NKS, ks = st % NKS;
 #ifdef GX_VAR_COALESCED  // timing experiment only (wrong lane <-> data assignment)
@@ -97,8 +101,18 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
 #else
     const float* a = A.agg + (m0[t] + row_l) * ld_agg + g * gs_ + 32 * ks + 8 * kq;
 #endif
+#ifdef GX_VAR_BLOCKED  // timing experiment only: a step's fragment as 2 KB of contiguous memory
+    const float* ab = A.agg + m0[t] * ld_agg + st * 512 + lane * 4;
+    raw[gs % GX_DEPTH][0] = *reinterpret_cast<const f32x4*>(ab);
+    raw[gs % GX_DEPTH][1] = *reinterpret_cast<const f32x4*>(ab + 256);
+    (void)a;
+#else
     raw[gs % GX_DEPTH][0] = *reinterpret_cast<const f32x4*>(a);  // default cache policy: the other
     raw[gs % GX_DEPTH][1] = *reinterpret_cast<const f32x4*>(a + 4);  // two slices find these lines in L2
+#endif
+#ifdef GX_VAR_NOSPLIT
+    raw[gs % GX_DEPTH][2] = *reinterpret_cast<const f32x4*>(a + 8);
+#endif
   };
 #pragma unroll
   for (int gs = 0; gs < GX_DEPTH && gs < T * NSTEP; ++gs) load_step(gs);
@@ -130,6 +144,12 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
     }
     // split this step's fragment, then reuse its ring slot for the step GX_DEPTH ahead
     u32x4 xb[3];
+#ifdef GX_VAR_NOSPLIT
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) xb[q][d] = __float_as_uint(raw[gs % GX_DEPTH][q][d]);
+#else
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       uint32_t p0, p1, p2;
@@ -138,6 +158,7 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
       xb[1][d] = p1;
       xb[2][d] = p2;
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);  // pin the issue point: hipcc otherwise sinks or bunches the ring loads
     if (gs + GX_DEPTH < T * NSTEP) load_step(gs + GX_DEPTH);
     __builtin_amdgcn_sched_barrier(0);

@@ -655,3 +655,61 @@ def test_row_strided_inputs():
         assert torch.equal(ya[k], yb[k])
     ca, cb = Cm(X, EI, EA), Cm(Xs, EI, EA)
     assert torch.equal(ca["edge_event"], cb["edge_event"])
+
+
+class _OneSweepPerLaunch:
+    """The HIP backend with ggnn_period_gat_aggregate_batch replaced by single-sweep launches."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def aggregate_batch(self, sweeps):
+        for sweep in sweeps:
+            self.inner.aggregate(*sweep)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("which", ["40", "cfg3"])
+def test_batched_sweeps_equal_single_launches(which):
+    """ggnn_period_gat_aggregate_batch == its sweeps launched one by one, bit for bit (row order
+    inside a sweep does not enter any sum), and it refuses sweeps that disagree on n_gates / h."""
+    from graingraphnn_amd import engine
+    from graingraphnn_amd.packing import NODE_TYPES
+    if which == "40":
+        x, ei, ea = load_graph("40")
+    else:
+        x, ei, ea = synthetic.honeycomb(100, 10, 0)
+    R, _ = product_models(3, 0.5, DEV)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    be = backend()
+    n_nodes = {nt: X[nt].size(0) for nt in NODE_TYPES}
+    graph = engine.graph_for(be, EI, n_nodes)
+    enc = R.gclstm_encoder.cell_list[0].packed(True)
+    dec = R.gclstm_decoder.cell_list[0].packed(False)
+    out = []
+    for b in (be, _OneSweepPerLaunch(be)):
+        ws = engine.Workspace(enc, dec, n_nodes, DEV)
+        h, c = engine.run_encoder_decoder(b, enc, dec, graph, ws, X, EA)
+        torch.cuda.synchronize()
+        out.append((ws, {nt: h[nt].clone() for nt in NODE_TYPES}))
+    for nt in NODE_TYPES:
+        assert torch.equal(out[0][0].agg_enc[nt], out[1][0].agg_enc[nt])
+        assert torch.equal(out[0][0].agg_dec[nt], out[1][0].agg_dec[nt])
+        assert torch.equal(out[0][1][nt], out[1][1][nt])
+    # argument checks of the batch entry
+    ws = out[0][0]
+    lay = dec.layout
+    sw = [(graph.csr[et], ws.einfo[et], ws.proj[et[0]], ws.proj[et[-1]], ws.h1[et[0]], dec.ep[et],
+           ws.agg_dec[et[-1]], lay[et[0]].v_off[et], lay[et[-1]].u_off.get(et, 0), lay[et[-1]].u4_off[et],
+           lay[et[-1]].a_off[et], lay[et[-1]].Kg, lay[et[-1]].sc_off[et], dec.G) for et in EDGE_TYPES]
+    with pytest.raises(_lib.GGNNError):
+        be.aggregate_batch([sw[0], sw[1][:4] + (None,) + sw[1][5:]])   # h_src given / absent
+    with pytest.raises(_lib.GGNNError):
+        be.aggregate_batch([sw[0], sw[1][:-1] + (3,)])                  # n_gates differ
+    with pytest.raises(_lib.GGNNError):
+        be.aggregate_batch(sw + sw[:1])                                 # more than three sweeps
+    with pytest.raises(_lib.GGNNError):
+        be.aggregate_batch([])
