@@ -273,6 +273,16 @@ def main():
 
     if rank == 0:
         roof = measure_roofline(ro, 10)
+        # forward-only rate beside the full step (eager launches, R then C on one stream)
+        with torch.no_grad():
+            for _ in range(5):
+                R(X, EI, EA), Cm(X, EI, EA)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(100):
+                R(X, EI, EA), Cm(X, EI, EA)
+            torch.cuda.synchronize()
+            forward_only = 100 / (time.perf_counter() - tf)
         line = {
             "metric": "rollout steps/sec (10k-grain heterograph)",
             "value": round(units_per_step * args.steps / dt, 2),
@@ -291,6 +301,7 @@ def main():
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
                        "results_finite": finite,
+                       "forward_only_steps_per_s_per_gpu": round(forward_only * (units_per_step // world), 2),
                        **({"events": {"grains_eliminated": int(sum(len(e) for e in ro.grain_events)),
                                       "edges_switched": int(sum(len(e) for e in ro.switched)),
                                       "edges_left": int(ro.edge_index[("joint", "connect", "joint")].size(1)),

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box (gpurun -- bash tools/profile_round.sh): PMC passes for
+# tools/pmc_aggregate.py, the rocprofv3 kernel-stats profiles kept under profiles/, and a default bench line.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 600 python3 -m pytest tests -m gpu -x -q -k "batched_sweeps or golden" 2>&1 | tail -2
