@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 11
+GGNN_ABI_VERSION = 12
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate",
-    "ggnn_period_gat_aggregate_batch", "ggnn_lstm_epilogue", "ggnn_heads_regressor",
+    "ggnn_period_gat_aggregate_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
+    "ggnn_lstm_epilogue", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -56,6 +57,23 @@ class AggregateArgs(Structure):
         ("edge_params", c_void_p), ("agg", c_void_p),
         ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
         ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
+        ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
+        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
+    ]
+
+
+class AggregateBwdArgs(Structure):
+    """Mirror of `ggnn_aggregate_bwd_args`."""
+    _fields_ = [
+        ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p),
+        ("p_src", c_void_p), ("p_dst", c_void_p), ("h_src", c_void_p),
+        ("edge_params", c_void_p), ("agg", c_void_p), ("g_agg", c_void_p),
+        ("r_rowptr", c_void_p), ("r_dst", c_void_p), ("r_slot", c_void_p),
+        ("edge_alpha", c_void_p), ("edge_ds", c_void_p), ("ep_partial", c_void_p),
+        ("g_p_dst", c_void_p), ("g_p_src", c_void_p), ("g_h_src", c_void_p),
+        ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
+        ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
+        ("n_partials", c_int64),
         ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
         ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
     ]
@@ -108,6 +126,10 @@ def _declare(lib):
     lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
     lib.ggnn_period_gat_aggregate_batch.restype = c_int
     lib.ggnn_period_gat_aggregate_batch.argtypes = [POINTER(AggregateArgs), c_int, c_void_p]
+    lib.ggnn_aggregate_bwd_partials.restype = c_int64
+    lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
+    lib.ggnn_period_gat_aggregate_backward.restype = c_int
+    lib.ggnn_period_gat_aggregate_backward.argtypes = [POINTER(AggregateBwdArgs), c_void_p]
     lib.ggnn_lstm_epilogue.restype = c_int
     lib.ggnn_lstm_epilogue.argtypes = [POINTER(EpilogueArgs), c_void_p]
     lib.ggnn_heads_regressor.restype = c_int

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AggregateArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
+from ._lib import AggregateArgs, AggregateBwdArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
 
 
 class CSR:
@@ -122,6 +122,41 @@ class HipBackend:
             self._sweep_args(a, *sweep)
         check(self.lib.ggnn_period_gat_aggregate_batch(arr, len(sweeps), _lib.current_stream()),
               "ggnn_period_gat_aggregate_batch")
+
+    def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates):
+        """ggnn_period_gat_aggregate_backward (include/ggnn.h).  `rcsr`: CSR of the flipped
+        edge_index (grouped by source), `r_slot` [E] int32: forward CSR slot of every reverse slot.
+        Returns (g_p_dst, g_p_src, g_h_src or None, g_ep [n_gates, 3, 96]); the gradient tensors
+        have the layout of their operands, columns the sweep does not read are zero."""
+        _require_cuda(csr.rowptr, rcsr.rowptr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg)
+        dev = p_src.device
+        E, G = csr.E, n_gates
+        a = AggregateBwdArgs()
+        a.rowptr, a.col, a.einfo = csr.rowptr.data_ptr(), csr.col.data_ptr(), einfo.data_ptr()
+        a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
+        a.h_src = None if h_src is None else h_src.data_ptr()
+        a.edge_params, a.agg, a.g_agg = ep.data_ptr(), agg.data_ptr(), g_agg.data_ptr()
+        a.r_rowptr, a.r_dst, a.r_slot = rcsr.rowptr.data_ptr(), rcsr.col.data_ptr(), r_slot.data_ptr()
+        if agg.stride(0) != g_agg.stride(0) or agg.shape != g_agg.shape:
+            raise _lib.GGNNError("g_agg must have the layout of agg")
+        n_part = self.lib.ggnn_aggregate_bwd_partials(p_dst.size(0))
+        f32 = dict(dtype=torch.float32, device=dev)
+        scratch = torch.empty(2, max(E, 1) * G, **f32)
+        ep_partial = torch.empty(n_part, G, _lib.GGNN_EDGE_PARAM_ROWS, 96, **f32)
+        g_p_dst, g_p_src = torch.zeros_like(p_dst), torch.zeros_like(p_src)
+        g_h_src = None if h_src is None else torch.empty_like(h_src)
+        a.edge_alpha, a.edge_ds, a.ep_partial = scratch[0].data_ptr(), scratch[1].data_ptr(), ep_partial.data_ptr()
+        a.g_p_dst, a.g_p_src = g_p_dst.data_ptr(), g_p_src.data_ptr()
+        a.g_h_src = None if g_h_src is None else g_h_src.data_ptr()
+        a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
+        a.ldh_src = 0 if h_src is None else h_src.stride(0)
+        a.n_src, a.n_dst, a.E, a.n_partials = p_src.size(0), p_dst.size(0), E, n_part
+        a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
+            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
+        check(self.lib.ggnn_period_gat_aggregate_backward(ctypes.byref(a), _lib.current_stream()),
+              "ggnn_period_gat_aggregate_backward")
+        return g_p_dst, g_p_src, g_h_src, ep_partial.sum(0)
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,

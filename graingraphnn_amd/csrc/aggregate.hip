@@ -73,15 +73,6 @@ constexpr int UE = GGNN_UNIT_EDGES;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// Sum over the 16 lanes of a DPP row, result in every lane of the row (four v_add_f32 with DPP).
-__device__ __forceinline__ float row_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------
 // edge_prepare: the 20-float record of every edge, in CSR order (GGNN_EINFO_ROW floats):
 //   [0..15]  tail of the score dot product: reloc_xyz, x_src[3 .. f_src), 0.., 1 @12, a_e @13, 0, 0

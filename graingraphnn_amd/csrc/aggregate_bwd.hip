@@ -1,0 +1,249 @@
+// Backward of the periodic-boundary GAT aggregation sweep (training path): the
+// gradient of ggnn_period_gat_aggregate with respect to its floating-point operands.  Replaces
+// what autograd does for PeriodConv.message + PyG propagate (periodGATconv.py:174-175, 204-236):
+// segment-softmax backward, the relu mask, scatter of the value gradient to the source rows.
+//
+// Forward, per destination i, gate g, in-edge e (source j):
+//   s_e = u4_i . x4_e + u_h,i . h_j          alpha_e = exp(s_e - max) / (sum + 1e-16)
+//   val_e = relu(V_j + W3 r_e)               out_i = sum alpha_e val_e
+//   den_i = sum alpha_e                      sae_i = sum alpha_e a_e
+// Backward, given (g_out, g_den, g_sae) per destination and gate:
+//   dalpha_e = g_out . val_e + g_den + g_sae a_e
+//   ds_e     = alpha_e (dalpha_e - S_i),  S_i = sum_e alpha_e dalpha_e = g_out . out_i + g_den den_i + g_sae sae_i
+//                                         (taken from the saved forward output: no extra pass)
+//   du4_i   += ds_e x4_e      du_h,i += ds_e h_j      dh_j += ds_e u_h,i  (summed over gates)
+//   dV_j    += alpha_e g_out [val_e > 0]              dW3  += (alpha_e g_out [val_e > 0]) r_e^T
+//
+// Two atomics-free passes, both with the forward sweep's lane layout (a 16-lane row per gate,
+// channels ch..ch+2 and 48+ch..48+ch+2 per lane):
+//   dst pass  one wave per destination row (grid-stride): recomputes the scores (online max and
+//             sum, then the gradients), writes the destination-side gradients, the per-edge
+//             (alpha, ds) records and this wave's partial sum of dW3 (reduced by the caller:
+//             a fixed grid, so the result is reproducible);
+//   src pass  one wave per source row over the REVERSE (source-grouped) CSR: gathers the
+//             destination rows' g_out / u_h and the edge records, writes dV_j and dh_j.
+// First correct version: one edge per iteration, no unit table, no prefetch.
+#include "common.h"
+
+namespace ggnn {
+
+constexpr int AB_WAVES = 4;
+
+struct BwdLane {
+  int wave, g, gc, l16, ch;
+  bool active;
+};
+
+template <int G>
+__device__ __forceinline__ BwdLane bwd_lane() {
+  BwdLane L;
+  const int tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  L.g = (tid >> 4) & 3;
+  L.active = L.g < G;
+  L.gc = L.active ? L.g : 0;
+  L.l16 = tid & 15;
+  L.ch = 3 * L.l16;
+  return L;
+}
+
+__device__ __forceinline__ void ld6(const float* p, float (&v)[6]) {
+  const f3 a = ld3(p), b = ld3(p + C / 2);
+  v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = b.x, v[4] = b.y, v[5] = b.z;
+}
+__device__ __forceinline__ void st6(float* p, const float (&v)[6]) {
+  st3(p, {v[0], v[1], v[2]});
+  st3(p + C / 2, {v[3], v[4], v[5]});
+}
+
+template <int G, bool HAS_H>
+__global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggregate_bwd_args A) {
+  const BwdLane L = bwd_lane<G>();
+  const int64_t w = (int64_t)blockIdx.x * AB_WAVES + L.wave, n_w = (int64_t)gridDim.x * AB_WAVES;
+  float wv[6][3];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const float* e = A.edge_params + L.gc * GGNN_EDGE_PARAM_ROWS * C + L.ch + (c < 3 ? c : C / 2 + c - 3);
+    wv[c][0] = e[0], wv[c][1] = e[C], wv[c][2] = e[2 * C];
+  }
+  float dwv[6][3] = {};
+  for (int64_t i = w; i < A.n_dst; i += n_w) {
+    const int beg = A.rowptr[i], end = A.rowptr[i + 1];
+    float uh[6] = {}, u4 = 0.f, go[6] = {}, out[6] = {}, gden = 0.f, gsae = 0.f, oden = 0.f, osae = 0.f;
+    if (L.active) {
+      const float* pd = A.p_dst + i * A.ldp_dst;
+      if (HAS_H) ld6(pd + A.u_off + L.gc * C + L.ch, uh);
+      u4 = pd[A.u4_off + L.gc * 16 + L.l16];
+      const int64_t o = i * A.ld_agg + (int64_t)L.gc * A.a_gstride;
+      ld6(A.g_agg + o + A.a_off + L.ch, go);
+      ld6(A.agg + o + A.a_off + L.ch, out);
+      gden = A.g_agg[o + A.sc_off], gsae = A.g_agg[o + A.sc_off + 1];
+      oden = A.agg[o + A.sc_off], osae = A.agg[o + A.sc_off + 1];
+    }
+    // scores: online max and sum
+    float mx = -INFINITY, den = 0.f;
+    for (int p = beg; p < end; ++p) {
+      const int64_t j = A.col[p];
+      float part = u4 * A.einfo[(int64_t)p * GGNN_EINFO_ROW + L.l16];
+      if (HAS_H) {
+        float h[6];
+        ld6(A.h_src + j * A.ldh_src + L.ch, h);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) part += uh[c] * h[c];
+      }
+      const float s = row_sum(part);
+      const float mn = fmaxf(mx, s);
+      den = den * __expf(mx - mn) + __expf(s - mn);
+      mx = mn;
+    }
+    const float inv = 1.0f / (den + 1e-16f);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dot += go[c] * out[c];
+    const float S = row_sum(dot) + gden * oden + gsae * osae;
+    float du4 = 0.f, duh[6] = {};
+    for (int p = beg; p < end; ++p) {
+      const int64_t j = A.col[p];
+      const float* rec = A.einfo + (int64_t)p * GGNN_EINFO_ROW;
+      const float x4 = rec[L.l16], rx = rec[16], ry = rec[17], rz = rec[18], ae = rec[19];
+      float h[6] = {}, v[6];
+      if (HAS_H) ld6(A.h_src + j * A.ldh_src + L.ch, h);
+      ld6(A.p_src + j * A.ldp_src + A.v_off + L.gc * C + L.ch, v);
+      float part = u4 * x4;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) part += uh[c] * h[c];
+      const float alpha = __expf(row_sum(part) - mx) * inv;
+      float gv[6], dpart = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float val = v[c] + wv[c][0] * rx + wv[c][1] * ry + wv[c][2] * rz;
+        gv[c] = val > 0.f ? go[c] : 0.f;  // g_out masked by the relu
+        dpart += gv[c] * val;
+      }
+      const float dalpha = row_sum(dpart) + gden + gsae * ae;
+      const float ds = alpha * (dalpha - S);
+      du4 += ds * x4;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        duh[c] += ds * h[c];
+        const float t = alpha * gv[c];
+        dwv[c][0] += t * rx, dwv[c][1] += t * ry, dwv[c][2] += t * rz;
+      }
+      if (L.active && L.l16 == 0) {
+        A.edge_alpha[(int64_t)p * G + L.g] = alpha;
+        A.edge_ds[(int64_t)p * G + L.g] = ds;
+      }
+    }
+    if (L.active) {
+      float* gd = A.g_p_dst + i * A.ldp_dst;
+      gd[A.u4_off + L.g * 16 + L.l16] = du4;
+      if (HAS_H) st6(gd + A.u_off + L.g * C + L.ch, duh);
+    }
+  }
+  if (L.active && w < A.n_partials) {  // this wave's share of dW3, [n_partials][G][3][96]
+    float* o = A.ep_partial + (w * G + L.g) * (int64_t)(GGNN_EDGE_PARAM_ROWS * C) + L.ch;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) o[k * C + (c < 3 ? c : C / 2 + c - 3)] = dwv[c][k];
+  }
+}
+
+template <int G, bool HAS_H>
+__global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggregate_bwd_args A) {
+  const BwdLane L = bwd_lane<G>();
+  const int64_t w = (int64_t)blockIdx.x * AB_WAVES + L.wave, n_w = (int64_t)gridDim.x * AB_WAVES;
+  float wv[6][3];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const float* e = A.edge_params + L.gc * GGNN_EDGE_PARAM_ROWS * C + L.ch + (c < 3 ? c : C / 2 + c - 3);
+    wv[c][0] = e[0], wv[c][1] = e[C], wv[c][2] = e[2 * C];
+  }
+  for (int64_t j = w; j < A.n_src; j += n_w) {
+    const int beg = A.r_rowptr[j], end = A.r_rowptr[j + 1];
+    float v[6], dv[6] = {}, dh[6] = {};
+    ld6(A.p_src + j * A.ldp_src + A.v_off + L.gc * C + L.ch, v);
+    for (int q = beg; q < end; ++q) {
+      const int64_t p = A.r_slot[q], i = A.r_dst[q];
+      const float* rec = A.einfo + p * GGNN_EINFO_ROW;
+      const float rx = rec[16], ry = rec[17], rz = rec[18];
+      const float alpha = L.active ? A.edge_alpha[p * G + L.gc] : 0.f;
+      const float ds = L.active ? A.edge_ds[p * G + L.gc] : 0.f;
+      float go[6];
+      ld6(A.g_agg + i * A.ld_agg + (int64_t)L.gc * A.a_gstride + A.a_off + L.ch, go);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float val = v[c] + wv[c][0] * rx + wv[c][1] * ry + wv[c][2] * rz;
+        dv[c] += val > 0.f ? alpha * go[c] : 0.f;
+      }
+      if (HAS_H) {
+        float uh[6];
+        ld6(A.p_dst + i * A.ldp_dst + A.u_off + L.gc * C + L.ch, uh);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dh[c] += ds * uh[c];
+      }
+    }
+    if (L.active) st6(A.g_p_src + j * A.ldp_src + A.v_off + L.g * C + L.ch, dv);
+    if (HAS_H) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {  // sum over the four gate rows of the wave
+        dh[c] += __shfl_xor(dh[c], 16, 64);
+        dh[c] += __shfl_xor(dh[c], 32, 64);
+      }
+      if (L.g == 0) st6(A.g_h_src + j * A.ldh_src + L.ch, dh);
+    }
+  }
+}
+
+}  // namespace ggnn
+
+extern "C" int64_t ggnn_aggregate_bwd_partials(int64_t n_dst) {
+  const int64_t want = (n_dst + ggnn::AB_WAVES - 1) / ggnn::AB_WAVES;
+  return (want < 512 ? (want > 0 ? want : 1) : 512) * ggnn::AB_WAVES;
+}
+
+extern "C" int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  ggnn_aggregate_bwd_args A = *args;
+  if (!A.rowptr || !A.einfo || !A.p_src || !A.p_dst || !A.edge_params || !A.agg || !A.g_agg || !A.r_rowptr ||
+      !A.edge_alpha || !A.edge_ds || !A.ep_partial || !A.g_p_dst || !A.g_p_src)
+    return GGNN_EINVAL;
+  if (A.n_dst <= 0 || A.n_src <= 0 || A.E < 0) return GGNN_EINVAL;
+  if (A.E > 0 && (!A.col || !A.r_dst || !A.r_slot)) return GGNN_EINVAL;
+  const int G = A.n_gates;
+  if (G != 1 && G != 3 && G != 4) return GGNN_EINVAL;
+  const bool has_h = A.h_src != nullptr;
+  if (has_h && (!A.g_h_src || A.ldh_src < C || A.u_off < 0)) return GGNN_EINVAL;
+  if (!has_h) {
+    A.h_src = A.p_src;
+    A.ldh_src = 0;
+    A.u_off = 0;
+  }
+  if (A.v_off < 0 || A.u4_off < 0 || A.a_off < 0 || A.sc_off < 0 || A.a_gstride < C) return GGNN_EINVAL;
+  if (A.ldp_src <= 0 || A.ldp_dst <= 0) return GGNN_EINVAL;
+  if (A.v_off + (int64_t)G * C > A.ldp_src || A.u4_off + (int64_t)G * 16 > A.ldp_dst) return GGNN_EINVAL;
+  if (has_h && A.u_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
+  if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
+  if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
+  if (A.n_partials != ggnn_aggregate_bwd_partials(A.n_dst)) return GGNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid_d((unsigned)(A.n_partials / AB_WAVES));
+  const int64_t want_s = (A.n_src + AB_WAVES - 1) / AB_WAVES;
+  const dim3 grid_s((unsigned)(want_s < 2048 ? want_s : 2048));
+#define GGNN_AB_LAUNCH(G_)                                                                          \
+  do {                                                                                              \
+    if (has_h) {                                                                                    \
+      hipLaunchKernelGGL((aggregate_bwd_dst_kernel<G_, true>), grid_d, dim3(256), 0, s, A);         \
+      hipLaunchKernelGGL((aggregate_bwd_src_kernel<G_, true>), grid_s, dim3(256), 0, s, A);         \
+    } else {                                                                                        \
+      hipLaunchKernelGGL((aggregate_bwd_dst_kernel<G_, false>), grid_d, dim3(256), 0, s, A);        \
+      hipLaunchKernelGGL((aggregate_bwd_src_kernel<G_, false>), grid_s, dim3(256), 0, s, A);        \
+    }                                                                                               \
+  } while (0)
+  if (G == 4) GGNN_AB_LAUNCH(4);
+  else if (G == 3) GGNN_AB_LAUNCH(3);
+  else GGNN_AB_LAUNCH(1);
+#undef GGNN_AB_LAUNCH
+  return launch_status();
+}

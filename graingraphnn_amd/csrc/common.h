@@ -82,6 +82,15 @@ __device__ __forceinline__ f32x4 mfma_x6(const u32x4 (&w)[3], const u32x4 (&x)[3
   return c;
 }
 
+// Sum over the 16 lanes of a DPP row, result in every lane of the row (four v_add_f32 with DPP).
+__device__ __forceinline__ float row_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 struct f3 {
   float x, y, z;
 };

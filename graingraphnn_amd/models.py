@@ -13,7 +13,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, training
 from .backend import default_backend
 from .engine import Workspace, _check_x, _edge_attr_1d, graph_for, run_encoder_decoder
 from .modules import SeqGCLSTM, _param_version
@@ -79,8 +79,15 @@ class GrainNN_regressor(_GrainNNBase):
             if len(t) != 2:
                 raise NotImplementedError("regressor heads are Linear(96, 2) per node type")
 
-    @torch.no_grad()
     def forward(self, x_dict, edge_index_dict, edge_attr):
+        """Inference (no autograd recording, or `.eval()`): the fused HIP path.  Inside a training
+        loop (train.py:158-166) the differentiable path of `training.py`."""
+        if training.wants_autograd(self):
+            return training.regressor_forward(self, x_dict, edge_index_dict, edge_attr)
+        return self._forward_inference(x_dict, edge_index_dict, edge_attr)
+
+    @torch.no_grad()
+    def _forward_inference(self, x_dict, edge_index_dict, edge_attr):
         be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
         h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
         w, b = self._packed_heads(pack_regressor_heads, self.linear)
@@ -129,8 +136,13 @@ class GrainNN_classifier(_GrainNNBase):
         # the heads read h_joint only (models.py:595-609): the decoder's grain update is dead code
         self._live_out = ("joint",)
 
-    @torch.no_grad()
     def forward(self, x_dict, edge_index_dict, edge_attr):
+        if training.wants_autograd(self):
+            return training.classifier_forward(self, x_dict, edge_index_dict, edge_attr)
+        return self._forward_inference(x_dict, edge_index_dict, edge_attr)
+
+    @torch.no_grad()
+    def _forward_inference(self, x_dict, edge_index_dict, edge_attr):
         be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
         h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
         w_node, w_edge = self._packed_heads(pack_classifier_heads, self.lin1, self.lin2)

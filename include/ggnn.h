@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 11
+#define GGNN_ABI_VERSION 12
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -156,6 +156,46 @@ int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t str
  * write disjoint columns of the same agg rows.  Same result as n_sweeps single calls. */
 int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,
                                     ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward of one sweep (training path).  Replaces what autograd does for
+ * PeriodConv.message + propagate (periodGATconv.py:174-175, 204-236) in train.py:158-166:
+ * segment-softmax backward, relu mask, scatter of the value / hidden-state gradients to the
+ * source rows -- without atomics (a destination-grouped pass, then a source-grouped pass over
+ * the reverse CSR), so gradients are reproducible run to run.
+ * Forward operands exactly as in ggnn_aggregate_args (same offsets and strides) plus the saved
+ * forward output `agg` and the incoming gradient `g_agg` (same layout as agg; only the 96 value
+ * columns and the two scalars of every gate are read).  Outputs, in the layout of their operand:
+ *   g_p_dst[i, u_off + g*96 ..], g_p_dst[i, u4_off + g*16 ..]   (other columns untouched)
+ *   g_p_src[j, v_off + g*96 ..]                                  (other columns untouched)
+ *   g_h_src[j, 0..95]                                            (when h_src != NULL)
+ *   ep_partial[w, g, k, c]: partial sums of d edge_params; the gradient is their sum over w.
+ * The geometry (einfo) is data, not a parameter: no gradient.
+ */
+typedef struct ggnn_aggregate_bwd_args {
+  const int32_t* rowptr;   /* [n_dst + 1] destination-grouped CSR (ggnn_build_csr) */
+  const int32_t* col;      /* [E] source node of every CSR slot */
+  const float* einfo;      /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] */
+  const float* p_src;      /* forward operands, as ggnn_aggregate_args */
+  const float* p_dst;
+  const float* h_src;      /* or NULL */
+  const float* edge_params;
+  const float* agg;        /* [n_dst, ld_agg] forward output */
+  const float* g_agg;      /* [n_dst, ld_agg] gradient with respect to agg */
+  const int32_t* r_rowptr; /* [n_src + 1] source-grouped (reverse) CSR of the same edges */
+  const int32_t* r_dst;    /* [E] destination node of every reverse slot */
+  const int32_t* r_slot;   /* [E] forward CSR slot of every reverse slot */
+  float* edge_alpha;       /* [E, n_gates] scratch: attention weights */
+  float* edge_ds;          /* [E, n_gates] scratch: score gradients */
+  float* ep_partial;       /* [n_partials, n_gates, 3, 96] out */
+  float* g_p_dst;          /* [n_dst, ldp_dst] out */
+  float* g_p_src;          /* [n_src, ldp_src] out */
+  float* g_h_src;          /* [n_src, ldh_src] out, or NULL */
+  int64_t ldp_src, ldp_dst, ld_agg, ldh_src, n_src, n_dst, E, n_partials;
+  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
+} ggnn_aggregate_bwd_args;
+int64_t ggnn_aggregate_bwd_partials(int64_t n_dst); /* rows of ep_partial the call writes */
+int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:

@@ -55,28 +55,64 @@ class TorchEmulatorBackend:
         for sweep in sweeps:
             self.aggregate(*sweep)
 
-    def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
-                  a_gstride, sc_off, n_gates):
+    @staticmethod
+    def _aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates):
+        """Per gate (values [n_dst, 96], sum alpha [n_dst], sum alpha * a [n_dst]); differentiable."""
         rowptr, col = csr.rowptr.long(), csr.col.long()
         n_dst = p_dst.size(0)
         E = int(rowptr[-1])
         dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
         j, reloc, a = col[:E], einfo[:E, 16:19], einfo[:E, 19]
         x4 = einfo[:E, :16]  # the per-edge 16-wide tail: reloc, raw features 3..F-1, zeros, 1 @12, a_e @13
+        out = []
         for g in range(n_gates):
             V = p_src[j, v_off + g * C: v_off + (g + 1) * C]
             s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
             if h_src is not None:
                 s = s + (p_dst[dst, u_off + g * C: u_off + (g + 1) * C] * h_src[j]).sum(-1)
-            smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
+            smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s.detach(), "amax")
             p = (s - smax[dst]).exp()
-            den = torch.zeros(n_dst).index_add_(0, dst, p)
+            den = torch.zeros(n_dst).index_add(0, dst, p)
             alpha = p / (den[dst] + 1e-16)
             r = torch.relu(V + reloc @ ep[g])
+            out.append((torch.zeros(n_dst, C).index_add(0, dst, alpha[:, None] * r),
+                        torch.zeros(n_dst).index_add(0, dst, alpha),
+                        torch.zeros(n_dst).index_add(0, dst, alpha * a)))
+        return out
+
+    def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
+                  a_gstride, sc_off, n_gates):
+        with torch.no_grad():
+            vals = self._aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates)
+        for g, (val, sa, sae) in enumerate(vals):
             base = g * a_gstride
-            agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add_(0, dst, alpha[:, None] * r)
-            agg[:, base + sc_off] = torch.zeros(n_dst).index_add_(0, dst, alpha)
-            agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add_(0, dst, alpha * a)
+            agg[:, base + a_off: base + a_off + C] = val
+            agg[:, base + sc_off] = sa
+            agg[:, base + sc_off + 1] = sae
+
+    def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates):
+        """ggnn_period_gat_aggregate_backward by autograd of the emulated forward.  The reverse
+        CSR is checked for what the HIP kernel relies on, then not needed."""
+        E = csr.E
+        if E:
+            assert torch.equal(csr.col[:E].long()[r_slot[:E].long()],
+                               torch.repeat_interleave(torch.arange(p_src.size(0)),
+                                                       (rcsr.rowptr[1:] - rcsr.rowptr[:-1]).long()))
+            assert torch.equal(csr.row[:E].long()[r_slot[:E].long()], rcsr.col[:E].long())
+        leaves = [t.detach().clone().requires_grad_(True) for t in (p_src, p_dst, ep)]
+        hl = None if h_src is None else h_src.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            vals = self._aggregate_values(csr, einfo, leaves[0], leaves[1], hl, leaves[2], v_off, u_off, u4_off, n_gates)
+            tot = 0.0
+            for g, (val, sa, sae) in enumerate(vals):
+                base = g * a_gstride
+                tot = tot + (val * g_agg[:, base + a_off: base + a_off + C]).sum() \
+                    + (sa * g_agg[:, base + sc_off]).sum() + (sae * g_agg[:, base + sc_off + 1]).sum()
+            grads = torch.autograd.grad(tot, leaves + ([hl] if hl is not None else []), allow_unused=True)
+        z = lambda g, like: torch.zeros_like(like) if g is None else g
+        return (z(grads[1], p_dst), z(grads[0], p_src), None if hl is None else z(grads[3], h_src),
+                z(grads[2], ep))
 
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
                       w2_planes=None, g_stride=0):

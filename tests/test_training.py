@@ -1,0 +1,198 @@
+"""Training path: losses and parameter gradients.
+
+Pins, in order: the oracle's autograd against digests of the UNMODIFIED reference's gradients
+(tests/golden/golden_cfg1_grads.npz, made by make_golden_grads.py); the product's differentiable
+forward (graingraphnn_amd/training.py) through the torch emulator of the C ABI against the
+oracle on the CPU; and, on the GPU, the HIP sweep + its hand-written backward against both.
+Tolerance: per parameter tensor max|g - g_ref| <= 2e-4 * max|g_ref| (fp32 sums in another order).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from emulator import TorchEmulatorBackend
+from helpers import EDGE_TYPES, GOLDEN, load_graph, oracle_models, product_models, tt
+from graingraphnn_amd import training
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+GTOL = 2e-4
+
+
+def _targets(x, ei):
+    """Same draw as tests/golden/make_golden_grads.py:targets."""
+    n_j, n_g, E = x["joint"].shape[0], x["grain"].shape[0], ei[EDGE_TYPES[2]].shape[1]
+    rs = np.random.RandomState(77)
+    y = {"joint": rs.uniform(-1, 1, (n_j, 2)).astype(np.float32),
+         "grain": rs.uniform(-1, 1, (n_g, 2)).astype(np.float32),
+         "edge_event": rs.randint(-1, 2, size=E).astype(np.int64)}
+    mask = {"joint": np.ones((n_j, 1), np.float32), "grain": np.ones((n_g, 1), np.float32)}
+    mask["joint"][::7] = 0
+    mask["grain"][::5] = 0
+    return y, mask
+
+
+def _digest(g):
+    g = g.detach().cpu().numpy().astype(np.float64).ravel()
+    idx = np.random.RandomState(5).randint(g.size, size=6)
+    return np.concatenate([[g.sum(), np.sqrt((g * g).sum()), np.abs(g).max()], g[idx]])
+
+
+def _grads(R, Cm, x, ei, ea, device="cpu"):
+    y_np, m_np = _targets(x, ei)
+    y, mask = tt(y_np, device), tt(m_np, device)
+    R.train(), Cm.train()
+    R.zero_grad(), Cm.zero_grad()
+    lr = training.regressor_loss(y, R(tt(x, device), tt(ei, device), tt(ea, device)), mask)
+    lc = training.classifier_loss(y, Cm(tt(x, device), tt(ei, device), tt(ea, device)), 1.0)
+    lr.backward()
+    lc.backward()
+    out = {}
+    for tag, m in (("R", R), ("C", Cm)):
+        for name, p in m.named_parameters():
+            out[f"{tag}/{name}"] = (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu()
+    return float(lr.detach()), float(lc.detach()), out
+
+
+def _check_digests(lr, lc, grads):
+    gold = np.load(os.path.join(GOLDEN, "golden_cfg1_grads.npz"))
+    assert abs(lr - float(gold["loss_regressor"])) <= 1e-5 * abs(float(gold["loss_regressor"]))
+    assert abs(lc - float(gold["loss_classifier"])) <= 1e-5 * abs(float(gold["loss_classifier"]))
+    assert len(grads) == len(gold.files) - 2 == 568
+    for name, g in grads.items():
+        d, r = _digest(g), gold[name]
+        gmax, n = max(r[2], 1e-9), g.numel()
+        assert abs(d[0] - r[0]) <= GTOL * gmax * np.sqrt(n) + 1e-9, (name, "sum", d[0], r[0])
+        assert abs(d[1] - r[1]) <= GTOL * max(r[1], 1e-9) + 1e-9, (name, "norm", d[1], r[1])
+        assert np.abs(d[2:] - r[2:]).max() <= GTOL * gmax + 1e-9, (name, "entries", d[2:], r[2:])
+
+
+def _check_full(grads, ref):
+    worst = 0.0
+    for name, g in ref.items():
+        scale = float(g.abs().max())
+        err = float((grads[name] - g).abs().max())
+        if scale > 1e-9:
+            worst = max(worst, err / scale)
+            assert err <= GTOL * scale, (name, err, scale)
+        else:
+            assert err <= 1e-9, (name, err)
+    return worst
+
+
+def test_oracle_gradients_match_the_reference_digests():
+    x, ei, ea = load_graph("40")
+    oR, oC = oracle_models(10020, 1.0)
+    lr, lc, grads = _grads(oR, oC, x, ei, ea)
+    _check_digests(lr, lc, grads)
+    # the encoder's forget gate multiplies c = 0: exactly zero gradient in the reference too
+    assert float(grads["R/gclstm_encoder.cell_list.0.b_f.joint"].abs().max()) == 0.0
+
+
+def test_training_path_on_the_emulator_matches_oracle_gradients(monkeypatch):
+    """Host logic of training.py (key-free operands from the parameters, gate batching, sweep
+    output layout, reverse CSR) with every C-ABI call emulated in torch."""
+    x, ei, ea = load_graph("40")
+    be = TorchEmulatorBackend()
+    monkeypatch.setattr(training, "default_backend", lambda: be)
+    R, Cm = product_models(10020, 1.0)
+    lr, lc, grads = _grads(R, Cm, x, ei, ea)
+    _check_digests(lr, lc, grads)
+    oR, oC = oracle_models(10020, 1.0)
+    _, _, ref = _grads(oR, oC, x, ei, ea)
+    _check_full(grads, ref)
+    # inference dispatch is untouched: eval() / no_grad still refuse CPU tensors
+    R.eval()
+    from graingraphnn_amd import _lib
+    with pytest.raises(_lib.GGNNError):
+        R(tt(x), tt(ei), tt(ea))
+
+
+def test_one_adam_step_on_the_emulator_follows_the_oracle(monkeypatch):
+    """train.py:158-166: forward, loss, zero_grad, backward, Adam step -- same new parameters."""
+    x, ei, ea = load_graph("40")
+    be = TorchEmulatorBackend()
+    monkeypatch.setattr(training, "default_backend", lambda: be)
+    R, _ = product_models(4, 1.0)
+    oR, _ = oracle_models(4, 1.0)
+    y_np, m_np = _targets(x, ei)
+    for m in (R, oR):
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+        for _ in range(2):
+            loss = training.regressor_loss(tt(y_np), m(tt(x), tt(ei), tt(ea)), tt(m_np))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    for (n, p), (_, q) in zip(R.named_parameters(), oR.named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-3 * max(float(q.abs().max()), 1e-3), n
+
+
+@pytest.mark.gpu
+def test_hip_training_gradients_match_oracle_and_reference_digests():
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, "cuda")
+    lr, lc, grads = _grads(R, Cm, x, ei, ea, "cuda")
+    _check_digests(lr, lc, grads)
+    oR, oC = oracle_models(10020, 1.0)
+    _, _, ref = _grads(oR, oC, x, ei, ea)
+    worst = _check_full(grads, ref)
+    print(f"worst per-tensor relative gradient error {worst:.2e}")
+    # reproducible: no atomics anywhere in the backward
+    _, _, again = _grads(R, Cm, x, ei, ea, "cuda")
+    assert all(torch.equal(grads[k], again[k]) for k in grads)
+    # the training forward agrees with the fused inference forward
+    R.eval()
+    X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
+    with torch.no_grad():
+        yi = R(X, EI, EA)
+    R.train()
+    yt = R(X, EI, EA)
+    for k in ("joint", "grain", "grain_area"):
+        assert float((yi[k] - yt[k].detach()).abs().max()) <= 1e-4 * float(yi[k].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,hub_deg", [(1, 37), (2, 900)])
+def test_hip_sweep_backward_on_ragged_graphs(seed, hub_deg):
+    """The sweep's backward alone against autograd of its torch emulation: empty rows, a hub of
+    degree `hub_deg`, sources without out-edges; G = 4 with hidden rows and G = 3 without."""
+    from graingraphnn_amd.backend import default_backend
+    be, emu = default_backend(), TorchEmulatorBackend()
+    rs = np.random.RandomState(seed)
+    n_src, n_dst, E = 70, 50, 400 + hub_deg
+    src = rs.randint(0, n_src - 5, size=E)           # the last 5 sources have no out-edge
+    dst = rs.randint(1, n_dst, size=E)               # destination 0 has no in-edge
+    dst[:hub_deg] = 7
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    xs = torch.from_numpy(rs.uniform(0, 1, (n_src, 8)).astype(np.float32))
+    xd = torch.from_numpy(rs.uniform(0, 1, (n_dst, 8)).astype(np.float32))
+    ea = torch.from_numpy(rs.uniform(0.01, 0.1, E).astype(np.float32))
+    for G, has_h in ((4, True), (3, False)):
+        mk = lambda *s: torch.from_numpy(rs.uniform(-1, 1, s).astype(np.float32))
+        p_dst = mk(n_dst, G * 112 if has_h else G * 16)
+        v, h, ep = mk(n_src, G * 96), (mk(n_src, 96) if has_h else None), mk(G, 3, 96)
+        g_agg = mk(n_dst, G * 128)
+        offs = (0, 0, G * 96 if has_h else 0, 0, 128, 96)
+        res = {}
+        for name, b, dev in (("hip", be, "cuda"), ("emu", emu, "cpu")):
+            t = lambda a: None if a is None else a.to(dev)
+            csr = b.build_csr(t(ei), n_src, n_dst)
+            rcsr = b.build_csr(t(ei).flip(0).contiguous(), n_dst, n_src)
+            inv = torch.empty(E, dtype=torch.int32, device=dev)
+            inv[csr.perm[:E].long()] = torch.arange(E, dtype=torch.int32, device=dev)
+            r_slot = inv[rcsr.perm[:E].long()].contiguous()
+            einfo = torch.zeros(E + 3, 20, device=dev)
+            b.edge_prepare([(csr, t(ea), t(xs), t(xd), einfo)])
+            agg = torch.zeros(n_dst, G * 128, device=dev)
+            b.aggregate(csr, einfo, t(v), t(p_dst), t(h), t(ep), agg, *offs, G)
+            res[name] = b.aggregate_backward(csr, rcsr, r_slot, einfo, t(v), t(p_dst), t(h), t(ep), agg,
+                                             t(g_agg), *offs, G)
+        for a, b_, what in zip(res["hip"], res["emu"], ("g_p_dst", "g_p_src", "g_h_src", "g_ep")):
+            if b_ is None:
+                assert a is None
+                continue
+            err, scale = float((a.cpu() - b_).abs().max()), float(b_.abs().max())
+            assert err <= GTOL * scale, (G, what, err, scale)

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/graingraphnn_amd/csrc
 OUT=$SRC/build/variants
 mkdir -p "$OUT/obj_$1"
-for f in abi csr project project_x6 aggregate gates gates_x6 heads step; do
+for f in abi csr project project_x6 aggregate aggregate_bwd gates gates_x6 heads step; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" $2 -c "$SRC/$f.hip" -o "$OUT/obj_$1/$f.o" &
 done
 wait
