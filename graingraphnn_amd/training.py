@@ -63,6 +63,7 @@ class _Sweep(torch.autograd.Function):
     edge type; agg is [n_dst, G, 128] = (96 values, sum alpha, sum alpha * a, zeros)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # the sweep is fp32 under bf16 autocast too
     def forward(ctx, p_dst, v, h_src, ep, backend, topo, et, einfo, G):
         p_dst, v, ep = p_dst.contiguous(), v.contiguous(), ep.contiguous()
         h_src = None if h_src is None else h_src.contiguous()
@@ -74,6 +75,7 @@ class _Sweep(torch.autograd.Function):
         return agg.view(-1, G, _KG)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_agg):
         p_dst, v, h_src, ep, agg, einfo = ctx.saved_tensors
         backend, topo, et, G, offs = ctx.misc
@@ -83,51 +85,61 @@ class _Sweep(torch.autograd.Function):
         return g_p_dst, g_v, g_h, g_ep, None, None, None, None, None
 
 
-def _conv_operands(conv, x_src, x_dst, h_src, h_dst, Fs, Fd):
-    """Key-free operands of one PeriodConv (one gate, one edge type) from its parameters."""
+def _edge_type_forward(convs, backend, topo, et, einfo, x_src, x_dst, h_src, h_dst, Fs, Fd):
+    """The PeriodConvs of all gates of one edge type (HeteroConv entry, heteropgclstm.py:113-138):
+    key-free operands from the parameters, one sweep, the linear tail.  -> [N_d, G, 96].
+    The gates are batched into single GEMMs (weights stacked along the output dimension)."""
+    G = len(convs)
     k2 = 0 if h_src is None else C
     inv = 1.0 / math.sqrt(C)
-    wq, wk, wv = conv.lin_query.weight, conv.lin_key.weight, conv.lin_value.weight
+    n_d = x_dst.size(0)
+    st = lambda f: torch.stack([f(cv) for cv in convs])                       # [G, ...]
     Xd = x_dst if not k2 else torch.cat([x_dst, h_dst], 1)
-    q = Xd @ wq[:, :Fd + k2].t() + conv.lin_query.bias                       # [N_d, 96]
-    u = (q @ wk[:, :Fs + k2]) * inv                                          # [N_d, Fs (+ 96)]
-    u4 = torch.zeros(x_dst.size(0), 16, dtype=q.dtype, device=q.device)
-    u4 = torch.cat([u[:, :Fs], u4[:, Fs:12], ((q @ conv.lin_key.bias) * inv).unsqueeze(1),
-                    ((q @ conv.lin_edge.weight[:, 0]) * inv).unsqueeze(1), u4[:, 14:]], 1)
-    xz = torch.cat([torch.zeros_like(x_src[:, :3]), x_src[:, 3:]], 1)        # the wrap moves columns 0..2 to the edge
+    xz = torch.cat([torch.zeros_like(x_src[:, :3]), x_src[:, 3:]], 1)         # the wrap moves columns 0..2 to the edge
     Xs = xz if not k2 else torch.cat([xz, h_src], 1)
-    val = Xs @ wv[:, :Fs + k2].t() + conv.lin_value.bias                     # [N_s, 96]
-    skip = Xd @ conv.lin_skip.weight[:, :Fd + k2].t() + conv.lin_skip.bias   # [N_d, 96]
-    return (u[:, Fs:] if k2 else None), u4, val, wv[:, :3].t(), skip
+    wq, bq = st(lambda cv: cv.lin_query.weight[:, :Fd + k2]), st(lambda cv: cv.lin_query.bias)
+    wk, bk = st(lambda cv: cv.lin_key.weight[:, :Fs + k2]), st(lambda cv: cv.lin_key.bias)
+    wv, bv = st(lambda cv: cv.lin_value.weight[:, :Fs + k2]), st(lambda cv: cv.lin_value.bias)
+    ws, bs = st(lambda cv: cv.lin_skip.weight[:, :Fd + k2]), st(lambda cv: cv.lin_skip.bias)
+    wl, bl = st(lambda cv: cv.lin_l2.weight), st(lambda cv: cv.lin_l2.bias)
+    we = st(lambda cv: cv.lin_edge.weight[:, 0])                              # [G, 96]
+    q = (Xd @ wq.reshape(G * C, -1).t() + bq.reshape(-1)).view(n_d, G, C)     # [N_d, G, 96]
+    u = torch.einsum("ngc,gcd->ngd", q, wk) * inv                             # u = W_k^T q / sqrt(96)
+    s1 = torch.einsum("ngc,gc->ng", q, bk) * inv
+    s2 = torch.einsum("ngc,gc->ng", q, we) * inv
+    z = torch.zeros(n_d, G, 16, dtype=q.dtype, device=q.device)
+    u4 = torch.cat([u[:, :, :Fs], z[:, :, Fs:12], s1.unsqueeze(-1), s2.unsqueeze(-1), z[:, :, 14:]], -1)
+    p_dst = u4.reshape(n_d, G * 16) if not k2 else torch.cat([u[:, :, Fs:].reshape(n_d, G * C),
+                                                              u4.reshape(n_d, G * 16)], 1)
+    val = Xs @ wv.reshape(G * C, -1).t() + bv.reshape(-1)                     # [N_s, G * 96]
+    ep = wv[:, :, :3].transpose(1, 2)                                         # [G, 3, 96]
+    agg = _Sweep.apply(p_dst, val, h_src, ep, backend, topo, et, einfo, G)    # [N_d, G, 128]
+    skip = (Xd @ ws.reshape(G * C, -1).t() + bs.reshape(-1)).view(n_d, G, C)
+    return (torch.einsum("ngc,gkc->ngk", agg[:, :, :C], wl) + agg[:, :, C:C + 1] * bl
+            + agg[:, :, C + 1:C + 2] * we + skip)
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
     """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable.  h, c: dicts or None
     (encoder: zero state; the forget gate multiplies c = 0 and is skipped, its gradient is 0)."""
     gates = "ifco" if h is not None else "ico"
-    G = len(gates)
     F = cell.in_channels_dict
-    pre = {nt: [0.0] * G for nt in NODE_TYPES}
+    pre = {nt: 0.0 for nt in NODE_TYPES}
     for et in EDGE_TYPES:
         s, d = et[0], et[-1]
-        ops = [_conv_operands(getattr(cell, "conv_" + g).convs[et_key(et)], x[s], x[d],
-                              None if h is None else h[s], None if h is None else h[d], F[s], F[d])
-               for g in gates]
-        u4 = torch.cat([o[1] for o in ops], 1)
-        p_dst = u4 if h is None else torch.cat([o[0] for o in ops] + [u4], 1)
-        val = torch.cat([o[2] for o in ops], 1)
-        ep = torch.stack([o[3] for o in ops])                                # [G, 3, 96]
-        agg = _Sweep.apply(p_dst, val, None if h is None else h[s], ep, backend, topo, et, einfo[et], G)
-        for k, g in enumerate(gates):
-            conv = getattr(cell, "conv_" + g).convs[et_key(et)]
-            out = (agg[:, k, :C] @ conv.lin_l2.weight.t() + agg[:, k, C:C + 1] * conv.lin_l2.bias
-                   + agg[:, k, C + 1:C + 2] * conv.lin_edge.weight[:, 0] + ops[k][4])
-            pre[d][k] = pre[d][k] + out
+        convs = [getattr(cell, "conv_" + g).convs[et_key(et)] for g in gates]
+        pre[d] = pre[d] + _edge_type_forward(convs, backend, topo, et, einfo[et], x[s], x[d],
+                                             None if h is None else h[s], None if h is None else h[d], F[s], F[d])
     h_new, c_new = {}, {}
+    # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an
+    # exactly zero gradient; they are touched here the same way, which also keeps
+    # DistributedDataParallel(model, device_ids=[rank]) (dist_train.py:82) usable as written.
+    touch = 0.0 if h is not None else 0.0 * sum(
+        q.sum() for q in list(cell.conv_f.parameters()) + list(cell.b_f.parameters()))
     for nt in NODE_TYPES:
-        p = {g: pre[nt][k] + getattr(cell, "b_" + g)[nt] for k, g in enumerate(gates)}
+        p = {g: pre[nt][:, k] + getattr(cell, "b_" + g)[nt] for k, g in enumerate(gates)}
         cand = torch.sigmoid(p["i"]) * torch.tanh(p["c"])
-        c_new[nt] = cand if h is None else torch.sigmoid(p["f"]) * c[nt] + cand
+        c_new[nt] = cand + touch if h is None else torch.sigmoid(p["f"]) * c[nt] + cand
         h_new[nt] = torch.sigmoid(p["o"]) * torch.tanh(c_new[nt])
     return h_new, c_new
 

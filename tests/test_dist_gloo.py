@@ -63,3 +63,59 @@ def test_two_rank_gloo_gather(tmp_path):
     assert got["ids"] == [0.0, 1.0]
     assert got["res"].shape == ref.shape
     assert np.array_equal(got["res"].numpy(), ref.numpy())  # same code, same seeds -> same bits
+
+
+# ---------------------------------------------------------------------------------------
+# training: DistributedDataParallel exactly as dist_train.py:82 wraps the model
+# ---------------------------------------------------------------------------------------
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel
+    from emulator import TorchEmulatorBackend
+    from helpers import product_models
+    from graingraphnn_amd import training
+    be = TorchEmulatorBackend()
+    training.default_backend = lambda: be          # this process only: every C-ABI call emulated
+    R, _ = product_models(4, 1.0)
+    R.train()
+    model = DistributedDataParallel(R)
+    x, ei, ea = load_graph("40")
+    y, mask = _train_targets(rank)
+    for _ in range(2):                              # the second iteration is what unused parameters break
+        model.zero_grad()
+        loss = training.regressor_loss(tt(y), model(tt(x), tt(ei), tt(ea)), tt(mask))
+        loss.backward()
+    if rank == 0:
+        torch.save({n: p.grad.clone() for n, p in R.named_parameters()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _train_targets(rank):
+    rs = np.random.RandomState(500 + rank)
+    y = {"joint": rs.uniform(-1, 1, (236, 2)).astype(np.float32), "grain": rs.uniform(-1, 1, (118, 2)).astype(np.float32)}
+    return y, {"joint": np.ones((236, 1), np.float32), "grain": np.ones((118, 1), np.float32)}
+
+
+def test_two_rank_ddp_gradients_are_the_rank_average(tmp_path):
+    from helpers import oracle_models as om
+    from graingraphnn_amd import training
+    torch.set_num_threads(1)
+    x, ei, ea = load_graph("40")
+    ref = None
+    for rank in range(2):                           # single-process reference: the oracle, per rank
+        oR, _ = om(4, 1.0)
+        oR.train()
+        y, mask = _train_targets(rank)
+        training.regressor_loss(tt(y), oR(tt(x), tt(ei), tt(ea)), tt(mask)).backward()
+        g = {n: p.grad.clone() for n, p in oR.named_parameters()}
+        ref = g if ref is None else {n: 0.5 * (ref[n] + g[n]) for n in g}
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert set(got) == set(ref)
+    for n, g in ref.items():
+        scale = float(g.abs().max())
+        assert float((got[n] - g).abs().max()) <= 2e-4 * scale + 1e-9, n

@@ -61,24 +61,26 @@ def _check_digests(lr, lc, grads):
     assert abs(lr - float(gold["loss_regressor"])) <= 1e-5 * abs(float(gold["loss_regressor"]))
     assert abs(lc - float(gold["loss_classifier"])) <= 1e-5 * abs(float(gold["loss_classifier"]))
     assert len(grads) == len(gold.files) - 2 == 568
+    # absolute floor for gradients that are zero in exact arithmetic (the key bias: a softmax is
+    # shift-invariant), relative to the largest gradient entry of the whole model
+    atol = 1e-6 * max(float(gold[name][2]) for name in grads)
     for name, g in grads.items():
         d, r = _digest(g), gold[name]
-        gmax, n = max(r[2], 1e-9), g.numel()
-        assert abs(d[0] - r[0]) <= GTOL * gmax * np.sqrt(n) + 1e-9, (name, "sum", d[0], r[0])
-        assert abs(d[1] - r[1]) <= GTOL * max(r[1], 1e-9) + 1e-9, (name, "norm", d[1], r[1])
-        assert np.abs(d[2:] - r[2:]).max() <= GTOL * gmax + 1e-9, (name, "entries", d[2:], r[2:])
+        gmax, n = r[2], g.numel()
+        assert abs(d[0] - r[0]) <= (GTOL * gmax + atol) * np.sqrt(n), (name, "sum", d[0], r[0])
+        assert abs(d[1] - r[1]) <= GTOL * r[1] + atol * np.sqrt(n), (name, "norm", d[1], r[1])
+        assert np.abs(d[2:] - r[2:]).max() <= GTOL * gmax + atol, (name, "entries", d[2:], r[2:])
 
 
 def _check_full(grads, ref):
     worst = 0.0
+    atol = 1e-6 * max(float(g.abs().max()) for g in ref.values())
     for name, g in ref.items():
         scale = float(g.abs().max())
         err = float((grads[name] - g).abs().max())
-        if scale > 1e-9:
+        assert err <= GTOL * scale + atol, (name, err, scale)
+        if scale > 100 * atol:
             worst = max(worst, err / scale)
-            assert err <= GTOL * scale, (name, err, scale)
-        else:
-            assert err <= 1e-9, (name, err)
     return worst
 
 
@@ -196,3 +198,21 @@ def test_hip_sweep_backward_on_ragged_graphs(seed, hub_deg):
                 continue
             err, scale = float((a.cpu() - b_).abs().max()), float(b_.abs().max())
             assert err <= GTOL * scale, (G, what, err, scale)
+
+
+@pytest.mark.gpu
+def test_bf16_autocast_training_step_stays_close_to_fp32():
+    """BASELINE config 5 names bf16: library GEMMs under torch.autocast, the sweep stays fp32."""
+    x, ei, ea = load_graph("40")
+    y_np, m_np = _targets(x, ei)
+    y, mask = tt(y_np, "cuda"), tt(m_np, "cuda")
+    R, _ = product_models(10020, 1.0, "cuda")
+    R.train()
+    X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
+    ref = training.regressor_loss(y, R(X, EI, EA), mask)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        low = training.regressor_loss(y, R(X, EI, EA), mask)
+    low.backward()
+    assert abs(float(low) - float(ref)) <= 2e-2 * abs(float(ref))
+    g = R.gclstm_decoder.cell_list[0].conv_i.convs["joint__connect__joint"].lin_value.weight.grad
+    assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
