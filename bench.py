@@ -301,7 +301,8 @@ def main():
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
                        "results_finite": finite,
-                       "forward_only_steps_per_s_per_gpu": round(forward_only * (units_per_step // world), 2),
+                       "forward_only": {"steps_per_s_per_gpu": round(forward_only * (units_per_step // world), 2),
+                                        "launch": "eager, R then C on one stream (no update / refresh)"},
                        **({"events": {"grains_eliminated": int(sum(len(e) for e in ro.grain_events)),
                                       "edges_switched": int(sum(len(e) for e in ro.switched)),
                                       "edges_left": int(ro.edge_index[("joint", "connect", "joint")].size(1)),
