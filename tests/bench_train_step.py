@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Development aid: time one training step (forward, loss, backward, Adam; train.py:158-166) of
-the regressor on the HIP training path, and the same step of the CPU oracle.
+the regressor on the HIP training path, and the same step of the CPU oracle (which is why this
+script lives under tests/: only tests, smoke() and bench.py's cpu_baseline may touch oracle/).
 
-    python tools/trainbench.py [--batch 4] [--steps 20] [--bf16] [--cfg3] [--no-cpu]
+    python tests/bench_train_step.py [--batch 4] [--steps 20] [--bf16] [--cfg3] [--no-cpu]
 
 Default workload: `--batch` copies of the 40 um fixture as one disjoint-union graph (what PyG's
 DataLoader collation does for train.py's batch_size 4); --cfg3: the 10k-grain honeycomb.
