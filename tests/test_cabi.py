@@ -47,6 +47,12 @@ def test_argument_validation_returns_einval_without_launching():
     assert lib.ggnn_period_gat_aggregate(ctypes.byref(a), None) == -1
     e = _lib.EpilogueArgs()
     assert lib.ggnn_lstm_epilogue(ctypes.byref(e), None) == -1
+    assert lib.ggnn_period_gat_aggregate_batch(None, 1, None) == -1
+    assert lib.ggnn_period_gat_aggregate_batch((_lib.AggregateArgs * 3)(), 4, None) == -1
+    assert lib.ggnn_period_gat_aggregate_backward(None, None) == -1
+    b = _lib.AggregateBwdArgs()
+    assert lib.ggnn_period_gat_aggregate_backward(ctypes.byref(b), None) == -1
+    assert lib.ggnn_aggregate_bwd_partials(20000) == 2048 and lib.ggnn_aggregate_bwd_partials(5) == 8
     assert lib.ggnn_build_csr(None, 5, 3, 0, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.ggnn_csr_max_units(60000, 20000) == 40001
     assert lib.ggnn_edge_prepare(None, 1, None) == -1
@@ -61,6 +67,7 @@ def test_argument_validation_returns_einval_without_launching():
 def test_struct_sizes_match_the_header():
     """ctypes mirrors of the POD argument blocks (natural alignment, no packing)."""
     assert ctypes.sizeof(_lib.AggregateArgs) == 8 * 8 + 7 * 8 + 8 * 4
+    assert ctypes.sizeof(_lib.AggregateBwdArgs) == 18 * 8 + 8 * 8 + 8 * 4
     assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 4 * 8
     assert ctypes.sizeof(_lib.EpilogueArgs) == 7 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4
     assert ctypes.sizeof(_lib.RefreshEdge) == 4 * 8 + 5 * 8
