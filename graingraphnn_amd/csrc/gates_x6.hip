@@ -8,7 +8,7 @@
 //
 // Structure: WEIGHT-STATIONARY, no workgroup barrier after the prologue (the pass-and-barrier
 // structure of gates.hip spent more time in barriers and pipeline refills than in MFMAs).
-//   * A workgroup owns a 32-channel slice for ALL gates and the whole reduction: its weights,
+//   * A workgroup owns a 32-channel slice (16 channels on small graphs, see GX slices below) for ALL gates and the whole reduction: its weights,
 //     already split into bf16 planes in MFMA fragment order by the host-side packing
 //     (ggnn_epilogue_args.w2_planes), are copied once into LDS (G x 6 k-steps x 3 planes x 2 column
 //     tiles x 1 KB = 144 KB at G = 4, Ka = 196) and read back lane-linearly (conflict-free).
@@ -27,18 +27,23 @@ namespace ggnn {
 
 constexpr int GX_BM = 16;     // nodes per wave tile
 constexpr int GX_WAVES = 8;   // waves per workgroup (two per SIMD)
-constexpr int GX_SLICES = 3;  // 32-channel slices
+// Channel slices: NCT column tiles of 16 channels per workgroup, 6 / NCT slices.  NCT = 2 (three
+// 32-channel slices) reads `agg` three times; NCT = 1 (six 16-channel slices) reads it six times but
+// halves the LDS fill and the MFMA chain per step and doubles the workgroups: used while the graph
+// is too small to give every CU a workgroup (cfg2, 2 086 joints: 0.180 -> 0.169 ms per rollout step).
 // (gate, k-step) steps of `agg` in flight per wave.  Measured (MI355X, 20 000 joints, isolated
 // launches): G = 4: 48 us at depth 4..8, 60 at 12; G = 3: 46 / 39 / 74 / 36 us at 4 / 6 / 8 / 12.
 constexpr int gx_depth(int G) { return G == 3 ? 12 : 8; }
 
-template <int G, int MODE, int KA, int T>
+template <int G, int MODE, int KA, int T, int NCT>
 __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_epilogue_args A, int n_ranges) {
+  constexpr int GX_SLICES = 6 / NCT;
+  constexpr int SW = 16 * NCT;  // channels per slice
   constexpr int KM = KA - 4;    // columns on the bf16 path (192 / 96)
   constexpr int NKS = KM / 32;  // k-steps per gate (6 / 3)
   constexpr int NSTEP = G * NKS;
   constexpr int GX_DEPTH = gx_depth(G);
-  constexpr int NPIECE = NSTEP * 3 * 2 * 64;  // 16-byte weight pieces of one slice
+  constexpr int NPIECE = NSTEP * 3 * NCT * 64;  // 16-byte weight pieces of one slice
   static_assert(KM % 32 == 0, "Ka - 4 must be a multiple of 32");
   __shared__ u32x4 s_w[NPIECE];
 
@@ -62,19 +67,19 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
     u32x4 wreg[NIT];  // all loads first: one L2 round trip, not one per piece
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = min(tid + it * GX_WAVES * 64, NPIECE - 1), gkp = idx >> 7, rem = idx & 127;  // 2 column tiles x 64 lanes
-      wreg[it] = wpl[((int64_t)gkp * 6 + 2 * slice) * 64 + rem];
+      const int idx = min(tid + it * GX_WAVES * 64, NPIECE - 1), gkp = idx / (NCT * 64), rem = idx % (NCT * 64);  // NCT column tiles x 64 lanes
+      wreg[it] = wpl[((int64_t)gkp * 6 + NCT * slice) * 64 + rem];
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
       if (tid + it * GX_WAVES * 64 < NPIECE) s_w[tid + it * GX_WAVES * 64] = wreg[it];
   }
   // operands of the exact fp32 tail (columns KM .. KM+3): weight side, 16x16x4 fragment layout
-  float wt[G][2];
+  float wt[G][NCT];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) wt[g][a] = A.w2[((int64_t)g * C + slice * 32 + a * 16 + lr) * KA + KM + kq];
+    for (int a = 0; a < NCT; ++a) wt[g][a] = A.w2[((int64_t)g * C + slice * SW + a * 16 + lr) * KA + KM + kq];
   __syncthreads();  // the only workgroup barrier
 #ifdef GX_VAR_CLOCK
   const uint64_t tr_pro = __builtin_amdgcn_s_memrealtime();
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
   for (int gs = 0; gs < GX_DEPTH && gs < T * NSTEP; ++gs) load_step(gs);
 
   const u32x4* pw = &s_w[lane];
-  f32x4 acc[G][2], skip[G][2], cold[2];
+  f32x4 acc[G][NCT], skip[G][NCT], cold[NCT];
   float xt[G];
 #pragma unroll
   for (int gs = 0; gs < T * NSTEP; ++gs) {
@@ -129,17 +134,17 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
 #pragma unroll
       for (int g2 = 0; g2 < G; ++g2) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < NCT; ++a) {
           acc[g2][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          skip[g2][a] = *reinterpret_cast<const f32x4*>(A.p_dst + m * A.ldp + A.s_off + g2 * C + slice * 32 +
+          skip[g2][a] = *reinterpret_cast<const f32x4*>(A.p_dst + m * A.ldp + A.s_off + g2 * C + slice * SW +
                                                         a * 16 + 4 * kq);
         }
         xt[g2] = A.agg[m * ld_agg + g2 * gs_ + KM + kq];
       }
       if (MODE == GGNN_MODE_LSTM) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          cold[a] = *reinterpret_cast<const f32x4*>(A.c_in + m * C + slice * 32 + a * 16 + 4 * kq);
+        for (int a = 0; a < NCT; ++a)
+          cold[a] = *reinterpret_cast<const f32x4*>(A.c_in + m * C + slice * SW + a * 16 + 4 * kq);
       }
     }
     // split this step's fragment, then reuse its ring slot for the step GX_DEPTH ahead
@@ -163,17 +168,17 @@ __global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_e
     if (gs + GX_DEPTH < T * NSTEP) load_step(gs + GX_DEPTH);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NCT; ++a) {
       u32x4 wf[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) wf[q] = pw[((st * 3 + q) * 2 + a) * 64];
+      for (int q = 0; q < 3; ++q) wf[q] = pw[((st * 3 + q) * NCT + a) * 64];
       acc[g][a] = mfma_x6(wf, xb, acc[g][a]);
     }
     if (st == NSTEP - 1) {
       // ---- tile epilogue: exact fp32 tail, + skip, LSTM; lane holds channels n..n+3 (twice) ----
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int n = slice * 32 + a * 16 + 4 * kq;
+      for (int a = 0; a < NCT; ++a) {
+        const int n = slice * SW + a * 16 + 4 * kq;
 #pragma unroll
         for (int g2 = 0; g2 < G; ++g2)
           acc[g2][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[g2][a], xt[g2], acc[g2][a], 0, 0, 0) + skip[g2][a];
@@ -221,16 +226,21 @@ int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args& A, hipStream_t s) {
   const int G = A.n_gates;
   const bool wide = A.Ka == 196;
   const int64_t n_mt = (A.N + GX_BM - 1) / GX_BM;
+  const int64_t n_wg_rows = (n_mt + GX_WAVES - 1) / GX_WAVES;  // workgroups along the nodes at one tile per wave
+  // narrow slices (6 x 16 channels) while three wide ones leave more than half of the CUs without a workgroup
+  const int NCT = 3 * n_wg_rows <= 128 ? 1 : 2;
+  const int n_slices = 6 / NCT;
   // tiles per wave: 1 while one round of workgroups (<= 256) covers the nodes, else 2
-  const int T = GX_SLICES * ((n_mt + GX_WAVES - 1) / GX_WAVES) <= 256 ? 1 : 2;
+  const int T = n_slices * n_wg_rows <= 256 ? 1 : 2;
   const int64_t n_ranges = (n_mt + GX_WAVES * T - 1) / (GX_WAVES * T);
-  const int64_t nblk = 8 * GX_SLICES * ((n_ranges + 7) / 8);
+  const int64_t nblk = 8 * n_slices * ((n_ranges + 7) / 8);
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
   const dim3 grid((unsigned)nblk), block(GX_WAVES * 64);
-#define GGNN_GX_LAUNCH2(G_, MODE_, KA_)                                                                        \
-  do {                                                                                                         \
-    if (T == 1) hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 1>), grid, block, 0, s, A, (int)n_ranges); \
-    else hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 2>), grid, block, 0, s, A, (int)n_ranges);        \
+#define GGNN_GX_LAUNCH2(G_, MODE_, KA_)                                                                           \
+  do {                                                                                                            \
+    if (NCT == 1) hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 1, 1>), grid, block, 0, s, A, (int)n_ranges);      \
+    else if (T == 1) hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 1, 2>), grid, block, 0, s, A, (int)n_ranges);   \
+    else hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 2, 2>), grid, block, 0, s, A, (int)n_ranges);        \
   } while (0)
 #define GGNN_GX_LAUNCH(G_, MODE_)              \
   do {                                         \
