@@ -104,9 +104,13 @@ def _edge_type_forward(convs, backend, topo, et, einfo, x_src, x_dst, h_src, h_d
     wl, bl = st(lambda cv: cv.lin_l2.weight), st(lambda cv: cv.lin_l2.bias)
     we = st(lambda cv: cv.lin_edge.weight[:, 0])                              # [G, 96]
     q = (Xd @ wq.reshape(G * C, -1).t() + bq.reshape(-1)).view(n_d, G, C)     # [N_d, G, 96]
-    u = torch.einsum("ngc,gcd->ngd", q, wk) * inv                             # u = W_k^T q / sqrt(96)
-    s1 = torch.einsum("ngc,gc->ng", q, bk) * inv
-    s2 = torch.einsum("ngc,gc->ng", q, we) * inv
+    # the per-gate batched products stay fp32 under bf16 autocast: they feed the attention logits,
+    # and the library's bf16 batched-GEMM backward is three orders of magnitude slower here
+    with torch.autocast(q.device.type, enabled=False):
+        q = q.float()
+        u = torch.einsum("ngc,gcd->ngd", q, wk) * inv                         # u = W_k^T q / sqrt(96)
+        s1 = torch.einsum("ngc,gc->ng", q, bk) * inv
+        s2 = torch.einsum("ngc,gc->ng", q, we) * inv
     z = torch.zeros(n_d, G, 16, dtype=q.dtype, device=q.device)
     u4 = torch.cat([u[:, :, :Fs], z[:, :, Fs:12], s1.unsqueeze(-1), s2.unsqueeze(-1), z[:, :, 14:]], -1)
     p_dst = u4.reshape(n_d, G * 16) if not k2 else torch.cat([u[:, :, Fs:].reshape(n_d, G * C),
@@ -115,8 +119,9 @@ def _edge_type_forward(convs, backend, topo, et, einfo, x_src, x_dst, h_src, h_d
     ep = wv[:, :, :3].transpose(1, 2)                                         # [G, 3, 96]
     agg = _Sweep.apply(p_dst, val, h_src, ep, backend, topo, et, einfo, G)    # [N_d, G, 128]
     skip = (Xd @ ws.reshape(G * C, -1).t() + bs.reshape(-1)).view(n_d, G, C)
-    return (torch.einsum("ngc,gkc->ngk", agg[:, :, :C], wl) + agg[:, :, C:C + 1] * bl
-            + agg[:, :, C + 1:C + 2] * we + skip)
+    with torch.autocast(agg.device.type, enabled=False):
+        return (torch.einsum("ngc,gkc->ngk", agg[:, :, :C], wl) + agg[:, :, C:C + 1] * bl
+                + agg[:, :, C + 1:C + 2] * we + skip.float())
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
