@@ -61,7 +61,8 @@ class Workspace:
         self.n_nodes = dict(n_nodes)
         f32 = dict(dtype=torch.float32, device=device)
         self.proj, self.agg_enc, self.agg_dec, self.h1, self.c1, self.h2, self.c2 = {}, {}, {}, {}, {}, {}, {}
-        self.einfo = None  # edge type -> [E, 4], (re)allocated by prepare_edges
+        self.einfo = None  # edge type -> [E + 3, 20], (re)allocated by prepare_edges
+        self.ea = None     # edge type -> [E]: the model's own copy of edge_attr (launch tape, models.py)
         for nt in NODE_TYPES:
             n = n_nodes[nt]
             ncols = max(enc.layout[nt].ncols, dec.layout[nt].ncols)

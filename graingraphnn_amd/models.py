@@ -34,9 +34,19 @@ class _GrainNNBase(nn.Module):
         self.dim = {"joint": 2, "grain": 1}
         self.scaling = {"grain": 20, "joint": 5}
         self._ws = None
+        self._tape = None
         self._heads = None
         # node types whose decoder state the output heads read (all of them for the regressor)
         self._live_out = NODE_TYPES
+
+    def __getstate__(self):
+        """Pickling / deepcopy: parameters and configuration only (workspaces and the launch tape
+        hold device scratch and raw pointers, and are rebuilt on the next forward)."""
+        d = self.__dict__.copy()
+        d["_ws"] = d["_tape"] = d["_heads"] = None
+        if "_tmp" in d:
+            d["_tmp"] = None
+        return d
 
     def _prepare(self, x_dict, edge_index_dict, edge_attr):
         be = default_backend()
@@ -50,6 +60,37 @@ class _GrainNNBase(nn.Module):
         if self._ws is None or self._ws.n_nodes != n_nodes or self._ws.proj["joint"].device != dev:
             self._ws = Workspace(enc, dec, n_nodes, dev)
         return be, graph, enc, dec, self._ws
+
+    def _run_cells(self, x_dict, edge_index_dict, edge_attr):
+        """Encoder + decoder cells -> (decoder h_dict, graph).  The launches of one call are kept
+        as a tape (backend.start_tape) and re-issued as long as the next call has the same
+        topology, weights, workspace, stream and x tensors -- the situation of the reference's
+        rollout loop, which updates x_dict in place and calls forward again (test.py:382-402).
+        edge_attr is copied into workspace-owned buffers so that fresh edge_attr tensors
+        (test.py:562-575 builds new ones every step) do not invalidate the tape."""
+        be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
+        if not hasattr(be, "start_tape"):  # test doubles
+            h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
+            return h, graph
+        ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
+        if ws.ea is None or any(ws.ea[et].shape != ea[et].shape for et in EDGE_TYPES):
+            ws.ea = {et: torch.empty_like(ea[et]) for et in EDGE_TYPES}
+        for et in EDGE_TYPES:
+            ws.ea[et].copy_(ea[et])
+        key = (graph, enc, dec, ws, torch.cuda.current_stream().cuda_stream,
+               tuple((x_dict[nt].data_ptr(), x_dict[nt].stride(0)) for nt in NODE_TYPES))
+        t = self._tape
+        if t is not None and all(a is b for a, b in zip(t[0][:4], key[:4])) and t[0][4:] == key[4:]:
+            be.replay(t[1])
+        else:
+            self._tape = None
+            be.start_tape()
+            try:
+                run_encoder_decoder(be, enc, dec, graph, ws, x_dict, ws.ea)
+            finally:
+                tape = be.stop_tape()
+            self._tape = (key, tape)
+        return ws.h2, graph
 
     def _packed_heads(self, fn, *mods):
         ver = tuple(_param_version(m) for m in mods)
@@ -88,8 +129,8 @@ class GrainNN_regressor(_GrainNNBase):
 
     @torch.no_grad()
     def _forward_inference(self, x_dict, edge_index_dict, edge_attr):
-        be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
-        h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
+        be = default_backend()
+        h, _ = self._run_cells(x_dict, edge_index_dict, edge_attr)
         w, b = self._packed_heads(pack_regressor_heads, self.linear)
         dev = x_dict["joint"].device
         y_joint = torch.empty(x_dict["joint"].size(0), 2, device=dev)
@@ -143,8 +184,8 @@ class GrainNN_classifier(_GrainNNBase):
 
     @torch.no_grad()
     def _forward_inference(self, x_dict, edge_index_dict, edge_attr):
-        be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
-        h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
+        be = default_backend()
+        h, graph = self._run_cells(x_dict, edge_index_dict, edge_attr)
         w_node, w_edge = self._packed_heads(pack_classifier_heads, self.lin1, self.lin2)
         dev = x_dict["joint"].device
         n_joint = x_dict["joint"].size(0)

@@ -22,7 +22,15 @@ from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, 
 
 
 def _param_version(module: nn.Module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    """(storage, version) of every parameter: changes when a parameter is updated in place, moved
+    or replaced.  Runs on every forward, so it walks the per-module parameter dicts collected
+    once (`module.parameters()` re-traverses the module tree: 0.3 ms per cell) -- the dicts
+    are updated in place by nn.Module when a Parameter object is replaced."""
+    dicts = module.__dict__.get("_ggnn_param_dicts")
+    if dicts is None:
+        dicts = [m._parameters for m in module.modules() if m._parameters]
+        module.__dict__["_ggnn_param_dicts"] = dicts
+    return tuple((p.data_ptr(), p._version) for d in dicts for p in d.values() if p is not None)
 
 
 class PeriodConv(nn.Module):

@@ -713,3 +713,57 @@ def test_batched_sweeps_equal_single_launches(which):
         be.aggregate_batch(sw + sw[:1])                                 # more than three sweeps
     with pytest.raises(_lib.GGNNError):
         be.aggregate_batch([])
+
+
+@torch.no_grad()
+def test_forward_launch_tape_tracks_inputs_weights_and_topology():
+    """The drop-in forward() re-issues its recorded launches while topology, weights, workspace,
+    stream and x tensors stay the same (models.py:_run_cells); anything else re-records."""
+    import copy
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(12, 1.0, DEV)
+    R2, Cm2 = product_models(12, 1.0, DEV)           # never replays: fresh tensors every call
+    X, EI = tt(x, DEV), tt(ei, DEV)
+    be = backend()
+    replays = []
+    orig = be.replay
+    be.replay = lambda tape: (replays.append(len(tape)), orig(tape))[1]
+    try:
+        for step in range(4):
+            EA = tt(ea, DEV)                         # new edge_attr tensors every step (test.py:562-575)
+            for et in EDGE_TYPES:
+                EA[et] *= 1.0 + 0.01 * step
+            ya, ca = R(X, EI, EA), Cm(X, EI, EA)
+            yb, cb = R2(tt({k: v.cpu().numpy() for k, v in X.items()}, DEV), tt(ei, DEV), EA), \
+                Cm2(tt({k: v.cpu().numpy() for k, v in X.items()}, DEV), tt(ei, DEV), EA)
+            for k in ("joint", "grain", "grain_area"):
+                assert torch.equal(ya[k], yb[k]), (step, k)
+            assert torch.equal(ca["edge_event"], cb["edge_event"]) and torch.equal(ca["edge"], cb["edge"])
+            R.update(X, ya, None)                    # x_dict changes in place, same tensors
+        # steps 1..3 replay: R = edge records + 2 x (2 projections + 1 sweep batch + 2 gate GEMMs) = 11
+        # launches, C = 10 (its decoder skips the dead grain gate GEMM)
+        assert replays == [11, 10] * 3, replays
+        # new weights -> the tape is dropped and re-recorded
+        R.linear["joint"].bias.add_(0.5)
+        R.gclstm_decoder.cell_list[0].b_i["joint"].add_(0.1)
+        R2.load_state_dict(R.state_dict())
+        n = len(replays)
+        EA = tt(ea, DEV)
+        ya = R(X, EI, EA)
+        assert len(replays) == n
+        yb = R2(tt({k: v.cpu().numpy() for k, v in X.items()}, DEV), tt(ei, DEV), EA)
+        assert torch.equal(ya["joint"], yb["joint"])
+        assert torch.equal(R(X, EI, EA)["joint"], ya["joint"]) and len(replays) == n + 1
+        # another stream -> re-record (the stream handle is part of every recorded call)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ys = R(X, EI, EA)
+        side.synchronize()
+        assert torch.equal(ys["joint"], ya["joint"]) and len(replays) == n + 1
+        # deepcopy / pickling keep parameters only
+        R3 = copy.deepcopy(R)
+        assert R3._tape is None and R3._ws is None
+        assert torch.equal(R3(X, EI, EA)["joint"], ya["joint"])
+    finally:
+        be.replay = orig
