@@ -251,14 +251,19 @@ def main():
             return ro.step_events()
     for _ in range(args.warmup):
         step()
+    if not args.events:
+        ro.run(GrainRollout.RUN_UNROLL)  # untimed: captures the multi-step graph
     gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if args.events:
+        for _ in range(args.steps):
+            step()
+    else:
+        ro.run(args.steps)  # exactly args.steps steps; hipGraph replay goes 4 steps per graph launch
     gathered = gather_states(ro.state(), world)  # RCCL all-gather of the rollout results
     torch.cuda.synchronize()
     if world > 1:
@@ -296,7 +301,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else "hipGraph replay") + (", R|C serial" if args.serial else ", R|C on two streams"),
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R|C serial" if args.serial else ", R|C on two streams"),
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),

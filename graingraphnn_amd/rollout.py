@@ -77,7 +77,7 @@ class GrainRollout:
         self.steps_done = 0
         self.use_graph = use_graph
         if use_graph:
-            self._capture()
+            self._graph_exec = self._capture()
 
     def _set_topology(self, edge_index_dict, edge_attr_dict=None):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
@@ -97,7 +97,7 @@ class GrainRollout:
         self.pred["edge_event"] = torch.empty(E, dtype=torch.float32, device=dev)
         self.pred["edge"] = torch.empty(E, 2, dtype=torch.float32, device=dev)
         self.einfo = alloc_einfo(self.graph, dev)
-        self._graph_exec = None
+        self._graph_exec = self._graph_multi = None
 
     # -- one step, enqueued on the current stream --------------------------------------
     def _enqueue_step(self):
@@ -151,8 +151,8 @@ class GrainRollout:
         be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
                         [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et]) for et in EDGE_TYPES])
 
-    def _capture(self):
-        """Record one step into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm); the
+    def _capture(self, n_steps: int = 1):
+        """Record `n_steps` steps into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm); the
         kernels are launched through the C ABI on the capturing stream."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -160,9 +160,10 @@ class GrainRollout:
             # the capture records, it does not execute: x / edge_attr are left untouched
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                self._enqueue_step()
+                for _ in range(n_steps):
+                    self._enqueue_step()
         torch.cuda.current_stream().wait_stream(s)
-        self._graph_exec = g
+        return g
 
     # -- event-driven mode ------------------------------------------------
     def enable_events(self, mask, area_threshold: float = 1e-4, edge_threshold: float = 0.6):
@@ -260,7 +261,7 @@ class GrainRollout:
     def step(self):
         """Advance one rollout step; returns the prediction dict (tensors are reused)."""
         if self.use_graph and self._graph_exec is None:
-            self._capture()
+            self._graph_exec = self._capture()
         if self._graph_exec is not None:
             self._graph_exec.replay()
         else:
@@ -268,7 +269,18 @@ class GrainRollout:
         self.steps_done += 1
         return self.pred
 
+    RUN_UNROLL = 4  # steps per graph in run(): one graph-to-graph boundary (~10 us on the GPU) per 4 steps
+
     def run(self, n_steps: int):
+        """`n_steps` static-topology steps.  With hipGraph replay the bulk goes through a graph of
+        RUN_UNROLL consecutive steps (same kernels, same order, same results as step() x n)."""
+        if self.use_graph and n_steps >= self.RUN_UNROLL:
+            if self._graph_multi is None:
+                self._graph_multi = self._capture(self.RUN_UNROLL)
+            for _ in range(n_steps // self.RUN_UNROLL):
+                self._graph_multi.replay()
+            self.steps_done += n_steps - n_steps % self.RUN_UNROLL
+            n_steps %= self.RUN_UNROLL
         for _ in range(n_steps):
             self.step()
         return self.pred

@@ -767,3 +767,28 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
         assert torch.equal(R3(X, EI, EA)["joint"], ya["joint"])
     finally:
         be.replay = orig
+
+
+@torch.no_grad()
+def test_run_with_multi_step_graph_equals_single_steps():
+    """GrainRollout.run(n) replays graphs of RUN_UNROLL steps: bit-identical to n x step()."""
+    from graingraphnn_amd.rollout import GrainRollout
+    x, ei, ea = load_graph("40")
+    out = []
+    for mode in ("run", "step", "eager"):
+        R, Cm = product_models(5, 1.0, DEV)
+        ro = GrainRollout(R, Cm, tt(x, DEV), tt(ei, DEV), tt(ea, DEV), 6, use_graph=mode != "eager",
+                          refresh_centres=True)
+        if mode == "run":
+            ro.run(2 * GrainRollout.RUN_UNROLL + 3)
+        else:
+            for _ in range(2 * GrainRollout.RUN_UNROLL + 3):
+                ro.step()
+        assert ro.steps_done == 2 * GrainRollout.RUN_UNROLL + 3
+        torch.cuda.synchronize()
+        out.append(({k: v.clone() for k, v in ro.x.items()}, {k: v.clone() for k, v in ro.pred.items()}))
+    for other in out[1:]:
+        for k in ("joint", "grain"):
+            assert torch.equal(out[0][0][k], other[0][k])
+        for k in out[0][1]:
+            assert torch.equal(out[0][1][k], other[1][k])
