@@ -30,7 +30,6 @@ from graingraphnn_amd import GrainRollout, synthetic  # noqa: E402
 from graingraphnn_amd.backend import default_backend  # noqa: E402
 from graingraphnn_amd.dist import gather_states  # noqa: E402
 from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor  # noqa: E402
-from graingraphnn_amd.packing import EDGE_TYPES  # noqa: E402
 from graingraphnn_amd.seeding import load_seeded  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

@@ -8,16 +8,14 @@ There is no CPU path: `forward` raises unless the model and the inputs live on a
 and libggnn.so is built.
 """
 import copy
-from typing import Dict
-
 import torch
 import torch.nn as nn
 
-from . import _lib, training
+from . import training
 from .backend import default_backend
 from .engine import Workspace, _check_x, _edge_attr_1d, graph_for, run_encoder_decoder
 from .modules import SeqGCLSTM, _param_version
-from .packing import C, EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
+from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
 ET_JJ = ("joint", "connect", "joint")
 

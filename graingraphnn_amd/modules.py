@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, graph_for, prepare_edges, run_cell
-from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, pack_conv, roundup4
+from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, pack_conv
 
 
 def _param_version(module: nn.Module):

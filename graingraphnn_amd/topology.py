@@ -15,7 +15,7 @@ fp32 junction coordinates.  Reference behaviours that look accidental are kept b
 trained models were run with them, each marked KEEP below.
 """
 from itertools import combinations
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 

@@ -17,11 +17,10 @@ The fused inference kernels (ggnn_project, ggnn_lstm_epilogue, heads) have no ba
 not used here.  Same results as the inference path up to fp32 re-association.
 """
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
-from . import _lib
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
 from .packing import C, EDGE_TYPES, NODE_TYPES, et_key

@@ -6,8 +6,6 @@ plan of graingraphnn_amd/engine.py) end-to-end against the oracle without a GPU.
 shipped, not importable from the package, and never used as a fallback: the product's only
 backend is `graingraphnn_amd.backend.HipBackend`.
 """
-import math
-
 import torch
 
 C = 96

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (EDGE_TYPES, RTOL, assert_close, etk, fold_120, golden, load_graph,
+from helpers import (EDGE_TYPES, assert_close, etk, fold_120, golden, load_graph,
                      oracle_models, product_models, random_state, rel_err, tt)
 from graingraphnn_amd import _lib, synthetic
 from oracle import grainnn_oracle as oracle

@@ -3,7 +3,7 @@
 32-bit row offsets, grids and L2 windows; r1: 2.44 ms and 5.75 ms per step, linear in size)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from graingraphnn_amd import GrainRollout, synthetic
 from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor
 from graingraphnn_amd.seeding import load_seeded

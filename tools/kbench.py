@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from graingraphnn_amd import _lib, engine, synthetic  # noqa: E402
+from graingraphnn_amd import engine, synthetic  # noqa: E402
 from graingraphnn_amd.backend import default_backend  # noqa: E402
 from graingraphnn_amd.models import GrainNN_regressor  # noqa: E402
 from graingraphnn_amd.packing import EDGE_TYPES, NODE_TYPES  # noqa: E402
