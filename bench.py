@@ -314,9 +314,9 @@ def main():
                           if args.events else {})},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and args.workload == "cfg3":
+        if not args.no_cpu_baseline and args.workload == "cfg3" and world == 1:  # N = 1 only: a reported baseline
             line["cpu_baseline"] = cpu_baseline(inputs)
-            if world == 1 and default_backend().lib.ggnn_gemm_mode() == 1 and not args.events:
+            if default_backend().lib.ggnn_gemm_mode() == 1 and not args.events:
                 # the same workload with the decoder GEMMs on the native fp32 matrix path, in a child
                 # process (the mode is fixed per process), so both arithmetic paths sit in one line
                 import subprocess
