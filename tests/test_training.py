@@ -216,3 +216,35 @@ def test_bf16_autocast_training_step_stays_close_to_fp32():
     assert abs(float(low) - float(ref)) <= 2e-2 * abs(float(ref))
     g = R.gclstm_decoder.cell_list[0].conv_i.convs["joint__connect__joint"].lin_value.weight.grad
     assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_ddp_over_rccl_as_the_reference_wraps_it():
+    """dist_train.py:79-82 on one GPU: init_process_group('nccl') + DistributedDataParallel(model,
+    device_ids=[rank]); two iterations (the second is what unused parameters would break)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    x, ei, ea = load_graph("40")
+    y_np, m_np = _targets(x, ei)
+    y, mask = tt(y_np, "cuda"), tt(m_np, "cuda")
+    R, _ = product_models(10020, 1.0, "cuda")
+    R.train()
+    X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
+    training.regressor_loss(y, R(X, EI, EA), mask).backward()
+    ref = {n: p.grad.clone() for n, p in R.named_parameters()}
+    R.zero_grad()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        model = DistributedDataParallel(R, device_ids=[0])
+        for _ in range(2):
+            model.zero_grad()
+            training.regressor_loss(y, model(X, EI, EA), mask).backward()
+        for n, p in R.named_parameters():
+            assert torch.equal(p.grad, ref[n]), n
+    finally:
+        dist.destroy_process_group()
