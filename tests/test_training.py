@@ -248,3 +248,57 @@ def test_ddp_over_rccl_as_the_reference_wraps_it():
             assert torch.equal(p.grad, ref[n]), n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sweep_backward_full_size_properties():
+    """cfg3 size (oracle autograd would take minutes): the backward is linear in the incoming
+    gradient, reproducible, and its destination-side part matches a float64 torch restatement
+    on a sample of rows."""
+    from graingraphnn_amd import synthetic
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    x, ei, ea = synthetic.honeycomb(100, 10, 0)
+    et = EDGE_TYPES[0]                                   # grain -> joint: 10 000 sources, 20 000 destinations
+    n_src, n_dst, E, G = x["grain"].shape[0], x["joint"].shape[0], ei[et].shape[1], 4
+    EI = torch.from_numpy(ei[et]).cuda()
+    xs, xd = torch.from_numpy(x["grain"]).cuda(), torch.from_numpy(x["joint"]).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    mk = lambda *s: torch.rand(*s, device="cuda", generator=gen) * 2 - 1
+    p_dst, v, h, ep = mk(n_dst, G * 112), mk(n_src, G * 96), mk(n_src, 96), mk(G, 3, 96)
+    csr = be.build_csr(EI, n_src, n_dst)
+    rcsr = be.build_csr(EI.flip(0).contiguous(), n_dst, n_src)
+    inv = torch.empty(E, dtype=torch.int32, device="cuda")
+    inv[csr.perm[:E].long()] = torch.arange(E, dtype=torch.int32, device="cuda")
+    r_slot = inv[rcsr.perm[:E].long()].contiguous()
+    einfo = torch.zeros(E + 3, 20, device="cuda")
+    be.edge_prepare([(csr, torch.from_numpy(ea[et]).cuda().view(-1), xs, xd, einfo)])
+    offs = (0, 0, G * 96, 0, 128, 96)
+    agg = torch.zeros(n_dst, G * 128, device="cuda")
+    be.aggregate(csr, einfo, v, p_dst, h, ep, agg, *offs, G)
+    bwd = lambda g: be.aggregate_backward(csr, rcsr, r_slot, einfo, v, p_dst, h, ep, agg, g, *offs, G)
+    g1, g2 = mk(n_dst, G * 128), mk(n_dst, G * 128)
+    a, b, c, again = bwd(g1), bwd(g2), bwd(g1 + 0.5 * g2), bwd(g1)
+    for ta, tb, tc, td, what in zip(a, b, c, again, ("g_p_dst", "g_p_src", "g_h_src", "g_ep")):
+        assert torch.equal(ta, td), what                 # no atomics: bit-reproducible
+        scale = float(tc.abs().max())
+        assert float((ta + 0.5 * tb - tc).abs().max()) <= 2e-5 * scale, what
+    # destination-side gradient of 64 sampled rows in float64
+    rows = torch.arange(0, n_dst, n_dst // 64, device="cuda")[:64]
+    rp, col = csr.rowptr.long(), csr.col.long()
+    for i in rows.tolist():
+        sl = slice(int(rp[i]), int(rp[i + 1]))
+        j = col[sl]
+        for g in range(G):
+            uh = p_dst[i, g * 96:(g + 1) * 96].double().requires_grad_(True)
+            u4 = p_dst[i, G * 96 + g * 16: G * 96 + (g + 1) * 16].double().requires_grad_(True)
+            s = einfo[sl, :16].double() @ u4 + h[j].double() @ uh
+            alpha = torch.softmax(s, 0)
+            val = torch.relu(v[j, g * 96:(g + 1) * 96].double() + einfo[sl, 16:19].double() @ ep[g].double())
+            out = torch.cat([(alpha[:, None] * val).sum(0), alpha.sum()[None], (alpha * einfo[sl, 19].double()).sum()[None]])
+            (out * g1[i, g * 128: g * 128 + 98].double()).sum().backward()
+            ref = torch.cat([uh.grad, u4.grad])
+            got = torch.cat([a[0][i, g * 96:(g + 1) * 96], a[0][i, G * 96 + g * 16: G * 96 + (g + 1) * 16]]).double()
+            # ds = alpha (dalpha - S) cancels 96-term sums of size ~5 down to ~1e-3 here: fp32 leaves
+            # a few 1e-6 absolute (as it does in the reference's own fp32 autograd)
+            assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 5e-6, (i, g)
