@@ -160,8 +160,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
-    ap.add_argument("--phase-shift", action="store_true",
-                    help="start the classifier one kernel phase after the regressor (measured slower)")
     ap.add_argument("--events", action="store_true",
                     help="event-driven mode (SURVEY 8f-2): per-step event detection + host topology update when "
                          "one fires; not the headline metric")
@@ -227,7 +225,7 @@ def main():
         R, Cm = R.to(device), Cm.to(device)
         X, EI, EA = synthetic.to_torch(x, ei, ea, device)
     ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial,
-                      phase_shift=args.phase_shift, refresh_centres=True, domain_factor=inputs[3],
+                      refresh_centres=True, domain_factor=inputs[3],
                       domain_offset=None if inputs[4] is None else torch.from_numpy(inputs[4]))
 
     step = ro.step

@@ -106,15 +106,12 @@ def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
 
 def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],
              einfo: Dict[ET, torch.Tensor], h_in: Optional[Dict[str, torch.Tensor]],
-             c_in: Optional[Dict[str, torch.Tensor]], proj, agg, h_out, c_out, after_project=None):
-    """One HeteroPGCLSTM.forward.  Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros).
-    `after_project()` is called once the projection GEMMs are enqueued (phase hook)."""
+             c_in: Optional[Dict[str, torch.Tensor]], proj, agg, h_out, c_out):
+    """One HeteroPGCLSTM.forward.  Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
     lay = pc.layout
     for nt in NODE_TYPES:  # 2 projection GEMMs
         P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
         backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
-    if after_project is not None:
-        after_project()
     sweeps = []  # 3 aggregation sweeps (fewer when a destination type is dead), one launch
     for et in EDGE_TYPES:
         s, d = et[0], et[-1]
@@ -135,13 +132,13 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,
                         x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor],
-                        einfo: Optional[Dict[ET, torch.Tensor]] = None, after_project=None):
+                        einfo: Optional[Dict[ET, torch.Tensor]] = None):
     """models.py:422-426 / 581-585: encoder from zero state, decoder from the encoder's (h, c),
     both on the same x_dict.  `einfo` (from prepare_edges) may be shared by several models that
     see the same x / edge_attr; when absent it is computed here.  Returns the decoder's (h, c)."""
     if einfo is None:
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
         einfo = ws.einfo = prepare_edges(backend, graph, x, ea, ws.einfo)
-    run_cell(backend, enc, graph, x, einfo, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1, after_project)
+    run_cell(backend, enc, graph, x, einfo, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1)
     run_cell(backend, dec, graph, x, einfo, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2)
     return ws.h2, ws.c2

@@ -27,7 +27,7 @@ ET_JJ = ("joint", "connect", "joint")
 class GrainRollout:
     def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
                  edge_attr_dict, span: int, use_graph: bool = False, concurrent: bool = True,
-                 phase_shift: bool = False, refresh_centres: bool = False,
+                 refresh_centres: bool = False,
                  domain_factor: float = 1.0, domain_offset: Optional[torch.Tensor] = None):
         """refresh_centres: also recompute x_grain[:, :2] from the junction polygons every step,
         like the reference's traj.GNN_update + test.py:556-559 (default off = the static-geometry
@@ -65,7 +65,6 @@ class GrainRollout:
         # the regressor and the classifier are independent given (x, edge geometry): run them
         # on two HIP streams so one model's launch tails overlap the other's kernels
         self.concurrent = concurrent
-        self.phase_shift = phase_shift
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if concurrent else None
         self.refresh_centres = refresh_centres
         self.domain_factor = float(domain_factor)
@@ -110,12 +109,10 @@ class GrainRollout:
         # edge geometry once per step, shared by both models and all four cells
         einfo = prepare_edges(be, self.graph, x, ea, self.einfo)
 
-        phase = torch.cuda.Event() if self._side is not None and self.phase_shift else None
 
         def regressor():
             enc, dec = self.packed["R"]
-            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo,
-                                       after_project=(lambda: phase.record()) if phase is not None else None)
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
             be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
                                p["joint"], p["grain"], p["grain_area"])
 
@@ -133,10 +130,6 @@ class GrainRollout:
             for st, fn in zip(self._side, (regressor, classifier)):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    if fn is classifier and phase is not None:
-                        # start the classifier one phase late: its MFMA-bound projections then run
-                        # beside the regressor's HBM-bound sweeps instead of beside its projections
-                        st.wait_event(phase)
                     fn()
             for st in self._side:
                 main.wait_stream(st)
