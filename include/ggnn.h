@@ -198,7 +198,7 @@ int64_t ggnn_aggregate_bwd_partials(int64_t n_dst); /* rows of ep_partial the ca
 int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Gate GEMM + LSTM epilogue (fp32 MFMA).  For every node and gate:
+ * Gate GEMM + LSTM epilogue (arithmetic per ggnn_gemm_mode).  For every node and gate:
  *   pre[g] = agg[:, g, 0:Ka] . W2[g]^T + p_dst[:, s_off + g*96 ...]
  * where W2[g] = [lin_l2.weight of each incoming edge type | b_l2, w_edge per edge type]
  * (periodGATconv.py:218, 231-235), the skip/bias term was produced by ggnn_project
