@@ -130,8 +130,11 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=20.0):
-    """The oracle (reference formulation, plain PyTorch CPU) on the same workload, bounded."""
+def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=12.0):
+    """The oracle (reference formulation, plain PyTorch CPU) on the same workload, bounded.
+    PyTorch's default of one thread per core is far from its best on a 2 x 64-core host (measured:
+    128 threads 8.2 s/step, 16 threads 0.9 s/step, 1 thread 4.0 s/step), so a few thread counts
+    are tried first and the baseline is quoted at the fastest one."""
     from oracle import grainnn_oracle as oracle
     x, ei, ea, factor, off = inputs
     centres = (factor, torch.from_numpy(off))
@@ -141,15 +144,30 @@ def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=20.0):
     load_seeded(R, seed, scale).eval()
     load_seeded(Cm, seed + 1, scale).eval()
     X, EI, EA = synthetic.to_torch(x, ei, ea, "cpu")
-    oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
-        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n} steps of the same 10k-grain workload after 1 warm-up"}
+    default_threads = torch.get_num_threads()
+    cands = sorted({t for t in (8, 16, 32) if t <= (os.cpu_count() or 1)}) or [default_threads]
+    trial = {}
+    try:
+        for t in cands:
+            torch.set_num_threads(t)
+            oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)  # warm-up at this thread count
+            t0 = time.perf_counter()
+            _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
+            trial[t] = time.perf_counter() - t0
+        best = min(trial, key=trial.get)
+        torch.set_num_threads(best)
+        oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
+            _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
+            n += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": best, "kind": "port",
+            "sample": f"{n} steps of the same 10k-grain workload at the fastest of "
+                      f"{{{', '.join(f'{t} threads: {1 / v:.2f} steps/s' for t, v in sorted(trial.items()))}}}"}
 
 
 def main():
