@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--cfg3", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
     args = ap.parse_args()
     if args.cfg3:
         x, ei, ea = synthetic.honeycomb(100, 10, 0)
@@ -76,6 +78,7 @@ def main():
           f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     if not args.no_cpu:
         from oracle import grainnn_oracle as oracle
+        torch.set_num_threads(args.cpu_threads)
         oR = load_seeded(oracle.GrainNN_regressor(synthetic.default_hyper("cpu")), 0, 1.0)
         Xc, EIc, EAc = synthetic.to_torch(x, ei, ea, "cpu")
         Yc = {k: torch.from_numpy(v) for k, v in y.items()}
