@@ -10,8 +10,11 @@ import torch
 from helpers import GOLDEN
 from graingraphnn_amd.topology import GJ, JG, JJ, TopologyError, update_topology
 
-EV = np.load(os.path.join(GOLDEN, "golden_cfg1_events.npz"))
-SCENARIOS = ["elim1", "switch1", "switch3", "mixed", "mass3", "mass4"]
+EV = dict(np.load(os.path.join(GOLDEN, "golden_cfg1_events.npz")))
+# + 12 random scenarios (0-3 eliminations and 0-4 switches each, chained up to 4 deep) recorded
+# by tests/golden/fuzz_events.py, which also ran several hundred more against the reference
+EV.update(np.load(os.path.join(GOLDEN, "golden_cfg1_events_fuzz.npz")))
+SCENARIOS = ["elim1", "switch1", "switch3", "mixed", "mass3", "mass4"] + [f"fuzz{i:02d}" for i in range(12)]
 
 
 def k(et):
