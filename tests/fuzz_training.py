@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""One-off GPU fuzz (not collected by pytest): parameter gradients of the HIP training path against
+autograd of the CPU oracle on random Voronoi structures, random targets / masks / labels.
+Tolerance per parameter tensor: max|g - g_ref| <= 2e-4 * max|g_ref| + 1e-6 * (largest gradient entry).
+    python tests/fuzz_training.py [--n 10] [--seed 0]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from helpers import oracle_models, product_models, tt  # noqa: E402
+from graingraphnn_amd import synthetic, training  # noqa: E402
+
+JJ = ("joint", "connect", "joint")
+
+
+def grads(R, Cm, x, ei, ea, y, mask, dev):
+    R.train(), Cm.train()
+    R.zero_grad(), Cm.zero_grad()
+    Y, M = tt(y, dev), tt(mask, dev)
+    lr = training.regressor_loss(Y, R(tt(x, dev), tt(ei, dev), tt(ea, dev)), M)
+    lc = training.classifier_loss(Y, Cm(tt(x, dev), tt(ei, dev), tt(ea, dev)), 1.0)
+    lr.backward()
+    lc.backward()
+    out = {}
+    for tag, m in (("R", R), ("C", Cm)):
+        for n, p in m.named_parameters():
+            out[f"{tag}/{n}"] = (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu()
+    return float(lr.detach()), float(lc.detach()), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rs = np.random.RandomState(args.seed)
+    worst = 0.0
+    for it in range(args.n):
+        n_g = int(rs.choice([12, 40, 150, 400]))
+        noise = None if rs.rand() < 0.5 else float(rs.uniform(0.05, 0.3))
+        wseed, scale = int(rs.randint(1, 10 ** 6)), float(rs.choice([0.5, 1.0, 2.0]))
+        x, ei, ea = synthetic.voronoi(n_g, seed=int(rs.randint(1, 10 ** 6)), lattice_noise=noise)
+        n_j, n_gr, E = x["joint"].shape[0], x["grain"].shape[0], ei[JJ].shape[1]
+        y = {"joint": rs.uniform(-1, 1, (n_j, 2)).astype(np.float32), "grain": rs.uniform(-1, 1, (n_gr, 2)).astype(np.float32),
+             "edge_event": rs.randint(-1, 2, size=E).astype(np.int64)}
+        mask = {"joint": (rs.rand(n_j, 1) > 0.1).astype(np.float32), "grain": (rs.rand(n_gr, 1) > 0.1).astype(np.float32)}
+        R, Cm = product_models(wseed, scale, "cuda")
+        oR, oC = oracle_models(wseed, scale)
+        la, lca, ga = grads(R, Cm, x, ei, ea, y, mask, "cuda")
+        lb, lcb, gb = grads(oR, oC, x, ei, ea, y, mask, "cpu")
+        assert abs(la - lb) <= 1e-5 * abs(lb) and abs(lca - lcb) <= 1e-5 * abs(lcb), (la, lb, lca, lcb)
+        atol = 1e-6 * max(float(g.abs().max()) for g in gb.values())
+        w = 0.0
+        for n, g in gb.items():
+            err, sc = float((ga[n] - g).abs().max()), float(g.abs().max())
+            assert err <= 2e-4 * sc + atol, (it, n, err, sc)
+            if sc > 100 * atol:
+                w = max(w, err / sc)
+        worst = max(worst, w)
+        print(f"{it:3d} grains {n_gr:4d} weights x{scale}: losses {la:.4f} / {lca:.4f}, worst gradient error {w:.2e}", flush=True)
+    print(f"{args.n} random structures: worst per-tensor relative gradient error {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
