@@ -792,3 +792,33 @@ def test_run_with_multi_step_graph_equals_single_steps():
             assert torch.equal(out[0][0][k], other[0][k])
         for k in out[0][1]:
             assert torch.equal(out[0][1][k], other[1][k])
+
+
+def test_edge_records_at_wrap_boundaries():
+    """periodGATconv.py:209-210: strict comparisons (a difference of exactly +-0.5 is NOT wrapped),
+    one shift only (1.25 -> 0.25), all three coordinates; bit-exact against numpy."""
+    be = backend()
+    vals = np.array([0.0, 0.5, -0.5, 0.5000001, -0.5000001, 0.75, -0.75, 1.25, -1.25, 0.49999997, 1.5, -1.5],
+                    dtype=np.float32)
+    n = len(vals)
+    xs = np.zeros((n, 8), np.float32)
+    xs[:, 0], xs[:, 1], xs[:, 2] = vals, vals[::-1], -vals
+    xs[:, 3:] = np.arange(n * 5, dtype=np.float32).reshape(n, 5) / 7
+    xd = np.zeros((3, 8), np.float32)
+    xd[1, :3] = (0.25, -0.25, 0.125)
+    xd[2, :3] = (-1.0, 1.0, 0.5)
+    src = np.repeat(np.arange(n), 3)
+    dst = np.tile(np.arange(3), n)
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
+    ea = torch.arange(len(src), dtype=torch.float32, device=DEV) / 100
+    csr = be.build_csr(ei, n, 3)
+    einfo = torch.zeros(len(src) + 3, 20, device=DEV)
+    be.edge_prepare([(csr, ea, torch.from_numpy(xs).to(DEV), torch.from_numpy(xd).to(DEV), einfo)])
+    col, row, perm = (t.cpu().numpy()[:len(src)] for t in (csr.col, csr.row, csr.perm))
+    rel = xs[col, :3] - xd[row, :3]
+    reloc = (-1 * (rel > 0.5) + 1 * (rel < -0.5) + rel).astype(np.float32)
+    got = einfo.cpu().numpy()[:len(src)]
+    assert np.array_equal(got[:, 0:3], reloc) and np.array_equal(got[:, 16:19], reloc)
+    assert np.array_equal(got[:, 3:8], xs[col, 3:8]) and (got[:, 8:12] == 0).all()
+    assert (got[:, 12] == 1).all() and np.array_equal(got[:, 13], ea.cpu().numpy()[perm])
+    assert np.array_equal(got[:, 19], got[:, 13]) and (got[:, 14:16] == 0).all()
