@@ -132,9 +132,10 @@ def pmc_traffic():
 
 def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=12.0):
     """The oracle (reference formulation, plain PyTorch CPU) on the same workload, bounded.
-    PyTorch's default of one thread per core is far from its best on a 2 x 64-core host (measured:
-    128 threads 8.2 s/step, 16 threads 0.9 s/step, 1 thread 4.0 s/step), so a few thread counts
-    are tried first and the baseline is quoted at the fastest one."""
+    PyTorch's default of one thread per hardware thread is far from its best on a 2 x 64-core host
+    (measured: 128 threads 8.2 s/step, 16 threads 0.9 s/step, 1 thread 4.0 s/step), so a few
+    thread counts are tried first and the baseline is quoted at the fastest one; the 1-thread
+    figure, the physical core count and the CPU model are reported beside it."""
     from oracle import grainnn_oracle as oracle
     x, ei, ea, factor, off = inputs
     centres = (factor, torch.from_numpy(off))
@@ -145,7 +146,8 @@ def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=12.0):
     load_seeded(Cm, seed + 1, scale).eval()
     X, EI, EA = synthetic.to_torch(x, ei, ea, "cpu")
     default_threads = torch.get_num_threads()
-    cands = sorted({t for t in (8, 16, 32) if t <= (os.cpu_count() or 1)}) or [default_threads]
+    model, physical, hw_threads = host_cpu()
+    cands = sorted({1} | {t for t in (8, 16, 32) if t <= hw_threads})
     trial = {}
     try:
         for t in cands:
@@ -165,9 +167,66 @@ def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=12.0):
         dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(default_threads)
-    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": best, "kind": "port",
+    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": best, "threads": best,
+            "physical_cores": physical, "hardware_threads": hw_threads, "cpu_model": model,
+            "one_thread_steps_per_s": round(1 / trial[1], 4), "kind": "port",
             "sample": f"{n} steps of the same 10k-grain workload at the fastest of "
-                      f"{{{', '.join(f'{t} threads: {1 / v:.2f} steps/s' for t, v in sorted(trial.items()))}}}"}
+                      f"{{{', '.join(f'{t} threads: {1 / v:.2f} steps/s' for t, v in sorted(trial.items()))}}} "
+                      "(one timed step each after a warm-up step)"}
+
+
+def host_cpu():
+    """(model name, physical cores, hardware threads) of this host from /proc/cpuinfo."""
+    model, cores, phys, core = "unknown", set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` started plainly (no torchrun): start N rank processes ourselves,
+    the way the reference does it (dist_train.py:394-395, mp.spawn(nprocs=device_count); :76-82).
+    The parent has made NO GPU call at this point and makes none: the ranks are fresh child
+    processes (never an exec of a GPU-initialised process); the parent relays rank 0's JSON line
+    and exits non-zero when any rank fails."""
+    import socket
+    import subprocess
+    if os.environ.get("GGNN_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
+    line = json.loads(out.strip().splitlines()[-1])
+    if line.get("n_gpus") != n:
+        raise SystemExit(f"--gpus {n} but the job reports n_gpus = {line.get('n_gpus')}")
 
 
 def main():
@@ -187,11 +246,13 @@ def main():
                          "rank batching its shard as one disjoint-union graph (--steps = steps per trajectory)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: ranks and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # GGNN_BENCH_BACKEND=gloo + fewer GPUs than ranks: single-GPU smoke run of the N > 1 code path
@@ -308,6 +369,9 @@ def main():
             "value": round(units_per_step * args.steps / dt, 2),
             "unit": "steps/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (backend + (" (RCCL " + ".".join(map(str, torch.cuda.nccl.version())) + ")"
+                                              if backend == "nccl" else "")) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

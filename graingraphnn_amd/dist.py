@@ -14,6 +14,15 @@ def shard_trajectories(n_traj: int, rank: int, world: int) -> List[int]:
     return [t for t in range(n_traj) if t % world == rank]
 
 
+def _check_shardable(n_traj: int, world: int):
+    """Raised identically on EVERY rank, before any work or collective: a rank that aborted alone
+    (an empty shard) would leave the others blocked in the all-gather."""
+    if n_traj < 1:
+        raise ValueError("no trajectories to run")
+    if n_traj < world:
+        raise ValueError(f"more ranks ({world}) than trajectories ({n_traj}): every rank needs at least one")
+
+
 def _staging(t: torch.Tensor) -> torch.Tensor:
     """RCCL ('nccl') moves device buffers directly; the 'gloo' backend (CPU tests, single-GPU
     smoke runs) needs host buffers."""
@@ -39,11 +48,10 @@ def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, 
     """Run `run_one(t)` (-> fixed-shape result tensor) for this rank's trajectories and
     all-gather everything: returns [n_traj, ...] in trajectory order on every rank.
     Ranks with fewer trajectories pad their shard so the collective stays regular."""
+    _check_shardable(n_traj, world)
     mine = shard_trajectories(n_traj, rank, world)
     per_rank = (n_traj + world - 1) // world
     results = [run_one(t) for t in mine]
-    if not results and n_traj:
-        raise ValueError("more ranks than trajectories")
     proto = results[0]
     local = torch.zeros((per_rank,) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
     for i, r in enumerate(results):
@@ -71,6 +79,7 @@ def rollout_trajectories(rmodel, cmodel, graphs, span: int, n_steps: int, rank: 
     from . import synthetic
     from .rollout import GrainRollout
 
+    _check_shardable(len(graphs), world)
     mine = shard_trajectories(len(graphs), rank, world)
     x, ei, ea, slices = synthetic.disjoint_union([graphs[t] for t in mine])
     X, EI, EA = synthetic.to_torch(x, ei, ea, device)

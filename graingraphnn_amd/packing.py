@@ -129,7 +129,14 @@ def bf16_planes(w2: torch.Tensor) -> torch.Tensor:
     mid = r1.to(torch.bfloat16)
     r2 = r1 - mid.float()
     lo = r2.to(torch.bfloat16)
-    assert torch.equal(hi.float() + mid.float() + lo.float(), w)
+    if not bool(torch.isfinite(w).all()):
+        raise ValueError("gate weights (lin_l2 / lin_edge) contain non-finite values: cannot be packed")
+    # hi + mid + lo == w exactly unless the last piece underflows bf16's exponent range
+    # (|w| < ~2^-110): such entries lose bits far below anything fp32 arithmetic could show
+    # (their products are subnormal in the fp32 accumulator) and are accepted
+    resid = (hi.float() + mid.float() + lo.float() - w).abs()
+    if resid.numel() and float(resid.max()) > 2.0 ** -120:
+        raise ValueError(f"bf16 split of the gate weights is not exact (residual {float(resid.max()):.3e})")
     pl = torch.stack([hi, mid, lo], 0).view(3, G, 6, 16, KM // 32, 4, 8)   # p g ct i ks kq j
     pl = pl.permute(1, 4, 0, 2, 5, 3, 6).contiguous()                      # g ks p ct kq i j
     return pl.view(torch.int16).view(-1)

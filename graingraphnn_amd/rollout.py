@@ -18,6 +18,7 @@ import torch
 from . import _lib
 from .backend import default_backend
 from .engine import Workspace, _check_x, alloc_einfo, graph_for, prepare_edges, run_encoder_decoder
+from .modules import _param_version
 from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
 TRAIN_FRAMES = 120  # test.py:190
@@ -50,13 +51,9 @@ class GrainRollout:
         self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
         self.packed = {}
         self.ws = {}
-        for name, m in (("R", rmodel), ("C", cmodel)):
-            enc = m.gclstm_encoder.cell_list[0].packed(True)
-            dec = m.gclstm_decoder.cell_list[0].packed(False, m._live_out)
-            self.packed[name] = (enc, dec)
-            self.ws[name] = Workspace(enc, dec, self.n_nodes, dev)
-        self.w_reg = pack_regressor_heads(rmodel.linear)
-        self.w_cls = pack_classifier_heads(cmodel.lin1, cmodel.lin2)
+        self._pack_weights()
+        for name in ("R", "C"):
+            self.ws[name] = Workspace(*self.packed[name], self.n_nodes, dev)
         nj, ng = self.n_nodes["joint"], self.n_nodes["grain"]
         f32 = dict(dtype=torch.float32, device=dev)
         self.pred.update({"joint": torch.empty(nj, 2, **f32), "grain": torch.empty(ng, 2, **f32),
@@ -77,6 +74,26 @@ class GrainRollout:
         self.use_graph = use_graph
         if use_graph:
             self._graph_exec = self._capture()
+
+    def _pack_weights(self):
+        """Fused device weights of both models, and the parameter versions they were packed from."""
+        self._wver = (_param_version(self.rmodel), _param_version(self.cmodel))
+        for name, m in (("R", self.rmodel), ("C", self.cmodel)):
+            self.packed[name] = (m.gclstm_encoder.cell_list[0].packed(True),
+                                 m.gclstm_decoder.cell_list[0].packed(False, m._live_out))
+        self.w_reg = pack_regressor_heads(self.rmodel.linear)
+        self.w_cls = pack_classifier_heads(self.cmodel.lin1, self.cmodel.lin2)
+
+    def refresh_weights(self, force: bool = False):
+        """Re-pack the weights and drop the captured hipGraphs (which hold the old buffers'
+        addresses) if a parameter of either model was updated, moved or replaced since they were
+        packed (load_state_dict, an optimizer step, .to()).  Checked on every run() and
+        step_events() call and on every 16th step() call (the check walks 568 tensors, ~0.15 ms);
+        call it directly after changing the models between two step() calls."""
+        if force or self._wver != (_param_version(self.rmodel), _param_version(self.cmodel)):
+            self._pack_weights()
+            self._graph_exec = self._graph_multi = None
+            self._graph_fwd = self._graph_ref = None
 
     def _set_topology(self, edge_index_dict, edge_attr_dict=None):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
@@ -205,6 +222,7 @@ class GrainRollout:
         host synchronisation unless an event fires."""
         if not hasattr(self, "mask"):
             raise _lib.GGNNError("call enable_events(mask, ...) first")
+        self.refresh_weights()
         self._run_segment("fwd")
         p = self.pred
         self.be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
@@ -212,7 +230,12 @@ class GrainRollout:
         self._ev_host.copy_(self._ev_flags, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         events, switches = np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
+        pred = self.pred
         if int(self._ev_host[0]) or int(self._ev_host[1]):
+            # _apply_events may replace the topology and with it the per-edge output buffers:
+            # the caller gets this step's predictions on the PRE-event edge list, as the
+            # reference's loop does (test.py:383-426 keeps `pred` across Cmodel.update)
+            pred = dict(self.pred)
             events, switches = self._apply_events()
         if len(events) or len(switches):
             self._quiet_steps = 0
@@ -222,7 +245,7 @@ class GrainRollout:
         self.steps_done += 1
         self.grain_events.append(events)
         self.switched.append(switches)
-        return self.pred, events, switches
+        return pred, events, switches
 
     def _apply_events(self):
         """Host round trip: read the predictions back, rewire, upload the new lists."""
@@ -240,8 +263,12 @@ class GrainRollout:
         yj, yg = p["joint"].cpu().numpy(), p["grain"].cpu().numpy()
         ei_jj = self.edge_index[ET_JJ].cpu().numpy()
         ei_jg = self.edge_index[("joint", "pull", "grain")].cpu().numpy()
+        # the rewiring mutates its arguments in place: give it copies and commit masks, coordinates
+        # and edge lists together, so a TopologyError leaves the rollout at the pre-event state
+        mg, mj = self.mask["grain"].copy(), self.mask["joint"].copy()
         pp, pq, qp, switches, events = update_topology(
-            xj, ei_jj, ei_jg, yj, yg, prob, ge, self.mask["grain"], self.mask["joint"], self.edge_threshold)
+            xj, ei_jj, ei_jg, yj, yg, prob, ge, mg, mj, self.edge_threshold)
+        self.mask["grain"], self.mask["joint"] = mg, mj
         self.x["joint"].copy_(torch.from_numpy(xj))
         p["joint"].copy_(torch.from_numpy(yj))
         self._live_grain.copy_(torch.from_numpy(self.mask["grain"][:, 0].astype(np.int32)))
@@ -253,6 +280,8 @@ class GrainRollout:
 
     def step(self):
         """Advance one rollout step; returns the prediction dict (tensors are reused)."""
+        if self.steps_done % 16 == 0:
+            self.refresh_weights()
         if self.use_graph and self._graph_exec is None:
             self._graph_exec = self._capture()
         if self._graph_exec is not None:
@@ -267,6 +296,7 @@ class GrainRollout:
     def run(self, n_steps: int):
         """`n_steps` static-topology steps.  With hipGraph replay the bulk goes through a graph of
         RUN_UNROLL consecutive steps (same kernels, same order, same results as step() x n)."""
+        self.refresh_weights()
         if self.use_graph and n_steps >= self.RUN_UNROLL:
             if self._graph_multi is None:
                 self._graph_multi = self._capture(self.RUN_UNROLL)

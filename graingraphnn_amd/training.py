@@ -39,10 +39,12 @@ class TrainTopology:
             n_src, n_dst = graph.n_nodes[et[0]], graph.n_nodes[et[-1]]
             self.rcsr[et] = backend.build_csr(ei.flip(0).contiguous(), n_dst, n_src)
             E = csr.E
-            inv = torch.empty(max(E, 1), dtype=torch.int32, device=ei.device)
-            if E:
-                inv[csr.perm[:E].long()] = torch.arange(E, dtype=torch.int32, device=ei.device)
-            self.r_slot[et] = inv[self.rcsr[et].perm[:max(E, 1)].long()].contiguous()
+            if E == 0:  # an edge type without edges: the CSR's perm is an unwritten placeholder
+                self.r_slot[et] = torch.zeros(1, dtype=torch.int32, device=ei.device)
+                continue
+            inv = torch.empty(E, dtype=torch.int32, device=ei.device)
+            inv[csr.perm[:E].long()] = torch.arange(E, dtype=torch.int32, device=ei.device)
+            self.r_slot[et] = inv[self.rcsr[et].perm[:E].long()].contiguous()
 
 
 _topo_cache: Dict[int, TrainTopology] = {}

@@ -79,7 +79,30 @@ def rel_err(got, ref):
                  / max(float(np.abs(ref).max()), 1e-30))
 
 
-def assert_close(got, ref, what, rtol=RTOL):
+ATOL_REL = 1e-6  # elementwise floor, as a fraction of max|ref| ("away from zeros")
+
+
+def elementwise_excess(got, ref, rtol=RTOL, atol_rel=ATOL_REL):
+    """SURVEY 8(c)'s second check: allclose(rtol, atol = atol_rel * max|ref|) element by element.
+    Returns (worst ratio |a-b| / (atol + rtol |b|), flat index of that element); <= 1 passes."""
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    a, b = got.astype(np.float64).ravel(), ref.astype(np.float64).ravel()
+    if b.size == 0:
+        return 0.0, -1
+    bound = atol_rel * max(float(np.abs(b).max()), 1e-30) + rtol * np.abs(b)
+    ratio = np.abs(a - b) / bound
+    k = int(np.argmax(ratio))
+    return float(ratio[k]), k
+
+
+def assert_close(got, ref, what, rtol=RTOL, atol_rel=ATOL_REL):
+    """Both parity checks of SURVEY 8(c): per tensor max|a-b| <= rtol * max|b|, and element by
+    element |a-b| <= rtol |b| + atol_rel * max|b| (so small-magnitude entries of a tensor are held
+    to their own size down to a floor of 1e-6 of the tensor's largest entry)."""
     e = rel_err(got, ref)
     assert np.isfinite(e) and e <= rtol, f"{what}: max|a-b|/max|b| = {e:.3e} > {rtol:g}"
+    worst, k = elementwise_excess(got, ref, rtol, atol_rel)
+    assert np.isfinite(worst) and worst <= 1.0, (
+        f"{what}: element {k} misses allclose(rtol={rtol:g}, atol={atol_rel:g}*max|ref|) by x{worst:.2f}")
     return e

@@ -391,6 +391,42 @@ def test_cfg3_full_size_step_and_properties():
     assert float((sa - 1).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["two_streams_graph"])
+@torch.no_grad()
+def test_cfg3_ten_step_rollout_as_benched(mode):
+    """The exact step bench.py times (BASELINE config 3: 10k-grain honeycomb folded x10, weights
+    x0.3, R + C + update + grain-centre refresh through the global frame + edge refresh, hipGraph
+    replay), ten consecutive steps against the oracle: predictions of every step, then the state."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea, off = synthetic.honeycomb(100, 10, 0, return_offset=True)
+    R, Cm = product_models(0, 0.3, DEV)
+    oR, oC = oracle_models(0, 0.3)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ooff = torch.from_numpy(off)
+    kw = dict(concurrent=True)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=True, refresh_centres=True, domain_factor=10.0,
+                      domain_offset=ooff, **kw)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))   # the oracle's best setting on a many-core host
+    try:
+        worst = 0.0
+        for step in range(10):
+            pred = {k: v.clone() for k, v in ro.step().items()}
+            opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6, centres=(10.0, ooff))
+            for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+                worst = max(worst, assert_close(pred[k], opred[k], f"cfg3 step {step} {k}"))
+    finally:
+        torch.set_num_threads(threads)
+    assert_close(X["joint"], oX["joint"], "cfg3 10 steps x joint")
+    assert_close(X["grain"][:, 2:], oX["grain"][:, 2:], "cfg3 10 steps x grain[2:]")
+    d = (X["grain"][:, :2].cpu() - oX["grain"][:, :2]).abs()
+    assert float(torch.minimum(d, 1 - d).max()) < 1e-4   # frac() may land on either side of 0/1
+    for et in EDGE_TYPES:
+        assert_close(ro.edge_attr_dict()[et], oEA[et], f"cfg3 10 steps edge_attr {et}")
+    print(f"cfg3 10-step rollout ({mode}): worst per-tensor error {worst:.2e}")
+
+
 # ---------------------------------------------------------------------------------------
 # SURVEY 8f-1: on-device grain-centre refresh (graph.update() + test.py:556-559)
 # ---------------------------------------------------------------------------------------
@@ -495,10 +531,16 @@ def test_event_rollout_reproduces_reference_trajectory(use_graph):
     ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=use_graph, refresh_centres=True)
     ro.enable_events({"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}, 1e-4, 0.6)
     for step in range(1, 5):
+        n_edges_before = ro.edge_index[JJ].size(1)
         pred, events, switches = ro.step_events()
+        # the classifier outputs returned are THIS step's predictions on the PRE-event edge list
+        # (test.py:383-426 keeps `pred` across Cmodel.update), never fresh buffers of the new size
+        assert pred["edge_event"].numel() == n_edges_before and pred["edge"].shape == (n_edges_before, 2)
+        assert bool(torch.isfinite(pred["edge_event"]).all()) and float(pred["edge"].abs().max()) <= 1.0
         if step < 3:
             assert len(events) == 0 and len(switches) == 0
             continue
+        assert ro.edge_index[JJ].size(1) < n_edges_before
         name = f"mass{step}"
         assert events.tolist() == ev[name + "__out_grain_event"].tolist()
         for et in EDGE_TYPES:
@@ -603,6 +645,40 @@ def test_packed_weights_follow_parameter_updates():
     oy = oR(tt(x), tt(ei), tt(ea))
     for k in ("joint", "grain", "grain_area"):
         assert_close(y1[k], oy[k], f"updated-weights regressor {k}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@torch.no_grad()
+def test_rollout_follows_parameter_updates(use_graph):
+    """A GrainRollout packs the weights once and bakes their addresses into its hipGraphs; after
+    load_state_dict / an optimizer-style in-place update it must re-pack (checked by run() and by
+    refresh_weights()), not keep rolling out with the stale copy."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(5, 1.0, DEV)
+    R2, Cm2 = product_models(9, 1.0, DEV)
+    ro = GrainRollout(R, Cm, tt(x, DEV), tt(ei, DEV), tt(ea, DEV), 6, use_graph=use_graph)
+    ro.run(4)
+    R.load_state_dict(R2.state_dict())
+    Cm.load_state_dict(Cm2.state_dict())
+    X = tt(x, DEV)
+    ro.x["joint"].copy_(X["joint"]), ro.x["grain"].copy_(X["grain"])
+    for et in EDGE_TYPES:
+        ro.edge_attr[et].copy_(torch.from_numpy(ea[et]).view(-1))
+    ro.run(4)
+    ref = GrainRollout(R2, Cm2, X, tt(ei, DEV), tt(ea, DEV), 6, use_graph=False)
+    ref.run(4)
+    for nt in x:
+        assert torch.equal(ro.x[nt], ref.x[nt]), nt
+    name = "gclstm_decoder.cell_list.0.conv_c.convs.joint__connect__joint.lin_value.weight"
+    dict(R.named_parameters())[name].mul_(1.5)
+    before = ro.x["joint"].clone()
+    ro.refresh_weights()
+    ro.step()
+    dict(R2.named_parameters())[name].mul_(1.5)
+    ref.refresh_weights()
+    ref.step()
+    assert torch.equal(ro.x["joint"], ref.x["joint"]) and not torch.equal(ro.x["joint"], before)
 
 
 @torch.no_grad()

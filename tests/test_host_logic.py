@@ -30,6 +30,55 @@ def test_state_dict_layout_matches_reference():
     R.load_state_dict(oR.state_dict(), strict=True)
 
 
+def test_top_level_models_module_is_the_drop_in(tmp_path):
+    """test.py:16 / train.py:16 / dist_train.py:15 do `from models import GrainNN_regressor,
+    GrainNN_classifier`: with the repository root on sys.path (in a fresh interpreter, as the
+    reference's scripts run) that resolves to the HIP classes; test.py:177-188's construction,
+    .pt loading and threshold assignments work on them unchanged."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    oR, oC = oracle_models(3)
+    torch.save(oR.state_dict(), tmp_path / "regressor0.pt")
+    torch.save(oC.state_dict(), tmp_path / "classifier1.pt")
+    code = f"""
+import json, sys, torch
+sys.path.insert(0, {ROOT!r})
+from models import GrainNN_regressor, GrainNN_classifier          # test.py:16
+import models, graingraphnn_amd.models as hip
+assert models.GrainNN_regressor is hip.GrainNN_regressor and models.GrainNN_classifier is hip.GrainNN_classifier
+from graingraphnn_amd import synthetic
+hp = synthetic.default_hyper('cpu')
+Rmodel = GrainNN_regressor(hp)                                     # test.py:177-184
+Rmodel.load_state_dict(torch.load({str(tmp_path / 'regressor0.pt')!r}, map_location=torch.device('cpu')))
+Rmodel.eval()
+Cmodel = GrainNN_classifier(hp, Rmodel)
+Cmodel.load_state_dict(torch.load({str(tmp_path / 'classifier1.pt')!r}, map_location='cpu'))
+Cmodel.eval()
+Rmodel.threshold = 1e-4                                            # test.py:187-188
+Cmodel.threshold = 0.6
+keys = json.load(open({os.path.join(GOLDEN, 'keys.json')!r}))
+assert {{k: list(v.shape) for k, v in Rmodel.state_dict().items()}} == keys['regressor']
+assert {{k: list(v.shape) for k, v in Cmodel.state_dict().items()}} == keys['classifier']
+assert len(keys['regressor']) == len(keys['classifier']) == 284
+print('ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_sharding_refuses_empty_shards_on_every_rank():
+    """A rank that raised alone would leave the others blocked in the all-gather."""
+    from graingraphnn_amd.dist import rollout_trajectories, run_sharded
+    for rank in range(4):
+        with pytest.raises(ValueError, match="more ranks"):
+            run_sharded(3, lambda t: torch.zeros(2), rank, 4)
+    with pytest.raises(ValueError, match="no trajectories"):
+        run_sharded(0, lambda t: torch.zeros(2), 0, 1)
+    with pytest.raises(ValueError, match="more ranks"):
+        rollout_trajectories(None, None, [None], 6, 1, rank=0, world=2)
+
+
 def test_classifier_deepcopies_regressor_cells():
     """models.py:551-552."""
     from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor

@@ -218,6 +218,71 @@ def test_bf16_autocast_training_step_stays_close_to_fp32():
     assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
 
 
+BF16_GTOL = 8e-2   # bf16 autocast: 8 significand bits (unit roundoff 2^-9) through the stacked
+#                     linears of two cells; per-tensor gradient error against the fp32 oracle
+
+
+@pytest.mark.gpu
+def test_cfg5_collated_minibatch_fp32_and_bf16_against_the_fp32_oracle():
+    """BASELINE config 5 as a config: a mini-batch of 4 graphs collated into one disjoint-union
+    graph with offset indices (what train.py:365-366's DataLoader(batch_size=4) hands the model),
+    (1) fp32 losses and all 568 parameter gradients against the oracle's autograd at 2e-4;
+    (2) the same under torch.autocast(bf16) against the FP32 oracle with the bf16 bound above;
+    (3) two Adam steps of the reference's loop (train.py:82, 158-166), fp32 and bf16."""
+    from graingraphnn_amd import synthetic
+    x0, ei0, ea0 = load_graph("40")
+    x, ei, ea, _ = synthetic.disjoint_union(
+        [(synthetic.perturbed_copy(x0, 1e-3, 1000 + t), ei0, ea0) for t in range(4)])
+    assert x["grain"].shape[0] == 4 * x0["grain"].shape[0]
+    R, Cm = product_models(10020, 1.0, "cuda")
+    oR, oC = oracle_models(10020, 1.0)
+    olr, olc, ref = _grads(oR, oC, x, ei, ea)
+    lr, lc, grads = _grads(R, Cm, x, ei, ea, "cuda")
+    assert abs(lr - olr) <= 1e-5 * abs(olr) and abs(lc - olc) <= 1e-5 * abs(olc)
+    worst32 = _check_full(grads, ref)
+    # (2) bf16 autocast (library GEMMs in bf16, the sweep and the attention logits in fp32)
+    y_np, m_np = _targets(x, ei)
+    y, mask = tt(y_np, "cuda"), tt(m_np, "cuda")
+    X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
+    R.zero_grad(), Cm.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        blr = training.regressor_loss(y, R(X, EI, EA), mask)
+        blc = training.classifier_loss(y, Cm(X, EI, EA), 1.0)
+    blr.backward()
+    blc.backward()
+    assert abs(float(blr) - olr) <= 2e-2 * abs(olr) and abs(float(blc) - olc) <= 2e-2 * abs(olc)
+    worst16 = 0.0
+    for tag, m in (("R", R), ("C", Cm)):
+        gmax = max(float(ref[f"{tag}/{n}"].abs().max()) for n, _ in m.named_parameters())
+        for name, p in m.named_parameters():
+            g, r = p.grad, ref[f"{tag}/{name}"]
+            assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()), name
+            err, scale = float((g.cpu() - r).abs().max()), float(r.abs().max())
+            # floor: tensors whose exact gradient is tiny next to the model's largest one
+            assert err <= BF16_GTOL * scale + 2e-3 * gmax, (tag, name, err, scale)
+            if scale > 1e-2 * gmax:
+                worst16 = max(worst16, err / scale)
+    print(f"cfg5 batch of 4: worst per-tensor gradient error fp32 {worst32:.2e}, bf16 autocast {worst16:.2e}")
+    # (3) two Adam steps, as train.py does them
+    for autocast, tol in ((False, 1e-3), (True, 5e-2)):
+        Rt, _ = product_models(4, 1.0, "cuda")
+        oRt, _ = oracle_models(4, 1.0)
+        for m, dev in ((Rt, "cuda"), (oRt, "cpu")):
+            m.train()
+            opt = torch.optim.Adam(m.parameters(), lr=5e-3)          # parameters.py:18-50 regressor lr
+            for _ in range(2):
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast and dev == "cuda"):
+                    loss = training.regressor_loss(tt(y_np, dev), m(tt(x, dev), tt(ei, dev), tt(ea, dev)), tt(m_np, dev))
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+        for (n, p), (_, q) in zip(Rt.named_parameters(), oRt.named_parameters()):
+            # Adam's first steps move every weight by ~lr whatever the gradient's size, so a sign
+            # flip of a near-zero gradient shows up as 2 lr: bound in units of lr for bf16
+            bound = tol * max(float(q.abs().max()), 1e-3) if not autocast else 2.5 * 5e-3 * 2
+            assert float((p.cpu() - q).abs().max()) <= bound, (autocast, n)
+
+
 @pytest.mark.gpu
 def test_ddp_over_rccl_as_the_reference_wraps_it():
     """dist_train.py:79-82 on one GPU: init_process_group('nccl') + DistributedDataParallel(model,
@@ -248,6 +313,66 @@ def test_ddp_over_rccl_as_the_reference_wraps_it():
             assert torch.equal(p.grad, ref[n]), n
     finally:
         dist.destroy_process_group()
+
+
+def _ddp_gpu_worker(rank, world, port, out):
+    """One of two ranks that share cuda:0 (the GPU box has one device and RCCL refuses two ranks
+    per device, so the process group is gloo; DistributedDataParallel, the bucketed gradient
+    all-reduce and the HIP training path are the ones an 8-GPU RCCL job runs)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.set_num_threads(1)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graingraphnn_amd import synthetic
+        x0, ei0, ea0 = load_graph("40")
+        x, ei, ea, _ = synthetic.disjoint_union(
+            [(synthetic.perturbed_copy(x0, 1e-3, 2000 + 4 * rank + t), ei0, ea0) for t in range(4)])
+        y_np, m_np = _targets(x, ei)
+        R, _ = product_models(4, 1.0, "cuda")
+        R.train()
+        model = DistributedDataParallel(R, device_ids=[0])
+        X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
+        for _ in range(2):
+            model.zero_grad()
+            training.regressor_loss(tt(y_np, "cuda"), model(X, EI, EA), tt(m_np, "cuda")).backward()
+        if rank == 0:
+            torch.save({n: p.grad.cpu() for n, p in R.named_parameters()}, out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_ddp_on_the_hip_path_averages_minibatch_gradients(tmp_path):
+    """dist_train.py:76-91 with two ranks: each rank gets its own collated mini-batch of 4 graphs
+    (DistributedSampler), DDP averages the gradients; reference = mean of the oracle's
+    single-process gradients of the two mini-batches."""
+    import socket
+    import torch.multiprocessing as mp
+    from graingraphnn_amd import synthetic
+    x0, ei0, ea0 = load_graph("40")
+    ref = None
+    for rank in range(2):
+        x, ei, ea, _ = synthetic.disjoint_union(
+            [(synthetic.perturbed_copy(x0, 1e-3, 2000 + 4 * rank + t), ei0, ea0) for t in range(4)])
+        y_np, m_np = _targets(x, ei)
+        oR, _ = oracle_models(4, 1.0)
+        oR.train()
+        training.regressor_loss(tt(y_np), oR(tt(x), tt(ei), tt(ea)), tt(m_np)).backward()
+        g = {n: p.grad.clone() for n, p in oR.named_parameters()}
+        ref = g if ref is None else {n: 0.5 * (ref[n] + g[n]) for n in g}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_ddp_gpu_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    atol = 1e-6 * max(float(g.abs().max()) for g in ref.values())
+    for n, g in ref.items():
+        assert float((got[n] - g).abs().max()) <= GTOL * float(g.abs().max()) + atol, n
 
 
 @pytest.mark.gpu
