@@ -79,7 +79,12 @@ def rel_err(got, ref):
                  / max(float(np.abs(ref).max()), 1e-30))
 
 
-ATOL_REL = 1e-6  # elementwise floor, as a fraction of max|ref| ("away from zeros")
+# Elementwise floor, as a fraction of max|ref| ("away from zeros").  The
+# alternate arithmetic path GGNN_GEMM=fp32 (native v_mfma_f32_16x16x4_f32 chains: 104 sequential
+# fp32 roundings per dot product where the default split path has 24) measures 2.6x the GEMM error
+# of the default path (test_gemm_arithmetic_is_fp32_equivalent: 7.0e-7 vs 2.7e-7 of sum|x||w|);
+# outputs that are small because O(0.1) terms cancel carry that noise, so its floor is 3x wider.
+ATOL_REL = 3e-6 if os.environ.get("GGNN_GEMM") == "fp32" else 1e-6
 
 
 def elementwise_excess(got, ref, rtol=RTOL, atol_rel=ATOL_REL):
