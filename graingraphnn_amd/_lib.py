@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 12
+GGNN_ABI_VERSION = 13
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
-    "ggnn_lstm_epilogue", "ggnn_heads_regressor",
+    "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -132,6 +132,8 @@ def _declare(lib):
     lib.ggnn_period_gat_aggregate_backward.argtypes = [POINTER(AggregateBwdArgs), c_void_p]
     lib.ggnn_lstm_epilogue.restype = c_int
     lib.ggnn_lstm_epilogue.argtypes = [POINTER(EpilogueArgs), c_void_p]
+    lib.ggnn_lstm_epilogue_batch.restype = c_int
+    lib.ggnn_lstm_epilogue_batch.argtypes = [POINTER(EpilogueArgs), c_int, c_void_p]
     lib.ggnn_heads_regressor.restype = c_int
     lib.ggnn_heads_regressor.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -182,11 +182,10 @@ class HipBackend:
         return g_p_dst, g_p_src, g_h_src, ep_partial.sum(0)
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
-    def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
-                      w2_planes=None, g_stride=0):
-        """w2_planes: packing.bf16_planes(w2) (selects the bf16x6 kernel unless GGNN_GEMM=fp32)."""
+    @staticmethod
+    def _epilogue_args(a, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
+                       w2_planes=None, g_stride=0):
         _require_cuda(agg, w2, p_dst, c_in, h_out, c_out, raw_out, w2_planes)
-        a = EpilogueArgs()
         a.agg, a.w2, a.p_dst = agg.data_ptr(), w2.data_ptr(), p_dst.data_ptr()
         a.c_in = None if c_in is None else c_in.data_ptr()
         a.h_out = None if h_out is None else h_out.data_ptr()
@@ -200,7 +199,22 @@ class HipBackend:
             if w2_planes.dtype != torch.int16 or w2_planes.numel() != 3 * w2.size(0) * _lib.GGNN_C * (w2.size(2) - 4):
                 raise _lib.GGNNError("w2_planes does not match w2 (see packing.bf16_planes)")
             a.w2_planes = w2_planes.data_ptr()
+
+    def lstm_epilogue(self, *problem, **kw):
+        """(agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode, w2_planes=None, g_stride=0);
+        w2_planes: packing.bf16_planes(w2) (selects the bf16x6 kernel unless GGNN_GEMM=fp32)."""
+        a = EpilogueArgs()
+        self._epilogue_args(a, *problem, **kw)
         self._launch(self.lib.ggnn_lstm_epilogue, "ggnn_lstm_epilogue", ctypes.byref(a), _lib.current_stream())
+
+    def lstm_epilogue_batch(self, problems):
+        """Up to four gate GEMM + LSTM problems (node types of a cell and / or both models) in one
+        launch (ggnn_lstm_epilogue_batch); each item is the argument tuple of `lstm_epilogue`."""
+        arr = (EpilogueArgs * len(problems))()
+        for a, prob in zip(arr, problems):
+            self._epilogue_args(a, *prob)
+        self._launch(self.lib.ggnn_lstm_epilogue_batch, "ggnn_lstm_epilogue_batch", arr, len(problems),
+                     _lib.current_stream())
 
     # -- heads -------------------------------------------------------------------------
     def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):

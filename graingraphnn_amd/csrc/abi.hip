@@ -15,6 +15,17 @@ int ggnn::gemm_mode() {
 }
 extern "C" int ggnn_gemm_mode(void) { return ggnn::gemm_mode(); }
 
+int ggnn::num_cu() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;  // MI355X
+    return v;
+  }();
+  return n;
+}
+
 extern "C" const char* ggnn_error_string(int code) {
   switch (code) {
     case GGNN_OK: return "ok";

@@ -68,7 +68,6 @@ constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;
 #define AG_VAR_BPC_NOH 6
 #endif
 constexpr int AG_BLOCKS_PER_CU_NOH = AG_VAR_BPC_NOH;  // encoder sweep (no hidden rows, 78 VGPRs): 4 -> 47.5 us, 5 -> 46.5, 6 -> 46, 7 -> 51
-constexpr int AG_NUM_CU = 256;
 constexpr int UE = GGNN_UNIT_EDGES;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -416,7 +415,7 @@ extern "C" int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, 
     want = std::max<int64_t>(want, (B.a[k].n_dst + 3) / 4);
   }
   // persistent grid: at least 4 rows per workgroup, at most the resident capacity
-  const int64_t cap = (int64_t)AG_NUM_CU * (has_h ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH);
+  const int64_t cap = (int64_t)num_cu() * (has_h ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH);
   const dim3 grid((unsigned)(want < cap ? want : cap));
   hipStream_t s = (hipStream_t)stream;
 #define GGNN_AG_LAUNCH(G_)                                                                   \

@@ -16,6 +16,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 3 x bf16 split kernels.  Read once per process.
 int gemm_mode();
 
+// Compute units of the current device (256 on MI355X), queried once per process: sizes the
+// persistent / one-round grids.  Affects speed only.
+int num_cu();
+
 static inline int launch_status() {
   return hipGetLastError() == hipSuccess ? GGNN_OK : GGNN_ELAUNCH;
 }

@@ -33,7 +33,6 @@ constexpr int GT_MAXG = 5;    // row groups per workgroup, upper bound (15 waves
 constexpr int GT_MING = 3;    // ... lower bound (sizes the weight staging registers: 5 pieces per lane)
 constexpr int GT_KC = 100;    // K chunk per pass (Ka = 196 -> 100 + 96, Ka = 100 -> 100)
 constexpr int GT_LD = GT_KC + 2;
-constexpr int GT_NUM_CU = 256;
 
 template <int G, int MODE, int KA>
 __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epilogue_args A) {
@@ -181,12 +180,11 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
 
 }  // namespace ggnn
 
-int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args& A, hipStream_t s);
+int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args* args, int n, hipStream_t s);
 
-extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream) {
-  using namespace ggnn;
-  if (!args) return GGNN_EINVAL;
-  ggnn_epilogue_args A = *args;
+namespace ggnn {
+// Argument checks of one gate-GEMM problem; normalises the packed agg layout.
+static int check_epilogue(ggnn_epilogue_args& A) {
   if (!A.agg || !A.w2 || !A.p_dst || A.N <= 0) return GGNN_EINVAL;
   if (A.g_stride == 0 && A.ld_agg == 0) {  // packed layout
     A.g_stride = A.Ka;
@@ -194,48 +192,73 @@ extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t 
   }
   if (A.g_stride < A.Ka || (A.g_stride & 3) || (A.ld_agg & 3) || A.ld_agg < (int64_t)A.n_gates * A.g_stride)
     return GGNN_EINVAL;
-  if (A.Ka < 4 || (A.Ka & 3) || A.Ka > 2 * GT_KC) return GGNN_EINVAL;
+  if (A.Ka != 196 && A.Ka != 100) return GGNN_EINVAL;  // two / one incoming edge types (packing.py)
   const int G = A.n_gates;
   if (A.s_off < 0 || (A.s_off & 3) || (A.ldp & 3) || A.s_off + (int64_t)G * C > A.ldp) return GGNN_EINVAL;
   if (!aligned16(A.agg) || !aligned16(A.w2) || !aligned16(A.p_dst)) return GGNN_EINVAL;
+  if (A.w2_planes && !aligned16(A.w2_planes)) return GGNN_EINVAL;
+  if (A.mode == GGNN_MODE_LSTM) {
+    if (G != 4 || !A.c_in || !A.h_out || !A.c_out) return GGNN_EINVAL;
+    if (!aligned16(A.c_in) || !aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
+  } else if (A.mode == GGNN_MODE_LSTM_H0) {
+    if (G != 3 || !A.h_out || !A.c_out) return GGNN_EINVAL;
+    if (!aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
+  } else if (A.mode == GGNN_MODE_RAW) {
+    if (!A.raw_out || !aligned16(A.raw_out)) return GGNN_EINVAL;
+    if (G != 4 && G != 3 && G != 1) return GGNN_EINVAL;
+  } else {
+    return GGNN_EINVAL;
+  }
+  return GGNN_OK;
+}
+
+// native fp32 MFMA kernel, one problem
+static int launch_fp32(const ggnn_epilogue_args& A, hipStream_t s) {
   // row groups per workgroup: one round of workgroups, at most one per CU (2..5 groups)
+  const int G = A.n_gates;
   const int64_t n16 = (A.N + GT_BM - 1) / GT_BM;
-  int64_t ng = (n16 + GT_NUM_CU - 1) / GT_NUM_CU;
+  int64_t ng = (n16 + num_cu() - 1) / num_cu();
   ng = ng < GT_MING ? GT_MING : (ng > GT_MAXG ? GT_MAXG : ng);
   const int64_t nblk = (n16 + ng - 1) / ng;
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
   const dim3 grid((unsigned)nblk), block((unsigned)(192 * ng));
-  hipStream_t s = (hipStream_t)stream;
-  if (A.Ka != 196 && A.Ka != 100) return GGNN_EINVAL;  // two / one incoming edge types (packing.py)
   const bool wide = A.Ka == 196;
-  const bool x6 = A.w2_planes && gemm_mode() == GGNN_GEMM_BF16X6;
-  if (x6 && !aligned16(A.w2_planes)) return GGNN_EINVAL;
 #define GGNN_GT_LAUNCH(G_, MODE_)                                                         \
   do {                                                                                    \
     if (wide) hipLaunchKernelGGL((gates_kernel<G_, MODE_, 196>), grid, block, 0, s, A);   \
     else hipLaunchKernelGGL((gates_kernel<G_, MODE_, 100>), grid, block, 0, s, A);        \
   } while (0)
-  if (A.mode == GGNN_MODE_LSTM) {
-    if (G != 4 || !A.c_in || !A.h_out || !A.c_out) return GGNN_EINVAL;
-    if (!aligned16(A.c_in) || !aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
-    if (x6) return ggnn_lstm_epilogue_x6(A, s);
-    GGNN_GT_LAUNCH(4, GGNN_MODE_LSTM);
-  } else if (A.mode == GGNN_MODE_LSTM_H0) {
-    if (G != 3 || !A.h_out || !A.c_out) return GGNN_EINVAL;
-    if (!aligned16(A.h_out) || !aligned16(A.c_out)) return GGNN_EINVAL;
-    if (x6) return ggnn_lstm_epilogue_x6(A, s);
-    GGNN_GT_LAUNCH(3, GGNN_MODE_LSTM_H0);
-  } else if (A.mode == GGNN_MODE_RAW) {
-    if (!A.raw_out || !aligned16(A.raw_out)) return GGNN_EINVAL;
-    if (G != 4 && G != 3 && G != 1) return GGNN_EINVAL;
-    if (x6) return ggnn_lstm_epilogue_x6(A, s);
-    if (G == 4) GGNN_GT_LAUNCH(4, GGNN_MODE_RAW);
-    else if (G == 3) GGNN_GT_LAUNCH(3, GGNN_MODE_RAW);
-    else if (G == 1) GGNN_GT_LAUNCH(1, GGNN_MODE_RAW);
-    else return GGNN_EINVAL;
-  } else {
-    return GGNN_EINVAL;
-  }
+  if (A.mode == GGNN_MODE_LSTM) GGNN_GT_LAUNCH(4, GGNN_MODE_LSTM);
+  else if (A.mode == GGNN_MODE_LSTM_H0) GGNN_GT_LAUNCH(3, GGNN_MODE_LSTM_H0);
+  else if (G == 4) GGNN_GT_LAUNCH(4, GGNN_MODE_RAW);
+  else if (G == 3) GGNN_GT_LAUNCH(3, GGNN_MODE_RAW);
+  else GGNN_GT_LAUNCH(1, GGNN_MODE_RAW);
 #undef GGNN_GT_LAUNCH
   return launch_status();
+}
+}  // namespace ggnn
+
+extern "C" int ggnn_lstm_epilogue_batch(const ggnn_epilogue_args* args, int n_problems, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_problems < 1 || n_problems > 4) return GGNN_EINVAL;
+  ggnn_epilogue_args A[4];
+  bool x6 = gemm_mode() == GGNN_GEMM_BF16X6;
+  for (int k = 0; k < n_problems; ++k) {
+    A[k] = args[k];
+    const int rc = check_epilogue(A[k]);
+    if (rc != GGNN_OK) return rc;
+    if (A[k].mode != A[0].mode || A[k].n_gates != A[0].n_gates) return GGNN_EINVAL;
+    x6 = x6 && A[k].w2_planes != nullptr;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (x6) return ggnn_lstm_epilogue_x6(A, n_problems, s);
+  for (int k = 0; k < n_problems; ++k) {
+    const int rc = launch_fp32(A[k], s);
+    if (rc != GGNN_OK) return rc;
+  }
+  return GGNN_OK;
+}
+
+extern "C" int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream) {
+  return ggnn_lstm_epilogue_batch(args, 1, stream);
 }

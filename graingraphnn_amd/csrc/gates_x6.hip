@@ -3,256 +3,327 @@
 // trailing rank-1 columns (sum alpha, sum alpha*a per incoming edge type) on one exact
 // v_mfma_f32_16x16x4_f32.  Same contract as gates_kernel (gates.hip):
 //   pre[g] = agg[:, g, 0:Ka] . W2[g]^T + skip[g];  LSTM cell of heteropgclstm.py:111-146.
-// Matrix-pipe cycles per 16x16 tile and gate: 6 x 6 x 16 + 32 = 608 instead of 49 x 32 = 1568,
-// which moves the kernel from the matrix pipe to the HBM stream of its `agg` operand.
 //
-// Structure: WEIGHT-STATIONARY, no workgroup barrier after the prologue (the pass-and-barrier
-// structure of gates.hip spent more time in barriers and pipeline refills than in MFMAs).
-//   * A workgroup owns a 32-channel slice (16 channels on small graphs, see GX slices below) for ALL gates and the whole reduction: its weights,
-//     already split into bf16 planes in MFMA fragment order by the host-side packing
-//     (ggnn_epilogue_args.w2_planes), are copied once into LDS (G x 6 k-steps x 3 planes x 2 column
-//     tiles x 1 KB = 144 KB at G = 4, Ka = 196) and read back lane-linearly (conflict-free).
-//   * A wave owns 16 nodes x those 32 channels (accumulators for all gates in registers, so the
-//     LSTM update needs no exchange) and streams the nodes' `agg` rows: per (gate, k-step) a lane
-//     loads the 32 bytes of its MFMA B fragment (node l&15, k = 32 ks + 8 (l>>4)..) straight into
-//     registers, GX_DEPTH steps ahead, and splits them into planes when their turn comes.
-//   * A wave processes T (1 or 2) node tiles as ONE unrolled stream of T x G x 6 steps, so the
-//     prefetch runs across the tile boundary and every wait is an exact counted vmcnt (a runtime
-//     tile loop would drain vmcnt to 0 at its header: project_x6.hip).
-//   * The three channel slices of a node range read the same `agg` rows; they are given the same
-//     XCD (workgroup id mod 8) and neighbouring dispatch slots, so two of the three reads hit L2.
+// Structure (round 2; the round-1 kernel kept a 32-channel weight slice per workgroup, so three
+// workgroups each re-read and re-split the same `agg` rows: 3 460 VALU against 584 MFMA
+// instructions per wave, matrix pipe 30 % busy):
+//   * the gates are INDEPENDENT GEMMs (gate g reads only agg[:, g, :]), so the unit of work is a
+//     JOB = (16-node tile, gate): one wave reads the tile's 16 x Ka aggregate block of that gate
+//     ONCE from memory, splits every fragment ONCE (48 VALU) and uses it against all 96 output
+//     channels (36 MFMAs per fragment instead of 12).  5 000 jobs of 216 MFMAs at cfg3 spread
+//     evenly over the 1 024 SIMDs (a whole tile x 4 gates per wave would not: 1 250 tiles);
+//   * a workgroup (one per CU; 8 waves at G = 4: 2 tile slots x 4 gates, 6 waves at G = 3) =
+//     SLOTS tile slots x G gates, up to three tiles per wave and pass; wave w = (gate w % G,
+//     slot w / G), so with 5 tiles per workgroup the two waves of a SIMD carry 3 + 2 jobs.  Two
+//     waves per SIMD leave each wave 256 VGPRs: 72 accumulators, a 48-register `agg` ring and 36
+//     weight-staging registers fit without spilling (a 12-wave variant at 168 VGPRs spilled 200);
+//   * the weights (442 KB of bf16 planes at G = 4, Ka = 196: more than the LDS) are STREAMED:
+//     k-step slice s of all gates (G x 18 KB, fragment order, ggnn_epilogue_args.w2_planes) sits in
+//     one half of a double buffer while every wave stages its share of slice s + 1 through
+//     registers (plain loads from L2 at the top of the k-step, ds_write_b128 at its end), one
+//     workgroup barrier per k-step.  Plain loads, not LDS-DMA: the wave's `agg` prefetch shares
+//     the vmcnt queue with them and the compiler only emits counted waits for plain loads;
+//   * `agg` fragments are prefetched two k-steps ahead (ring of two register sets per tile);
+//   * the LSTM update needs all gates of a (node, channel): the waves leave their 16 x 96
+//     pre-activation blocks in LDS (the weight buffers are free by then; rows padded to 100 floats:
+//     conflict-free ds_write_b128 from the MFMA D layout), and after one barrier every thread
+//     handles whole (node, 4-channel) quads: c_in is read and h / c written as contiguous
+//     384-byte rows (the D layout would touch 64-byte pieces).  The accumulators START from the
+//     skip / bias term (loaded in the D layout in the prologue), so the LSTM phase needs no
+//     side input but c_in, whose loads are issued before the last k-step of the pass.
+//   * up to four problems (node types x models) per launch: workgroups are dealt to the problems
+//     in proportion to their MFMA work (ggnn_lstm_epilogue_batch).
+#include <algorithm>
+
 #include "common.h"
 
 namespace ggnn {
 
-constexpr int GX_BM = 16;     // nodes per wave tile
-constexpr int GX_WAVES = 8;   // waves per workgroup (two per SIMD)
-// Channel slices: NCT column tiles of 16 channels per workgroup, 6 / NCT slices.  NCT = 2 (three
-// 32-channel slices) reads `agg` three times; NCT = 1 (six 16-channel slices) reads it six times but
-// halves the LDS fill and the MFMA chain per step and doubles the workgroups: used while the graph
-// is too small to give every CU a workgroup (cfg2, 2 086 joints: 0.180 -> 0.169 ms per rollout step).
-// (gate, k-step) steps of `agg` in flight per wave.  Measured (MI355X, 20 000 joints, isolated
-// launches): G = 4: 48 us at depth 4..8, 60 at 12; G = 3: 46 / 39 / 74 / 36 us at 4 / 6 / 8 / 12.
-constexpr int gx_depth(int G) { return G == 3 ? 12 : 8; }
+constexpr int gw_waves(int G) { return G == 3 ? 6 : 8; }  // two per SIMD (G = 3: 2, 2, 1, 1)
+constexpr int GW_BM = 16;      // nodes per tile
+constexpr int GW_TMAX = 3;     // tiles per wave and pass
+constexpr int GW_PRE_LD = 100; // floats per node row of the pre-activation exchange image
+constexpr int GW_LDS_BYTES = 8 * GW_TMAX * GW_BM * GW_PRE_LD * 4;  // 153 600 (>= 2 x 4 x 18 KB of weight slices)
+constexpr int GW_MAX_PROBLEMS = 4;
 
-template <int G, int MODE, int KA, int T, int NCT>
-__global__ __launch_bounds__(GX_WAVES * 64, 1) void gates_x6_kernel(const ggnn_epilogue_args A, int n_ranges) {
-  constexpr int GX_SLICES = 6 / NCT;
-  constexpr int SW = 16 * NCT;  // channels per slice
-  constexpr int KM = KA - 4;    // columns on the bf16 path (192 / 96)
-  constexpr int NKS = KM / 32;  // k-steps per gate (6 / 3)
-  constexpr int NSTEP = G * NKS;
-  constexpr int GX_DEPTH = gx_depth(G);
-  constexpr int NPIECE = NSTEP * 3 * NCT * 64;  // 16-byte weight pieces of one slice
-  static_assert(KM % 32 == 0, "Ka - 4 must be a multiple of 32");
-  __shared__ u32x4 s_w[NPIECE];
+struct GateBatch {
+  ggnn_epilogue_args a[GW_MAX_PROBLEMS];
+  int wg_off[GW_MAX_PROBLEMS + 1];  // first workgroup of every problem
+  int tpw[GW_MAX_PROBLEMS];         // tiles per workgroup
+  int n;
+};
+
+// All global traffic of the kernel goes through raw buffer instructions: a wave-uniform resource
+// (base in SGPRs) + a 32-bit lane offset + a wave-uniform scalar offset.  With plain pointers hipcc
+// formed one 64-bit VGPR address per (weight piece, k-step) and per fragment load, hoisted all of
+// them to the top of the kernel and spilled 200 registers.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);  // raw, no bounds clamp in range
+}
+__device__ __forceinline__ u32x4 bld128(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ f32x4 bld128f(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4, bld128(r, voff, soff));
+}
+__device__ __forceinline__ float bld32f(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst128f(rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
+}
+
+// One workgroup = one pass over tiles [mt_lo, mt_hi), mt_hi - mt_lo <= SLOTS * GW_TMAX.
+template <int G, int MODE, int KA>
+__device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t mt_lo, int64_t mt_hi,
+                                           u32x4* __restrict__ smem) {
+  constexpr int KM = KA - 4;                 // columns on the bf16 path (192 / 96)
+  constexpr int NKS = KM / 32;               // k-steps (6 / 3)
+  constexpr int GW_WAVES = gw_waves(G), GW_THREADS = GW_WAVES * 64;
+  constexpr int SLOTS = GW_WAVES / G;        // tile slots
+  constexpr int TP = SLOTS * GW_TMAX;        // tiles per workgroup, at most
+  constexpr int NPIECE = G * 18;             // 1 KB pieces of one k-step slice: [gate][plane 3][column tile 6]
+  constexpr int PPW = (NPIECE + GW_WAVES - 1) / GW_WAVES;  // pieces a wave stages per k-step
+  constexpr int SLICE = NPIECE * 64;         // u32x4 per slice
+  static_assert(KM % 32 == 0 && GW_WAVES % G == 0, "shape");
+  static_assert(2 * SLICE * 16 <= GW_LDS_BYTES && TP * G * GW_BM * GW_PRE_LD * 4 <= GW_LDS_BYTES, "LDS");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-#ifdef GX_VAR_CLOCK
-  const uint64_t tr_start = __builtin_amdgcn_s_memrealtime();
-#endif
-  // workgroup -> (node range, channel slice): the slices of a range share blockIdx mod 8 (= XCD)
-  const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-  const int slice = j % GX_SLICES, range = (j / GX_SLICES) * 8 + xcd;
-  if (range >= n_ranges) return;
-  const int64_t ld_agg = A.ld_agg;
-  const int gs_ = A.g_stride;
+  const int g = wave % G, slot = wave / G;
+  const int64_t m_last = max(A.N - GW_BM, (int64_t)0);   // a ragged last tile slides back (identical duplicate stores)
+  const int row_l = (int)min((int64_t)lr, A.N - 1);      // N < 16: clamp the lane's row instead
+  float* __restrict__ pre = reinterpret_cast<float*>(smem);
+  const int n_t = (int)(mt_hi - mt_lo);                  // tiles of this workgroup; tile j -> slot j % SLOTS, t = j / SLOTS
+  const int nt_w = (n_t > slot ? 1 : 0) + (n_t > slot + SLOTS ? 1 : 0) + (n_t > slot + 2 * SLOTS ? 1 : 0);
+  const int64_t row0 = min(mt_lo * GW_BM, m_last);       // first row of the workgroup: every offset below is relative to it
+  const uint32_t ld_agg = (uint32_t)A.ld_agg, ldp = (uint32_t)A.ldp;
 
-  // ---- prologue: this slice's weight planes -> LDS (a linear copy per (gate, k-step, plane)) ----
-  {
-    const u32x4* wpl = reinterpret_cast<const u32x4*>(A.w2_planes);
-    constexpr int NIT = (NPIECE + GX_WAVES * 64 - 1) / (GX_WAVES * 64);
-    u32x4 wreg[NIT];  // all loads first: one L2 round trip, not one per piece
+  const rsrc_t r_w = make_rsrc(A.w2_planes), r_w2 = make_rsrc(A.w2);
+  const rsrc_t r_agg = make_rsrc(A.agg + row0 * A.ld_agg), r_skip = make_rsrc(A.p_dst + row0 * A.ldp + A.s_off);
+  // lane offsets (bytes) inside a tile; a tile's first row and the gate go into the scalar offset
+  const uint32_t lo_agg = (uint32_t)row_l * ld_agg * 4u + 32u * kq;
+  const uint32_t lo_tail = (uint32_t)row_l * ld_agg * 4u + 4u * kq;
+  const uint32_t lo_skip = (uint32_t)row_l * ldp * 4u + 16u * kq;
+  const uint32_t lo_lane = 16u * lane;
+  // absent tiles repeat the wave's first tile (or the workgroup's first): their loads hit L1, their MFMAs are skipped
+  uint32_t so_agg[GW_TMAX], so_skip[GW_TMAX];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = min(tid + it * GX_WAVES * 64, NPIECE - 1), gkp = idx / (NCT * 64), rem = idx % (NCT * 64);  // NCT column tiles x 64 lanes
-      wreg[it] = wpl[((int64_t)gkp * 6 + NCT * slice) * 64 + rem];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      if (tid + it * GX_WAVES * 64 < NPIECE) s_w[tid + it * GX_WAVES * 64] = wreg[it];
+  for (int t = 0; t < GW_TMAX; ++t) {
+    const int j = t < nt_w ? slot + t * SLOTS : (nt_w ? slot : 0);
+    const uint32_t dm = (uint32_t)(min((mt_lo + j) * GW_BM, m_last) - row0);
+    so_agg[t] = (dm * ld_agg + (uint32_t)(g * A.g_stride)) * 4u;
+    so_skip[t] = (dm * ldp + (uint32_t)(g * C)) * 4u;
   }
-  // operands of the exact fp32 tail (columns KM .. KM+3): weight side, 16x16x4 fragment layout
-  float wt[G][NCT];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int a = 0; a < NCT; ++a) wt[g][a] = A.w2[((int64_t)g * C + slice * SW + a * 16 + lr) * KA + KM + kq];
-  __syncthreads();  // the only workgroup barrier
-#ifdef GX_VAR_CLOCK
-  const uint64_t tr_pro = __builtin_amdgcn_s_memrealtime();
-#endif
 
-  // ---- this wave's T node tiles; a ragged last tile slides back (identical duplicate stores) ----
-  const int64_t n_mt = (A.N + GX_BM - 1) / GX_BM;
-  const int64_t m_last = max(A.N - GX_BM, (int64_t)0);
-  const int row_l = (int)min((int64_t)lr, A.N - 1);  // N < 16: clamp the lane's row instead
-  int64_t m0[T];
+  // the pieces of a slice this wave stages: piece q = (gate gq, r = plane * 6 + column tile) of k-step
+  // ks is the 1 KB at w2_planes + (((gq * NKS + ks) * 18 + r) * 64 + lane) * 16; surplus slots
+  // repeat the last piece (same bytes to the same place)
+  u32x4 stage[PPW];
+  auto stage_load = [&](int ks) {
 #pragma unroll
-  for (int t = 0; t < T; ++t)
-    m0[t] = min(min(((int64_t)range * T + t) * GX_WAVES + wave, n_mt - 1) * GX_BM, m_last);
-
-#ifdef GX_VAR_NOSPLIT  // timing experiment only: `agg` taken as if it already were three bf16 planes
-  f32x4 raw[GX_DEPTH][3];
-#else
-  f32x4 raw[GX_DEPTH][2];
-#endif
-  auto load_step = [&](int gs) {  // global step -> (tile, gate, k-step); nothing here uses a loaded value
-    const int t = gs / NSTEP, st = gs % NSTEP, g = st / NKS, ks = st % NKS;
-#ifdef GX_VAR_COALESCED  // timing experiment only (wrong lane <-> data assignment)
-    const float* a = A.agg + (m0[t] + (lane >> 2)) * ld_agg + g * gs_ + 32 * ks + 8 * (lane & 3);
-#else
-    const float* a = A.agg + (m0[t] + row_l) * ld_agg + g * gs_ + 32 * ks + 8 * kq;
-#endif
-#ifdef GX_VAR_BLOCKED  // timing experiment only: a step's fragment as 2 KB of contiguous memory
-    const float* ab = A.agg + m0[t] * ld_agg + st * 512 + lane * 4;
-    raw[gs % GX_DEPTH][0] = *reinterpret_cast<const f32x4*>(ab);
-    raw[gs % GX_DEPTH][1] = *reinterpret_cast<const f32x4*>(ab + 256);
-    (void)a;
-#else
-    raw[gs % GX_DEPTH][0] = *reinterpret_cast<const f32x4*>(a);  // default cache policy: the other
-    raw[gs % GX_DEPTH][1] = *reinterpret_cast<const f32x4*>(a + 4);  // two slices find these lines in L2
-#endif
-#ifdef GX_VAR_NOSPLIT
-    raw[gs % GX_DEPTH][2] = *reinterpret_cast<const f32x4*>(a + 8);
-#endif
+    for (int i = 0; i < PPW; ++i) {
+      const int q = min(wave + i * GW_WAVES, NPIECE - 1), gq = q / 18, r = q - gq * 18;
+      stage[i] = bld128(r_w, lo_lane, (uint32_t)(((gq * NKS + ks) * 18 + r) * 1024));
+    }
   };
+  auto stage_store = [&](int buf) {
 #pragma unroll
-  for (int gs = 0; gs < GX_DEPTH && gs < T * NSTEP; ++gs) load_step(gs);
+    for (int i = 0; i < PPW; ++i) smem[buf * SLICE + min(wave + i * GW_WAVES, NPIECE - 1) * 64 + lane] = stage[i];
+  };
+  f32x4 raw[2][GW_TMAX][2];
+  auto agg_load = [&](int ks, int t) {
+    raw[ks & 1][t][0] = bld128f(r_agg, lo_agg, so_agg[t] + 128u * ks);
+    raw[ks & 1][t][1] = bld128f(r_agg, lo_agg, so_agg[t] + 128u * ks + 16u);
+  };
 
-  const u32x4* pw = &s_w[lane];
-  f32x4 acc[G][NCT], skip[G][NCT], cold[NCT];
-  float xt[G];
+  // ---- prologue: slice 0 -> LDS; the first two k-steps of `agg`, the tail operands and the
+  // skip / bias term (the accumulators start from it: D layout, node lr, channels 16 ct + 4 kq ..) in flight ----
+  stage_load(0);
+  float xt[GW_TMAX], wt[6];
+  f32x4 acc[GW_TMAX][6];
 #pragma unroll
-  for (int gs = 0; gs < T * NSTEP; ++gs) {
-    const int t = gs / NSTEP, st = gs % NSTEP, g = st / NKS;
-    const int64_t m = m0[t] + row_l;
-    if (st == 0) {
-      // per-tile side inputs: requested now, consumed in the tile's epilogue
+  for (int t = 0; t < GW_TMAX; ++t) {
+    agg_load(0, t);
+    if (NKS > 1) agg_load(1, t);
+  }
 #pragma unroll
-      for (int g2 = 0; g2 < G; ++g2) {
+  for (int t = 0; t < GW_TMAX; ++t) {
+    xt[t] = bld32f(r_agg, lo_tail, so_agg[t] + KM * 4u);
 #pragma unroll
-        for (int a = 0; a < NCT; ++a) {
-          acc[g2][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          skip[g2][a] = *reinterpret_cast<const f32x4*>(A.p_dst + m * A.ldp + A.s_off + g2 * C + slice * SW +
-                                                        a * 16 + 4 * kq);
-        }
-        xt[g2] = A.agg[m * ld_agg + g2 * gs_ + KM + kq];
+    for (int ct = 0; ct < 6; ++ct) acc[t][ct] = bld128f(r_skip, lo_skip, so_skip[t] + 64u * ct);
+  }
+  // weight side of the exact fp32 tail (columns KM .. KM+3), 16x16x4 fragment layout
+#pragma unroll
+  for (int ct = 0; ct < 6; ++ct)
+    wt[ct] = bld32f(r_w2, ((uint32_t)lr * KA + kq) * 4u, (uint32_t)(((g * C + ct * 16) * KA + KM) * 4));
+  stage_store(0);
+  __syncthreads();
+
+  // the LSTM phase: this thread's (node, 4-channel) quads, as byte offsets from row0
+  constexpr int NQ = (TP * GW_BM * 24 + GW_THREADS - 1) / GW_THREADS;  // 5 (G = 4), 6 (G = 3)
+  f32x4 cold[NQ];
+  uint32_t qo[NQ];   // ((row - row0) * 96 + 4 c4) * 4
+  int qoff[NQ];
+  bool qok[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * GW_THREADS;
+    const int j = q / (GW_BM * 24), rem = q - j * (GW_BM * 24), node = rem / 24, c4 = rem - node * 24;
+    qok[i] = j < n_t;
+    const int jj = qok[i] ? j : 0;
+    const uint32_t row = (uint32_t)(min((mt_lo + jj) * GW_BM, m_last) - row0 + min((int64_t)node, A.N - 1));
+    qo[i] = (row * C + 4 * c4) * 4u;
+    qoff[i] = (jj * G * GW_BM + node) * GW_PRE_LD + 4 * c4;
+  }
+
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 1 < NKS) stage_load(ks + 1);
+    if constexpr (MODE == GGNN_MODE_LSTM) {
+      if (ks == NKS - 1) {
+        const rsrc_t r_c = make_rsrc(A.c_in + row0 * C);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) cold[i] = bld128f(r_c, qo[i], 0);
       }
-      if (MODE == GGNN_MODE_LSTM) {
+    }
+    const u32x4* pw = smem + (ks & 1) * SLICE + g * (18 * 64) + lane;
 #pragma unroll
-        for (int a = 0; a < NCT; ++a)
-          cold[a] = *reinterpret_cast<const f32x4*>(A.c_in + m * C + slice * SW + a * 16 + 4 * kq);
+    for (int t = 0; t < GW_TMAX; ++t) {
+      // split this k-step's fragment, then reuse its registers for the fragment two k-steps ahead
+      u32x4 xb[3];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t q0, q1, q2;
+        split_bf16x3(raw[ks & 1][t][d >> 1][2 * (d & 1)], raw[ks & 1][t][d >> 1][2 * (d & 1) + 1], q0, q1, q2);
+        xb[0][d] = q0;
+        xb[1][d] = q1;
+        xb[2][d] = q2;
       }
-    }
-    // split this step's fragment, then reuse its ring slot for the step GX_DEPTH ahead
-    u32x4 xb[3];
-#ifdef GX_VAR_NOSPLIT
+      if (ks + 2 < NKS) agg_load(ks + 2, t);
+      if (t < nt_w) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+        for (int ct = 0; ct < 6; ++ct) {
+          u32x4 wf[3];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) xb[q][d] = __float_as_uint(raw[gs % GX_DEPTH][q][d]);
-#else
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      uint32_t p0, p1, p2;
-      split_bf16x3(raw[gs % GX_DEPTH][d >> 1][2 * (d & 1)], raw[gs % GX_DEPTH][d >> 1][2 * (d & 1) + 1], p0, p1, p2);
-      xb[0][d] = p0;
-      xb[1][d] = p1;
-      xb[2][d] = p2;
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);  // pin the issue point: hipcc otherwise sinks or bunches the ring loads
-    if (gs + GX_DEPTH < T * NSTEP) load_step(gs + GX_DEPTH);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int a = 0; a < NCT; ++a) {
-      u32x4 wf[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) wf[q] = pw[((st * 3 + q) * NCT + a) * 64];
-      acc[g][a] = mfma_x6(wf, xb, acc[g][a]);
-    }
-    if (st == NSTEP - 1) {
-      // ---- tile epilogue: exact fp32 tail, + skip, LSTM; lane holds channels n..n+3 (twice) ----
-#pragma unroll
-      for (int a = 0; a < NCT; ++a) {
-        const int n = slice * SW + a * 16 + 4 * kq;
-#pragma unroll
-        for (int g2 = 0; g2 < G; ++g2)
-          acc[g2][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[g2][a], xt[g2], acc[g2][a], 0, 0, 0) + skip[g2][a];
-        if (MODE == GGNN_MODE_RAW) {
-#pragma unroll
-          for (int g2 = 0; g2 < G; ++g2)
-            *reinterpret_cast<f32x4*>(A.raw_out + m * (int64_t)(G * C) + g2 * C + n) = acc[g2][a];
-        } else {
-          constexpr int GI = 0, GF = 1, GC = (MODE == GGNN_MODE_LSTM) ? 2 : 1,
-                        GO = (MODE == GGNN_MODE_LSTM) ? 3 : 2;
-          f32x4 hn, cn;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoidf_(acc[GI][a][r]);
-            const float tg = tanhf_(acc[GC][a][r]);
-            float cv = ig * tg;
-            if (MODE == GGNN_MODE_LSTM) cv = sigmoidf_(acc[GF < G ? GF : 0][a][r]) * cold[a][r] + cv;
-            const float og = sigmoidf_(acc[GO][a][r]);
-            cn[r] = cv;
-            hn[r] = og * tanhf_(cv);
-          }
-          *reinterpret_cast<f32x4*>(A.c_out + m * C + n) = cn;
-          *reinterpret_cast<f32x4*>(A.h_out + m * C + n) = hn;
+          for (int q = 0; q < 3; ++q) wf[q] = pw[(q * 6 + ct) * 64];
+          acc[t][ct] = mfma_x6(wf, xb, acc[t][ct]);
         }
       }
     }
+    if (ks + 1 < NKS) stage_store((ks + 1) & 1);
+    __syncthreads();  // slice ks + 1 complete and visible; every wave is done with slice ks
   }
-#ifdef GX_VAR_CLOCK  // diagnostic build: (start, prologue end, end) in 10 ns ticks per wave, into c_out
-  if (lane == 0 && MODE != GGNN_MODE_RAW) {
-    __builtin_amdgcn_s_waitcnt(0);
-    float* o = A.c_out + ((int64_t)blockIdx.x * GX_WAVES + wave) * 4;
-    o[0] = (float)(tr_start & 0xffffff);
-    o[1] = (float)(tr_pro - tr_start);
-    o[2] = (float)(__builtin_amdgcn_s_memrealtime() - tr_start);
+
+  // ---- exact fp32 tail, then the pre-activation blocks -> LDS (the weight buffers are free) ----
+#pragma unroll
+  for (int t = 0; t < GW_TMAX; ++t) {
+    if (t < nt_w) {
+      const int j = slot + t * SLOTS;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) {
+        acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ct], xt[t], acc[t][ct], 0, 0, 0);
+        *reinterpret_cast<f32x4*>(&pre[((j * G + g) * GW_BM + lr) * GW_PRE_LD + ct * 16 + 4 * kq]) = acc[t][ct];
+      }
+    }
   }
-#endif
+  __syncthreads();
+
+  // ---- LSTM phase: whole (node, 4-channel) quads per thread, contiguous rows in memory ----
+  const rsrc_t r_h = make_rsrc(MODE == GGNN_MODE_RAW ? A.raw_out + row0 * (G * C) : A.h_out + row0 * C);
+  const rsrc_t r_co = make_rsrc(MODE == GGNN_MODE_RAW ? A.raw_out : A.c_out + row0 * C);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    if (!qok[i]) continue;
+    f32x4 p[G];
+#pragma unroll
+    for (int g2 = 0; g2 < G; ++g2) p[g2] = *reinterpret_cast<const f32x4*>(&pre[qoff[i] + g2 * GW_BM * GW_PRE_LD]);
+    if constexpr (MODE == GGNN_MODE_RAW) {
+      const uint32_t row = qo[i] / (C * 4u), cb = qo[i] - row * (C * 4u);
+#pragma unroll
+      for (int g2 = 0; g2 < G; ++g2) bst128f(r_h, row * (G * C * 4u) + cb, (uint32_t)(g2 * C * 4), p[g2]);
+    } else {
+      constexpr int GI = 0, GF = 1, GC = (MODE == GGNN_MODE_LSTM) ? 2 : 1, GO = (MODE == GGNN_MODE_LSTM) ? 3 : 2;
+      f32x4 hn, cn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = sigmoidf_(p[GI][r]);
+        const float tg = tanhf_(p[GC][r]);
+        float cv = ig * tg;
+        if constexpr (MODE == GGNN_MODE_LSTM) cv = sigmoidf_(p[GF][r]) * cold[i][r] + cv;
+        const float og = sigmoidf_(p[GO][r]);
+        cn[r] = cv;
+        hn[r] = og * tanhf_(cv);
+      }
+      bst128f(r_co, qo[i], 0, cn);
+      bst128f(r_h, qo[i], 0, hn);
+    }
+  }
+}
+
+template <int G, int MODE>
+__global__ __launch_bounds__(gw_waves(G) * 64, 1) void gates_x6_kernel(const GateBatch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[GW_LDS_BYTES];
+  u32x4* smem = reinterpret_cast<u32x4*>(s_raw);
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
+  const ggnn_epilogue_args& A = B.a[k];
+  const int64_t n_mt = (A.N + GW_BM - 1) / GW_BM;
+  const int64_t mt_lo = (int64_t)((int)blockIdx.x - B.wg_off[k]) * B.tpw[k];
+  const int64_t mt_hi = min(n_mt, mt_lo + B.tpw[k]);
+  if (mt_lo >= mt_hi) return;
+  if (A.Ka == 196) gates_body<G, MODE, 196>(A, mt_lo, mt_hi, smem);
+  else gates_body<G, MODE, 100>(A, mt_lo, mt_hi, smem);
 }
 
 }  // namespace ggnn
 
-// Called by ggnn_lstm_epilogue (gates.hip) after argument validation, when w2_planes is given
-// and GGNN_GEMM != fp32.
-int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args& A, hipStream_t s) {
+// Called by ggnn_lstm_epilogue_batch (gates.hip) after argument validation, when every problem has
+// w2_planes and GGNN_GEMM != fp32.  All problems share mode and n_gates.
+int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args* args, int n, hipStream_t s) {
   using namespace ggnn;
-  const int G = A.n_gates;
-  const bool wide = A.Ka == 196;
-  const int64_t n_mt = (A.N + GX_BM - 1) / GX_BM;
-  const int64_t n_wg_rows = (n_mt + GX_WAVES - 1) / GX_WAVES;  // workgroups along the nodes at one tile per wave
-  // narrow slices (6 x 16 channels) while three wide ones leave more than half of the CUs without a workgroup
-  const int NCT = 3 * n_wg_rows <= 128 ? 1 : 2;
-  const int n_slices = 6 / NCT;
-  // tiles per wave: 1 while one round of workgroups (<= 256) covers the nodes, else 2
-  const int T = n_slices * n_wg_rows <= 256 ? 1 : 2;
-  const int64_t n_ranges = (n_mt + GX_WAVES * T - 1) / (GX_WAVES * T);
-  const int64_t nblk = 8 * n_slices * ((n_ranges + 7) / 8);
-  if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  const dim3 grid((unsigned)nblk), block(GX_WAVES * 64);
-#define GGNN_GX_LAUNCH2(G_, MODE_, KA_)                                                                           \
-  do {                                                                                                            \
-    if (NCT == 1) hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 1, 1>), grid, block, 0, s, A, (int)n_ranges);      \
-    else if (T == 1) hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 1, 2>), grid, block, 0, s, A, (int)n_ranges);   \
-    else hipLaunchKernelGGL((gates_x6_kernel<G_, MODE_, KA_, 2, 2>), grid, block, 0, s, A, (int)n_ranges);        \
-  } while (0)
-#define GGNN_GX_LAUNCH(G_, MODE_)              \
-  do {                                         \
-    if (wide) GGNN_GX_LAUNCH2(G_, MODE_, 196); \
-    else GGNN_GX_LAUNCH2(G_, MODE_, 100);      \
-  } while (0)
-  if (A.mode == GGNN_MODE_LSTM) GGNN_GX_LAUNCH(4, GGNN_MODE_LSTM);
-  else if (A.mode == GGNN_MODE_LSTM_H0) GGNN_GX_LAUNCH(3, GGNN_MODE_LSTM_H0);
-  else if (G == 4) GGNN_GX_LAUNCH(4, GGNN_MODE_RAW);
-  else if (G == 3) GGNN_GX_LAUNCH(3, GGNN_MODE_RAW);
-  else GGNN_GX_LAUNCH(1, GGNN_MODE_RAW);
-#undef GGNN_GX_LAUNCH
-#undef GGNN_GX_LAUNCH2
+  GateBatch B;
+  B.n = n;
+  // Workgroups are dealt in proportion to the MFMA work: a workgroup takes `tpw` tiles of one
+  // problem with tpw * k-steps ~ W, the smallest W for which one round of workgroups (one per CU)
+  // covers everything.
+  const int ncu = num_cu();
+  int64_t n_mt[GW_MAX_PROBLEMS], nks[GW_MAX_PROBLEMS];
+  for (int k = 0; k < n; ++k) {
+    n_mt[k] = (args[k].N + GW_BM - 1) / GW_BM;
+    nks[k] = (args[k].Ka - 4) / 32;
+  }
+  const int G = args[0].n_gates, mode = args[0].mode;
+  const int64_t tp_max = (int64_t)(gw_waves(G) / G) * GW_TMAX;  // tiles a workgroup can take
+  int64_t total = 0;
+  for (int W = 6;; W += 3) {
+    total = 0;
+    bool capped = true;
+    for (int k = 0; k < n; ++k) {
+      const int64_t tpw = std::min(tp_max, std::max<int64_t>(1, W / nks[k]));
+      capped = capped && tpw == tp_max;
+      B.tpw[k] = (int)tpw;
+      total += (n_mt[k] + tpw - 1) / tpw;
+    }
+    if (total <= ncu || capped) break;  // more than one round of workgroups: full workgroups, dealt by the hardware
+  }
+  if (total >= INT32_MAX) return GGNN_EINVAL;
+  B.wg_off[0] = 0;
+  for (int k = 0; k < GW_MAX_PROBLEMS; ++k) {
+    B.a[k] = args[k < n ? k : 0];
+    if (k < n) B.wg_off[k + 1] = B.wg_off[k] + (int)((n_mt[k] + B.tpw[k] - 1) / B.tpw[k]);
+    else {
+      B.wg_off[k + 1] = B.wg_off[k];
+      B.tpw[k] = 1;
+    }
+  }
+  const dim3 grid((unsigned)total), block(gw_waves(G) * 64);
+  if (mode == GGNN_MODE_LSTM) hipLaunchKernelGGL((gates_x6_kernel<4, GGNN_MODE_LSTM>), grid, block, 0, s, B);
+  else if (mode == GGNN_MODE_LSTM_H0) hipLaunchKernelGGL((gates_x6_kernel<3, GGNN_MODE_LSTM_H0>), grid, block, 0, s, B);
+  else if (G == 4) hipLaunchKernelGGL((gates_x6_kernel<4, GGNN_MODE_RAW>), grid, block, 0, s, B);
+  else if (G == 3) hipLaunchKernelGGL((gates_x6_kernel<3, GGNN_MODE_RAW>), grid, block, 0, s, B);
+  else hipLaunchKernelGGL((gates_x6_kernel<1, GGNN_MODE_RAW>), grid, block, 0, s, B);
   return launch_status();
 }

@@ -33,7 +33,6 @@ namespace ggnn {
 constexpr int PJ_BM = 16;      // nodes per wave tile
 constexpr int PJ_BN = 96;      // output columns per workgroup
 constexpr int PJ_WAVES = 8;    // waves per workgroup (two per SIMD)
-constexpr int PJ_NUM_CU = 256;
 
 template <int FP, int K2>
 __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
@@ -200,7 +199,7 @@ extern "C" int ggnn_project(const float* X, int64_t ldx, int F, const float* H, 
   const int64_t n_mt = (M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
   // decoder (K ~ 104): MFMA-bound, one 95 KB workgroup per CU; encoder (K <= 12): store-bound
   // with a tiny LDS footprint, so two workgroups per CU keep more stores in flight
-  int64_t m_splits = (k2 ? PJ_NUM_CU : 2 * PJ_NUM_CU) / nb_n;
+  int64_t m_splits = (k2 ? num_cu() : 2 * num_cu()) / nb_n;
   if (m_splits < 1) m_splits = 1;
   if (m_splits > n_mt) m_splits = n_mt;
   const dim3 grid((unsigned)(nb_n * m_splits)), block(PJ_WAVES * 64);

@@ -1,7 +1,8 @@
 """Launch plan of one model forward on the HIP kernels.
 
 One HeteroPGCLSTM cell (heteropgclstm.py:148-183: 4 gates x 3 PeriodConv + LSTM update) is
-2 projection GEMMs + 1 launch of 3 aggregation sweeps + 2 gate-GEMM/LSTM epilogues = 5 launches; a
+2 projection GEMMs + 1 launch of 3 aggregation sweeps + 1 launch of the gate-GEMM/LSTM epilogues of both
+node types = 4 launches; a
 model forward (edge geometry, encoder cell with h = c = 0, decoder cell, heads;
 models.py:422-452, 581-609) is 12-13 launches instead of the ~600 framework kernels the reference issues.
 """
@@ -121,13 +122,15 @@ def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor
                        pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
                        lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
     backend.aggregate_batch(sweeps)
+    backend.lstm_epilogue_batch(gate_problems(pc, proj, agg, c_in, h_out, c_out))  # both node types, one launch
+
+
+def gate_problems(pc: PackedCell, proj, agg, c_in, h_out, c_out):
+    """Argument tuples of ggnn_lstm_epilogue for the live node types of one cell."""
     mode = _lib.MODE_LSTM if pc.k2 else _lib.MODE_LSTM_H0
-    for nt in NODE_TYPES:  # 2 gate GEMM + LSTM epilogues
-        if not lay[nt].live:
-            continue
-        backend.lstm_epilogue(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off,
-                              c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt], None, pc.G, mode,
-                              pc.w2p.get(nt), lay[nt].Kg)
+    lay = pc.layout
+    return [(agg[nt], pc.w2[nt], proj[nt], lay[nt].s_off, c_in[nt] if pc.k2 else None, h_out[nt], c_out[nt],
+             None, pc.G, mode, pc.w2p.get(nt), lay[nt].Kg) for nt in NODE_TYPES if lay[nt].live]
 
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,

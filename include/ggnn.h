@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 12
+#define GGNN_ABI_VERSION 13
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -233,6 +233,11 @@ typedef struct ggnn_epilogue_args {
   int32_t g_stride, reserved;
 } ggnn_epilogue_args;
 int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream);
+/* Up to four gate GEMM + LSTM problems in ONE launch: the node types of one cell
+ * (heteropgclstm.py:111-146 runs the update per node type) and / or the same cell of the
+ * regressor and the classifier (test.py:382-383 calls both models on the same x_dict).  All
+ * problems must share `mode` and `n_gates`; Ka may differ.  Same result as n single calls. */
+int ggnn_lstm_epilogue_batch(const ggnn_epilogue_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads.

@@ -136,6 +136,10 @@ class TorchEmulatorBackend:
             c_out.copy_(c)
             h_out.copy_(o * torch.tanh(c))
 
+    def lstm_epilogue_batch(self, problems):
+        for prob in problems:
+            self.lstm_epilogue(*prob)
+
     def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):
         y_joint.copy_(torch.tanh(h_joint @ w[0].t() + b[0:2]))
         yg = h_grain @ w[1].t() + b[2:4]

@@ -120,6 +120,75 @@ def test_gemm_arithmetic_is_fp32_equivalent():
     assert err < bound, f"decoder projection error {err:.2e} of sum|x||w| (mode {backend().lib.ggnn_gemm_mode()})"
 
 
+def _gate_problem(N, Ka, mode, seed):
+    """Random operands of one ggnn_lstm_epilogue problem in the workspace layout (gate stride padded
+    to 32 floats) + its float64 result."""
+    rs = np.random.RandomState(seed)
+    G = {_lib.MODE_LSTM: 4, _lib.MODE_LSTM_H0: 3}.get(mode, 1 + 3 * (seed % 2))
+    Kg = (Ka + 31) // 32 * 32
+    agg = torch.from_numpy(rs.uniform(-1, 1, (N, G * Kg)).astype(np.float32))
+    w2 = torch.from_numpy((rs.standard_normal((G, 96, Ka)) * 0.2).astype(np.float32))
+    ldp = G * 96 + 32
+    pd = torch.from_numpy(rs.uniform(-1, 1, (N, ldp)).astype(np.float32))
+    c_in = torch.from_numpy(rs.uniform(-1, 1, (N, 96)).astype(np.float32))
+    s_off = 32
+    pre = [agg[:, g * Kg:g * Kg + Ka].double() @ w2[g].double().t() + pd[:, s_off + g * 96:s_off + (g + 1) * 96].double()
+           for g in range(G)]
+    if mode == _lib.MODE_RAW:
+        ref = (torch.cat(pre, 1),)
+    elif mode == _lib.MODE_LSTM:
+        c = torch.sigmoid(pre[1]) * c_in.double() + torch.sigmoid(pre[0]) * torch.tanh(pre[2])
+        ref = (torch.sigmoid(pre[3]) * torch.tanh(c), c)
+    else:
+        c = torch.sigmoid(pre[0]) * torch.tanh(pre[1])
+        ref = (torch.sigmoid(pre[2]) * torch.tanh(c), c)
+    return dict(agg=agg, w2=w2, pd=pd, c_in=c_in, s_off=s_off, G=G, Kg=Kg, ref=ref)
+
+
+def _gate_args(P, mode):
+    from graingraphnn_amd.packing import bf16_planes
+    d = lambda t: t.to(DEV)
+    N = P["agg"].size(0)
+    out = [torch.full((N, 96 * (P["G"] if mode == _lib.MODE_RAW else 1)), float("nan"), device=DEV),
+           torch.full((N, 96), float("nan"), device=DEV)]
+    w2 = d(P["w2"])
+    args = (d(P["agg"]), w2, d(P["pd"]), P["s_off"], d(P["c_in"]) if mode == _lib.MODE_LSTM else None,
+            None if mode == _lib.MODE_RAW else out[0], None if mode == _lib.MODE_RAW else out[1],
+            out[0] if mode == _lib.MODE_RAW else None, P["G"], mode, bf16_planes(w2), P["Kg"])
+    return args, out
+
+
+@pytest.mark.parametrize("mode", [_lib.MODE_LSTM, _lib.MODE_LSTM_H0, _lib.MODE_RAW])
+@pytest.mark.parametrize("N,Ka", [(1, 100), (15, 196), (16, 100), (17, 196), (95, 196), (96, 100), (1000, 196),
+                                  (4099, 100), (20000, 196)])
+def test_gate_gemm_and_lstm_against_float64(N, Ka, mode):
+    """ggnn_lstm_epilogue alone (every tile count a workgroup can get, ragged last tiles, N < 16)."""
+    P = _gate_problem(N, Ka, mode, N + Ka)
+    args, out = _gate_args(P, mode)
+    backend().lstm_epilogue(*args)
+    for got, ref, what in zip(out, P["ref"], ("h / raw", "c")):
+        assert_close(got, ref.float(), f"gates N={N} Ka={Ka} mode={mode} {what}", 2e-6)
+
+
+@pytest.mark.parametrize("mode", [_lib.MODE_LSTM, _lib.MODE_LSTM_H0])
+def test_gate_batch_equals_single_launches(mode):
+    """ggnn_lstm_epilogue_batch: four problems of different sizes and widths in one launch give
+    the bits of four single launches."""
+    shapes = [(20000, 196), (10000, 100), (777, 196), (33, 100)]
+    probs = [_gate_problem(N, Ka, mode, 7 * k + 1) for k, (N, Ka) in enumerate(shapes)]
+    single, batch = [], []
+    for P in probs:
+        a, o = _gate_args(P, mode)
+        backend().lstm_epilogue(*a)
+        single.append(o)
+        batch.append(_gate_args(P, mode))
+    backend().lstm_epilogue_batch([a for a, _ in batch])
+    for (a, o), s, P in zip(batch, single, probs):
+        for got, one, ref in zip(o, s, P["ref"]):
+            assert torch.equal(got, one)
+            assert_close(got, ref.float(), "gate batch", 2e-6)
+
+
 def test_native_fp32_gemm_mode_in_a_subprocess():
     """GGNN_GEMM=fp32 (native v_mfma_f32_16x16x4_f32 kernels) is fixed per process: run the GEMM,
     cell and forward parity tests once more under it."""

@@ -255,8 +255,9 @@ def test_cfg5_collated_minibatch_fp32_and_bf16_against_the_fp32_oracle():
     for tag, m in (("R", R), ("C", Cm)):
         gmax = max(float(ref[f"{tag}/{n}"].abs().max()) for n, _ in m.named_parameters())
         for name, p in m.named_parameters():
-            g, r = p.grad, ref[f"{tag}/{name}"]
-            assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()), name
+            # (parameters behind the classifier's dead decoder outputs get no gradient: zero, as in _grads)
+            g, r = (torch.zeros_like(p) if p.grad is None else p.grad), ref[f"{tag}/{name}"]
+            assert g.dtype == torch.float32 and bool(torch.isfinite(g).all()), name
             err, scale = float((g.cpu() - r).abs().max()), float(r.abs().max())
             # floor: tensors whose exact gradient is tiny next to the model's largest one
             assert err <= BF16_GTOL * scale + 2e-3 * gmax, (tag, name, err, scale)
