@@ -196,7 +196,7 @@ class HipBackend:
         if g_stride:  # agg gate stride (floats) when the rows are padded; 0 = packed [N, n_gates * Ka]
             a.g_stride, a.ld_agg = g_stride, agg.stride(0)
         if w2_planes is not None:
-            if w2_planes.dtype != torch.int16 or w2_planes.numel() != 3 * w2.size(0) * _lib.GGNN_C * (w2.size(2) - 4):
+            if w2_planes.dtype != torch.int16 or w2_planes.numel() != 2 * w2.size(0) * _lib.GGNN_C * (w2.size(2) - 4):
                 raise _lib.GGNNError("w2_planes does not match w2 (see packing.bf16_planes)")
             a.w2_planes = w2_planes.data_ptr()
 

@@ -17,25 +17,25 @@
 //     slot w / G), so with 5 tiles per workgroup the two waves of a SIMD carry 3 + 2 jobs.  Two
 //     waves per SIMD leave each wave 256 VGPRs: 72 accumulators, a 48-register `agg` ring and 36
 //     weight-staging registers fit without spilling (a 12-wave variant at 168 VGPRs spilled 200);
-//   * the weights (442 KB of bf16 planes at G = 4, Ka = 196: more than the LDS) are STREAMED:
-//     k-step slice s of all gates (G x 18 KB, fragment order, ggnn_epilogue_args.w2_planes) sits in
-//     one half of a double buffer while every wave stages its share of slice s + 1 through
-//     registers (plain loads from L2 at the top of the k-step, ds_write_b128 at its end), one
-//     workgroup barrier per k-step.  Plain loads, not LDS-DMA: the wave's `agg` prefetch shares
-//     the vmcnt queue with them and the compiler only emits counted waits for plain loads;
+//   * the weights (442 KB as bf16 planes at G = 4, Ka = 196: more than the LDS) are STREAMED:
+//     k-step slice s of all gates (G x 18 KB of planes in fragment order) sits in one half of a
+//     double buffer while every wave stages its share of slice s + 1 through registers: fp32
+//     fragments from L2 at the top of the k-step, split into planes and ds_write_b128 at its end,
+//     one workgroup barrier per k-step.  (Not LDS-DMA: the wave's `agg` prefetch shares the vmcnt
+//     queue, and the compiler only emits counted waits for plain loads.);
 //   * `agg` fragments are prefetched two k-steps ahead (ring of two register sets per tile);
 //   * the LSTM update needs all gates of a (node, channel): the waves leave their 16 x 96
 //     pre-activation blocks in LDS (the weight buffers are free by then; rows padded to 100 floats:
 //     conflict-free ds_write_b128 from the MFMA D layout), and after one barrier every thread
 //     handles whole (node, 4-channel) quads: c_in is read and h / c written as contiguous
-//     384-byte rows (the D layout would touch 64-byte pieces).  The accumulators START from the
-//     skip / bias term (loaded in the D layout in the prologue), so the LSTM phase needs no
-//     side input but c_in, whose loads are issued before the last k-step of the pass.
+//     384-byte rows (the D layout would touch 64-byte pieces); these side loads are issued before
+//     the last k-step (into the registers the weight staging and the `agg` ring no longer need).
 //   * up to four problems (node types x models) per launch: workgroups are dealt to the problems
 //     in proportion to their MFMA work (ggnn_lstm_epilogue_batch).
 #include <algorithm>
 
 #include "common.h"
+#include "stamps.h"
 
 namespace ggnn {
 
@@ -84,13 +84,15 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
   constexpr int SLOTS = GW_WAVES / G;        // tile slots
   constexpr int TP = SLOTS * GW_TMAX;        // tiles per workgroup, at most
   constexpr int NPIECE = G * 18;             // 1 KB pieces of one k-step slice: [gate][plane 3][column tile 6]
-  constexpr int PPW = (NPIECE + GW_WAVES - 1) / GW_WAVES;  // pieces a wave stages per k-step
+  constexpr int NFRAG = G * 6;               // (gate, column tile) fp32 fragments of one k-step slice, 2 KB each
+  constexpr int FPW = (NFRAG + GW_WAVES - 1) / GW_WAVES;  // fragments a wave stages per k-step
   constexpr int SLICE = NPIECE * 64;         // u32x4 per slice
   static_assert(KM % 32 == 0 && GW_WAVES % G == 0, "shape");
   static_assert(2 * SLICE * 16 <= GW_LDS_BYTES && TP * G * GW_BM * GW_PRE_LD * 4 <= GW_LDS_BYTES, "LDS");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GGNN_STAMP(0);
   const int lr = lane & 15, kq = lane >> 4;
   const int g = wave % G, slot = wave / G;
   const int64_t m_last = max(A.N - GW_BM, (int64_t)0);   // a ragged last tile slides back (identical duplicate stores)
@@ -101,37 +103,57 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
   const int64_t row0 = min(mt_lo * GW_BM, m_last);       // first row of the workgroup: every offset below is relative to it
   const uint32_t ld_agg = (uint32_t)A.ld_agg, ldp = (uint32_t)A.ldp;
 
-  const rsrc_t r_w = make_rsrc(A.w2_planes), r_w2 = make_rsrc(A.w2);
+  const rsrc_t r_w2 = make_rsrc(A.w2);
   const rsrc_t r_agg = make_rsrc(A.agg + row0 * A.ld_agg), r_skip = make_rsrc(A.p_dst + row0 * A.ldp + A.s_off);
+  const rsrc_t r_c = make_rsrc(MODE == GGNN_MODE_LSTM ? A.c_in + row0 * C : A.p_dst);
   // lane offsets (bytes) inside a tile; a tile's first row and the gate go into the scalar offset
   const uint32_t lo_agg = (uint32_t)row_l * ld_agg * 4u + 32u * kq;
   const uint32_t lo_tail = (uint32_t)row_l * ld_agg * 4u + 4u * kq;
-  const uint32_t lo_skip = (uint32_t)row_l * ldp * 4u + 16u * kq;
-  const uint32_t lo_lane = 16u * lane;
   // absent tiles repeat the wave's first tile (or the workgroup's first): their loads hit L1, their MFMAs are skipped
-  uint32_t so_agg[GW_TMAX], so_skip[GW_TMAX];
+  uint32_t so_agg[GW_TMAX];
 #pragma unroll
   for (int t = 0; t < GW_TMAX; ++t) {
     const int j = t < nt_w ? slot + t * SLOTS : (nt_w ? slot : 0);
     const uint32_t dm = (uint32_t)(min((mt_lo + j) * GW_BM, m_last) - row0);
     so_agg[t] = (dm * ld_agg + (uint32_t)(g * A.g_stride)) * 4u;
-    so_skip[t] = (dm * ldp + (uint32_t)(g * C)) * 4u;
   }
 
-  // the pieces of a slice this wave stages: piece q = (gate gq, r = plane * 6 + column tile) of k-step
-  // ks is the 1 KB at w2_planes + (((gq * NKS + ks) * 18 + r) * 64 + lane) * 16; surplus slots
-  // repeat the last piece (same bytes to the same place)
-  u32x4 stage[PPW];
+  // Weight staging.  The weights arrive as fp32 MFMA A fragments in fragment order
+  // (ggnn_epilogue_args.w2_planes: [g][ks][ct][half][lane][4 floats], 1 KB of contiguous memory per
+  // load instruction) -- lane (i = l & 15, kq = l >> 4) of fragment (gate gq, column tile ct, k-step
+  // ks) holds w2[gq][16 ct + i][32 ks + 8 kq ..+7] --, are split into the three bf16 planes here
+  // (44 VALU per fragment and lane) and stored lane-linearly at [gq][plane][ct][lane]: 4 bytes per
+  // weight travel from L2 instead of the 6 of pre-split planes (every CU streams all weights: the
+  // XCD's L2 bandwidth, not the matrix pipe, is what this stream costs).
+  // Surplus slots repeat the last fragment (same bytes to the same place).
+  const uint32_t lo_w = 16u * lane;
+  const rsrc_t r_wf = make_rsrc(A.w2_planes);
+  f32x4 stage[FPW][2];
   auto stage_load = [&](int ks) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int q = min(wave + i * GW_WAVES, NPIECE - 1), gq = q / 18, r = q - gq * 18;
-      stage[i] = bld128(r_w, lo_lane, (uint32_t)(((gq * NKS + ks) * 18 + r) * 1024));
+    for (int i = 0; i < FPW; ++i) {
+      const int f = min(wave + i * GW_WAVES, NFRAG - 1), gq = f / 6, ct = f - gq * 6;
+      const uint32_t so = (uint32_t)((((gq * NKS + ks) * 6 + ct) * 2) * 1024);
+      stage[i][0] = bld128f(r_wf, lo_w, so);
+      stage[i][1] = bld128f(r_wf, lo_w, so + 1024u);
     }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) smem[buf * SLICE + min(wave + i * GW_WAVES, NPIECE - 1) * 64 + lane] = stage[i];
+    for (int i = 0; i < FPW; ++i) {
+      const int f = min(wave + i * GW_WAVES, NFRAG - 1), gq = f / 6, ct = f - gq * 6;
+      u32x4 pl[3];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t q0, q1, q2;
+        split_bf16x3(stage[i][d >> 1][2 * (d & 1)], stage[i][d >> 1][2 * (d & 1) + 1], q0, q1, q2);
+        pl[0][d] = q0;
+        pl[1][d] = q1;
+        pl[2][d] = q2;
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) smem[buf * SLICE + ((gq * 3 + q) * 6 + ct) * 64 + lane] = pl[q];
+    }
   };
   f32x4 raw[2][GW_TMAX][2];
   auto agg_load = [&](int ks, int t) {
@@ -139,8 +161,7 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
     raw[ks & 1][t][1] = bld128f(r_agg, lo_agg, so_agg[t] + 128u * ks + 16u);
   };
 
-  // ---- prologue: slice 0 -> LDS; the first two k-steps of `agg`, the tail operands and the
-  // skip / bias term (the accumulators start from it: D layout, node lr, channels 16 ct + 4 kq ..) in flight ----
+  // ---- prologue: slice 0 -> LDS; the first two k-steps of `agg` and the tail operands in flight ----
   stage_load(0);
   float xt[GW_TMAX], wt[6];
   f32x4 acc[GW_TMAX][6];
@@ -153,19 +174,21 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
   for (int t = 0; t < GW_TMAX; ++t) {
     xt[t] = bld32f(r_agg, lo_tail, so_agg[t] + KM * 4u);
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[t][ct] = bld128f(r_skip, lo_skip, so_skip[t] + 64u * ct);
+    for (int ct = 0; ct < 6; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // weight side of the exact fp32 tail (columns KM .. KM+3), 16x16x4 fragment layout
 #pragma unroll
   for (int ct = 0; ct < 6; ++ct)
     wt[ct] = bld32f(r_w2, ((uint32_t)lr * KA + kq) * 4u, (uint32_t)(((g * C + ct * 16) * KA + KM) * 4));
+  GGNN_STAMP(1);
   stage_store(0);
   __syncthreads();
+  GGNN_STAMP(2);
 
   // the LSTM phase: this thread's (node, 4-channel) quads, as byte offsets from row0
   constexpr int NQ = (TP * GW_BM * 24 + GW_THREADS - 1) / GW_THREADS;  // 5 (G = 4), 6 (G = 3)
-  f32x4 cold[NQ];
-  uint32_t qo[NQ];   // ((row - row0) * 96 + 4 c4) * 4
+  f32x4 cold[NQ], skipv[NQ][G];
+  uint32_t qo[NQ], qs[NQ];   // ((row - row0) * 96 + 4 c4) * 4, ((row - row0) * ldp + 4 c4) * 4
   int qoff[NQ];
   bool qok[NQ];
 #pragma unroll
@@ -176,19 +199,26 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
     const int jj = qok[i] ? j : 0;
     const uint32_t row = (uint32_t)(min((mt_lo + jj) * GW_BM, m_last) - row0 + min((int64_t)node, A.N - 1));
     qo[i] = (row * C + 4 * c4) * 4u;
+    qs[i] = (row * ldp + 4 * c4) * 4u;
     qoff[i] = (jj * G * GW_BM + node) * GW_PRE_LD + 4 * c4;
   }
+
+  constexpr int NQ_EARLY = NQ < 2 ? NQ : 2;
+  auto side_load = [&](int i0, int i1) {
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+      for (int g2 = 0; g2 < G; ++g2) skipv[i][g2] = bld128f(r_skip, qs[i], (uint32_t)(g2 * C * 4));
+      if constexpr (MODE == GGNN_MODE_LSTM) cold[i] = bld128f(r_c, qo[i], 0);
+    }
+  };
 
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     if (ks + 1 < NKS) stage_load(ks + 1);
-    if constexpr (MODE == GGNN_MODE_LSTM) {
-      if (ks == NKS - 1) {
-        const rsrc_t r_c = make_rsrc(A.c_in + row0 * C);
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) cold[i] = bld128f(r_c, qo[i], 0);
-      }
-    }
+    // side inputs of the LSTM phase: the first quads' behind the last k-step, the rest behind the
+    // tail / exchange (all at once they would fill the CU's load queue in front of the last MFMAs)
+    if (ks == NKS - 1 && MODE != GGNN_MODE_RAW) side_load(0, NQ_EARLY);
     const u32x4* pw = smem + (ks & 1) * SLICE + g * (18 * 64) + lane;
 #pragma unroll
     for (int t = 0; t < GW_TMAX; ++t) {
@@ -204,19 +234,30 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
       }
       if (ks + 2 < NKS) agg_load(ks + 2, t);
       if (t < nt_w) {
+        // the three weight fragments of column tile ct + 1 are read while the six MFMAs of ct run
+        u32x4 wf[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wf[0][q] = pw[(q * 6) * 64];
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS reads of ct = 0, then [reads ct + 1 | MFMAs ct] ...
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) {
-          u32x4 wf[3];
+          if (ct + 1 < 6) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) wf[q] = pw[(q * 6 + ct) * 64];
-          acc[t][ct] = mfma_x6(wf, xb, acc[t][ct]);
+            for (int q = 0; q < 3; ++q) wf[(ct + 1) & 1][q] = pw[(q * 6 + ct + 1) * 64];
+          }
+          acc[t][ct] = mfma_x6(wf[ct & 1], xb, acc[t][ct]);
+          if (ct + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                  // MFMA
         }
       }
     }
+    GGNN_STAMP(3 + 2 * ks);
     if (ks + 1 < NKS) stage_store((ks + 1) & 1);
     __syncthreads();  // slice ks + 1 complete and visible; every wave is done with slice ks
+    GGNN_STAMP(4 + 2 * ks);
   }
 
+  if constexpr (MODE != GGNN_MODE_RAW) side_load(NQ_EARLY, NQ);
   // ---- exact fp32 tail, then the pre-activation blocks -> LDS (the weight buffers are free) ----
 #pragma unroll
   for (int t = 0; t < GW_TMAX; ++t) {
@@ -230,6 +271,7 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
     }
   }
   __syncthreads();
+  GGNN_STAMP(15);
 
   // ---- LSTM phase: whole (node, 4-channel) quads per thread, contiguous rows in memory ----
   const rsrc_t r_h = make_rsrc(MODE == GGNN_MODE_RAW ? A.raw_out + row0 * (G * C) : A.h_out + row0 * C);
@@ -239,7 +281,10 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
     if (!qok[i]) continue;
     f32x4 p[G];
 #pragma unroll
-    for (int g2 = 0; g2 < G; ++g2) p[g2] = *reinterpret_cast<const f32x4*>(&pre[qoff[i] + g2 * GW_BM * GW_PRE_LD]);
+    for (int g2 = 0; g2 < G; ++g2) {
+      if constexpr (MODE == GGNN_MODE_RAW) skipv[i][g2] = bld128f(r_skip, qs[i], (uint32_t)(g2 * C * 4));  // parity-test mode
+      p[g2] = *reinterpret_cast<const f32x4*>(&pre[qoff[i] + g2 * GW_BM * GW_PRE_LD]) + skipv[i][g2];
+    }
     if constexpr (MODE == GGNN_MODE_RAW) {
       const uint32_t row = qo[i] / (C * 4u), cb = qo[i] - row * (C * 4u);
 #pragma unroll
@@ -261,6 +306,7 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
       bst128f(r_h, qo[i], 0, hn);
     }
   }
+  GGNN_STAMP(16);
 }
 
 template <int G, int MODE>

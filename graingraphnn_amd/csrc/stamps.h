@@ -1,0 +1,27 @@
+// In-kernel time stamps for development (tools/stamps.py).  The product build defines nothing: every
+// GGNN_STAMP(i) is empty.  `make STAMPS=1` builds a diagnostic library whose instrumented kernels
+// write s_memrealtime (100 MHz) of phase i for every wave into a device array that
+// ggnn_debug_stamps() copies out; no output of a kernel depends on a stamp.
+#pragma once
+#ifdef GGNN_STAMPS
+#define GGNN_STAMP_SLOTS 20
+#define GGNN_STAMP_WAVES 8192
+__device__ unsigned long long ggnn_stamp_buf[GGNN_STAMP_WAVES * GGNN_STAMP_SLOTS];
+#define GGNN_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if ((threadIdx.x & 63) == 0) {                                                                 \
+      const unsigned w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                     \
+      if (w_ < GGNN_STAMP_WAVES) ggnn_stamp_buf[w_ * GGNN_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                              \
+  } while (0)
+extern "C" int ggnn_debug_stamps(unsigned long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ggnn_stamp_buf), sizeof(ggnn_stamp_buf)) == hipSuccess ? 0 : -2;
+}
+extern "C" int ggnn_debug_stamps_clear(void) {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(ggnn_stamp_buf)) == hipSuccess &&
+                 hipMemset(p, 0, sizeof(ggnn_stamp_buf)) == hipSuccess ? 0 : -2;
+}
+#else
+#define GGNN_STAMP(i) do { } while (0)
+#endif

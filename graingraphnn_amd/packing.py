@@ -117,29 +117,31 @@ class PackedCell:
 
 @torch.no_grad()
 def bf16_planes(w2: torch.Tensor) -> torch.Tensor:
-    """`ggnn_epilogue_args.w2_planes` (include/ggnn.h): w2[:, :, :Ka-4] split exactly into three
-    bf16 pieces (hi = rne(w), mid = rne(w - hi), lo = rne(w - hi - mid); hi + mid + lo == w) and
-    laid out in MFMA fragment order [G][(Ka-4)/32][3][6][64][8] as int16 bit patterns."""
+    """`ggnn_epilogue_args.w2_planes` (include/ggnn.h): w2[:, :, :Ka-4] in MFMA A-fragment order, fp32,
+    [G][(Ka-4)/32][6][2][64][4]: element [g][ks][ct][h][l][j] = w2[g][16 ct + (l & 15)][32 ks + 8 (l >> 4)
+    + 4 h + j], so that one 16-byte load per lane of a wave is 1 KB of contiguous memory.  The kernel
+    splits every value exactly into three bf16 pieces (hi = rne(w), mid = rne(w - hi), lo = rne(w - hi
+    - mid); hi + mid + lo == w) on the fly; that this split is exact for the given weights is checked
+    here.  Returned as int16 bit patterns (two per float), the dtype the binding checks."""
     G, nch, Ka = w2.shape
     KM = Ka - 4
     assert nch == C and KM % 32 == 0
     w = w2[:, :, :KM].float()
+    if not bool(torch.isfinite(w).all()):
+        raise ValueError("gate weights (lin_l2 / lin_edge) contain non-finite values: cannot be packed")
     hi = w.to(torch.bfloat16)
     r1 = w - hi.float()
     mid = r1.to(torch.bfloat16)
-    r2 = r1 - mid.float()
-    lo = r2.to(torch.bfloat16)
-    if not bool(torch.isfinite(w).all()):
-        raise ValueError("gate weights (lin_l2 / lin_edge) contain non-finite values: cannot be packed")
+    lo = (r1 - mid.float()).to(torch.bfloat16)
     # hi + mid + lo == w exactly unless the last piece underflows bf16's exponent range
     # (|w| < ~2^-110): such entries lose bits far below anything fp32 arithmetic could show
     # (their products are subnormal in the fp32 accumulator) and are accepted
     resid = (hi.float() + mid.float() + lo.float() - w).abs()
     if resid.numel() and float(resid.max()) > 2.0 ** -120:
         raise ValueError(f"bf16 split of the gate weights is not exact (residual {float(resid.max()):.3e})")
-    pl = torch.stack([hi, mid, lo], 0).view(3, G, 6, 16, KM // 32, 4, 8)   # p g ct i ks kq j
-    pl = pl.permute(1, 4, 0, 2, 5, 3, 6).contiguous()                      # g ks p ct kq i j
-    return pl.view(torch.int16).view(-1)
+    fr = w.view(G, 6, 16, KM // 32, 4, 2, 4)          # g ct i ks kq h j
+    fr = fr.permute(0, 3, 1, 5, 4, 2, 6).contiguous()  # g ks ct h kq i j   (lane l = 16 kq + i)
+    return fr.view(torch.int16).view(-1)
 
 
 def _conv(cell, gate, et):

@@ -219,11 +219,13 @@ typedef struct ggnn_epilogue_args {
   float* raw_out;     /* [N, n_gates*96] (GGNN_MODE_RAW) */
   int64_t ldp, N;
   int32_t Ka, s_off, n_gates, mode;
-  /* Optional (NULL = native fp32 MFMA kernel): w2[:, :, 0:Ka-4] split into three bf16 planes in
-   * MFMA fragment order, uint16 [n_gates][(Ka-4)/32][3][6][64][8]: element [g][ks][p][ct][l][j] is
-   * piece p (0 = hi, 1 = mid, 2 = lo; x = hi + mid + lo exactly, each the bf16 round-to-nearest of
-   * what is left) of w2[g][16 ct + (l & 15)][32 ks + 8 (l >> 4) + j].  16-byte aligned.  Used
-   * when ggnn_gemm_mode() == GGNN_GEMM_BF16X6; Ka - 4 must be a multiple of 32. */
+  /* Optional (NULL = native fp32 MFMA kernel): w2[:, :, 0:Ka-4] re-ordered into MFMA A fragments,
+   * fp32, [n_gates][(Ka-4)/32][6][2][64][4]: element [g][ks][ct][h][l][j] =
+   * w2[g][16 ct + (l & 15)][32 ks + 8 (l >> 4) + 4 h + j] (one 16-byte load per lane of a wave =
+   * 1 KB of contiguous memory).  The kernel splits every value exactly into three bf16 pieces
+   * (x = hi + mid + lo, each the bf16 round-to-nearest of what is left) on the fly.  16-byte
+   * aligned; declared as uint16 pairs for historical reasons (ABI <= 12 passed pre-split planes).
+   * Used when ggnn_gemm_mode() == GGNN_GEMM_BF16X6; Ka - 4 must be a multiple of 32. */
   const uint16_t* w2_planes;
   /* Layout of agg: row stride ld_agg and gate stride g_stride, in floats (0, 0 = packed:
    * g_stride = Ka, ld_agg = n_gates * Ka).  Both multiples of 4, g_stride >= Ka,

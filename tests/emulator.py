@@ -118,8 +118,8 @@ class TorchEmulatorBackend:
         gs = g_stride or Ka
         if w2_planes is not None:  # the planes must reassemble to w2[:, :, :Ka-4] exactly (ggnn.h layout)
             G, KM = w2.size(0), Ka - 4
-            pl = w2_planes.view(torch.bfloat16).view(G, KM // 32, 3, 6, 4, 16, 8).float().sum(2)  # g ks ct kq i j
-            back = pl.permute(0, 2, 4, 1, 3, 5).reshape(G, 96, KM)
+            fr = w2_planes.view(torch.float32).view(G, KM // 32, 6, 2, 4, 16, 4)  # g ks ct h kq i j
+            back = fr.permute(0, 2, 5, 1, 4, 3, 6).reshape(G, 96, KM)
             assert torch.equal(back, w2[:, :, :KM])
         pre = [agg[:, g * gs:g * gs + Ka] @ w2[g].t() + p_dst[:, s_off + g * C: s_off + (g + 1) * C]
                for g in range(n_gates)]

@@ -162,12 +162,14 @@ def _gate_args(P, mode):
 @pytest.mark.parametrize("N,Ka", [(1, 100), (15, 196), (16, 100), (17, 196), (95, 196), (96, 100), (1000, 196),
                                   (4099, 100), (20000, 196)])
 def test_gate_gemm_and_lstm_against_float64(N, Ka, mode):
-    """ggnn_lstm_epilogue alone (every tile count a workgroup can get, ragged last tiles, N < 16)."""
+    """ggnn_lstm_epilogue alone (every tile count a workgroup can get, ragged last tiles, N < 16).
+    Floor: these operands have sum_k |agg||w| ~ 19 per output, and the split GEMM is good to 2.7e-7
+    of that (test_gemm_arithmetic_is_fp32_equivalent) = 5e-6 on a pre-activation."""
     P = _gate_problem(N, Ka, mode, N + Ka)
     args, out = _gate_args(P, mode)
     backend().lstm_epilogue(*args)
     for got, ref, what in zip(out, P["ref"], ("h / raw", "c")):
-        assert_close(got, ref.float(), f"gates N={N} Ka={Ka} mode={mode} {what}", 1e-5)
+        assert_close(got, ref.float(), f"gates N={N} Ka={Ka} mode={mode} {what}", 1e-5, 5e-6)
 
 
 @pytest.mark.parametrize("mode", [_lib.MODE_LSTM, _lib.MODE_LSTM_H0])
@@ -186,7 +188,7 @@ def test_gate_batch_equals_single_launches(mode):
     for (a, o), s, P in zip(batch, single, probs):
         for got, one, ref in zip(o, s, P["ref"]):
             assert torch.equal(got, one)
-            assert_close(got, ref.float(), "gate batch", 1e-5)
+            assert_close(got, ref.float(), "gate batch", 1e-5, 5e-6)
 
 
 def test_native_fp32_gemm_mode_in_a_subprocess():
