@@ -111,21 +111,37 @@ def measure_roofline(ro, n_steps):
     avg_us = float(np.mean(bracket)) - overhead
     avg_bytes = float(np.mean([ev[5] for ev in timed.events]))  # per launch, as launched
     achieved = avg_bytes / avg_us / 1e3
+    spl = round(float(np.mean([ev[6] for ev in timed.events])), 2)
     return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(), "avg_launch_us": round(avg_us, 2),
+            "traffic": pmc_traffic(spl), "avg_launch_us": round(avg_us, 2),
             "event_bracket_us": round(float(np.mean(bracket)), 2), "bracket_overhead_us": round(overhead, 2),
             "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(bracket),
-            "sweeps_per_launch": round(float(np.mean([ev[6] for ev in timed.events])), 2)}
+            "sweeps_per_launch": spl}
 
 
-def pmc_traffic():
+def kernel_source_hash():
+    """What a PMC record is tied to: the ABI version of the loaded library + the sources of the sweep."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("aggregate.hip", "common.h"):
+        with open(os.path.join(ROOT, "graingraphnn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return f"abi{default_backend().lib.ggnn_version()}-{h.hexdigest()[:16]}"
+
+
+def pmc_traffic(sweeps_per_launch):
     """HBM bytes per aggregate_kernel<4, true> launch from the rocprofv3 --pmc passes recorded in
-    profiles/r1_pmc_aggregate.json (PMC collection cannot run inside this process; the file
-    says how it was taken and corrected).  None when the file is absent."""
+    profiles/r2_pmc_aggregate.json (PMC collection cannot run inside this process; the file says
+    how it was taken and corrected, tools/pmc_aggregate.py).  The record is stamped with the ABI
+    version and a hash of the sweep's sources and with the launch shape it was taken on: None when
+    the file is absent or does not describe the kernel that is running."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_aggregate.json")) as f:
-            return int(json.load(f)["traffic_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_aggregate.json")) as f:
+            doc = json.load(f)
+        if doc["kernel_source_hash"] != kernel_source_hash() or abs(doc["sweeps_per_launch"] - sweeps_per_launch) > 1e-6:
+            return None
+        return int(doc["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -236,7 +252,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="regressor and classifier on one stream")
+    ap.add_argument("--serial", action="store_true", help="one set of launches per model, on one stream")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="one set of launches per model, regressor and classifier on two streams (round-1 plan)")
     ap.add_argument("--events", action="store_true",
                     help="event-driven mode (SURVEY 8f-2): per-step event detection + host topology update when "
                          "one fires; not the headline metric")
@@ -303,7 +321,8 @@ def main():
         inputs = (x, ei, ea, factor, off)
         R, Cm = R.to(device), Cm.to(device)
         X, EI, EA = synthetic.to_torch(x, ei, ea, device)
-    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial,
+    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=args.two_streams,
+                      joint_launches=not (args.serial or args.two_streams),
                       refresh_centres=True, domain_factor=inputs[3],
                       domain_offset=None if inputs[4] is None else torch.from_numpy(inputs[4]))
 
@@ -380,7 +399,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R|C serial" if args.serial else ", R|C on two streams"),
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R then C on one stream" if args.serial else ", R|C on two streams" if args.two_streams
+                                  else ", R+C in the same launches (13 per step)"),
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),

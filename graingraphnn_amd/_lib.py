@@ -24,7 +24,7 @@ MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
-    "ggnn_edge_prepare", "ggnn_project", "ggnn_period_gat_aggregate",
+    "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
@@ -46,6 +46,15 @@ class PrepareEdge(Structure):
         ("col", c_void_p), ("perm", c_void_p), ("row", c_void_p), ("edge_attr", c_void_p),
         ("x_src", c_void_p), ("x_dst", c_void_p), ("einfo", c_void_p),
         ("ldx_src", c_int64), ("ldx_dst", c_int64), ("E", c_int64), ("f_src", c_int64),
+    ]
+
+
+class ProjectArgs(Structure):
+    """Mirror of `ggnn_project_args`."""
+    _fields_ = [
+        ("X", c_void_p), ("H", c_void_p), ("Wp", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+        ("ldx", c_int64), ("ldh", c_int64), ("M", c_int64), ("ldo", c_int64),
+        ("F", c_int32), ("k2", c_int32), ("ncols", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -122,6 +131,8 @@ def _declare(lib):
     lib.ggnn_project.restype = c_int
     lib.ggnn_project.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p,
                                  c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
+    lib.ggnn_project_batch.restype = c_int
+    lib.ggnn_project_batch.argtypes = [POINTER(ProjectArgs), c_int, c_void_p]
     lib.ggnn_period_gat_aggregate.restype = c_int
     lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
     lib.ggnn_period_gat_aggregate_batch.restype = c_int

@@ -7,7 +7,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AggregateArgs, AggregateBwdArgs, EpilogueArgs, PrepareEdge, RefreshEdge, check, ptr
+from ._lib import (AggregateArgs, AggregateBwdArgs, EpilogueArgs, PrepareEdge, ProjectArgs, RefreshEdge, check,
+                   ptr)
 
 
 class CSR:
@@ -112,6 +113,18 @@ class HipBackend:
         self._launch(self.lib.ggnn_project, "ggnn_project", ptr(x), x.stride(0), F, ptr(h),
                      0 if h is None else h.stride(0), k2, ptr(wp), ptr(bp), M, wp.size(0), ptr(out),
                      out.stride(0), _lib.current_stream())
+
+    def project_batch(self, problems):
+        """Up to four projections in one launch (ggnn_project_batch); each item is the argument tuple
+        of `project`: (x, F, h, wp, bp, out).  All with h or all without."""
+        arr = (ProjectArgs * len(problems))()
+        for a, (x, F, h, wp, bp, out) in zip(arr, problems):
+            _require_cuda(x, h, wp, bp, out)
+            a.X, a.Wp, a.bias, a.out = x.data_ptr(), wp.data_ptr(), bp.data_ptr(), out.data_ptr()
+            a.H = None if h is None else h.data_ptr()
+            a.ldx, a.ldh, a.M, a.ldo = x.stride(0), 0 if h is None else h.stride(0), x.size(0), out.stride(0)
+            a.F, a.k2, a.ncols = F, 0 if h is None else h.size(1), wp.size(0)
+        self._launch(self.lib.ggnn_project_batch, "ggnn_project_batch", arr, len(problems), _lib.current_stream())
 
     # -- aggregation -------------------------------------------------------------------
     @staticmethod

@@ -57,17 +57,11 @@
 
 namespace ggnn {
 
-#ifndef AG_VAR_BPC
-#define AG_VAR_BPC 3
-#endif
 // Workgroups per CU of the persistent grid (measured on the batched launch, cfg3: 2 -> 80 us,
 // 3 -> 70, 4 -> 72, 5 -> 76: fewer streams keep the sliding window of rows, and with it the
 // re-reads of source rows, inside the XCD's L2; 116 VGPRs allow 4 waves per SIMD)
-constexpr int AG_BLOCKS_PER_CU = AG_VAR_BPC;
-#ifndef AG_VAR_BPC_NOH
-#define AG_VAR_BPC_NOH 6
-#endif
-constexpr int AG_BLOCKS_PER_CU_NOH = AG_VAR_BPC_NOH;  // encoder sweep (no hidden rows, 78 VGPRs): 4 -> 47.5 us, 5 -> 46.5, 6 -> 46, 7 -> 51
+constexpr int AG_BLOCKS_PER_CU = 3;
+constexpr int AG_BLOCKS_PER_CU_NOH = 6;  // encoder sweep (no hidden rows, 78 VGPRs): 4 -> 47.5 us, 5 -> 46.5, 6 -> 46, 7 -> 51
 constexpr int UE = GGNN_UNIT_EDGES;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -134,20 +128,18 @@ typedef const int __attribute__((address_space(4))) * const_i32_ptr;
 
 constexpr int AG_WAVES = 4;  // independent row streams per workgroup
 
-// Up to three sweeps of one cell in one launch: every workgroup walks its rows of sweep 0, then
-// of sweep 1, ... (no barrier in between: a stream that runs out of rows moves on, so the tail
-// of one sweep is filled by the head of the next, and a cell pays one launch instead of three).
+// Up to six sweeps in one launch (the three edge types of one cell, for one model or for the
+// regressor and the classifier together): every workgroup walks its rows of sweep 0, then of
+// sweep 1, ... (no barrier in between: a stream that runs out of rows moves on, so the tail of
+// one sweep is filled by the head of the next, and a cell pays one launch instead of three).
+constexpr int AG_MAX_SWEEPS = 6;
 struct AggregateBatch {
-  ggnn_aggregate_args a[3];
+  ggnn_aggregate_args a[AG_MAX_SWEEPS];
   int n;
 };
 
 template <int G, bool HAS_H>
-#ifdef AG_VAR_LB
-__global__ __launch_bounds__(256, HAS_H ? AG_BLOCKS_PER_CU : AG_BLOCKS_PER_CU_NOH)
-#else
 __global__ __launch_bounds__(256)
-#endif
 void aggregate_kernel(const AggregateBatch B) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,9 +170,6 @@ void aggregate_kernel(const AggregateBatch B) {
   const int64_t n_streams = (int64_t)nb_grp * AG_WAVES;
   int64_t r = x_lo + (int64_t)lb * AG_WAVES + wave;
   if (r >= x_hi) continue;
-#ifdef AG_VAR_EXIT_EARLY
-  if (A.n_gates > 0) return;
-#endif
   const const_i32_ptr uptr = (const_i32_ptr)(uintptr_t)A.unit_ptr;
   const const_i32x8_ptr udesc = (const_i32x8_ptr)(uintptr_t)A.units;
   const const_f32x4_ptr erec = (const_f32x4_ptr)(uintptr_t)A.einfo;  // 5 float4 per edge; [4] = (reloc, a)
@@ -224,29 +213,21 @@ void aggregate_kernel(const AggregateBatch B) {
       }
     }
     if (ALL || active) {
-#ifndef AG_VAR_NO_U
       if (HAS_H) {
         uh[0] = ld3_nt(uhbase + (uint32_t)i * ldp_dst);  // read once
         uh[1] = ld3_nt(uhbase + (uint32_t)i * ldp_dst + CH2);
       }
       u4 = __builtin_nontemporal_load(u4base + (uint32_t)i * ldp_dst);
-#endif
 #pragma unroll
       for (int t = 0; t < UE; ++t) {
         const uint32_t j = (uint32_t)d[4 + t];
-#ifndef AG_VAR_NO_H
         if (HAS_H) {
           hh[t][0] = ld3(hbase + j * ldh);
           hh[t][1] = ld3(hbase + j * ldh + CH2);
         }
-#endif
-#ifndef AG_VAR_NO_X
         x4[t] = tbase[((uint32_t)d[1] + t) * GGNN_EINFO_ROW];
-#endif
-#ifndef AG_VAR_NO_V
         vv[t][0] = ld3(vbase + j * ldp_src);
         vv[t][1] = ld3(vbase + j * ldp_src + CH2);
-#endif
       }
     }
     // ---- scalar side for the next unit (same row, or the first unit of this stream's next
@@ -311,20 +292,11 @@ void aggregate_kernel(const AggregateBatch B) {
       }
       mx = mnew;
     }
-#ifdef AG_VAR_NO_STORE
-    if ((ALL || active) && last && den == 1.2345f) {
-#else
     if ((ALL || active) && last) {
-#endif
       const float inv = 1.0f / (den + 1e-16f);  // PyG softmax denominator
       float* orow = A.agg + (int64_t)i * A.ld_agg + g * A.a_gstride;
-#ifdef AG_VAR_PLAIN_STORE
-      st3(orow + A.a_off + ch, {acc[0] * inv, acc[1] * inv, acc[2] * inv});
-      st3(orow + A.a_off + ch + CH2, {acc[3] * inv, acc[4] * inv, acc[5] * inv});
-#else
       st3_nt(orow + A.a_off + ch, {acc[0] * inv, acc[1] * inv, acc[2] * inv});
       st3_nt(orow + A.a_off + ch + CH2, {acc[3] * inv, acc[4] * inv, acc[5] * inv});
-#endif
       if (l16 == 0) {  // 8 bytes of a line the other edge type's sweep also writes into: through L2
         orow[A.sc_off] = den * inv;
         orow[A.sc_off + 1] = sae * inv;
@@ -401,13 +373,13 @@ static int check_sweep(ggnn_aggregate_args& A) {
 extern "C" int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,
                                                ggnn_stream_t stream) {
   using namespace ggnn;
-  if (!args || n_sweeps < 1 || n_sweeps > 3) return GGNN_EINVAL;
+  if (!args || n_sweeps < 1 || n_sweeps > AG_MAX_SWEEPS) return GGNN_EINVAL;
   AggregateBatch B;
   B.n = n_sweeps;
   const int G = args[0].n_gates;
   const bool has_h = args[0].h_src != nullptr;
   int64_t want = 1;
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < AG_MAX_SWEEPS; ++k) {
     B.a[k] = args[k < n_sweeps ? k : 0];
     if (B.a[k].n_gates != G || (B.a[k].h_src != nullptr) != has_h) return GGNN_EINVAL;
     const int rc = check_sweep(B.a[k]);

@@ -26,7 +26,10 @@
 //   D[i][j] -> lane l, reg r: i = 4*(l>>4) + r, j = l&15
 // LDS rows have stride Kp + 2 floats (= 2 * odd), which makes the ds_read_b32 operand
 // reads bank-conflict-free (bank = (row*ld + k) mod 32 covers 0..31 over 16 rows x 2 k).
+#include <algorithm>
+
 #include "common.h"
+#include "project_batch.h"
 
 namespace ggnn {
 
@@ -34,24 +37,30 @@ constexpr int PJ_BM = 16;      // nodes per wave tile
 constexpr int PJ_BN = 96;      // output columns per workgroup
 constexpr int PJ_WAVES = 8;    // waves per workgroup (two per SIMD)
 
+constexpr int pj_lds_floats(int k2) { return (PJ_BN + PJ_WAVES * PJ_BM) * (12 + k2 + 2); }
+
 template <int FP, int K2>
-__global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
-    const float* __restrict__ X, int64_t ldx, int F, const float* __restrict__ H, int64_t ldh,
-    const float* __restrict__ Wp, const float* __restrict__ bias, int64_t M, int ncols,
-    float* __restrict__ out, int64_t ldo, int m_splits) {
+__device__ __forceinline__ void project_body(const ggnn_project_args& A, int blk, int m_splits, float* smem) {
   constexpr int KP = FP + K2;
   constexpr int LD = KP + 2;
   constexpr int NVH = K2 > 0 ? K2 / 4 : 1;                   // 16-byte pieces per hidden row (24)
   constexpr int NH = K2 > 0 ? (PJ_BM * NVH) / 64 : 0;        // hidden pieces per lane per tile (6 or 0)
   constexpr int NX = (PJ_BM * FP) / 64;                      // feature floats per lane per tile (1..3)
   static_assert((K2 == 0 || (PJ_BM * NVH) % 64 == 0) && (PJ_BM * FP) % 64 == 0, "tile / lane mismatch");
-  __shared__ float s_w[PJ_BN * LD];
-  __shared__ float s_x[PJ_WAVES][PJ_BM * LD];
+  float* s_w = smem;                                          // [PJ_BN][LD]
+  float* s_xs = smem + PJ_BN * LD;                            // [PJ_WAVES][PJ_BM * LD]
+  const float* __restrict__ X = A.X;
+  const float* __restrict__ H = A.H;
+  const float* __restrict__ Wp = A.Wp;
+  const float* __restrict__ bias = A.bias;
+  float* __restrict__ out = A.out;
+  const int64_t ldx = A.ldx, ldh = A.ldh, M = A.M, ldo = A.ldo;
+  const int F = A.F, ncols = A.ncols;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb_n = ncols / PJ_BN;
-  const int bn = blockIdx.x % nb_n, ms = blockIdx.x / nb_n;
+  const int bn = blk % nb_n, ms = blk / nb_n;
   const int n0 = bn * PJ_BN;
 
   // ---- prologue: the weight tile, shared and constant from here on ----
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
   const int64_t per = (n_mt + m_splits - 1) / m_splits;
   const int64_t mt_lo = ms * per + wave, mt_hi = min(n_mt, (ms + 1) * per);
   if (mt_lo >= mt_hi) return;
-  float* sx = s_x[wave];
+  float* sx = s_xs + wave * (PJ_BM * LD);
 
   // ---- global -> register stage of one node tile (issued early, written to LDS late) ----
   f32x4 rh[NH > 0 ? NH : 1];
@@ -120,9 +129,7 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
   // together and reach their load / store phases together, leaving the matrix pipe idle.  A
   // half-sweep head start for one of them makes the phases complementary for the whole kernel
   // (there is no barrier to re-align them).  Speed only.
-#ifndef PJ_VAR_NO_STAGGER
   if (K2 > 0 && wave >= 4) __builtin_amdgcn_s_sleep(40);  // 40 x 64 clocks ~ half a sweep
-#endif
   load_tile(mt_lo);
   store_tile();
   for (int64_t mt = mt_lo; mt < mt_hi; mt += PJ_WAVES) {
@@ -178,46 +185,71 @@ __global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(
   }
 }
 
+template <int K2>
+__global__ __launch_bounds__(PJ_WAVES * 64, 1) void project_kernel(const ProjectBatch B) {
+  __shared__ __attribute__((aligned(16))) float smem[pj_lds_floats(K2)];
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
+  const ggnn_project_args& A = B.a[k];
+  const int blk = (int)blockIdx.x - B.wg_off[k], Fp = (A.F + 3) & ~3;
+  if (Fp == 4) project_body<4, K2>(A, blk, B.m_splits[k], smem);
+  else if (Fp == 8) project_body<8, K2>(A, blk, B.m_splits[k], smem);
+  else project_body<12, K2>(A, blk, B.m_splits[k], smem);
+}
+
 }  // namespace ggnn
 
-int ggnn_project_x6(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, const float* Wp,
-                    const float* bias, int64_t M, int ncols, float* out, int64_t ldo,
-                    int m_splits, hipStream_t s);
+int ggnn_project_x6(const ggnn::ProjectBatch& B, int n_wg, hipStream_t s);
+
+extern "C" int ggnn_project_batch(const ggnn_project_args* args, int n_problems, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_problems < 1 || n_problems > PJ_MAX_PROBLEMS) return GGNN_EINVAL;
+  ProjectBatch B;
+  B.n = n_problems;
+  const int k2 = args[0].k2;
+  double work[PJ_MAX_PROBLEMS], total = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    const ggnn_project_args& A = args[k];
+    if (!A.X || !A.Wp || !A.bias || !A.out || A.M <= 0) return GGNN_EINVAL;
+    if (A.F < 1 || A.F > 12 || A.ldx < A.F) return GGNN_EINVAL;
+    if (A.k2 != k2 || (k2 != 0 && k2 != C)) return GGNN_EINVAL;
+    if (k2 != 0 && (!A.H || A.ldh < k2 || (A.ldh & 3) || !aligned16(A.H))) return GGNN_EINVAL;
+    if (A.ncols <= 0 || A.ncols % PJ_BN != 0 || A.ldo < A.ncols || (A.ldo & 3)) return GGNN_EINVAL;
+    if (!aligned16(A.Wp) || !aligned16(A.bias) || !aligned16(A.out)) return GGNN_EINVAL;
+    if (A.M * std::max(A.ldo, std::max(A.ldx, A.ldh)) >= INT32_MAX) return GGNN_EINVAL;  // 32-bit row offsets
+    work[k] = (double)A.M * A.ncols;
+    total += work[k];
+  }
+  // decoder (K ~ 104): MFMA-bound, one workgroup per CU; encoder (K <= 12): store-bound with a
+  // tiny LDS footprint, so two workgroups per CU keep more stores in flight.  The workgroups are
+  // dealt to the problems in proportion to their output size.
+  const double budget = k2 ? num_cu() : 2 * num_cu();
+  B.wg_off[0] = 0;
+  for (int k = 0; k < PJ_MAX_PROBLEMS; ++k) {
+    B.a[k] = args[k < n_problems ? k : 0];
+    if (k >= n_problems) {
+      B.wg_off[k + 1] = B.wg_off[k];
+      B.m_splits[k] = 1;
+      continue;
+    }
+    const int nb_n = B.a[k].ncols / PJ_BN;
+    const int64_t n_mt = (B.a[k].M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
+    int64_t ms = (int64_t)(budget * work[k] / total / nb_n + 0.5);
+    ms = std::max<int64_t>(1, std::min(ms, n_mt));
+    B.m_splits[k] = (int)ms;
+    B.wg_off[k + 1] = B.wg_off[k] + (int)(nb_n * ms);
+  }
+  const int n_wg = B.wg_off[PJ_MAX_PROBLEMS];
+  hipStream_t s = (hipStream_t)stream;
+  if (k2 != 0 && gemm_mode() == GGNN_GEMM_BF16X6) return ggnn_project_x6(B, n_wg, s);
+  if (k2 == 0) hipLaunchKernelGGL((project_kernel<0>), dim3(n_wg), dim3(PJ_WAVES * 64), 0, s, B);
+  else hipLaunchKernelGGL((project_kernel<96>), dim3(n_wg), dim3(PJ_WAVES * 64), 0, s, B);
+  return launch_status();
+}
 
 extern "C" int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh,
                             int k2, const float* Wp, const float* bias, int64_t M, int ncols,
                             float* out, int64_t ldo, ggnn_stream_t stream) {
-  using namespace ggnn;
-  if (!X || !Wp || !bias || !out || M <= 0) return GGNN_EINVAL;
-  if (F < 1 || F > 12 || ldx < F) return GGNN_EINVAL;
-  if (k2 != 0 && k2 != C) return GGNN_EINVAL;
-  if (k2 != 0 && (!H || ldh < k2 || (ldh & 3) || !aligned16(H))) return GGNN_EINVAL;
-  if (ncols <= 0 || ncols % PJ_BN != 0 || ldo < ncols || (ldo & 3)) return GGNN_EINVAL;
-  if (!aligned16(Wp) || !aligned16(bias) || !aligned16(out)) return GGNN_EINVAL;
-  const int Fp = (F + 3) & ~3;
-  const int nb_n = ncols / PJ_BN;
-  const int64_t n_mt = (M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
-  // decoder (K ~ 104): MFMA-bound, one 95 KB workgroup per CU; encoder (K <= 12): store-bound
-  // with a tiny LDS footprint, so two workgroups per CU keep more stores in flight
-  int64_t m_splits = (k2 ? num_cu() : 2 * num_cu()) / nb_n;
-  if (m_splits < 1) m_splits = 1;
-  if (m_splits > n_mt) m_splits = n_mt;
-  const dim3 grid((unsigned)(nb_n * m_splits)), block(PJ_WAVES * 64);
-  hipStream_t s = (hipStream_t)stream;
-  if (k2 != 0 && gemm_mode() == GGNN_GEMM_BF16X6)
-    return ggnn_project_x6(X, ldx, F, H, ldh, Wp, bias, M, ncols, out, ldo, (int)m_splits, s);
-#define GGNN_PJ_LAUNCH(FP_, K2_)                                                                \
-  hipLaunchKernelGGL((project_kernel<FP_, K2_>), grid, block, 0, s, X, ldx, F, H, ldh, Wp, bias, \
-                     M, ncols, out, ldo, (int)m_splits)
-  if (k2 == 0) {
-    if (Fp == 4) GGNN_PJ_LAUNCH(4, 0);
-    else if (Fp == 8) GGNN_PJ_LAUNCH(8, 0);
-    else GGNN_PJ_LAUNCH(12, 0);
-  } else {
-    if (Fp == 4) GGNN_PJ_LAUNCH(4, 96);
-    else if (Fp == 8) GGNN_PJ_LAUNCH(8, 96);
-    else GGNN_PJ_LAUNCH(12, 96);
-  }
-#undef GGNN_PJ_LAUNCH
-  return launch_status();
+  const ggnn_project_args a = {X, H, Wp, bias, out, ldx, ldh, M, ldo, F, k2, ncols, 0};
+  return ggnn_project_batch(&a, 1, stream);
 }

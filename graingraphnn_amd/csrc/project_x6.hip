@@ -17,38 +17,41 @@
 //     reads (node l&15, the 8 consecutive k = 32 ks + 8 (l>>4)..) -> split into three planes in
 //     registers, where they stay for the whole 96-column sweep.  No workgroup barrier in the loop.
 #include "common.h"
+#include "project_batch.h"
 
 namespace ggnn {
 
-#ifndef PX_NWAVES
-#define PX_NWAVES 12
-#endif
-#ifndef PX_LDF
-#define PX_LDF 112
-#endif
-constexpr int PX_BM = 16, PX_BN = 96, PX_WAVES = PX_NWAVES, PX_KS = 4;
-constexpr int PX_LD = PX_LDF;  // floats per staged node row (96 + 16); 12 stages + weights = 160 128 B of LDS
+constexpr int PX_BM = 16, PX_BN = 96, PX_WAVES = 12, PX_KS = 4;
+constexpr int PX_LD = 112;  // floats per staged node row (96 + 16); 12 stages + weights = 160 128 B of LDS
+
+struct ProjectX6Lds {
+  u32x4 w[3][PX_BN][16];
+  f32x4 b[PX_BN / 4];
+  int next;  // tile queue of the workgroup: waves take the next 16-node tile when free
+  __attribute__((aligned(16))) float x[PX_WAVES][PX_BM * PX_LD];
+};
 
 template <int FP>
-__global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
-    const float* __restrict__ X, int64_t ldx, int F, const float* __restrict__ H, int64_t ldh,
-    const float* __restrict__ Wp, const float* __restrict__ bias, int64_t M, int ncols,
-    float* __restrict__ out, int64_t ldo, int m_splits) {
+__device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int blk, int m_splits, ProjectX6Lds& L) {
   constexpr int KP = FP + 96;  // row length of Wp: [X(FP) | H(96)]
-  __shared__ u32x4 s_w[3][PX_BN][16];
-  __shared__ f32x4 s_b[PX_BN / 4];
-  __shared__ int s_next;  // tile queue of the workgroup: waves take the next 16-node tile when free
-  __shared__ __attribute__((aligned(16))) float s_x[PX_WAVES][PX_BM * PX_LD];
+  auto& s_w = L.w;
+  auto& s_b = L.b;
+  int& s_next = L.next;
+  auto& s_x = L.x;
+  const float* __restrict__ X = A.X;
+  const float* __restrict__ H = A.H;
+  const float* __restrict__ Wp = A.Wp;
+  const float* __restrict__ bias = A.bias;
+  float* __restrict__ out = A.out;
+  const int64_t ldx = A.ldx, ldh = A.ldh, M = A.M, ldo = A.ldo;
+  const int F = A.F, ncols = A.ncols;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb_n = ncols / PX_BN;
-  const int bn = blockIdx.x % nb_n, ms = blockIdx.x / nb_n;
+  const int bn = blk % nb_n, ms = blk / nb_n;
   const int n0 = bn * PX_BN;
 
-#ifdef PX_VAR_CLOCK
-  const uint64_t t_p0 = __builtin_amdgcn_s_memrealtime();
-#endif
   // ---- prologue: split the weight tile into its three planes ----
 #pragma unroll
   for (int it = 0; it < PX_BN * 64 / (PX_WAVES * 64); ++it) {  // 12 independent load->split->write chains
@@ -71,9 +74,6 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
   if (tid == 0) s_next = PX_WAVES;
   __syncthreads();  // the only workgroup barrier
 
-#ifdef PX_VAR_CLOCK
-  const uint64_t t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   const int64_t n_mt = (M + PX_BM - 1) / PX_BM;
   const int64_t per = (n_mt + m_splits - 1) / m_splits;
   const int64_t mt_lo = ms * per, mt_hi = min(n_mt, (ms + 1) * per);
@@ -189,21 +189,12 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
       f32x4 acc_next = acc;
       if (st + 1 < NSTEP) {
         const int ct1 = (st + 1) / PX_KS, ks1 = (st + 1) % PX_KS;
-#ifndef PX_VAR_NO_LDS
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           wf[nxt][p] = pw[(p * PX_BN + ct1 * 16) * 16 + ((4 * ks1 + kq) ^ lr)];
-#else
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wf[nxt][p] = wf[cur][p] + (u32x4){1u, 2u, 3u, 4u};
-#endif
         if (ks1 == 0) acc_next = s_b[ct1 * 4 + kq];
       }
-#ifdef PX_VAR_NO_MFMA
-      acc[0] += __uint_as_float(wf[cur][0][0] ^ wf[cur][1][1] ^ wf[cur][2][2] ^ xb[ks][0][0]);
-#else
       acc = mfma_x6(wf[cur], xb[ks], acc);
-#endif
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -212,11 +203,7 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       if (ks == PX_KS - 1) {
-#ifdef PX_VAR_NO_STORE
-        if (acc[0] == 1.2345f) *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
-#else
         *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
-#endif
         acc = acc_next;
       }
     }
@@ -225,33 +212,24 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(
     if (!has_next) break;
     mt = mt_next;
   }
-#ifdef PX_VAR_CLOCK  // diagnostic build only: wave 0 of block 0 overwrites out[0, 0:4]
-  if (blockIdx.x == 0 && wave == 0 && lane == 0) {
-    const uint64_t dc = __builtin_amdgcn_s_memtime() - t_c0, dr = __builtin_amdgcn_s_memrealtime() - t_r0;
-    __builtin_amdgcn_s_waitcnt(0);
-    out[0] = (float)dc;
-    out[1] = (float)dr;
-    out[2] = (float)(mt_hi - mt_lo);
-    out[3] = (float)(t_r0 - t_p0);
-  }
-#endif
+}
+
+__global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(const ProjectBatch B) {
+  __shared__ ProjectX6Lds lds;
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
+  const ggnn_project_args& A = B.a[k];
+  const int blk = (int)blockIdx.x - B.wg_off[k], Fp = (A.F + 3) & ~3;
+  if (Fp == 4) project_x6_body<4>(A, blk, B.m_splits[k], lds);
+  else if (Fp == 8) project_x6_body<8>(A, blk, B.m_splits[k], lds);
+  else project_x6_body<12>(A, blk, B.m_splits[k], lds);
 }
 
 }  // namespace ggnn
 
-// Called by ggnn_project (project.hip) for k2 == 96 unless GGNN_GEMM=fp32.
-int ggnn_project_x6(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, const float* Wp,
-                    const float* bias, int64_t M, int ncols, float* out, int64_t ldo,
-                    int m_splits, hipStream_t s) {
+// Called by ggnn_project_batch (project.hip) for k2 == 96 unless GGNN_GEMM=fp32.
+int ggnn_project_x6(const ggnn::ProjectBatch& B, int n_wg, hipStream_t s) {
   using namespace ggnn;
-  const int Fp = (F + 3) & ~3;
-  const dim3 grid((unsigned)((ncols / PX_BN) * m_splits)), block(PX_WAVES * 64);
-#define GGNN_PX_LAUNCH(FP_)                                                                     \
-  hipLaunchKernelGGL((project_x6_kernel<FP_>), grid, block, 0, s, X, ldx, F, H, ldh, Wp, bias, M, \
-                     ncols, out, ldo, m_splits)
-  if (Fp == 4) GGNN_PX_LAUNCH(4);
-  else if (Fp == 8) GGNN_PX_LAUNCH(8);
-  else GGNN_PX_LAUNCH(12);
-#undef GGNN_PX_LAUNCH
+  hipLaunchKernelGGL(project_x6_kernel, dim3((unsigned)n_wg), dim3(PX_WAVES * 64), 0, s, B);
   return launch_status();
 }

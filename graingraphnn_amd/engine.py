@@ -1,10 +1,11 @@
 """Launch plan of one model forward on the HIP kernels.
 
 One HeteroPGCLSTM cell (heteropgclstm.py:148-183: 4 gates x 3 PeriodConv + LSTM update) is
-2 projection GEMMs + 1 launch of 3 aggregation sweeps + 1 launch of the gate-GEMM/LSTM epilogues of both
-node types = 4 launches; a
-model forward (edge geometry, encoder cell with h = c = 0, decoder cell, heads;
-models.py:422-452, 581-609) is 12-13 launches instead of the ~600 framework kernels the reference issues.
+THREE launches: the projection GEMMs of both node types, the three aggregation sweeps, the gate
+GEMM + LSTM epilogues of both node types -- for one model, or for the regressor and the classifier
+together (they run on the same x_dict / graph, test.py:382-383).  A model forward (edge geometry,
+encoder cell with h = c = 0, decoder cell, heads; models.py:422-452, 581-609) is 8-9 launches
+instead of the ~600 framework kernels the reference issues; a rollout step of both models is 13.
 """
 from typing import Dict, Optional, Tuple
 
@@ -105,24 +106,36 @@ def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
     return einfo
 
 
+def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo: Dict[ET, torch.Tensor]):
+    """One HeteroPGCLSTM.forward for every entry of `cells` -- (pc, h_in, c_in, proj, agg, h_out,
+    c_out), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
+    geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
+    launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
+    Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
+    projs, sweeps, gates = [], [], []
+    for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
+        lay = pc.layout
+        for nt in NODE_TYPES:
+            P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
+            projs.append((x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P))
+        for et in EDGE_TYPES:  # fewer sweeps when a destination type is dead
+            s, d = et[0], et[-1]
+            if not lay[d].live:
+                continue
+            sweeps.append((graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
+                           pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
+                           lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
+        gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
+    backend.project_batch(projs)
+    backend.aggregate_batch(sweeps)
+    backend.lstm_epilogue_batch(gates)
+
+
 def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],
              einfo: Dict[ET, torch.Tensor], h_in: Optional[Dict[str, torch.Tensor]],
              c_in: Optional[Dict[str, torch.Tensor]], proj, agg, h_out, c_out):
-    """One HeteroPGCLSTM.forward.  Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
-    lay = pc.layout
-    for nt in NODE_TYPES:  # 2 projection GEMMs
-        P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
-        backend.project(x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P)
-    sweeps = []  # 3 aggregation sweeps (fewer when a destination type is dead), one launch
-    for et in EDGE_TYPES:
-        s, d = et[0], et[-1]
-        if not lay[d].live:
-            continue
-        sweeps.append((graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
-                       pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
-                       lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
-    backend.aggregate_batch(sweeps)
-    backend.lstm_epilogue_batch(gate_problems(pc, proj, agg, c_in, h_out, c_out))  # both node types, one launch
+    """One HeteroPGCLSTM.forward of one model."""
+    run_cells(backend, [(pc, h_in, c_in, proj, agg, h_out, c_out)], graph, x, einfo)
 
 
 def gate_problems(pc: PackedCell, proj, agg, c_in, h_out, c_out):
@@ -142,6 +155,15 @@ def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphC
     if einfo is None:
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
         einfo = ws.einfo = prepare_edges(backend, graph, x, ea, ws.einfo)
-    run_cell(backend, enc, graph, x, einfo, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1)
-    run_cell(backend, dec, graph, x, einfo, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2)
+    run_encoder_decoder_multi(backend, [(enc, dec, ws)], graph, x, einfo)
     return ws.h2, ws.c2
+
+
+def run_encoder_decoder_multi(backend, models, graph: GraphCSR, x: Dict[str, torch.Tensor],
+                              einfo: Dict[ET, torch.Tensor]):
+    """The encoder cells of all `models` = [(enc, dec, workspace), ...] in three launches, then
+    their decoder cells in three more (every model keeps its own weights, workspace and state)."""
+    run_cells(backend, [(enc, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1) for enc, _, ws in models],
+              graph, x, einfo)
+    run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2) for _, dec, ws in models],
+              graph, x, einfo)

@@ -7,8 +7,9 @@ graph.update(), when `refresh_centres=True`] + edge-length refresh (:562-575).  
 edge-event topology surgery (Cmodel.update, :426) is host code outside this path; the topology
 is therefore static here.
 
-The whole step is ~35 kernel launches with no host synchronisation and no allocation, so it
-can be replayed from a hipGraph (`use_graph=True`) to remove launch overhead on small graphs.
+The whole step is 13 kernel launches (the regressor and the classifier share every launch of
+their cells) with no host synchronisation and no allocation, so it can be replayed from a hipGraph
+(`use_graph=True`) to remove launch overhead on small graphs.
 """
 from typing import Dict, Optional
 
@@ -17,7 +18,8 @@ import torch
 
 from . import _lib
 from .backend import default_backend
-from .engine import Workspace, _check_x, alloc_einfo, graph_for, prepare_edges, run_encoder_decoder
+from .engine import (Workspace, _check_x, alloc_einfo, graph_for, prepare_edges, run_encoder_decoder,
+                     run_encoder_decoder_multi)
 from .modules import _param_version
 from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
@@ -29,11 +31,15 @@ class GrainRollout:
     def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
                  edge_attr_dict, span: int, use_graph: bool = False, concurrent: bool = True,
                  refresh_centres: bool = False,
-                 domain_factor: float = 1.0, domain_offset: Optional[torch.Tensor] = None):
+                 domain_factor: float = 1.0, domain_offset: Optional[torch.Tensor] = None,
+                 joint_launches: bool = True):
         """refresh_centres: also recompute x_grain[:, :2] from the junction polygons every step,
         like the reference's traj.GNN_update + test.py:556-559 (default off = the static-geometry
         goldens).  domain_factor / domain_offset: `geometry_scaling` of test.py:310-312 when the
-        domain was folded by scale_feature_patchs (offset [n_joint, 2], floor of the scaled xy)."""
+        domain was folded by scale_feature_patchs (offset [n_joint, 2], floor of the scaled xy).
+        joint_launches (default): the regressor and the classifier see the same x, graph and edge
+        geometry, so every stage of their cells goes out as ONE launch for both (13 launches per
+        step); False = one set of launches per model, on two streams when `concurrent`."""
         self.be = default_backend()
         self.rmodel, self.cmodel = rmodel, cmodel
         self.x = {nt: x_dict[nt] for nt in NODE_TYPES}  # mutated in place, like the reference
@@ -61,8 +67,9 @@ class GrainRollout:
         self._tmp = torch.empty(nj, 8, **f32)
         # the regressor and the classifier are independent given (x, edge geometry): run them
         # on two HIP streams so one model's launch tails overlap the other's kernels
-        self.concurrent = concurrent
-        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if concurrent else None
+        self.joint_launches = joint_launches
+        self.concurrent = concurrent and not joint_launches
+        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.concurrent else None
         self.refresh_centres = refresh_centres
         self.domain_factor = float(domain_factor)
         self.domain_offset = None
@@ -139,7 +146,14 @@ class GrainRollout:
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                 self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
 
-        if self._side is None:
+        if self.joint_launches:
+            run_encoder_decoder_multi(be, [(*self.packed["R"], self.ws["R"]), (*self.packed["C"], self.ws["C"])],
+                                      self.graph, x, einfo)
+            be.heads_regressor(self.ws["R"].h2["joint"], self.ws["R"].h2["grain"], x["grain"], self.w_reg[0],
+                               self.w_reg[1], p["joint"], p["grain"], p["grain_area"])
+            be.heads_classifier(self.ws["C"].h2["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+        elif self._side is None:
             regressor()
             classifier()
         else:

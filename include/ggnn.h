@@ -117,6 +117,20 @@ int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_str
 int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh, int k2,
                  const float* Wp, const float* bias, int64_t M, int ncols, float* out,
                  int64_t ldo, ggnn_stream_t stream);
+/* Up to four projections in ONE launch: the node types of one cell and / or the same cell of the
+ * regressor and the classifier (both see the same x_dict, test.py:382-383).  Fields as the
+ * arguments of ggnn_project; all problems must share k2.  M * max(ldx, ldh, ldo) < 2^31.
+ * Same result as n single calls. */
+typedef struct ggnn_project_args {
+  const float* X;
+  const float* H; /* NULL when k2 == 0 */
+  const float* Wp;
+  const float* bias;
+  float* out;
+  int64_t ldx, ldh, M, ldo;
+  int32_t F, k2, ncols, reserved;
+} ggnn_project_args;
+int ggnn_project_batch(const ggnn_project_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Periodic-boundary GAT aggregation for one edge type, all gates fused.  Replaces
@@ -151,7 +165,8 @@ typedef struct ggnn_aggregate_args {
   int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
-/* The 1..3 sweeps of one cell (HeteroConv over the edge types, heteropgclstm.py:148-183) in ONE
+/* The 1..6 sweeps of one cell (HeteroConv over the edge types, heteropgclstm.py:148-183; of one
+ * model, or of the regressor and the classifier, which see the same graph: test.py:382-383) in ONE
  * launch: args[0..n_sweeps).  All must have the same n_gates and agree on h_src == NULL; they may
  * write disjoint columns of the same agg rows.  Same result as n_sweeps single calls. */
 int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,

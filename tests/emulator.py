@@ -136,6 +136,10 @@ class TorchEmulatorBackend:
             c_out.copy_(c)
             h_out.copy_(o * torch.tanh(c))
 
+    def project_batch(self, problems):
+        for prob in problems:
+            self.project(*prob)
+
     def lstm_epilogue_batch(self, problems):
         for prob in problems:
             self.lstm_epilogue(*prob)

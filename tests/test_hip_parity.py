@@ -288,17 +288,18 @@ def test_forward_golden(tag, seed, scale):
     assert gs["active_grains"].numel() == x["grain"].shape[0]
 
 
-@pytest.mark.parametrize("use_graph,concurrent", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("use_graph,launches", [(False, "joint"), (True, "joint"), (False, "serial"), (True, "two_streams")])
 @pytest.mark.parametrize("tag,seed,scale", CASES)
 @torch.no_grad()
-def test_rollout_golden(tag, seed, scale, use_graph, concurrent):
+def test_rollout_golden(tag, seed, scale, use_graph, launches):
     from graingraphnn_amd import GrainRollout
     x, ei, ea = _inputs(tag)
     g = golden(tag)
     n_steps, span = int(g["meta"][2]), int(g["meta"][3])
     R, Cm = product_models(seed, scale, DEV)
     X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
-    ro = GrainRollout(R, Cm, X, EI, EA, span, use_graph=use_graph, concurrent=concurrent)
+    ro = GrainRollout(R, Cm, X, EI, EA, span, use_graph=use_graph, joint_launches=launches == "joint",
+                      concurrent=launches == "two_streams")
     for step in range(1, n_steps + 1):
         pred = ro.step()
         if step == 1:
@@ -462,7 +463,7 @@ def test_cfg3_full_size_step_and_properties():
     assert float((sa - 1).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["two_streams_graph"])
+@pytest.mark.parametrize("mode", ["joint_launches_graph", "two_streams_graph"])
 @torch.no_grad()
 def test_cfg3_ten_step_rollout_as_benched(mode):
     """The exact step bench.py times (BASELINE config 3: 10k-grain honeycomb folded x10, weights
@@ -475,7 +476,7 @@ def test_cfg3_ten_step_rollout_as_benched(mode):
     X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
     oX, oEI, oEA = tt(x), tt(ei), tt(ea)
     ooff = torch.from_numpy(off)
-    kw = dict(concurrent=True)
+    kw = dict(joint_launches=True) if mode == "joint_launches_graph" else dict(joint_launches=False, concurrent=True)
     ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=True, refresh_centres=True, domain_factor=10.0,
                       domain_offset=ooff, **kw)
     threads = torch.get_num_threads()
@@ -887,9 +888,8 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
                 assert torch.equal(ya[k], yb[k]), (step, k)
             assert torch.equal(ca["edge_event"], cb["edge_event"]) and torch.equal(ca["edge"], cb["edge"])
             R.update(X, ya, None)                    # x_dict changes in place, same tensors
-        # steps 1..3 replay: R = edge records + 2 x (2 projections + 1 sweep batch + 2 gate GEMMs) = 11
-        # launches, C = 10 (its decoder skips the dead grain gate GEMM)
-        assert replays == [11, 10] * 3, replays
+        # steps 1..3 replay: edge records + 2 cells x (projections, sweeps, gate GEMMs) = 7 launches per model
+        assert replays == [7, 7] * 3, replays
         # new weights -> the tape is dropped and re-recorded
         R.linear["joint"].bias.add_(0.5)
         R.gclstm_decoder.cell_list[0].b_i["joint"].add_(0.1)
