@@ -252,6 +252,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="for rocprofv3 runs: only the rollout steps (no roofline timing, forward-only figure, "
+                         "CPU baseline or native-fp32 child run), so every traced kernel belongs to a step")
+    ap.add_argument("--joint", action="store_true", help="R and C in the same launches whatever the graph size")
     ap.add_argument("--serial", action="store_true", help="one set of launches per model, on one stream")
     ap.add_argument("--two-streams", action="store_true",
                     help="one set of launches per model, regressor and classifier on two streams (round-1 plan)")
@@ -321,8 +325,8 @@ def main():
         inputs = (x, ei, ea, factor, off)
         R, Cm = R.to(device), Cm.to(device)
         X, EI, EA = synthetic.to_torch(x, ei, ea, device)
-    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=args.two_streams,
-                      joint_launches=not (args.serial or args.two_streams),
+    ro = GrainRollout(R, Cm, X, EI, EA, SPAN, use_graph=not args.no_graph, concurrent=not args.serial,
+                      joint_launches=True if args.joint else False if (args.serial or args.two_streams) else None,
                       refresh_centres=True, domain_factor=inputs[3],
                       domain_offset=None if inputs[4] is None else torch.from_numpy(inputs[4]))
 
@@ -372,14 +376,15 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for g in gathered for v in g.values())
 
     if rank == 0:
-        roof = measure_roofline(ro, 10)
+        roof = None if args.profile else measure_roofline(ro, 10)
         # forward-only rate beside the full step (eager launches, R then C on one stream)
+        forward_only = 0.0
         with torch.no_grad():
-            for _ in range(5):
+            for _ in range(0 if args.profile else 5):
                 R(X, EI, EA), Cm(X, EI, EA)
             torch.cuda.synchronize()
             tf = time.perf_counter()
-            for _ in range(100):
+            for _ in range(0 if args.profile else 100):
                 R(X, EI, EA), Cm(X, EI, EA)
             torch.cuda.synchronize()
             forward_only = 100 / (time.perf_counter() - tf)
@@ -399,8 +404,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R then C on one stream" if args.serial else ", R|C on two streams" if args.two_streams
-                                  else ", R+C in the same launches (13 per step)"),
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R+C in the same launches (13 per step)" if ro.joint_launches else
+                                  ", R|C on two streams" if ro.concurrent else ", R then C on one stream"),
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
@@ -414,7 +419,7 @@ def main():
                           if args.events else {})},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and args.workload == "cfg3" and world == 1:  # N = 1 only: a reported baseline
+        if not args.no_cpu_baseline and not args.profile and args.workload == "cfg3" and world == 1:  # N = 1 only: a reported baseline
             line["cpu_baseline"] = cpu_baseline(inputs)
             if default_backend().lib.ggnn_gemm_mode() == 1 and not args.events:
                 # the same workload with the decoder GEMMs on the native fp32 matrix path, in a child

@@ -28,18 +28,24 @@ ET_JJ = ("joint", "connect", "joint")
 
 
 class GrainRollout:
+    JOINT_LAUNCH_MAX_JOINTS = 8000
+
     def __init__(self, rmodel, cmodel, x_dict: Dict[str, torch.Tensor], edge_index_dict,
                  edge_attr_dict, span: int, use_graph: bool = False, concurrent: bool = True,
                  refresh_centres: bool = False,
                  domain_factor: float = 1.0, domain_offset: Optional[torch.Tensor] = None,
-                 joint_launches: bool = True):
+                 joint_launches: Optional[bool] = None):
         """refresh_centres: also recompute x_grain[:, :2] from the junction polygons every step,
         like the reference's traj.GNN_update + test.py:556-559 (default off = the static-geometry
         goldens).  domain_factor / domain_offset: `geometry_scaling` of test.py:310-312 when the
         domain was folded by scale_feature_patchs (offset [n_joint, 2], floor of the scaled xy).
-        joint_launches (default): the regressor and the classifier see the same x, graph and edge
-        geometry, so every stage of their cells goes out as ONE launch for both (13 launches per
-        step); False = one set of launches per model, on two streams when `concurrent`."""
+        joint_launches: the regressor and the classifier see the same x, graph and edge geometry,
+        so every stage of their cells can go out as ONE launch for both (13 launches per step);
+        False = one set of launches per model, on two streams when `concurrent`.  Default (None):
+        joint launches below JOINT_LAUNCH_MAX_JOINTS junctions, where a step is launch-bound
+        (cfg2: 0.139 vs 0.162 ms per step); above it every kernel fills the chip by itself and the
+        two-stream plan wins by overlapping kernels of different kinds -- one model's matrix-bound
+        projection beside the other's memory-bound sweep (cfg3: 0.61 vs 0.66 ms per step)."""
         self.be = default_backend()
         self.rmodel, self.cmodel = rmodel, cmodel
         self.x = {nt: x_dict[nt] for nt in NODE_TYPES}  # mutated in place, like the reference
@@ -67,6 +73,8 @@ class GrainRollout:
         self._tmp = torch.empty(nj, 8, **f32)
         # the regressor and the classifier are independent given (x, edge geometry): run them
         # on two HIP streams so one model's launch tails overlap the other's kernels
+        if joint_launches is None:
+            joint_launches = self.n_nodes["joint"] < self.JOINT_LAUNCH_MAX_JOINTS
         self.joint_launches = joint_launches
         self.concurrent = concurrent and not joint_launches
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.concurrent else None

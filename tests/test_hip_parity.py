@@ -858,7 +858,7 @@ def test_batched_sweeps_equal_single_launches(which):
     with pytest.raises(_lib.GGNNError):
         be.aggregate_batch([sw[0], sw[1][:-1] + (3,)])                  # n_gates differ
     with pytest.raises(_lib.GGNNError):
-        be.aggregate_batch(sw + sw[:1])                                 # more than three sweeps
+        be.aggregate_batch(sw + sw + sw[:1])                            # more than six sweeps
     with pytest.raises(_lib.GGNNError):
         be.aggregate_batch([])
 

@@ -218,7 +218,7 @@ def test_bf16_autocast_training_step_stays_close_to_fp32():
     assert g is not None and g.dtype == torch.float32 and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
 
 
-BF16_GTOL = 8e-2   # bf16 autocast: 8 significand bits (unit roundoff 2^-9) through the stacked
+BF16_GTOL = 5e-2   # bf16 autocast: 8 significand bits (unit roundoff 2^-9) through the stacked
 #                     linears of two cells; per-tensor gradient error against the fp32 oracle
 
 
@@ -265,55 +265,32 @@ def test_cfg5_collated_minibatch_fp32_and_bf16_against_the_fp32_oracle():
                 worst16 = max(worst16, err / scale)
     print(f"cfg5 batch of 4: worst per-tensor gradient error fp32 {worst32:.2e}, bf16 autocast {worst16:.2e}")
     # (3) two Adam steps, as train.py does them
-    for autocast, tol in ((False, 1e-3), (True, 5e-2)):
+    lr_adam = 5e-3                                                   # parameters.py:18-50 regressor lr
+    for autocast in (False, True):
         Rt, _ = product_models(4, 1.0, "cuda")
         oRt, _ = oracle_models(4, 1.0)
+        g_first = {}
         for m, dev in ((Rt, "cuda"), (oRt, "cpu")):
             m.train()
-            opt = torch.optim.Adam(m.parameters(), lr=5e-3)          # parameters.py:18-50 regressor lr
-            for _ in range(2):
+            opt = torch.optim.Adam(m.parameters(), lr=lr_adam)
+            for it in range(2):
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast and dev == "cuda"):
                     loss = training.regressor_loss(tt(y_np, dev), m(tt(x, dev), tt(ei, dev), tt(ea, dev)), tt(m_np, dev))
                 opt.zero_grad()
                 loss.backward()
+                if dev == "cpu" and it == 0:
+                    g_first = {n: float(p.grad.abs().max()) for n, p in m.named_parameters()}
                 opt.step()
+        gmax = max(g_first.values())
         for (n, p), (_, q) in zip(Rt.named_parameters(), oRt.named_parameters()):
-            # Adam's first steps move every weight by ~lr whatever the gradient's size, so a sign
-            # flip of a near-zero gradient shows up as 2 lr: bound in units of lr for bf16
-            bound = tol * max(float(q.abs().max()), 1e-3) if not autocast else 2.5 * 5e-3 * 2
-            assert float((p.cpu() - q).abs().max()) <= bound, (autocast, n)
-
-
-@pytest.mark.gpu
-def test_ddp_over_rccl_as_the_reference_wraps_it():
-    """dist_train.py:79-82 on one GPU: init_process_group('nccl') + DistributedDataParallel(model,
-    device_ids=[rank]); two iterations (the second is what unused parameters would break)."""
-    import torch.distributed as dist
-    from torch.nn.parallel import DistributedDataParallel
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    x, ei, ea = load_graph("40")
-    y_np, m_np = _targets(x, ei)
-    y, mask = tt(y_np, "cuda"), tt(m_np, "cuda")
-    R, _ = product_models(10020, 1.0, "cuda")
-    R.train()
-    X, EI, EA = tt(x, "cuda"), tt(ei, "cuda"), tt(ea, "cuda")
-    training.regressor_loss(y, R(X, EI, EA), mask).backward()
-    ref = {n: p.grad.clone() for n, p in R.named_parameters()}
-    R.zero_grad()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
-    try:
-        model = DistributedDataParallel(R, device_ids=[0])
-        for _ in range(2):
-            model.zero_grad()
-            training.regressor_loss(y, model(X, EI, EA), mask).backward()
-        for n, p in R.named_parameters():
-            assert torch.equal(p.grad, ref[n]), n
-    finally:
-        dist.destroy_process_group()
+            # Adam moves a weight by ~lr per step whatever the gradient's size: where the exact
+            # gradient is zero (key biases: a softmax is shift-invariant; the encoder's forget gate)
+            # each implementation steps along its own rounding noise, so those tensors are only held
+            # to 2 steps x lr each way.  Under bf16 every tensor is held to that bound: a gradient
+            # entry near zero may change sign.
+            noise_only = g_first[n] <= 1e-5 * gmax
+            bound = 4 * lr_adam * 1.01 if (autocast or noise_only) else 1e-3 * max(float(q.abs().max()), 1e-3)
+            assert float((p.detach().cpu() - q.detach()).abs().max()) <= bound, (autocast, n, noise_only)
 
 
 def _ddp_gpu_worker(rank, world, port, out):
