@@ -223,21 +223,38 @@ extern "C" int ggnn_project_batch(const ggnn_project_args* args, int n_problems,
   // decoder (K ~ 104): MFMA-bound, one workgroup per CU; encoder (K <= 12): store-bound with a
   // tiny LDS footprint, so two workgroups per CU keep more stores in flight.  The workgroups are
   // dealt to the problems in proportion to their output size.
-  const double budget = k2 ? num_cu() : 2 * num_cu();
+  const int budget = k2 ? num_cu() : 2 * num_cu();
+  // row splits per problem: proportional to the output size, rounded DOWN (one workgroup more than
+  // the budget would wait for a second round and double the launch), then the spare workgroups
+  // go, one row split at a time, to the problem whose workgroups have the most rows
+  int nb_n[PJ_MAX_PROBLEMS];
+  int64_t n_mt[PJ_MAX_PROBLEMS], ms[PJ_MAX_PROBLEMS];
+  int used = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    nb_n[k] = args[k].ncols / PJ_BN;
+    n_mt[k] = (args[k].M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
+    ms[k] = std::max<int64_t>(1, std::min<int64_t>((int64_t)(budget * work[k] / total / nb_n[k]), n_mt[k]));
+    used += (int)(nb_n[k] * ms[k]);
+  }
+  for (;;) {
+    int best = -1;
+    double best_rows = 0;
+    for (int k = 0; k < n_problems; ++k) {
+      const double rows = (double)args[k].M / ms[k];
+      if (ms[k] < n_mt[k] && used + nb_n[k] <= budget && rows > best_rows) {
+        best = k;
+        best_rows = rows;
+      }
+    }
+    if (best < 0) break;
+    ms[best] += 1;
+    used += nb_n[best];
+  }
   B.wg_off[0] = 0;
   for (int k = 0; k < PJ_MAX_PROBLEMS; ++k) {
     B.a[k] = args[k < n_problems ? k : 0];
-    if (k >= n_problems) {
-      B.wg_off[k + 1] = B.wg_off[k];
-      B.m_splits[k] = 1;
-      continue;
-    }
-    const int nb_n = B.a[k].ncols / PJ_BN;
-    const int64_t n_mt = (B.a[k].M + PJ_BM * PJ_WAVES - 1) / (PJ_BM * PJ_WAVES);  // 128-node groups
-    int64_t ms = (int64_t)(budget * work[k] / total / nb_n + 0.5);
-    ms = std::max<int64_t>(1, std::min(ms, n_mt));
-    B.m_splits[k] = (int)ms;
-    B.wg_off[k + 1] = B.wg_off[k] + (int)(nb_n * ms);
+    B.m_splits[k] = k < n_problems ? (int)ms[k] : 1;
+    B.wg_off[k + 1] = B.wg_off[k] + (k < n_problems ? (int)(nb_n[k] * ms[k]) : 0);
   }
   const int n_wg = B.wg_off[PJ_MAX_PROBLEMS];
   hipStream_t s = (hipStream_t)stream;
