@@ -351,7 +351,10 @@ def main():
     for _ in range(args.warmup):
         step()
     if not args.events:
-        ro.run(GrainRollout.RUN_UNROLL)  # untimed: captures the multi-step graph
+        # steps per hipGraph (measured, cfg3, 20 / 500 timed steps: 4 -> 0.591 / 0.564 ms per step,
+        # 10 -> 0.587 / 0.582, 20 -> 0.606 / 0.580)
+        ro.RUN_UNROLL = max(1, min(args.steps, int(os.environ.get("GGNN_BENCH_UNROLL", "4"))))
+        ro.run(ro.RUN_UNROLL)  # untimed: captures the multi-step graph
     gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
     torch.cuda.synchronize()
     if world > 1:
@@ -404,7 +407,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({GrainRollout.RUN_UNROLL} steps per graph)") + (", R+C in the same launches (13 per step)" if ro.joint_launches else
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({ro.RUN_UNROLL} steps per graph)") + (", R+C in the same launches (13 per step)" if ro.joint_launches else
                                   ", R|C on two streams" if ro.concurrent else ", R then C on one stream"),
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
