@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
-    "ggnn_period_gat_aggregate_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
+    "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
@@ -68,6 +68,17 @@ class AggregateArgs(Structure):
         ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
         ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
         ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
+    ]
+
+
+class AggregateEncArgs(Structure):
+    """Mirror of `ggnn_aggregate_enc_args`."""
+    _fields_ = [
+        ("unit_ptr", c_void_p), ("units", c_void_p), ("einfo", c_void_p), ("p_dst", c_void_p),
+        ("wv_frag", c_void_p), ("agg", c_void_p),
+        ("ldp_dst", c_int64), ("ld_agg", c_int64), ("n_dst", c_int64), ("E", c_int64),
+        ("u4_off", c_int32), ("a_off", c_int32), ("a_gstride", c_int32), ("sc_off", c_int32),
+        ("n_gates", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -137,6 +148,8 @@ def _declare(lib):
     lib.ggnn_period_gat_aggregate.argtypes = [POINTER(AggregateArgs), c_void_p]
     lib.ggnn_period_gat_aggregate_batch.restype = c_int
     lib.ggnn_period_gat_aggregate_batch.argtypes = [POINTER(AggregateArgs), c_int, c_void_p]
+    lib.ggnn_period_gat_aggregate_enc_batch.restype = c_int
+    lib.ggnn_period_gat_aggregate_enc_batch.argtypes = [POINTER(AggregateEncArgs), c_int, c_void_p]
     lib.ggnn_aggregate_bwd_partials.restype = c_int64
     lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
     lib.ggnn_period_gat_aggregate_backward.restype = c_int

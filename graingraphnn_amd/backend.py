@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (AggregateArgs, AggregateBwdArgs, EpilogueArgs, PrepareEdge, ProjectArgs, RefreshEdge, check,
+from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, EpilogueArgs, PrepareEdge, ProjectArgs, RefreshEdge, check,
                    ptr)
 
 
@@ -157,6 +157,22 @@ class HipBackend:
         for a, sweep in zip(arr, sweeps):
             self._sweep_args(a, *sweep)
         self._launch(self.lib.ggnn_period_gat_aggregate_batch, "ggnn_period_gat_aggregate_batch", arr,
+                     len(sweeps), _lib.current_stream())
+
+    def aggregate_enc_batch(self, sweeps):
+        """Encoder sweeps (h = 0) with the edge values on the matrix cores
+        (ggnn_period_gat_aggregate_enc_batch); each item: (csr, einfo, p_dst, wv_frag, agg, u4_off, a_off,
+        a_gstride, sc_off, n_gates)."""
+        arr = (AggregateEncArgs * len(sweeps))()
+        for a, (csr, einfo, p_dst, wvf, agg, u4_off, a_off, a_gstride, sc_off, n_gates) in zip(arr, sweeps):
+            _require_cuda(csr.unit_ptr, einfo, p_dst, wvf, agg)
+            if wvf.dtype != torch.float32 or wvf.numel() != 6 * n_gates * 3 * 64:
+                raise _lib.GGNNError("wv_frag does not match n_gates (see packing.value_fragments)")
+            a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
+            a.p_dst, a.wv_frag, a.agg = p_dst.data_ptr(), wvf.data_ptr(), agg.data_ptr()
+            a.ldp_dst, a.ld_agg, a.n_dst, a.E = p_dst.stride(0), agg.stride(0), p_dst.size(0), csr.E
+            a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = u4_off, a_off, a_gstride, sc_off, n_gates
+        self._launch(self.lib.ggnn_period_gat_aggregate_enc_batch, "ggnn_period_gat_aggregate_enc_batch", arr,
                      len(sweeps), _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
 #pragma unroll
     for (int c = 3; c < 12; ++c)
       if (c < T.f_src) rec[c] = xs[c];
+    if (T.f_src <= 11) rec[11] = 1.0f;  // bias row of the encoder sweep's value product (aggregate_enc.hip)
     rec[12] = 1.0f;
     rec[13] = rec[19] = T.edge_attr[T.perm[p]];
   }

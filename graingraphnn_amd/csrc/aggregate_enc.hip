@@ -1,0 +1,259 @@
+// Encoder aggregation sweep (h = c = 0: the cell sees only the 8 / 11 node features) with the edge
+// values on the matrix cores.  Same contract as the h_src == NULL form of
+// ggnn_period_gat_aggregate (aggregate.hip) -- PeriodConv.message (periodGATconv.py:204-236) +
+// propagate's gather / scatter-add, all gates of one edge type --, but nothing is gathered from a
+// projected source row: with h = 0 the value of edge e = (j -> i) is
+//     r_e = relu(W_value . x~_e + b_value),   x~_e = [reloc_e, x_j[3:F]]
+// a 96 x (<= 11) product of the edge's own 16-float record (ggnn_edge_prepare: reloc, x_j[3:F], .., 1
+// at 11 and 12, a_e at 13), so the source-side projection of the encoder (3 x 96 value columns per
+// edge type and node: 46 + 23 + 46 MB written and gathered again per model at cfg3) disappears:
+//   * a wave works on FOUR units at a time (a unit = one destination row x <= 3 in-edges; 16-lane
+//     group q of the wave owns unit q); their 4 x (3 + 1 pad) edge records are the 16 rows of an
+//     MFMA A operand (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains);
+//   * VALUES: A x [12 x 288] weight fragments that stay in 54 VGPRs for the whole sweep (bias in
+//     row 11) -> per column tile a 16 x 16 block D[edge][column]; the columns are ordered so that
+//     lane c of group q ends up with channels 6c .. 6c+5 of every gate of ITS unit: the
+//     alpha-weighted sum over the unit's edges is lane-local (registers r = 0..2 of D) and the row
+//     leaves as contiguous 384-byte pieces;
+//   * SCORES: the same A x a [16 x 16] operand whose column 4u + g is the destination-side tail
+//     u4 of unit u's row for gate g (ggnn_project: u . x + s1 + a_e s2, see aggregate.hip) and
+//     whose column 4u + 3 picks a_e: one more MFMA chain; the softmax of a unit is local to lane
+//     4q + g of group q, its 3 weights and the rescale factor reach the group through
+//     ds_bpermute;
+//   * rows of any degree: units of one row are folded with the online-max softmax carried in
+//     registers, exactly as in aggregate.hip; no atomics, one owner per output row.
+// Everything that describes the four unit streams of a wave (rows r = 4 (W + k NW) + q) is
+// wave-uniform and lives on the scalar side (SMEM loads of unit_ptr / descriptors one block ahead).
+#include <algorithm>
+
+#include "common.h"
+
+namespace ggnn {
+
+constexpr int AE_MAX_SWEEPS = 6;
+constexpr int AE_BLOCKS_PER_CU = 3;  // 4 waves each: 12 waves per CU, 3 per SIMD (<= 168 VGPRs)
+
+struct EncSweepBatch {
+  ggnn_aggregate_enc_args a[AE_MAX_SWEEPS];
+  int n;
+};
+
+typedef int ae_i32x4 __attribute__((ext_vector_type(4)));
+typedef const ae_i32x4 __attribute__((address_space(4))) * ae_desc_ptr;  // uniform index -> s_load_dwordx4
+typedef const int __attribute__((address_space(4))) * ae_i32_ptr;
+
+__device__ __forceinline__ float bperm(int byte_addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float quad_lane3(float v) {  // value of the quad's 4th lane in all four
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
+}
+template <typename T>
+__device__ __forceinline__ T sel4(int k, T a0, T a1, T a2, T a3) {
+  return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
+}
+
+template <int G>
+__global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(const EncSweepBatch B) {
+  constexpr int NT = 6 * G;  // column tiles: gate t / 6, channels 6 c + t % 6 of lane c
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int qa = c >> 2, ra = c & 3;  // A / score-B role: row or column c belongs to unit qa
+  const int64_t W = (int64_t)blockIdx.x * 4 + wave, NWV = (int64_t)gridDim.x * 4;
+  const int src_lane4 = (20 * q) * 4;  // byte address of lane 16 q + 4 q for ds_bpermute
+
+  for (int k = 0; k < B.n; ++k) {
+    const ggnn_aggregate_enc_args& A = B.a[k];
+    if (4 * W >= A.n_dst) continue;
+    const ae_i32_ptr uptr = (ae_i32_ptr)(uintptr_t)A.unit_ptr;
+    const ae_desc_ptr udesc = (ae_desc_ptr)(uintptr_t)A.units;  // 2 x int4 per unit; [0] = {i, p0, flags, -}
+    const float* __restrict__ einfo = A.einfo;
+    const uint32_t ldp = (uint32_t)A.ldp_dst;
+    const int e_last = (int)A.E + GGNN_UNIT_EDGES - 1;  // einfo holds E + GGNN_UNIT_EDGES records
+
+    // value weights: B fragments, stationary in registers
+    float bw[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[t][s] = A.wv_frag[(t * 3 + s) * 64 + lane];
+
+    // ---- scalar cursors of the four unit streams: current row (u .. ue), next row (un .. une) ----
+    int64_t r[4];
+    int u[4], ue[4], un[4], une[4];
+    bool alive[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      r[g4] = 4 * W + g4;
+      alive[g4] = r[g4] < A.n_dst;
+      u[g4] = ue[g4] = un[g4] = une[g4] = 0;
+      if (alive[g4]) {
+        u[g4] = uptr[r[g4]];
+        ue[g4] = uptr[r[g4] + 1];
+        const int64_t rn = r[g4] + 4 * NWV;
+        if (rn < A.n_dst) {
+          un[g4] = uptr[rn];
+          une[g4] = uptr[rn + 1];
+        }
+      }
+    }
+    ae_i32x4 d[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) d[g4] = alive[g4] ? udesc[2 * (int64_t)u[g4]] : (ae_i32x4){0, 0, 0, 0};
+
+    // per-lane softmax / accumulation state of the row group q is folding
+    float mx = -INFINITY;  // meaningful in lanes c = 4 q + g
+    float den[G], sae[G], acc[NT];
+#pragma unroll
+    for (int g = 0; g < G; ++g) den[g] = sae[g] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+
+    while (alive[0] | alive[1] | alive[2] | alive[3]) {
+      // ---- vector operands of this block (issued back to back, one exposed round trip) ----
+      const int p0_a = sel4(qa, d[0][1], d[1][1], d[2][1], d[3][1]);
+      const int i_b = sel4(qa, d[0][0], d[1][0], d[2][0], d[3][0]);
+      const int i_q = sel4(q, d[0][0], d[1][0], d[2][0], d[3][0]);
+      const int fl_q = sel4(q, d[0][2], d[1][2], d[2][2], d[3][2]);
+      // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer)
+      const float* arow = einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + q;
+      const float* brow = A.p_dst + (uint32_t)i_b * ldp + A.u4_off + 16 * min(ra, G - 1) + q;
+      float a[4], bs[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = arow[4 * s];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bs[s] = __builtin_nontemporal_load(brow + 4 * s);
+      if (ra >= G) {  // column 4 u + 3: picks a_e = x4[13] (k-step 3, k = 12 + q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bs[s] = (s == 3 && q == 1) ? 1.0f : 0.0f;
+      }
+
+      // ---- scalar side: the next block's descriptors, under the vector round trip ----
+      ae_i32x4 dn[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (alive[g4]) {
+          if (u[g4] + 1 < ue[g4]) {
+            u[g4] += 1;
+          } else {
+            r[g4] += 4 * NWV;
+            if (r[g4] < A.n_dst) {
+              u[g4] = un[g4];
+              ue[g4] = une[g4];
+              const int64_t rn = r[g4] + 4 * NWV;
+              if (rn < A.n_dst) {
+                un[g4] = uptr[rn];
+                une[g4] = uptr[rn + 1];
+              }
+            } else {
+              alive[g4] = false;
+            }
+          }
+        }
+        dn[g4] = alive[g4] ? udesc[2 * (int64_t)u[g4]] : (ae_i32x4){0, 0, 0, 0};
+      }
+
+      const int nact = fl_q & 0xFF;
+      const bool first = (fl_q >> 8) & 1, last = (fl_q >> 9) & 1;
+      if (first) {
+        mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < G; ++g) den[g] = sae[g] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+      }
+
+      // ---- scores: D[edge 4 q + r][column c]; lane c = 4 q + g holds unit q's scores for gate g ----
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bs[s], sc, 0, 0, 0);
+      const float ae0 = quad_lane3(sc[0]), ae1 = quad_lane3(sc[1]), ae2 = quad_lane3(sc[2]);
+      const float s0 = nact > 0 ? sc[0] : -INFINITY, s1 = nact > 1 ? sc[1] : -INFINITY,
+                  s2 = nact > 2 ? sc[2] : -INFINITY;
+      const float mnew = fmaxf(fmaxf(mx, s0), fmaxf(s1, s2));
+      const bool any = nact > 0;  // (an empty row has one unit with nact == 0: zeros are stored)
+      const float scale_l = any ? __expf(mx - mnew) : 1.0f;  // exp(-inf) = 0 on a row's first unit
+      const float p0_l = any ? __expf(s0 - mnew) : 0.f, p1_l = any ? __expf(s1 - mnew) : 0.f,
+                  p2_l = any ? __expf(s2 - mnew) : 0.f;
+      if (any) mx = mnew;
+      // the softmax lanes' results -> every lane of the group
+      float scale[G], p0[G], p1[G], p2[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        scale[g] = bperm(src_lane4 + 4 * g, scale_l);
+        p0[g] = bperm(src_lane4 + 4 * g, p0_l);
+        p1[g] = bperm(src_lane4 + 4 * g, p1_l);
+        p2[g] = bperm(src_lane4 + 4 * g, p2_l);
+      }
+      const float e0 = bperm(src_lane4, ae0), e1 = bperm(src_lane4, ae1), e2 = bperm(src_lane4, ae2);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        den[g] = den[g] * scale[g] + (p0[g] + p1[g] + p2[g]);
+        sae[g] = sae[g] * scale[g] + (p0[g] * e0 + p1[g] * e1 + p2[g] * e2);
+      }
+
+      // ---- values: per column tile D[edge 4 q + r][column c] = W x~ + b, relu, alpha-weighted sum ----
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int g = t / 6;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[t][s], v, 0, 0, 0);
+        acc[t] = acc[t] * scale[g] + (p0[g] * fmaxf(v[0], 0.f) + p1[g] * fmaxf(v[1], 0.f) + p2[g] * fmaxf(v[2], 0.f));
+      }
+
+      if (last) {
+        float* orow = A.agg + (int64_t)i_q * A.ld_agg + A.a_off + 6 * c;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float inv = 1.0f / (den[g] + 1e-16f);  // PyG softmax denominator
+          float* o = orow + g * A.a_gstride;
+#pragma unroll
+          for (int m = 0; m < 6; m += 2) {
+            const f32x2_ w2 = {acc[6 * g + m] * inv, acc[6 * g + m + 1] * inv};
+            __builtin_nontemporal_store(w2, reinterpret_cast<f32x2_*>(o + m));
+          }
+          if (c == 0) {  // 8 bytes of a line the other edge type's sweep also writes into: through L2
+            float* sp = A.agg + (int64_t)i_q * A.ld_agg + g * A.a_gstride + A.sc_off;
+            sp[0] = den[g] * inv;
+            sp[1] = sae[g] * inv;
+          }
+        }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) d[g4] = dn[g4];
+    }
+  }
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_period_gat_aggregate_enc_batch(const ggnn_aggregate_enc_args* args, int n_sweeps,
+                                                   ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_sweeps < 1 || n_sweeps > AE_MAX_SWEEPS) return GGNN_EINVAL;
+  EncSweepBatch B;
+  B.n = n_sweeps;
+  int64_t want = 1;
+  for (int k = 0; k < AE_MAX_SWEEPS; ++k) {
+    B.a[k] = args[k < n_sweeps ? k : 0];
+    const ggnn_aggregate_enc_args& A = B.a[k];
+    if (!A.unit_ptr || !A.units || !A.einfo || !A.p_dst || !A.wv_frag || !A.agg) return GGNN_EINVAL;
+    if (!aligned16(A.units) || !aligned16(A.einfo) || (reinterpret_cast<uintptr_t>(A.agg) & 7u)) return GGNN_EINVAL;
+    if (A.n_dst <= 0 || A.E < 0 || A.n_gates != 3) return GGNN_EINVAL;
+    if (A.u4_off < 0 || A.a_off < 0 || (A.a_off & 1) || A.sc_off < 0 || A.a_gstride < C || (A.a_gstride & 1) ||
+        (A.ld_agg & 1))
+      return GGNN_EINVAL;
+    if (A.ldp_dst <= 0 || A.n_dst * A.ldp_dst >= INT32_MAX || (A.E + GGNN_UNIT_EDGES + 1) * GGNN_EINFO_ROW >= INT32_MAX)
+      return GGNN_EINVAL;  // 32-bit row offsets
+    if (A.u4_off + (int64_t)A.n_gates * 16 > A.ldp_dst) return GGNN_EINVAL;
+    if ((int64_t)(A.n_gates - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
+    if ((int64_t)(A.n_gates - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
+    want = std::max<int64_t>(want, (A.n_dst + 15) / 16);  // 4 waves x 4 rows per workgroup
+  }
+  const int64_t cap = (int64_t)num_cu() * AE_BLOCKS_PER_CU;
+  const dim3 grid((unsigned)(want < cap ? want : cap));
+  hipLaunchKernelGGL((aggregate_enc_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, B);
+  return launch_status();
+}

@@ -112,7 +112,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
     launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
     Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
-    projs, sweeps, gates = [], [], []
+    projs, sweeps, enc_sweeps, gates = [], [], [], []
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
         for nt in NODE_TYPES:
@@ -122,12 +122,19 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
             s, d = et[0], et[-1]
             if not lay[d].live:
                 continue
+            if pc.wvf:  # encoder: values from the edge records on the matrix cores
+                enc_sweeps.append((graph.csr[et], einfo[et], proj[d], pc.wvf[et], agg[d], lay[d].u4_off[et],
+                                   lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
+                continue
             sweeps.append((graph.csr[et], einfo[et], proj[s], proj[d], h_in[s] if pc.k2 else None,
                            pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
                            lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
         gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
     backend.project_batch(projs)
-    backend.aggregate_batch(sweeps)
+    if enc_sweeps:
+        backend.aggregate_enc_batch(enc_sweeps)
+    if sweeps:
+        backend.aggregate_batch(sweeps)
     backend.lstm_epilogue_batch(gates)
 
 

@@ -6,7 +6,9 @@ Layouts (C = 96, G = number of gates, F = features of the node type, Fp = roundu
 * projection weight of node type T, `Wp [ncols, Kp]`, Kp = Fp + (96 if the cell sees h else 0).
   Rows of Wp = columns of the projection output, in this order:
       for each edge type with source T:       for g: V_g   [96]  lin_value, first three input
-                                              columns zeroed (the sweep re-adds W[:, :3] . reloc)
+                                              columns zeroed (the sweep re-adds W[:, :3] . reloc);
+                                              decoder only -- the encoder sweep forms its values
+                                              from the edge records (value_fragments below)
       for each edge type with destination T:  for g: u_h_g [96]  (only when the cell sees h)
       summed skip + gate bias:                for g: S_g   [96]  (lin_skip summed over incoming
                                               edge types = HeteroConv aggr 'sum', + b_{i,f,c,o})
@@ -71,16 +73,18 @@ U4 = 16  # width of the per-(destination, gate) tail record: u[0:F_src], s1 @12,
 
 
 def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True,
-                sees_h: bool = True) -> NodeLayout:
+                sees_h: bool = True, with_values: bool = True) -> NodeLayout:
     """`live=False`: the new (h, c) of this node type is never read (the classifier's decoder only
     feeds h_joint to its head, models.py:595-609), so the type keeps only its role as a message
     SOURCE: no score / skip columns, no aggregation into it, no gate update.
-    `sees_h=False` (encoder, h = 0): the hidden-state part of u is not needed."""
+    `sees_h=False` (encoder, h = 0): the hidden-state part of u is not needed.
+    `with_values=False` (encoder): no value columns -- the encoder sweep forms the values from the
+    edge records on the matrix cores (ggnn_period_gat_aggregate_enc_batch)."""
     src_ets = [tuple(et) for et in edge_types if et[0] == node_type]
     dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type] if live else []
     lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets, live=live)
     off = 0
-    for et in src_ets:
+    for et in src_ets if with_values else ():
         lay.v_off[et] = off
         off += G * C
     if sees_h:
@@ -112,7 +116,8 @@ class PackedCell:
     bp: Dict[str, torch.Tensor]     # node type -> [ncols]
     ep: Dict[Tuple[str, str, str], torch.Tensor]  # edge type -> [G, 3, 96]
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
-    w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> bf16 planes of w2 (bf16_planes)
+    w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> fragment-ordered w2 (bf16_planes)
+    wvf: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # encoder: edge type -> value_fragments
 
 
 @torch.no_grad()
@@ -144,6 +149,25 @@ def bf16_planes(w2: torch.Tensor) -> torch.Tensor:
     return fr.view(torch.int16).view(-1)
 
 
+@torch.no_grad()
+def value_fragments(weights, biases, F_src: int) -> torch.Tensor:
+    """`ggnn_aggregate_enc_args.wv_frag` (include/ggnn.h): the encoder's lin_value of the G gates of
+    one edge type (weights[g]: [96, >= F_src], biases[g]: [96]) as MFMA B fragments of
+    Bp [12, G * 96]: Bp[k][g*96 + ch] = W_g[ch][k] (k < F_src), Bp[11] = b_g; element
+    [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 6 (l & 15) + t % 6]."""
+    G = len(weights)
+    if F_src > 11:
+        raise ValueError("the encoder sweep keeps its bias in record slot 11: at most 11 source features")
+    dev = weights[0].device
+    Bp = torch.zeros(12, G * C, dtype=torch.float32, device=dev)
+    for g in range(G):
+        Bp[:F_src, g * C:(g + 1) * C] = weights[g].detach().float()[:, :F_src].t()
+        Bp[11, g * C:(g + 1) * C] = biases[g].detach().float()
+    fr = Bp.view(3, 4, G, 16, 6)               # s kq g j m   (k = 4 s + kq, column = g*96 + 6 j + m)
+    fr = fr.permute(2, 4, 0, 1, 3).contiguous()  # g m s kq j  (tile t = 6 g + m, lane l = 16 kq + j)
+    return fr.view(-1)
+
+
 def _conv(cell, gate, et):
     return getattr(cell, "conv_" + gate).convs[et_key(et)]
 
@@ -159,7 +183,10 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
     some = _conv(cell, "i", edge_types[0]).lin_key.weight
     dev, dt = some.device, torch.float32
     F_of = dict(in_channels)
-    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, not encoder) for nt in NODE_TYPES}
+    # encoder: the sweep forms the values from the edge records (no value columns in the projection)
+    enc_mfma = encoder and all(F <= 11 for F in in_channels.values())
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, not encoder, not enc_mfma)
+              for nt in NODE_TYPES}
     wp, bp, w2, ep = {}, {}, {}, {}
 
     def put(dst_w, dst_b, row0, F, Fp, weight, bias, zero_xyz=False):
@@ -181,7 +208,7 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
         F, Fp = lay.F, lay.Fp
         W = torch.zeros(lay.ncols, Fp + k2, dtype=dt, device=dev)
         B = torch.zeros(lay.ncols, dtype=dt, device=dev)
-        for et in lay.src_ets:
+        for et in lay.src_ets if not enc_mfma else ():
             for g, gate in enumerate(gates):
                 conv = _conv(cell, gate, et)
                 put(W, B, lay.v_off[et] + g * C, F, Fp, conv.lin_value.weight, conv.lin_value.bias, True)
@@ -230,7 +257,13 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             E[g] = _conv(cell, gate, et).lin_value.weight.detach().to(dt)[:, 0:3].t()
         ep[et] = E.contiguous()
     w2p = {nt: bf16_planes(t) for nt, t in w2.items()}
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p)
+    wvf = {}
+    if enc_mfma:
+        for et in ep:
+            convs = [_conv(cell, gate, et) for gate in gates]
+            wvf[et] = value_fragments([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
+                                      F_of[et[0]])
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf)
 
 
 @torch.no_grad()

@@ -82,7 +82,9 @@ int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t 
  * Per-edge record in CSR order, computed once per forward and shared by every gate of the
  * encoder and decoder cells (GGNN_EINFO_ROW = 20 floats per edge):
  *   einfo[p, 0..15]  = (reloc_xyz, x_src[col[p], 3 .. f_src), 0.., 1 at 12, edge_attr at 13, 0, 0)
- *                      -- the non-hidden part of the source row the attention score is taken with
+ *                      -- the non-hidden part of the source row the attention score is taken with;
+ *                      when f_src <= 11 slot 11 is 1 as well (the bias row of the encoder sweep's
+ *                      value product; the score tail u4 is 0 there)
  *   einfo[p, 16..19] = (reloc_x, reloc_y, reloc_z, edge_attr)
  * with reloc = min-image(x_src[col[p], :3] - x_dst[row[p], :3]) exactly as periodGATconv.py:209-210
  * (rel > 0.5 -> rel - 1, rel < -0.5 -> rel + 1) and edge_attr taken from the ORIGINAL COO
@@ -171,6 +173,31 @@ int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t str
  * write disjoint columns of the same agg rows.  Same result as n_sweeps single calls. */
 int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweeps,
                                     ggnn_stream_t stream);
+
+/* Encoder form of the sweep (h = c = 0, heteropgclstm.py:101-110 with the zero state of
+ * models.py:422: the cell sees the bare features), values on the matrix cores: nothing is gathered
+ * from a projected source row.  With h = 0 the value of an edge is relu(W_value . [reloc, x_j[3:F]]
+ * + b_value), a product of the edge's own einfo record, so p_src / v_off / edge_params of
+ * ggnn_aggregate_args are replaced by
+ *   wv_frag: [6 * n_gates][3][64] fp32, MFMA B fragments of Bp [12, n_gates * 96] with
+ *            Bp[k][g*96 + ch] = W_value_g[ch][k] for k < F_src (columns 0..2 act on reloc),
+ *            Bp[11][.] = b_value_g, 0 elsewhere (F_src <= 11; einfo[:, 11] = 1):
+ *            element [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 6 (l & 15) + t % 6].
+ * p_dst, u4_off, agg, a_off, a_gstride, sc_off and the result are those of the h_src == NULL form
+ * of ggnn_period_gat_aggregate (same sums up to fp32 re-association).  n_gates = 3; a_off, a_gstride,
+ * ld_agg even.  Up to six sweeps per launch (three edge types x two models). */
+typedef struct ggnn_aggregate_enc_args {
+  const int32_t* unit_ptr; /* [n_dst + 1] from ggnn_build_csr */
+  const int32_t* units;    /* [n_units, 8] from ggnn_build_csr */
+  const float* einfo;      /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] from ggnn_edge_prepare */
+  const float* p_dst;      /* [n_dst, ldp_dst] destination projections (the u4 tails) */
+  const float* wv_frag;    /* [6 * n_gates][3][64] */
+  float* agg;              /* [n_dst, ld_agg] */
+  int64_t ldp_dst, ld_agg, n_dst, E;
+  int32_t u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
+} ggnn_aggregate_enc_args;
+int ggnn_period_gat_aggregate_enc_batch(const ggnn_aggregate_enc_args* args, int n_sweeps,
+                                        ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward of one sweep (training path).  Replaces what autograd does for

@@ -38,6 +38,8 @@ class TorchEmulatorBackend:
             einfo[:E, 3:Fs] = xs[col[:E], 3:Fs]
             einfo[:E, 12] = 1.0
             einfo[:E, 13] = einfo[:E, 19] = ea[perm[:E]]
+            if xs.size(1) <= 11:
+                einfo[:E, 11] = 1.0
 
     def project(self, x, F, h, wp, bp, out):
         Fp = (F + 3) & ~3
@@ -52,6 +54,29 @@ class TorchEmulatorBackend:
     def aggregate_batch(self, sweeps):
         for sweep in sweeps:
             self.aggregate(*sweep)
+
+    def aggregate_enc_batch(self, sweeps):
+        """ggnn_period_gat_aggregate_enc_batch: values relu(Bp^T x4[:12]) from the edge records."""
+        for csr, einfo, p_dst, wvf, agg, u4_off, a_off, a_gstride, sc_off, G in sweeps:
+            rowptr = csr.rowptr.long()
+            n_dst, E = p_dst.size(0), int(rowptr[-1])
+            dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
+            fr = wvf.view(G, 6, 3, 4, 16)                       # g m s kq j
+            Bp = fr.permute(2, 3, 0, 4, 1).reshape(12, G * C)   # k = 4 s + kq, column = g*96 + 6 j + m
+            x4, a = einfo[:E, :16], einfo[:E, 19]
+            assert E == 0 or (bool((x4[:, 11] == 1).all()) and bool((x4[:, 12] == 1).all()))
+            val = torch.relu(x4[:, :12] @ Bp)                    # [E, G * 96]
+            for g in range(G):
+                s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
+                smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
+                p = (s - smax[dst]).exp()
+                den = torch.zeros(n_dst).index_add(0, dst, p)
+                alpha = p / (den[dst] + 1e-16)
+                base = g * a_gstride
+                agg[:, base + a_off: base + a_off + C] = torch.zeros(n_dst, C).index_add(
+                    0, dst, alpha[:, None] * val[:, g * C:(g + 1) * C])
+                agg[:, base + sc_off] = torch.zeros(n_dst).index_add(0, dst, alpha)
+                agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add(0, dst, alpha * a)
 
     @staticmethod
     def _aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates):

@@ -805,6 +805,46 @@ def test_row_strided_inputs():
     assert torch.equal(ca["edge_event"], cb["edge_event"])
 
 
+@pytest.mark.parametrize("n_src,n_dst,E,F,hub", [(40, 30, 0, 8, 0), (1, 1, 1, 11, 0), (236, 118, 708, 8, 0),
+                                                 (118, 236, 708, 11, 0), (70, 50, 400, 8, 37), (70, 50, 1300, 11, 900),
+                                                 (10000, 20000, 60000, 11, 0), (20000, 10000, 60000, 8, 0)])
+@torch.no_grad()
+def test_encoder_sweep_on_matrix_cores_equals_the_gathering_sweep(n_src, n_dst, E, F, hub):
+    """ggnn_period_gat_aggregate_enc_batch (values formed from the edge records by MFMA) against the
+    h_src == NULL form of ggnn_period_gat_aggregate (values gathered from a projected source row):
+    empty graph, single edge, fixture sizes, a hub of degree `hub`, rows without edges, cfg3 sizes."""
+    from graingraphnn_amd.packing import value_fragments
+    be = backend()
+    rs = np.random.RandomState(E + F)
+    src = rs.randint(0, max(n_src - 5, 1), size=E)
+    dst = rs.randint(1 if n_dst > 1 else 0, n_dst, size=E)     # destination 0 has no in-edge
+    dst[:hub] = 7
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
+    xs = torch.from_numpy(rs.uniform(0, 1, (n_src, F)).astype(np.float32)).to(DEV)
+    xd = torch.from_numpy(rs.uniform(0, 1, (n_dst, 8)).astype(np.float32)).to(DEV)
+    ea = torch.from_numpy(rs.uniform(0.01, 0.1, E).astype(np.float32)).to(DEV)
+    G = 3
+    Wv = [torch.from_numpy(rs.uniform(-1, 1, (96, F)).astype(np.float32)).to(DEV) for _ in range(G)]
+    bv = [torch.from_numpy(rs.uniform(-1, 1, 96).astype(np.float32)).to(DEV) for _ in range(G)]
+    p_dst = torch.from_numpy(rs.uniform(-2, 2, (n_dst, G * 16 + 16)).astype(np.float32)).to(DEV)
+    p_dst.view(n_dst, -1)[:, 16:].view(n_dst, G, 16)[:, :, 11] = 0      # the score tail is 0 in the bias slot
+    csr = be.build_csr(ei, n_src, n_dst)
+    einfo = torch.zeros(E + 3, 20, device=DEV)
+    be.edge_prepare([(csr, ea, xs, xd, einfo)])
+    # gathering sweep: V0 per source node without the three reloc columns, which go through edge_params
+    v0 = torch.cat([xs[:, 3:] @ w[:, 3:].t() + b for w, b in zip(Wv, bv)], 1).contiguous()
+    ep = torch.stack([w[:, :3].t() for w in Wv]).contiguous()
+    ref = torch.zeros(n_dst, G * 128, device=DEV)
+    be.aggregate(csr, einfo, v0, p_dst, None, ep, ref, 0, 0, 16, 0, 128, 96, G)
+    got = torch.full((n_dst, G * 128), 0.0, device=DEV)
+    be.aggregate_enc_batch([(csr, einfo, p_dst, value_fragments(Wv, bv, F), got, 16, 0, 128, 96, G)])
+    for g in range(G):
+        assert_close(got[:, g * 128:g * 128 + 98], ref[:, g * 128:g * 128 + 98], f"encoder sweep gate {g}", 1e-5, 2e-6)
+    again = torch.zeros_like(got)
+    be.aggregate_enc_batch([(csr, einfo, p_dst, value_fragments(Wv, bv, F), again, 16, 0, 128, 96, G)])
+    assert torch.equal(got, again)                                  # no atomics: bit-reproducible
+
+
 class _OneSweepPerLaunch:
     """The HIP backend with ggnn_period_gat_aggregate_batch replaced by single-sweep launches."""
 
