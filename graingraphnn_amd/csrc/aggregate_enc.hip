@@ -33,8 +33,11 @@ namespace ggnn {
 constexpr int AE_MAX_SWEEPS = 6;
 constexpr int AE_BLOCKS_PER_CU = 3;  // 4 waves each: 12 waves per CU, 3 per SIMD (<= 168 VGPRs)
 
+// Every workgroup belongs to ONE sweep (its waves load that edge type's weight fragments once and
+// then only walk rows); the workgroups are dealt to the sweeps in proportion to their rows.
 struct EncSweepBatch {
   ggnn_aggregate_enc_args a[AE_MAX_SWEEPS];
+  int wg_off[AE_MAX_SWEEPS + 1];  // first workgroup of every sweep
   int n;
 };
 
@@ -60,12 +63,15 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   const int qa = c >> 2, ra = c & 3;  // A / score-B role: row or column c belongs to unit qa
-  const int64_t W = (int64_t)blockIdx.x * 4 + wave, NWV = (int64_t)gridDim.x * 4;
   const int src_lane4 = (20 * q) * 4;  // byte address of lane 16 q + 4 q for ds_bpermute
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
+  const int64_t W = (int64_t)((int)blockIdx.x - B.wg_off[k]) * 4 + wave;  // this wave among the sweep's waves
+  const int64_t NWV = (int64_t)(B.wg_off[k + 1] - B.wg_off[k]) * 4;
 
-  for (int k = 0; k < B.n; ++k) {
+  {
     const ggnn_aggregate_enc_args& A = B.a[k];
-    if (4 * W >= A.n_dst) continue;
+    if (4 * W >= A.n_dst) return;
     const ae_i32_ptr uptr = (ae_i32_ptr)(uintptr_t)A.unit_ptr;
     const ae_desc_ptr udesc = (ae_desc_ptr)(uintptr_t)A.units;  // 2 x int4 per unit; [0] = {i, p0, flags, -}
     const float* __restrict__ einfo = A.einfo;
@@ -235,7 +241,7 @@ extern "C" int ggnn_period_gat_aggregate_enc_batch(const ggnn_aggregate_enc_args
   if (!args || n_sweeps < 1 || n_sweeps > AE_MAX_SWEEPS) return GGNN_EINVAL;
   EncSweepBatch B;
   B.n = n_sweeps;
-  int64_t want = 1;
+  int64_t rows = 0;
   for (int k = 0; k < AE_MAX_SWEEPS; ++k) {
     B.a[k] = args[k < n_sweeps ? k : 0];
     const ggnn_aggregate_enc_args& A = B.a[k];
@@ -250,10 +256,22 @@ extern "C" int ggnn_period_gat_aggregate_enc_batch(const ggnn_aggregate_enc_args
     if (A.u4_off + (int64_t)A.n_gates * 16 > A.ldp_dst) return GGNN_EINVAL;
     if ((int64_t)(A.n_gates - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
     if ((int64_t)(A.n_gates - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
-    want = std::max<int64_t>(want, (A.n_dst + 15) / 16);  // 4 waves x 4 rows per workgroup
+    if (k < n_sweeps) rows += A.n_dst + A.E / GGNN_UNIT_EDGES;  // ~ units
   }
+  // persistent grid: at most the resident capacity, dealt to the sweeps by their (approximate) unit
+  // counts; a workgroup covers at least 16 rows (4 waves x 4 streams)
   const int64_t cap = (int64_t)num_cu() * AE_BLOCKS_PER_CU;
-  const dim3 grid((unsigned)(want < cap ? want : cap));
+  B.wg_off[0] = 0;
+  for (int k = 0; k < AE_MAX_SWEEPS; ++k) {
+    int64_t n = 0;
+    if (k < n_sweeps) {
+      const ggnn_aggregate_enc_args& A = B.a[k];
+      n = std::max<int64_t>(1, cap * (A.n_dst + A.E / GGNN_UNIT_EDGES) / rows);
+      n = std::min<int64_t>(n, (A.n_dst + 15) / 16);
+    }
+    B.wg_off[k + 1] = B.wg_off[k] + (int)n;
+  }
+  const dim3 grid((unsigned)B.wg_off[AE_MAX_SWEEPS]);
   hipLaunchKernelGGL((aggregate_enc_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, B);
   return launch_status();
 }

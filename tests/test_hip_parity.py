@@ -1006,6 +1006,7 @@ def test_edge_records_at_wrap_boundaries():
     reloc = (-1 * (rel > 0.5) + 1 * (rel < -0.5) + rel).astype(np.float32)
     got = einfo.cpu().numpy()[:len(src)]
     assert np.array_equal(got[:, 0:3], reloc) and np.array_equal(got[:, 16:19], reloc)
-    assert np.array_equal(got[:, 3:8], xs[col, 3:8]) and (got[:, 8:12] == 0).all()
+    assert np.array_equal(got[:, 3:8], xs[col, 3:8]) and (got[:, 8:11] == 0).all()
+    assert (got[:, 11] == 1).all()            # bias row of the encoder sweep's value product (f_src <= 11)
     assert (got[:, 12] == 1).all() and np.array_equal(got[:, 13], ea.cpu().numpy()[perm])
     assert np.array_equal(got[:, 19], got[:, 13]) and (got[:, 14:16] == 0).all()
