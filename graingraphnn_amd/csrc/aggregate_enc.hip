@@ -22,8 +22,8 @@
 //     ds_bpermute;
 //   * rows of any degree: units of one row are folded with the online-max softmax carried in
 //     registers, exactly as in aggregate.hip; no atomics, one owner per output row.
-// Everything that describes the four unit streams of a wave (rows r = 4 (W + k NW) + q) is
-// wave-uniform and lives on the scalar side (SMEM loads of unit_ptr / descriptors one block ahead).
+// The four unit streams of a wave (rows r = 4 (W + k NW) + q for group q) keep their cursors in
+// VGPRs (group-uniform), advanced with selects and clamped vector loads one block ahead.
 #include <algorithm>
 
 #include "common.h"
@@ -31,7 +31,7 @@
 namespace ggnn {
 
 constexpr int AE_MAX_SWEEPS = 6;
-constexpr int AE_BLOCKS_PER_CU = 3;  // 4 waves each: 12 waves per CU, 3 per SIMD (<= 168 VGPRs)
+constexpr int AE_BLOCKS_PER_CU = 2;  // 4 waves each: 2 per SIMD (the kernel needs ~180 VGPRs: 3 per SIMD spilled weight fragments)
 
 // Every workgroup belongs to ONE sweep (its waves load that edge type's weight fragments once and
 // then only walk rows); the workgroups are dealt to the sweeps in proportion to their rows.
@@ -42,18 +42,12 @@ struct EncSweepBatch {
 };
 
 typedef int ae_i32x4 __attribute__((ext_vector_type(4)));
-typedef const ae_i32x4 __attribute__((address_space(4))) * ae_desc_ptr;  // uniform index -> s_load_dwordx4
-typedef const int __attribute__((address_space(4))) * ae_i32_ptr;
 
 __device__ __forceinline__ float bperm(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ float quad_lane3(float v) {  // value of the quad's 4th lane in all four
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
-}
-template <typename T>
-__device__ __forceinline__ T sel4(int k, T a0, T a1, T a2, T a3) {
-  return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
 }
 
 template <int G>
@@ -72,8 +66,6 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
   {
     const ggnn_aggregate_enc_args& A = B.a[k];
     if (4 * W >= A.n_dst) return;
-    const ae_i32_ptr uptr = (ae_i32_ptr)(uintptr_t)A.unit_ptr;
-    const ae_desc_ptr udesc = (ae_desc_ptr)(uintptr_t)A.units;  // 2 x int4 per unit; [0] = {i, p0, flags, -}
     const float* __restrict__ einfo = A.einfo;
     const uint32_t ldp = (uint32_t)A.ldp_dst;
     const int e_last = (int)A.E + GGNN_UNIT_EDGES - 1;  // einfo holds E + GGNN_UNIT_EDGES records
@@ -85,28 +77,25 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
 #pragma unroll
       for (int s = 0; s < 3; ++s) bw[t][s] = A.wv_frag[(t * 3 + s) * 64 + lane];
 
-    // ---- scalar cursors of the four unit streams: current row (u .. ue), next row (un .. une) ----
-    int64_t r[4];
-    int u[4], ue[4], un[4], une[4];
-    bool alive[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      r[g4] = 4 * W + g4;
-      alive[g4] = r[g4] < A.n_dst;
-      u[g4] = ue[g4] = un[g4] = une[g4] = 0;
-      if (alive[g4]) {
-        u[g4] = uptr[r[g4]];
-        ue[g4] = uptr[r[g4] + 1];
-        const int64_t rn = r[g4] + 4 * NWV;
-        if (rn < A.n_dst) {
-          un[g4] = uptr[rn];
-          une[g4] = uptr[rn + 1];
-        }
-      }
+    // ---- cursor of the unit stream of group q (group-uniform values in VGPRs; vector loads with
+    // clamped addresses and selects instead of branches: scalar loads would share lgkmcnt with the
+    // ds_bpermutes below, and loads under branches drag waits to the merge points):
+    // current row r with units u .. ue, the next row's (un .. une) one row ahead ----
+    const int n_dst = (int)A.n_dst, stride = (int)(4 * NWV);
+    const int32_t* __restrict__ uptr = A.unit_ptr;
+    const ae_i32x4* __restrict__ udesc = reinterpret_cast<const ae_i32x4*>(A.units);  // 2 x int4 per unit; [0] = {i, p0, flags, -}
+    int r = (int)(4 * W) + q;
+    bool alive = r < n_dst;
+    int u, ue, un, une;
+    {
+      const int rc = min(r, n_dst - 1), rnc = min(r + stride, n_dst - 1);
+      u = uptr[rc];
+      ue = uptr[rc + 1];
+      un = uptr[rnc];
+      une = uptr[rnc + 1];
     }
-    ae_i32x4 d[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) d[g4] = alive[g4] ? udesc[2 * (int64_t)u[g4]] : (ae_i32x4){0, 0, 0, 0};
+    ae_i32x4 d = udesc[2 * (int64_t)(alive ? u : 0)];
+    if (!alive) d[2] = 0;  // a dead stream: no edges, neither first nor last
 
     // per-lane softmax / accumulation state of the row group q is folding
     float mx = -INFINITY;  // meaningful in lanes c = 4 q + g
@@ -115,13 +104,13 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
     for (int g = 0; g < G; ++g) den[g] = sae[g] = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    const int src_grp = (16 * qa) * 4;  // byte address of a lane of group qa for ds_bpermute
 
-    while (alive[0] | alive[1] | alive[2] | alive[3]) {
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
       // ---- vector operands of this block (issued back to back, one exposed round trip) ----
-      const int p0_a = sel4(qa, d[0][1], d[1][1], d[2][1], d[3][1]);
-      const int i_b = sel4(qa, d[0][0], d[1][0], d[2][0], d[3][0]);
-      const int i_q = sel4(q, d[0][0], d[1][0], d[2][0], d[3][0]);
-      const int fl_q = sel4(q, d[0][2], d[1][2], d[2][2], d[3][2]);
+      const int p0_a = __builtin_amdgcn_ds_bpermute(src_grp, d[1]);
+      const int i_b = __builtin_amdgcn_ds_bpermute(src_grp, d[0]);
+      const int i_q = d[0], fl_q = d[2];
       // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer)
       const float* arow = einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + q;
       const float* brow = A.p_dst + (uint32_t)i_b * ldp + A.u4_off + 16 * min(ra, G - 1) + q;
@@ -135,30 +124,15 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
         for (int s = 0; s < 4; ++s) bs[s] = (s == 3 && q == 1) ? 1.0f : 0.0f;
       }
 
-      // ---- scalar side: the next block's descriptors, under the vector round trip ----
-      ae_i32x4 dn[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        if (alive[g4]) {
-          if (u[g4] + 1 < ue[g4]) {
-            u[g4] += 1;
-          } else {
-            r[g4] += 4 * NWV;
-            if (r[g4] < A.n_dst) {
-              u[g4] = un[g4];
-              ue[g4] = une[g4];
-              const int64_t rn = r[g4] + 4 * NWV;
-              if (rn < A.n_dst) {
-                un[g4] = uptr[rn];
-                une[g4] = uptr[rn + 1];
-              }
-            } else {
-              alive[g4] = false;
-            }
-          }
-        }
-        dn[g4] = alive[g4] ? udesc[2 * (int64_t)u[g4]] : (ae_i32x4){0, 0, 0, 0};
-      }
+      // ---- the next block's unit of this stream: descriptor and (when the row changes) the row
+      // pointers one row further ahead; in flight during the MFMAs below ----
+      const bool row_done = u + 1 >= ue;
+      const int r2 = row_done ? r + stride : r;
+      const int u2 = row_done ? un : u + 1, ue2 = row_done ? une : ue;
+      const bool alive2 = alive && r2 < n_dst;
+      const int rnc = min(r2 + stride, n_dst - 1);
+      const int un_ld = uptr[rnc], une_ld = uptr[rnc + 1];
+      ae_i32x4 dn = udesc[2 * (int64_t)(alive2 ? u2 : 0)];
 
       const int nact = fl_q & 0xFF;
       const bool first = (fl_q >> 8) & 1, last = (fl_q >> 9) & 1;
@@ -209,6 +183,18 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
         acc[t] = acc[t] * scale[g] + (p0[g] * fmaxf(v[0], 0.f) + p1[g] * fmaxf(v[1], 0.f) + p2[g] * fmaxf(v[2], 0.f));
       }
 
+      // the prefetched descriptor / row pointers are taken over HERE, in front of the stores: a wait
+      // placed behind them (or carried over the loop's back edge) would drain the stores as well
+      __builtin_amdgcn_sched_barrier(0);  // (and not earlier: the scheduler would hoist the selects to the loop head)
+      r = r2;
+      u = u2;
+      ue = ue2;
+      un = row_done ? un_ld : un;
+      une = row_done ? une_ld : une;
+      alive = alive2;
+      d = dn;
+      if (!alive) d[2] = 0;
+      asm volatile("" : "+v"(un), "+v"(une), "+v"(d));  // keep the selects (and their waits) here
       if (last) {
         float* orow = A.agg + (int64_t)i_q * A.ld_agg + A.a_off + 6 * c;
 #pragma unroll
@@ -227,8 +213,6 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
           }
         }
       }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) d[g4] = dn[g4];
     }
   }
 }
