@@ -31,7 +31,7 @@
 namespace ggnn {
 
 constexpr int AE_MAX_SWEEPS = 6;
-constexpr int AE_BLOCKS_PER_CU = 2;  // 4 waves each: 2 per SIMD (the kernel needs ~180 VGPRs: 3 per SIMD spilled weight fragments)
+constexpr int AE_BLOCKS_PER_CU = 3;  // 4 waves each: 12 waves per CU, 3 per SIMD (148 VGPRs)
 
 // Every workgroup belongs to ONE sweep (its waves load that edge type's weight fragments once and
 // then only walk rows); the workgroups are dealt to the sweeps in proportion to their rows.
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
     const int n_dst = (int)A.n_dst, stride = (int)(4 * NWV);
     const int32_t* __restrict__ uptr = A.unit_ptr;
     const ae_i32x4* __restrict__ udesc = reinterpret_cast<const ae_i32x4*>(A.units);  // 2 x int4 per unit; [0] = {i, p0, flags, -}
-    int r = (int)(4 * W) + q;
+    // Software pipeline over the blocks b = 0, 1, .. of this wave: at the top of iteration b the
+    // operands of block b + 1 (addresses from its descriptor) and the descriptor of block b + 2 are
+    // requested; both are taken over at the END of the iteration, in front of the stores.
+    int r = (int)(4 * W) + q;     // cursor: the unit of the block whose descriptor was requested last
     bool alive = r < n_dst;
     int u, ue, un, une;
     {
@@ -94,8 +97,49 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
       un = uptr[rnc];
       une = uptr[rnc + 1];
     }
-    ae_i32x4 d = udesc[2 * (int64_t)(alive ? u : 0)];
-    if (!alive) d[2] = 0;  // a dead stream: no edges, neither first nor last
+    const int src_grp = (16 * qa) * 4;  // byte address of a lane of group qa for ds_bpermute
+    int un_ld = 0, une_ld = 0;
+    bool row_done = false;
+    auto advance = [&]() {  // cursor -> next unit of the stream; requests the row pointers one row further ahead
+      row_done = u + 1 >= ue;
+      r = row_done ? r + stride : r;
+      u = row_done ? un : u + 1;
+      ue = row_done ? une : ue;
+      alive = alive && r < n_dst;
+      const int rnc = min(r + stride, n_dst - 1);
+      un_ld = uptr[rnc];
+      une_ld = uptr[rnc + 1];
+    };
+    auto settle = [&]() {  // takes the requested row pointers over
+      un = row_done ? un_ld : un;
+      une = row_done ? une_ld : une;
+    };
+    auto load_desc = [&]() {
+      ae_i32x4 v = udesc[2 * (int64_t)(alive ? u : 0)];
+      return v;
+    };
+    auto operands = [&](const ae_i32x4& dd, float (&a)[4], float (&bs)[4]) {
+      const int p0_a = __builtin_amdgcn_ds_bpermute(src_grp, dd[1]);
+      const int i_b = __builtin_amdgcn_ds_bpermute(src_grp, dd[0]);
+      // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer)
+      const float* arow = einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + q;
+      const float* brow = A.p_dst + (uint32_t)i_b * ldp + A.u4_off + 16 * min(ra, G - 1) + q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = arow[4 * s];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bs[s] = __builtin_nontemporal_load(brow + 4 * s);
+    };
+    // prologue: descriptors of blocks 0 and 1, operands of block 0
+    bool alive_c = alive;
+    ae_i32x4 d = load_desc();
+    if (!alive_c) d[0] = d[1] = d[2] = 0;  // a dead stream: row 0, no edges, neither first nor last
+    advance();
+    settle();
+    bool alive_n = alive;
+    ae_i32x4 dn = load_desc();
+    if (!alive_n) dn[0] = dn[1] = dn[2] = 0;
+    float a[4], bs[4];
+    operands(d, a, bs);
 
     // per-lane softmax / accumulation state of the row group q is folding
     float mx = -INFINITY;  // meaningful in lanes c = 4 q + g
@@ -104,35 +148,19 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
     for (int g = 0; g < G; ++g) den[g] = sae[g] = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-    const int src_grp = (16 * qa) * 4;  // byte address of a lane of group qa for ds_bpermute
 
-    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
-      // ---- vector operands of this block (issued back to back, one exposed round trip) ----
-      const int p0_a = __builtin_amdgcn_ds_bpermute(src_grp, d[1]);
-      const int i_b = __builtin_amdgcn_ds_bpermute(src_grp, d[0]);
+    while (__builtin_amdgcn_ballot_w64(alive_c) != 0) {
+      // ---- requests for the blocks ahead ----
+      float a_n[4], bs_n[4];
+      operands(dn, a_n, bs_n);
+      advance();
+      const bool alive_nn = alive;
+      ae_i32x4 dnn = load_desc();
       const int i_q = d[0], fl_q = d[2];
-      // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer)
-      const float* arow = einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + q;
-      const float* brow = A.p_dst + (uint32_t)i_b * ldp + A.u4_off + 16 * min(ra, G - 1) + q;
-      float a[4], bs[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = arow[4 * s];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bs[s] = __builtin_nontemporal_load(brow + 4 * s);
       if (ra >= G) {  // column 4 u + 3: picks a_e = x4[13] (k-step 3, k = 12 + q)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bs[s] = (s == 3 && q == 1) ? 1.0f : 0.0f;
       }
-
-      // ---- the next block's unit of this stream: descriptor and (when the row changes) the row
-      // pointers one row further ahead; in flight during the MFMAs below ----
-      const bool row_done = u + 1 >= ue;
-      const int r2 = row_done ? r + stride : r;
-      const int u2 = row_done ? un : u + 1, ue2 = row_done ? une : ue;
-      const bool alive2 = alive && r2 < n_dst;
-      const int rnc = min(r2 + stride, n_dst - 1);
-      const int un_ld = uptr[rnc], une_ld = uptr[rnc + 1];
-      ae_i32x4 dn = udesc[2 * (int64_t)(alive2 ? u2 : 0)];
 
       const int nact = fl_q & 0xFF;
       const bool first = (fl_q >> 8) & 1, last = (fl_q >> 9) & 1;
@@ -183,18 +211,22 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
         acc[t] = acc[t] * scale[g] + (p0[g] * fmaxf(v[0], 0.f) + p1[g] * fmaxf(v[1], 0.f) + p2[g] * fmaxf(v[2], 0.f));
       }
 
-      // the prefetched descriptor / row pointers are taken over HERE, in front of the stores: a wait
-      // placed behind them (or carried over the loop's back edge) would drain the stores as well
+      // what was requested at the top is taken over HERE, in front of the stores: a wait placed behind
+      // them (or carried over the loop's back edge) would drain the stores as well
       __builtin_amdgcn_sched_barrier(0);  // (and not earlier: the scheduler would hoist the selects to the loop head)
-      r = r2;
-      u = u2;
-      ue = ue2;
-      un = row_done ? un_ld : un;
-      une = row_done ? une_ld : une;
-      alive = alive2;
+      settle();
       d = dn;
-      if (!alive) d[2] = 0;
-      asm volatile("" : "+v"(un), "+v"(une), "+v"(d));  // keep the selects (and their waits) here
+      alive_c = alive_n;
+      dn = dnn;
+      alive_n = alive_nn;
+      if (!alive_n) dn[0] = dn[1] = dn[2] = 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = a_n[s];
+        bs[s] = bs_n[s];
+      }
+      asm volatile("" : "+v"(un), "+v"(une), "+v"(dn), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(bs[0]),
+                   "+v"(bs[1]), "+v"(bs[2]), "+v"(bs[3]));  // keep the waits here
       if (last) {
         float* orow = A.agg + (int64_t)i_q * A.ld_agg + A.a_off + 6 * c;
 #pragma unroll
