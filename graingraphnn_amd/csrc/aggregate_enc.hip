@@ -46,6 +46,11 @@ typedef int ae_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bperm(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
+__device__ __forceinline__ float relu_(float x) {  // ONE v_max_f32 (fmaxf / fmed3 add a canonicalising v_max per operand)
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
 __device__ __forceinline__ float quad_lane3(float v) {  // value of the quad's 4th lane in all four
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
 }
@@ -203,12 +208,20 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
 
       // ---- values: per column tile D[edge 4 q + r][column c] = W x~ + b, relu, alpha-weighted sum ----
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int g = t / 6;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int t0 = 0; t0 < NT; t0 += 3) {
+        // three column tiles (of one gate) as three independent MFMA chains, issued k-step by k-step
+        const int g = t0 / 6;
+        f32x4 v[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[t][s], v, 0, 0, 0);
-        acc[t] = acc[t] * scale[g] + (p0[g] * fmaxf(v[0], 0.f) + p1[g] * fmaxf(v[1], 0.f) + p2[g] * fmaxf(v[2], 0.f));
+        for (int m = 0; m < 3; ++m) v[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[t0 + m][s], v[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          acc[t0 + m] = acc[t0 + m] * scale[g] +
+                        (p0[g] * relu_(v[m][0]) + p1[g] * relu_(v[m][1]) + p2[g] * relu_(v[m][2]));
       }
 
       // what was requested at the top is taken over HERE, in front of the stores: a wait placed behind
