@@ -12,9 +12,9 @@
 //     MFMA A operand (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains);
 //   * VALUES: A x [12 x 288] weight fragments that stay in 54 VGPRs for the whole sweep (bias in
 //     row 11) -> per column tile a 16 x 16 block D[edge][column]; the columns are ordered so that
-//     lane c of group q ends up with channels 6c .. 6c+5 of every gate of ITS unit: the
-//     alpha-weighted sum over the unit's edges is lane-local (registers r = 0..2 of D) and the row
-//     leaves as contiguous 384-byte pieces;
+//     lane c of group q ends up with channels 32 m + 2c, 32 m + 2c + 1 (m = 0..2) of every gate of
+//     ITS unit: the alpha-weighted sum over the unit's edges is lane-local (registers r = 0..2 of
+//     D) and every 8-byte store instruction of a group covers one whole 128-byte line;
 //   * SCORES: the same A x a [16 x 16] operand whose column 4u + g is the destination-side tail
 //     u4 of unit u's row for gate g (ggnn_project: u . x + s1 + a_e s2, see aggregate.hip) and
 //     whose column 4u + 3 picks a_e: one more MFMA chain; the softmax of a unit is local to lane
@@ -57,7 +57,7 @@ __device__ __forceinline__ float quad_lane3(float v) {  // value of the quad's 4
 
 template <int G>
 __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(const EncSweepBatch B) {
-  constexpr int NT = 6 * G;  // column tiles: gate t / 6, channels 6 c + t % 6 of lane c
+  constexpr int NT = 6 * G;  // column tiles: gate t / 6; lane c holds channel 32 ((t % 6) / 2) + 2 c + t % 2 of tile t
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
@@ -241,15 +241,15 @@ __global__ __launch_bounds__(256, AE_BLOCKS_PER_CU) void aggregate_enc_kernel(co
       asm volatile("" : "+v"(un), "+v"(une), "+v"(dn), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(bs[0]),
                    "+v"(bs[1]), "+v"(bs[2]), "+v"(bs[3]));  // keep the waits here
       if (last) {
-        float* orow = A.agg + (int64_t)i_q * A.ld_agg + A.a_off + 6 * c;
+        float* orow = A.agg + (int64_t)i_q * A.ld_agg + A.a_off + 2 * c;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float inv = 1.0f / (den[g] + 1e-16f);  // PyG softmax denominator
           float* o = orow + g * A.a_gstride;
 #pragma unroll
-          for (int m = 0; m < 6; m += 2) {
+          for (int m = 0; m < 6; m += 2) {  // every store instruction covers one whole 128-byte line per group
             const f32x2_ w2 = {acc[6 * g + m] * inv, acc[6 * g + m + 1] * inv};
-            __builtin_nontemporal_store(w2, reinterpret_cast<f32x2_*>(o + m));
+            __builtin_nontemporal_store(w2, reinterpret_cast<f32x2_*>(o + 16 * m));
           }
           if (c == 0) {  // 8 bytes of a line the other edge type's sweep also writes into: through L2
             float* sp = A.agg + (int64_t)i_q * A.ld_agg + g * A.a_gstride + A.sc_off;

@@ -154,7 +154,7 @@ def value_fragments(weights, biases, F_src: int) -> torch.Tensor:
     """`ggnn_aggregate_enc_args.wv_frag` (include/ggnn.h): the encoder's lin_value of the G gates of
     one edge type (weights[g]: [96, >= F_src], biases[g]: [96]) as MFMA B fragments of
     Bp [12, G * 96]: Bp[k][g*96 + ch] = W_g[ch][k] (k < F_src), Bp[11] = b_g; element
-    [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 6 (l & 15) + t % 6]."""
+    [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 32 ((t % 6) / 2) + 2 (l & 15) + t % 2]."""
     G = len(weights)
     if F_src > 11:
         raise ValueError("the encoder sweep keeps its bias in record slot 11: at most 11 source features")
@@ -163,8 +163,8 @@ def value_fragments(weights, biases, F_src: int) -> torch.Tensor:
     for g in range(G):
         Bp[:F_src, g * C:(g + 1) * C] = weights[g].detach().float()[:, :F_src].t()
         Bp[11, g * C:(g + 1) * C] = biases[g].detach().float()
-    fr = Bp.view(3, 4, G, 16, 6)               # s kq g j m   (k = 4 s + kq, column = g*96 + 6 j + m)
-    fr = fr.permute(2, 4, 0, 1, 3).contiguous()  # g m s kq j  (tile t = 6 g + m, lane l = 16 kq + j)
+    fr = Bp.view(3, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
+    fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 6 g + 2 m2 + e, lane l = 16 kq + j)
     return fr.view(-1)
 
 

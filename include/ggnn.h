@@ -182,7 +182,7 @@ int ggnn_period_gat_aggregate_batch(const ggnn_aggregate_args* args, int n_sweep
  *   wv_frag: [6 * n_gates][3][64] fp32, MFMA B fragments of Bp [12, n_gates * 96] with
  *            Bp[k][g*96 + ch] = W_value_g[ch][k] for k < F_src (columns 0..2 act on reloc),
  *            Bp[11][.] = b_value_g, 0 elsewhere (F_src <= 11; einfo[:, 11] = 1):
- *            element [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 6 (l & 15) + t % 6].
+ *            element [t][s][l] = Bp[4 s + (l >> 4)][(t / 6) * 96 + 32 ((t % 6) / 2) + 2 (l & 15) + t % 2].
  * p_dst, u4_off, agg, a_off, a_gstride, sc_off and the result are those of the h_src == NULL form
  * of ggnn_period_gat_aggregate (same sums up to fp32 re-association).  n_gates = 3; a_off, a_gstride,
  * ld_agg even.  Up to six sweeps per launch (three edge types x two models). */

@@ -61,8 +61,8 @@ class TorchEmulatorBackend:
             rowptr = csr.rowptr.long()
             n_dst, E = p_dst.size(0), int(rowptr[-1])
             dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
-            fr = wvf.view(G, 6, 3, 4, 16)                       # g m s kq j
-            Bp = fr.permute(2, 3, 0, 4, 1).reshape(12, G * C)   # k = 4 s + kq, column = g*96 + 6 j + m
+            fr = wvf.view(G, 3, 2, 3, 4, 16)                       # g m2 e s kq j
+            Bp = fr.permute(3, 4, 0, 1, 5, 2).reshape(12, G * C)   # k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e
             x4, a = einfo[:E, :16], einfo[:E, 19]
             assert E == 0 or (bool((x4[:, 11] == 1).all()) and bool((x4[:, 12] == 1).all()))
             val = torch.relu(x4[:, :12] @ Bp)                    # [E, G * 96]
