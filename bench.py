@@ -52,30 +52,32 @@ def build(device, n=100, fold=10, seed=0, scale=0.3):
     return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea, float(fold), off)
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+
+
 class EventTimedBackend:
-    """Wraps the HIP backend so that every aggregation launch of the decoder cells (G = 4, the
-    dominant kernel: all sweeps of the cell in one launch, 3 for the regressor and 2 for the
-    classifier) is bracketed by HIP events recorded on the launch stream."""
+    """Wraps the HIP backend so that the launches of the four heavy kernel families are bracketed by
+    HIP events recorded on the launch stream: the decoder sweep (aggregate_kernel<4, true>, the
+    kernel graded against the HBM roofline), the encoder sweep (aggregate_enc_kernel<3>), the
+    decoder projection (project_x6_kernel) and the decoder gate GEMM + LSTM (gates_x6_kernel<4, 0>).
+    An event bracket also contains the dispatch/event overhead of the launch (3-6 us in eager mode),
+    which rocprofv3's kernel durations do not.  It is calibrated right behind the launch on a kernel
+    that is too small to care about cache state: a [1 launch] and a [2 launches] bracket of it
+    differ by exactly its duration, what is left of the first bracket is the overhead.
+    (Differencing the kernel itself would time a re-run whose operands the first run left in the
+    256 MB MALL.)"""
 
     def __init__(self, inner):
         self.inner = inner
-        self.events = []
+        self.events = {}
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
 
-    def aggregate_batch(self, sweeps):
-        if sweeps[0][-1] != 4:  # n_gates
-            return self.inner.aggregate_batch(sweeps)
-        # An event bracket also contains the dispatch/event overhead of the launch (3-6 us in eager
-        # mode), which rocprofv3's kernel durations do not.  It is calibrated right behind the
-        # sweep on a kernel that is too small to care about cache state: a [1 launch] and a
-        # [2 launches] bracket of it differ by exactly its duration, what is left of the first
-        # bracket is the overhead.  (Differencing the sweep itself would time a re-run whose
-        # operands the first run left in the 256 MB MALL.)
+    def _timed(self, key, fn, arg, meta):
         e0, e1, c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
         e0.record()
-        self.inner.aggregate_batch(sweeps)
+        fn(arg)
         e1.record()
         c0.record()
         self.null.zero_()
@@ -83,41 +85,96 @@ class EventTimedBackend:
         self.null.zero_()
         self.null.zero_()
         c2.record()
+        self.events.setdefault(key, []).append((e0, e1, c0, c1, c2, meta))
+
+    def aggregate_batch(self, sweeps):
+        if sweeps[0][-1] != 4:  # n_gates
+            return self.inner.aggregate_batch(sweeps)
         nbytes = sum(algorithmic_bytes(sw[2].size(0), sw[3].size(0), sw[0].E, 4) for sw in sweeps)
-        self.events.append((e0, e1, c0, c1, c2, nbytes, len(sweeps)))
+        self._timed("dec_sweep", self.inner.aggregate_batch, sweeps, (nbytes, len(sweeps)))
+
+    def aggregate_enc_batch(self, sweeps):
+        # (csr, einfo, p_dst, wv_frag, agg, u4_off, a_off, a_gstride, sc_off, n_gates)
+        real = 0
+        for sw in sweeps:
+            E, n_dst, G = sw[0].E, sw[2].size(0), sw[-1]
+            n_units = int(sw[0].units.size(0))
+            real += 80 * E + 4 * (n_dst + 1) + 32 * n_units + 4 * n_dst * G * 16 + 4 * n_dst * G * 98
+        self._timed("enc_sweep", self.inner.aggregate_enc_batch, sweeps, (real, len(sweeps)))
+
+    def project_batch(self, problems):
+        if problems[0][2] is None:  # encoder (K <= 12): store-bound, not a GEMM worth grading
+            return self.inner.project_batch(problems)
+        flops = sum(2.0 * x.size(0) * (F + h.size(1)) * wp.size(0) for x, F, h, wp, bp, out in problems)
+        self._timed("dec_project", self.inner.project_batch, problems, (flops, len(problems)))
+
+    def lstm_epilogue_batch(self, problems):
+        if problems[0][9] != 0:  # GGNN_MODE_LSTM only (decoder)
+            return self.inner.lstm_epilogue_batch(problems)
+        flops = sum(2.0 * p[0].size(0) * p[8] * 96 * p[1].size(2) for p in problems)
+        self._timed("dec_gates", self.inner.lstm_epilogue_batch, problems, (flops, len(problems)))
+
+    def summary(self, key):
+        evs = self.events.get(key)
+        if not evs:
+            return None
+        bracket = np.array([ev[0].elapsed_time(ev[1]) for ev in evs]) * 1e3
+        null1 = np.array([ev[2].elapsed_time(ev[3]) for ev in evs]) * 1e3
+        null2 = np.array([ev[3].elapsed_time(ev[4]) for ev in evs]) * 1e3
+        overhead = float(np.median(null1 - (null2 - null1)))     # bracket minus the null kernel itself
+        return {"avg_us": float(np.mean(bracket)) - overhead, "bracket_us": float(np.mean(bracket)),
+                "overhead_us": overhead, "work": float(np.mean([ev[5][0] for ev in evs])),
+                "per_launch": round(float(np.mean([ev[5][1] for ev in evs])), 2), "n": len(evs)}
 
 
 def measure_roofline(ro, n_steps):
-    """Average duration of the aggregate_kernel<4, true> launches inside real rollout steps
-    (eager launches, regressor and classifier serialised so that no other kernel shares the chip
-    with the launch being timed; HIP events on the launch stream, minus the bracket overhead
-    calibrated on a null kernel)."""
+    """Average durations of the heavy kernels inside real rollout steps (eager launches, one set
+    per model on ONE stream, so that no other kernel shares the chip with the launch being timed;
+    HIP events on the launch stream, minus the bracket overhead calibrated on a null kernel).
+    Returns (roofline of the decoder sweep, roofline of the encoder sweep, GEMM records)."""
     timed = EventTimedBackend(ro.be)
     timed.null = torch.zeros(64, device="cuda")
-    ro.be, side = timed, ro._side
-    ro._side = None
+    ro.be, side, joint = timed, ro._side, ro.joint_launches
+    ro._side, ro.joint_launches = None, False
     try:
         for _ in range(n_steps):
             ro._enqueue_step()
         torch.cuda.synchronize()
     finally:
-        ro.be, ro._side = timed.inner, side
-    if not timed.events:
-        return None
-    bracket = np.array([ev[0].elapsed_time(ev[1]) for ev in timed.events]) * 1e3
-    null1 = np.array([ev[2].elapsed_time(ev[3]) for ev in timed.events]) * 1e3
-    null2 = np.array([ev[3].elapsed_time(ev[4]) for ev in timed.events]) * 1e3
-    overhead = float(np.median(null1 - (null2 - null1)))     # bracket minus the null kernel itself
-    avg_us = float(np.mean(bracket)) - overhead
-    avg_bytes = float(np.mean([ev[5] for ev in timed.events]))  # per launch, as launched
-    achieved = avg_bytes / avg_us / 1e3
-    spl = round(float(np.mean([ev[6] for ev in timed.events])), 2)
-    return {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(spl), "avg_launch_us": round(avg_us, 2),
-            "event_bracket_us": round(float(np.mean(bracket)), 2), "bracket_overhead_us": round(overhead, 2),
-            "algorithmic_bytes_per_launch": int(avg_bytes), "launches_timed": len(bracket),
-            "sweeps_per_launch": spl}
+        ro.be, ro._side, ro.joint_launches = timed.inner, side, joint
+    roof = enc = None
+    gemm = []
+    d = timed.summary("dec_sweep")
+    if d:
+        achieved = d["work"] / d["avg_us"] / 1e3
+        roof = {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic(d["per_launch"]), "avg_launch_us": round(d["avg_us"], 2),
+                "event_bracket_us": round(d["bracket_us"], 2), "bracket_overhead_us": round(d["overhead_us"], 2),
+                "algorithmic_bytes_per_launch": int(d["work"]), "launches_timed": d["n"],
+                "sweeps_per_launch": d["per_launch"]}
+    e = timed.summary("enc_sweep")
+    if e:
+        achieved = e["work"] / e["avg_us"] / 1e3
+        enc = {"bound": "hbm", "kernel": "ggnn::aggregate_enc_kernel<3>", "achieved": round(achieved, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+               "avg_launch_us": round(e["avg_us"], 2), "sweeps_per_launch": e["per_launch"],
+               "bytes_per_launch": int(e["work"]),
+               "bytes": "what the kernel as built must move, per sweep: 80 E (edge records) + 4 (n_dst + 1) + 32 "
+                        "n_units (unit table) + 64 G n_dst (score tails) + 392 G n_dst (rows written); the "
+                        "SURVEY 8(d) formula does not apply (no K / V / Q rows exist)"}
+    for key, name in (("dec_project", "ggnn::project_x6_kernel (decoder projection, both node types of a model)"),
+                      ("dec_gates", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, live node types of a model)")):
+        g = timed.summary(key)
+        if g:
+            tf = g["work"] / g["avg_us"] / 1e6
+            gemm.append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "gflop_per_launch": round(g["work"] / 1e9, 3), "avg_launch_us": round(g["avg_us"], 2),
+                         "problems_per_launch": g["per_launch"],
+                         "flops": "fp32-equivalent, as launched: 2 M (F + 96) ncols per projection problem, "
+                                  "2 N n_gates 96 Ka per gate problem (each product runs as 6 bf16 MFMA products)"})
+    return roof, enc, gemm
 
 
 def kernel_source_hash():
@@ -379,7 +436,7 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for g in gathered for v in g.values())
 
     if rank == 0:
-        roof = None if args.profile else measure_roofline(ro, 10)
+        roof, roof_enc, roof_gemm = (None, None, []) if args.profile else measure_roofline(ro, 10)
         # forward-only rate beside the full step (eager launches, R then C on one stream)
         forward_only = 0.0
         with torch.no_grad():
@@ -421,6 +478,8 @@ def main():
                                       "stopped": ev_state["stopped"]}}
                           if args.events else {})},
             "roofline": roof,
+            "roofline_encoder_sweep": roof_enc,
+            "roofline_gemm": roof_gemm,
         }
         if not args.no_cpu_baseline and not args.profile and args.workload == "cfg3" and world == 1:  # N = 1 only: a reported baseline
             line["cpu_baseline"] = cpu_baseline(inputs)
