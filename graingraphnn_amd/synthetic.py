@@ -141,6 +141,47 @@ def voronoi(n_grains: int = 400, seed: int = 0, fold: int = 1, lattice_noise: fl
         r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
         pts = np.stack([(c.ravel() + 0.5 * (r.ravel() & 1)) / n, r.ravel() / n], 1)
         pts = (pts + rs.normal(0, lattice_noise / n, pts.shape)) % 1.0
+    return _from_seeds(pts, rs, seed, fold, shuffle_edges, return_offset)
+
+
+def generate(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, span: int = 6,
+             grain_size: float = 4.0, noise: float = 0.01, shuffle_edges: bool = False):
+    """Initial grain structure with the interface of the reference's generator
+    (`graph_trajectory.py --mode=generate --lxd --seed --G --R`, :1289-1333): a `lxd` x `lxd` um
+    periodic domain seeded with a hexagonal lattice of mean grain size `grain_size` um and Gaussian
+    jitter, tessellated into grains (Voronoi cells) and junctions (Voronoi vertices).
+    The lattice is the reference's (graph_datastruct.py:118-160, 207-260): spacing dx = grain_size /
+    lxd, points ((col + (row % 2) / 2) sqrt(3) dx + 0.1 dx, row dx / 2 + 0.25 dx), jitter variance
+    noise / lxd / (lxd / 40) per coordinate, the points that land in the unit box are kept (the
+    lattice is not commensurate with the box: the seam grains are irregular, as in the reference).
+    Features as graph_trajectory.py:901-1005 writes them at frame 0: grain (centre x, y, z = 0, area as a
+    fraction of one 40 um patch, extraV = 0, cos / sin of the two misorientation angles, span / 120,
+    0), joint (x, y, 0, 1 - G / 10, R / 2, span / 120, 0, 0); edge lengths test.py:562-575.
+    What is NOT the reference: the random streams (the reference draws its jitter and angles from
+    numpy's global generator in its own order, and reads `span` from its (G, R) lookup table
+    GR_train_grid.pkl -- here `span` is an argument), and areas are exact polygon areas where the
+    reference counts pixels of a 0.08 um raster.  Same distribution, not the same sample:
+    tests/test_host_logic.py compares counts, degree histograms, areas and edge lengths with
+    fixtures the reference generator produced (tests/golden/generated_40_seed*.npz)."""
+    rs = np.random.RandomState(seed)
+    dx = grain_size / lxd
+    rows, cols = int(1 / dx) + 1, int(1 / dx)
+    r, c = np.meshgrid(np.arange(2 * rows), np.arange(cols), indexing="ij")
+    pts = np.stack([(c.ravel() + 0.5 * (r.ravel() % 2)) * np.sqrt(3.0) * dx + 0.1 * dx,
+                    r.ravel() * 0.5 * dx + 0.25 * dx], 1)
+    pts = pts + rs.normal(0.0, np.sqrt(noise / lxd / (lxd / 40.0)), pts.shape)
+    pts = pts[np.all((pts > 0) & (pts < 1), axis=1)]
+    x, ei, ea = _from_seeds(pts, rs, seed, 1, shuffle_edges, False)
+    patches = (lxd / 40.0) ** 2                     # areas are fractions of one 40 um patch
+    x["grain"][:, 3] *= np.float32(patches)
+    x["grain"][:, 9] = x["joint"][:, 5] = np.float32(span / 120)
+    x["joint"][:, 3], x["joint"][:, 4] = np.float32(1 - G / 10), np.float32(R / 2)
+    return x, ei, ea
+
+
+def _from_seeds(pts, rs, seed, fold, shuffle_edges, return_offset):
+    """Periodic Voronoi tessellation of the seed points `pts` (unit torus) -> (x, ei, ea) numpy dicts."""
+    from scipy.spatial import Voronoi
     n_g = len(pts)
     shifts = np.array([[dx, dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1)], dtype=np.float64)
     tiled = (pts[None, :, :] + shifts[:, None, :]).reshape(-1, 2)      # copy k of seed g = row k * n_g + g

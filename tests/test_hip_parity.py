@@ -421,6 +421,35 @@ def test_voronoi_graph_rollout_against_oracle():
         assert_close(X[nt], oX[nt], f"voronoi x {nt}")
 
 
+@pytest.mark.parametrize("source", ["reference_generator_fixture", "own_generator"])
+@torch.no_grad()
+def test_generated_structures_roll_out_like_the_oracle(source):
+    """an initial structure from the reference's `--mode=generate` (fixture) and one
+    from `synthetic.generate` go through the HIP rollout and match the oracle step by step."""
+    import os
+    from helpers import GOLDEN
+    from graingraphnn_amd import GrainRollout
+    if source == "own_generator":
+        x, ei, ea = synthetic.generate(lxd=40, seed=5, G=2.0, R=0.4, span=8)
+    else:
+        g = np.load(os.path.join(GOLDEN, "generated_40_seed1.npz"))
+        x = {"grain": g["x_grain"], "joint": g["x_joint"]}
+        ei = {et: g["ei_" + etk(et)] for et in EDGE_TYPES}
+        ea = {et: g["ea_" + etk(et)] for et in EDGE_TYPES}
+    R, Cm = product_models(21, 1.0, DEV)
+    oR, oC = oracle_models(21, 1.0)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ro = GrainRollout(R, Cm, X, EI, EA, 8, refresh_centres=True)
+    for step in range(3):
+        pred = {k: v.clone() for k, v in ro.step().items()}
+        opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 8, centres=(1.0, None))
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert_close(pred[k], opred[k], f"generated ({source}) step {step} {k}")
+    for nt in x:
+        assert_close(X[nt], oX[nt], f"generated ({source}) x {nt}")
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE full size (cfg3): one oracle step + size-independent properties
 # ---------------------------------------------------------------------------------------
