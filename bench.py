@@ -170,6 +170,10 @@ def measure_roofline(ro, n_steps):
             tf = g["work"] / g["avg_us"] / 1e6
             gemm.append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "frac_of_bf16_pipe": round(6 * tf / 2500.0, 4),
+                         "note": "fp32-equivalent rate against the fp32 matrix peak (a value above 1 means the exact "
+                                 "bf16 split beats what native fp32 MFMA could deliver at all); frac_of_bf16_pipe = the "
+                                 "6 bf16 products per fp32 product against the 2.5 PFLOP/s dense bf16 peak",
                          "gflop_per_launch": round(g["work"] / 1e9, 3), "avg_launch_us": round(g["avg_us"], 2),
                          "problems_per_launch": g["per_launch"],
                          "flops": "fp32-equivalent, as launched: 2 M (F + 96) ncols per projection problem, "
