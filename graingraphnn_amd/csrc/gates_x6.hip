@@ -39,11 +39,14 @@
 
 namespace ggnn {
 
+// Waves per workgroup / tiles per wave.  (Measured at G = 3, 20 000 joints, cold caches: 6 waves x 3
+// tiles, 9 x 2, 12 x 2 all 36 us, 12 x 1 45 us -- the kernel is bound by the CU's load path, not by
+// how its jobs are spread over the SIMDs; loading `agg` in pairs of k-steps was slower, 57 vs 50 us.)
 constexpr int gw_waves(int G) { return G == 3 ? 6 : 8; }  // two per SIMD (G = 3: 2, 2, 1, 1)
+constexpr int gw_tmax(int G) { return 3; }
 constexpr int GW_BM = 16;      // nodes per tile
-constexpr int GW_TMAX = 3;     // tiles per wave and pass
 constexpr int GW_PRE_LD = 100; // floats per node row of the pre-activation exchange image
-constexpr int GW_LDS_BYTES = 8 * GW_TMAX * GW_BM * GW_PRE_LD * 4;  // 153 600 (>= 2 x 4 x 18 KB of weight slices)
+constexpr int GW_LDS_BYTES = 8 * 3 * GW_BM * GW_PRE_LD * 4;  // 153 600 (>= 2 x 4 x 18 KB of weight slices)
 constexpr int GW_MAX_PROBLEMS = 4;
 
 struct GateBatch {
@@ -80,7 +83,7 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
                                            u32x4* __restrict__ smem) {
   constexpr int KM = KA - 4;                 // columns on the bf16 path (192 / 96)
   constexpr int NKS = KM / 32;               // k-steps (6 / 3)
-  constexpr int GW_WAVES = gw_waves(G), GW_THREADS = GW_WAVES * 64;
+  constexpr int GW_WAVES = gw_waves(G), GW_THREADS = GW_WAVES * 64, GW_TMAX = gw_tmax(G);
   constexpr int SLOTS = GW_WAVES / G;        // tile slots
   constexpr int TP = SLOTS * GW_TMAX;        // tiles per workgroup, at most
   constexpr int NPIECE = G * 18;             // 1 KB pieces of one k-step slice: [gate][plane 3][column tile 6]
@@ -99,7 +102,7 @@ __device__ __forceinline__ void gates_body(const ggnn_epilogue_args& A, int64_t 
   const int row_l = (int)min((int64_t)lr, A.N - 1);      // N < 16: clamp the lane's row instead
   float* __restrict__ pre = reinterpret_cast<float*>(smem);
   const int n_t = (int)(mt_hi - mt_lo);                  // tiles of this workgroup; tile j -> slot j % SLOTS, t = j / SLOTS
-  const int nt_w = (n_t > slot ? 1 : 0) + (n_t > slot + SLOTS ? 1 : 0) + (n_t > slot + 2 * SLOTS ? 1 : 0);
+  const int nt_w = (n_t > slot ? 1 : 0) + (n_t > slot + SLOTS ? 1 : 0) + (GW_TMAX > 2 && n_t > slot + 2 * SLOTS ? 1 : 0);
   const int64_t row0 = min(mt_lo * GW_BM, m_last);       // first row of the workgroup: every offset below is relative to it
   const uint32_t ld_agg = (uint32_t)A.ld_agg, ldp = (uint32_t)A.ldp;
 
@@ -342,7 +345,7 @@ int ggnn_lstm_epilogue_x6(const ggnn_epilogue_args* args, int n, hipStream_t s) 
     nks[k] = (args[k].Ka - 4) / 32;
   }
   const int G = args[0].n_gates, mode = args[0].mode;
-  const int64_t tp_max = (int64_t)(gw_waves(G) / G) * GW_TMAX;  // tiles a workgroup can take
+  const int64_t tp_max = (int64_t)(gw_waves(G) / G) * gw_tmax(G);  // tiles a workgroup can take
   int64_t total = 0;
   for (int W = 6;; W += 3) {
     total = 0;
