@@ -67,9 +67,6 @@ class _GrainNNBase(nn.Module):
         edge_attr is copied into workspace-owned buffers so that fresh edge_attr tensors
         (test.py:562-575 builds new ones every step) do not invalidate the tape."""
         be, graph, enc, dec, ws = self._prepare(x_dict, edge_index_dict, edge_attr)
-        if not hasattr(be, "start_tape"):  # test doubles
-            h, _ = run_encoder_decoder(be, enc, dec, graph, ws, x_dict, edge_attr)
-            return h, graph
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
         if ws.ea is None or any(ws.ea[et].shape != ea[et].shape for et in EDGE_TYPES):
             ws.ea = {et: torch.empty_like(ea[et]) for et in EDGE_TYPES}
