@@ -176,7 +176,7 @@ class HipBackend:
                      len(sweeps), _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
-                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates):
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None):
         """ggnn_period_gat_aggregate_backward (include/ggnn.h).  `rcsr`: CSR of the flipped
         edge_index (grouped by source), `r_slot` [E] int32: forward CSR slot of every reverse slot.
         Returns (g_p_dst, g_p_src, g_h_src or None, g_ep [n_gates, 3, 96]); the gradient tensors
@@ -196,7 +196,13 @@ class HipBackend:
         f32 = dict(dtype=torch.float32, device=dev)
         scratch = torch.empty(2, max(E, 1) * G, **f32)
         ep_partial = torch.empty(n_part, G, _lib.GGNN_EDGE_PARAM_ROWS, 96, **f32)
-        g_p_dst, g_p_src = torch.zeros_like(p_dst), torch.zeros_like(p_src)
+        # out_p_dst / out_p_src: zero-initialised gradient buffers shared by the sweeps of a cell (every
+        # sweep writes its own columns only)
+        g_p_dst = torch.zeros_like(p_dst) if out_p_dst is None else out_p_dst
+        g_p_src = torch.zeros_like(p_src) if out_p_src is None else out_p_src
+        if g_p_dst.shape != p_dst.shape or g_p_src.shape != p_src.shape or g_p_dst.stride(0) != p_dst.stride(0) \
+                or g_p_src.stride(0) != p_src.stride(0):
+            raise _lib.GGNNError("gradient buffers must have the layout of their operands")
         g_h_src = None if h_src is None else torch.empty_like(h_src)
         a.edge_alpha, a.edge_ds, a.ep_partial = scratch[0].data_ptr(), scratch[1].data_ptr(), ep_partial.data_ptr()
         a.g_p_dst, a.g_p_src = g_p_dst.data_ptr(), g_p_src.data_ptr()

@@ -61,7 +61,8 @@ def train_topology(backend, graph) -> TrainTopology:
 
 class _Sweep(torch.autograd.Function):
     """agg = sweep(p_dst = [u_h (G x 96) | u4 (G x 16)], v (G x 96), h_src, edge_params) for one
-    edge type; agg is [n_dst, G, 128] = (96 values, sum alpha, sum alpha * a, zeros)."""
+    edge type; agg is [n_dst, G, 128] = (96 values, sum alpha, sum alpha * a, zeros).  (Single-sweep
+    form, kept for op-level tests; the models go through _CellSweeps.)"""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # the sweep is fp32 under bf16 autocast too
@@ -86,64 +87,189 @@ class _Sweep(torch.autograd.Function):
         return g_p_dst, g_v, g_h, g_ep, None, None, None, None, None
 
 
-def _edge_type_forward(convs, backend, topo, et, einfo, x_src, x_dst, h_src, h_dst, Fs, Fd):
-    """The PeriodConvs of all gates of one edge type (HeteroConv entry, heteropgclstm.py:113-138):
-    key-free operands from the parameters, one sweep, the linear tail.  -> [N_d, G, 96].
-    The gates are batched into single GEMMs (weights stacked along the output dimension)."""
-    G = len(convs)
-    k2 = 0 if h_src is None else C
-    inv = 1.0 / math.sqrt(C)
-    n_d = x_dst.size(0)
-    st = lambda f: torch.stack([f(cv) for cv in convs])                       # [G, ...]
-    Xd = x_dst if not k2 else torch.cat([x_dst, h_dst], 1)
-    xz = torch.cat([torch.zeros_like(x_src[:, :3]), x_src[:, 3:]], 1)         # the wrap moves columns 0..2 to the edge
-    Xs = xz if not k2 else torch.cat([xz, h_src], 1)
-    wq, bq = st(lambda cv: cv.lin_query.weight[:, :Fd + k2]), st(lambda cv: cv.lin_query.bias)
-    wk, bk = st(lambda cv: cv.lin_key.weight[:, :Fs + k2]), st(lambda cv: cv.lin_key.bias)
-    wv, bv = st(lambda cv: cv.lin_value.weight[:, :Fs + k2]), st(lambda cv: cv.lin_value.bias)
-    ws, bs = st(lambda cv: cv.lin_skip.weight[:, :Fd + k2]), st(lambda cv: cv.lin_skip.bias)
-    wl, bl = st(lambda cv: cv.lin_l2.weight), st(lambda cv: cv.lin_l2.bias)
-    we = st(lambda cv: cv.lin_edge.weight[:, 0])                              # [G, 96]
-    q = (Xd @ wq.reshape(G * C, -1).t() + bq.reshape(-1)).view(n_d, G, C)     # [N_d, G, 96]
-    # the per-gate batched products stay fp32 under bf16 autocast: they feed the attention logits,
-    # and the library's bf16 batched-GEMM backward is three orders of magnitude slower here
-    with torch.autocast(q.device.type, enabled=False):
-        q = q.float()
-        u = torch.einsum("ngc,gcd->ngd", q, wk) * inv                         # u = W_k^T q / sqrt(96)
-        s1 = torch.einsum("ngc,gc->ng", q, bk) * inv
-        s2 = torch.einsum("ngc,gc->ng", q, we) * inv
-    z = torch.zeros(n_d, G, 16, dtype=q.dtype, device=q.device)
-    u4 = torch.cat([u[:, :, :Fs], z[:, :, Fs:12], s1.unsqueeze(-1), s2.unsqueeze(-1), z[:, :, 14:]], -1)
-    p_dst = u4.reshape(n_d, G * 16) if not k2 else torch.cat([u[:, :, Fs:].reshape(n_d, G * C),
-                                                              u4.reshape(n_d, G * 16)], 1)
-    val = Xs @ wv.reshape(G * C, -1).t() + bv.reshape(-1)                     # [N_s, G * 96]
-    ep = wv[:, :, :3].transpose(1, 2)                                         # [G, 3, 96]
-    agg = _Sweep.apply(p_dst, val, h_src, ep, backend, topo, et, einfo, G)    # [N_d, G, 128]
-    skip = (Xd @ ws.reshape(G * C, -1).t() + bs.reshape(-1)).view(n_d, G, C)
-    with torch.autocast(agg.device.type, enabled=False):
-        return (torch.einsum("ngc,gkc->ngk", agg[:, :, :C], wl) + agg[:, :, C:C + 1] * bl
-                + agg[:, :, C + 1:C + 2] * we + skip.float())
+# ---------------------------------------------------------------------------------------
+# The cell in its packed (inference) formulation, differentiable.
+#
+# One projection GEMM per node type produces, for all gates and edge types at once, what the
+# sweeps and the gate stage consume (value rows, key-free score rows u_h / u4, summed skip rows:
+# DESIGN.md section 2, packing.py); its weight matrix is assembled from the reference parameters
+# by differentiable torch ops on weight-sized tensors, so autograd carries the gradient back to
+# every lin_key / lin_query / lin_value / lin_skip / lin_l2 / lin_edge / gate bias.  All parameters
+# of a cell are first gathered into ONE flat buffer (a single cat kernel); every stacked per-gate
+# weight is a view of it.
+# ---------------------------------------------------------------------------------------
+_KINDS = (("wq", "lin_query", "weight"), ("bq", "lin_query", "bias"), ("wk", "lin_key", "weight"),
+          ("bk", "lin_key", "bias"), ("wv", "lin_value", "weight"), ("bv", "lin_value", "bias"),
+          ("ws", "lin_skip", "weight"), ("bs", "lin_skip", "bias"), ("wl", "lin_l2", "weight"),
+          ("bl", "lin_l2", "bias"), ("we", "lin_edge", "weight"))
+
+
+def _gather_params(cell, gates):
+    """All parameters the cell's forward reads, as views of one flat tensor: get(et, kind) ->
+    [G, *param.shape]; gate bias get(("b", nt)) -> [G, 96]."""
+    G = len(gates)
+    plist, index, off = [], {}, 0
+    for et in EDGE_TYPES:
+        for kind, lin, wb in _KINDS:
+            ts = [getattr(getattr(getattr(cell, "conv_" + g).convs[et_key(et)], lin), wb) for g in gates]
+            index[(et, kind)] = (off, (G,) + tuple(ts[0].shape))
+            off += G * ts[0].numel()
+            plist += ts
+    for nt in NODE_TYPES:
+        ts = [getattr(cell, "b_" + g)[nt] for g in gates]
+        index[("b", nt)] = (off, (G, C))
+        off += G * C
+        plist += ts
+    flat = torch.cat([t.reshape(-1) for t in plist])
+
+    def get(*key):
+        o, shape = index[key if len(key) > 1 else key[0]]
+        n = 1
+        for d in shape:
+            n *= d
+        return flat[o:o + n].view(shape)
+    return get
+
+
+def _packed_weights(cell, gates, F, sees_h):
+    """-> (layout, wp, bp, ep, w2): the projection weight [ncols, F + k2] / bias [ncols] per node type in
+    the column order of packing.node_layout (value rows, u_h rows, skip rows, u4 tails), the reloc
+    columns of lin_value per edge type [G, 3, 96] and the gate weight [G, 96, Ka] per node type."""
+    from .packing import node_layout
+    G, k2 = len(gates), (C if sees_h else 0)
+    scale = 1.0 / math.sqrt(C)
+    get = _gather_params(cell, gates)
+    dev = get(EDGE_TYPES[0], "wq").device
+    zeros = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
+    prod = {}
+    for et in EDGE_TYPES:  # key-free score rows: M = W_k^T W_q / sqrt(96) and friends, per gate
+        Fs, Fd = F[et[0]], F[et[-1]]
+        wq, bq = get(et, "wq")[:, :, :Fd + k2], get(et, "bq")
+        wk, bk = get(et, "wk")[:, :, :Fs + k2], get(et, "bk")
+        we = get(et, "we")[:, :, 0]
+        wkt = wk.transpose(1, 2)                                     # [G, Fs + k2, 96]
+        M = torch.bmm(wkt, wq) * scale                               # [G, Fs + k2, Fd + k2]
+        mb = torch.bmm(wkt, bq.unsqueeze(-1)).squeeze(-1) * scale    # [G, Fs + k2]
+        rows = torch.bmm(torch.stack([bk, we], 1), wq) * scale       # [G, 2, Fd + k2]: s1, s2 rows
+        rb = torch.bmm(torch.stack([bk, we], 1), bq.unsqueeze(-1)).squeeze(-1) * scale   # [G, 2]
+        tail_w = torch.cat([M[:, :Fs], zeros(G, 12 - Fs, Fd + k2), rows, zeros(G, 2, Fd + k2)], 1)   # [G, 16, .]
+        tail_b = torch.cat([mb[:, :Fs], zeros(G, 12 - Fs), rb, zeros(G, 2)], 1)                      # [G, 16]
+        prod[et] = (M[:, Fs:], mb[:, Fs:], tail_w, tail_b)
+    for nt in NODE_TYPES:
+        lay = node_layout(nt, F[nt], G, EDGE_TYPES, True, sees_h, True)
+        Fn, D = F[nt], F[nt] + k2
+        blocks_w, blocks_b = [], []
+        for et in lay.src_ets:                                       # value rows, reloc columns zeroed
+            wv = get(et, "wv")[:, :, :D]
+            blocks_w.append(torch.cat([zeros(G, C, 3), wv[:, :, 3:]], 2).reshape(G * C, D))
+            blocks_b.append(get(et, "bv").reshape(-1))
+        if sees_h:
+            for et in lay.dst_ets:                                   # hidden-state part of u
+                blocks_w.append(prod[et][0].reshape(G * C, D))
+                blocks_b.append(prod[et][1].reshape(-1))
+        ws = sum(get(et, "ws")[:, :, :D] for et in lay.dst_ets)      # HeteroConv aggr 'sum' -> summed skip
+        bs = sum(get(et, "bs") for et in lay.dst_ets) + get("b", nt)
+        blocks_w.append(ws.reshape(G * C, D))
+        blocks_b.append(bs.reshape(-1))
+        for et in lay.dst_ets:
+            blocks_w.append(prod[et][2].reshape(G * 16, D))
+            blocks_b.append(prod[et][3].reshape(-1))
+        n_rows = sum(b.size(0) for b in blocks_w)
+        blocks_w.append(zeros(lay.ncols - n_rows, D))
+        blocks_b.append(zeros(lay.ncols - n_rows))
+        wp[nt], bp[nt], layout[nt] = torch.cat(blocks_w), torch.cat(blocks_b), lay
+        n_in = len(lay.dst_ets)
+        w2[nt] = torch.cat([get(et, "wl") for et in lay.dst_ets]
+                           + [torch.stack([get(et, "bl"), get(et, "we")[:, :, 0]], 2) for et in lay.dst_ets]
+                           + [zeros(G, C, lay.Ka - n_in * (C + 2))], 2)   # [G, 96, Ka]
+    for et in EDGE_TYPES:
+        ep[et] = get(et, "wv")[:, :, :3].transpose(1, 2).contiguous()   # [G, 3, 96]
+    return layout, wp, bp, ep, w2
+
+
+class _CellSweeps(torch.autograd.Function):
+    """The three aggregation sweeps of one cell on the projections P[nt] (layout as in inference):
+    (P_grain, P_joint, h_grain, h_joint, ep_gj, ep_jg, ep_jj) -> (agg_grain, agg_joint).  One launch
+    forward; backward = ggnn_period_gat_aggregate_backward per edge type into shared gradient
+    buffers (each sweep owns its columns)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # the sweeps are fp32 under bf16 autocast too
+    def forward(ctx, P_grain, P_joint, h_grain, h_joint, ep_gj, ep_jg, ep_jj, backend, topo, einfo, layout, G):
+        P = {"grain": P_grain.contiguous(), "joint": P_joint.contiguous()}
+        h = {"grain": None if h_grain is None else h_grain.contiguous(),
+             "joint": None if h_joint is None else h_joint.contiguous()}
+        ep = dict(zip(EDGE_TYPES, (ep_gj.contiguous(), ep_jg.contiguous(), ep_jj.contiguous())))
+        agg = {nt: torch.zeros(P[nt].size(0), G * layout[nt].Kg, dtype=torch.float32, device=P[nt].device)
+               for nt in NODE_TYPES}
+        sweeps = []
+        for et in EDGE_TYPES:
+            s, d = et[0], et[-1]
+            sweeps.append((topo.graph.csr[et], einfo[et], P[s], P[d], h[s], ep[et], agg[d], layout[s].v_off[et],
+                           layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et], layout[d].Kg,
+                           layout[d].sc_off[et], G))
+        backend.aggregate_batch(sweeps)
+        ctx.save_for_backward(P["grain"], P["joint"], h["grain"], h["joint"], ep_gj, ep_jg, ep_jj, agg["grain"],
+                              agg["joint"], *[einfo[et] for et in EDGE_TYPES])
+        ctx.misc = (backend, topo, layout, G, sweeps)
+        return agg["grain"], agg["joint"]
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_grain, g_joint):
+        Pg, Pj, hg, hj, ep_gj, ep_jg, ep_jj, agg_g, agg_j, *einfos = ctx.saved_tensors
+        backend, topo, layout, G, sweeps = ctx.misc
+        P, h = {"grain": Pg, "joint": Pj}, {"grain": hg, "joint": hj}
+        agg = {"grain": agg_g, "joint": agg_j}
+        g_agg = {"grain": g_grain.contiguous(), "joint": g_joint.contiguous()}
+        ep = dict(zip(EDGE_TYPES, (ep_gj, ep_jg, ep_jj)))
+        gP = {nt: torch.zeros_like(P[nt]) for nt in NODE_TYPES}
+        gh = {nt: None for nt in NODE_TYPES}
+        g_ep = {}
+        for et, einfo in zip(EDGE_TYPES, einfos):
+            s, d = et[0], et[-1]
+            _, _, g_h, g_ep[et] = backend.aggregate_backward(
+                topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo, P[s], P[d], h[s], ep[et], agg[d], g_agg[d],
+                layout[s].v_off[et], layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et],
+                layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s])
+            if g_h is not None:
+                gh[s] = g_h if gh[s] is None else gh[s] + g_h
+        return (gP["grain"], gP["joint"], gh["grain"], gh["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]],
+                g_ep[EDGE_TYPES[2]], None, None, None, None, None)
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
-    """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable.  h, c: dicts or None
-    (encoder: zero state; the forget gate multiplies c = 0 and is skipped, its gradient is 0)."""
+    """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation:
+    2 projection GEMMs, 1 launch of the three sweeps, 2 batched gate GEMMs, the LSTM update.
+    h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped)."""
     gates = "ifco" if h is not None else "ico"
+    G = len(gates)
     F = cell.in_channels_dict
-    pre = {nt: 0.0 for nt in NODE_TYPES}
-    for et in EDGE_TYPES:
-        s, d = et[0], et[-1]
-        convs = [getattr(cell, "conv_" + g).convs[et_key(et)] for g in gates]
-        pre[d] = pre[d] + _edge_type_forward(convs, backend, topo, et, einfo[et], x[s], x[d],
-                                             None if h is None else h[s], None if h is None else h[d], F[s], F[d])
-    h_new, c_new = {}, {}
+    with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
+        layout, wp, bp, ep, w2 = _packed_weights(cell, gates, F, h is not None)
+    P = {}
+    for nt in NODE_TYPES:
+        xin = x[nt] if h is None else torch.cat([x[nt], h[nt]], 1)
+        P[nt] = torch.nn.functional.linear(xin, wp[nt], bp[nt])       # [N, ncols] (bf16 under autocast)
+    agg_g, agg_j = _CellSweeps.apply(P["grain"], P["joint"], None if h is None else h["grain"],
+                                     None if h is None else h["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]],
+                                     ep[EDGE_TYPES[2]], backend, topo, einfo, layout, G)
+    agg = {"grain": agg_g, "joint": agg_j}
     # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an
     # exactly zero gradient; they are touched here the same way, which also keeps
     # DistributedDataParallel(model, device_ids=[rank]) (dist_train.py:82) usable as written.
     touch = 0.0 if h is not None else 0.0 * sum(
         q.sum() for q in list(cell.conv_f.parameters()) + list(cell.b_f.parameters()))
+    h_new, c_new = {}, {}
     for nt in NODE_TYPES:
-        p = {g: pre[nt][:, k] + getattr(cell, "b_" + g)[nt] for k, g in enumerate(gates)}
+        lay = layout[nt]
+        n = agg[nt].size(0)
+        with torch.autocast(agg[nt].device.type, enabled=False):
+            a = agg[nt].view(n, G, lay.Kg)[:, :, :lay.Ka].transpose(0, 1)          # [G, N, Ka]
+            skip = P[nt][:, lay.s_off:lay.s_off + G * C].float().view(n, G, C)
+            pre = torch.bmm(a, w2[nt].transpose(1, 2)).transpose(0, 1) + skip      # [N, G, 96]
+        p = {g: pre[:, k] for k, g in enumerate(gates)}
         cand = torch.sigmoid(p["i"]) * torch.tanh(p["c"])
         c_new[nt] = cand + touch if h is None else torch.sigmoid(p["f"]) * c[nt] + cand
         h_new[nt] = torch.sigmoid(p["o"]) * torch.tanh(c_new[nt])

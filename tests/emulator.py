@@ -114,7 +114,7 @@ class TorchEmulatorBackend:
             agg[:, base + sc_off + 1] = sae
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
-                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates):
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None):
         """ggnn_period_gat_aggregate_backward by autograd of the emulated forward.  The reverse
         CSR is checked for what the HIP kernel relies on, then not needed."""
         E = csr.E
@@ -134,8 +134,14 @@ class TorchEmulatorBackend:
                     + (sa * g_agg[:, base + sc_off]).sum() + (sae * g_agg[:, base + sc_off + 1]).sum()
             grads = torch.autograd.grad(tot, leaves + ([hl] if hl is not None else []), allow_unused=True)
         z = lambda g, like: torch.zeros_like(like) if g is None else g
-        return (z(grads[1], p_dst), z(grads[0], p_src), None if hl is None else z(grads[3], h_src),
-                z(grads[2], ep))
+        g_p_dst, g_p_src = z(grads[1], p_dst), z(grads[0], p_src)
+        if out_p_dst is not None:   # shared buffers: this sweep owns its own columns only (they are disjoint)
+            out_p_dst += g_p_dst
+            g_p_dst = out_p_dst
+        if out_p_src is not None:
+            out_p_src += g_p_src
+            g_p_src = out_p_src
+        return (g_p_dst, g_p_src, None if hl is None else z(grads[3], h_src), z(grads[2], ep))
 
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
                       w2_planes=None, g_stride=0):

@@ -113,23 +113,32 @@ def test_training_path_on_the_emulator_matches_oracle_gradients(monkeypatch):
 
 
 def test_one_adam_step_on_the_emulator_follows_the_oracle(monkeypatch):
-    """train.py:158-166: forward, loss, zero_grad, backward, Adam step -- same new parameters."""
+    """train.py:158-166: forward, loss, zero_grad, backward, Adam step -- same new parameters.
+    (Where the exact gradient is zero -- key biases: a softmax is shift-invariant; the encoder's
+    forget gate -- Adam steps along each implementation's own rounding noise: those tensors are
+    held to 2 steps x lr each way only.)"""
     x, ei, ea = load_graph("40")
     be = TorchEmulatorBackend()
     monkeypatch.setattr(training, "default_backend", lambda: be)
     R, _ = product_models(4, 1.0)
     oR, _ = oracle_models(4, 1.0)
     y_np, m_np = _targets(x, ei)
+    lr_adam, g_first = 5e-3, {}
     for m in (R, oR):
         m.train()
-        opt = torch.optim.Adam(m.parameters(), lr=5e-3)
-        for _ in range(2):
+        opt = torch.optim.Adam(m.parameters(), lr=lr_adam)
+        for it in range(2):
             loss = training.regressor_loss(tt(y_np), m(tt(x), tt(ei), tt(ea)), tt(m_np))
             opt.zero_grad()
             loss.backward()
+            if m is oR and it == 0:
+                g_first = {n: float(p.grad.abs().max()) for n, p in m.named_parameters()}
             opt.step()
+    gmax = max(g_first.values())
     for (n, p), (_, q) in zip(R.named_parameters(), oR.named_parameters()):
-        assert float((p - q).abs().max()) <= 1e-3 * max(float(q.abs().max()), 1e-3), n
+        noise_only = g_first[n] <= 1e-5 * gmax
+        bound = 4 * lr_adam * 1.01 if noise_only else 1e-3 * max(float(q.abs().max()), 1e-3)
+        assert float((p.detach() - q.detach()).abs().max()) <= bound, (n, noise_only)
 
 
 @pytest.mark.gpu
