@@ -105,30 +105,40 @@ _KINDS = (("wq", "lin_query", "weight"), ("bq", "lin_query", "bias"), ("wk", "li
 
 
 def _gather_params(cell, gates):
-    """All parameters the cell's forward reads, as views of one flat tensor: get(et, kind) ->
-    [G, *param.shape]; gate bias get(("b", nt)) -> [G, 96]."""
+    """All parameters the cell's forward reads, stacked per gate: get(et, kind) -> [G, *param.shape];
+    gate bias get("b", nt) -> [G, 96].  ONE cat kernel gathers them into a flat buffer and ONE
+    split hands out the views (a slice per tensor would cost a full-size zero fill + add each in the
+    backward; the split's backward is a single cat)."""
     G = len(gates)
-    plist, index, off = [], {}, 0
+    plist, keys, shapes, sizes = [], [], [], []
     for et in EDGE_TYPES:
         for kind, lin, wb in _KINDS:
             ts = [getattr(getattr(getattr(cell, "conv_" + g).convs[et_key(et)], lin), wb) for g in gates]
-            index[(et, kind)] = (off, (G,) + tuple(ts[0].shape))
-            off += G * ts[0].numel()
+            keys.append((et, kind))
+            shapes.append((G,) + tuple(ts[0].shape))
+            sizes.append(G * ts[0].numel())
             plist += ts
     for nt in NODE_TYPES:
         ts = [getattr(cell, "b_" + g)[nt] for g in gates]
-        index[("b", nt)] = (off, (G, C))
-        off += G * C
+        keys.append(("b", nt))
+        shapes.append((G, C))
+        sizes.append(G * C)
         plist += ts
-    flat = torch.cat([t.reshape(-1) for t in plist])
+    parts = torch.split(torch.cat([t.reshape(-1) for t in plist]), sizes)
+    table = {k: part.view(shape) for k, part, shape in zip(keys, parts, shapes)}
+    return lambda *key: table[key]
 
-    def get(*key):
-        o, shape = index[key if len(key) > 1 else key[0]]
-        n = 1
-        for d in shape:
-            n *= d
-        return flat[o:o + n].view(shape)
-    return get
+
+_zero_cache = {}
+
+
+def _zeros(dev, *shape):
+    """Constant zero blocks of the packed matrices (no gradient flows into them): made once."""
+    key = (str(dev), shape)
+    z = _zero_cache.get(key)
+    if z is None:
+        z = _zero_cache[key] = torch.zeros(*shape, dtype=torch.float32, device=dev)
+    return z
 
 
 def _packed_weights(cell, gates, F, sees_h):
@@ -140,7 +150,7 @@ def _packed_weights(cell, gates, F, sees_h):
     scale = 1.0 / math.sqrt(C)
     get = _gather_params(cell, gates)
     dev = get(EDGE_TYPES[0], "wq").device
-    zeros = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    zeros = lambda *shape: _zeros(dev, *shape)
     layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
     prod = {}
     for et in EDGE_TYPES:  # key-free score rows: M = W_k^T W_q / sqrt(96) and friends, per gate
