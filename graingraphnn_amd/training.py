@@ -153,48 +153,49 @@ def _packed_weights(cell, gates, F, sees_h):
     zeros = lambda *shape: _zeros(dev, *shape)
     layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
     prod = {}
+    cut = lambda t, n, dim: t if t.size(dim) == n else t.narrow(dim, 0, n)   # (the encoder ignores the h columns)
+    wv3, wvr = {}, {}
     for et in EDGE_TYPES:  # key-free score rows: M = W_k^T W_q / sqrt(96) and friends, per gate
         Fs, Fd = F[et[0]], F[et[-1]]
-        wq, bq = get(et, "wq")[:, :, :Fd + k2], get(et, "bq")
-        wk, bk = get(et, "wk")[:, :, :Fs + k2], get(et, "bk")
-        we = get(et, "we")[:, :, 0]
+        wq, bq = cut(get(et, "wq"), Fd + k2, 2), get(et, "bq")
+        wk, bk = cut(get(et, "wk"), Fs + k2, 2), get(et, "bk")
+        we = get(et, "we").squeeze(-1)
         wkt = wk.transpose(1, 2)                                     # [G, Fs + k2, 96]
-        M = torch.bmm(wkt, wq) * scale                               # [G, Fs + k2, Fd + k2]
-        mb = torch.bmm(wkt, bq.unsqueeze(-1)).squeeze(-1) * scale    # [G, Fs + k2]
-        rows = torch.bmm(torch.stack([bk, we], 1), wq) * scale       # [G, 2, Fd + k2]: s1, s2 rows
-        rb = torch.bmm(torch.stack([bk, we], 1), bq.unsqueeze(-1)).squeeze(-1) * scale   # [G, 2]
-        tail_w = torch.cat([M[:, :Fs], zeros(G, 12 - Fs, Fd + k2), rows, zeros(G, 2, Fd + k2)], 1)   # [G, 16, .]
-        tail_b = torch.cat([mb[:, :Fs], zeros(G, 12 - Fs), rb, zeros(G, 2)], 1)                      # [G, 16]
-        prod[et] = (M[:, Fs:], mb[:, Fs:], tail_w, tail_b)
+        # (splits, not slices: a slice's backward is a full-size zero fill + add, a split's one cat)
+        Mb = torch.bmm(wkt, torch.cat([wq, bq.unsqueeze(-1)], 2)) * scale          # [G, Fs + k2, Fd + k2 + 1]
+        Rb = torch.bmm(torch.stack([bk, we], 1), torch.cat([wq, bq.unsqueeze(-1)], 2)) * scale   # [G, 2, . + 1]: s1, s2 rows
+        if sees_h:
+            Mb_x, Mb_h = torch.split(Mb, [Fs, k2], 1)
+        else:
+            Mb_x, Mb_h = Mb, None
+        tail = torch.cat([Mb_x, zeros(G, 12 - Fs, Fd + k2 + 1), Rb, zeros(G, 2, Fd + k2 + 1)], 1)   # [G, 16, . + 1]
+        prod[et] = (Mb_h, tail)
+        wv3[et], wvr[et] = torch.split(cut(get(et, "wv"), Fs + k2, 2), [3, Fs + k2 - 3], 2)
     for nt in NODE_TYPES:
         lay = node_layout(nt, F[nt], G, EDGE_TYPES, True, sees_h, True)
         Fn, D = F[nt], F[nt] + k2
-        blocks_w, blocks_b = [], []
+        blocks = []                                                  # rows of [W | b]: [n, D + 1]
         for et in lay.src_ets:                                       # value rows, reloc columns zeroed
-            wv = get(et, "wv")[:, :, :D]
-            blocks_w.append(torch.cat([zeros(G, C, 3), wv[:, :, 3:]], 2).reshape(G * C, D))
-            blocks_b.append(get(et, "bv").reshape(-1))
+            blocks.append(torch.cat([zeros(G, C, 3), wvr[et], get(et, "bv").unsqueeze(-1)], 2).reshape(G * C, D + 1))
         if sees_h:
             for et in lay.dst_ets:                                   # hidden-state part of u
-                blocks_w.append(prod[et][0].reshape(G * C, D))
-                blocks_b.append(prod[et][1].reshape(-1))
-        ws = sum(get(et, "ws")[:, :, :D] for et in lay.dst_ets)      # HeteroConv aggr 'sum' -> summed skip
+                blocks.append(prod[et][0].reshape(G * C, D + 1))
+        ws = sum(cut(get(et, "ws"), D, 2) for et in lay.dst_ets)      # HeteroConv aggr 'sum' -> summed skip
         bs = sum(get(et, "bs") for et in lay.dst_ets) + get("b", nt)
-        blocks_w.append(ws.reshape(G * C, D))
-        blocks_b.append(bs.reshape(-1))
+        blocks.append(torch.cat([ws, bs.unsqueeze(-1)], 2).reshape(G * C, D + 1))
         for et in lay.dst_ets:
-            blocks_w.append(prod[et][2].reshape(G * 16, D))
-            blocks_b.append(prod[et][3].reshape(-1))
-        n_rows = sum(b.size(0) for b in blocks_w)
-        blocks_w.append(zeros(lay.ncols - n_rows, D))
-        blocks_b.append(zeros(lay.ncols - n_rows))
-        wp[nt], bp[nt], layout[nt] = torch.cat(blocks_w), torch.cat(blocks_b), lay
+            blocks.append(prod[et][1].reshape(G * 16, D + 1))
+        n_rows = sum(b.size(0) for b in blocks)
+        blocks.append(zeros(lay.ncols - n_rows, D + 1))
+        wp[nt], bp[nt] = torch.split(torch.cat(blocks), [D, 1], 1)
+        bp[nt] = bp[nt].reshape(-1)
+        layout[nt] = lay
         n_in = len(lay.dst_ets)
         w2[nt] = torch.cat([get(et, "wl") for et in lay.dst_ets]
-                           + [torch.stack([get(et, "bl"), get(et, "we")[:, :, 0]], 2) for et in lay.dst_ets]
+                           + [torch.cat([get(et, "bl").unsqueeze(-1), get(et, "we")], 2) for et in lay.dst_ets]
                            + [zeros(G, C, lay.Ka - n_in * (C + 2))], 2)   # [G, 96, Ka]
     for et in EDGE_TYPES:
-        ep[et] = get(et, "wv")[:, :, :3].transpose(1, 2).contiguous()   # [G, 3, 96]
+        ep[et] = wv3[et].transpose(1, 2).contiguous()                # [G, 3, 96]
     return layout, wp, bp, ep, w2
 
 
@@ -276,9 +277,10 @@ def cell_forward(cell, backend, topo, einfo, x, h, c):
         lay = layout[nt]
         n = agg[nt].size(0)
         with torch.autocast(agg[nt].device.type, enabled=False):
-            a = agg[nt].view(n, G, lay.Kg)[:, :, :lay.Ka].transpose(0, 1)          # [G, N, Ka]
-            skip = P[nt][:, lay.s_off:lay.s_off + G * C].float().view(n, G, C)
-            pre = torch.bmm(a, w2[nt].transpose(1, 2)).transpose(0, 1) + skip      # [N, G, 96]
+            a = agg[nt].view(n, G, lay.Kg).transpose(0, 1)                         # [G, N, Kg] (pad columns meet zero weights)
+            w2p = w2[nt] if lay.Kg == lay.Ka else torch.cat([w2[nt], _zeros(w2[nt].device, G, C, lay.Kg - lay.Ka)], 2)
+            skip = P[nt].narrow(1, lay.s_off, G * C).float().view(n, G, C)
+            pre = torch.bmm(a, w2p.transpose(1, 2)).transpose(0, 1) + skip         # [N, G, 96]
         p = {g: pre[:, k] for k, g in enumerate(gates)}
         cand = torch.sigmoid(p["i"]) * torch.tanh(p["c"])
         c_new[nt] = cand + touch if h is None else torch.sigmoid(p["f"]) * c[nt] + cand

@@ -24,21 +24,37 @@ from graingraphnn_amd.models import GrainNN_regressor  # noqa: E402
 from graingraphnn_amd.seeding import load_seeded  # noqa: E402
 
 
-def run(model, X, EI, EA, y, mask, steps, sync, autocast=False):
+def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False):
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph)
     losses = []
 
     def one():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             loss = training.regressor_loss(y, model(X, EI, EA), mask)
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=not graph)
         loss.backward()
         opt.step()
         return loss
     for _ in range(3):
         one()
     sync()
+    if graph:
+        # the whole step (forward, loss, backward, Adam) replayed from one hipGraph: the eager step is
+        # bound by the host (~800 launches), the kernels themselves take about half of its time
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                static_loss = one()
+        torch.cuda.current_stream().wait_stream(s)
+        eager_one = one
+
+        def one():
+            g.replay()
+            return static_loss.clone()
+        sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses.append(one())
@@ -54,6 +70,7 @@ def main():
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--cfg3", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
     args = ap.parse_args()
@@ -73,8 +90,9 @@ def main():
     X, EI, EA = synthetic.to_torch(x, ei, ea, dev)
     Y = {k: torch.from_numpy(v).to(dev) for k, v in y.items()}
     M = {k: torch.from_numpy(v).to(dev) for k, v in mask.items()}
-    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16)
-    print(f"{name}: HIP training path{' (bf16 autocast GEMMs)' if args.bf16 else ''}: {dt * 1e3:.2f} ms/step, "
+    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph)
+    print(f"{name}: HIP training path{' (bf16 autocast GEMMs)' if args.bf16 else ''}"
+          f"{' (hipGraph replay)' if args.graph else ''}: {dt * 1e3:.2f} ms/step, "
           f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     if not args.no_cpu:
         from oracle import grainnn_oracle as oracle
