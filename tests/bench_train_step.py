@@ -36,20 +36,24 @@ def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(3):
-        one()
-    sync()
-    if graph:
+    if not graph:
+        for _ in range(3):
+            one()
+        sync()
+    else:
         # the whole step (forward, loss, backward, Adam) replayed from one hipGraph: the eager step is
-        # bound by the host (~800 launches), the kernels themselves take about half of its time
+        # bound by the host (~800 launches), the kernels themselves take about half of its time.
+        # Warm-up and capture on the same side stream (PyTorch's whole-network capture recipe).
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
                 static_loss = one()
         torch.cuda.current_stream().wait_stream(s)
-        eager_one = one
 
         def one():
             g.replay()
