@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 13
+GGNN_ABI_VERSION = 14
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
-    "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
+    "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
+    "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
@@ -79,6 +80,25 @@ class AggregateEncArgs(Structure):
         ("ldp_dst", c_int64), ("ld_agg", c_int64), ("n_dst", c_int64), ("E", c_int64),
         ("u4_off", c_int32), ("a_off", c_int32), ("a_gstride", c_int32), ("sc_off", c_int32),
         ("n_gates", c_int32), ("reserved", c_int32),
+    ]
+
+
+class EncCellSweep(Structure):
+    """Mirror of `ggnn_enc_cell_sweep`."""
+    _fields_ = [
+        ("rowptr", c_void_p), ("einfo", c_void_p), ("wv_frag", c_void_p),
+        ("E", c_int64), ("u4_off", c_int32), ("f_src", c_int32),
+    ]
+
+
+class EncCellArgs(Structure):
+    """Mirror of `ggnn_enc_cell_args`."""
+    _fields_ = [
+        ("sweeps", EncCellSweep * 2),
+        ("p_dst", c_void_p), ("w2_frag", c_void_p), ("w2", c_void_p), ("pre", c_void_p),
+        ("h_out", c_void_p), ("c_out", c_void_p), ("x_dst", c_void_p), ("ws_t", c_void_p),
+        ("ldp", c_int64), ("n_dst", c_int64), ("ldx", c_int64),
+        ("n_in", c_int32), ("f_dst", c_int32), ("Ka", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -150,6 +170,8 @@ def _declare(lib):
     lib.ggnn_period_gat_aggregate_batch.argtypes = [POINTER(AggregateArgs), c_int, c_void_p]
     lib.ggnn_period_gat_aggregate_enc_batch.restype = c_int
     lib.ggnn_period_gat_aggregate_enc_batch.argtypes = [POINTER(AggregateEncArgs), c_int, c_void_p]
+    lib.ggnn_encoder_cell_batch.restype = c_int
+    lib.ggnn_encoder_cell_batch.argtypes = [POINTER(EncCellArgs), c_int, c_void_p]
     lib.ggnn_aggregate_bwd_partials.restype = c_int64
     lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
     lib.ggnn_period_gat_aggregate_backward.restype = c_int

@@ -3,12 +3,13 @@ tensors in, launches enqueued on the current HIP stream, nothing returned but th
 written in place.  `HipBackend` is the only backend the package ships: it refuses CPU
 tensors and raises if libggnn.so cannot be loaded -- there is no CPU fallback."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib
-from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, EpilogueArgs, PrepareEdge, ProjectArgs, RefreshEdge, check,
-                   ptr)
+from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, EncCellArgs, EpilogueArgs, PrepareEdge, ProjectArgs,
+                   RefreshEdge, check, ptr)
 
 
 class CSR:
@@ -40,6 +41,9 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._tape = None  # while a list: every hot-path launch is also recorded as (cfunc, name, cargs)
+        # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
+        # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
+        self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
 
     # -- launch tape: the drop-in forward() issues the same dozen launches with the same arguments
     # step after step (test.py:382-383); re-issuing the recorded C calls skips the per-launch
@@ -174,6 +178,41 @@ class HipBackend:
             a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = u4_off, a_off, a_gstride, sc_off, n_gates
         self._launch(self.lib.ggnn_period_gat_aggregate_enc_batch, "ggnn_period_gat_aggregate_enc_batch", arr,
                      len(sweeps), _lib.current_stream())
+
+    def encoder_cell_batch(self, problems):
+        """Encoder cells (h = c = 0) of up to four (node type, model) problems with sweep and gate GEMM
+        fused (ggnn_encoder_cell_batch).  Each item: (sweeps, p_dst, x_dst, ws_t, w2, w2_frag, pre, h_out, c_out)
+        with sweeps = [(csr, einfo, wv_frag, u4_off, f_src)] for the 1 or 2 incoming edge types; ws_t:
+        packing.skip_transposed ([F_dst + 1, 288])."""
+        arr = (EncCellArgs * len(problems))()
+        for a, (sweeps, p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out) in zip(arr, problems):
+            _require_cuda(p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out)
+            if ws_t.dtype != torch.float32 or ws_t.dim() != 2 or ws_t.size(1) != 288 or not ws_t.is_contiguous() \
+                    or x_dst.dtype != torch.float32 or x_dst.size(0) != p_dst.size(0) or x_dst.stride(1) != 1 \
+                    or x_dst.size(1) < ws_t.size(0) - 1:
+                raise _lib.GGNNError("ws_t must be contiguous [F_dst + 1, 288] and x_dst [n_dst, >= F_dst]")
+            n_in, n = len(sweeps), p_dst.size(0)
+            if w2.dim() != 3 or w2.size(0) != 3 or w2.size(2) != 96 * n_in + 4 or not w2.is_contiguous():
+                raise _lib.GGNNError("w2 must be contiguous [3, 96, 96 * n_in + 4]")
+            if w2f.dtype != torch.float32 or w2f.numel() != 3 * 96 * 96 * n_in:
+                raise _lib.GGNNError("w2_frag does not match w2 (see packing.gate_fragments)")
+            if tuple(pre.shape) != (n_in, n, 288) or not pre.is_contiguous() or tuple(h_out.shape) != (n, 96) \
+                    or tuple(c_out.shape) != (n, 96) or not h_out.is_contiguous() or not c_out.is_contiguous():
+                raise _lib.GGNNError("pre / h_out / c_out must be contiguous [n_in, n_dst, 288] / [n_dst, 96]")
+            for sw, (csr, einfo, wvb, u4_off, f_src) in zip(a.sweeps, sweeps):
+                _require_cuda(csr.rowptr, einfo, wvb)
+                if wvb.dtype != torch.float32 or wvb.numel() != 3 * 6 * 4 * 64:
+                    raise _lib.GGNNError("wv_frag must be packing.value_fragments_bias of three gates")
+                if csr.rowptr.numel() != n + 1:
+                    raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
+                sw.rowptr, sw.einfo = csr.rowptr.data_ptr(), einfo.data_ptr()
+                sw.wv_frag, sw.E, sw.u4_off, sw.f_src = wvb.data_ptr(), csr.E, u4_off, f_src
+            a.p_dst, a.w2_frag, a.w2, a.pre = p_dst.data_ptr(), w2f.data_ptr(), w2.data_ptr(), pre.data_ptr()
+            a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
+            a.x_dst, a.ws_t, a.ldx, a.f_dst = x_dst.data_ptr(), ws_t.data_ptr(), x_dst.stride(0), ws_t.size(0) - 1
+            a.ldp, a.n_dst, a.n_in, a.Ka = p_dst.stride(0), n, n_in, w2.size(2)
+        self._launch(self.lib.ggnn_encoder_cell_batch, "ggnn_encoder_cell_batch", arr, len(problems),
+                     _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
                            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None):

@@ -112,9 +112,19 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
     launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
     Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
-    projs, sweeps, enc_sweeps, gates = [], [], [], []
+    projs, sweeps, enc_sweeps, gates, enc_cells = [], [], [], [], []
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
+        if pc.wvb and getattr(backend, "fused_encoder", False):
+            # encoder: sweep and gate GEMM of a node type in one kernel; the projection only emits the score
+            # tails (the skip term is formed in the LSTM launch); `agg` = {node type: pre-activation scratch}
+            for nt in NODE_TYPES:
+                if lay[nt].live:
+                    projs.append((x[nt], lay[nt].F, None, pc.wps[nt], pc.bps[nt], proj[nt][:, :pc.wps[nt].size(0)]))
+                    enc_cells.append(([(graph.csr[et], einfo[et], pc.wvb[et], pc.u4s[et], lay[et[0]].F)
+                                       for et in lay[nt].dst_ets], proj[nt], x[nt], pc.wst[nt], pc.w2[nt], pc.w2f[nt],
+                                      _pre_view(agg[nt], len(lay[nt].dst_ets)), h_out[nt], c_out[nt]))
+            continue
         for nt in NODE_TYPES:
             P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
             projs.append((x[nt], lay[nt].F, h_in[nt] if pc.k2 else None, pc.wp[nt], pc.bp[nt], P))
@@ -131,11 +141,23 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                            lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
         gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
     backend.project_batch(projs)
+    if enc_cells:
+        backend.encoder_cell_batch(enc_cells)
     if enc_sweeps:
         backend.aggregate_enc_batch(enc_sweeps)
     if sweeps:
         backend.aggregate_batch(sweeps)
-    backend.lstm_epilogue_batch(gates)
+    if gates:
+        backend.lstm_epilogue_batch(gates)
+
+
+def _pre_view(agg: torch.Tensor, n_in: int) -> torch.Tensor:
+    """[n_in, n, 3 * 96] partial pre-activation scratch of the fused encoder cell inside the (otherwise
+    unused) aggregate buffer of the node type."""
+    n = agg.size(0)
+    if agg.numel() < n_in * n * 3 * C:
+        raise _lib.GGNNError("aggregate buffer too small for the fused encoder cell's scratch")
+    return agg.view(-1)[:n_in * n * 3 * C].view(n_in, n, 3 * C)
 
 
 def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],

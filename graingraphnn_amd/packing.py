@@ -118,6 +118,14 @@ class PackedCell:
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
     w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> fragment-ordered w2 (bf16_planes)
     wvf: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # encoder: edge type -> value_fragments
+    # encoder, fused cell (ggnn_encoder_cell_batch): node type -> gate_fragments(w2), edge type -> value_fragments_bias
+    w2f: Dict[str, torch.Tensor] = field(default_factory=dict)
+    wvb: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)
+    # ... whose projection only emits the score tails (the skip term is formed in the LSTM launch):
+    wps: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [roundup96(16 G n_in), Fp] tail rows of wp
+    bps: Dict[str, torch.Tensor] = field(default_factory=dict)
+    u4s: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> tail column in that projection
+    wst: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> skip_transposed [F + 1, 288]
 
 
 @torch.no_grad()
@@ -165,6 +173,40 @@ def value_fragments(weights, biases, F_src: int) -> torch.Tensor:
         Bp[11, g * C:(g + 1) * C] = biases[g].detach().float()
     fr = Bp.view(3, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
     fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 6 g + 2 m2 + e, lane l = 16 kq + j)
+    return fr.view(-1)
+
+
+@torch.no_grad()
+def gate_fragments(w2: torch.Tensor) -> torch.Tensor:
+    """`ggnn_enc_cell_args.w2_frag` (include/ggnn.h): w2[:, :, :Ka-4] as fp32 MFMA A fragments in the
+    fused encoder cell's k order, [G][(Ka-4)/32][6][2][64][4]: element [g][ks][ct][h][l][j] =
+    w2[g][16 ct + (l & 15)][32 ks + 16 h + 4 (l >> 4) + j].  The kernel splits every value into three
+    bf16 pieces on the fly; exactness of that split is checked as in bf16_planes."""
+    bf16_planes(w2)  # raises on non-finite / unsplittable weights
+    G, nch, Ka = w2.shape
+    KM = Ka - 4
+    fr = w2[:, :, :KM].float().reshape(G, 6, 16, KM // 32, 2, 4, 4)   # g ct i ks h kq j
+    fr = fr.permute(0, 3, 1, 4, 5, 2, 6).contiguous()                 # g ks ct h kq i j   (lane l = 16 kq + i)
+    return fr.view(-1)
+
+
+@torch.no_grad()
+def value_fragments_bias(weights, biases, F_src: int) -> torch.Tensor:
+    """`ggnn_enc_cell_sweep.wv_frag` (include/ggnn.h): lin_value of the G gates of one edge type
+    (weights[g]: [96, >= F_src], biases[g]: [96]) as [G][6][4][64]: for gate g and column tile t the
+    k-steps s = 0..2 of the MFMA B fragments, [s][l] = W_g[ch][4 s + (l >> 4)] (0 for k >= F_src) with
+    ch = 32 (t / 2) + 2 (l & 15) + t % 2, and as entry s = 3 the bias b_g[ch] (the accumulator's
+    initial value: 8 source features are two k-steps)."""
+    G = len(weights)
+    if F_src > 12:
+        raise ValueError("the fused encoder cell reads at most 12 source features")
+    dev = weights[0].device
+    Bp = torch.zeros(16, G * C, dtype=torch.float32, device=dev)   # rows 0..11: W^T, rows 12..15: bias
+    for g in range(G):
+        Bp[:F_src, g * C:(g + 1) * C] = weights[g].detach().float()[:, :F_src].t()
+        Bp[12:16, g * C:(g + 1) * C] = biases[g].detach().float()
+    fr = Bp.view(4, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
+    fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 2 m2 + e, lane l = 16 kq + j)
     return fr.view(-1)
 
 
@@ -263,7 +305,30 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             convs = [_conv(cell, gate, et) for gate in gates]
             wvf[et] = value_fragments([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
                                       F_of[et[0]])
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf)
+    w2f, wvb, wps, bps, u4s, wst = {}, {}, {}, {}, {}, {}
+    if enc_mfma:  # fused cell: fragments in its own k order, value bias apart
+        w2f = {nt: gate_fragments(t) for nt, t in w2.items() if layout[nt].live}
+        for nt in NODE_TYPES:
+            lay = layout[nt]
+            if not lay.live:
+                continue
+            rows = [torch.arange(lay.u4_off[et], lay.u4_off[et] + G * U4, device=dev) for et in lay.dst_ets]
+            idx = torch.cat(rows)
+            ncs = (idx.numel() + C - 1) // C * C
+            wps[nt] = torch.zeros(ncs, wp[nt].size(1), dtype=dt, device=dev)
+            bps[nt] = torch.zeros(ncs, dtype=dt, device=dev)
+            wps[nt][:idx.numel()], bps[nt][:idx.numel()] = wp[nt][idx], bp[nt][idx]
+            for k, et in enumerate(lay.dst_ets):
+                u4s[et] = k * G * U4
+            # skip term: [F + 1, G * 96], rows = input features, last row = bias (the cell sees no h: k2 = 0)
+            wst[nt] = torch.cat([wp[nt][lay.s_off:lay.s_off + G * C, :lay.F].t(),
+                                 bp[nt][lay.s_off:lay.s_off + G * C].view(1, -1)]).contiguous()
+        for et in ep:
+            convs = [_conv(cell, gate, et) for gate in gates]
+            wvb[et] = value_fragments_bias([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
+                                           F_of[et[0]])
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, w2f=w2f, wvb=wvb,
+                      wps=wps, bps=bps, u4s=u4s, wst=wst)
 
 
 @torch.no_grad()

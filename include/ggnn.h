@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 13
+#define GGNN_ABI_VERSION 14
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -282,6 +282,60 @@ int ggnn_lstm_epilogue(const ggnn_epilogue_args* args, ggnn_stream_t stream);
  * regressor and the classifier (test.py:382-383 calls both models on the same x_dict).  All
  * problems must share `mode` and `n_gates`; Ka may differ.  Same result as n single calls. */
 int ggnn_lstm_epilogue_batch(const ggnn_epilogue_args* args, int n_problems, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Encoder cell (h = c = 0; HeteroPGCLSTM.forward on the zero state of models.py:422,
+ * heteropgclstm.py:101-183) with sweep and gate GEMM fused: replaces
+ * ggnn_period_gat_aggregate_enc_batch + ggnn_lstm_epilogue_batch(GGNN_MODE_LSTM_H0) -- same sums up to
+ * fp32 re-association, but the aggregates stay in the compute unit's LDS instead of an [N, 3 * 224]
+ * buffer.  One problem = one destination node type of one model, with its 1 or 2 incoming edge types
+ * (HeteroConv sums them, heteropgclstm.py:113-138); up to four problems (two node types x regressor
+ * and classifier, test.py:382-383) per call.  Per incoming edge type:
+ *   rowptr  : [n_dst + 1] destination-grouped CSR row pointers (ggnn_build_csr)
+ *   einfo   : as ggnn_aggregate_enc_args
+ *   wv_frag : [3][6][4][64] fp32: per gate g and column tile t, k-steps s = 0..2 of the MFMA B
+ *             fragments of lin_value ([s][l] = W_value_g[ch][4 s + (l >> 4)], 0 for k >= f_src, with
+ *             ch = 32 (t / 2) + 2 (l & 15) + t % 2) and, as entry s = 3, the bias b_value_g[ch]
+ *   u4_off  : column of the edge type's score tails in p_dst (as ggnn_aggregate_enc_args)
+ *   f_src   : features of the source node type (3..12)
+ * and per problem
+ *   p_dst   : [n_dst, ldp] destination projections: the u4 tails (ggnn_project)
+ *   x_dst   : [n_dst, ldx] features of the destination nodes (first f_dst columns)
+ *   ws_t    : [f_dst + 1][288] fp32: lin_skip summed over the incoming edge types (HeteroConv aggr 'sum'),
+ *             transposed -- row k, column g*96 + ch = sum_et W_skip_{et,g}[ch][k] -- and, as the last row,
+ *             the summed skip biases + b_{i,c,o}: the skip term is formed in the LSTM launch
+ *   w2      : [3][96][Ka], Ka = 96 n_in + 4, as ggnn_epilogue_args (only the four tail columns are read)
+ *   w2_frag : w2[:, :, 0:Ka-4] as MFMA A fragments, fp32, [3][(Ka-4)/32][6][2][64][4]: element
+ *             [g][ks][ct][h][l][j] = w2[g][16 ct + (l & 15)][32 ks + 16 h + 4 (l >> 4) + j]
+ *             (the k-groups of a step are interleaved by four: conflict-free LDS fragment reads)
+ *   pre     : [n_in, n_dst, 288] scratch: per incoming edge type the gates' partial pre-activations
+ *             (lin_l2 of the aggregate + b_l2 sum alpha + w_edge sum alpha a)
+ *   h_out, c_out : [n_dst, 96]
+ * n_dst < 2^23.  Two launches: the fused sweep + GEMM (one persistent workgroup per compute unit, each
+ * owning one (problem, edge type, gate): that PeriodConv's lin_l2 stays in LDS as bf16 planes, the
+ * operands of the sweep arrive through a per-wave LDS-DMA ring), then the element-wise sum over the
+ * edge types + skip + LSTM update. */
+typedef struct ggnn_enc_cell_sweep {
+  const int32_t* rowptr;   /* [n_dst + 1] */
+  const float* einfo;      /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] */
+  const float* wv_frag;    /* [3][6][4][64] */
+  int64_t E;
+  int32_t u4_off, f_src;
+} ggnn_enc_cell_sweep;
+typedef struct ggnn_enc_cell_args {
+  ggnn_enc_cell_sweep in[2];
+  const float* p_dst;   /* [n_dst, ldp] */
+  const float* w2_frag; /* [3][(Ka-4)/32][6][2][64][4] */
+  const float* w2;      /* [3][96][Ka] */
+  float* pre;           /* [n_in, n_dst, 288] */
+  float* h_out;         /* [n_dst, 96] */
+  float* c_out;         /* [n_dst, 96] */
+  const float* x_dst;   /* [n_dst, ldx] */
+  const float* ws_t;    /* [f_dst + 1][288] */
+  int64_t ldp, n_dst, ldx;
+  int32_t n_in, f_dst, Ka, reserved;
+} ggnn_enc_cell_args;
+int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads.

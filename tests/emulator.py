@@ -13,6 +13,7 @@ C = 96
 
 class TorchEmulatorBackend:
     name = "torch-emulator (tests only)"
+    fused_encoder = True  # engine.run_cells: encoder cells through encoder_cell_batch (False: sweep + gate epilogue)
 
     def build_csr(self, edge_index, n_src, n_dst):
         src, dst = edge_index[0], edge_index[1]
@@ -77,6 +78,47 @@ class TorchEmulatorBackend:
                     0, dst, alpha[:, None] * val[:, g * C:(g + 1) * C])
                 agg[:, base + sc_off] = torch.zeros(n_dst).index_add(0, dst, alpha)
                 agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add(0, dst, alpha * a)
+
+    def encoder_cell_batch(self, problems):
+        """ggnn_encoder_cell_batch: sweep of every incoming edge type (values relu(W x4[:12] + b) from the
+        edge records), gate GEMM on [A_et0 | A_et1 | sum alpha, sum alpha a per edge type], skip, LSTM from
+        zero state.  The fragment tensors must decode to the plain weights exactly."""
+        for sweeps, p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out in problems:
+            G, n_in, n_dst = 3, len(sweeps), p_dst.size(0)
+            Ka, KM = w2.size(2), w2.size(2) - 4
+            assert KM == 96 * n_in
+            fr = w2f.view(G, KM // 32, 6, 2, 4, 16, 4)                      # g ks ct h kq i j
+            assert torch.equal(fr.permute(0, 2, 5, 1, 3, 4, 6).reshape(G, 96, KM), w2[:, :, :KM])
+            agg = torch.zeros(G, n_dst, Ka)
+            for d, (csr, einfo, wvb, u4_off, f_src) in enumerate(sweeps):
+                rowptr = csr.rowptr.long()
+                E = int(rowptr[-1])
+                dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
+                fb = wvb.view(G, 3, 2, 4, 4, 16)                            # g m2 e s kq j
+                Bp = fb.permute(3, 4, 0, 1, 5, 2).reshape(16, G * C)        # k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e
+                assert torch.equal(Bp[12], Bp[13]) and torch.equal(Bp[12], Bp[15]) and not bool(Bp[f_src:12].any())
+                nk = 12 if f_src > 8 else 8
+                x4, a = einfo[:E, :16], einfo[:E, 19]
+                val = torch.relu(x4[:, :nk] @ Bp[:nk] + Bp[12])             # [E, G * 96]
+                for g in range(G):
+                    s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
+                    smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
+                    p = (s - smax[dst]).exp()
+                    den = torch.zeros(n_dst).index_add(0, dst, p)
+                    alpha = p / (den[dst] + 1e-16)
+                    agg[g, :, d * C:(d + 1) * C] = torch.zeros(n_dst, C).index_add(0, dst, alpha[:, None] * val[:, g * C:(g + 1) * C])
+                    agg[g, :, KM + 2 * d] = torch.zeros(n_dst).index_add(0, dst, alpha)
+                    agg[g, :, KM + 2 * d + 1] = torch.zeros(n_dst).index_add(0, dst, alpha * a)
+            raw = torch.zeros(n_dst, G * C)
+            for d in range(n_in):  # one partial per incoming edge type: its 96 aggregate columns and its two scalars
+                cols = list(range(d * C, (d + 1) * C)) + [KM + 2 * d, KM + 2 * d + 1]
+                pre[d].copy_(torch.cat([agg[g][:, cols] @ w2[g][:, cols].t() for g in range(G)], 1))
+                raw = raw + pre[d]
+            F_dst = ws_t.size(0) - 1
+            z = raw + x_dst[:, :F_dst] @ ws_t[:F_dst] + ws_t[F_dst]
+            c = torch.sigmoid(z[:, :C]) * torch.tanh(z[:, C:2 * C])
+            c_out.copy_(c)
+            h_out.copy_(torch.sigmoid(z[:, 2 * C:]) * torch.tanh(c))
 
     @staticmethod
     def _aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates):
