@@ -58,7 +58,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) pea
 class EventTimedBackend:
     """Wraps the HIP backend so that the launches of the four heavy kernel families are bracketed by
     HIP events recorded on the launch stream: the decoder sweep (aggregate_kernel<4, true>, the
-    kernel graded against the HBM roofline), the encoder sweep (aggregate_enc_kernel<3>), the
+    kernel graded against the HBM roofline), the encoder cell (enc_cell_kernel; aggregate_enc_kernel<3> with
+    GGNN_ENC=split), the
     decoder projection (project_x6_kernel) and the decoder gate GEMM + LSTM (gates_x6_kernel<4, 0>).
     An event bracket also contains the dispatch/event overhead of the launch (3-6 us in eager mode),
     which rocprofv3's kernel durations do not.  It is calibrated right behind the launch on a kernel
@@ -101,6 +102,22 @@ class EventTimedBackend:
             n_units = int(sw[0].units.size(0))
             real += 80 * E + 4 * (n_dst + 1) + 32 * n_units + 4 * n_dst * G * 16 + 4 * n_dst * G * 98
         self._timed("enc_sweep", self.inner.aggregate_enc_batch, sweeps, (real, len(sweeps)))
+
+    def encoder_cell_batch(self, problems):
+        # (sweeps [(csr, einfo, wv_frag, u4_off, f_src)], p_dst, x_dst, ws_t, w2, w2_frag, pre, h_out, c_out)
+        cycles = 0.0
+        for sweeps, p_dst, *_ in problems:
+            n = p_dst.size(0)
+            n_t = (n + 15) // 16
+            for csr, _, _, _, f_src in sweeps:
+                deg = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+                nu = torch.clamp((deg + 2) // 3, min=1)
+                nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)  # units per (tile, lane group)
+                blocks = int(nu.max(1).values.sum())
+                # per gate: fp32 MFMAs of 32 cycles per block (4 score + 6 per value k-step), per tile 108 bf16
+                # MFMAs of 16 cycles + 6 fp32 ones for the rank-1 columns
+                cycles += 3 * (blocks * (4 + 6 * (3 if f_src > 8 else 2)) * 32 + n_t * (108 * 16 + 6 * 32))
+        self._timed("enc_cell", self.inner.encoder_cell_batch, problems, (cycles, len(problems)))
 
     def project_batch(self, problems):
         if problems[0][2] is None:  # encoder (K <= 12): store-bound, not a GEMM worth grading
@@ -163,6 +180,16 @@ def measure_roofline(ro, n_steps):
                "bytes": "what the kernel as built must move, per sweep: 80 E (edge records) + 4 (n_dst + 1) + 32 "
                         "n_units (unit table) + 64 G n_dst (score tails) + 392 G n_dst (rows written); the "
                         "SURVEY 8(d) formula does not apply (no K / V / Q rows exist)"}
+    c = timed.summary("enc_cell")
+    if c:  # the fused encoder cell: matrix-pipe cycles as launched against the chip's 1024 SIMDs at 2.4 GHz
+        busy = c["work"] / (1024 * 2400.0 * c["avg_us"])
+        enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (+ enc_lstm_kernel, in the same bracket)",
+               "achieved": round(busy * FP32_MFMA_PEAK_TFLOPS, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(busy, 4), "avg_launch_us": round(c["avg_us"], 2), "problems_per_launch": c["per_launch"],
+               "mfma_cycles_per_launch": int(c["work"]),
+               "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, bf16 MFMAs of the "
+                       "gate GEMM at 16) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
+                       "kernel is bound by instruction issue (profiles/README.md)"}
     for key, name in (("dec_project", "ggnn::project_x6_kernel (decoder projection, both node types of a model)"),
                       ("dec_gates", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, live node types of a model)")):
         g = timed.summary(key)
@@ -482,7 +509,7 @@ def main():
                                       "stopped": ev_state["stopped"]}}
                           if args.events else {})},
             "roofline": roof,
-            "roofline_encoder_sweep": roof_enc,
+            "roofline_encoder_cell": roof_enc,
             "roofline_gemm": roof_gemm,
         }
         if not args.no_cpu_baseline and not args.profile and args.workload == "cfg3" and world == 1:  # N = 1 only: a reported baseline

@@ -316,6 +316,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     // (a block past the end -- only the second of a pair can be one -- has real operands, no edges and
     // neither first nor last: it changes nothing)
     f32x4 sc[2], v[2][6];
+    float ae[2][3];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float* __restrict__ sa = reinterpret_cast<const float*>(sl + j * EC_SLOT) + 4 * c + q;
@@ -324,12 +325,11 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
 #pragma unroll
       for (int s = 0; s < 4; ++s) a[s] = sa[64 * s];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bs[s] = sb[4 * s];
-      if (ra != 0) {  // score columns 4 u + 1, 4 u + 2: unused; 4 u + 3: picks a_e = x4[13] (k-step 3, k = 12 + q)
+      for (int s = 0; s < 4; ++s) bs[s] = sb[4 * s];  // (score columns other than 4 u: never read)
+      // a_e = x4[13] of the three edges of unit q: piece 3 of records 4 q + r (group-uniform reads)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bs[s] = (ra == 3 && s == 3 && q == 1) ? 1.0f : 0.0f;
-      }
-      // scores: D[edge 4 q + r][column c]; lane c = 4 q holds unit q's scores, lane 4 q + 3 its a_e
+      for (int r = 0; r < 3; ++r) ae[j][r] = reinterpret_cast<const float*>(sl + j * EC_SLOT)[4 * (48 + 4 * q + r) + 1];
+      // scores: D[edge 4 q + r][column c]; lane c = 4 q holds unit q's scores
       sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) sc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bs[s], sc[j], 0, 0, 0);
@@ -357,7 +357,6 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
 #pragma unroll
         for (int t = 0; t < 6; ++t) acc[t] = 0.f;
       }
-      const float ae0 = ec_quad_lane3(sc[j][0]), ae1 = ec_quad_lane3(sc[j][1]), ae2 = ec_quad_lane3(sc[j][2]);
       const float s0 = nact > 0 ? sc[j][0] : -INFINITY, s1 = nact > 1 ? sc[j][1] : -INFINITY,
                   s2 = nact > 2 ? sc[j][2] : -INFINITY;
       const float mnew = fmaxf(fmaxf(mx, s0), fmaxf(s1, s2));
@@ -368,7 +367,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
       if (any) mx = mnew;
       const float scale = ec_bperm(src_sm, scale_l), p0 = ec_bperm(src_sm, p0_l), p1 = ec_bperm(src_sm, p1_l),
                   p2 = ec_bperm(src_sm, p2_l);
-      const float e0 = ec_bperm(src_sm, ae0), e1 = ec_bperm(src_sm, ae1), e2 = ec_bperm(src_sm, ae2);
+      const float e0 = ae[j][0], e1 = ae[j][1], e2 = ae[j][2];
       den = den * scale + (p0 + p1 + p2);
       sae = sae * scale + (p0 * e0 + p1 * e1 + p2 * e2);
       // relu, alpha-weighted sum
@@ -443,38 +442,42 @@ __global__ __launch_bounds__(256) void enc_lstm_kernel(const EncLstmBatch B) {
   const int F = A.f_dst;
   for (int t = threadIdx.x; t < (F + 1) * EC_G * C; t += 256) s_w[t] = A.ws_t[t];
   __syncthreads();
-  const int64_t t = (int64_t)((int)blockIdx.x - B.blk_off[k]) * 256 + threadIdx.x;
-  const int64_t node = t / 24;
-  const int c4 = (int)(t - node * 24);
-  if (node >= A.n_dst) return;
-  const float* __restrict__ pr = A.pre + node * (EC_G * C) + 4 * c4;
+  // a workgroup keeps the weights for a whole range of nodes: (node, 4-channel) quads, 256 per pass
+  const int nblk = B.blk_off[k + 1] - B.blk_off[k], blk = (int)blockIdx.x - B.blk_off[k];
+  const int64_t n_q = A.n_dst * 24, per = (n_q + nblk - 1) / nblk;
+  const int64_t q_hi = min(n_q, (int64_t)(blk + 1) * per);
   const int64_t part = A.n_dst * (int64_t)(EC_G * C);  // one partial per incoming edge type (HeteroConv sums them)
-  f32x4 p[EC_G];
-#pragma unroll
-  for (int g = 0; g < EC_G; ++g) {
-    p[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + g * C)) +
-           *reinterpret_cast<const f32x4*>(&s_w[F * EC_G * C + g * C + 4 * c4]);
-    if (A.n_in == 2) p[g] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + part + g * C));
-  }
-  const float* __restrict__ x = A.x_dst + node * A.ldx;
-  for (int f = 0; f < F; ++f) {
-    const float xv = x[f];
+  for (int64_t t = (int64_t)blk * per + threadIdx.x; t < q_hi; t += 256) {
+    const int64_t node = t / 24;
+    const int c4 = (int)(t - node * 24);
+    const float* __restrict__ pr = A.pre + node * (EC_G * C) + 4 * c4;
+    f32x4 p[EC_G];
 #pragma unroll
     for (int g = 0; g < EC_G; ++g) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv, w[r], p[g][r]);
+      p[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + g * C)) +
+             *reinterpret_cast<const f32x4*>(&s_w[F * EC_G * C + g * C + 4 * c4]);
+      if (A.n_in == 2) p[g] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + part + g * C));
     }
-  }
-  f32x4 hn, cn;
+    const float* __restrict__ x = A.x_dst + node * A.ldx;
+    for (int f = 0; f < F; ++f) {
+      const float xv = x[f];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float cv = sigmoidf_(p[0][r]) * tanhf_(p[1][r]);
-    cn[r] = cv;
-    hn[r] = sigmoidf_(p[2][r]) * tanhf_(cv);
+      for (int g = 0; g < EC_G; ++g) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv, w[r], p[g][r]);
+      }
+    }
+    f32x4 hn, cn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float cv = sigmoidf_(p[0][r]) * tanhf_(p[1][r]);
+      cn[r] = cv;
+      hn[r] = sigmoidf_(p[2][r]) * tanhf_(cv);
+    }
+    *reinterpret_cast<f32x4*>(A.c_out + node * C + 4 * c4) = cn;
+    *reinterpret_cast<f32x4*>(A.h_out + node * C + 4 * c4) = hn;
   }
-  *reinterpret_cast<f32x4*>(A.c_out + node * C + 4 * c4) = cn;
-  *reinterpret_cast<f32x4*>(A.h_out + node * C + 4 * c4) = hn;
 }
 
 }  // namespace ggnn
@@ -485,7 +488,7 @@ extern "C" int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_pro
   EncCellBatch B;
   EncLstmBatch L;
   L.n = n_problems;
-  double cost[EC_MAX_COMBOS];   // matrix-core cycles of one (problem, edge type) sweep + GEMM, per gate
+  double cost[EC_MAX_COMBOS];   // relative time of one (problem, edge type) sweep + GEMM, per gate
   int64_t n_t[EC_MAX_COMBOS];
   int kd[EC_MAX_COMBOS];
   int n_kd = 0;
@@ -507,9 +510,11 @@ extern "C" int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_pro
         return GGNN_EINVAL;
       if ((Sw.E + GGNN_UNIT_EDGES + 1) * GGNN_EINFO_ROW >= INT32_MAX) return GGNN_EINVAL;
       n_t[n_kd] = (A.n_dst + 15) / 16;
-      // blocks of four units x (4 score + 6 x k-steps value) fp32 MFMAs of 32 cycles, + the bf16 MFMAs of 16
-      cost[n_kd] = (double)(A.n_dst + Sw.E / GGNN_UNIT_EDGES) / 4.0 * (4 + 6 * (Sw.f_src > 8 ? 3 : 2)) * 32.0 +
-                   (double)n_t[n_kd] * (3 * 36 * 16 + 6 * 32);
+      // time of the combination in units of one sweep block (four units; measured: the loop is bound by
+      // instruction issue, a third k-step adds ~12 %, a tile's GEMM costs ~1.6 blocks); a row has
+      // max(1, ceil(deg / 3)) units: ~ max(n_dst, E / 3) for the degrees of a grain structure
+      cost[n_kd] = (double)std::max<int64_t>(A.n_dst, Sw.E / GGNN_UNIT_EDGES) / 4.0 * (Sw.f_src > 8 ? 1.12 : 1.0) +
+                   (double)n_t[n_kd] * 1.6;
       total += EC_G * cost[n_kd];
       kd[n_kd++] = k | (e << 2);
     }
@@ -538,9 +543,18 @@ extern "C" int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_pro
     B.combo[j] = jj < n_kd ? (kd[jj] | (g << 3)) : 0;
     B.wg_off[j + 1] = B.wg_off[j] + (jj < n_kd ? nwg[jj] : 0);
   }
+  // LSTM launch: at most eight workgroups per compute unit in all, dealt by node count, 256 quads per pass
+  int64_t quads = 0;
+  for (int k = 0; k < n_problems; ++k) quads += B.a[k].n_dst * 24;
   L.blk_off[0] = 0;
-  for (int k = 0; k < EC_MAX_PROBLEMS; ++k)
-    L.blk_off[k + 1] = L.blk_off[k] + (k < n_problems ? (int)((B.a[k].n_dst * 24 + 255) / 256) : 0);
+  for (int k = 0; k < EC_MAX_PROBLEMS; ++k) {
+    int64_t nb = 0;
+    if (k < n_problems) {
+      const int64_t full = (B.a[k].n_dst * 24 + 255) / 256;
+      nb = std::max<int64_t>(1, std::min<int64_t>(full, (int64_t)8 * ncu * (B.a[k].n_dst * 24) / quads));
+    }
+    L.blk_off[k + 1] = L.blk_off[k] + (int)nb;
+  }
   hipLaunchKernelGGL(enc_cell_kernel, dim3((unsigned)B.wg_off[EC_MAX_COMBOS]), dim3(EC_WAVES * 64), 0,
                      (hipStream_t)stream, B);
   hipLaunchKernelGGL(enc_lstm_kernel, dim3((unsigned)L.blk_off[EC_MAX_PROBLEMS]), dim3(256), 0, (hipStream_t)stream, L);

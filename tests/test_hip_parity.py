@@ -874,7 +874,7 @@ def test_encoder_sweep_on_matrix_cores_equals_the_gathering_sweep(n_src, n_dst, 
     assert torch.equal(got, again)                                  # no atomics: bit-reproducible
 
 
-def _enc_cell_problem(be, rs, n_dst, ins, hub=0):
+def _enc_cell_problem(be, rs, n_dst, ins, hub=0, regular=False):
     """Random encoder-cell problem: destination type with 8 features, `ins` = [(n_src, F_src, E)] incoming
     edge types.  Returns the fused-call tuple, the split-path tuples and the emulator inputs."""
     from graingraphnn_amd.packing import bf16_planes, gate_fragments, value_fragments, value_fragments_bias
@@ -896,6 +896,8 @@ def _enc_cell_problem(be, rs, n_dst, ins, hub=0):
         src = rs.randint(0, max(n_src - 5, 1), size=E)
         dst = rs.randint(1 if n_dst > 1 else 0, n_dst, size=E)     # destination 0 has no in-edge
         dst[:hub] = min(7, n_dst - 1)
+        if regular:                                                 # every destination the same in-degree (timing tools)
+            dst = rs.permutation(np.repeat(np.arange(n_dst), E // n_dst))
         ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
         xs = torch.from_numpy(rs.uniform(0, 1, (n_src, F)).astype(np.float32)).to(DEV)
         ea = torch.from_numpy(rs.uniform(0.01, 0.1, E).astype(np.float32)).to(DEV)

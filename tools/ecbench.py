@@ -34,7 +34,7 @@ J = (20000, [(10000, 11, 60000), (20000, 8, 60000)])
 Gr = (10000, [(20000, 8, 60000)])
 for name, shapes in (("joint", [J]), ("grain", [Gr]), ("one model (joint + grain)", [J, Gr]),
                      ("R + C (2 x joint + grain)", [J, Gr, J, Gr])):
-    probs = [_enc_cell_problem(be, rs, n, ins) for n, ins in shapes]
+    probs = [_enc_cell_problem(be, rs, n, ins, regular=True) for n, ins in shapes]
     fused = [p[0] for p in probs]
     sweeps = [s for p in probs for s in p[1]]
     gates = [p[2] for p in probs]

@@ -18,8 +18,8 @@ lib = ctypes.CDLL(_lib.LIB_PATH)
 rs = np.random.RandomState(0)
 J = (20000, [(10000, 11, 60000), (20000, 8, 60000)])
 Gr = (10000, [(20000, 8, 60000)])
-for name, shapes in (("joint", [J]), ("R + C", [J, Gr, J, Gr])):
-    probs = [_enc_cell_problem(be, rs, n, ins)[0] for n, ins in shapes]
+for name, shapes in (("one model", [J, Gr]), ("R + C", [J, Gr, J, Gr])):
+    probs = [_enc_cell_problem(be, rs, n, ins, regular=True)[0] for n, ins in shapes]
     for _ in range(3):
         torch.cuda.synchronize()
         assert lib.ggnn_debug_stamps_clear_enc() == 0
@@ -39,6 +39,12 @@ for name, shapes in (("joint", [J]), ("R + C", [J, Gr, J, Gr])):
         r = us(st[:, i])
         print(f"  {nm:16s} med {np.median(r):7.2f}  max {r.max():7.2f} us")
     print(f"  steps per wave   med {np.median(st[:, 8]):.0f} max {st[:, 8].max()}   tiles per wave med {np.median(st[:, 9]):.0f} max {st[:, 9].max()}")
+    # end time per workgroup, grouped in runs of equal step counts (= combinations, in launch order)
+    wg_end = us(st[:, 16] - t0).reshape(-1, 8).max(1)
+    wg_steps = st[:, 8].reshape(-1, 8).sum(1)
+    print("  workgroup end times (us), 16 per row:")
+    for i in range(0, len(wg_end), 16):
+        print("   ", " ".join(f"{v:5.1f}" for v in wg_end[i:i + 16]), " | steps", wg_steps[i])
     n = np.maximum(st[:, 8], 1)
     print(f"  per step: wait {np.median(us(st[:, 4]) / n):.3f}  compute {np.median(us(st[:, 5]) / n):.3f}  issue {np.median(us(st[:, 6]) / n):.3f} us;"
           f"  per tile gemm {np.median(us(st[:, 7]) / np.maximum(st[:, 9], 1)):.3f} us")
