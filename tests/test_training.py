@@ -414,3 +414,41 @@ def test_sweep_backward_full_size_properties():
             # ds = alpha (dalpha - S) cancels 96-term sums of size ~5 down to ~1e-3 here: fp32 leaves
             # a few 1e-6 absolute (as it does in the reference's own fp32 autograd)
             assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 5e-6, (i, g)
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_follows_the_eager_step():
+    """training.GraphedTrainStep (forward, loss, backward, Adam replayed from one hipGraph) against the same
+    steps run eagerly on a second copy of the model: losses and parameters agree (same kernels, same
+    order: bit for bit), also with new targets copied into the captured buffers."""
+    import copy
+    from graingraphnn_amd import training
+    x, ei, ea = load_graph("40")
+    dev = "cuda"
+    A, _ = product_models(4, 1.0, dev)
+    B = copy.deepcopy(A)
+    X, EI, EA = tt(x, dev), tt(ei, dev), tt(ea, dev)
+    rs = np.random.RandomState(9)
+    Ys = [{nt: torch.from_numpy(rs.uniform(-1, 1, (x[nt].shape[0], 2)).astype(np.float32)).to(dev) for nt in x}
+          for _ in range(2)]
+    mask = {nt: torch.ones(x[nt].shape[0], 1, device=dev) for nt in x}
+    loss_fn = lambda pred, y: training.regressor_loss(y, pred, mask)
+    optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True)
+    optB = torch.optim.Adam(B.parameters(), lr=1e-3, capturable=True)
+    step = training.GraphedTrainStep(A, optA, loss_fn, X, EI, EA, Ys[0], warmup=3)
+    B.train()
+
+    def eager(y):
+        loss = loss_fn(B(X, EI, EA), y)
+        optB.zero_grad(set_to_none=False)
+        loss.backward()
+        optB.step()
+        return loss
+    for _ in range(3):                      # the warm-up steps updated A (the capture only records)
+        eager(Ys[0])
+    for k in range(4):
+        y = Ys[k % 2]
+        la, lb = step(X, EA, y), eager(y)
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (k, float(la), float(lb))
+    for (n, pa), (_, pb) in zip(A.named_parameters(), B.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), n
