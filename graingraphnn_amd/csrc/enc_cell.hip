@@ -22,7 +22,7 @@
 //     of EC_U slots, requested EC_U blocks ahead of their use ACROSS tile boundaries -- a wave alone on
 //     its SIMD has nobody to hide a memory round trip behind, registers are not held while the loads
 //     fly, and the ring is the only vector-memory traffic of the loop besides the output stores, so
-//     its completion is one counted s_waitcnt vmcnt(3 (EC_U - 1)) per block; a group of 16 lanes walks
+//     its completion is one counted s_waitcnt vmcnt per pair of blocks; a group of 16 lanes walks
 //     FOUR CONSECUTIVE rows of the tile, cutting them into units of <= 3 edges arithmetically from the
 //     17 rowptr entries of the tile, which arrive by LDS-DMA as well (a header ring, fetched EC_HMAX
 //     tiles ahead): no scalar load and no register-destination load in the loop (a scalar load would
@@ -53,7 +53,7 @@ constexpr int EC_HSLOT = 80;                 // 17 rowptr entries
 constexpr int EC_WAVE_LDS = 16 * EC_S * 4 + EC_U * EC_SLOT + EC_HR * EC_HSLOT;  // 6 656 + 5 248 + 640
 constexpr int EC_LDS_BYTES = EC_PLANES + EC_WAVES * EC_WAVE_LDS;  // 155 648
 static_assert(EC_LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(3 * (EC_U - 1) < 64, "vmcnt is a 6-bit counter");
+static_assert(2 * (EC_U - 2) < 64 && 2 * EC_HMAX > 2 * (EC_U - 2) + 4, "vmcnt is a 6-bit counter; headers land in time");
 static_assert(EC_HMAX >= EC_U && EC_HMAX < EC_HR, "a header must be requested a ring length ahead of its use");
 
 struct EncCellBatch {
@@ -132,6 +132,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   const int32_t* __restrict__ rowptr = Sw.rowptr;
   const float* __restrict__ einfo = Sw.einfo;
   const float* __restrict__ tails = A.p_dst + Sw.u4_off + 16 * g;
+  const int ldp32 = (int)A.ldp;            // n_dst * ldp < 2^31 (checked by the host)
   float* __restrict__ pre = A.pre + (int64_t)d * n_dst * (EC_G * C) + g * C;
   const int src_grp = (16 * qa) * 4;       // byte address of a lane of group qa (ds_bpermute)
 
@@ -220,13 +221,13 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer), piece q
     ec_dma16(einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + 4 * q, base);
     // score tail of unit q's row, element c
-    ec_dma4(tails + (int64_t)i_q * A.ldp + c, base + 1024);
+    ec_dma4(tails + (uint32_t)(i_q * ldp32 + c), base + 1024);
     int* __restrict__ cw = reinterpret_cast<int*>(ring + slot * EC_SLOT + 1280);
     if (c == 0) cw[q] = word;
     if (lane == 0) cw[4] = meta;
-    // one header per block keeps the DMA count per block fixed; at the look-ahead limit the newest is re-fetched
-    if (h_idx - f_idx < EC_HMAX) ++h_idx;
-    hdr_issue(h_idx - 1);
+    // headers are requested as the cursor moves on (one per tile in the steady state): the loop's counted
+    // wait assumes none in its window, so a recent one only makes it wait for one DMA more than needed
+    if (h_idx - f_idx < EC_HMAX) hdr_issue(h_idx++);
     // advance
     const bool row_done = alive && f_j + 1 == nuk;
     f_j = row_done ? 0 : f_j + (alive ? 1 : 0);
@@ -302,7 +303,9 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   static_assert(EC_U % 2 == 0, "two blocks per iteration");
   for (int slot = 0;; slot = slot + 2 == EC_U ? 0 : slot + 2) {
     const unsigned long long st0 = GGNN_STAMP_NOW();
-    ec_dma_wait<3 * (EC_U - 2)>();  // everything but the DMAs of the EC_U - 2 blocks issued after these two
+    // everything but the two DMAs of each of the EC_U - 2 blocks issued after these two (a header DMA issued
+    // EC_HMAX tiles ahead of its use has >= 2 EC_HMAX younger DMAs by then: complete as well)
+    ec_dma_wait<2 * (EC_U - 2)>();
     const unsigned long long st1 = GGNN_STAMP_NOW();
     const unsigned char* __restrict__ sl = ring + slot * EC_SLOT;
     int my[2], meta[2];
@@ -459,13 +462,18 @@ __global__ __launch_bounds__(256) void enc_lstm_kernel(const EncLstmBatch B) {
       if (A.n_in == 2) p[g] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + part + g * C));
     }
     const float* __restrict__ x = A.x_dst + node * A.ldx;
-    for (int f = 0; f < F; ++f) {
-      const float xv = x[f];
+    float xv[EL_MAXF];  // all features requested at once (clamped index: no load under a branch)
 #pragma unroll
-      for (int g = 0; g < EC_G; ++g) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
+    for (int f = 0; f < EL_MAXF; ++f) xv[f] = x[min(f, F - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv, w[r], p[g][r]);
+    for (int f = 0; f < EL_MAXF; ++f) {
+      if (f < F) {
+#pragma unroll
+        for (int g = 0; g < EC_G; ++g) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv[f], w[r], p[g][r]);
+        }
       }
     }
     f32x4 hn, cn;
