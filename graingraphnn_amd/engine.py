@@ -106,12 +106,15 @@ def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
     return einfo
 
 
-def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo: Dict[ET, torch.Tensor]):
+def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo: Dict[ET, torch.Tensor],
+              after_projection=None, after_sweeps=None):
     """One HeteroPGCLSTM.forward for every entry of `cells` -- (pc, h_in, c_in, proj, agg, h_out,
     c_out), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
     launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
-    Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros)."""
+    Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros).  `after_projection`: called right behind the
+    projection launch -- for a decoder cell the last launch of the forward that reads x -- and `after_sweeps`
+    behind the last launch that reads the edge records (a caller may record stream events there)."""
     projs, sweeps, enc_sweeps, gates, enc_cells = [], [], [], [], []
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
@@ -141,12 +144,16 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                            lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
         gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
     backend.project_batch(projs)
+    if after_projection is not None:
+        after_projection()
     if enc_cells:
         backend.encoder_cell_batch(enc_cells)
     if enc_sweeps:
         backend.aggregate_enc_batch(enc_sweeps)
     if sweeps:
         backend.aggregate_batch(sweeps)
+    if after_sweeps is not None:
+        after_sweeps()
     if gates:
         backend.lstm_epilogue_batch(gates)
 
@@ -177,22 +184,24 @@ def gate_problems(pc: PackedCell, proj, agg, c_in, h_out, c_out):
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,
                         x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor],
-                        einfo: Optional[Dict[ET, torch.Tensor]] = None):
+                        einfo: Optional[Dict[ET, torch.Tensor]] = None, x_read=None, einfo_read=None):
     """models.py:422-426 / 581-585: encoder from zero state, decoder from the encoder's (h, c),
     both on the same x_dict.  `einfo` (from prepare_edges) may be shared by several models that
     see the same x / edge_attr; when absent it is computed here.  Returns the decoder's (h, c)."""
     if einfo is None:
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
         einfo = ws.einfo = prepare_edges(backend, graph, x, ea, ws.einfo)
-    run_encoder_decoder_multi(backend, [(enc, dec, ws)], graph, x, einfo)
+    run_encoder_decoder_multi(backend, [(enc, dec, ws)], graph, x, einfo, x_read, einfo_read)
     return ws.h2, ws.c2
 
 
 def run_encoder_decoder_multi(backend, models, graph: GraphCSR, x: Dict[str, torch.Tensor],
-                              einfo: Dict[ET, torch.Tensor]):
+                              einfo: Dict[ET, torch.Tensor], x_read=None, einfo_read=None):
     """The encoder cells of all `models` = [(enc, dec, workspace), ...] in three launches, then
     their decoder cells in three more (every model keeps its own weights, workspace and state)."""
     run_cells(backend, [(enc, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1) for enc, _, ws in models],
               graph, x, einfo)
+    # (x_read / einfo_read: called once the last launch that reads x -- the decoder projection -- / the edge
+    # records -- the decoder sweeps -- is enqueued)
     run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2) for _, dec, ws in models],
-              graph, x, einfo)
+              graph, x, einfo, after_projection=x_read, after_sweeps=einfo_read)

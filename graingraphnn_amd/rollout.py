@@ -11,6 +11,7 @@ The whole step is 13 kernel launches (the regressor and the classifier share eve
 their cells) with no host synchronisation and no allocation, so it can be replayed from a hipGraph
 (`use_graph=True`) to remove launch overhead on small graphs.
 """
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -87,8 +88,6 @@ class GrainRollout:
             self.domain_offset = domain_offset.to(dev, torch.float32).contiguous()
         self.steps_done = 0
         self.use_graph = use_graph
-        if use_graph:
-            self._graph_exec = self._capture()
 
     def _pack_weights(self):
         """Fused device weights of both models, and the parameter versions they were packed from."""
@@ -107,7 +106,7 @@ class GrainRollout:
         call it directly after changing the models between two step() calls."""
         if force or self._wver != (_param_version(self.rmodel), _param_version(self.cmodel)):
             self._pack_weights()
-            self._graph_exec = self._graph_multi = None
+            self._graphs = None
             self._graph_fwd = self._graph_ref = None
 
     def _set_topology(self, edge_index_dict, edge_attr_dict=None):
@@ -122,18 +121,96 @@ class GrainRollout:
                               for et in EDGE_TYPES}
         else:  # lengths are recomputed by the refresh that follows an event
             self.edge_attr = {et: torch.zeros(self.edge_index[et].size(1), device=dev) for et in EDGE_TYPES}
+        # second buffer of the pipelined step (_enqueue_step_pipelined): the refresh writes the lengths of step
+        # k + 1 while the classifier's head still reads those of step k
+        self._ea_other = {et: torch.empty_like(self.edge_attr[et]) for et in EDGE_TYPES}
+        self._einfo_fresh = False   # True: self.einfo already holds the records of the step to come
         E = self.graph.edge_index[ET_JJ].size(1)
         if not hasattr(self, "pred"):
             self.pred = {}
         self.pred["edge_event"] = torch.empty(E, dtype=torch.float32, device=dev)
         self.pred["edge"] = torch.empty(E, 2, dtype=torch.float32, device=dev)
         self.einfo = alloc_einfo(self.graph, dev)
-        self._graph_exec = self._graph_multi = None
+        self._graphs = None
+        self._seen = None
 
     # -- one step, enqueued on the current stream --------------------------------------
+    def _pipelined(self):
+        """Two streams, static topology: update, grain centres, edge refresh and the NEXT step's edge records
+        run on the regressor's stream beside the classifier's last kernels (_enqueue_step_pipelined)."""
+        return self._side is not None and not self.joint_launches and os.environ.get("GGNN_TAIL", "") != "join"
+
     def _enqueue_step(self):
-        self._enqueue_forward_update()
-        self._enqueue_refresh()
+        self._enqueue_steps(1)
+
+    def _enqueue_steps(self, n_steps: int):
+        if self._pipelined():
+            return self._enqueue_steps_pipelined(n_steps)
+        for _ in range(n_steps):
+            self._enqueue_forward_update()
+            self._enqueue_refresh()
+        self._einfo_fresh = False
+
+    def _enqueue_steps_pipelined(self, n_steps: int):
+        """`n_steps` static-topology steps on two streams with the small launches hidden and no join between
+        steps.  After both forwards only four small kernels remain -- Rmodel.update, grain centres, z clamp + edge
+        lengths, and the edge records of the next forward -- during which the chip is nearly idle (~34 us of a
+        ~530 us step at 10 000 grains, plus a join and a fork).  None of them needs the classifier's results: they
+        run on the regressor's stream, beside the classifier's gate GEMM and heads, and the regressor's next forward
+        follows them directly.  Cross-stream edges per step (each costs a few us inside a hipGraph, so there are
+        exactly two):
+          * regressor stream waits for the classifier's decoder sweeps of this step (event `swept`) before
+            Rmodel.update: by then the classifier has read x for the last time (its decoder projection) and the edge
+            records too, so x (update, centres, z clamp) and einfo (next step's records) may be overwritten;
+          * classifier stream waits for the regressor stream's edge records (event `ready`) before its next forward.
+        The refreshed edge lengths go to the OTHER edge_attr buffer: the classifier's head still reads this step's
+        (models.py:595-609); the buffers swap every step.  Needs self.einfo to hold the records of the first step
+        already (step() / run() see to that)."""
+        be, x, p = self.be, self.x, self.pred
+        einfo = self.einfo
+        # the regressor's chain stays on the current stream (it carries every step-to-step dependency), the
+        # classifier forks from it at the top of every step and is joined once, behind the last one
+        main = torch.cuda.current_stream()
+        st_c = self._side[1]
+        events = []  # kept alive until the streams are joined (and a capture has ended)
+        for _ in range(n_steps):
+            ea, ea_next = self.edge_attr, self._ea_other
+            swept = torch.cuda.Event()
+            events.append(swept)
+            st_c.wait_stream(main)   # x, einfo and edge_attr of this step are final on `main`
+            enc, dec = self.packed["R"]
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
+            be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
+                               p["joint"], p["grain"], p["grain_area"])
+            with torch.cuda.stream(st_c):
+                enc, dec = self.packed["C"]
+                h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo,
+                                           None, lambda: swept.record(st_c))
+                be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                                    self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+            main.wait_event(swept)
+            be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+            if self.refresh_centres:
+                be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
+                                 self.domain_factor, self.domain_offset)
+            be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
+                            [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea_next[et]) for et in EDGE_TYPES])
+            prepare_edges(be, self.graph, x, ea_next, einfo)
+            self.edge_attr, self._ea_other = ea_next, ea
+        main.wait_stream(st_c)
+        self._einfo_fresh = True
+        return events
+
+    def _ensure_edge_records(self):
+        """Before a pipelined step outside a capture: einfo must hold the records of the step to come.  They are
+        stale after construction, a topology change, an event-mode or single-stream step, and when the caller
+        wrote into x / edge_attr (in-place Python writes bump the tensors' version counters; the kernels do not)."""
+        seen = tuple(t._version for t in self.x.values()) + tuple(sorted(
+            t._version for t in (*self.edge_attr.values(), *self._ea_other.values())))
+        if not self._einfo_fresh or seen != self._seen:
+            prepare_edges(self.be, self.graph, self.x, self.edge_attr, self.einfo)
+            self._einfo_fresh = True
+        self._seen = seen
 
     def _enqueue_forward_update(self):
         """test.py:382-402: both forwards, Rmodel.update, z advance."""
@@ -148,9 +225,9 @@ class GrainRollout:
             be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
                                p["joint"], p["grain"], p["grain_area"])
 
-        def classifier():
+        def classifier(x_read=None):
             enc, dec = self.packed["C"]
-            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo)
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo, x_read)
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                 self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
 
@@ -165,13 +242,25 @@ class GrainRollout:
             regressor()
             classifier()
         else:
+            # Two streams.  Rmodel.update (and the grain centres) need the regressor's heads only, and they may
+            # overwrite x as soon as the classifier's last reader of x -- its decoder projection -- has run:
+            # they go on the regressor's stream behind that event and hide beside the classifier's sweep, gate
+            # GEMM and heads (the chip is otherwise nearly idle during these small launches).
             main = torch.cuda.current_stream()
-            for st, fn in zip(self._side, (regressor, classifier)):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    fn()
-            for st in self._side:
-                main.wait_stream(st)
+            st_r, st_c = self._side
+            x_free = torch.cuda.Event()
+            st_r.wait_stream(main)
+            st_c.wait_stream(main)
+            with torch.cuda.stream(st_r):
+                regressor()
+            with torch.cuda.stream(st_c):
+                classifier(lambda: x_free.record(st_c))
+            with torch.cuda.stream(st_r):
+                st_r.wait_event(x_free)
+                be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+            main.wait_stream(st_r)
+            main.wait_stream(st_c)
+            return
         be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
 
     def _enqueue_refresh(self):
@@ -185,17 +274,38 @@ class GrainRollout:
 
     def _capture(self, n_steps: int = 1):
         """Record `n_steps` steps into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm); the
-        kernels are launched through the C ABI on the capturing stream."""
+        kernels are launched through the C ABI on the capturing stream.  A pipelined step swaps the two
+        edge_attr buffers: a graph is only valid from the buffer it was captured on, so graphs are kept per
+        buffer (`_graphs[(n_steps, id of the current buffer)]`), and an odd number of steps leaves the other one
+        current after every replay."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        state = (self.edge_attr, self._ea_other, self._einfo_fresh)
         with torch.cuda.stream(s):
             # the capture records, it does not execute: x / edge_attr are left untouched
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                for _ in range(n_steps):
-                    self._enqueue_step()
+                keep = self._enqueue_steps(n_steps)   # (its stream events outlive the capture)
         torch.cuda.current_stream().wait_stream(s)
+        del keep
+        self.edge_attr, self._ea_other, self._einfo_fresh = state
         return g
+
+    def _replay(self, n_steps: int):
+        """`n_steps` steps from the hipGraph captured for this step count and the current edge_attr buffer."""
+        if self._graphs is None:
+            self._graphs = {}
+        key = (n_steps, self.edge_attr[ET_JJ].data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(n_steps)
+        g.replay()
+        if self._pipelined():
+            if n_steps % 2:
+                self.edge_attr, self._ea_other = self._ea_other, self.edge_attr
+            self._einfo_fresh = True
+        else:
+            self._einfo_fresh = False
 
     # -- event-driven mode (SURVEY 8f-2) ------------------------------------------------
     def enable_events(self, mask, area_threshold: float = 1e-4, edge_threshold: float = 0.6):
@@ -245,6 +355,7 @@ class GrainRollout:
         if not hasattr(self, "mask"):
             raise _lib.GGNNError("call enable_events(mask, ...) first")
         self.refresh_weights()
+        self._einfo_fresh = False   # this mode prepares its edge records at the start of every step
         self._run_segment("fwd")
         p = self.pred
         self.be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
@@ -304,10 +415,10 @@ class GrainRollout:
         """Advance one rollout step; returns the prediction dict (tensors are reused)."""
         if self.steps_done % 16 == 0:
             self.refresh_weights()
-        if self.use_graph and self._graph_exec is None:
-            self._graph_exec = self._capture()
-        if self._graph_exec is not None:
-            self._graph_exec.replay()
+        if self._pipelined():
+            self._ensure_edge_records()
+        if self.use_graph:
+            self._replay(1)
         else:
             self._enqueue_step()
         self.steps_done += 1
@@ -320,10 +431,10 @@ class GrainRollout:
         RUN_UNROLL consecutive steps (same kernels, same order, same results as step() x n)."""
         self.refresh_weights()
         if self.use_graph and n_steps >= self.RUN_UNROLL:
-            if self._graph_multi is None:
-                self._graph_multi = self._capture(self.RUN_UNROLL)
+            if self._pipelined():
+                self._ensure_edge_records()
             for _ in range(n_steps // self.RUN_UNROLL):
-                self._graph_multi.replay()
+                self._replay(self.RUN_UNROLL)
             self.steps_done += n_steps - n_steps % self.RUN_UNROLL
             n_steps %= self.RUN_UNROLL
         for _ in range(n_steps):
