@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
-    "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor",
+    "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
+    "ggnn_step_refresh_prepare",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -183,6 +184,13 @@ def _declare(lib):
     lib.ggnn_heads_regressor.restype = c_int
     lib.ggnn_heads_regressor.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.ggnn_heads_regressor_update.restype = c_int
+    lib.ggnn_heads_regressor_update.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                                c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_float, c_float, c_void_p, c_void_p]
+    lib.ggnn_step_refresh_prepare.restype = c_int
+    lib.ggnn_step_refresh_prepare.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p,
+                                              POINTER(PrepareEdge), c_int, c_void_p]
     lib.ggnn_heads_classifier.restype = c_int
     lib.ggnn_heads_classifier.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

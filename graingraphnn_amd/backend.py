@@ -298,6 +298,33 @@ class HipBackend:
                                             ptr(b), ptr(y_joint), ptr(y_grain), ptr(grain_area),
                                             _lib.current_stream()), "ggnn_heads_regressor")
 
+    def heads_regressor_update(self, h_joint, h_grain, x_joint, x_grain, w, b, y_joint, y_grain, grain_area, dz, zmax,
+                               flags):
+        """heads_regressor + step_update in one launch (ggnn_heads_regressor_update)."""
+        _require_cuda(h_joint, h_grain, x_joint, x_grain, w, b, y_joint, y_grain, grain_area, flags)
+        self._launch(self.lib.ggnn_heads_regressor_update, "ggnn_heads_regressor_update", ptr(h_joint), h_joint.size(0),
+                     ptr(h_grain), h_grain.size(0), ptr(x_joint), x_joint.stride(0), ptr(x_grain), x_grain.stride(0),
+                     x_grain.size(1), ptr(w), ptr(b), ptr(y_joint), ptr(y_grain), ptr(grain_area), dz, zmax,
+                     ptr(flags), _lib.current_stream())
+
+    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items):
+        """step_refresh + edge_prepare of the next forward in one launch (ggnn_step_refresh_prepare); items as
+        edge_prepare: (csr, edge_attr [E] COO order -- WRITTEN here --, x_src, x_dst, einfo_out)."""
+        _require_cuda(x_joint, x_grain, flags)
+        arr = (PrepareEdge * max(len(items), 1))()
+        for k, (csr, ea, xs, xd, einfo) in enumerate(items):
+            _require_cuda(csr.col, ea, xs, xd, einfo)
+            if einfo.size(0) < ea.numel() + _lib.GGNN_UNIT_EDGES or einfo.size(1) != _lib.GGNN_EINFO_ROW:
+                raise _lib.GGNNError("einfo must be [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
+            a = arr[k]
+            a.col, a.perm, a.row = csr.col.data_ptr(), csr.perm.data_ptr(), csr.row.data_ptr()
+            a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
+            a.einfo = einfo.data_ptr()
+            a.ldx_src, a.ldx_dst, a.E, a.f_src = xs.stride(0), xd.stride(0), ea.numel(), xs.size(1)
+        self._launch(self.lib.ggnn_step_refresh_prepare, "ggnn_step_refresh_prepare", ptr(x_joint), x_joint.size(0),
+                     x_joint.stride(0), ptr(x_grain), x_grain.size(0), x_grain.stride(0), zmax, ptr(flags), arr,
+                     len(items), _lib.current_stream())
+
     def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
                          edge_event, edge):
         _require_cuda(h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp, edge_event, edge)

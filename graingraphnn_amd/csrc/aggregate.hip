@@ -77,15 +77,20 @@ struct PrepareArgs {
   int n_et;
 };
 
-__global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) {
+// REFRESH = true: ggnn_step_refresh_prepare -- the record's edge length is not read from edge_attr but
+// recomputed from the xy offsets (the same w + rel the record holds: test.py:570-572) and ALSO written to
+// edge_attr[perm[p]]; the z offset uses the clamped z when flags[1] is set (the node part of the launch,
+// below, clamps x itself: test.py:405-407).
+template <bool REFRESH>
+__device__ __forceinline__ void edge_prepare_body(const PrepareArgs& P, int blk, float zmax, bool clamp) {
   // One thread builds one record (one gather of the source row, the destination xyz and the edge
   // length); the workgroup's 256 records are contiguous in memory and leave through LDS as 1 280
   // consecutive 16-byte pieces, so every store instruction covers 1 KB.
   __shared__ __attribute__((aligned(16))) float s_rec[256 * GGNN_EINFO_ROW];
   int k = 0;
-  while (k + 1 < P.n_et && (int)blockIdx.x >= P.b_off[k + 1]) ++k;
+  while (k + 1 < P.n_et && blk >= P.b_off[k + 1]) ++k;
   const ggnn_prepare_edge& T = P.et[k];
-  const int64_t p0 = (int64_t)((int)blockIdx.x - P.b_off[k]) * 256, p = p0 + threadIdx.x;
+  const int64_t p0 = (int64_t)(blk - P.b_off[k]) * 256, p = p0 + threadIdx.x;
   float rec[GGNN_EINFO_ROW];
 #pragma unroll
   for (int c = 0; c < GGNN_EINFO_ROW; ++c) rec[c] = 0.f;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
     const float* xd = T.x_dst + (int64_t)T.row[p] * T.ldx_dst;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float rel = xs[c] - xd[c];
+      const float rel = (REFRESH && clamp && c == 2) ? 0.f : xs[c] - xd[c];
       const float w = rel > 0.5f ? -1.0f : (rel < -0.5f ? 1.0f : 0.0f);
       rec[c] = rec[16 + c] = w + rel;  // periodGATconv.py:210
     }
@@ -103,7 +108,13 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
       if (c < T.f_src) rec[c] = xs[c];
     if (T.f_src <= 11) rec[11] = 1.0f;  // bias row of the encoder sweep's value product (aggregate_enc.hip)
     rec[12] = 1.0f;
-    rec[13] = rec[19] = T.edge_attr[T.perm[p]];
+    if (REFRESH) {
+      const float len = sqrtf(rec[0] * rec[0] + rec[1] * rec[1]);  // test.py:572
+      const_cast<float*>(T.edge_attr)[T.perm[p]] = len;
+      rec[13] = rec[19] = len;
+    } else {
+      rec[13] = rec[19] = T.edge_attr[T.perm[p]];
+    }
   }
   f32x4* mine = reinterpret_cast<f32x4*>(&s_rec[threadIdx.x * GGNN_EINFO_ROW]);
 #pragma unroll
@@ -117,6 +128,27 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
     const int i = threadIdx.x + c * 256;
     if (i < n_rec * (GGNN_EINFO_ROW / 4)) dst[i] = src[i];
   }
+}
+
+__global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) {
+  edge_prepare_body<false>(P, (int)blockIdx.x, 0.f, false);
+}
+
+// z clamp of every node (test.py:405-407) in the first workgroups, then refresh + records per edge
+__global__ __launch_bounds__(256) void refresh_prepare_kernel(const PrepareArgs P, float* __restrict__ x_joint,
+                                                              int64_t n_joint, int64_t ldxj, float* __restrict__ x_grain,
+                                                              int64_t n_grain, int64_t ldxg, float zmax,
+                                                              const int32_t* __restrict__ flags, int node_blocks) {
+  const bool clamp = flags[1] != 0;
+  if ((int)blockIdx.x < node_blocks) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (clamp && t < n_joint + n_grain) {
+      if (t < n_joint) x_joint[t * ldxj + 2] = zmax;
+      else x_grain[(t - n_joint) * ldxg + 2] = zmax;
+    }
+    return;
+  }
+  edge_prepare_body<true>(P, (int)blockIdx.x - node_blocks, zmax, clamp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -340,6 +372,38 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
     }
   }
   hipLaunchKernelGGL(edge_prepare_kernel, dim3((unsigned)P.b_off[n_edge_types]), dim3(256), 0, (hipStream_t)stream, P);
+  return launch_status();
+}
+
+extern "C" int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
+                                         int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
+                                         const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!x_joint || !x_grain || !flags || n_joint <= 0 || n_grain <= 0 || ldx_joint < 3 || ldx_grain < 3) return GGNN_EINVAL;
+  if (!edges || n_edge_types < 1 || n_edge_types > 3) return GGNN_EINVAL;
+  PrepareArgs P;
+  P.n_et = n_edge_types;
+  P.b_off[0] = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (k < n_edge_types) {
+      const ggnn_prepare_edge& T = edges[k];
+      if (T.E < 0 || T.ldx_src < 3 || T.ldx_dst < 3 || !T.einfo || !aligned16(T.einfo)) return GGNN_EINVAL;
+      if (T.f_src < 3 || T.f_src > 12 || T.ldx_src < T.f_src) return GGNN_EINVAL;
+      if (T.E > 0 && (!T.col || !T.perm || !T.row || !T.edge_attr || !T.x_src || !T.x_dst)) return GGNN_EINVAL;
+      const int64_t nb = (T.E + GGNN_UNIT_EDGES + 255) / 256;
+      if (P.b_off[k] + nb >= INT32_MAX) return GGNN_EINVAL;
+      P.et[k] = T;
+      P.b_off[k + 1] = P.b_off[k] + (int)nb;
+    } else {
+      P.et[k] = ggnn_prepare_edge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+      P.b_off[k + 1] = P.b_off[k];
+    }
+  }
+  const int64_t node_blocks = (n_joint + n_grain + 255) / 256;
+  if (node_blocks + P.b_off[n_edge_types] >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(refresh_prepare_kernel, dim3((unsigned)(node_blocks + P.b_off[n_edge_types])), dim3(256), 0,
+                     (hipStream_t)stream, P, x_joint, n_joint, ldx_joint, x_grain, n_grain, ldx_grain, zmax, flags,
+                     (int)node_blocks);
   return launch_status();
 }
 

@@ -291,7 +291,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   enter_tile();
   for (int r = 0; r < EC_U; ++r) issue(r);
   GGNN_STAMP(3);
-  unsigned long long st_wait = 0, st_comp = 0, st_issue = 0, st_gemm = 0, st_n = 0, st_t = 0;
+  [[maybe_unused]] unsigned long long st_wait = 0, st_comp = 0, st_issue = 0, st_gemm = 0, st_n = 0, st_t = 0;
 
   float mx = -INFINITY, den = 0.f, sae = 0.f;  // softmax state of the row group q is folding (mx: lane 4 q)
   float acc[6];
@@ -302,11 +302,11 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   // chain -- LDS round trips, dependent MFMAs --, not by the SIMD), only the softmax fold is sequential.
   static_assert(EC_U % 2 == 0, "two blocks per iteration");
   for (int slot = 0;; slot = slot + 2 == EC_U ? 0 : slot + 2) {
-    const unsigned long long st0 = GGNN_STAMP_NOW();
+    [[maybe_unused]] const unsigned long long st0 = GGNN_STAMP_NOW();
     // everything but the two DMAs of each of the EC_U - 2 blocks issued after these two (a header DMA issued
     // EC_HMAX tiles ahead of its use has >= 2 EC_HMAX younger DMAs by then: complete as well)
     ec_dma_wait<2 * (EC_U - 2)>();
-    const unsigned long long st1 = GGNN_STAMP_NOW();
+    [[maybe_unused]] const unsigned long long st1 = GGNN_STAMP_NOW();
     const unsigned char* __restrict__ sl = ring + slot * EC_SLOT;
     int my[2], meta[2];
 #pragma unroll
@@ -348,7 +348,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
         for (int t = 0; t < 6; ++t) v[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bw[t][2], v[j][t], 0, 0, 0);
       }
     }
-    const unsigned long long st2 = GGNN_STAMP_NOW();
+    [[maybe_unused]] const unsigned long long st2 = GGNN_STAMP_NOW();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row0 = meta[j] & 0x7FFFFF;
@@ -391,17 +391,17 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
         }
       }
       if ((meta[j] >> 28) & 1) {
-        const unsigned long long sg0 = GGNN_STAMP_NOW();
+        [[maybe_unused]] const unsigned long long sg0 = GGNN_STAMP_NOW();
         gemm(row0);
         st_gemm += GGNN_STAMP_NOW() - sg0;
         ++st_t;
       }
     }
     // ---- the two slots are free: blocks n + EC_U, n + EC_U + 1 take them over ----
-    const unsigned long long st3 = GGNN_STAMP_NOW();
+    [[maybe_unused]] const unsigned long long st3 = GGNN_STAMP_NOW();
     issue(slot);
     issue(slot + 1);
-    const unsigned long long st4 = GGNN_STAMP_NOW();
+    [[maybe_unused]] const unsigned long long st4 = GGNN_STAMP_NOW();
     st_wait += st1 - st0;
     st_comp += st3 - st1;
     st_issue += st4 - st3;

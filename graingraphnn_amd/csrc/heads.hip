@@ -52,6 +52,49 @@ __global__ __launch_bounds__(256) void heads_regressor_kernel(
   }
 }
 
+// The regressor's heads followed, for the same node, by GrainNN_regressor.update's periodic branch and the z
+// advance (step_update_kernel, step.hip): one launch instead of two behind the last gate GEMM of a step.
+__global__ __launch_bounds__(256) void heads_regressor_update_kernel(
+    const float* __restrict__ h_joint, int64_t n_joint, const float* __restrict__ h_grain, int64_t n_grain,
+    float* __restrict__ x_joint, int64_t ldxj, float* __restrict__ x_grain, int64_t ldxg, int f_grain,
+    const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y_joint,
+    float* __restrict__ y_grain, float* __restrict__ grain_area, float dz, float zmax, int32_t* __restrict__ flags) {
+  const int64_t node = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  if (node >= n_joint + n_grain) return;  // uniform per 16-lane group
+  float d[2];
+  if (node < n_joint) {
+    node_dots<2>(h_joint + node * C, w, l16, d);
+    if (l16 == 0) {
+      const float dx = tanhf_(d[0] + b[0]), dy = tanhf_(d[1] + b[1]);  // models.py:443
+      y_joint[2 * node] = dx;
+      y_joint[2 * node + 1] = dy;
+      float* x = x_joint + node * ldxj;
+      x[0] += dx / 5.0f;  // models.py:505 (scaling['joint'] = 5)
+      x[1] += dy / 5.0f;
+      x[2] += dz;         // test.py:402
+      x[6] = dx;          // models.py:510
+      x[7] = dy;
+    }
+  } else {
+    const int64_t g = node - n_joint;
+    node_dots<2>(h_grain + g * C, w + 2 * C, l16, d);
+    if (l16 == 0) {
+      float* x = x_grain + g * ldxg;
+      const float da = tanhf_(d[0] + b[2]), dv = fmaxf(d[1] + b[3], 0.f);
+      grain_area[g] = da / 20.0f + x[3];  // models.py:445, on the area the forward saw
+      y_grain[2 * g] = da;                // :450
+      y_grain[2 * g + 1] = dv;            // :452
+      const float z = x[2] + dz;          // test.py:401
+      x[2] = z;
+      x[3] += da / 20.0f;                 // models.py:506 (scaling['grain'] = 20)
+      x[4] = dv;                          // :507
+      x[f_grain - 1] = da;                // :511
+      if (g == 0) flags[1] = z > zmax ? 1 : 0;  // test.py:405
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void heads_classifier_node_kernel(
     const float* __restrict__ h_joint, int64_t n_joint, const float* __restrict__ w_node,
     float* __restrict__ node_tmp) {
@@ -104,6 +147,23 @@ extern "C" int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const
   hipLaunchKernelGGL(heads_regressor_kernel, dim3((unsigned)nblk), dim3(256), 0,
                      (hipStream_t)stream, h_joint, n_joint, h_grain, n_grain, x_grain, ldx_grain, w,
                      b, y_joint, y_grain, grain_area);
+  return launch_status();
+}
+
+extern "C" int ggnn_heads_regressor_update(const float* h_joint, int64_t n_joint, const float* h_grain,
+                                           int64_t n_grain, float* x_joint, int64_t ldx_joint, float* x_grain,
+                                           int64_t ldx_grain, int f_grain, const float* w, const float* b,
+                                           float* y_joint, float* y_grain, float* grain_area, float dz, float zmax,
+                                           int32_t* flags, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!h_joint || !h_grain || !x_joint || !x_grain || !w || !b || !y_joint || !y_grain || !grain_area || !flags)
+    return GGNN_EINVAL;
+  if (n_joint <= 0 || n_grain <= 0 || ldx_joint < 8 || f_grain < 6 || ldx_grain < f_grain) return GGNN_EINVAL;
+  const int64_t nblk = ((n_joint + n_grain) * 16 + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(heads_regressor_update_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     h_joint, n_joint, h_grain, n_grain, x_joint, ldx_joint, x_grain, ldx_grain, f_grain, w, b,
+                     y_joint, y_grain, grain_area, dz, zmax, flags);
   return launch_status();
 }
 

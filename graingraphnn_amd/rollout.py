@@ -179,9 +179,7 @@ class GrainRollout:
             events.append(swept)
             st_c.wait_stream(main)   # x, einfo and edge_attr of this step are final on `main`
             enc, dec = self.packed["R"]
-            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
-            be.heads_regressor(h["joint"], h["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
-                               p["joint"], p["grain"], p["grain_area"])
+            hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
             with torch.cuda.stream(st_c):
                 enc, dec = self.packed["C"]
                 h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo,
@@ -189,13 +187,27 @@ class GrainRollout:
                 be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                     self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
             main.wait_event(swept)
-            be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+            if os.environ.get("GGNN_GLUE", "") == "split":  # development: the four glue launches one by one
+                be.heads_regressor(hr["joint"], hr["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
+                                   p["joint"], p["grain"], p["grain_area"])
+                be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
+                if self.refresh_centres:
+                    be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
+                                     self.domain_factor, self.domain_offset)
+                be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
+                                [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea_next[et]) for et in EDGE_TYPES])
+                prepare_edges(be, self.graph, x, ea_next, einfo)
+                self.edge_attr, self._ea_other = ea_next, ea
+                continue
+            # heads + Rmodel.update in one launch; z clamp + edge lengths + next records in one launch
+            be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
+                                      p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
             if self.refresh_centres:
                 be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
                                  self.domain_factor, self.domain_offset)
-            be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
-                            [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea_next[et]) for et in EDGE_TYPES])
-            prepare_edges(be, self.graph, x, ea_next, einfo)
+            be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
+                                    [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo[et])
+                                     for et in EDGE_TYPES])
             self.edge_attr, self._ea_other = ea_next, ea
         main.wait_stream(st_c)
         self._einfo_fresh = True

@@ -347,6 +347,15 @@ int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const float* h_g
                          int64_t n_grain, const float* x_grain, int64_t ldx_grain,
                          const float* w, const float* b, float* y_joint, float* y_grain,
                          float* grain_area, ggnn_stream_t stream);
+/* ggnn_heads_regressor followed by ggnn_step_update (below) in ONE launch: the heads write y_joint / y_grain /
+ * grain_area (grain_area from the area the forward saw), then the same thread applies Rmodel.update and the z
+ * advance to its node.  For a rollout step in which nothing reads x after this point (GrainRollout's
+ * two-stream plan orders it behind the classifier's last reader of x). */
+int ggnn_heads_regressor_update(const float* h_joint, int64_t n_joint, const float* h_grain,
+                                int64_t n_grain, float* x_joint, int64_t ldx_joint, float* x_grain,
+                                int64_t ldx_grain, int f_grain, const float* w, const float* b,
+                                float* y_joint, float* y_grain, float* grain_area, float dz, float zmax,
+                                int32_t* flags, ggnn_stream_t stream);
 /* Classifier (models.py:595-609): pair = [h_j[src] | h_j[dst] | edge_attr];
  * edge_event = lin2(pair); edge = tanh(lin1(pair)).  Computed as per-node partial dots
  * (node_tmp [n_joint, 8] scratch) + a per-edge combine in the original COO order.
@@ -403,6 +412,14 @@ typedef struct ggnn_refresh_edge {
 int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
                       int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
                       const ggnn_refresh_edge* edges, int n_edge_types, ggnn_stream_t stream);
+
+/* ggnn_step_refresh + ggnn_edge_prepare of the NEXT forward in ONE launch: z clamp of every node when
+ * flags[1] is set, then per CSR slot the edge length from the min-image xy offsets (written to
+ * edge_attr[perm[p]], the COO order: edges[k].edge_attr is an OUTPUT here) and the einfo record with that
+ * length.  Same values as the two calls in sequence (the length is the same expression on the same operands). */
+int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
+                              int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
+                              const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
 
 /* Bytes of device scratch one model forward needs (projections + aggregates + h/c), so a
  * caller can size a single arena; the Python host allocates the same amounts as tensors. */

@@ -225,6 +225,23 @@ class TorchEmulatorBackend:
         y_grain[:, 0] = t0
         y_grain[:, 1] = torch.relu(yg[:, 1])
 
+    def heads_regressor_update(self, h_joint, h_grain, x_joint, x_grain, w, b, y_joint, y_grain, grain_area, dz, zmax,
+                               flags):
+        self.heads_regressor(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area)
+        self.step_update(x_joint, x_grain, y_joint, y_grain, dz, zmax, flags)
+
+    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items):
+        if int(flags[1]):
+            x_joint[:, 2] = zmax
+            x_grain[:, 2] = zmax
+        for csr, ea, xs, xd, einfo in items:
+            col, perm, row = csr.col.long(), csr.perm.long(), csr.row.long()
+            E = ea.numel()
+            rel = xs[col[:E], :2] - xd[row[:E], :2]
+            rel = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
+            ea[perm[:E]] = torch.sqrt(rel[:, 0] ** 2 + rel[:, 1] ** 2)
+        self.edge_prepare(items)
+
     def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
                          edge_event, edge):
         node_tmp[:, :6] = h_joint @ w_node.t()

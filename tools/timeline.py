@@ -5,7 +5,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""))
             for r in rows if "ggnn" in r["Kernel_Name"])
-ups = [i for i, e in enumerate(ev) if "step_update" in e[2]]
+ups = [i for i, e in enumerate(ev) if "step_update" in e[2] or "heads_regressor_update" in e[2]]
 a, b = ups[20], ups[28]
 win = ev[a:b]
 t0, t1 = win[0][0], win[-1][1]
