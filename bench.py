@@ -438,11 +438,18 @@ def main():
             return ro.step_events()
     for _ in range(args.warmup):
         step()
+    untimed_steps = args.warmup
     if not args.events:
         # steps per hipGraph (measured, cfg3, 20 / 500 timed steps: 4 -> 0.591 / 0.564 ms per step,
         # 10 -> 0.587 / 0.582, 20 -> 0.606 / 0.580)
         ro.RUN_UNROLL = max(1, min(args.steps, int(os.environ.get("GGNN_BENCH_UNROLL", "4"))))
-        ro.run(ro.RUN_UNROLL)  # untimed: captures the multi-step graph
+        # untimed: captures the multi-step graph and replays it a few times -- a freshly instantiated graph and a
+        # memory system that has seen 5 steps run the first replays ~4 % slower than the steady state the metric
+        # is about (measured with --steps 20: 1 872-1 889 steps/s without, 1 940-1 981 with a longer warm-up);
+        # reported as config.untimed_steps
+        settle = 1 + int(os.environ.get("GGNN_BENCH_SETTLE", "4"))
+        ro.run(ro.RUN_UNROLL * settle)
+        untimed_steps = args.warmup + ro.RUN_UNROLL * settle
     gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
     torch.cuda.synchronize()
     if world > 1:
@@ -500,7 +507,7 @@ def main():
                        "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
                                 "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
-                       "results_finite": finite,
+                       "results_finite": finite, "untimed_steps": untimed_steps,
                        "forward_only": {"steps_per_s_per_gpu": round(forward_only * (units_per_step // world), 2),
                                         "launch": "eager, R then C on one stream (no update / refresh)"},
                        **({"events": {"grains_eliminated": int(sum(len(e) for e in ro.grain_events)),

@@ -437,18 +437,18 @@ struct EncLstmBatch {
 };
 constexpr int EL_MAXF = 12;
 
-// No LDS and few registers on purpose: in the two-stream rollout this launch of one model runs beside the
-// other model's enc_cell_kernel, whose workgroups leave 8 KB of LDS per compute unit -- with its weights in
-// LDS (10-14 KB) it could not share a compute unit with them and waited for that kernel to finish.  The
-// 10-14 KB weight table is read through the vector cache instead (every thread of a launch reads the same
-// table: L1 hits).
+// (Tried: no LDS, the weight table through the vector cache, so that this launch of one model could share
+// compute units with the other model's enc_cell_kernel in the two-stream rollout, whose workgroups leave 8 KB of
+// LDS: 26.8 instead of 20.4 us alone, and no overlap gained -- the issue-bound encoder cell starves it anyway.)
 __global__ __launch_bounds__(256) void enc_lstm_kernel(const EncLstmBatch B) {
+  __shared__ __attribute__((aligned(16))) float s_w[(EL_MAXF + 1) * EC_G * C];  // [k][288] skip weights, then the bias row
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.blk_off[k + 1]) ++k;
   const ggnn_enc_cell_args& A = B.a[k];
   const int F = A.f_dst;
-  const float* __restrict__ ws = A.ws_t;   // [F + 1][288]: skip weights, then the bias row
-  // a workgroup handles a range of (node, 4-channel) quads, 256 per pass
+  for (int t = threadIdx.x; t < (F + 1) * EC_G * C; t += 256) s_w[t] = A.ws_t[t];
+  __syncthreads();
+  // a workgroup keeps the weights for a whole range of nodes: (node, 4-channel) quads, 256 per pass
   const int nblk = B.blk_off[k + 1] - B.blk_off[k], blk = (int)blockIdx.x - B.blk_off[k];
   const int64_t n_q = A.n_dst * 24, per = (n_q + nblk - 1) / nblk;
   const int64_t q_hi = min(n_q, (int64_t)(blk + 1) * per);
@@ -457,23 +457,23 @@ __global__ __launch_bounds__(256) void enc_lstm_kernel(const EncLstmBatch B) {
     const int64_t node = t / 24;
     const int c4 = (int)(t - node * 24);
     const float* __restrict__ pr = A.pre + node * (EC_G * C) + 4 * c4;
-    const float* __restrict__ x = A.x_dst + node * A.ldx;
-    float xv[EL_MAXF];  // all features requested at once (clamped index: no load under a branch)
-#pragma unroll
-    for (int f = 0; f < EL_MAXF; ++f) xv[f] = x[min(f, F - 1)];
     f32x4 p[EC_G];
 #pragma unroll
     for (int g = 0; g < EC_G; ++g) {
       p[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + g * C)) +
-             *reinterpret_cast<const f32x4*>(ws + F * EC_G * C + g * C + 4 * c4);
+             *reinterpret_cast<const f32x4*>(&s_w[F * EC_G * C + g * C + 4 * c4]);
       if (A.n_in == 2) p[g] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + part + g * C));
     }
+    const float* __restrict__ x = A.x_dst + node * A.ldx;
+    float xv[EL_MAXF];  // all features requested at once (clamped index: no load under a branch)
+#pragma unroll
+    for (int f = 0; f < EL_MAXF; ++f) xv[f] = x[min(f, F - 1)];
 #pragma unroll
     for (int f = 0; f < EL_MAXF; ++f) {
       if (f < F) {
 #pragma unroll
         for (int g = 0; g < EC_G; ++g) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(ws + f * EC_G * C + g * C + 4 * c4);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv[f], w[r], p[g][r]);
         }
