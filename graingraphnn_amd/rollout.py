@@ -78,6 +78,9 @@ class GrainRollout:
             joint_launches = self.n_nodes["joint"] < self.JOINT_LAUNCH_MAX_JOINTS
         self.joint_launches = joint_launches
         self.concurrent = concurrent and not joint_launches
+        # GGNN_TAIL=join (development, A/B runs): the plain two-stream plan -- update, centres, refresh and edge
+        # records behind a join of both streams -- instead of the pipelined one
+        self.pipeline_tail = os.environ.get("GGNN_TAIL", "") != "join"
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.concurrent else None
         self.refresh_centres = refresh_centres
         self.domain_factor = float(domain_factor)
@@ -138,7 +141,7 @@ class GrainRollout:
     def _pipelined(self):
         """Two streams, static topology: update, grain centres, edge refresh and the NEXT step's edge records
         run on the regressor's stream beside the classifier's last kernels (_enqueue_step_pipelined)."""
-        return self._side is not None and not self.joint_launches and os.environ.get("GGNN_TAIL", "") != "join"
+        return self._side is not None and not self.joint_launches and self.pipeline_tail
 
     def _enqueue_step(self):
         self._enqueue_steps(1)
@@ -187,18 +190,6 @@ class GrainRollout:
                 be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                     self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
             main.wait_event(swept)
-            if os.environ.get("GGNN_GLUE", "") == "split":  # development: the four glue launches one by one
-                be.heads_regressor(hr["joint"], hr["grain"], x["grain"], self.w_reg[0], self.w_reg[1],
-                                   p["joint"], p["grain"], p["grain_area"])
-                be.step_update(x["joint"], x["grain"], p["joint"], p["grain"], self.dz, self.zmax, self.flags)
-                if self.refresh_centres:
-                    be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
-                                     self.domain_factor, self.domain_offset)
-                be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
-                                [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea_next[et]) for et in EDGE_TYPES])
-                prepare_edges(be, self.graph, x, ea_next, einfo)
-                self.edge_attr, self._ea_other = ea_next, ea
-                continue
             # heads + Rmodel.update in one launch; z clamp + edge lengths + next records in one launch
             be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                       p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)

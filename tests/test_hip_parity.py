@@ -1142,3 +1142,48 @@ def test_edge_records_at_wrap_boundaries():
     assert (got[:, 11] == 1).all()            # bias row of the encoder sweep's value product (f_src <= 11)
     assert (got[:, 12] == 1).all() and np.array_equal(got[:, 13], ea.cpu().numpy()[perm])
     assert np.array_equal(got[:, 19], got[:, 13]) and (got[:, 14:16] == 0).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("clamp", [False, True])
+def test_fused_glue_launches_equal_the_separate_calls(clamp):
+    """ggnn_heads_regressor_update == ggnn_heads_regressor + ggnn_step_update and ggnn_step_refresh_prepare ==
+    ggnn_step_refresh + ggnn_edge_prepare, bit for bit (same expressions on the same operands), with and
+    without the z clamp of test.py:405-407 firing."""
+    from graingraphnn_amd.engine import GraphCSR, alloc_einfo, prepare_edges
+    be = backend()
+    x, ei, ea = load_graph("40")
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    if clamp:
+        X["joint"][:, 2] = 0.99
+        X["grain"][:, 2] = 0.99
+    nj, ng = X["joint"].size(0), X["grain"].size(0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    h = {"joint": torch.randn(nj, 96, generator=g).to(DEV), "grain": torch.randn(ng, 96, generator=g).to(DEV)}
+    w, b = (torch.randn(2, 2, 96, generator=g) * 0.2).to(DEV), (torch.randn(4, generator=g) * 0.1).to(DEV)
+    dz, zmax = float(np.float32(6 / 121)), float(np.float32(120 / 121))
+    graph = GraphCSR(be, EI, {"joint": nj, "grain": ng})
+
+    def fresh():
+        return ({k: v.clone() for k, v in X.items()}, {et: EA[et].view(-1).clone() for et in EDGE_TYPES},
+                {"joint": torch.empty(nj, 2, device=DEV), "grain": torch.empty(ng, 2, device=DEV),
+                 "area": torch.empty(ng, device=DEV)}, torch.zeros(2, dtype=torch.int32, device=DEV),
+                alloc_einfo(graph, DEV))
+    xa, eaa, pa, fa, eia = fresh()
+    be.heads_regressor(h["joint"], h["grain"], xa["grain"], w, b, pa["joint"], pa["grain"], pa["area"])
+    be.step_update(xa["joint"], xa["grain"], pa["joint"], pa["grain"], dz, zmax, fa)
+    be.step_refresh(xa["joint"], xa["grain"], zmax, fa,
+                    [(graph.edge_index[et], xa[et[0]], xa[et[-1]], eaa[et]) for et in EDGE_TYPES])
+    prepare_edges(be, graph, xa, eaa, eia)
+    xb, eab, pb, fb, eib = fresh()
+    be.heads_regressor_update(h["joint"], h["grain"], xb["joint"], xb["grain"], w, b, pb["joint"], pb["grain"],
+                              pb["area"], dz, zmax, fb)
+    be.step_refresh_prepare(xb["joint"], xb["grain"], zmax, fb,
+                            [(graph.csr[et], eab[et], xb[et[0]], xb[et[-1]], eib[et]) for et in EDGE_TYPES])
+    assert int(fa[1]) == int(fb[1]) == int(clamp)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    for nt in xa:
+        assert torch.equal(xa[nt], xb[nt]), nt
+    for et in EDGE_TYPES:
+        assert torch.equal(eaa[et], eab[et]) and torch.equal(eia[et], eib[et]), et
