@@ -88,7 +88,7 @@ class EncCellSweep(Structure):
     """Mirror of `ggnn_enc_cell_sweep`."""
     _fields_ = [
         ("rowptr", c_void_p), ("einfo", c_void_p), ("wv_frag", c_void_p),
-        ("E", c_int64), ("u4_off", c_int32), ("f_src", c_int32),
+        ("E", c_int64), ("u4_off", c_int32), ("f_src", c_int32), ("n_blocks", c_int64),
     ]
 
 

@@ -14,11 +14,12 @@ from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, EncCellArg
 
 class CSR:
     """Destination-grouped edge list of one edge type (all int32, device resident)."""
-    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E")
+    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E", "n_blocks")
 
     def __init__(self, rowptr, col, perm, row, unit_ptr, units, E):
         self.rowptr, self.col, self.perm, self.row = rowptr, col, perm, row
         self.unit_ptr, self.units, self.E = unit_ptr, units, E
+        self.n_blocks = 0   # sweep blocks of the fused encoder cell (engine.GraphCSR fills it in; 0 = unknown)
 
 
 def _require_cuda(*tensors):
@@ -207,6 +208,7 @@ class HipBackend:
                     raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
                 sw.rowptr, sw.einfo = csr.rowptr.data_ptr(), einfo.data_ptr()
                 sw.wv_frag, sw.E, sw.u4_off, sw.f_src = wvb.data_ptr(), csr.E, u4_off, f_src
+                sw.n_blocks = getattr(csr, "n_blocks", 0) or 0
             a.p_dst, a.w2_frag, a.w2, a.pre = p_dst.data_ptr(), w2f.data_ptr(), w2.data_ptr(), pre.data_ptr()
             a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
             a.x_dst, a.ws_t, a.ldx, a.f_dst = x_dst.data_ptr(), ws_t.data_ptr(), x_dst.stride(0), ws_t.size(0) - 1

@@ -40,15 +40,21 @@
 
 namespace ggnn {
 
-constexpr int EC_WAVES = 8;                  // two per SIMD: a wave alone issues one instruction per >= 4 cycles
+#ifndef EC_CFG_WAVES       // (development: make VARIANT=.. EXTRA="-DEC_CFG_WAVES=.. -DEC_CFG_U=.. -DEC_CFG_HMAX=.. -DEC_CFG_MINW=..")
+#define EC_CFG_WAVES 8
+#define EC_CFG_U 4
+#define EC_CFG_HMAX 6
+#define EC_CFG_MINW 2
+#endif
+constexpr int EC_WAVES = EC_CFG_WAVES;       // two per SIMD: a wave alone issues one instruction per >= 4 cycles
 constexpr int EC_MAX_PROBLEMS = 4;
 constexpr int EC_MAX_COMBOS = EC_MAX_PROBLEMS * 2 * 3;  // (problem, incoming edge type, gate)
 constexpr int EC_G = 3;                      // i, c, o
 constexpr int EC_S = 104;                    // stage row stride in floats: 8 mod 16
-constexpr int EC_U = 4;                      // ring slots per wave = blocks in flight
+constexpr int EC_U = EC_CFG_U;               // ring slots per wave = blocks in flight
 constexpr int EC_SLOT = 1024 + 256 + 32;     // 16 records x 64 B | 4 tails x 64 B | control words
 constexpr int EC_PLANES = 3 * 18 * 1024;     // 55 296 B
-constexpr int EC_HR = 8, EC_HMAX = 6;        // header ring slots, tiles fetched ahead of the front cursor
+constexpr int EC_HMAX = EC_CFG_HMAX, EC_HR = EC_HMAX + 1 + (EC_HMAX & 1);  // tiles fetched ahead of the front cursor, header ring slots
 constexpr int EC_HSLOT = 80;                 // 17 rowptr entries
 constexpr int EC_WAVE_LDS = 16 * EC_S * 4 + EC_U * EC_SLOT + EC_HR * EC_HSLOT;  // 6 656 + 5 248 + 640
 constexpr int EC_LDS_BYTES = EC_PLANES + EC_WAVES * EC_WAVE_LDS;  // 155 648
@@ -417,7 +423,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   GGNN_STAMP(16);
 }
 
-__global__ __launch_bounds__(EC_WAVES * 64, EC_WAVES / 4) void enc_cell_kernel(const EncCellBatch B) {
+__global__ __launch_bounds__(EC_WAVES * 64, EC_CFG_MINW) void enc_cell_kernel(const EncCellBatch B) {
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[EC_LDS_BYTES];
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
@@ -524,7 +530,9 @@ extern "C" int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_pro
       // time of the combination in units of one sweep block (four units; measured: the loop is bound by
       // instruction issue, a third k-step adds ~12 %, a tile's GEMM costs ~1.6 blocks); a row has
       // max(1, ceil(deg / 3)) units: ~ max(n_dst, E / 3) for the degrees of a grain structure
-      cost[n_kd] = (double)std::max<int64_t>(A.n_dst, Sw.E / GGNN_UNIT_EDGES) / 4.0 * (Sw.f_src > 8 ? 1.12 : 1.0) +
+      const double blocks = Sw.n_blocks > 0 ? (double)Sw.n_blocks
+                                            : (double)std::max<int64_t>(A.n_dst, Sw.E / GGNN_UNIT_EDGES) / 4.0;
+      cost[n_kd] = blocks * (Sw.f_src > 8 ? 1.12 : 1.0) +
                    (double)n_t[n_kd] * 1.6;
       total += EC_G * cost[n_kd];
       kd[n_kd++] = k | (e << 2);

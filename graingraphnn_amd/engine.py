@@ -30,9 +30,24 @@ class GraphCSR:
             ei = edge_index_dict[et]
             self.edge_index[et] = ei.contiguous()
             self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
+            self.csr[et].n_blocks = _sweep_blocks(self.csr[et].rowptr)
 
     def n_edges(self, et):
         return self.edge_index[et].size(1)
+
+
+def _sweep_blocks(rowptr: torch.Tensor) -> int:
+    """Blocks the fused encoder cell walks for this edge type: per 16-row tile the largest unit count
+    (units of <= 3 edges, an empty row = one unit) among its four groups of 4 rows.  One small reduction
+    and one read-back per topology; only used to balance the workgroups."""
+    n = rowptr.numel() - 1
+    if n <= 0:
+        return 0
+    n_t = (n + 15) // 16
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    nu = torch.clamp((deg + 2) // 3, min=1)
+    nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)
+    return int(nu.max(1).values.sum())
 
 
 _graph_cache: Dict[tuple, GraphCSR] = {}

@@ -321,6 +321,9 @@ typedef struct ggnn_enc_cell_sweep {
   const float* wv_frag;    /* [3][6][4][64] */
   int64_t E;
   int32_t u4_off, f_src;
+  int64_t n_blocks;        /* optional: sweep blocks of this edge type (sum over the 16-row tiles of the largest
+                              unit count among the four 4-row groups); 0 = estimated from n_dst and E.  Only
+                              used to deal the workgroups: affects speed, never results */
 } ggnn_enc_cell_sweep;
 typedef struct ggnn_enc_cell_args {
   ggnn_enc_cell_sweep in[2];
