@@ -1187,3 +1187,36 @@ def test_fused_glue_launches_equal_the_separate_calls(clamp):
         assert torch.equal(xa[nt], xb[nt]), nt
     for et in EDGE_TYPES:
         assert torch.equal(eaa[et], eab[et]) and torch.equal(eia[et], eib[et]), et
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_two_stream_rollout_equals_the_single_stream_plan(use_graph):
+    """The pipelined two-stream step (update, grain centres, refresh and the next edge records behind the
+    regressor's heads, second edge_attr buffer, no join between the steps of a graph) is a re-ordering of the same
+    launches: 23 steps on the folded 120 um fixture -- odd, so both edge_attr buffers end up current once, through
+    4-step and single-step graphs -- must reproduce the single-stream plan bit for bit (x, edge_attr and every
+    prediction), also after the caller wrote into x between two runs (stale edge records)."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("120")
+    x, ea = {k: v.copy() for k, v in x.items()}, {k: v.copy() for k, v in ea.items()}
+    off = synthetic.scale_feature_patchs(3.0, x, ea)
+    R, Cm = product_models(77, 0.5, DEV)
+    ros = []
+    for two_streams in (False, True):
+        X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+        ro = GrainRollout(R, Cm, X, EI, EA, 5, use_graph=use_graph and two_streams, joint_launches=False,
+                          concurrent=two_streams, refresh_centres=True, domain_factor=3.0,
+                          domain_offset=torch.from_numpy(off))
+        assert ro._pipelined() == two_streams
+        ro.run(10)
+        ro.x["joint"][:, 0] += 0.001              # the caller moves the junctions: the prepared records are stale
+        ro.run(13)
+        ros.append(ro)
+    a, b = ros
+    for nt in x:
+        assert torch.equal(a.x[nt], b.x[nt]), nt
+    for et in EDGE_TYPES:
+        assert torch.equal(a.edge_attr[et], b.edge_attr[et]), et
+    for k in a.pred:
+        assert torch.equal(a.pred[k], b.pred[k]), k
