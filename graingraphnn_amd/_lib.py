@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 14
+GGNN_ABI_VERSION = 15
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -28,7 +28,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
-    "ggnn_step_refresh_prepare",
+    "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
+    "ggnn_wgrad_splits", "ggnn_wgrad",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -100,6 +101,15 @@ class EncCellArgs(Structure):
         ("h_out", c_void_p), ("c_out", c_void_p), ("x_dst", c_void_p), ("ws_t", c_void_p),
         ("ldp", c_int64), ("n_dst", c_int64), ("ldx", c_int64),
         ("n_in", c_int32), ("f_dst", c_int32), ("Ka", c_int32), ("reserved", c_int32),
+    ]
+
+
+class WgradArgs(Structure):
+    """Mirror of `ggnn_wgrad_args`."""
+    _fields_ = [
+        ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p),
+        ("lda", c_int64), ("ldb", c_int64), ("a_bstride", c_int64), ("b_bstride", c_int64), ("K", c_int64),
+        ("M", c_int32), ("Nc", c_int32), ("batch", c_int32), ("n_split", c_int32),
     ]
 
 
@@ -191,6 +201,16 @@ def _declare(lib):
     lib.ggnn_step_refresh_prepare.restype = c_int
     lib.ggnn_step_refresh_prepare.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p,
                                               POINTER(PrepareEdge), c_int, c_void_p]
+    lib.ggnn_lstm_train_forward.restype = c_int
+    lib.ggnn_lstm_train_forward.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                            c_int, c_void_p]
+    lib.ggnn_lstm_train_backward.restype = c_int
+    lib.ggnn_lstm_train_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]
+    lib.ggnn_wgrad_splits.restype = c_int
+    lib.ggnn_wgrad_splits.argtypes = [c_int64, c_int, c_int, c_int]
+    lib.ggnn_wgrad.restype = c_int
+    lib.ggnn_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     lib.ggnn_heads_classifier.restype = c_int
     lib.ggnn_heads_classifier.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -292,6 +292,47 @@ class HipBackend:
         self._launch(self.lib.ggnn_lstm_epilogue_batch, "ggnn_lstm_epilogue_batch", arr, len(problems),
                      _lib.current_stream())
 
+    # -- LSTM update of the training path -----------------------------------------------
+    def lstm_train_forward(self, z, p_dst, s_off, c_in, h_out, c_out):
+        """ggnn_lstm_train_forward: z [G, N, 96] (gate GEMM output in, pre-activations out)."""
+        _require_cuda(z, p_dst, c_in, h_out, c_out)
+        G, N = z.size(0), z.size(1)
+        if not z.is_contiguous() or z.size(2) != _lib.GGNN_C or not (h_out.is_contiguous() and c_out.is_contiguous()) \
+                or (c_in is not None and not c_in.is_contiguous()):
+            raise _lib.GGNNError("z [G, N, 96], c_in, h_out, c_out [N, 96] must be contiguous")
+        self._launch(self.lib.ggnn_lstm_train_forward, "ggnn_lstm_train_forward", ptr(z), ptr(p_dst), p_dst.stride(0),
+                     s_off, ptr(c_in), ptr(h_out), ptr(c_out), N, G, _lib.current_stream())
+
+    def lstm_train_backward(self, z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in):
+        """ggnn_lstm_train_backward: g_h / g_c / g_p_dst / g_c_in may be None."""
+        _require_cuda(z, c_in, c_out, g_h, g_c, g_z, g_p_dst, g_c_in)
+        G, N = z.size(0), z.size(1)
+        for t in (z, c_in, c_out, g_h, g_c, g_z, g_c_in):
+            if t is not None and not t.is_contiguous():
+                raise _lib.GGNNError("lstm_train_backward: z, g_z [G, N, 96] and the [N, 96] operands must be contiguous")
+        if g_z.shape != z.shape:
+            raise _lib.GGNNError("g_z must have the shape of z")
+        self._launch(self.lib.ggnn_lstm_train_backward, "ggnn_lstm_train_backward", ptr(z), ptr(c_in), ptr(c_out),
+                     ptr(g_h), ptr(g_c), ptr(g_z), ptr(g_p_dst), 0 if g_p_dst is None else g_p_dst.stride(0), s_off,
+                     ptr(g_c_in), N, G, _lib.current_stream())
+
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0):
+        """ggnn_wgrad: C[batch, M, Nc] = A_k^T B_k; A_k = K rows of M floats, row pitch lda, from element
+        k * a_bstride of the contiguous tensor `a` on (B_k likewise).  Returns the sum over the splits."""
+        _require_cuda(a, b)
+        for t, ld, bs, w in ((a, lda, a_bstride, M), (b, ldb, b_bstride, Nc)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or ld < w \
+                    or (batch - 1) * bs + (K - 1) * ld + w > t.numel():
+                raise _lib.GGNNError("wgrad: operands must be contiguous float32 tensors that hold every addressed row")
+        S = self.lib.ggnn_wgrad_splits(K, M, Nc, batch)
+        partial = torch.empty(S, batch, M, Nc, dtype=torch.float32, device=a.device)
+        w = _lib.WgradArgs()
+        w.a, w.b, w.partial = a.data_ptr(), b.data_ptr(), partial.data_ptr()
+        w.lda, w.ldb, w.a_bstride, w.b_bstride, w.K = lda, ldb, a_bstride, b_bstride, K
+        w.M, w.Nc, w.batch, w.n_split = M, Nc, batch, S
+        self._launch(self.lib.ggnn_wgrad, "ggnn_wgrad", ctypes.byref(w), _lib.current_stream())
+        return partial.sum(0) if S > 1 else partial[0]
+
     # -- heads -------------------------------------------------------------------------
     def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):
         _require_cuda(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area)

@@ -1,0 +1,204 @@
+// Weight-gradient GEMM of the training path:  C[b] = A[b]^T B[b],  A [K, M], B [K, Nc] with K = number of
+// nodes (10^4..10^5) and a small M x Nc result (the gradient of a packed projection / gate weight matrix:
+// train.py:158-166's loss.backward() reaching lin_* through the packed formulation).
+// The BLAS library runs these shapes on a few dozen workgroups (no split over K): 150-290 us each at the
+// 10k-grain graph, a quarter of the whole training step.  Here K is split over the chip:
+//
+//   * one wave owns a (16 TA) x 112 block of C over one K range and accumulates it in registers with
+//     v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate);
+//   * both operands of that MFMA are K-major (lane l supplies row k0 + l/16), so the fragments come straight from
+//     the row-major operands -- no LDS, no transpose.  A lane loads TA consecutive floats of A and 4 + 2 + 1 of B
+//     per row (dwordx4 / x2 / x1: 256-byte row pieces per 16 lanes), and component j of a load is the lane's
+//     element of MFMA tile j: a "tile" is the strided column set {c0 + w i + j}, which the MFMA does not care about
+//     and the store undoes;
+//   * a ring of four 4-row groups: a group's registers are reloaded for 16 rows ahead as soon as its 7 TA MFMAs
+//     have issued, so loads have ~1 us of matrix work to land;
+//   * logical blocks are dealt to the XCDs in contiguous ranges (xcd_remap): the waves that share a K range -- and
+//     so the rows of B -- sit behind one L2;
+//   * every wave writes its partial block to partial[split]; the caller sums over the split axis (a fixed
+//     decomposition: results are reproducible run to run).
+// Lanes whose columns fall beyond M / Nc load a clamped address and store nothing.
+#include "common.h"
+
+namespace ggnn {
+
+constexpr int WG_TB = 7;   // 16-column tiles of B per wave: 4 (dwordx4) + 2 (dwordx2) + 1 (dword)
+constexpr int WG_NB = 16 * WG_TB;
+constexpr int WG_U = 4;    // 4-row MFMA groups per pipeline stage
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int W> struct wg_vec;
+template <> struct wg_vec<4> { typedef f32x4 type; };
+template <> struct wg_vec<2> { typedef f32x2 type; };
+
+template <int TA>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const ggnn_wgrad_args W, int n_mt, int n_nb, int64_t chunk) {
+  typedef typename wg_vec<TA>::type avec;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  int64_t w = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t total = (int64_t)W.batch * n_nb * W.n_split * n_mt;
+  if (w >= total) return;
+  const int mt = (int)(w % n_mt);
+  w /= n_mt;
+  const int nb = (int)(w % n_nb);
+  w /= n_nb;
+  const int b = (int)(w % W.batch), s = (int)(w / W.batch);
+  const int m0 = mt * 16 * TA, n0 = nb * WG_NB;
+  const int64_t k_begin = s * chunk, k_end = min(W.K, k_begin + chunk);
+
+  // this lane's columns (clamped into the matrix; clamped lanes do not store)
+  const int ca = min(m0 + TA * li, W.M - TA);
+  const int cb4 = min(n0 + 4 * li, W.Nc - 4), cb2 = min(n0 + 64 + 2 * li, W.Nc - 2), cb1 = min(n0 + 96 + li, W.Nc - 1);
+  const float* A = W.a + (int64_t)b * W.a_bstride + (int64_t)lq * W.lda + ca;
+  const float* B = W.b + (int64_t)b * W.b_bstride + (int64_t)lq * W.ldb;
+
+  f32x4 acc[TA][WG_TB];
+#pragma unroll
+  for (int t = 0; t < TA; ++t)
+#pragma unroll
+    for (int u = 0; u < WG_TB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A ring of WG_U row groups: group j's registers are reloaded (rows 4 WG_U further on) right after its MFMAs
+  // have issued, so every load has the MFMAs of the other WG_U - 1 groups (~1 us) to land.  The loads are inline
+  // asm with counted waits: hipcc's own waits drain every outstanding load at the top of the loop (it cannot
+  // carry the count over the back edge), which exposes a full memory latency per 16 rows.
+  avec ra[WG_U];
+  f32x4 rb4[WG_U];
+  f32x2 rb2[WG_U];
+  float rb1[WG_U];
+  auto load = [&](int j, int64_t k) {  // the 4 rows from k (all below k_end): 4 loads
+    const float* pa = A + k * W.lda;
+    const float* pb = B + k * W.ldb;
+    if constexpr (TA == 4)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(pa));
+    else
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ra[j]) : "v"(pa));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4[j]) : "v"(pb + cb4));
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rb2[j]) : "v"(pb + cb2));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(rb1[j]) : "v"(pb + cb1));
+  };
+  auto compute = [&](int j) {
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+      const float a = ra[j][t];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rb4[j][u], acc[t][u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        acc[t][4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rb2[j][u], acc[t][4 + u], 0, 0, 0);
+      acc[t][6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rb1[j], acc[t][6], 0, 0, 0);
+    }
+  };
+#define WG_WAIT(n)                                    \
+  do {                                                \
+    asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+
+  const int64_t n_grp = (k_end - k_begin) / 4;  // full 4-row groups
+  int64_t gi = 0;
+#pragma unroll
+  for (int j = 0; j < WG_U; ++j)
+    if (j < n_grp) load(j, k_begin + 4 * j);
+  __builtin_amdgcn_sched_barrier(0);
+  for (; gi + 2 * WG_U <= n_grp; gi += WG_U) {  // steady state: every group of the ring has a successor in flight
+#pragma unroll
+    for (int j = 0; j < WG_U; ++j) {
+      WG_WAIT(12);  // 4 (WG_U - 1) younger loads may stay in flight
+      compute(j);
+      __builtin_amdgcn_sched_barrier(0);
+      load(j, k_begin + 4 * (gi + j + WG_U));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (; gi < n_grp; gi += WG_U) {  // drain
+#pragma unroll
+    for (int j = 0; j < WG_U; ++j) {
+      if (gi + j < n_grp) {
+        WG_WAIT(0);
+        compute(j);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi + j + WG_U < n_grp) load(j, k_begin + 4 * (gi + j + WG_U));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (k_begin + 4 * n_grp < k_end) {  // 1-3 rows left: lanes of the rows at and behind k_end contribute zero
+    const int64_t k = k_begin + 4 * n_grp;
+    const bool ok = k + lq < k_end;
+    load(0, ok ? k : k_end - 1 - lq);
+    WG_WAIT(0);
+#pragma unroll
+    for (int t = 0; t < TA; ++t) ra[0][t] = ok ? ra[0][t] : 0.f;
+    compute(0);
+  }
+#undef WG_WAIT
+
+  // acc[t][u][r]: C row = A column of (tile t, lane 4 lq + r), C column = B column of (tile u, lane li)
+  float* out = W.partial + ((int64_t)s * W.batch + b) * W.M * W.Nc;
+#pragma unroll
+  for (int u = 0; u < WG_TB; ++u) {
+    const int n = u < 4 ? n0 + 4 * li + u : u < 6 ? n0 + 64 + 2 * li + (u - 4) : n0 + 96 + li;
+    if (n >= W.Nc) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mrow = m0 + TA * (4 * lq + r);
+      if (mrow >= W.M) continue;
+#pragma unroll
+      for (int t = 0; t < TA; ++t) out[(int64_t)(mrow + t) * W.Nc + n] = acc[t][u][r];
+    }
+  }
+}
+
+struct WgradPlan {
+  int ta, n_mt, n_nb, n_split;
+  int64_t chunk;
+};
+
+static WgradPlan wgrad_plan(int64_t K, int M, int Nc, int batch) {
+  WgradPlan p;
+  p.ta = M % 64 == 0 || M >= 512 ? 4 : 2;
+  p.n_mt = (M + 16 * p.ta - 1) / (16 * p.ta);
+  p.n_nb = (Nc + WG_NB - 1) / WG_NB;
+  const int64_t tiles = (int64_t)batch * p.n_mt * p.n_nb;
+  // one wave per SIMD of a 256-CU part (the kernel is bound by the matrix pipe: a second wave per SIMD only
+  // shares it), the K ranges at least 64 rows long
+  int64_t want = 1024 / tiles;
+  const int64_t most = (K + 63) / 64;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  p.chunk = ((K + want - 1) / want + 3) / 4 * 4;
+  p.n_split = (int)((K + p.chunk - 1) / p.chunk);
+  if (p.n_split < 1) p.n_split = 1;
+  return p;
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch) {
+  if (K <= 0 || M <= 0 || Nc <= 0 || batch <= 0) return 0;
+  return ggnn::wgrad_plan(K, M, Nc, batch).n_split;
+}
+
+extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  ggnn_wgrad_args W = *args;
+  if (!W.a || !W.b || !W.partial || W.K <= 0 || W.M <= 0 || W.Nc <= 0 || W.batch <= 0) return GGNN_EINVAL;
+  if ((W.M & 3) || (W.Nc & 3) || W.lda < W.M || W.ldb < W.Nc) return GGNN_EINVAL;
+  if ((W.lda & 3) || (W.ldb & 3) || (W.a_bstride & 3) || (W.b_bstride & 3) || !aligned16(W.a) || !aligned16(W.b))
+    return GGNN_EINVAL;  // dwordx4 row pieces
+  const WgradPlan p = wgrad_plan(W.K, W.M, W.Nc, W.batch);
+  if (W.n_split != p.n_split) return GGNN_EINVAL;  // the caller sized `partial` with ggnn_wgrad_splits
+  const int64_t waves = (int64_t)W.batch * p.n_nb * p.n_split * p.n_mt;
+  const int64_t blocks = (waves + 3) / 4;
+  if (blocks > 0x7fffffff) return GGNN_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p.ta == 4)
+    hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
+  return hipGetLastError() == hipSuccess ? 0 : GGNN_ELAUNCH;
+}

@@ -59,34 +59,6 @@ def train_topology(backend, graph) -> TrainTopology:
     return t
 
 
-class _Sweep(torch.autograd.Function):
-    """agg = sweep(p_dst = [u_h (G x 96) | u4 (G x 16)], v (G x 96), h_src, edge_params) for one
-    edge type; agg is [n_dst, G, 128] = (96 values, sum alpha, sum alpha * a, zeros).  (Single-sweep
-    form, kept for op-level tests; the models go through _CellSweeps.)"""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # the sweep is fp32 under bf16 autocast too
-    def forward(ctx, p_dst, v, h_src, ep, backend, topo, et, einfo, G):
-        p_dst, v, ep = p_dst.contiguous(), v.contiguous(), ep.contiguous()
-        h_src = None if h_src is None else h_src.contiguous()
-        agg = torch.zeros(p_dst.size(0), G * _KG, dtype=torch.float32, device=p_dst.device)
-        offs = (0, 0, G * C if h_src is not None else 0, 0, _KG, C)  # v, u_h, u4, a, gate stride, scalars
-        backend.aggregate(topo.graph.csr[et], einfo, v, p_dst, h_src, ep, agg, *offs, G)
-        ctx.save_for_backward(p_dst, v, h_src, ep, agg, einfo)
-        ctx.misc = (backend, topo, et, G, offs)
-        return agg.view(-1, G, _KG)
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, g_agg):
-        p_dst, v, h_src, ep, agg, einfo = ctx.saved_tensors
-        backend, topo, et, G, offs = ctx.misc
-        g_agg = g_agg.contiguous().view(-1, G * _KG)
-        g_p_dst, g_v, g_h, g_ep = backend.aggregate_backward(
-            topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo, v, p_dst, h_src, ep, agg, g_agg, *offs, G)
-        return g_p_dst, g_v, g_h, g_ep, None, None, None, None, None
-
-
 # ---------------------------------------------------------------------------------------
 # The cell in its packed (inference) formulation, differentiable.
 #
@@ -104,11 +76,32 @@ _KINDS = (("wq", "lin_query", "weight"), ("bq", "lin_query", "bias"), ("wk", "li
           ("bl", "lin_l2", "bias"), ("we", "lin_edge", "weight"))
 
 
-def _gather_params(cell, gates):
+class _GatherParams(torch.autograd.Function):
+    """flat = cat(params[:n_used]); params[n_used:] are read by the reference but contribute nothing (zero
+    gradient).  The backward hands every parameter a fresh tensor filled by ONE multi-tensor copy / fill, which
+    AccumulateGrad adopts as .grad without a kernel (views of the flat gradient would cost a clone per parameter)."""
+
+    @staticmethod
+    def forward(ctx, n_used, *params):
+        ctx.shapes, ctx.n_used = [p.shape for p in params], n_used
+        return torch.cat([p.reshape(-1) for p in params[:n_used]])
+
+    @staticmethod
+    def backward(ctx, g_flat):
+        n_used, shapes = ctx.n_used, ctx.shapes
+        outs = [g_flat.new_empty(shape) for shape in shapes]
+        parts = torch.split(g_flat, [math.prod(sh) for sh in shapes[:n_used]])
+        torch._foreach_copy_(outs[:n_used], [p.view(sh) for p, sh in zip(parts, shapes)])
+        if len(outs) > n_used:
+            torch._foreach_zero_(outs[n_used:])
+        return (None, *outs)
+
+
+def _gather_params(cell, gates, unused=()):
     """All parameters the cell's forward reads, stacked per gate: get(et, kind) -> [G, *param.shape];
     gate bias get("b", nt) -> [G, 96].  ONE cat kernel gathers them into a flat buffer and ONE
     split hands out the views (a slice per tensor would cost a full-size zero fill + add each in the
-    backward; the split's backward is a single cat)."""
+    backward; the split's backward is a single cat).  `unused`: parameters that get a zero gradient."""
     G = len(gates)
     plist, keys, shapes, sizes = [], [], [], []
     for et in EDGE_TYPES:
@@ -124,7 +117,7 @@ def _gather_params(cell, gates):
         shapes.append((G, C))
         sizes.append(G * C)
         plist += ts
-    parts = torch.split(torch.cat([t.reshape(-1) for t in plist]), sizes)
+    parts = torch.split(_GatherParams.apply(len(plist), *plist, *unused), sizes)
     table = {k: part.view(shape) for k, part, shape in zip(keys, parts, shapes)}
     return lambda *key: table[key]
 
@@ -148,7 +141,11 @@ def _packed_weights(cell, gates, F, sees_h):
     from .packing import node_layout
     G, k2 = len(gates), (C if sees_h else 0)
     scale = 1.0 / math.sqrt(C)
-    get = _gather_params(cell, gates)
+    # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an exactly zero
+    # gradient; they are handed to the gather the same way, which also keeps
+    # DistributedDataParallel(model, device_ids=[rank]) (dist_train.py:82) usable as written.
+    unused = () if "f" in gates else list(cell.conv_f.parameters()) + list(cell.b_f.parameters())
+    get = _gather_params(cell, gates, unused)
     dev = get(EDGE_TYPES[0], "wq").device
     zeros = lambda *shape: _zeros(dev, *shape)
     layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
@@ -199,21 +196,54 @@ def _packed_weights(cell, gates, F, sees_h):
     return layout, wp, bp, ep, w2
 
 
-class _CellSweeps(torch.autograd.Function):
-    """The three aggregation sweeps of one cell on the projections P[nt] (layout as in inference):
-    (P_grain, P_joint, h_grain, h_joint, ep_gj, ep_jg, ep_jj) -> (agg_grain, agg_joint).  One launch
-    forward; backward = ggnn_period_gat_aggregate_backward per edge type into shared gradient
-    buffers (each sweep owns its columns)."""
+def _pad_columns(wp, F, Fp):
+    """[ncols, F + k2] -> [ncols, Fp + k2] (ggnn_project's input order: features padded to a multiple of 4)."""
+    if Fp == F:
+        return wp.contiguous()
+    out = wp.new_zeros(wp.size(0), wp.size(1) + Fp - F)
+    out[:, :F] = wp[:, :F]
+    out[:, Fp:] = wp[:, F:]
+    return out
+
+
+class _PackedCell(torch.autograd.Function):
+    """One HeteroPGCLSTM cell (heteropgclstm.py:101-183) on the packed weights, forward and backward written
+    out by hand so that a cell is ~10 launches forward and ~25 backward with no autograd bookkeeping between them:
+
+      forward   P[nt] = [x | h] Wp^T + bp             ggnn_project_batch (the inference kernel; one launch)
+                agg   = sweeps(P, h)                   ggnn_period_gat_aggregate_batch (one launch)
+                z     = agg W2^T (per gate, batched)   library GEMM
+                h', c' = LSTM(z + skip(P), c)          ggnn_lstm_train_forward
+      backward  g_z, gP[skip], g_c                     ggnn_lstm_train_backward
+                g_W2 = g_z^T agg, g_agg = g_z W2       library GEMMs
+                gP[u, u4, v], g_h (source side), g_ep  ggnn_period_gat_aggregate_backward per edge type
+                g_[Wp | bp] = gP^T [x | h | 1], g_h += gP Wp[:, h columns]   library GEMMs
+
+    Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j); h / c None = zero state
+    (encoder, 3 gates).  x carries no gradient (data).  Everything is fp32, also under bf16 autocast."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # the sweeps are fp32 under bf16 autocast too
-    def forward(ctx, P_grain, P_joint, h_grain, h_joint, ep_gj, ep_jg, ep_jj, backend, topo, einfo, layout, G):
-        P = {"grain": P_grain.contiguous(), "joint": P_joint.contiguous()}
-        h = {"grain": None if h_grain is None else h_grain.contiguous(),
-             "joint": None if h_joint is None else h_joint.contiguous()}
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep_gj, ep_jg, ep_jj, w2_g, w2_j,
+                backend, topo, einfo, layout, G):
+        x = {"grain": x_g.contiguous(), "joint": x_j.contiguous()}
+        sees_h = h_g is not None
+        h = {"grain": h_g.contiguous() if sees_h else None, "joint": h_j.contiguous() if sees_h else None}
+        c = {"grain": c_g.contiguous() if sees_h else None, "joint": c_j.contiguous() if sees_h else None}
+        wp, bp = {"grain": wp_g, "joint": wp_j}, {"grain": bp_g.contiguous(), "joint": bp_j.contiguous()}
+        w2 = {"grain": w2_g, "joint": w2_j}
         ep = dict(zip(EDGE_TYPES, (ep_gj.contiguous(), ep_jg.contiguous(), ep_jj.contiguous())))
-        agg = {nt: torch.zeros(P[nt].size(0), G * layout[nt].Kg, dtype=torch.float32, device=P[nt].device)
-               for nt in NODE_TYPES}
+        dev, f32 = x_j.device, dict(dtype=torch.float32, device=x_j.device)
+        P, agg, w2p = {}, {}, {}
+        problems = []
+        for nt in NODE_TYPES:
+            lay, n = layout[nt], x[nt].size(0)
+            P[nt] = torch.empty(n, lay.ncols, **f32)
+            problems.append((x[nt], lay.F, h[nt], _pad_columns(wp[nt], lay.F, lay.Fp), bp[nt], P[nt]))
+            agg[nt] = torch.zeros(n, G * lay.Kg, **f32)
+            w2p[nt] = w2[nt].contiguous() if lay.Kg == lay.Ka else torch.cat(
+                [w2[nt], _zeros(dev, G, C, lay.Kg - lay.Ka)], 2)   # [G, 96, Kg]: agg's pad columns meet zero weights
+        backend.project_batch(problems)
         sweeps = []
         for et in EDGE_TYPES:
             s, d = et[0], et[-1]
@@ -221,71 +251,107 @@ class _CellSweeps(torch.autograd.Function):
                            layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et], layout[d].Kg,
                            layout[d].sc_off[et], G))
         backend.aggregate_batch(sweeps)
-        ctx.save_for_backward(P["grain"], P["joint"], h["grain"], h["joint"], ep_gj, ep_jg, ep_jj, agg["grain"],
-                              agg["joint"], *[einfo[et] for et in EDGE_TYPES])
-        ctx.misc = (backend, topo, layout, G, sweeps)
-        return agg["grain"], agg["joint"]
+        z, out = {}, []
+        for nt in NODE_TYPES:
+            lay, n = layout[nt], x[nt].size(0)
+            z[nt] = torch.bmm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2p[nt].transpose(1, 2))   # [G, N, 96]
+            h_new, c_new = torch.empty(n, C, **f32), torch.empty(n, C, **f32)
+            backend.lstm_train_forward(z[nt], P[nt], lay.s_off, c[nt], h_new, c_new)
+            out += [h_new, c_new]
+        saved = []
+        for nt in NODE_TYPES:
+            saved += [x[nt], h[nt], c[nt], wp[nt], w2p[nt], P[nt], agg[nt], z[nt]]
+        ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES])
+        ctx.misc = (backend, topo, layout, G, sees_h)
+        ctx.set_materialize_grads(False)
+        return tuple(out)                                           # h_grain, c_grain, h_joint, c_joint
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, g_grain, g_joint):
-        Pg, Pj, hg, hj, ep_gj, ep_jg, ep_jj, agg_g, agg_j, *einfos = ctx.saved_tensors
-        backend, topo, layout, G, sweeps = ctx.misc
-        P, h = {"grain": Pg, "joint": Pj}, {"grain": hg, "joint": hj}
-        agg = {"grain": agg_g, "joint": agg_j}
-        g_agg = {"grain": g_grain.contiguous(), "joint": g_joint.contiguous()}
-        ep = dict(zip(EDGE_TYPES, (ep_gj, ep_jg, ep_jj)))
-        gP = {nt: torch.zeros_like(P[nt]) for nt in NODE_TYPES}
-        gh = {nt: None for nt in NODE_TYPES}
+    def backward(ctx, g_hg, g_cg, g_hj, g_cj):
+        backend, topo, layout, G, sees_h = ctx.misc
+        t = ctx.saved_tensors
+        x, h, c, wp, w2p, P, agg, z, c_new = {}, {}, {}, {}, {}, {}, {}, {}, {}
+        for k, nt in enumerate(NODE_TYPES):
+            x[nt], h[nt], c[nt], wp[nt], w2p[nt], P[nt], agg[nt], z[nt] = t[8 * k:8 * k + 8]
+            c_new[nt] = t[16 + 2 * k + 1]
+        ep = dict(zip(EDGE_TYPES, t[20:23]))
+        einfo = dict(zip(EDGE_TYPES, t[23:26]))
+        g_h_out = {"grain": g_hg, "joint": g_hj}
+        g_c_out = {"grain": g_cg, "joint": g_cj}
+        f32 = dict(dtype=torch.float32, device=P["joint"].device)
+        gP, g_agg, g_w2, g_c = {}, {}, {}, {}
+        for nt in NODE_TYPES:
+            lay, n = layout[nt], x[nt].size(0)
+            gP[nt] = torch.empty_like(P[nt])
+            used = max(lay.u4_off[et] + G * 16 for et in lay.dst_ets)   # columns behind it are padding
+            if used < lay.ncols:
+                gP[nt][:, used:].zero_()
+            g_z = torch.empty_like(z[nt])
+            g_c[nt] = torch.empty(n, C, **f32) if sees_h else None
+            ok = lambda g: None if g is None else g.contiguous()
+            backend.lstm_train_backward(z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z, gP[nt],
+                                        lay.s_off, g_c[nt])
+            a = agg[nt].view(n, G, lay.Kg).transpose(0, 1)                                    # [G, N, Kg]
+            g_w2[nt] = backend.wgrad(g_z, agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
+                                     b_bstride=lay.Kg)[:, :, :lay.Ka]                          # [G, 96, Ka]
+            g_agg[nt] = torch.empty_like(agg[nt])
+            torch.bmm(g_z, w2p[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
+        gh_src = {nt: None for nt in NODE_TYPES}
         g_ep = {}
-        for et, einfo in zip(EDGE_TYPES, einfos):
+        for et in EDGE_TYPES:
             s, d = et[0], et[-1]
             _, _, g_h, g_ep[et] = backend.aggregate_backward(
-                topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo, P[s], P[d], h[s], ep[et], agg[d], g_agg[d],
-                layout[s].v_off[et], layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et],
+                topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo[et], P[s], P[d], h[s], ep[et], agg[d],
+                g_agg[d], layout[s].v_off[et], layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et],
                 layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s])
             if g_h is not None:
-                gh[s] = g_h if gh[s] is None else gh[s] + g_h
-        return (gP["grain"], gP["joint"], gh["grain"], gh["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]],
-                g_ep[EDGE_TYPES[2]], None, None, None, None, None)
+                gh_src[s] = g_h if gh_src[s] is None else gh_src[s].add_(g_h)
+        g_wp, g_bp, g_h = {}, {}, {}
+        for nt in NODE_TYPES:
+            lay, n = layout[nt], x[nt].size(0)
+            F = lay.F
+            D = F + (C if sees_h else 0)
+            ones = _ones(P[nt].device, n, 1 + (-(D + 1)) % 4)         # [1, 0, ..]: pads [x | h | 1] to 4 k columns
+            xin = torch.cat([x[nt][:, :F], h[nt], ones] if sees_h else [x[nt][:, :F], ones], 1)
+            g_wpb = backend.wgrad(gP[nt], xin, n, lay.ncols, xin.size(1), lay.ncols, xin.size(1))[0]   # [ncols, D + 1 + pad]
+            g_wp[nt], g_bp[nt] = g_wpb[:, :D], g_wpb[:, D]
+            g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, F:]) if sees_h else None      # [N, 96]
+        return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
+                g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
+                g_w2["grain"], g_w2["joint"], None, None, None, None, None)
+
+
+_ones_cache = {}
+
+
+def _ones(dev, n, width):
+    """[n, width]: a column of ones followed by zero columns (constant)."""
+    key = (str(dev), n, width)
+    o = _ones_cache.get(key)
+    if o is None:
+        if len(_ones_cache) >= 16:
+            _ones_cache.clear()
+        o = _ones_cache[key] = torch.zeros(n, width, dtype=torch.float32, device=dev)
+        o[:, 0] = 1.0
+    return o
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
-    """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation:
-    2 projection GEMMs, 1 launch of the three sweeps, 2 batched gate GEMMs, the LSTM update.
+    """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation: the packed
+    weights are assembled from the parameters by recorded torch ops, the cell itself is _PackedCell.
     h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped)."""
     gates = "ifco" if h is not None else "ico"
     G = len(gates)
     F = cell.in_channels_dict
     with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
         layout, wp, bp, ep, w2 = _packed_weights(cell, gates, F, h is not None)
-    P = {}
-    for nt in NODE_TYPES:
-        xin = x[nt] if h is None else torch.cat([x[nt], h[nt]], 1)
-        P[nt] = torch.nn.functional.linear(xin, wp[nt], bp[nt])       # [N, ncols] (bf16 under autocast)
-    agg_g, agg_j = _CellSweeps.apply(P["grain"], P["joint"], None if h is None else h["grain"],
-                                     None if h is None else h["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]],
-                                     ep[EDGE_TYPES[2]], backend, topo, einfo, layout, G)
-    agg = {"grain": agg_g, "joint": agg_j}
-    # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an
-    # exactly zero gradient; they are touched here the same way, which also keeps
-    # DistributedDataParallel(model, device_ids=[rank]) (dist_train.py:82) usable as written.
-    touch = 0.0 if h is not None else 0.0 * sum(
-        q.sum() for q in list(cell.conv_f.parameters()) + list(cell.b_f.parameters()))
-    h_new, c_new = {}, {}
-    for nt in NODE_TYPES:
-        lay = layout[nt]
-        n = agg[nt].size(0)
-        with torch.autocast(agg[nt].device.type, enabled=False):
-            a = agg[nt].view(n, G, lay.Kg).transpose(0, 1)                         # [G, N, Kg] (pad columns meet zero weights)
-            w2p = w2[nt] if lay.Kg == lay.Ka else torch.cat([w2[nt], _zeros(w2[nt].device, G, C, lay.Kg - lay.Ka)], 2)
-            skip = P[nt].narrow(1, lay.s_off, G * C).float().view(n, G, C)
-            pre = torch.bmm(a, w2p.transpose(1, 2)).transpose(0, 1) + skip         # [N, G, 96]
-        p = {g: pre[:, k] for k, g in enumerate(gates)}
-        cand = torch.sigmoid(p["i"]) * torch.tanh(p["c"])
-        c_new[nt] = cand + touch if h is None else torch.sigmoid(p["f"]) * c[nt] + cand
-        h_new[nt] = torch.sigmoid(p["o"]) * torch.tanh(c_new[nt])
-    return h_new, c_new
+    hg, cg, hj, cj = _PackedCell.apply(
+        x["grain"], x["joint"], None if h is None else h["grain"], None if h is None else h["joint"],
+        None if c is None else c["grain"], None if c is None else c["joint"], wp["grain"], wp["joint"], bp["grain"],
+        bp["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]], ep[EDGE_TYPES[2]], w2["grain"], w2["joint"], backend, topo,
+        einfo, layout, G)
+    return {"grain": hg, "joint": hj}, {"grain": cg, "joint": cj}
 
 
 def encoder_decoder(model, x_dict, edge_index_dict, edge_attr):
@@ -306,11 +372,36 @@ def encoder_decoder(model, x_dict, edge_index_dict, edge_attr):
     return h, graph
 
 
+class _RowLinear(torch.autograd.Function):
+    """y = x W^T + b for many rows (nodes / edges) and a head of 1-3 outputs (models.py:427-433, 600-603).  The
+    weight and bias gradients are reductions over all rows: one ggnn_wgrad launch ([g_y | 0]^T [x | 1 | 0]) instead
+    of the BLAS call that runs such a shape on half a dozen workgroups (50-80 us at the 10k-grain graph)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias, backend):
+        ctx.save_for_backward(x, weight)
+        ctx.backend = backend
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        n, n_in, n_out = x.size(0), x.size(1), weight.size(0)
+        g = g.contiguous()
+        gp = torch.nn.functional.pad(g, (0, (-n_out) % 4))
+        xin = torch.cat([x, _ones(x.device, n, 1 + (-(n_in + 1)) % 4)], 1)
+        gw = ctx.backend.wgrad(gp, xin, n, gp.size(1), xin.size(1), gp.size(1), xin.size(1))[0]
+        return g @ weight, gw[:n_out, :n_in], gw[:n_out, n_in], None
+
+
 def regressor_forward(model, x_dict, edge_index_dict, edge_attr):
     """GrainNN_regressor.forward (models.py:401-467) with autograd."""
     h, _ = encoder_decoder(model, x_dict, edge_index_dict, edge_attr)
-    y_joint = torch.tanh(model.linear["joint"](h["joint"]))
-    yg = model.linear["grain"](h["grain"])
+    be = default_backend()
+    y_joint = torch.tanh(_RowLinear.apply(h["joint"], model.linear["joint"].weight, model.linear["joint"].bias, be))
+    yg = _RowLinear.apply(h["grain"], model.linear["grain"].weight, model.linear["grain"].bias, be)
     y0 = torch.tanh(yg[:, 0])
     area = y0 / model.scaling["grain"] + x_dict["grain"][:, 3]
     y_grain = torch.stack([y0, torch.relu(yg[:, 1])], 1)
@@ -323,7 +414,9 @@ def classifier_forward(model, x_dict, edge_index_dict, edge_attr):
     et = ("joint", "connect", "joint")
     src, dst = graph.edge_index[et][0], graph.edge_index[et][1]
     pair = torch.cat([h["joint"][src], h["joint"][dst], edge_attr[et].view(-1, 1)], -1)
-    return {"edge_event": model.lin2(pair).view(-1), "edge": torch.tanh(model.lin1(pair))}
+    y = _RowLinear.apply(pair, torch.cat([model.lin1.weight, model.lin2.weight]),
+                         torch.cat([model.lin1.bias, model.lin2.bias]), default_backend())   # both heads in one product
+    return {"edge_event": y[:, 2].contiguous(), "edge": torch.tanh(y[:, :2])}
 
 
 def regressor_loss(y_dict, pred, mask):
@@ -337,7 +430,7 @@ def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
     y, z = y_dict["edge_event"], pred["edge_event"]
     keep = y > -1
     return torch.nn.functional.binary_cross_entropy_with_logits(
-        z[keep], y[keep].float(), pos_weight=torch.tensor(pos_weight, device=z.device))
+        z[keep], y[keep].to(z.dtype), pos_weight=torch.tensor(pos_weight, device=z.device, dtype=z.dtype))
 
 
 def wants_autograd(model) -> bool:
@@ -355,8 +448,8 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, optimizer, lambda pred, y: regressor_loss(y, pred, mask), X, EI, EA, Y)
         loss = step(X, EA, Y)            # same tensors or new values of the same shapes
 
-    `optimizer` must be created with `capturable=True` (torch.optim.Adam(..., capturable=True)); gradients
-    are kept as buffers (zero_grad(set_to_none=False)).  Warm-up (3 eager steps, which DO update the model)
+    `optimizer` must be created with `capturable=True` (torch.optim.Adam(..., capturable=True)); the .grad
+    tensors are those of the captured step (its memory pool): valid after every call, replaced by none.  Warm-up (3 eager steps, which DO update the model)
     and capture (which only records) run on a side stream, PyTorch's whole-network capture recipe."""
 
     def __init__(self, model, optimizer, loss_fn, x_dict, edge_index_dict, edge_attr, y_dict, autocast_dtype=None,
@@ -382,7 +475,7 @@ class GraphedTrainStep:
     def _eager(self):
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             loss = self.loss_fn(self.model(self.x, self.ei, self.ea), self.y)
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)   # (inside the capture the new .grad tensors come from the graph's pool)
         loss.backward()
         self.opt.step()
         return loss

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 14
+#define GGNN_ABI_VERSION 15
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -423,6 +423,39 @@ int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint, float*
 int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
                               int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
                               const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Training path: the LSTM update of HeteroPGCLSTM.forward (heteropgclstm.py:140-183) with the
+ * state its backward needs, and that backward.  Replaces what autograd records for the sigmoid / tanh /
+ * multiply / add chain of `i, f, c, o` (one launch each way instead of ~40).  n_gates = 4: (i, f, c, o) with
+ * c_in; n_gates = 3: (i, c, o), zero state (encoder), c_in = NULL.
+ *   forward : z [n_gates, N, 96] holds the gate GEMM's output (lin_l2 part) on entry; on exit the
+ *             pre-activations z_g = gemm_g + p_dst[n, s_off + g*96 ..] (skip rows of ggnn_project); writes
+ *             h_out, c_out [N, 96].
+ *   backward: g_h / g_c (gradients of h_out / c_out; NULL = zero) -> g_z [n_gates, N, 96], the same values
+ *             into g_p_dst[n, s_off + g*96 ..] (gradient of the skip rows; NULL = skip), g_c_in (NULL = skip).
+ * ldp % 4 == 0, s_off % 4 == 0, every pointer 16-byte aligned. */
+int ggnn_lstm_train_forward(float* z, const float* p_dst, int64_t ldp, int s_off, const float* c_in,
+                            float* h_out, float* c_out, int64_t N, int n_gates, ggnn_stream_t stream);
+int ggnn_lstm_train_backward(const float* z, const float* c_in, const float* c_out, const float* g_h,
+                             const float* g_c, float* g_z, float* g_p_dst, int64_t ldp, int s_off,
+                             float* g_c_in, int64_t N, int n_gates, ggnn_stream_t stream);
+
+/* Weight-gradient GEMM of the training path: C[b] = A[b]^T B[b] with a long reduction (K = nodes) and a small
+ * M x Nc result -- the gradient of a packed projection ([ncols, F + 97]) or gate ([96, Kg] per gate) weight
+ * matrix, replacing the BLAS call autograd would make for x.t() @ g (which does not split K).  The reduction is
+ * split over the chip in a fixed way; the call writes partial[s][b][M][Nc], s < ggnn_wgrad_splits(K, M, Nc, batch),
+ * and the caller sums over s.  Exact fp32 products (v_mfma_f32_16x16x4_f32).  M, Nc, lda, ldb, a_bstride,
+ * b_bstride multiples of 4 (pad B with zero columns otherwise); a, b 16-byte aligned. */
+typedef struct ggnn_wgrad_args {
+  const float* a;  /* [batch] x [K, lda] row-major, first M columns used; batch b starts at a + b * a_bstride */
+  const float* b;  /* [batch] x [K, ldb], first Nc columns used; batch b starts at b + b * b_bstride */
+  float* partial;  /* [n_split, batch, M, Nc] out */
+  int64_t lda, ldb, a_bstride, b_bstride, K;
+  int32_t M, Nc, batch, n_split;
+} ggnn_wgrad_args;
+int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch);
+int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
 
 /* Bytes of device scratch one model forward needs (projections + aggregates + h/c), so a
  * caller can size a single arena; the Python host allocates the same amounts as tensors. */

@@ -32,7 +32,7 @@ def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False):
     def one():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             loss = training.regressor_loss(y, model(X, EI, EA), mask)
-        opt.zero_grad(set_to_none=not graph)
+        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         return loss

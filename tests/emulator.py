@@ -177,11 +177,13 @@ class TorchEmulatorBackend:
             grads = torch.autograd.grad(tot, leaves + ([hl] if hl is not None else []), allow_unused=True)
         z = lambda g, like: torch.zeros_like(like) if g is None else g
         g_p_dst, g_p_src = z(grads[1], p_dst), z(grads[0], p_src)
-        if out_p_dst is not None:   # shared buffers: this sweep owns its own columns only (they are disjoint)
-            out_p_dst += g_p_dst
+        if out_p_dst is not None:   # shared buffers: this sweep WRITES its own columns only, as the kernel does
+            cols = [(u4_off, n_gates * 16)] + ([(u_off, n_gates * C)] if hl is not None else [])
+            for o, w in cols:
+                out_p_dst[:, o:o + w] = g_p_dst[:, o:o + w]
             g_p_dst = out_p_dst
         if out_p_src is not None:
-            out_p_src += g_p_src
+            out_p_src[:, v_off:v_off + n_gates * C] = g_p_src[:, v_off:v_off + n_gates * C]
             g_p_src = out_p_src
         return (g_p_dst, g_p_src, None if hl is None else z(grads[3], h_src), z(grads[2], ep))
 
@@ -208,6 +210,40 @@ class TorchEmulatorBackend:
             c = i * t
             c_out.copy_(c)
             h_out.copy_(o * torch.tanh(c))
+
+    def lstm_train_forward(self, z, p_dst, s_off, c_in, h_out, c_out):
+        G = z.size(0)
+        for g in range(G):
+            z[g] += p_dst[:, s_off + g * C: s_off + (g + 1) * C]
+        c = torch.sigmoid(z[0]) * torch.tanh(z[G - 2])
+        if G == 4:
+            c = c + torch.sigmoid(z[1]) * c_in
+        c_out.copy_(c)
+        h_out.copy_(torch.sigmoid(z[G - 1]) * torch.tanh(c))
+
+    def lstm_train_backward(self, z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in):
+        G = z.size(0)
+        gh = torch.zeros_like(c_out) if g_h is None else g_h
+        gc = torch.zeros_like(c_out) if g_c is None else g_c
+        o, tc = torch.sigmoid(z[G - 1]), torch.tanh(c_out)
+        g_z[G - 1] = gh * tc * o * (1 - o)
+        dc = gc + gh * o * (1 - tc * tc)
+        i, ct = torch.sigmoid(z[0]), torch.tanh(z[G - 2])
+        g_z[0] = dc * ct * i * (1 - i)
+        g_z[G - 2] = dc * i * (1 - ct * ct)
+        if G == 4:
+            f = torch.sigmoid(z[1])
+            g_z[1] = dc * c_in * f * (1 - f)
+            if g_c_in is not None:
+                g_c_in.copy_(dc * f)
+        if g_p_dst is not None:
+            for g in range(G):
+                g_p_dst[:, s_off + g * C: s_off + (g + 1) * C] = g_z[g]
+
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0):
+        fa, fb = a.reshape(-1), b.reshape(-1)
+        return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), k * a_bstride).t()
+                            @ torch.as_strided(fb, (K, Nc), (ldb, 1), k * b_bstride) for k in range(batch)])
 
     def project_batch(self, problems):
         for prob in problems:

@@ -40,13 +40,15 @@ def _digest(g):
     return np.concatenate([[g.sum(), np.sqrt((g * g).sum()), np.abs(g).max()], g[idx]])
 
 
-def _grads(R, Cm, x, ei, ea, device="cpu"):
+def _grads(R, Cm, x, ei, ea, device="cpu", dtype=torch.float32):
+    """dtype=float64 (oracle only): the models must have been cast with .double()."""
     y_np, m_np = _targets(x, ei)
-    y, mask = tt(y_np, device), tt(m_np, device)
+    cast = lambda d: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in tt(d, device).items()}
+    y, mask = cast(y_np), cast(m_np)
     R.train(), Cm.train()
     R.zero_grad(), Cm.zero_grad()
-    lr = training.regressor_loss(y, R(tt(x, device), tt(ei, device), tt(ea, device)), mask)
-    lc = training.classifier_loss(y, Cm(tt(x, device), tt(ei, device), tt(ea, device)), 1.0)
+    lr = training.regressor_loss(y, R(cast(x), tt(ei, device), cast(ea)), mask)
+    lc = training.classifier_loss(y, Cm(cast(x), tt(ei, device), cast(ea)), 1.0)
     lr.backward()
     lc.backward()
     out = {}
@@ -245,7 +247,15 @@ def test_cfg5_collated_minibatch_fp32_and_bf16_against_the_fp32_oracle():
     assert x["grain"].shape[0] == 4 * x0["grain"].shape[0]
     R, Cm = product_models(10020, 1.0, "cuda")
     oR, oC = oracle_models(10020, 1.0)
-    olr, olc, ref = _grads(oR, oC, x, ei, ea)
+    olr, olc, ref32 = _grads(oR, oC, x, ei, ea)
+    # The gradients are held to the oracle evaluated in fp64: in fp32 the oracle itself is 1.5e-6 of the model's
+    # largest gradient entry off on the decoder's forget-gate value weights of this batch (the product's error
+    # against fp64 is 1e-8 there), which is more than the floor of _check_full allows either side.
+    _, _, ref = _grads(oR.double(), oC.double(), x, ei, ea, dtype=torch.float64)
+    ref = {k: v.float() for k, v in ref.items()}
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    assert max(float((ref32[k] - ref[k]).abs().max()) for k in ref) <= 5e-6 * gmax     # the fp32 oracle's own noise
+    oR.float(), oC.float()
     lr, lc, grads = _grads(R, Cm, x, ei, ea, "cuda")
     assert abs(lr - olr) <= 1e-5 * abs(olr) and abs(lc - olc) <= 1e-5 * abs(olc)
     worst32 = _check_full(grads, ref)
@@ -452,3 +462,31 @@ def test_graphed_train_step_follows_the_eager_step():
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (k, float(la), float(lb))
     for (n, pa), (_, pb) in zip(A.named_parameters(), B.named_parameters()):
         assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,Nc,batch", [(20000, 1984, 108, 1), (20000, 96, 224, 4), (10000, 96, 128, 3),
+                                           (472, 480, 12, 1), (77, 96, 12, 1), (15, 16, 4, 2), (1000, 1060, 116, 1),
+                                           (3, 4, 4, 1), (20001, 288, 8, 1)])
+def test_wgrad_is_the_transposed_product(K, M, Nc, batch):
+    """ggnn_wgrad (C = A^T B, reduction over the nodes split across the chip) against the fp64 product: operands
+    with row pitches wider than the used columns, batches addressed by element offsets, K not a multiple of the
+    4-row MFMA group (and shorter than the register ring), Nc / M below and not a multiple of the wave's block.  The
+    bound is that of an fp32 dot product (3e-6 of sum |a||b|); the result is reproducible bit for bit."""
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(K + M)
+    lda, ldb = M + 8, batch * Nc + 4
+    a = torch.randn(batch, K, lda, generator=g).cuda()
+    b = torch.randn(K, ldb, generator=g).cuda()
+    c = be.wgrad(a, b, K, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)
+    assert c.shape == (batch, M, Nc)
+    for k in range(batch):
+        a64, b64 = a[k, :, :M].double(), b[:, k * Nc:(k + 1) * Nc].double()
+        ref, mag = a64.t() @ b64, a64.abs().t() @ b64.abs()
+        assert bool(((c[k].double() - ref).abs() <= 3e-6 * mag + 1e-30).all()), (k, float((c[k] - ref).abs().max()))
+    assert torch.equal(c, be.wgrad(a, b, K, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc))
+    with pytest.raises(Exception):
+        be.wgrad(a, b, K + 1, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)   # rows beyond the tensor
+    with pytest.raises(Exception):
+        be.wgrad(a, b, K, M, Nc - 1, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)   # Nc % 4 != 0
