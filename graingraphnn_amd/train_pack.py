@@ -1,0 +1,302 @@
+"""Packed weights of one HeteroPGCLSTM cell for the TRAINING path, differentiable.
+
+The cell runs in the packed formulation of the inference path (packing.py): one projection
+per node type whose weight rows are, for all gates and edge types at once, the value rows of lin_value, the
+key-free score rows  M = W_k^T W_q / sqrt(96)  (hidden-state part and the 16-float `u4` tails), the summed
+lin_skip rows + gate bias; the relocation columns of lin_value per edge type; the gate weight (lin_l2 | its bias |
+lin_edge) per node type.  Every entry of these matrices is either a SUM OF UP TO THREE reference parameters or an
+entry of one of three small batched products, so the whole assembly is
+
+    flat2  = [ all parameters | (scale K_ext) Q_ext per edge type | 0 ]        1 cat, 1 gather, 3 bmm
+    packed = flat2[idx3].sum(1)                                                1 gather, 1 sum
+
+with index tables made once per cell configuration, and its backward is the same two gathers through the inverse
+tables plus 6 bmm (`_PackWeights`): ~15 launches each way where recorded torch ops needed ~120.  The tables are
+produced by running the readable definition of the layout (`assemble`) on index tensors; `packed_weights_ops` runs the
+same definition on the parameter values with autograd and is what tests compare the tables with.
+"""
+import math
+from typing import Dict
+
+import torch
+
+from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, node_layout
+
+_KINDS = (("wq", "lin_query", "weight"), ("bq", "lin_query", "bias"), ("wk", "lin_key", "weight"),
+          ("bk", "lin_key", "bias"), ("wv", "lin_value", "weight"), ("bv", "lin_value", "bias"),
+          ("ws", "lin_skip", "weight"), ("bs", "lin_skip", "bias"), ("wl", "lin_l2", "weight"),
+          ("bl", "lin_l2", "bias"), ("we", "lin_edge", "weight"))
+SCALE = 1.0 / math.sqrt(C)   # periodGATconv.py:226
+
+_zero_cache, _ones_cache = {}, {}
+
+
+def _zeros(dev, *shape):
+    """Constant zero blocks (no gradient flows into them): made once."""
+    key = (str(dev), shape)
+    z = _zero_cache.get(key)
+    if z is None:
+        if len(_zero_cache) >= 64:
+            _zero_cache.clear()
+        z = _zero_cache[key] = torch.zeros(*shape, dtype=torch.float32, device=dev)
+    return z
+
+
+def _ones(dev, n, width):
+    """[n, width]: a column of ones followed by zero columns (constant)."""
+    key = (str(dev), n, width)
+    o = _ones_cache.get(key)
+    if o is None:
+        if len(_ones_cache) >= 16:
+            _ones_cache.clear()
+        o = _ones_cache[key] = torch.zeros(n, width, dtype=torch.float32, device=dev)
+        o[:, 0] = 1.0
+    return o
+
+
+def cell_params(cell, gates):
+    """The parameters the cell's forward reads, in the order of the flat buffer: per edge type, per kind, per
+    gate; then the gate biases per node type.  -> (list, {key: (offset, stacked shape [G, *param.shape])})."""
+    plist, table, off = [], {}, 0
+    G = len(gates)
+    for et in EDGE_TYPES:
+        for kind, lin, wb in _KINDS:
+            ts = [getattr(getattr(getattr(cell, "conv_" + g).convs[et_key(et)], lin), wb) for g in gates]
+            table[(et, kind)] = (off, (G,) + tuple(ts[0].shape))
+            off += G * ts[0].numel()
+            plist += ts
+    for nt in NODE_TYPES:
+        ts = [getattr(cell, "b_" + g)[nt] for g in gates]
+        table[("b", nt)] = (off, (G, C))
+        off += G * C
+        plist += ts
+    return plist, table, off
+
+
+def kq_operands(get, F, k2, et):
+    """K_ext [G, Fs + k2 + 2, 96] = rows (W_k^T, b_k, w_edge), Q_ext [G, 96, Fd + k2 + 1] = [W_q | b_q]: their
+    product (times 1/sqrt(96)) holds every key-free score coefficient of the edge type (the encoder cuts the
+    hidden-state columns off the weights)."""
+    Fs, Fd = F[et[0]], F[et[-1]]
+    wq, wk = get(et, "wq")[:, :, :Fd + k2], get(et, "wk")[:, :, :Fs + k2]
+    K = torch.cat([wk.transpose(1, 2), get(et, "bk").unsqueeze(1), get(et, "we").squeeze(-1).unsqueeze(1)], 1)
+    Q = torch.cat([wq, get(et, "bq").unsqueeze(-1)], 2)
+    return K, Q
+
+
+def assemble(get, get_s, mr, zeros, sum_of, F, G, sees_h):
+    """The layout, on values or on indices.  get(et, kind): stacked parameters [G, *shape] that are the single
+    source of an entry; get_s(et, kind) / get_s("b", nt): the same for the terms of a sum; mr(et): the product block
+    [G, Fs + k2 + 2, Fd + k2 + 1]; zeros(*shape); sum_of(list): elementwise sum (HeteroConv aggr='sum').
+    -> (layout, {nt: W [ncols, Fp + k2]}, {nt: b [ncols]}, {et: ep [G, 3, 96]}, {nt: w2 [G, 96, Kg]})."""
+    k2 = C if sees_h else 0
+    layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
+    for nt in NODE_TYPES:
+        lay = node_layout(nt, F[nt], G, EDGE_TYPES, True, sees_h, True)
+        Fn, Fp, D = F[nt], lay.Fp, F[nt] + k2
+        blocks = []                                                  # rows of [W | b]: [n, D + 1]
+        for et in lay.src_ets:                                       # value rows, relocation columns zeroed
+            wvr = get(et, "wv")[:, :, 3:D]
+            blocks.append(torch.cat([zeros(G, C, 3), wvr, get(et, "bv").unsqueeze(-1)], 2).reshape(G * C, D + 1))
+        if sees_h:
+            for et in lay.dst_ets:                                   # hidden-state part of u
+                Fs = F[et[0]]
+                blocks.append(mr(et)[:, Fs:Fs + k2].reshape(G * C, D + 1))
+        ws = sum_of([get_s(et, "ws")[:, :, :D] for et in lay.dst_ets])  # summed skip rows + gate bias
+        bs = sum_of([get_s(et, "bs") for et in lay.dst_ets] + [get_s("b", nt)])
+        blocks.append(torch.cat([ws, bs.unsqueeze(-1)], 2).reshape(G * C, D + 1))
+        for et in lay.dst_ets:                                       # u4 tails: feature part of u, s1, s2 rows
+            Fs, m = F[et[0]], mr(et)
+            tail = torch.cat([m[:, :Fs], zeros(G, 12 - Fs, D + 1), m[:, Fs + k2:Fs + k2 + 2], zeros(G, 2, D + 1)], 1)
+            blocks.append(tail.reshape(G * 16, D + 1))
+        n_rows = sum(b.size(0) for b in blocks)
+        blocks.append(zeros(lay.ncols - n_rows, D + 1))
+        rows = torch.cat(blocks)
+        wp[nt] = torch.cat([rows[:, :Fn], zeros(lay.ncols, Fp - Fn), rows[:, Fn:D]], 1)   # ggnn_project's input order
+        bp[nt] = rows[:, D]
+        layout[nt] = lay
+        n_in = len(lay.dst_ets)
+        w2[nt] = torch.cat([get(et, "wl") for et in lay.dst_ets]
+                           + [torch.cat([get(et, "bl").unsqueeze(-1), get(et, "we")], 2) for et in lay.dst_ets]
+                           + [zeros(G, C, lay.Kg - n_in * (C + 2))], 2)   # [G, 96, Kg]: agg's pad columns meet zeros
+    for et in EDGE_TYPES:
+        ep[et] = get(et, "wv")[:, :, :3].transpose(1, 2)              # [G, 3, 96]
+    return layout, wp, bp, ep, w2
+
+
+def _outputs_in_order(wp, bp, ep, w2):
+    return [wp["grain"], wp["joint"], bp["grain"], bp["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]],
+            ep[EDGE_TYPES[2]], w2["grain"], w2["joint"]]
+
+
+def packed_weights_ops(cell, gates, F, sees_h):
+    """The readable definition: `assemble` on the parameter values, recorded by autograd (~120 launches each way)."""
+    G, k2 = len(gates), (C if sees_h else 0)
+    plist, table, _ = cell_params(cell, gates)
+    flat = torch.cat([p.reshape(-1) for p in plist])
+    get = lambda *key: flat[table[key][0]:table[key][0] + math.prod(table[key][1])].view(table[key][1])
+    dev = flat.device
+    prod = {}
+
+    def mr(et):
+        if et not in prod:
+            K, Q = kq_operands(get, F, k2, et)
+            prod[et] = torch.bmm(K * SCALE, Q)
+        return prod[et]
+    layout, wp, bp, ep, w2 = assemble(get, get, mr, lambda *s: _zeros(dev, *s), lambda ts: sum(ts), F, G, sees_h)
+    return layout, wp, bp, {et: v.contiguous() for et, v in ep.items()}, w2
+
+
+class PackPlan:
+    """Index tables of one cell configuration (feature widths, gates, sees_h), built on the CPU once."""
+
+    def __init__(self, cell, gates, F, sees_h, device):
+        G, k2 = len(gates), (C if sees_h else 0)
+        plist, table, n_flat = cell_params(cell, gates)
+        self.shapes = [tuple(p.shape) for p in plist]
+        self.sizes = [p.numel() for p in plist]
+        self.n_flat = n_flat
+        idx_of = lambda *key: torch.arange(table[key][0], table[key][0] + math.prod(table[key][1])).view(table[key][1])
+        # the products: operand gather (from flat), coefficient (the 1/sqrt(96) on the K side), result blocks
+        self.kq, kq_idx, kq_coef, off_kq, off = {}, [], [], 0, n_flat
+        mr_idx = {}
+        for et in EDGE_TYPES:
+            K, Q = kq_operands(idx_of, F, k2, et)
+            r, c = K.size(1), Q.size(2)
+            self.kq[et] = (off_kq, tuple(K.shape), off_kq + K.numel(), tuple(Q.shape), off, (G, r, c))
+            kq_idx += [K.reshape(-1), Q.reshape(-1)]
+            kq_coef += [torch.full((K.numel(),), SCALE), torch.ones(Q.numel())]
+            off_kq += K.numel() + Q.numel()
+            mr_idx[et] = torch.arange(off, off + G * r * c).view(G, r, c)
+            off += G * r * c
+        self.n_kq, self.zero, self.n_flat2 = off_kq, off, off + 1
+        Z = self.zero
+        blank = lambda *key: torch.full(table[key][1], Z)
+        fill = lambda *shape: torch.full(shape, Z)
+        layers = []
+        for layer in range(3):
+            # term l of a sum sits on layer l; every other entry has its single source on layer 0 and reads the
+            # zero slot on the upper layers
+            sum_of = lambda ts, l=layer: ts[l] if l < len(ts) else torch.full_like(ts[0], Z)
+            if layer == 0:
+                layers.append(assemble(idx_of, idx_of, lambda et: mr_idx[et], fill, sum_of, F, G, sees_h))
+            else:
+                layers.append(assemble(blank, idx_of, lambda et: torch.full_like(mr_idx[et], Z), fill, sum_of, F, G,
+                                       sees_h))
+        self.layout = layers[0][0]
+        outs = [_outputs_in_order(*lay[1:]) for lay in layers]
+        self.out_shapes = [tuple(t.shape) for t in outs[0]]
+        self.out_sizes = [t.numel() for t in outs[0]]
+        idx3 = torch.stack([torch.cat([t.reshape(-1) for t in o]) for o in outs], 1)      # [n_packed, 3]
+        while idx3.size(1) > 1 and bool((idx3[:, -1] == Z).all()):
+            idx3 = idx3[:, :-1]
+        self.n_packed = idx3.size(0)
+        # inverse tables: which packed entries read a flat2 element / which operand entry reads a parameter
+        inv = _inverse(idx3, self.n_flat2, Z, self.n_packed)
+        kq_idx = torch.cat(kq_idx)
+        inv_kq = _inverse(kq_idx.view(-1, 1), n_flat, -1, self.n_kq)
+        to = lambda t: t.to(device)
+        self.idx3, self.kq_idx, self.kq_coef = to(idx3), to(kq_idx), to(torch.cat(kq_coef))
+        self.inv, self.inv_kq = to(inv), to(inv_kq)
+
+
+def _inverse(idx, n_src, skip, n_dst):
+    """idx [n_dst, L] (entries == skip ignored) -> inv [n_src, m]: the positions (row of idx) that read each source
+    element, padded with n_dst (a zero slot behind the gathered vector)."""
+    rows = torch.arange(idx.size(0)).unsqueeze(1).expand_as(idx).reshape(-1)
+    flat = idx.reshape(-1)
+    keep = flat != skip
+    src, dst = flat[keep], rows[keep]
+    order = torch.argsort(src, stable=True)
+    src, dst = src[order], dst[order]
+    counts = torch.bincount(src, minlength=n_src)
+    m = max(int(counts.max()) if counts.numel() else 1, 1)
+    start = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(src.numel()) - start[src]
+    inv = torch.full((n_src, m), n_dst, dtype=torch.int64)
+    inv[src, rank] = dst
+    return inv
+
+
+_plans: Dict[tuple, PackPlan] = {}
+
+
+def pack_plan(cell, gates, F, sees_h, device) -> PackPlan:
+    key = (tuple(sorted(F.items())), gates, sees_h, str(device))
+    p = _plans.get(key)
+    if p is None:
+        p = _plans[key] = PackPlan(cell, gates, F, sees_h, device)
+    return p
+
+
+class _PackWeights(torch.autograd.Function):
+    """(plan, n_used, *parameters) -> the nine packed matrices (views of one buffer).  parameters[n_used:] are
+    read by the reference but contribute nothing (the encoder's forget gate: f * c with c = 0): zero gradient."""
+
+    @staticmethod
+    def forward(ctx, plan, n_used, *params):
+        dev = params[0].device
+        flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
+        torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
+        flat2[plan.zero:].zero_()
+        kq = flat2[plan.kq_idx] * plan.kq_coef
+        for et in EDGE_TYPES:
+            k0, ks, q0, qs, m0, ms = plan.kq[et]
+            torch.bmm(kq[k0:q0].view(ks), kq[q0:q0 + math.prod(qs)].view(qs),
+                      out=flat2[m0:m0 + math.prod(ms)].view(ms))
+        packed = flat2[plan.idx3].sum(1) if plan.idx3.size(1) > 1 else flat2[plan.idx3[:, 0]]
+        ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
+        ctx.save_for_backward(kq)
+        ctx.set_materialize_grads(False)
+        outs = torch.split(packed, plan.out_sizes)
+        return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        kq, = ctx.saved_tensors
+        dev = kq.device
+        g_packed = torch.empty(plan.n_packed + 1, dtype=torch.float32, device=dev)
+        slots = [s.view(sh) for s, sh in zip(torch.split(g_packed[:plan.n_packed], plan.out_sizes), plan.out_shapes)]
+        have = [(s, g) for s, g in zip(slots, grads) if g is not None]
+        if have:
+            torch._foreach_copy_([s for s, _ in have], [g for _, g in have])
+        for s, g in zip(slots, grads):
+            if g is None:
+                s.zero_()
+        g_packed[plan.n_packed:].zero_()
+        g_flat2 = g_packed[plan.inv].sum(1) if plan.inv.size(1) > 1 else g_packed[plan.inv[:, 0]]
+        g_kq = torch.empty(plan.n_kq + 1, dtype=torch.float32, device=dev)
+        for et in EDGE_TYPES:
+            k0, ks, q0, qs, m0, ms = plan.kq[et]
+            K, Q = kq[k0:q0].view(ks), kq[q0:q0 + math.prod(qs)].view(qs)
+            g_m = g_flat2[m0:m0 + math.prod(ms)].view(ms)
+            torch.bmm(g_m, Q.transpose(1, 2), out=g_kq[k0:q0].view(ks))
+            torch.bmm(K.transpose(1, 2), g_m, out=g_kq[q0:q0 + math.prod(qs)].view(qs))
+        g_kq[:plan.n_kq].mul_(plan.kq_coef)
+        g_kq[plan.n_kq:].zero_()
+        g_via_kq = g_kq[plan.inv_kq].sum(1) if plan.inv_kq.size(1) > 1 else g_kq[plan.inv_kq[:, 0]]
+        g_flat = g_flat2[:plan.n_flat] + g_via_kq
+        # every parameter gets a fresh tensor filled by ONE multi-tensor copy: AccumulateGrad adopts it as .grad
+        # without a kernel (views of g_flat would cost a clone per parameter)
+        outs = [g_flat.new_empty(sh) for sh in plan.shapes]
+        torch._foreach_copy_(outs, [p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)])
+        zeros = [g_flat.new_empty(sh) for sh in ctx.unused_shapes]
+        if zeros:
+            torch._foreach_zero_(zeros)
+        return (None, None, *outs, *zeros)
+
+
+def packed_weights(cell, gates, F, sees_h):
+    """-> (layout, wp {nt: [ncols, Fp + k2]}, bp {nt: [ncols]}, ep {et: [G, 3, 96]}, w2 {nt: [G, 96, Kg]}) of the
+    cell, differentiable with respect to every parameter the reference's forward reads."""
+    plist, _, _ = cell_params(cell, gates)
+    # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an exactly zero
+    # gradient; they get one here too, which also keeps DistributedDataParallel(model, device_ids=[rank])
+    # (dist_train.py:82) usable as written.
+    unused = [] if "f" in gates else list(cell.conv_f.parameters()) + list(cell.b_f.parameters())
+    plan = pack_plan(cell, gates, dict(F), sees_h, plist[0].device)
+    o = _PackWeights.apply(plan, len(plist), *plist, *unused)
+    nt_g, nt_j = "grain", "joint"
+    return (plan.layout, {nt_g: o[0], nt_j: o[1]}, {nt_g: o[2], nt_j: o[3]}, dict(zip(EDGE_TYPES, o[4:7])),
+            {nt_g: o[7], nt_j: o[8]})

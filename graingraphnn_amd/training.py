@@ -23,7 +23,8 @@ import torch
 
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
-from .packing import C, EDGE_TYPES, NODE_TYPES, et_key
+from .packing import C, EDGE_TYPES, NODE_TYPES
+from .train_pack import _ones, _zeros, packed_weights
 
 _KG = 128  # row pitch of one gate in the sweep's output: 96 values, sum(alpha), sum(alpha * a), padding
 
@@ -60,151 +61,10 @@ def train_topology(backend, graph) -> TrainTopology:
 
 
 # ---------------------------------------------------------------------------------------
-# The cell in its packed (inference) formulation, differentiable.
-#
-# One projection GEMM per node type produces, for all gates and edge types at once, what the
-# sweeps and the gate stage consume (value rows, key-free score rows u_h / u4, summed skip rows:
-# DESIGN.md section 2, packing.py); its weight matrix is assembled from the reference parameters
-# by differentiable torch ops on weight-sized tensors, so autograd carries the gradient back to
-# every lin_key / lin_query / lin_value / lin_skip / lin_l2 / lin_edge / gate bias.  All parameters
-# of a cell are first gathered into ONE flat buffer (a single cat kernel); every stacked per-gate
-# weight is a view of it.
+# The cell in its packed (inference) formulation, differentiable: the packed matrices come from
+# train_pack.packed_weights (an autograd function of the reference parameters), the cell that
+# consumes them is _PackedCell.
 # ---------------------------------------------------------------------------------------
-_KINDS = (("wq", "lin_query", "weight"), ("bq", "lin_query", "bias"), ("wk", "lin_key", "weight"),
-          ("bk", "lin_key", "bias"), ("wv", "lin_value", "weight"), ("bv", "lin_value", "bias"),
-          ("ws", "lin_skip", "weight"), ("bs", "lin_skip", "bias"), ("wl", "lin_l2", "weight"),
-          ("bl", "lin_l2", "bias"), ("we", "lin_edge", "weight"))
-
-
-class _GatherParams(torch.autograd.Function):
-    """flat = cat(params[:n_used]); params[n_used:] are read by the reference but contribute nothing (zero
-    gradient).  The backward hands every parameter a fresh tensor filled by ONE multi-tensor copy / fill, which
-    AccumulateGrad adopts as .grad without a kernel (views of the flat gradient would cost a clone per parameter)."""
-
-    @staticmethod
-    def forward(ctx, n_used, *params):
-        ctx.shapes, ctx.n_used = [p.shape for p in params], n_used
-        return torch.cat([p.reshape(-1) for p in params[:n_used]])
-
-    @staticmethod
-    def backward(ctx, g_flat):
-        n_used, shapes = ctx.n_used, ctx.shapes
-        outs = [g_flat.new_empty(shape) for shape in shapes]
-        parts = torch.split(g_flat, [math.prod(sh) for sh in shapes[:n_used]])
-        torch._foreach_copy_(outs[:n_used], [p.view(sh) for p, sh in zip(parts, shapes)])
-        if len(outs) > n_used:
-            torch._foreach_zero_(outs[n_used:])
-        return (None, *outs)
-
-
-def _gather_params(cell, gates, unused=()):
-    """All parameters the cell's forward reads, stacked per gate: get(et, kind) -> [G, *param.shape];
-    gate bias get("b", nt) -> [G, 96].  ONE cat kernel gathers them into a flat buffer and ONE
-    split hands out the views (a slice per tensor would cost a full-size zero fill + add each in the
-    backward; the split's backward is a single cat).  `unused`: parameters that get a zero gradient."""
-    G = len(gates)
-    plist, keys, shapes, sizes = [], [], [], []
-    for et in EDGE_TYPES:
-        for kind, lin, wb in _KINDS:
-            ts = [getattr(getattr(getattr(cell, "conv_" + g).convs[et_key(et)], lin), wb) for g in gates]
-            keys.append((et, kind))
-            shapes.append((G,) + tuple(ts[0].shape))
-            sizes.append(G * ts[0].numel())
-            plist += ts
-    for nt in NODE_TYPES:
-        ts = [getattr(cell, "b_" + g)[nt] for g in gates]
-        keys.append(("b", nt))
-        shapes.append((G, C))
-        sizes.append(G * C)
-        plist += ts
-    parts = torch.split(_GatherParams.apply(len(plist), *plist, *unused), sizes)
-    table = {k: part.view(shape) for k, part, shape in zip(keys, parts, shapes)}
-    return lambda *key: table[key]
-
-
-_zero_cache = {}
-
-
-def _zeros(dev, *shape):
-    """Constant zero blocks of the packed matrices (no gradient flows into them): made once."""
-    key = (str(dev), shape)
-    z = _zero_cache.get(key)
-    if z is None:
-        z = _zero_cache[key] = torch.zeros(*shape, dtype=torch.float32, device=dev)
-    return z
-
-
-def _packed_weights(cell, gates, F, sees_h):
-    """-> (layout, wp, bp, ep, w2): the projection weight [ncols, F + k2] / bias [ncols] per node type in
-    the column order of packing.node_layout (value rows, u_h rows, skip rows, u4 tails), the reloc
-    columns of lin_value per edge type [G, 3, 96] and the gate weight [G, 96, Ka] per node type."""
-    from .packing import node_layout
-    G, k2 = len(gates), (C if sees_h else 0)
-    scale = 1.0 / math.sqrt(C)
-    # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an exactly zero
-    # gradient; they are handed to the gather the same way, which also keeps
-    # DistributedDataParallel(model, device_ids=[rank]) (dist_train.py:82) usable as written.
-    unused = () if "f" in gates else list(cell.conv_f.parameters()) + list(cell.b_f.parameters())
-    get = _gather_params(cell, gates, unused)
-    dev = get(EDGE_TYPES[0], "wq").device
-    zeros = lambda *shape: _zeros(dev, *shape)
-    layout, wp, bp, ep, w2 = {}, {}, {}, {}, {}
-    prod = {}
-    cut = lambda t, n, dim: t if t.size(dim) == n else t.narrow(dim, 0, n)   # (the encoder ignores the h columns)
-    wv3, wvr = {}, {}
-    for et in EDGE_TYPES:  # key-free score rows: M = W_k^T W_q / sqrt(96) and friends, per gate
-        Fs, Fd = F[et[0]], F[et[-1]]
-        wq, bq = cut(get(et, "wq"), Fd + k2, 2), get(et, "bq")
-        wk, bk = cut(get(et, "wk"), Fs + k2, 2), get(et, "bk")
-        we = get(et, "we").squeeze(-1)
-        wkt = wk.transpose(1, 2)                                     # [G, Fs + k2, 96]
-        # (splits, not slices: a slice's backward is a full-size zero fill + add, a split's one cat)
-        Mb = torch.bmm(wkt, torch.cat([wq, bq.unsqueeze(-1)], 2)) * scale          # [G, Fs + k2, Fd + k2 + 1]
-        Rb = torch.bmm(torch.stack([bk, we], 1), torch.cat([wq, bq.unsqueeze(-1)], 2)) * scale   # [G, 2, . + 1]: s1, s2 rows
-        if sees_h:
-            Mb_x, Mb_h = torch.split(Mb, [Fs, k2], 1)
-        else:
-            Mb_x, Mb_h = Mb, None
-        tail = torch.cat([Mb_x, zeros(G, 12 - Fs, Fd + k2 + 1), Rb, zeros(G, 2, Fd + k2 + 1)], 1)   # [G, 16, . + 1]
-        prod[et] = (Mb_h, tail)
-        wv3[et], wvr[et] = torch.split(cut(get(et, "wv"), Fs + k2, 2), [3, Fs + k2 - 3], 2)
-    for nt in NODE_TYPES:
-        lay = node_layout(nt, F[nt], G, EDGE_TYPES, True, sees_h, True)
-        Fn, D = F[nt], F[nt] + k2
-        blocks = []                                                  # rows of [W | b]: [n, D + 1]
-        for et in lay.src_ets:                                       # value rows, reloc columns zeroed
-            blocks.append(torch.cat([zeros(G, C, 3), wvr[et], get(et, "bv").unsqueeze(-1)], 2).reshape(G * C, D + 1))
-        if sees_h:
-            for et in lay.dst_ets:                                   # hidden-state part of u
-                blocks.append(prod[et][0].reshape(G * C, D + 1))
-        ws = sum(cut(get(et, "ws"), D, 2) for et in lay.dst_ets)      # HeteroConv aggr 'sum' -> summed skip
-        bs = sum(get(et, "bs") for et in lay.dst_ets) + get("b", nt)
-        blocks.append(torch.cat([ws, bs.unsqueeze(-1)], 2).reshape(G * C, D + 1))
-        for et in lay.dst_ets:
-            blocks.append(prod[et][1].reshape(G * 16, D + 1))
-        n_rows = sum(b.size(0) for b in blocks)
-        blocks.append(zeros(lay.ncols - n_rows, D + 1))
-        wp[nt], bp[nt] = torch.split(torch.cat(blocks), [D, 1], 1)
-        bp[nt] = bp[nt].reshape(-1)
-        layout[nt] = lay
-        n_in = len(lay.dst_ets)
-        w2[nt] = torch.cat([get(et, "wl") for et in lay.dst_ets]
-                           + [torch.cat([get(et, "bl").unsqueeze(-1), get(et, "we")], 2) for et in lay.dst_ets]
-                           + [zeros(G, C, lay.Ka - n_in * (C + 2))], 2)   # [G, 96, Ka]
-    for et in EDGE_TYPES:
-        ep[et] = wv3[et].transpose(1, 2).contiguous()                # [G, 3, 96]
-    return layout, wp, bp, ep, w2
-
-
-def _pad_columns(wp, F, Fp):
-    """[ncols, F + k2] -> [ncols, Fp + k2] (ggnn_project's input order: features padded to a multiple of 4)."""
-    if Fp == F:
-        return wp.contiguous()
-    out = wp.new_zeros(wp.size(0), wp.size(1) + Fp - F)
-    out[:, :F] = wp[:, :F]
-    out[:, Fp:] = wp[:, F:]
-    return out
-
 
 class _PackedCell(torch.autograd.Function):
     """One HeteroPGCLSTM cell (heteropgclstm.py:101-183) on the packed weights, forward and backward written
@@ -219,7 +79,8 @@ class _PackedCell(torch.autograd.Function):
                 gP[u, u4, v], g_h (source side), g_ep  ggnn_period_gat_aggregate_backward per edge type
                 g_[Wp | bp] = gP^T [x | h | 1], g_h += gP Wp[:, h columns]   library GEMMs
 
-    Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j); h / c None = zero state
+    Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j) with the packed matrices as
+    train_pack.packed_weights lays them out (wp [ncols, Fp + k2], w2 [G, 96, Kg]); h / c None = zero state
     (encoder, 3 gates).  x carries no gradient (data).  Everything is fp32, also under bf16 autocast."""
 
     @staticmethod
@@ -230,8 +91,9 @@ class _PackedCell(torch.autograd.Function):
         sees_h = h_g is not None
         h = {"grain": h_g.contiguous() if sees_h else None, "joint": h_j.contiguous() if sees_h else None}
         c = {"grain": c_g.contiguous() if sees_h else None, "joint": c_j.contiguous() if sees_h else None}
-        wp, bp = {"grain": wp_g, "joint": wp_j}, {"grain": bp_g.contiguous(), "joint": bp_j.contiguous()}
-        w2 = {"grain": w2_g, "joint": w2_j}
+        wp, bp = {"grain": wp_g.contiguous(), "joint": wp_j.contiguous()}, {"grain": bp_g.contiguous(),
+                                                                            "joint": bp_j.contiguous()}
+        w2 = {"grain": w2_g.contiguous(), "joint": w2_j.contiguous()}
         ep = dict(zip(EDGE_TYPES, (ep_gj.contiguous(), ep_jg.contiguous(), ep_jj.contiguous())))
         dev, f32 = x_j.device, dict(dtype=torch.float32, device=x_j.device)
         P, agg, w2p = {}, {}, {}
@@ -239,10 +101,9 @@ class _PackedCell(torch.autograd.Function):
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
             P[nt] = torch.empty(n, lay.ncols, **f32)
-            problems.append((x[nt], lay.F, h[nt], _pad_columns(wp[nt], lay.F, lay.Fp), bp[nt], P[nt]))
+            problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt]))
             agg[nt] = torch.zeros(n, G * lay.Kg, **f32)
-            w2p[nt] = w2[nt].contiguous() if lay.Kg == lay.Ka else torch.cat(
-                [w2[nt], _zeros(dev, G, C, lay.Kg - lay.Ka)], 2)   # [G, 96, Kg]: agg's pad columns meet zero weights
+            w2p[nt] = w2[nt]                                        # [G, 96, Kg]: agg's pad columns meet zero weights
         backend.project_batch(problems)
         sweeps = []
         for et in EDGE_TYPES:
@@ -294,7 +155,7 @@ class _PackedCell(torch.autograd.Function):
                                         lay.s_off, g_c[nt])
             a = agg[nt].view(n, G, lay.Kg).transpose(0, 1)                                    # [G, N, Kg]
             g_w2[nt] = backend.wgrad(g_z, agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
-                                     b_bstride=lay.Kg)[:, :, :lay.Ka]                          # [G, 96, Ka]
+                                     b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
             torch.bmm(g_z, w2p[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
         gh_src = {nt: None for nt in NODE_TYPES}
@@ -310,31 +171,16 @@ class _PackedCell(torch.autograd.Function):
         g_wp, g_bp, g_h = {}, {}, {}
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
-            F = lay.F
-            D = F + (C if sees_h else 0)
-            ones = _ones(P[nt].device, n, 1 + (-(D + 1)) % 4)         # [1, 0, ..]: pads [x | h | 1] to 4 k columns
-            xin = torch.cat([x[nt][:, :F], h[nt], ones] if sees_h else [x[nt][:, :F], ones], 1)
-            g_wpb = backend.wgrad(gP[nt], xin, n, lay.ncols, xin.size(1), lay.ncols, xin.size(1))[0]   # [ncols, D + 1 + pad]
-            g_wp[nt], g_bp[nt] = g_wpb[:, :D], g_wpb[:, D]
-            g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, F:]) if sees_h else None      # [N, 96]
+            F, Fp = lay.F, lay.Fp
+            Kp = Fp + (C if sees_h else 0)                              # columns of wp: [x (F) | 0 (Fp - F) | h]
+            parts = [x[nt][:, :F]] + ([_zeros(P[nt].device, n, Fp - F)] if Fp > F else []) + ([h[nt]] if sees_h else [])
+            xin = torch.cat(parts + [_ones(P[nt].device, n, 1 + (-(Kp + 1)) % 4)], 1)   # [.. | 1 | 0 ..]: 4 k columns
+            g_wpb = backend.wgrad(gP[nt], xin, n, lay.ncols, xin.size(1), lay.ncols, xin.size(1))[0]
+            g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
+            g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, Fp:]) if sees_h else None     # [N, 96]
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
                 g_w2["grain"], g_w2["joint"], None, None, None, None, None)
-
-
-_ones_cache = {}
-
-
-def _ones(dev, n, width):
-    """[n, width]: a column of ones followed by zero columns (constant)."""
-    key = (str(dev), n, width)
-    o = _ones_cache.get(key)
-    if o is None:
-        if len(_ones_cache) >= 16:
-            _ones_cache.clear()
-        o = _ones_cache[key] = torch.zeros(n, width, dtype=torch.float32, device=dev)
-        o[:, 0] = 1.0
-    return o
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
@@ -345,7 +191,7 @@ def cell_forward(cell, backend, topo, einfo, x, h, c):
     G = len(gates)
     F = cell.in_channels_dict
     with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
-        layout, wp, bp, ep, w2 = _packed_weights(cell, gates, F, h is not None)
+        layout, wp, bp, ep, w2 = packed_weights(cell, gates, F, h is not None)
     hg, cg, hj, cj = _PackedCell.apply(
         x["grain"], x["joint"], None if h is None else h["grain"], None if h is None else h["joint"],
         None if c is None else c["grain"], None if c is None else c["joint"], wp["grain"], wp["joint"], bp["grain"],

@@ -490,3 +490,42 @@ def test_wgrad_is_the_transposed_product(K, M, Nc, batch):
         be.wgrad(a, b, K + 1, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)   # rows beyond the tensor
     with pytest.raises(Exception):
         be.wgrad(a, b, K, M, Nc - 1, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)   # Nc % 4 != 0
+
+
+@pytest.mark.parametrize("encoder", [True, False])
+def test_index_table_packing_equals_the_recorded_torch_ops(encoder):
+    """train_pack._PackWeights (gathers through index tables + 3 bmm, hand-written backward) against the same
+    layout definition run on the parameter values under autograd: identical packed matrices (bit for bit: every
+    entry is one parameter, a sum in the same order, or the same bmm), gradients of a random functional of all nine
+    outputs to fp32 rounding, exactly zero gradients for the encoder's unused forget gate."""
+    from graingraphnn_amd import train_pack
+    R, _ = product_models(123, 1.0)
+    cell = (R.gclstm_encoder if encoder else R.gclstm_decoder).cell_list[0]
+    gates, sees_h = ("ico", False) if encoder else ("ifco", True)
+    F = cell.in_channels_dict
+    g = torch.Generator().manual_seed(5)
+    res = {}
+    for name, fn in (("tables", train_pack.packed_weights), ("ops", train_pack.packed_weights_ops)):
+        R.zero_grad()
+        layout, wp, bp, ep, w2 = fn(cell, gates, F, sees_h)
+        outs = train_pack._outputs_in_order(wp, bp, ep, w2)
+        if name == "tables":
+            probes = [torch.randn(o.shape, generator=g) for o in outs]
+        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+        res[name] = ([o.detach().clone() for o in outs],
+                     {n: (None if p.grad is None else p.grad.clone()) for n, p in cell.named_parameters()}, layout)
+    for a, b in zip(res["tables"][0], res["ops"][0]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for nt in ("grain", "joint"):
+        assert vars(res["tables"][2][nt]) == vars(res["ops"][2][nt])
+    n_checked = 0
+    for n, gt in res["tables"][1].items():
+        go = res["ops"][1][n]
+        if encoder and (n.startswith("conv_f.") or n.startswith("b_f.")):
+            assert gt is not None and not bool(gt.any()), n         # read by the reference, contributes nothing
+            continue
+        assert gt is not None and go is not None, n
+        scale = max(float(go.abs().max()), 1e-6)
+        assert float((gt - go).abs().max()) <= 2e-6 * scale + 1e-7, n
+        n_checked += 1
+    assert n_checked >= 100
