@@ -125,13 +125,10 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
       const int kc = kc_of(c), ld = kc + 2;
       const bool has_next = p + 1 < NPASS;
       const int gn = (p + 1) / NCH, cn = (p + 1) % NCH;
-#ifndef GT_VAR_NO_STAGE
       if (has_next) load_pass(gn, cn * GT_KC, kc_of(cn));  // in flight during the sweep below
-#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the loads above the sweep (hipcc sinks them otherwise)
       const float* pw = &s_w[p & 1][(third * 32 + lr) * ld + lq];
       const float* px = &s_a[p & 1][rg][lr * ld + lq];
-#ifndef GT_VAR_NO_MFMA
 #pragma unroll 5
       for (int k0 = 0; k0 < kc; k0 += 4) {
         const float xf = px[k0];
@@ -139,12 +136,7 @@ __global__ __launch_bounds__(GT_MAXG * 192, 1) void gates_kernel(const ggnn_epil
         for (int a = 0; a < 2; ++a)
           acc[g][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[a * 16 * ld + k0], xf, acc[g][a], 0, 0, 0);
       }
-#else
-      acc[g][0][0] += pw[0] + px[0];
-#endif
-#ifndef GT_VAR_NO_STAGE
       if (has_next) store_pass((p + 1) & 1, kc_of(cn));  // the other buffer: last read in pass p - 1
-#endif
       __syncthreads();
     }
   }
