@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """One-off GPU fuzz (not collected by pytest): parameter gradients of the HIP training path against
-autograd of the CPU oracle on random Voronoi structures, random targets / masks / labels.
+autograd of the CPU oracle on random Voronoi structures, random targets / masks / labels.  The reference is
+the oracle evaluated in fp64; the fp32 oracle's own distance from it is printed beside the product's.
 Tolerance per parameter tensor: max|g - g_ref| <= 2e-4 * max|g_ref| + 1e-6 * (largest gradient entry).
+Typical worst error 1e-6 of a tensor's scale.  One case in ten shows 2.8e-4 on a small lin_value.weight gradient,
+confined to ONE of its 96 rows: an edge value within rounding of 0 whose relu mask (periodGATconv.py:233) falls on
+the other side in the product's projection arithmetic -- 4.5e-7 of the largest gradient entry, inside the bar.
     python tests/fuzz_training.py [--n 10] [--seed 0]
 """
 import argparse
@@ -20,12 +24,13 @@ from graingraphnn_amd import synthetic, training  # noqa: E402
 JJ = ("joint", "connect", "joint")
 
 
-def grads(R, Cm, x, ei, ea, y, mask, dev):
+def grads(R, Cm, x, ei, ea, y, mask, dev, dtype=torch.float32):
     R.train(), Cm.train()
     R.zero_grad(), Cm.zero_grad()
-    Y, M = tt(y, dev), tt(mask, dev)
-    lr = training.regressor_loss(Y, R(tt(x, dev), tt(ei, dev), tt(ea, dev)), M)
-    lc = training.classifier_loss(Y, Cm(tt(x, dev), tt(ei, dev), tt(ea, dev)), 1.0)
+    cast = lambda d: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in tt(d, dev).items()}
+    Y, M = cast(y), cast(mask)
+    lr = training.regressor_loss(Y, R(cast(x), tt(ei, dev), cast(ea)), M)
+    lc = training.classifier_loss(Y, Cm(cast(x), tt(ei, dev), cast(ea)), 1.0)
     lr.backward()
     lc.backward()
     out = {}
@@ -54,17 +59,26 @@ def main():
         R, Cm = product_models(wseed, scale, "cuda")
         oR, oC = oracle_models(wseed, scale)
         la, lca, ga = grads(R, Cm, x, ei, ea, y, mask, "cuda")
-        lb, lcb, gb = grads(oR, oC, x, ei, ea, y, mask, "cpu")
+        _, _, g32 = grads(oR, oC, x, ei, ea, y, mask, "cpu")
+        lb, lcb, gb = grads(oR.double(), oC.double(), x, ei, ea, y, mask, "cpu", torch.float64)
         assert abs(la - lb) <= 1e-5 * abs(lb) and abs(lca - lcb) <= 1e-5 * abs(lcb), (la, lb, lca, lcb)
         atol = 1e-6 * max(float(g.abs().max()) for g in gb.values())
-        w = 0.0
+        w = w32 = 0.0
+        wname = ""
         for n, g in gb.items():
-            err, sc = float((ga[n] - g).abs().max()), float(g.abs().max())
+            err, sc = float((ga[n].double() - g).abs().max()), float(g.abs().max())
             assert err <= 2e-4 * sc + atol, (it, n, err, sc)
             if sc > 100 * atol:
+                if err / sc > w:
+                    wname = f"{n} (scale {sc / (atol * 1e6):.1e} of the largest gradient)"
+                    if g.dim() == 2:  # a relu mask that flips at a value within rounding of 0 shows as ONE bad row
+                        rows = (ga[n].double() - g).abs().max(1).values
+                        wname += f"; rows above 1e-5 of the scale: {int((rows > 1e-5 * sc).sum())} of {g.size(0)}"
                 w = max(w, err / sc)
+                w32 = max(w32, float((g32[n].double() - g).abs().max()) / sc)
         worst = max(worst, w)
-        print(f"{it:3d} grains {n_gr:4d} weights x{scale}: losses {la:.4f} / {lca:.4f}, worst gradient error {w:.2e}", flush=True)
+        print(f"{it:3d} grains {n_gr:4d} weights x{scale}: losses {la:.4f} / {lca:.4f}, worst gradient error "
+              f"{w:.2e} (fp32 oracle against its fp64 self: {w32:.2e}) at {wname}", flush=True)
     print(f"{args.n} random structures: worst per-tensor relative gradient error {worst:.2e}")
 
 
