@@ -333,6 +333,24 @@ def spawn_ranks(n, argv):
         raise SystemExit(f"--gpus {n} but the job reports n_gpus = {line.get('n_gpus')}")
 
 
+def train_step_records():
+    """BASELINE config 5's kernel path beside the headline: one optimisation step of the regressor (forward, loss,
+    backward, Adam) on the HIP training path, for a collated batch of four 40 um graphs (train.py:365-366's batch) and
+    for the 10k-grain graph, eager and replayed from a hipGraph.  Child processes (tests/bench_train_step.py); a
+    failure leaves a string in the record and never touches the headline."""
+    import subprocess
+    script = os.path.join(ROOT, "tests", "bench_train_step.py")
+    out = []
+    for extra in (["--graph"], ["--graph", "--cfg3"], ["--cfg3"]):
+        try:
+            r = subprocess.run([sys.executable, script, "--no-cpu", "--json", "--steps", "20"] + extra,
+                               capture_output=True, text=True, timeout=300)
+            out.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        except Exception as e:  # noqa: BLE001 -- informational record only
+            out.append({"args": extra, "error": f"{type(e).__name__}: {e}"[:200]})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -532,6 +550,8 @@ def main():
                     line["config"]["native_fp32_gemm_steps_per_s"] = json.loads(r.stdout.strip().splitlines()[-1])["value"]
                 except (ValueError, IndexError, KeyError):
                     line["config"]["native_fp32_gemm_steps_per_s"] = None
+            if not args.events:
+                line["train_step"] = train_step_records()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

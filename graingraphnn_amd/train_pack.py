@@ -7,11 +7,11 @@ lin_skip rows + gate bias; the relocation columns of lin_value per edge type; th
 lin_edge) per node type.  Every entry of these matrices is either a SUM OF UP TO THREE reference parameters or an
 entry of one of three small batched products, so the whole assembly is
 
-    flat2  = [ all parameters | (scale K_ext) Q_ext per edge type | 0 ]        1 cat, 1 gather, 3 bmm
+    flat2  = [ all parameters | (scale K_ext) Q_ext per edge type | 0 ]        1 cat, 1 gather, 1 bmm
     packed = flat2[idx3].sum(1)                                                1 gather, 1 sum
 
 with index tables made once per cell configuration, and its backward is the same two gathers through the inverse
-tables plus 6 bmm (`_PackWeights`): ~15 launches each way where recorded torch ops needed ~120.  The tables are
+tables plus 2 bmm (`_PackWeights`): ~15 launches each way where recorded torch ops needed ~120.  The tables are
 produced by running the readable definition of the layout (`assemble`) on index tensors; `packed_weights_ops` runs the
 same definition on the parameter values with autograd and is what tests compare the tables with.
 """
@@ -167,20 +167,26 @@ class PackPlan:
         self.sizes = [p.numel() for p in plist]
         self.n_flat = n_flat
         idx_of = lambda *key: torch.arange(table[key][0], table[key][0] + math.prod(table[key][1])).view(table[key][1])
-        # the products: operand gather (from flat), coefficient (the 1/sqrt(96) on the K side), result blocks
-        self.kq, kq_idx, kq_coef, off_kq, off = {}, [], [], 0, n_flat
-        mr_idx = {}
-        for et in EDGE_TYPES:
-            K, Q = kq_operands(idx_of, F, k2, et)
-            r, c = K.size(1), Q.size(2)
-            self.kq[et] = (off_kq, tuple(K.shape), off_kq + K.numel(), tuple(Q.shape), off, (G, r, c))
-            kq_idx += [K.reshape(-1), Q.reshape(-1)]
-            kq_coef += [torch.full((K.numel(),), SCALE), torch.ones(Q.numel())]
-            off_kq += K.numel() + Q.numel()
-            mr_idx[et] = torch.arange(off, off + G * r * c).view(G, r, c)
-            off += G * r * c
-        self.n_kq, self.zero, self.n_flat2 = off_kq, off, off + 1
+        # the products, batched over the three edge types: operands padded to common shapes (pad entries read the
+        # zero slot), one bmm [3 G, r, 96] x [3 G, 96, c]; coefficient = the 1/sqrt(96) on the K side
+        ops = [kq_operands(idx_of, F, k2, et) for et in EDGE_TYPES]
+        r_max, c_max = max(K.size(1) for K, _ in ops), max(Q.size(2) for _, Q in ops)
+        nE = len(EDGE_TYPES)
+        n_mr = nE * G * r_max * c_max
+        self.zero, self.n_flat2 = n_flat + n_mr, n_flat + n_mr + 1
         Z = self.zero
+        K_all = torch.full((nE * G, r_max, C), Z)
+        Q_all = torch.full((nE * G, C, c_max), Z)
+        mr_all = torch.arange(n_flat, n_flat + n_mr).view(nE * G, r_max, c_max)
+        mr_idx = {}
+        for e, (et, (K, Q)) in enumerate(zip(EDGE_TYPES, ops)):
+            K_all[e * G:(e + 1) * G, :K.size(1)] = K
+            Q_all[e * G:(e + 1) * G, :, :Q.size(2)] = Q
+            mr_idx[et] = mr_all[e * G:(e + 1) * G, :K.size(1), :Q.size(2)]
+        self.k_shape, self.q_shape, self.mr_shape = tuple(K_all.shape), tuple(Q_all.shape), tuple(mr_all.shape)
+        self.n_k, self.n_kq = K_all.numel(), K_all.numel() + Q_all.numel()
+        kq_idx = torch.cat([K_all.reshape(-1), Q_all.reshape(-1)])
+        kq_coef = torch.cat([torch.full((K_all.numel(),), SCALE), torch.ones(Q_all.numel())])
         blank = lambda *key: torch.full(table[key][1], Z)
         fill = lambda *shape: torch.full(shape, Z)
         layers = []
@@ -203,10 +209,9 @@ class PackPlan:
         self.n_packed = idx3.size(0)
         # inverse tables: which packed entries read a flat2 element / which operand entry reads a parameter
         inv = _inverse(idx3, self.n_flat2, Z, self.n_packed)
-        kq_idx = torch.cat(kq_idx)
-        inv_kq = _inverse(kq_idx.view(-1, 1), n_flat, -1, self.n_kq)
+        inv_kq = _inverse(kq_idx.view(-1, 1), n_flat, Z, self.n_kq)
         to = lambda t: t.to(device)
-        self.idx3, self.kq_idx, self.kq_coef = to(idx3), to(kq_idx), to(torch.cat(kq_coef))
+        self.idx3, self.kq_idx, self.kq_coef = to(idx3), to(kq_idx), to(kq_coef)
         self.inv, self.inv_kq = to(inv), to(inv_kq)
 
 
@@ -250,10 +255,8 @@ class _PackWeights(torch.autograd.Function):
         torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
         flat2[plan.zero:].zero_()
         kq = flat2[plan.kq_idx] * plan.kq_coef
-        for et in EDGE_TYPES:
-            k0, ks, q0, qs, m0, ms = plan.kq[et]
-            torch.bmm(kq[k0:q0].view(ks), kq[q0:q0 + math.prod(qs)].view(qs),
-                      out=flat2[m0:m0 + math.prod(ms)].view(ms))
+        torch.bmm(kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape),
+                  out=flat2[plan.n_flat:plan.zero].view(plan.mr_shape))
         packed = flat2[plan.idx3].sum(1) if plan.idx3.size(1) > 1 else flat2[plan.idx3[:, 0]]
         ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
         ctx.save_for_backward(kq)
@@ -277,12 +280,10 @@ class _PackWeights(torch.autograd.Function):
         g_packed[plan.n_packed:].zero_()
         g_flat2 = g_packed[plan.inv].sum(1) if plan.inv.size(1) > 1 else g_packed[plan.inv[:, 0]]
         g_kq = torch.empty(plan.n_kq + 1, dtype=torch.float32, device=dev)
-        for et in EDGE_TYPES:
-            k0, ks, q0, qs, m0, ms = plan.kq[et]
-            K, Q = kq[k0:q0].view(ks), kq[q0:q0 + math.prod(qs)].view(qs)
-            g_m = g_flat2[m0:m0 + math.prod(ms)].view(ms)
-            torch.bmm(g_m, Q.transpose(1, 2), out=g_kq[k0:q0].view(ks))
-            torch.bmm(K.transpose(1, 2), g_m, out=g_kq[q0:q0 + math.prod(qs)].view(qs))
+        K, Q = kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape)
+        g_m = g_flat2[plan.n_flat:plan.zero].view(plan.mr_shape)          # (pad entries: nobody reads them -> zero)
+        torch.bmm(g_m, Q.transpose(1, 2), out=g_kq[:plan.n_k].view(plan.k_shape))
+        torch.bmm(K.transpose(1, 2), g_m, out=g_kq[plan.n_k:plan.n_kq].view(plan.q_shape))
         g_kq[:plan.n_kq].mul_(plan.kq_coef)
         g_kq[plan.n_kq:].zero_()
         g_via_kq = g_kq[plan.inv_kq].sum(1) if plan.inv_kq.size(1) > 1 else g_kq[plan.inv_kq[:, 0]]

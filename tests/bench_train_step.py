@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cfg3", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
+    ap.add_argument("--json", action="store_true", help="print one JSON line instead of text (bench.py's train_step record)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
     args = ap.parse_args()
@@ -95,6 +96,13 @@ def main():
     Y = {k: torch.from_numpy(v).to(dev) for k, v in y.items()}
     M = {k: torch.from_numpy(v).to(dev) for k, v in mask.items()}
     dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph)
+    if args.json:
+        import json
+        print(json.dumps({"workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
+                          "launch": "hipGraph replay (training.GraphedTrainStep recipe)" if args.graph else "eager",
+                          "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; fp32",
+                          "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}))
+        return
     print(f"{name}: HIP training path{' (bf16 autocast GEMMs)' if args.bf16 else ''}"
           f"{' (hipGraph replay)' if args.graph else ''}: {dt * 1e3:.2f} ms/step, "
           f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
