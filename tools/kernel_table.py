@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Per-step kernel table from rocprofv3 *_kernel_stats.csv files of `bench.py --profile` runs."""
 import csv, sys
-STEPS = 56  # --warmup 4 + RUN_UNROLL 4 + --steps 48
 for f in sys.argv[1:]:
     print(f)
     tot = 0.0
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    # steps of the run (warm-up, settle replays, timed): the regressor's head kernel runs once per step
+    STEPS = max(int(r["Calls"]) for r in rows if "heads_regressor" in r["Name"])
+    for r in rows:
         if "ggnn" not in r["Name"] or "csr_" in r["Name"]:
             continue
         n = r["Name"].split("(")[0].replace("void ", "")
