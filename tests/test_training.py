@@ -529,3 +529,57 @@ def test_index_table_packing_equals_the_recorded_torch_ops(encoder):
         assert float((gt - go).abs().max()) <= 2e-6 * scale + 1e-7, n
         n_checked += 1
     assert n_checked >= 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [4, 3])
+def test_lstm_train_kernels_against_autograd_of_the_update(G):
+    """ggnn_lstm_train_forward / _backward through the C ABI against torch autograd of heteropgclstm.py:140-183's
+    update in fp64: z = gemm + skip is left in the buffer, h', c' to 1e-6; g_z (twice: the [G, N, 96] copy and the
+    skip columns of the projection gradient, other columns untouched) and g_c to 1e-5 of their scale; absent
+    gradients (None) are zeros; bad arguments are refused."""
+    from graingraphnn_amd import _lib
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(G)
+    N, ldp, s_off = 777, 1056, 384
+    gemm = torch.randn(G, N, 96, generator=g)
+    P = torch.randn(N, ldp, generator=g)
+    c_in = torch.randn(N, 96, generator=g) if G == 4 else None
+    g_h, g_c = torch.randn(N, 96, generator=g), torch.randn(N, 96, generator=g)
+    # reference in fp64
+    zr = (gemm.double() + P[:, s_off:s_off + G * 96].double().view(N, G, 96).transpose(0, 1)).requires_grad_(True)
+    cr = None if c_in is None else c_in.double().requires_grad_(True)
+    i, o, ct = torch.sigmoid(zr[0]), torch.sigmoid(zr[G - 1]), torch.tanh(zr[G - 2])
+    c_new = i * ct + (torch.sigmoid(zr[1]) * cr if G == 4 else 0.0)
+    h_new = o * torch.tanh(c_new)
+    for gh, gc in ((g_h, g_c), (g_h, None), (None, g_c)):
+        zr.grad = None
+        if cr is not None:
+            cr.grad = None
+        terms = ([(h_new * gh.double()).sum()] if gh is not None else []) + ([(c_new * gc.double()).sum()] if gc is not None else [])
+        sum(terms).backward(retain_graph=True)
+        z = gemm.clone().cuda()
+        h_out, c_out = torch.empty(N, 96, device="cuda"), torch.empty(N, 96, device="cuda")
+        cin_d = None if c_in is None else c_in.cuda()
+        be.lstm_train_forward(z, P.cuda(), s_off, cin_d, h_out, c_out)
+        assert float((z.double().cpu() - zr.detach()).abs().max()) <= 1e-6
+        assert float((h_out.double().cpu() - h_new.detach()).abs().max()) <= 1e-6
+        assert float((c_out.double().cpu() - c_new.detach()).abs().max()) <= 2e-6
+        g_z = torch.empty_like(z)
+        gP = torch.full((N, ldp), 7.0, device="cuda")
+        g_cin = torch.empty(N, 96, device="cuda") if G == 4 else None
+        be.lstm_train_backward(z, cin_d, c_out, None if gh is None else gh.cuda(), None if gc is None else gc.cuda(),
+                               g_z, gP, s_off, g_cin)
+        scale = float(zr.grad.abs().max())
+        assert float((g_z.double().cpu() - zr.grad).abs().max()) <= 1e-5 * scale
+        assert torch.equal(gP[:, s_off:s_off + G * 96].view(N, G, 96).transpose(0, 1), g_z)
+        assert bool((gP[:, :s_off] == 7.0).all()) and bool((gP[:, s_off + G * 96:] == 7.0).all())
+        if G == 4:
+            assert float((g_cin.double().cpu() - cr.grad).abs().max()) <= 1e-5 * float(cr.grad.abs().max())
+    with pytest.raises(_lib.GGNNError):
+        be.lstm_train_forward(z, P.cuda(), s_off + 2, cin_d, h_out, c_out)                   # s_off % 4 != 0
+    with pytest.raises(_lib.GGNNError):
+        be.lstm_train_forward(z, P.cuda(), ldp - 96, cin_d, h_out, c_out)                    # skip columns beyond the row
+    with pytest.raises(_lib.GGNNError):
+        be.lstm_train_forward(z, P.cuda(), s_off, c_out if G == 3 else None, h_out, c_out)   # c_in must match the gate count
