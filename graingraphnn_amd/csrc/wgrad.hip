@@ -25,6 +25,10 @@ namespace ggnn {
 constexpr int WG_TB = 7;   // 16-column tiles of B per wave: 4 (dwordx4) + 2 (dwordx2) + 1 (dword)
 constexpr int WG_NB = 16 * WG_TB;
 constexpr int WG_U = 4;    // 4-row MFMA groups per pipeline stage
+#ifndef WG_CFG_WAVES
+#define WG_CFG_WAVES 1024
+#endif
+constexpr int WG_WAVES = WG_CFG_WAVES;  // waves a launch aims for (overridable for measurements: make VARIANT=..)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -165,7 +169,7 @@ static WgradPlan wgrad_plan(int64_t K, int M, int Nc, int batch) {
   const int64_t tiles = (int64_t)batch * p.n_mt * p.n_nb;
   // one wave per SIMD of a 256-CU part (the kernel is bound by the matrix pipe: a second wave per SIMD only
   // shares it), the K ranges at least 64 rows long
-  int64_t want = 1024 / tiles;
+  int64_t want = WG_WAVES / tiles;
   const int64_t most = (K + 63) / 64;
   if (want > most) want = most;
   if (want < 1) want = 1;

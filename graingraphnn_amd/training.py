@@ -66,6 +66,20 @@ def train_topology(backend, graph) -> TrainTopology:
 # consumes them is _PackedCell.
 # ---------------------------------------------------------------------------------------
 
+def _wgrad2d(backend, a, b):
+    """a^T b for contiguous a [K, M], b [K, Nc] through ggnn_wgrad, in the cheaper of the two orientations: a wave
+    computes a (32 or 64) x 112 block whatever part of it is inside the matrix, so a narrow factor (the encoder's
+    [x | 1]: 12 columns) belongs on the row side."""
+    K, M, Nc = a.size(0), a.size(1), b.size(1)
+
+    def blocks(m, n):  # 16-row tiles a launch computes for an m x n result (wgrad.hip: wgrad_plan)
+        ta = 4 if m % 64 == 0 or m >= 512 else 2
+        return -(-m // (16 * ta)) * ta * -(-n // 112)
+    if blocks(Nc, M) < blocks(M, Nc):
+        return backend.wgrad(b, a, K, Nc, M, Nc, M)[0].t()
+    return backend.wgrad(a, b, K, M, Nc, M, Nc)[0]
+
+
 class _PackedCell(torch.autograd.Function):
     """One HeteroPGCLSTM cell (heteropgclstm.py:101-183) on the packed weights, forward and backward written
     out by hand so that a cell is ~10 launches forward and ~25 backward with no autograd bookkeeping between them:
@@ -175,7 +189,7 @@ class _PackedCell(torch.autograd.Function):
             Kp = Fp + (C if sees_h else 0)                              # columns of wp: [x (F) | 0 (Fp - F) | h]
             parts = [x[nt][:, :F]] + ([_zeros(P[nt].device, n, Fp - F)] if Fp > F else []) + ([h[nt]] if sees_h else [])
             xin = torch.cat(parts + [_ones(P[nt].device, n, 1 + (-(Kp + 1)) % 4)], 1)   # [.. | 1 | 0 ..]: 4 k columns
-            g_wpb = backend.wgrad(gP[nt], xin, n, lay.ncols, xin.size(1), lay.ncols, xin.size(1))[0]
+            g_wpb = _wgrad2d(backend, gP[nt], xin)                                          # [ncols, Kp + 1 + pad]
             g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
             g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, Fp:]) if sees_h else None     # [N, 96]
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
