@@ -1,22 +1,23 @@
-"""Training path (first stage): a differentiable forward of the same modules.
+"""Training path: a differentiable forward of the same modules.
 
 `GrainNN_regressor.forward` / `GrainNN_classifier.forward` come here when autograd is recording
 and the module is in training mode, i.e. inside the reference's loop (train.py:158-166:
 `model.train(); pred = model(...); loss.backward(); optimizer.step()`).  What runs where:
 
-  * the aggregation (PeriodConv.message + propagate, periodGATconv.py:174-175, 204-236) is the
-    HIP sweep `ggnn_period_gat_aggregate` with its hand-written backward
-    `ggnn_period_gat_aggregate_backward` (segment-softmax backward, relu mask, atomics-free
-    scatter to the source rows) behind one `torch.autograd.Function`;
-  * the dense algebra around it (query / key-transpose / value / l2 / skip linears, the LSTM
-    update, the heads) is plain library GEMMs and pointwise ops on the same device, recorded by
-    autograd.  It uses the key-free form of DESIGN.md section 2 directly on the parameters
-    (u = (W_q x_i + b_q) W_k / sqrt(96)), so gradients reach every reference parameter.
+  * the packed weight matrices of a cell (packing.py's layout) are an autograd function of the reference
+    parameters: index-table gathers + one batched product each way (`train_pack._PackWeights`), so gradients
+    reach every lin_key / lin_query / lin_value / lin_skip / lin_l2 / lin_edge / gate bias;
+  * a cell (heteropgclstm.py:101-183) is ONE autograd function on HIP kernels (`_PackedCell`): the inference
+    projection `ggnn_project_batch`, the sweeps `ggnn_period_gat_aggregate_batch` (PeriodConv.message + propagate,
+    periodGATconv.py:174-175, 204-236) with their hand-written backward `ggnn_period_gat_aggregate_backward`
+    (segment-softmax backward, relu mask, atomics-free scatter to the source rows), the LSTM update
+    `ggnn_lstm_train_forward / _backward`, every weight gradient through the split-K `ggnn_wgrad`; the gate GEMM,
+    its input gradient and the hidden-state gradient of the projection are library GEMMs;
+  * the heads are `_RowLinear` (weight gradient through `ggnn_wgrad`) and a few recorded pointwise ops.
 
-The fused inference kernels (ggnn_project, ggnn_lstm_epilogue, heads) have no backward; they are
-not used here.  Same results as the inference path up to fp32 re-association.
+Everything inside the cell is fp32, also under bf16 autocast.  Same results as the inference path up to fp32
+re-association.
 """
-import math
 from typing import Dict
 
 import torch
@@ -89,9 +90,11 @@ class _PackedCell(torch.autograd.Function):
                 z     = agg W2^T (per gate, batched)   library GEMM
                 h', c' = LSTM(z + skip(P), c)          ggnn_lstm_train_forward
       backward  g_z, gP[skip], g_c                     ggnn_lstm_train_backward
-                g_W2 = g_z^T agg, g_agg = g_z W2       library GEMMs
+                g_W2 = g_z^T agg                       ggnn_wgrad (reduction over the nodes, split over the chip)
+                g_agg = g_z W2                         library GEMM
                 gP[u, u4, v], g_h (source side), g_ep  ggnn_period_gat_aggregate_backward per edge type
-                g_[Wp | bp] = gP^T [x | h | 1], g_h += gP Wp[:, h columns]   library GEMMs
+                g_[Wp | bp] = gP^T [x | h | 1]         ggnn_wgrad
+                g_h += gP Wp[:, h columns]             library GEMM
 
     Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j) with the packed matrices as
     train_pack.packed_weights lays them out (wp [ncols, Fp + k2], w2 [G, 96, Kg]); h / c None = zero state
@@ -109,15 +112,14 @@ class _PackedCell(torch.autograd.Function):
                                                                             "joint": bp_j.contiguous()}
         w2 = {"grain": w2_g.contiguous(), "joint": w2_j.contiguous()}
         ep = dict(zip(EDGE_TYPES, (ep_gj.contiguous(), ep_jg.contiguous(), ep_jj.contiguous())))
-        dev, f32 = x_j.device, dict(dtype=torch.float32, device=x_j.device)
-        P, agg, w2p = {}, {}, {}
+        f32 = dict(dtype=torch.float32, device=x_j.device)
+        P, agg = {}, {}
         problems = []
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
             P[nt] = torch.empty(n, lay.ncols, **f32)
             problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt]))
-            agg[nt] = torch.zeros(n, G * lay.Kg, **f32)
-            w2p[nt] = w2[nt]                                        # [G, 96, Kg]: agg's pad columns meet zero weights
+            agg[nt] = torch.zeros(n, G * lay.Kg, **f32)              # (its pad columns meet zero columns of w2)
         backend.project_batch(problems)
         sweeps = []
         for et in EDGE_TYPES:
@@ -129,13 +131,13 @@ class _PackedCell(torch.autograd.Function):
         z, out = {}, []
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
-            z[nt] = torch.bmm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2p[nt].transpose(1, 2))   # [G, N, 96]
+            z[nt] = torch.bmm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt].transpose(1, 2))    # [G, N, 96]
             h_new, c_new = torch.empty(n, C, **f32), torch.empty(n, C, **f32)
             backend.lstm_train_forward(z[nt], P[nt], lay.s_off, c[nt], h_new, c_new)
             out += [h_new, c_new]
         saved = []
         for nt in NODE_TYPES:
-            saved += [x[nt], h[nt], c[nt], wp[nt], w2p[nt], P[nt], agg[nt], z[nt]]
+            saved += [x[nt], h[nt], c[nt], wp[nt], w2[nt], P[nt], agg[nt], z[nt]]
         ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES])
         ctx.misc = (backend, topo, layout, G, sees_h)
         ctx.set_materialize_grads(False)
@@ -146,9 +148,9 @@ class _PackedCell(torch.autograd.Function):
     def backward(ctx, g_hg, g_cg, g_hj, g_cj):
         backend, topo, layout, G, sees_h = ctx.misc
         t = ctx.saved_tensors
-        x, h, c, wp, w2p, P, agg, z, c_new = {}, {}, {}, {}, {}, {}, {}, {}, {}
+        x, h, c, wp, w2, P, agg, z, c_new = {}, {}, {}, {}, {}, {}, {}, {}, {}
         for k, nt in enumerate(NODE_TYPES):
-            x[nt], h[nt], c[nt], wp[nt], w2p[nt], P[nt], agg[nt], z[nt] = t[8 * k:8 * k + 8]
+            x[nt], h[nt], c[nt], wp[nt], w2[nt], P[nt], agg[nt], z[nt] = t[8 * k:8 * k + 8]
             c_new[nt] = t[16 + 2 * k + 1]
         ep = dict(zip(EDGE_TYPES, t[20:23]))
         einfo = dict(zip(EDGE_TYPES, t[23:26]))
@@ -167,11 +169,10 @@ class _PackedCell(torch.autograd.Function):
             ok = lambda g: None if g is None else g.contiguous()
             backend.lstm_train_backward(z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z, gP[nt],
                                         lay.s_off, g_c[nt])
-            a = agg[nt].view(n, G, lay.Kg).transpose(0, 1)                                    # [G, N, Kg]
             g_w2[nt] = backend.wgrad(g_z, agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
                                      b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
-            torch.bmm(g_z, w2p[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
+            torch.bmm(g_z, w2[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
         gh_src = {nt: None for nt in NODE_TYPES}
         g_ep = {}
         for et in EDGE_TYPES:
