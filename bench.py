@@ -336,12 +336,14 @@ def spawn_ranks(n, argv):
 def train_step_records():
     """BASELINE config 5's kernel path beside the headline: one optimisation step of the regressor (forward, loss,
     backward, Adam) on the HIP training path, for a collated batch of four 40 um graphs (train.py:365-366's batch) and
-    for the 10k-grain graph, eager and replayed from a hipGraph.  Child processes (tests/bench_train_step.py); a
-    failure leaves a string in the record and never touches the headline."""
+    for the 10k-grain graph, eager and replayed from a hipGraph, with the reference's optimizer call
+    (torch.optim.Adam(...): the foreach implementation, ~40 launches over 284 tensors) and with Adam(fused=True) (the
+    same update in one launch).  Child processes (tests/bench_train_step.py); a failure leaves a string in the
+    record and never touches the headline."""
     import subprocess
     script = os.path.join(ROOT, "tests", "bench_train_step.py")
     out = []
-    for extra in (["--graph"], ["--graph", "--cfg3"], ["--cfg3"]):
+    for extra in (["--graph", "--fused"], ["--graph", "--fused", "--cfg3"], ["--graph", "--cfg3"], ["--cfg3"]):
         try:
             r = subprocess.run([sys.executable, script, "--no-cpu", "--json", "--steps", "20"] + extra,
                                capture_output=True, text=True, timeout=300)

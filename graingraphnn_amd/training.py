@@ -300,8 +300,8 @@ def wants_autograd(model) -> bool:
 
 class GraphedTrainStep:
     """One optimisation step of train.py:158-166 (forward, loss, backward, optimizer.step) replayed from
-    a hipGraph.  The eager step is bound by the host (~700 launches: 10.8 ms at the 10k-grain graph, 5.9 ms of
-    it on the GPU); captured once, a step is one graph launch (7.8 ms there, 4.5 ms for a collated batch of
+    a hipGraph.  The eager step is bound by the host (~270 launches: 7 ms at the 10k-grain graph, 3 ms of it on
+    the GPU); captured once, a step is one graph launch (3.8 ms there, 2.2 ms for a collated batch of
     four 40 um graphs).  Static shapes and topology: the inputs are copied into the buffers of the captured
     step, so every call must bring a batch of the captured sizes on the same edge lists (what a fixed-size
     DataLoader batch of one structure family gives; anything else: run the eager step).
@@ -309,9 +309,12 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, optimizer, lambda pred, y: regressor_loss(y, pred, mask), X, EI, EA, Y)
         loss = step(X, EA, Y)            # same tensors or new values of the same shapes
 
-    `optimizer` must be created with `capturable=True` (torch.optim.Adam(..., capturable=True)); the .grad
-    tensors are those of the captured step (its memory pool): valid after every call, replaced by none.  Warm-up (3 eager steps, which DO update the model)
-    and capture (which only records) run on a side stream, PyTorch's whole-network capture recipe."""
+    `optimizer` must be created with `capturable=True` (torch.optim.Adam(..., capturable=True)); add `fused=True`:
+    the default foreach Adam is ~40 launches over the model's 284 parameter tensors and costs 1.3 ms of a replayed
+    step (3.8 -> 2.4 ms at the 10k-grain graph, 2.2 -> 1.0 ms for four 40 um graphs; same update).  The .grad
+    tensors are those of the captured step (its memory pool): valid after every call, replaced by none.  Warm-up
+    (3 eager steps, which DO update the model) and capture (which only records) run on a side stream, PyTorch's
+    whole-network capture recipe."""
 
     def __init__(self, model, optimizer, loss_fn, x_dict, edge_index_dict, edge_attr, y_dict, autocast_dtype=None,
                  warmup: int = 3):

@@ -24,9 +24,9 @@ from graingraphnn_amd.models import GrainNN_regressor  # noqa: E402
 from graingraphnn_amd.seeding import load_seeded  # noqa: E402
 
 
-def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False):
+def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fused=False):
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph, **({"fused": True} if fused else {}))
     losses = []
 
     def one():
@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cfg3", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
+    ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of ~40")
     ap.add_argument("--json", action="store_true", help="print one JSON line instead of text (bench.py's train_step record)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
@@ -95,16 +96,17 @@ def main():
     X, EI, EA = synthetic.to_torch(x, ei, ea, dev)
     Y = {k: torch.from_numpy(v).to(dev) for k, v in y.items()}
     M = {k: torch.from_numpy(v).to(dev) for k, v in mask.items()}
-    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph)
+    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph, args.fused)
     if args.json:
         import json
         print(json.dumps({"workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
                           "launch": "hipGraph replay (training.GraphedTrainStep recipe)" if args.graph else "eager",
                           "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; fp32",
+                          "optimizer": "torch.optim.Adam(fused=True)" if args.fused else "torch.optim.Adam (default: foreach)",
                           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}))
         return
     print(f"{name}: HIP training path{' (bf16 autocast GEMMs)' if args.bf16 else ''}"
-          f"{' (hipGraph replay)' if args.graph else ''}: {dt * 1e3:.2f} ms/step, "
+          f"{' (hipGraph replay)' if args.graph else ''}{' (fused Adam)' if args.fused else ''}: {dt * 1e3:.2f} ms/step, "
           f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     if not args.no_cpu:
         from oracle import grainnn_oracle as oracle
