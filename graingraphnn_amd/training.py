@@ -119,7 +119,12 @@ class _PackedCell(torch.autograd.Function):
             lay, n = layout[nt], x[nt].size(0)
             P[nt] = torch.empty(n, lay.ncols, **f32)
             problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt]))
-            agg[nt] = torch.zeros(n, G * lay.Kg, **f32)              # (its pad columns meet zero columns of w2)
+            # the sweeps write every aggregate and scalar column of every row; the pad columns behind them meet zero
+            # columns of w2 and only have to be finite
+            agg[nt] = torch.empty(n, G * lay.Kg, **f32)
+            used = len(lay.dst_ets) * (C + 2)
+            if used < lay.Kg:
+                agg[nt].view(n, G, lay.Kg)[:, :, used:].zero_()
         backend.project_batch(problems)
         sweeps = []
         for et in EDGE_TYPES:
