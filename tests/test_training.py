@@ -427,10 +427,13 @@ def test_sweep_backward_full_size_properties():
 
 
 @pytest.mark.gpu
-def test_graphed_train_step_follows_the_eager_step():
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_train_step_follows_the_eager_step(fused):
     """training.GraphedTrainStep (forward, loss, backward, Adam replayed from one hipGraph) against the same
     steps run eagerly on a second copy of the model: losses and parameters agree (same kernels, same
-    order: bit for bit), also with new targets copied into the captured buffers."""
+    order), also with new targets copied into the captured buffers, and the .grad tensors of the captured step
+    hold the last step's gradients.  fused: the replayed step with Adam(fused=True) (one optimizer launch) against
+    the eager step with the default foreach Adam."""
     import copy
     from graingraphnn_amd import training
     x, ei, ea = load_graph("40")
@@ -443,7 +446,7 @@ def test_graphed_train_step_follows_the_eager_step():
           for _ in range(2)]
     mask = {nt: torch.ones(x[nt].shape[0], 1, device=dev) for nt in x}
     loss_fn = lambda pred, y: training.regressor_loss(y, pred, mask)
-    optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True)
+    optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True, **({"fused": True} if fused else {}))
     optB = torch.optim.Adam(B.parameters(), lr=1e-3, capturable=True)
     step = training.GraphedTrainStep(A, optA, loss_fn, X, EI, EA, Ys[0], warmup=3)
     B.train()
@@ -460,8 +463,24 @@ def test_graphed_train_step_follows_the_eager_step():
         y = Ys[k % 2]
         la, lb = step(X, EA, y), eager(y)
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (k, float(la), float(lb))
+    gmax = max(float(p.grad.abs().max()) for p in B.parameters())
     for (n, pa), (_, pb) in zip(A.named_parameters(), B.named_parameters()):
-        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), n
+        # Adam moves a weight by ~lr per step whatever the gradient's size: where the gradient is rounding noise
+        # around zero (key biases / weights: a softmax is shift-invariant) the fused and the foreach update may step
+        # in different directions, so those tensors are only held to 7 steps x lr each way
+        d = (pa - pb).abs()
+        if fused:
+            noise = pb.grad.abs() <= 1e-4 * gmax
+            assert float(d[noise].max() if bool(noise.any()) else 0.0) <= 2 * 7 * 1e-3, n
+            d = d[~noise]
+            assert float(d.max() if d.numel() else 0.0) <= 2e-4, n    # (lr 1e-3: a fifth of one step)
+        else:
+            assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), n
+        # (floor relative to the model's largest gradient entry: some gradients are rounding noise around zero, and
+        # the two Adam implementations leave the parameters a rounding apart)
+        assert pa.grad is not None and bool(torch.isfinite(pa.grad).all()), n
+        if not fused:  # (fused: the parameters already differ by up to a step in the noise directions)
+            assert torch.allclose(pa.grad, pb.grad, rtol=1e-3, atol=1e-5 * gmax), n
 
 
 @pytest.mark.gpu
