@@ -19,6 +19,7 @@ import math
 from typing import Dict
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, node_layout
 
@@ -265,6 +266,7 @@ class _PackWeights(torch.autograd.Function):
         return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *grads):
         plan = ctx.plan
         kq, = ctx.saved_tensors

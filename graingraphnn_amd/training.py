@@ -21,6 +21,7 @@ re-association.
 from typing import Dict
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
@@ -149,6 +150,7 @@ class _PackedCell(torch.autograd.Function):
         return tuple(out)                                           # h_grain, c_grain, h_joint, c_joint
 
     @staticmethod
+    @once_differentiable   # (a second derivative through the hand-written backward fails loudly)
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_hg, g_cg, g_hj, g_cj):
         backend, topo, layout, G, sees_h = ctx.misc
@@ -251,6 +253,7 @@ class _RowLinear(torch.autograd.Function):
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
+    @once_differentiable   # (a second derivative through the hand-written backward fails loudly)
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         x, weight = ctx.saved_tensors

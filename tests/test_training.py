@@ -602,3 +602,19 @@ def test_lstm_train_kernels_against_autograd_of_the_update(G):
         be.lstm_train_forward(z, P.cuda(), ldp - 96, cin_d, h_out, c_out)                    # skip columns beyond the row
     with pytest.raises(_lib.GGNNError):
         be.lstm_train_forward(z, P.cuda(), s_off, c_out if G == 3 else None, h_out, c_out)   # c_in must match the gate count
+
+
+def test_second_derivatives_are_refused(monkeypatch):
+    """The cell's backward is hand-written and not itself differentiable: asking for a second derivative
+    (create_graph=True, e.g. a gradient penalty) must fail loudly instead of returning a wrong number."""
+    x, ei, ea = load_graph("40")
+    be = TorchEmulatorBackend()
+    monkeypatch.setattr(training, "default_backend", lambda: be)
+    R, _ = product_models(4, 1.0)
+    R.train()
+    y_np, m_np = _targets(x, ei)
+    loss = training.regressor_loss(tt(y_np), R(tt(x), tt(ei), tt(ea)), tt(m_np))
+    w = R.gclstm_decoder.cell_list[0].conv_i.convs["joint__connect__joint"].lin_l2.weight
+    g, = torch.autograd.grad(loss, w, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiate twice"):
+        g.pow(2).sum().backward()
