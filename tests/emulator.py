@@ -241,9 +241,10 @@ class TorchEmulatorBackend:
                 g_p_dst[:, s_off + g * C: s_off + (g + 1) * C] = g_z[g]
 
     def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0):
-        fa, fb = a.reshape(-1), b.reshape(-1)
-        return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), k * a_bstride).t()
-                            @ torch.as_strided(fb, (K, Nc), (ldb, 1), k * b_bstride) for k in range(batch)])
+        fa, fb = a.reshape(-1), b.reshape(-1)   # (as_strided offsets are absolute in the storage)
+        oa, ob = fa.storage_offset(), fb.storage_offset()
+        return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), oa + k * a_bstride).t()
+                            @ torch.as_strided(fb, (K, Nc), (ldb, 1), ob + k * b_bstride) for k in range(batch)])
 
     def project_batch(self, problems):
         for prob in problems:
