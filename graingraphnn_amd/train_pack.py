@@ -290,10 +290,10 @@ class _PackWeights(torch.autograd.Function):
         g_kq[plan.n_kq:].zero_()
         g_via_kq = g_kq[plan.inv_kq].sum(1) if plan.inv_kq.size(1) > 1 else g_kq[plan.inv_kq[:, 0]]
         g_flat = g_flat2[:plan.n_flat] + g_via_kq
-        # every parameter gets a fresh tensor filled by ONE multi-tensor copy: AccumulateGrad adopts it as .grad
-        # without a kernel (views of g_flat would cost a clone per parameter)
-        outs = [g_flat.new_empty(sh) for sh in plan.shapes]
-        torch._foreach_copy_(outs, [p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)])
+        # every parameter gets a fresh tensor made by ONE multi-tensor op (a functional foreach allocates its results
+        # on the C++ side): AccumulateGrad adopts it as .grad without a kernel (views of g_flat would cost a clone per
+        # parameter, 142 Python-side allocations 0.3 ms of host time per cell)
+        outs = torch._foreach_mul([p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)], 1.0)
         zeros = [g_flat.new_empty(sh) for sh in ctx.unused_shapes]
         if zeros:
             torch._foreach_zero_(zeros)
