@@ -217,11 +217,14 @@ class HipBackend:
                      _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
-                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None):
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None,
+                           ep_partial_out=None):
         """ggnn_period_gat_aggregate_backward (include/ggnn.h).  `rcsr`: CSR of the flipped
         edge_index (grouped by source), `r_slot` [E] int32: forward CSR slot of every reverse slot.
         Returns (g_p_dst, g_p_src, g_h_src or None, g_ep [n_gates, 3, 96]); the gradient tensors
-        have the layout of their operands, columns the sweep does not read are zero."""
+        have the layout of their operands, columns the sweep does not read are zero.
+        `ep_partial_out` [>= aggregate_bwd_partials(n_dst), n_gates, 3, 96]: the per-wave partial sums of g_ep go
+        there and g_ep is returned as None -- the caller sums them (one reduction for the sweeps of a cell)."""
         _require_cuda(csr.rowptr, rcsr.rowptr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg)
         dev = p_src.device
         E, G = csr.E, n_gates
@@ -236,7 +239,13 @@ class HipBackend:
         n_part = self.lib.ggnn_aggregate_bwd_partials(p_dst.size(0))
         f32 = dict(dtype=torch.float32, device=dev)
         scratch = torch.empty(2, max(E, 1) * G, **f32)
-        ep_partial = torch.empty(n_part, G, _lib.GGNN_EDGE_PARAM_ROWS, 96, **f32)
+        if ep_partial_out is None:
+            ep_partial = torch.empty(n_part, G, _lib.GGNN_EDGE_PARAM_ROWS, 96, **f32)
+        else:
+            ep_partial = ep_partial_out
+            if not ep_partial.is_contiguous() or ep_partial.dtype != torch.float32 \
+                    or tuple(ep_partial.shape[1:]) != (G, _lib.GGNN_EDGE_PARAM_ROWS, 96) or ep_partial.size(0) < n_part:
+                raise _lib.GGNNError("ep_partial_out must be a contiguous [>= partials, n_gates, 3, 96] float32 tensor")
         # out_p_dst / out_p_src: zero-initialised gradient buffers shared by the sweeps of a cell (every
         # sweep writes its own columns only)
         g_p_dst = torch.zeros_like(p_dst) if out_p_dst is None else out_p_dst
@@ -255,7 +264,11 @@ class HipBackend:
             v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
         check(self.lib.ggnn_period_gat_aggregate_backward(ctypes.byref(a), _lib.current_stream()),
               "ggnn_period_gat_aggregate_backward")
-        return g_p_dst, g_p_src, g_h_src, ep_partial.sum(0)
+        return g_p_dst, g_p_src, g_h_src, (ep_partial.sum(0) if ep_partial_out is None else None)
+
+    def aggregate_bwd_partials(self, n_dst):
+        """Rows of the partial-sum output one backward call writes (ggnn_aggregate_bwd_partials)."""
+        return self.lib.ggnn_aggregate_bwd_partials(n_dst)
 
     # -- gate GEMM + LSTM --------------------------------------------------------------
     @staticmethod

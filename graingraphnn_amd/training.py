@@ -181,15 +181,18 @@ class _PackedCell(torch.autograd.Function):
             g_agg[nt] = torch.empty_like(agg[nt])
             torch.bmm(g_z, w2[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
         gh_src = {nt: None for nt in NODE_TYPES}
-        g_ep = {}
-        for et in EDGE_TYPES:
+        # the per-wave partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
+        n_part = [backend.aggregate_bwd_partials(x[et[-1]].size(0)) for et in EDGE_TYPES]
+        ep_part = (torch.empty if len(set(n_part)) == 1 else torch.zeros)(len(EDGE_TYPES), max(n_part), G, 3, C, **f32)
+        for k, et in enumerate(EDGE_TYPES):
             s, d = et[0], et[-1]
-            _, _, g_h, g_ep[et] = backend.aggregate_backward(
+            _, _, g_h, _ = backend.aggregate_backward(
                 topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo[et], P[s], P[d], h[s], ep[et], agg[d],
                 g_agg[d], layout[s].v_off[et], layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et],
-                layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s])
+                layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s], ep_partial_out=ep_part[k])
             if g_h is not None:
                 gh_src[s] = g_h if gh_src[s] is None else gh_src[s].add_(g_h)
+        g_ep = dict(zip(EDGE_TYPES, ep_part.sum(1)))
         g_wp, g_bp, g_h = {}, {}, {}
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)

@@ -156,7 +156,8 @@ class TorchEmulatorBackend:
             agg[:, base + sc_off + 1] = sae
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
-                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None):
+                           v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None,
+                           ep_partial_out=None):
         """ggnn_period_gat_aggregate_backward by autograd of the emulated forward.  The reverse
         CSR is checked for what the HIP kernel relies on, then not needed."""
         E = csr.E
@@ -185,7 +186,18 @@ class TorchEmulatorBackend:
         if out_p_src is not None:
             out_p_src[:, v_off:v_off + n_gates * C] = g_p_src[:, v_off:v_off + n_gates * C]
             g_p_src = out_p_src
-        return (g_p_dst, g_p_src, None if hl is None else z(grads[3], h_src), z(grads[2], ep))
+        g_ep = z(grads[2], ep)
+        if ep_partial_out is not None:  # all of it in the first partial, zeros in the others the kernel would write
+            n_part = self.aggregate_bwd_partials(p_dst.size(0))
+            ep_partial_out[:n_part] = 0.0
+            ep_partial_out[0] = g_ep
+            g_ep = None
+        return (g_p_dst, g_p_src, None if hl is None else z(grads[3], h_src), g_ep)
+
+    @staticmethod
+    def aggregate_bwd_partials(n_dst):
+        want = (n_dst + 3) // 4
+        return min(max(want, 1), 512) * 4
 
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
                       w2_planes=None, g_stride=0):
