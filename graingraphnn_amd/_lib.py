@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 15
+GGNN_ABI_VERSION = 16
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
-    "ggnn_wgrad_splits", "ggnn_wgrad",
+    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_heads_regressor_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -211,6 +211,8 @@ def _declare(lib):
     lib.ggnn_wgrad_splits.argtypes = [c_int64, c_int, c_int, c_int]
     lib.ggnn_wgrad.restype = c_int
     lib.ggnn_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
+    lib.ggnn_heads_regressor_backward.restype = c_int
+    lib.ggnn_heads_regressor_backward.argtypes = [c_int64, c_int64] + [c_void_p] * 11
     lib.ggnn_heads_classifier.restype = c_int
     lib.ggnn_heads_classifier.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -354,6 +354,22 @@ class HipBackend:
                                             ptr(b), ptr(y_joint), ptr(y_grain), ptr(grain_area),
                                             _lib.current_stream()), "ggnn_heads_regressor")
 
+    def heads_regressor_backward(self, w, y_joint, y_grain, g_y_joint, g_y_grain, g_grain_area):
+        """ggnn_heads_regressor_backward -> (g_pre_joint [n, 4], g_pre_grain [n, 4], g_h_joint, g_h_grain [n, 96]);
+        the three incoming gradients may be None."""
+        _require_cuda(w, y_joint, y_grain, g_y_joint, g_y_grain, g_grain_area)
+        for t in (w, y_joint, y_grain, g_y_joint, g_y_grain, g_grain_area):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                raise _lib.GGNNError("heads_regressor_backward: contiguous float32 operands")
+        nj, ng = y_joint.size(0), y_grain.size(0)
+        f32 = dict(dtype=torch.float32, device=w.device)
+        gpj, gpg = torch.empty(nj, 4, **f32), torch.empty(ng, 4, **f32)
+        ghj, ghg = torch.empty(nj, 96, **f32), torch.empty(ng, 96, **f32)
+        self._launch(self.lib.ggnn_heads_regressor_backward, "ggnn_heads_regressor_backward", nj, ng, ptr(w), ptr(y_joint),
+                     ptr(y_grain), ptr(g_y_joint), ptr(g_y_grain), ptr(g_grain_area), ptr(gpj), ptr(gpg), ptr(ghj),
+                     ptr(ghg), _lib.current_stream())
+        return gpj, gpg, ghj, ghg
+
     def heads_regressor_update(self, h_joint, h_grain, x_joint, x_grain, w, b, y_joint, y_grain, grain_area, dz, zmax,
                                flags):
         """heads_regressor + step_update in one launch (ggnn_heads_regressor_update)."""

@@ -132,6 +132,43 @@ __global__ __launch_bounds__(256) void heads_classifier_edge_kernel(
   edge_event[e] = ts[2] + td[5] + w_edge[2] * a + w_edge[5];           // models.py:607
 }
 
+// Backward of heads_regressor_kernel (training path): from the gradients of (y_joint, y_grain, grain_area) and the
+// saved outputs the gradient of the pre-activations (4 floats per node, columns 2-3 zero: the [N, 4] operand of
+// ggnn_wgrad for the head weights) and of the hidden states (g_h = g_pre W).  Sixteen lanes own one node.
+__global__ __launch_bounds__(256) void heads_regressor_bwd_kernel(
+    int64_t n_joint, int64_t n_grain, const float* __restrict__ w, const float* __restrict__ y_joint,
+    const float* __restrict__ y_grain, const float* __restrict__ g_yj, const float* __restrict__ g_yg,
+    const float* __restrict__ g_area, float* __restrict__ g_pre_joint, float* __restrict__ g_pre_grain,
+    float* __restrict__ g_h_joint, float* __restrict__ g_h_grain) {
+  const int64_t node = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  if (node >= n_joint + n_grain) return;
+  const bool joint = node < n_joint;
+  const int64_t i = joint ? node : node - n_joint;
+  float p0, p1;
+  if (joint) {
+    const float y0 = y_joint[2 * i], y1 = y_joint[2 * i + 1];
+    p0 = (g_yj ? g_yj[2 * i] : 0.f) * (1.f - y0 * y0);  // models.py:443
+    p1 = (g_yj ? g_yj[2 * i + 1] : 0.f) * (1.f - y1 * y1);
+  } else {
+    const float t0 = y_grain[2 * i];
+    const float gt = (g_yg ? g_yg[2 * i] : 0.f) + (g_area ? g_area[i] / 20.0f : 0.f);  // models.py:445, 450
+    p0 = gt * (1.f - t0 * t0);
+    p1 = y_grain[2 * i + 1] > 0.f ? (g_yg ? g_yg[2 * i + 1] : 0.f) : 0.f;                // :452
+  }
+  float* gp = (joint ? g_pre_joint : g_pre_grain) + 4 * i;
+  if (l16 < 4) gp[l16] = l16 == 0 ? p0 : l16 == 1 ? p1 : 0.f;
+  const float* wr = w + (joint ? 0 : 2 * C);
+  float* gh = (joint ? g_h_joint : g_h_grain) + i * C;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float2 w0 = *reinterpret_cast<const float2*>(wr + 32 * k + 2 * l16);
+    const float2 w1 = *reinterpret_cast<const float2*>(wr + C + 32 * k + 2 * l16);
+    *reinterpret_cast<float2*>(gh + 32 * k + 2 * l16) = make_float2(p0 * w0.x + p1 * w1.x, p0 * w0.y + p1 * w1.y);
+  }
+}
+
+
 }  // namespace ggnn
 
 extern "C" int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const float* h_grain,
@@ -147,6 +184,21 @@ extern "C" int ggnn_heads_regressor(const float* h_joint, int64_t n_joint, const
   hipLaunchKernelGGL(heads_regressor_kernel, dim3((unsigned)nblk), dim3(256), 0,
                      (hipStream_t)stream, h_joint, n_joint, h_grain, n_grain, x_grain, ldx_grain, w,
                      b, y_joint, y_grain, grain_area);
+  return launch_status();
+}
+
+extern "C" int ggnn_heads_regressor_backward(int64_t n_joint, int64_t n_grain, const float* w, const float* y_joint,
+                                             const float* y_grain, const float* g_y_joint, const float* g_y_grain,
+                                             const float* g_grain_area, float* g_pre_joint, float* g_pre_grain,
+                                             float* g_h_joint, float* g_h_grain, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!w || !y_joint || !y_grain || !g_pre_joint || !g_pre_grain || !g_h_joint || !g_h_grain) return GGNN_EINVAL;
+  if (n_joint <= 0 || n_grain <= 0) return GGNN_EINVAL;
+  const int64_t nblk = ((n_joint + n_grain) * 16 + 255) / 256;
+  if (nblk >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(heads_regressor_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, n_joint,
+                     n_grain, w, y_joint, y_grain, g_y_joint, g_y_grain, g_grain_area, g_pre_joint, g_pre_grain,
+                     g_h_joint, g_h_grain);
   return launch_status();
 }
 

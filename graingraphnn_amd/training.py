@@ -268,15 +268,49 @@ class _RowLinear(torch.autograd.Function):
         return g @ weight, gw[:n_out, :n_in], gw[:n_out, n_in], None
 
 
+class _RegressorHeads(torch.autograd.Function):
+    """The regressor's output heads (models.py:427-452): (h_joint, h_grain, x_grain, W_j, b_j, W_g, b_g) ->
+    (y_joint, y_grain, grain_area).  Forward = the inference kernel `ggnn_heads_regressor`; backward =
+    `ggnn_heads_regressor_backward` (pre-activation and hidden-state gradients in one launch) + one `ggnn_wgrad` per
+    node type for the weights and biases: 12 launches each way where the recorded ops needed 32."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, h_joint, h_grain, x_grain, w_j, b_j, w_g, b_g, backend):
+        h_joint, h_grain = h_joint.contiguous(), h_grain.contiguous()
+        w, b = torch.stack([w_j, w_g]), torch.cat([b_j, b_g])             # [2, 2, 96], [4] (packing.pack_regressor_heads)
+        nj, ng = h_joint.size(0), h_grain.size(0)
+        f32 = dict(dtype=torch.float32, device=h_joint.device)
+        y_joint, y_grain, area = torch.empty(nj, 2, **f32), torch.empty(ng, 2, **f32), torch.empty(ng, **f32)
+        backend.heads_regressor(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, area)
+        ctx.save_for_backward(h_joint, h_grain, w, y_joint, y_grain)
+        ctx.backend = backend
+        ctx.set_materialize_grads(False)
+        return y_joint, y_grain, area
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_yj, g_yg, g_area):
+        h_joint, h_grain, w, y_joint, y_grain = ctx.saved_tensors
+        be = ctx.backend
+        ok = lambda g: None if g is None else g.contiguous()
+        gpj, gpg, ghj, ghg = be.heads_regressor_backward(w, y_joint, y_grain, ok(g_yj), ok(g_yg), ok(g_area))
+        out = []
+        for gp, h in ((gpj, h_joint), (gpg, h_grain)):   # [g_pre | 0]^T [h | 1 | 0]: weight and bias gradient in one product
+            xin = torch.cat([h, _ones(h.device, h.size(0), 4)], 1)
+            gw = be.wgrad(gp, xin, h.size(0), 4, C + 4, 4, C + 4)[0]
+            out += [gw[:2, :C], gw[:2, C]]
+        return ghj, ghg, None, out[0], out[1], out[2], out[3], None
+
+
 def regressor_forward(model, x_dict, edge_index_dict, edge_attr):
     """GrainNN_regressor.forward (models.py:401-467) with autograd."""
     h, _ = encoder_decoder(model, x_dict, edge_index_dict, edge_attr)
-    be = default_backend()
-    y_joint = torch.tanh(_RowLinear.apply(h["joint"], model.linear["joint"].weight, model.linear["joint"].bias, be))
-    yg = _RowLinear.apply(h["grain"], model.linear["grain"].weight, model.linear["grain"].bias, be)
-    y0 = torch.tanh(yg[:, 0])
-    area = y0 / model.scaling["grain"] + x_dict["grain"][:, 3]
-    y_grain = torch.stack([y0, torch.relu(yg[:, 1])], 1)
+    lin = model.linear
+    y_joint, y_grain, area = _RegressorHeads.apply(h["joint"], h["grain"], x_dict["grain"].detach().contiguous(),
+                                                   lin["joint"].weight, lin["joint"].bias, lin["grain"].weight,
+                                                   lin["grain"].bias, default_backend())
     return {"grain": y_grain, "joint": y_joint, "grain_area": area}
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 15
+#define GGNN_ABI_VERSION 16
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -440,6 +440,15 @@ int ggnn_lstm_train_forward(float* z, const float* p_dst, int64_t ldp, int s_off
 int ggnn_lstm_train_backward(const float* z, const float* c_in, const float* c_out, const float* g_h,
                              const float* g_c, float* g_z, float* g_p_dst, int64_t ldp, int s_off,
                              float* g_c_in, int64_t N, int n_gates, ggnn_stream_t stream);
+
+/* Training path: backward of ggnn_heads_regressor.  From the gradients of (y_joint [n_joint, 2], y_grain [n_grain, 2],
+ * grain_area [n_grain]; any may be NULL = zero) and the forward's saved y_joint / y_grain: g_pre_* [n, 4] = gradient of
+ * the heads' pre-activations (columns 2-3 zero: the operand of ggnn_wgrad for the head weights and biases) and
+ * g_h_* [n, 96] = g_pre W.  w as in the forward. */
+int ggnn_heads_regressor_backward(int64_t n_joint, int64_t n_grain, const float* w, const float* y_joint,
+                                  const float* y_grain, const float* g_y_joint, const float* g_y_grain,
+                                  const float* g_grain_area, float* g_pre_joint, float* g_pre_grain,
+                                  float* g_h_joint, float* g_h_grain, ggnn_stream_t stream);
 
 /* Weight-gradient GEMM of the training path: C[b] = A[b]^T B[b] with a long reduction (K = nodes) and a small
  * M x Nc result -- the gradient of a packed projection ([ncols, F + 97]) or gate ([96, Kg] per gate) weight

@@ -274,6 +274,16 @@ class TorchEmulatorBackend:
         y_grain[:, 0] = t0
         y_grain[:, 1] = torch.relu(yg[:, 1])
 
+    def heads_regressor_backward(self, w, y_joint, y_grain, g_y_joint, g_y_grain, g_grain_area):
+        z = lambda g, like: torch.zeros_like(like) if g is None else g
+        gyj, gyg = z(g_y_joint, y_joint), z(g_y_grain, y_grain)
+        ga = torch.zeros(y_grain.size(0)) if g_grain_area is None else g_grain_area
+        gpj, gpg = torch.zeros(y_joint.size(0), 4), torch.zeros(y_grain.size(0), 4)
+        gpj[:, :2] = gyj * (1 - y_joint * y_joint)
+        gpg[:, 0] = (gyg[:, 0] + ga / 20.0) * (1 - y_grain[:, 0] ** 2)
+        gpg[:, 1] = gyg[:, 1] * (y_grain[:, 1] > 0)
+        return gpj, gpg, gpj[:, :2] @ w[0], gpg[:, :2] @ w[1]
+
     def heads_regressor_update(self, h_joint, h_grain, x_joint, x_grain, w, b, y_joint, y_grain, grain_area, dz, zmax,
                                flags):
         self.heads_regressor(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area)
