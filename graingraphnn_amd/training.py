@@ -356,7 +356,7 @@ class GraphedTrainStep:
 
     `optimizer` must be created with `capturable=True` (torch.optim.Adam(..., capturable=True)); add `fused=True`:
     the default foreach Adam is ~40 launches over the model's 284 parameter tensors and costs 1.3 ms of a replayed
-    step (3.8 -> 2.4 ms at the 10k-grain graph, 2.2 -> 1.0 ms for four 40 um graphs; same update).  The .grad
+    step (3.7 -> 2.3 ms at the 10k-grain graph, 2.2 -> 0.9 ms for four 40 um graphs; same update).  The .grad
     tensors are those of the captured step (its memory pool): valid after every call, replaced by none.  Warm-up
     (3 eager steps, which DO update the model) and capture (which only records) run on a side stream, PyTorch's
     whole-network capture recipe."""
