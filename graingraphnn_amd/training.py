@@ -13,7 +13,9 @@ and the module is in training mode, i.e. inside the reference's loop (train.py:1
     (segment-softmax backward, relu mask, atomics-free scatter to the source rows), the LSTM update
     `ggnn_lstm_train_forward / _backward`, every weight gradient through the split-K `ggnn_wgrad`; the gate GEMM,
     its input gradient and the hidden-state gradient of the projection are library GEMMs;
-  * the heads are `_RowLinear` (weight gradient through `ggnn_wgrad`) and a few recorded pointwise ops.
+  * the regressor's heads are `_RegressorHeads` (the inference head kernel forward, `ggnn_heads_regressor_backward`
+    + `ggnn_wgrad` backward); the classifier's pair heads are `_RowLinear` (weight gradient through `ggnn_wgrad`)
+    and a few recorded pointwise ops.
 
 Everything inside the cell is fp32, also under bf16 autocast.  Same results as the inference path up to fp32
 re-association.
