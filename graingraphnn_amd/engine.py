@@ -30,24 +30,36 @@ class GraphCSR:
             ei = edge_index_dict[et]
             self.edge_index[et] = ei.contiguous()
             self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
-            self.csr[et].n_blocks = _sweep_blocks(self.csr[et].rowptr)
+        self._balanced = False
 
     def n_edges(self, et):
         return self.edge_index[et].size(1)
 
+    def balance(self):
+        """Exact block counts of the fused encoder cell's sweeps (csr.n_blocks; 0 = the kernel's own estimate from
+        n_dst and E) for its workgroup deal: three small reductions and ONE read-back.  For topologies that stay: a
+        rollout whose edge lists change every few steps (events) keeps the estimate -- the read-back would cost more
+        (1.7 ms per edge type behind a busy stream) than the balance gains."""
+        if not self._balanced:
+            counts = torch.stack([_sweep_blocks(self.csr[et].rowptr) for et in EDGE_TYPES]).tolist()
+            for et, n in zip(EDGE_TYPES, counts):
+                self.csr[et].n_blocks = int(n)
+            self._balanced = True
+        return self
 
-def _sweep_blocks(rowptr: torch.Tensor) -> int:
-    """Blocks the fused encoder cell walks for this edge type: per 16-row tile the largest unit count
-    (units of <= 3 edges, an empty row = one unit) among its four groups of 4 rows.  One small reduction
-    and one read-back per topology; only used to balance the workgroups."""
+
+def _sweep_blocks(rowptr: torch.Tensor) -> torch.Tensor:
+    """Blocks the fused encoder cell walks for this edge type (a 0-d int64 tensor on the device): per 16-row tile
+    the largest unit count (units of <= 3 edges, an empty row = one unit) among its four groups of 4 rows.  Only
+    used to balance the workgroups."""
     n = rowptr.numel() - 1
     if n <= 0:
-        return 0
+        return torch.zeros((), dtype=torch.int64, device=rowptr.device)
     n_t = (n + 15) // 16
     deg = (rowptr[1:] - rowptr[:-1]).long()
     nu = torch.clamp((deg + 2) // 3, min=1)
     nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)
-    return int(nu.max(1).values.sum())
+    return nu.max(1).values.sum()
 
 
 _graph_cache: Dict[tuple, GraphCSR] = {}
@@ -61,6 +73,8 @@ def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
                  tuple(edge_index_dict[et].shape)) for et in EDGE_TYPES if et in edge_index_dict)
     key = key + tuple(sorted(n_nodes.items()))
     g = _graph_cache.get(key)
+    if g is not None:
+        g.balance()   # seen before: this topology stays for a while
     if g is None:
         g = GraphCSR(backend, edge_index_dict, n_nodes)
         if len(_graph_cache) >= _GRAPH_CACHE_MAX:

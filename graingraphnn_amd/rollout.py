@@ -112,13 +112,16 @@ class GrainRollout:
             self._graphs = None
             self._graph_fwd = self._graph_ref = None
 
-    def _set_topology(self, edge_index_dict, edge_attr_dict=None):
+    def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
         buffers (refreshed in place every step), the per-edge geometry records and the per-edge
-        outputs.  Called once at construction and after every topological event."""
+        outputs.  Called once at construction and after every topological event (`lasting=False`: the
+        next event may be a step away, the exact workgroup balance is not worth its read-back)."""
         dev = self.x["joint"].device
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
         self.graph = graph_for(self.be, self.edge_index, self.n_nodes)
+        if lasting:
+            self.graph.balance()
         if edge_attr_dict is not None:
             self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
                               for et in EDGE_TYPES}
@@ -339,6 +342,7 @@ class GrainRollout:
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
         if self.use_graph and self._quiet_steps >= 2:
             if getattr(self, attr) is None:
+                self.graph.balance()   # quiet for two steps: worth the read-back now
                 st = torch.cuda.Stream()
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
@@ -410,7 +414,7 @@ class GrainRollout:
         self._live_grain.copy_(torch.from_numpy(self.mask["grain"][:, 0].astype(np.int32)))
         new_ei = {ET_JJ: torch.from_numpy(pp).to(dev), ("joint", "pull", "grain"): torch.from_numpy(pq).to(dev),
                   ("grain", "push", "joint"): torch.from_numpy(np.ascontiguousarray(qp)).to(dev)}
-        self._set_topology(new_ei)
+        self._set_topology(new_ei, lasting=False)
         self._graph_fwd = self._graph_ref = None
         return events, switches
 
