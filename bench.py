@@ -303,6 +303,28 @@ def host_cpu():
     return model, (len(cores) or (os.cpu_count() or 1)), (os.cpu_count() or 1)
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the parent of the rank processes must
+    stay free of GPU state): the kfd topology's nodes with SIMDs, cut down by a HIP_/ROCR_VISIBLE_DEVICES
+    list.  None when the topology cannot be read (the ranks then fail on their own if a device is missing)."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` started plainly (no torchrun): start N rank processes ourselves,
     the way the reference does it (dist_train.py:394-395, mp.spawn(nprocs=device_count); :76-82).
@@ -311,8 +333,9 @@ def spawn_ranks(n, argv):
     and exits non-zero when any rank fails."""
     import socket
     import subprocess
-    if os.environ.get("GGNN_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
-        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
+    visible = visible_gpus()
+    if os.environ.get("GGNN_BENCH_BACKEND", "nccl") == "nccl" and visible is not None and visible < n:
+        raise SystemExit(f"--gpus {n} but only {visible} GPU(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

@@ -123,8 +123,27 @@ class HipBackend:
         """Up to four projections in one launch (ggnn_project_batch); each item is the argument tuple
         of `project`: (x, F, h, wp, bp, out).  All with h or all without."""
         arr = (ProjectArgs * len(problems))()
+        if len({h is None for _, _, h, _, _, _ in problems}) > 1:
+            raise _lib.GGNNError("ggnn_project_batch: every problem with a hidden state or none of them "
+                                 "(problems with k2 = 96 and k2 = 0 cannot share a launch)")
         for a, (x, F, h, wp, bp, out) in zip(arr, problems):
             _require_cuda(x, h, wp, bp, out)
+            # what the C side cannot see behind a raw pointer: dtypes, unit column strides, the weight's shape
+            k2 = 0 if h is None else h.size(1)
+            for t, name in ((x, "x"), (h, "h"), (wp, "wp"), (bp, "bp"), (out, "out")):
+                if t is not None and t.dtype != torch.float32:
+                    raise _lib.GGNNError(f"ggnn_project_batch: {name} must be float32")
+            if x.dim() != 2 or x.stride(1) != 1 or x.size(1) < F or out.dim() != 2 or out.stride(1) != 1:
+                raise _lib.GGNNError("ggnn_project_batch: x [M, >= F] and out [M, ncols] need unit column stride")
+            if h is not None and (h.dim() != 2 or h.stride(1) != 1 or h.size(0) != x.size(0)):
+                raise _lib.GGNNError("ggnn_project_batch: h must be [M, k2] with unit column stride")
+            if not wp.is_contiguous() or wp.dim() != 2 or wp.size(1) != ((F + 3) & ~3) + k2:
+                raise _lib.GGNNError(f"ggnn_project_batch: wp must be contiguous [ncols, roundup4(F) + k2] = "
+                                     f"[*, {((F + 3) & ~3) + k2}], got {tuple(wp.shape)}")
+            if bp.numel() != wp.size(0) or not bp.is_contiguous():
+                raise _lib.GGNNError("ggnn_project_batch: bp must hold ncols contiguous values")
+            if out.size(0) != x.size(0) or out.size(1) < wp.size(0):
+                raise _lib.GGNNError("ggnn_project_batch: out must be [M, >= ncols]")
             a.X, a.Wp, a.bias, a.out = x.data_ptr(), wp.data_ptr(), bp.data_ptr(), out.data_ptr()
             a.H = None if h is None else h.data_ptr()
             a.ldx, a.ldh, a.M, a.ldo = x.stride(0), 0 if h is None else h.stride(0), x.size(0), out.stride(0)
@@ -192,6 +211,8 @@ class HipBackend:
                     or x_dst.dtype != torch.float32 or x_dst.size(0) != p_dst.size(0) or x_dst.stride(1) != 1 \
                     or x_dst.size(1) < ws_t.size(0) - 1:
                 raise _lib.GGNNError("ws_t must be contiguous [F_dst + 1, 288] and x_dst [n_dst, >= F_dst]")
+            if p_dst.dtype != torch.float32 or p_dst.dim() != 2 or p_dst.stride(1) != 1:
+                raise _lib.GGNNError("p_dst must be float32 [n_dst, ldp] with unit column stride")
             n_in, n = len(sweeps), p_dst.size(0)
             if w2.dim() != 3 or w2.size(0) != 3 or w2.size(2) != 96 * n_in + 4 or not w2.is_contiguous():
                 raise _lib.GGNNError("w2 must be contiguous [3, 96, 96 * n_in + 4]")
@@ -206,6 +227,11 @@ class HipBackend:
                     raise _lib.GGNNError("wv_frag must be packing.value_fragments_bias of three gates")
                 if csr.rowptr.numel() != n + 1:
                     raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
+                if einfo.dtype != torch.float32 or not einfo.is_contiguous() or einfo.dim() != 2 \
+                        or einfo.size(1) != _lib.GGNN_EINFO_ROW or einfo.size(0) < csr.E + _lib.GGNN_UNIT_EDGES:
+                    raise _lib.GGNNError("einfo must be contiguous float32 [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
+                if u4_off < 0 or u4_off + 3 * 16 > p_dst.stride(0):
+                    raise _lib.GGNNError("u4_off: the three gates' score tails must lie inside a p_dst row")
                 sw.rowptr, sw.einfo = csr.rowptr.data_ptr(), einfo.data_ptr()
                 sw.wv_frag, sw.E, sw.u4_off, sw.f_src = wvb.data_ptr(), csr.E, u4_off, f_src
                 sw.n_blocks = getattr(csr, "n_blocks", 0) or 0

@@ -30,16 +30,29 @@ def _staging(t: torch.Tensor) -> torch.Tensor:
 
 
 def gather_states(state: Dict[str, torch.Tensor], world: int) -> List[Dict[str, torch.Tensor]]:
-    """All-gather a dict of equally-shaped tensors; returns one dict per rank (rank order)."""
+    """All-gather a dict of tensors whose shapes and dtypes agree across ranks; returns one dict per
+    rank (rank order).  ONE collective whatever the number of keys: the tensors travel as one packed
+    byte buffer (a collective per key would pay the launch + ring latency of a small message each)."""
     if world <= 1 or not dist.is_initialized():
         return [state]
-    out = [dict() for _ in range(world)]
-    for k in sorted(state):
-        t = _staging(state[k])
-        bufs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(bufs, t)
-        for r in range(world):
-            out[r][k] = bufs[r].to(state[k].device)
+    keys = sorted(state)
+    flat, sizes = [], []
+    for k in keys:
+        b = state[k].contiguous().view(-1).view(torch.uint8)
+        sizes.append(b.numel())
+        pad = -b.numel() % 16  # every segment starts 16-byte aligned: it is viewed back as its own dtype
+        flat.append(torch.cat([b, b.new_zeros(pad)]) if pad else b)
+    packed = _staging(torch.cat(flat) if len(flat) > 1 else flat[0])
+    bufs = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(bufs, packed)
+    out = []
+    for r in range(world):
+        d, off = {}, 0
+        for k, n in zip(keys, sizes):
+            ref = state[k]
+            d[k] = bufs[r][off:off + n].to(ref.device).view(ref.dtype).view(ref.shape)
+            off += n + (-n % 16)
+        out.append(d)
     return out
 
 

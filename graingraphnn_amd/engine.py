@@ -11,7 +11,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, _pins
 from .packing import C, EDGE_TYPES, NODE_TYPES, PackedCell
 
 ET = Tuple[str, str, str]
@@ -73,14 +73,14 @@ def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
                  tuple(edge_index_dict[et].shape)) for et in EDGE_TYPES if et in edge_index_dict)
     key = key + tuple(sorted(n_nodes.items()))
     g = _graph_cache.get(key)
-    if g is not None:
-        g.balance()   # seen before: this topology stays for a while
+    if g is not None and not torch.cuda.is_current_stream_capturing():
+        g.balance()   # seen before: this topology stays for a while (one read-back: never inside a capture)
     if g is None:
         g = GraphCSR(backend, edge_index_dict, n_nodes)
         if len(_graph_cache) >= _GRAPH_CACHE_MAX:
             _graph_cache.pop(next(iter(_graph_cache)))
         _graph_cache[key] = g
-    return g
+    return _pins.note(g)
 
 
 class Workspace:

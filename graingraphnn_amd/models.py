@@ -73,7 +73,8 @@ class _GrainNNBase(nn.Module):
         for et in EDGE_TYPES:
             ws.ea[et].copy_(ea[et])
         key = (graph, enc, dec, ws, torch.cuda.current_stream().cuda_stream,
-               tuple((x_dict[nt].data_ptr(), x_dict[nt].stride(0)) for nt in NODE_TYPES))
+               tuple((x_dict[nt].data_ptr(), x_dict[nt].stride(0)) for nt in NODE_TYPES),
+               graph._balanced)   # the exact block balance arrives on a topology's second forward: re-record then
         t = self._tape
         if t is not None and all(a is b for a, b in zip(t[0][:4], key[:4])) and t[0][4:] == key[4:]:
             be.replay(t[1])
@@ -118,7 +119,7 @@ class GrainNN_regressor(_GrainNNBase):
     def forward(self, x_dict, edge_index_dict, edge_attr):
         """Inference (no autograd recording, or `.eval()`): the fused HIP path.  Inside a training
         loop (train.py:158-166) the differentiable path of `training.py`."""
-        if training.wants_autograd(self):
+        if training.wants_autograd(self, x_dict):
             return training.regressor_forward(self, x_dict, edge_index_dict, edge_attr)
         return self._forward_inference(x_dict, edge_index_dict, edge_attr)
 
@@ -173,7 +174,7 @@ class GrainNN_classifier(_GrainNNBase):
         self._live_out = ("joint",)
 
     def forward(self, x_dict, edge_index_dict, edge_attr):
-        if training.wants_autograd(self):
+        if training.wants_autograd(self, x_dict):
             return training.classifier_forward(self, x_dict, edge_index_dict, edge_attr)
         return self._forward_inference(x_dict, edge_index_dict, edge_attr)
 

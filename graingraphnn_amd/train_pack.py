@@ -19,6 +19,8 @@ import math
 from typing import Dict
 
 import torch
+
+from . import _pins
 from torch.autograd.function import once_differentiable
 
 from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, node_layout
@@ -40,7 +42,7 @@ def _zeros(dev, *shape):
         if len(_zero_cache) >= 64:
             _zero_cache.clear()
         z = _zero_cache[key] = torch.zeros(*shape, dtype=torch.float32, device=dev)
-    return z
+    return _pins.note(z)
 
 
 def _ones(dev, n, width):
@@ -52,7 +54,7 @@ def _ones(dev, n, width):
             _ones_cache.clear()
         o = _ones_cache[key] = torch.zeros(n, width, dtype=torch.float32, device=dev)
         o[:, 0] = 1.0
-    return o
+    return _pins.note(o)
 
 
 def cell_params(cell, gates):

@@ -25,6 +25,7 @@ from typing import Dict
 import torch
 from torch.autograd.function import once_differentiable
 
+from . import _pins
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
 from .packing import C, EDGE_TYPES, NODE_TYPES
@@ -61,7 +62,7 @@ def train_topology(backend, graph) -> TrainTopology:
         if len(_topo_cache) >= 8:
             _topo_cache.pop(next(iter(_topo_cache)))
         t = _topo_cache[id(graph)] = TrainTopology(backend, graph)
-    return t
+    return _pins.note(t)
 
 
 # ---------------------------------------------------------------------------------------
@@ -341,8 +342,30 @@ def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
         z[keep], y[keep].to(z.dtype), pos_weight=torch.tensor(pos_weight, device=z.device, dtype=z.dtype))
 
 
-def wants_autograd(model) -> bool:
-    return torch.is_grad_enabled() and model.training and any(p.requires_grad for p in model.parameters())
+_warned_eval_grad = False
+
+
+def wants_autograd(model, x_dict=None) -> bool:
+    """The differentiable path is taken in training mode with autograd recording (train.py:158-166).  In
+    `.eval()` mode the forward is the fused inference path and its outputs carry no grad_fn -- unlike the
+    reference, which is differentiable in either mode: asking for input gradients there is refused, and a
+    forward in eval mode with autograd recording warns once (wrap inference in torch.no_grad(), as test.py:240
+    does, or call model.train() to differentiate)."""
+    global _warned_eval_grad
+    if not torch.is_grad_enabled():
+        return False
+    if x_dict is not None and any(torch.is_tensor(v) and v.requires_grad for v in x_dict.values()):
+        raise NotImplementedError("gradients with respect to x_dict are not built (the reference's training "
+                                  "loop never asks for them, train.py:158-166): detach the inputs")
+    if model.training:
+        return any(p.requires_grad for p in model.parameters())
+    if not _warned_eval_grad and any(p.requires_grad for p in model.parameters()):
+        _warned_eval_grad = True
+        import warnings
+        warnings.warn("graingraphnn_amd: forward in .eval() mode with autograd recording takes the fused "
+                      "inference path, whose outputs have no grad_fn; use torch.no_grad() for inference or "
+                      "model.train() to differentiate", stacklevel=3)
+    return False
 
 
 class GraphedTrainStep:
@@ -371,17 +394,25 @@ class GraphedTrainStep:
         self.ea = {k: v.detach().clone() for k, v in edge_attr.items()}
         self.y = {k: v.detach().clone() for k, v in y_dict.items()}
         self.autocast_dtype = autocast_dtype
+        if warmup < 1:
+            raise ValueError("GraphedTrainStep needs at least one eager warm-up step before the capture")
         model.train()
+        # Everything the captured launches read out of the package's evictable caches (constant blocks, CSR and
+        # reverse-CSR tables) is pinned here for the lifetime of the step object: the graph holds raw addresses.
+        self._pins = []
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(s), _pins.collect(self._pins):
             for _ in range(warmup):
                 self._eager()
+            # the topology's exact block balance is one read-back: take it now, never inside the capture
+            graph_for(default_backend(), self.ei, {nt: self.x[nt].size(0) for nt in NODE_TYPES}).balance()
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):
                 self._loss = self._eager()
         torch.cuda.current_stream().wait_stream(s)
+        self._pins = list({id(o): o for o in self._pins}.values())
 
     def _eager(self):
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):

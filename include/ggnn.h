@@ -121,7 +121,8 @@ int ggnn_project(const float* X, int64_t ldx, int F, const float* H, int64_t ldh
                  int64_t ldo, ggnn_stream_t stream);
 /* Up to four projections in ONE launch: the node types of one cell and / or the same cell of the
  * regressor and the classifier (both see the same x_dict, test.py:382-383).  Fields as the
- * arguments of ggnn_project; all problems must share k2.  M * max(ldx, ldh, ldo) < 2^31.
+ * arguments of ggnn_project; all problems must share k2.  Rows are addressed with a 64-bit tile base
+ * and 32-bit offsets inside a 16-row tile: 16 * max(ldx, ldh, ldo) < 2^31 is the only size limit.
  * Same result as n single calls. */
 typedef struct ggnn_project_args {
   const float* X;

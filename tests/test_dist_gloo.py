@@ -40,9 +40,13 @@ def _worker(rank, world, port, out):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = run_sharded(N_TRAJ, _run_one, rank, world)
-    states = gather_states({"rank_id": torch.full((3,), float(rank))}, world)
+    # several keys of different dtypes and shapes travel as ONE packed all-gather
+    states = gather_states({"rank_id": torch.full((3,), float(rank)),
+                            "xy": torch.arange(8, dtype=torch.float64).view(4, 2) + rank,
+                            "step": torch.tensor([10 * rank + 1], dtype=torch.int64)}, world)
     if rank == 0:
-        torch.save({"res": res, "ids": [float(s["rank_id"][0]) for s in states]}, out)
+        torch.save({"res": res, "ids": [float(s["rank_id"][0]) for s in states],
+                    "xy": [s["xy"] for s in states], "step": [int(s["step"]) for s in states]}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +64,10 @@ def test_two_rank_gloo_gather(tmp_path):
     out = str(tmp_path / "gathered.pt")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
-    assert got["ids"] == [0.0, 1.0]
+    assert got["ids"] == [0.0, 1.0] and got["step"] == [1, 11]
+    for r in range(2):
+        assert got["xy"][r].dtype == torch.float64 and got["xy"][r].shape == (4, 2)
+        assert torch.equal(got["xy"][r], torch.arange(8, dtype=torch.float64).view(4, 2) + r)
     assert got["res"].shape == ref.shape
     assert np.array_equal(got["res"].numpy(), ref.numpy())  # same code, same seeds -> same bits
 

@@ -15,7 +15,7 @@ import torch
 
 from emulator import TorchEmulatorBackend
 from helpers import EDGE_TYPES, GOLDEN, load_graph, oracle_models, product_models, tt
-from graingraphnn_amd import training
+from graingraphnn_amd import synthetic, training
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 GTOL = 2e-4
@@ -312,6 +312,24 @@ def test_cfg5_collated_minibatch_fp32_and_bf16_against_the_fp32_oracle():
             assert float((p.detach().cpu() - q.detach()).abs().max()) <= bound, (autocast, n, noise_only)
 
 
+@pytest.mark.gpu
+def test_ddp_over_rccl_as_the_reference_wraps_it():
+    """dist_train.py:76-82 on one GPU, over RCCL: init_process_group('nccl', device_id=cuda:0), the packed
+    all-gather of graingraphnn_amd.dist on device buffers, DistributedDataParallel(model, device_ids=[0]) for
+    two iterations with gradients bit-equal to the unwrapped model.  Runs in a child process
+    (tests/rccl_worker.py) so that no communicator outlives the test inside pytest."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker.py"),
+                        str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    print(r.stdout.strip().splitlines()[-1])
+
+
 def _ddp_gpu_worker(rank, world, port, out):
     """One of two ranks that share cuda:0 (the GPU box has one device and RCCL refuses two ranks
     per device, so the process group is gloo; DistributedDataParallel, the bucketed gradient
@@ -481,6 +499,63 @@ def test_graphed_train_step_follows_the_eager_step(fused):
         assert pa.grad is not None and bool(torch.isfinite(pa.grad).all()), n
         if not fused:  # (fused: the parameters already differ by up to a step in the noise directions)
             assert torch.allclose(pa.grad, pb.grad, rtol=1e-3, atol=1e-5 * gmax), n
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_survives_cache_eviction():
+    """The captured step holds raw addresses of tensors that only evictable caches own (constant blocks of
+    train_pack, the reverse CSR of training._topo_cache, the CSR tables of engine._graph_cache).  Between two
+    replays: eager steps on a dozen OTHER topologies of other sizes (more than every cache holds), the allocator's
+    cache emptied and re-filled with garbage.  The replayed steps must still follow the eager steps of a twin
+    model -- the step object pins what its graph reads (graingraphnn_amd/_pins.py)."""
+    import copy
+    from graingraphnn_amd import engine, train_pack, training
+    x, ei, ea = load_graph("40")
+    dev = "cuda"
+    A, _ = product_models(4, 1.0, dev)
+    B = copy.deepcopy(A)
+    X, EI, EA = tt(x, dev), tt(ei, dev), tt(ea, dev)
+    rs = np.random.RandomState(19)
+    Y = {nt: torch.from_numpy(rs.uniform(-1, 1, (x[nt].shape[0], 2)).astype(np.float32)).to(dev) for nt in x}
+    mask = {nt: torch.ones(x[nt].shape[0], 1, device=dev) for nt in x}
+    loss_fn = lambda pred, y: training.regressor_loss(y, pred, mask)
+    optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True)
+    optB = torch.optim.Adam(B.parameters(), lr=1e-3, capturable=True)
+    step = training.GraphedTrainStep(A, optA, loss_fn, X, EI, EA, Y, warmup=2)
+    assert len(step._pins) > 0
+    B.train()
+
+    def eager(model, opt, Xd, EId, EAd, y, m):
+        loss = training.regressor_loss(y, model(Xd, EId, EAd), m)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        eager(B, optB, X, EI, EA, Y, mask)
+    la, lb = step(X, EA, Y), eager(B, optB, X, EI, EA, Y, mask)
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    # a dozen other topologies and batch shapes through the same caches, on a throw-away model
+    T, _ = product_models(5, 1.0, dev)
+    T.train()
+    optT = torch.optim.Adam(T.parameters(), lr=1e-3)
+    for k in range(12):
+        gx, gei, gea = synthetic.voronoi(20 + 3 * k, seed=100 + k)
+        Xk, EIk, EAk = tt(gx, dev), tt(gei, dev), tt(gea, dev)
+        yk = {nt: torch.zeros(gx[nt].shape[0], 2, device=dev) for nt in gx}
+        mk = {nt: torch.ones(gx[nt].shape[0], 1, device=dev) for nt in gx}
+        eager(T, optT, Xk, EIk, EAk, yk, mk)
+    assert len(engine._graph_cache) <= engine._GRAPH_CACHE_MAX and len(training._topo_cache) <= 8
+    del T, optT
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]   # re-use freed blocks, poisoned
+    del junk
+    for k in range(3):
+        la, lb = step(X, EA, Y), eager(B, optB, X, EI, EA, Y, mask)
+        assert np.isfinite(float(la)) and abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (k, float(la), float(lb))
+    for (n, pa), (_, pb) in zip(A.named_parameters(), B.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), n
 
 
 @pytest.mark.gpu
