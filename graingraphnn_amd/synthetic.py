@@ -144,7 +144,27 @@ def voronoi(n_grains: int = 400, seed: int = 0, fold: int = 1, lattice_noise: fl
     return _from_seeds(pts, rs, seed, fold, shuffle_edges, return_offset)
 
 
-def generate(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, span: int = 6,
+_span_grid = None
+
+
+def span_for(G: float, R: float) -> int:
+    """Frame span of a run at thermal gradient G and pulling speed R: the reference's generator does not take it
+    as an argument, it looks it up by nearest neighbour in normalised (G, R) among the 1 441 points of its
+    training grid (graph_trajectory.py:1308-1316: `griddata(..., method='nearest')` on GR_train_grid.pkl, i.e. a
+    k-d tree query).  The table ships as data (graingraphnn_amd/data/gr_span_grid.npz, extracted by
+    tests/golden/make_gr_span_grid.py); pinned to the reference's own expression on 47 (G, R) pairs."""
+    global _span_grid
+    if _span_grid is None:
+        import os
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gr_span_grid.npz"))
+        from scipy.spatial import cKDTree
+        _span_grid = (cKDTree(np.stack([z["G"], z["R"]], 1)), z["span"], z["bounds"])
+    tree, span, (g0, g1, r0, r1) = _span_grid
+    _, k = tree.query(np.array([(G - g0) / (g1 - g0), (R - r0) / (r1 - r0)]))
+    return int(span[k])
+
+
+def generate(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, span: int = None,
              grain_size: float = 4.0, noise: float = 0.01, shuffle_edges: bool = False):
     """Initial grain structure with the interface of the reference's generator
     (`graph_trajectory.py --mode=generate --lxd --seed --G --R`, :1289-1333): a `lxd` x `lxd` um
@@ -163,6 +183,8 @@ def generate(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, s
     reference counts pixels of a 0.08 um raster.  Same distribution, not the same sample:
     tests/test_host_logic.py compares counts, degree histograms, areas and edge lengths with
     fixtures the reference generator produced (tests/golden/generated_40_seed*.npz)."""
+    if span is None:
+        span = span_for(G, R)
     rs = np.random.RandomState(seed)
     dx = grain_size / lxd
     rows, cols = int(1 / dx) + 1, int(1 / dx)

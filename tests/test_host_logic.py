@@ -345,6 +345,21 @@ def _structure_stats(x, ei, ea):
                 len_gj=float(ea[EDGE_TYPES[0]].mean()), len_jj=float(ea[EDGE_TYPES[2]].mean()))
 
 
+def test_span_lookup_matches_the_reference_expression():
+    """the reference's generator takes its frame span from a nearest-neighbour lookup in its (G, R)
+    training grid (graph_trajectory.py:1308-1316).  `synthetic.span_for` on the shipped table against spans the
+    reference's own expression returned (tests/golden/make_gr_span_grid.py): fixtures' parameters, the CLI
+    defaults, the grid's corners and 40 random pairs; and `generate(G, R)` writes that span into its features."""
+    z = np.load(os.path.join(GOLDEN, "gr_span_pins.npz"))
+    assert len(z["GR"]) >= 5
+    for (G, R), s in zip(z["GR"], z["span"]):
+        assert synthetic.span_for(float(G), float(R)) == int(s), (G, R)
+    assert len(set(z["span"].tolist())) > 3          # the pins do exercise different table entries
+    x, _, _ = synthetic.generate(lxd=40, seed=3, G=10.0, R=0.2)
+    want = np.float32(synthetic.span_for(10.0, 0.2) / 120)
+    assert synthetic.span_for(10.0, 0.2) == 60 and np.all(x["grain"][:, 9] == want) and np.all(x["joint"][:, 5] == want)
+
+
 def test_generator_against_the_reference_generator_fixtures():
     """`synthetic.generate` has the interface and the construction of the reference's
     `graph_trajectory.py --mode=generate` (:1289-1333) but its own random streams, so it is compared
