@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 16
+#define GGNN_ABI_VERSION 17
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -340,6 +340,67 @@ typedef struct ggnn_enc_cell_args {
   int32_t n_in, f_dst, Ka, reserved;
 } ggnn_enc_cell_args;
 int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn_stream_t stream);
+
+/* Decoder HeteroPGCLSTM cell (h, c from the encoder; heteropgclstm.py:101-183 with the PeriodConv of
+ * periodGATconv.py:204-236) with EVERYTHING that belongs to a destination node in one kernel: replaces the
+ * destination-side columns of ggnn_project_batch (u_h, u4, S), ggnn_period_gat_aggregate_batch and
+ * ggnn_lstm_epilogue_batch(GGNN_MODE_LSTM) -- same sums up to fp32 re-association.  Only the source-side value
+ * rows V (one ggnn_project_batch with the value rows alone) go through memory; the score operands, the
+ * aggregates and the gates' pre-activations never leave the compute unit.
+ *
+ * A workgroup of four waves owns 64 consecutive destination nodes, one 16-node tile per wave, and walks the
+ * gates in the order i, c~, f, o (the LSTM update is folded in as the gates arrive).  Per gate g and incoming
+ * edge type e a wave (P1) multiplies its tile's [h | x | 1] rows with the (e, g) score weights -> u_h | u4 of its
+ * 16 nodes, (P2) sweeps the tile's in-edges of that edge type (gathers of h_src and V rows, periodic min-image
+ * correction, online-max softmax, relu, alpha-weighted sum: exactly ggnn_period_gat_aggregate's arithmetic),
+ * (P3) multiplies the 16 x 98 aggregate block with lin_l2 | (b_l2, w_edge) of (e, g) into the gate's
+ * pre-activation, then (P4) adds the summed skip term of the gate.  All three GEMMs run on the bf16 matrix cores
+ * with the exact 3-piece split (6 products per k-step, fp32-equivalent) against weights that arrive as k-step
+ * slices of pre-split bf16 planes through a double-buffered LDS region shared by the four waves (LDS-DMA).
+ *
+ * Per incoming edge type:
+ *   rowptr, col : destination-grouped CSR of the edge type (ggnn_build_csr)
+ *   einfo       : edge records in CSR order (ggnn_edge_prepare)
+ *   h_src       : [n_src, ldh_src] hidden state of the source node type
+ *   v_src       : [n_src, ldv] projection of the source node type; columns v_off + g * 96 .. + 95 = the value
+ *                 rows of gate g for this edge type (first three input columns zeroed, as for the sweep)
+ *   edge_params : [4][GGNN_EDGE_PARAM_ROWS][96] = W_value[:, 0..2] per gate
+ * per problem (one destination node type of one model):
+ *   x_dst [n_dst, ldx], h_dst [n_dst, ldh] (the encoder's h), c_in [n_dst, 96]; h_out, c_out [n_dst, 96]
+ *   wstream : the weight slices in the order the kernel consumes them (packing.decoder_cell_stream):
+ *             for g in (i, c~, f, o): for e: 4 slices P1(e, g) | 3 slices P3(e, g); then 4 slices P4(g).
+ *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, mid, lo][64 lanes][8 bf16] --
+ *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles
+ *             (u_h 0..95 | u4 96..111), P3 / P4 six (the tail of their slice is unused).  The reduction index
+ *             of P1 / P4 is [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128, of P3 the 96 aggregate channels
+ *   w2_tail : [4][n_in][6][64] fp32: (b_l2, w_edge) of (g, e) as v_mfma_f32_16x16x4_f32 A fragments
+ *             ([ct][l] = k < 2 ? tail[16 ct + (l & 15)][k = l >> 4] : 0)
+ * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
+ * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
+#define GGNN_DC_SLICE_BYTES 21504 /* 7 column tiles x 3 planes x 1 KB */
+typedef struct ggnn_dec_cell_sweep {
+  const int32_t* rowptr;     /* [n_dst + 1] */
+  const int32_t* col;        /* [E] source node of every edge, CSR order */
+  const float* einfo;        /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] */
+  const float* h_src;        /* [n_src, ldh_src] */
+  const float* v_src;        /* [n_src, ldv] */
+  const float* edge_params;  /* [4][GGNN_EDGE_PARAM_ROWS][96] */
+  int64_t E, n_src, ldh_src, ldv;
+  int32_t v_off, reserved;
+} ggnn_dec_cell_sweep;
+typedef struct ggnn_dec_cell_args {
+  ggnn_dec_cell_sweep in[2];
+  const float* x_dst;    /* [n_dst, ldx] */
+  const float* h_dst;    /* [n_dst, ldh] */
+  const float* c_in;     /* [n_dst, 96] */
+  float* h_out;          /* [n_dst, 96] */
+  float* c_out;          /* [n_dst, 96] */
+  const void* wstream;   /* [n_slices][GGNN_DC_SLICE_BYTES], n_slices = 4 * (7 n_in + 4) */
+  const float* w2_tail;  /* [4][n_in][6][64] */
+  int64_t n_dst, ldx, ldh;
+  int32_t n_in, f_dst;
+} ggnn_dec_cell_args;
+int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads.

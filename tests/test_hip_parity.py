@@ -1060,8 +1060,11 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
                 assert torch.equal(ya[k], yb[k]), (step, k)
             assert torch.equal(ca["edge_event"], cb["edge_event"]) and torch.equal(ca["edge"], cb["edge"])
             R.update(X, ya, None)                    # x_dict changes in place, same tensors
-        # steps 1..3 replay: edge records + 2 cells x (projections, sweeps, gate GEMMs) = 7 launches per model
-        assert replays == [6 if be.fused_encoder else 7] * 6, replays
+        # steps 1..3 replay: edge records + 2 cells x (projections, sweeps, gate GEMMs) = 7 launches per model.
+        # One re-record among them: the topology's exact block balance (engine.GraphCSR.balance) arrives with its
+        # second forward -- the classifier's first call -- and is part of the tape key, so the regressor's tape of
+        # step 0 (recorded with the estimate) is recorded again at step 1; results are the same either way.
+        assert replays == [6 if be.fused_encoder else 7] * 5, replays
         # new weights -> the tape is dropped and re-recorded
         R.linear["joint"].bias.add_(0.5)
         R.gclstm_decoder.cell_list[0].b_i["joint"].add_(0.1)
