@@ -13,11 +13,12 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 16
+GGNN_ABI_VERSION = 17
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 3
+GGNN_DC_SLICE_BYTES = 21504
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
@@ -26,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
+    "ggnn_decoder_cell_batch",
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
@@ -101,6 +103,27 @@ class EncCellArgs(Structure):
         ("h_out", c_void_p), ("c_out", c_void_p), ("x_dst", c_void_p), ("ws_t", c_void_p),
         ("ldp", c_int64), ("n_dst", c_int64), ("ldx", c_int64),
         ("n_in", c_int32), ("f_dst", c_int32), ("Ka", c_int32), ("reserved", c_int32),
+    ]
+
+
+class DecCellSweep(Structure):
+    """Mirror of `ggnn_dec_cell_sweep`."""
+    _fields_ = [
+        ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p), ("h_src", c_void_p), ("v_src", c_void_p),
+        ("edge_params", c_void_p),
+        ("E", c_int64), ("n_src", c_int64), ("ldh_src", c_int64), ("ldv", c_int64),
+        ("v_off", c_int32), ("reserved", c_int32),
+    ]
+
+
+class DecCellArgs(Structure):
+    """Mirror of `ggnn_dec_cell_args`."""
+    _fields_ = [
+        ("sweeps", DecCellSweep * 2),
+        ("x_dst", c_void_p), ("h_dst", c_void_p), ("c_in", c_void_p), ("h_out", c_void_p), ("c_out", c_void_p),
+        ("wstream", c_void_p), ("w2_tail", c_void_p),
+        ("n_dst", c_int64), ("ldx", c_int64), ("ldh", c_int64),
+        ("n_in", c_int32), ("f_dst", c_int32),
     ]
 
 
@@ -183,6 +206,8 @@ def _declare(lib):
     lib.ggnn_period_gat_aggregate_enc_batch.argtypes = [POINTER(AggregateEncArgs), c_int, c_void_p]
     lib.ggnn_encoder_cell_batch.restype = c_int
     lib.ggnn_encoder_cell_batch.argtypes = [POINTER(EncCellArgs), c_int, c_void_p]
+    lib.ggnn_decoder_cell_batch.restype = c_int
+    lib.ggnn_decoder_cell_batch.argtypes = [POINTER(DecCellArgs), c_int, c_void_p]
     lib.ggnn_aggregate_bwd_partials.restype = c_int64
     lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
     lib.ggnn_period_gat_aggregate_backward.restype = c_int

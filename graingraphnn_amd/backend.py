@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, EncCellArgs, EpilogueArgs, PrepareEdge, ProjectArgs,
+from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, DecCellArgs, EncCellArgs, EpilogueArgs, PrepareEdge, ProjectArgs,
                    RefreshEdge, check, ptr)
 
 
@@ -45,6 +45,9 @@ class HipBackend:
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
+        # decoder cell: one fused kernel behind a value-only projection (default), or GGNN_DEC=split: projection with
+        # the destination-side columns + sweeps + gate GEMM (the round-2 path; also what GGNN_GEMM=fp32 runs)
+        self.fused_decoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_DEC", "") != "split")
 
     # -- launch tape: the drop-in forward() issues the same dozen launches with the same arguments
     # step after step (test.py:382-383); re-issuing the recorded C calls skips the per-launch
@@ -240,6 +243,56 @@ class HipBackend:
             a.x_dst, a.ws_t, a.ldx, a.f_dst = x_dst.data_ptr(), ws_t.data_ptr(), x_dst.stride(0), ws_t.size(0) - 1
             a.ldp, a.n_dst, a.n_in, a.Ka = p_dst.stride(0), n, n_in, w2.size(2)
         self._launch(self.lib.ggnn_encoder_cell_batch, "ggnn_encoder_cell_batch", arr, len(problems),
+                     _lib.current_stream())
+
+    def decoder_cell_batch(self, problems):
+        """ggnn_decoder_cell_batch (include/ggnn.h): the decoder cell of up to four (model, destination node type)
+        problems in one launch.  Each item: (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out) with
+        sweeps = [(csr, einfo, h_src, v_src, v_off, edge_params)] for the 1 or 2 incoming edge types; wstream /
+        w2_tail: packing.decoder_cell_stream."""
+        arr = (DecCellArgs * len(problems))()
+        for a, (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
+            _require_cuda(x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
+            n, n_in = x_dst.size(0), len(sweeps)
+            for t, name in ((x_dst, "x_dst"), (h_dst, "h_dst"), (c_in, "c_in"), (h_out, "h_out"), (c_out, "c_out"),
+                            (w2_tail, "w2_tail")):
+                if t.dtype != torch.float32 or t.dim() < 2 or t.stride(-1) != 1:
+                    raise _lib.GGNNError(f"ggnn_decoder_cell_batch: {name} must be float32 with unit column stride")
+            if n_in not in (1, 2) or tuple(h_dst.shape) != (n, 96) or tuple(c_in.shape) != (n, 96) \
+                    or not c_in.is_contiguous() or tuple(h_out.shape) != (n, 96) or not h_out.is_contiguous() \
+                    or tuple(c_out.shape) != (n, 96) or not c_out.is_contiguous():
+                raise _lib.GGNNError("ggnn_decoder_cell_batch: h_dst / c_in / h_out / c_out must be [n_dst, 96] "
+                                     "(c_in, h_out, c_out contiguous), 1 or 2 incoming edge types")
+            if wstream.dtype != torch.int16 or not wstream.is_contiguous() \
+                    or wstream.numel() * 2 != 4 * (7 * n_in + 4) * _lib.GGNN_DC_SLICE_BYTES:
+                raise _lib.GGNNError("ggnn_decoder_cell_batch: wstream is not packing.decoder_cell_stream of this "
+                                     "number of incoming edge types")
+            if tuple(w2_tail.shape) != (4, n_in, 6, 64) or not w2_tail.is_contiguous():
+                raise _lib.GGNNError("ggnn_decoder_cell_batch: w2_tail must be contiguous [4, n_in, 6, 64]")
+            for sw, (csr, einfo, h_src, v_src, v_off, ep) in zip(a.sweeps, sweeps):
+                _require_cuda(csr.rowptr, csr.col, einfo, h_src, v_src, ep)
+                if csr.rowptr.numel() != n + 1:
+                    raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
+                if einfo.dtype != torch.float32 or not einfo.is_contiguous() or einfo.dim() != 2 \
+                        or einfo.size(1) != _lib.GGNN_EINFO_ROW or einfo.size(0) < csr.E + _lib.GGNN_UNIT_EDGES:
+                    raise _lib.GGNNError("einfo must be contiguous float32 [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
+                for t, name in ((h_src, "h_src"), (v_src, "v_src")):
+                    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.size(0) != h_src.size(0):
+                        raise _lib.GGNNError(f"ggnn_decoder_cell_batch: {name} must be float32 [n_src, *] with unit "
+                                             "column stride")
+                if h_src.size(1) < 96 or v_off < 0 or v_off + 4 * 96 > v_src.size(1):
+                    raise _lib.GGNNError("ggnn_decoder_cell_batch: h_src needs 96 columns, the four gates' value rows "
+                                         "must lie inside a v_src row")
+                if ep.dtype != torch.float32 or not ep.is_contiguous() or tuple(ep.shape) != (4, 3, 96):
+                    raise _lib.GGNNError("edge_params must be contiguous float32 [4, 3, 96]")
+                sw.rowptr, sw.col, sw.einfo = csr.rowptr.data_ptr(), csr.col.data_ptr(), einfo.data_ptr()
+                sw.h_src, sw.v_src, sw.edge_params = h_src.data_ptr(), v_src.data_ptr(), ep.data_ptr()
+                sw.E, sw.n_src, sw.ldh_src, sw.ldv, sw.v_off = csr.E, h_src.size(0), h_src.stride(0), v_src.stride(0), v_off
+            a.x_dst, a.h_dst, a.c_in = x_dst.data_ptr(), h_dst.data_ptr(), c_in.data_ptr()
+            a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
+            a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()
+            a.n_dst, a.ldx, a.ldh, a.n_in, a.f_dst = n, x_dst.stride(0), h_dst.stride(0), n_in, x_dst.size(1)
+        self._launch(self.lib.ggnn_decoder_cell_batch, "ggnn_decoder_cell_batch", arr, len(problems),
                      _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,

@@ -1,0 +1,433 @@
+// Decoder HeteroPGCLSTM cell with everything that belongs to a destination node in ONE kernel
+// (ggnn_decoder_cell_batch, include/ggnn.h): the destination-side projections (u_h | u4 per edge type and
+// gate, the summed skip term), the periodic-boundary GAT sweep (PeriodConv.message, periodGATconv.py:204-236,
+// + propagate's gather / scatter-add), lin_l2 + the value-side lin_edge term, HeteroConv's sum over the edge
+// types and the LSTM update (heteropgclstm.py:111-146).  Replaces two thirds of the decoder projection's
+// columns, ggnn_period_gat_aggregate_batch and ggnn_lstm_epilogue_batch: per model forward at the 10k-grain
+// graph 142 MB of u_h / u4 / S rows and 92 MB of aggregates that were written and read back once each.
+//
+// Why it is organised around a 16-node tile per WAVE with the weights streaming past:
+//   * the three GEMMs of a destination node (score weights K = 104, lin_l2 K = 96, skip K = 104) chain through
+//     the MFMA layouts without a transpose when the NODES are the B operand: D[out][node] leaves lane
+//     (node l & 15, out rows 4 (l >> 4) ..+3), and a B fragment wants lane (node l & 15, k = 8 (l >> 4) ..+7);
+//   * the sweep wants the other layout (a node's 96 channels across the 16 lanes of a DPP row: whole 384-byte
+//     rows per gather, dot products closed with four DPP adds), so u and the aggregates cross a wave-private
+//     LDS stage ([16][116] floats) once each way -- 7 KB per wave instead of 57 + 50 KB of u / agg per tile if
+//     all gates were kept at once: the gates are walked ONE AFTER THE OTHER (i, c~, f, o) and the LSTM update is
+//     folded in as they arrive (sig(i) -> sig(i) tanh(c~) -> c' -> h'), so a wave holds one gate's 16 x 96
+//     pre-activations (24 VGPRs) plus the running LSTM term (24), never four;
+//   * the weights of a destination type are 1.25 MB as bf16 planes (joints: 2 x 4 score blocks [112 x 128],
+//     8 lin_l2 blocks, 4 skip blocks) -- eight times the LDS.  They arrive as k-step slices (one 32-deep
+//     k-step of one block: 21 KB) through a double-buffered LDS region shared by the workgroup's four waves,
+//     fetched by LDS-DMA one slice ahead, one workgroup barrier per slice.  Host-side pre-split planes: no
+//     splitting arithmetic on the weight side in the kernel (the gate kernel's split cost 44 VALU per fragment).
+//   * two workgroups per compute unit (80 KB of LDS each, two waves per SIMD) so that one workgroup's sweep
+//     phases (latency-bound gathers) run beside the other's matrix phases.
+// A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
+// and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ggnn {
+
+constexpr int DC_WAVES = 4;
+constexpr int DC_MAX_PROBLEMS = 4;
+constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 21 pieces of 1 KB
+constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
+constexpr int DC_STAGE = 16 * DC_S * 4;             // 7 424 B
+constexpr int DC_XF = 16 * 16 * 4;                  // feature tile [16 nodes][16]
+constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
+constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
+constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
+constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 80 896 B: two workgroups per CU
+static_assert(2 * DC_LDS <= 160 * 1024, "two workgroups per compute unit");
+
+struct DecCellBatch {
+  ggnn_dec_cell_args a[DC_MAX_PROBLEMS];
+  int wg_off[DC_MAX_PROBLEMS + 1];
+  int n;
+};
+
+// LDS-DMA: every lane copies 16 bytes from its own global address to lds_base + lane * 16 (wave-uniform base
+// in M0).  Not tracked by the compiler: completion = s_waitcnt vmcnt (in issue order with every other
+// vector-memory operation of the wave).
+__device__ __forceinline__ void dc_dma16(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+               : "memory");
+}
+
+__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[3]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x4 h = e < 2 ? r0 : r1;
+    uint32_t q0, q1, q2;
+    split_bf16x3(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1, q2);
+    xb[0][e] = q0;
+    xb[1][e] = q1;
+    xb[2][e] = q2;
+  }
+}
+
+// One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
+// lane; piece (nb, plane) at (nb * 3 + plane) * 64).  The three weight fragments of tile nb + 1 are read while the
+// six MFMAs of tile nb run.
+template <int NB>
+__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[3], f32x4 (&acc)[NB]) {
+  u32x4 wf[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) wf[0][p] = pw[p * 64];
+  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (nb + 1 < NB) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[(nb + 1) & 1][p] = pw[((nb + 1) * 3 + p) * 64];
+    }
+    acc[nb] = mfma_x6(wf[nb & 1], xb, acc[nb]);
+    if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                   // MFMA
+  }
+}
+
+__device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const int tileset,
+                                              unsigned char* __restrict__ smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;  // matrix view: node lr of the tile, k-group / output rows 4 kq ..
+  const int ch = 3 * lr;                     // sweep view: lane lr of DPP row kq owns channels ch..ch+2, 48+ch..
+  constexpr int CH2 = C / 2;
+
+  unsigned char* __restrict__ wbase = smem + 2 * DC_SLICE + wave * DC_WAVE_LDS;
+  float* __restrict__ stage = reinterpret_cast<float*>(wbase);
+  float* __restrict__ xf = reinterpret_cast<float*>(wbase + DC_STAGE);
+  int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_STAGE + DC_XF);   // [e][17 + DC_CW]
+  const uint32_t slice_lds =
+      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
+
+  const int n_dst = (int)A.n_dst, n_in = A.n_in, F = A.f_dst;
+  // a ragged last tile slides back over rows the previous tile also produces (identical duplicate results);
+  // tiles past the end (a workgroup's surplus waves) repeat the last one: every wave runs the whole program,
+  // so the workgroup barriers of the slice stream need no special case
+  const int row0 = max(0, min((tileset * DC_WAVES + wave) * 16, n_dst - 16));
+  const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node in the matrix view (n_dst < 16: clamped)
+
+  // ---- the weight stream: slice s -> buffer s & 1, fetched one slice ahead by all four waves ----
+  const int per_gate = 7 * n_in + 4, n_slices = 4 * per_gate;
+  const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(A.wstream) + lane * 16;
+  auto slice_pieces = [&](int s) {   // P1 slices have 7 column tiles, P3 / P4 six
+    const int r = s % per_gate;
+    return (r < 7 * n_in && (r % 7) < 4) ? 21 : 18;
+  };
+  auto dma_slice = [&](int s) {
+    const int np = slice_pieces(s);
+    const unsigned char* src = wsrc + (size_t)s * DC_SLICE;
+    const uint32_t dst = slice_lds + (s & 1) * DC_SLICE;
+    for (int p = wave; p < np; p += DC_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
+  };
+  int s_cur = 0;
+  auto begin_slice = [&]() -> const u32x4* {   // the slice about to be used landed at the previous end_slice
+    if (s_cur + 1 < n_slices) dma_slice(s_cur + 1);
+    return reinterpret_cast<const u32x4*>(smem + (s_cur & 1) * DC_SLICE) + lane;
+  };
+  auto end_slice = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice are in LDS
+    __syncthreads();                                   // ... everybody's are, and nobody reads the old one any more
+    ++s_cur;
+  };
+  dma_slice(0);
+
+  // ---- tile prologue: h rows as B fragments (kept for the whole tile), features -> LDS, CSR windows -> LDS ----
+  f32x4 xh[3][2];
+  {
+    const float* hrow = A.h_dst + (int64_t)node_m * A.ldh + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      xh[ks][0] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks);
+      xh[ks][1] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks + 4);
+    }
+    // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
+    const int fn = lane >> 2, fq = (lane & 3) * 4;
+    const float* xrow = A.x_dst + (int64_t)min(row0 + fn, n_dst - 1) * A.ldx;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xv = xrow[min(fq + j, F - 1)];   // unconditional (clamped) load
+      v[j] = fq + j < F ? xv : (fq + j == F ? 1.0f : 0.0f);
+    }
+    *reinterpret_cast<f32x4*>(&xf[fn * 16 + fq]) = v;
+    for (int e = 0; e < n_in; ++e) {
+      const ggnn_dec_cell_sweep& Sw = A.in[e];
+      int* __restrict__ rp = csr + e * (17 + DC_CW);
+      if (lane < 17) rp[lane] = Sw.rowptr[min(row0 + lane, n_dst)];
+      __builtin_amdgcn_wave_barrier();
+      const int pbase = rp[0], e_last = (int)Sw.E - 1;
+      if (Sw.E > 0) {
+        for (int k = lane; k < DC_CW; k += 64) rp[17 + k] = Sw.col[min(pbase + k, e_last)];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // slice 0 is in LDS
+
+  f32x4 run[6];   // the LSTM update as the gates arrive: sig(i) -> sig(i) tanh(c~) -> c' -> (h')
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int g = gi == 1 ? 2 : (gi == 2 ? 1 : gi);   // weights are indexed i, f, c, o; processed i, c~, f, o
+    f32x4 cin[6];
+    if (gi == 2) {   // the old cell state, in flight during the forget gate's phases
+      const float* crow = A.c_in + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) cin[ct] = *reinterpret_cast<const f32x4*>(crow + 16 * ct);
+    }
+    f32x4 pre[6];
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) pre[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int e = 0; e < n_in; ++e) {
+      const ggnn_dec_cell_sweep& Sw = A.in[e];
+      // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
+      {
+        f32x4 u[7];
+#pragma unroll
+        for (int nb = 0; nb < 7; ++nb) u[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4* pw = begin_slice();
+          f32x4 r0, r1;
+          if (ks < 3) {
+            r0 = xh[ks][0];
+            r1 = xh[ks][1];
+          } else {   // k = 96 .. 127: the 16 feature slots in k-groups 0 and 1, zeros behind
+            const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
+            r0 = *reinterpret_cast<const f32x4*>(fr);
+            r1 = *reinterpret_cast<const f32x4*>(fr + 4);
+            if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+          u32x4 xb[3];
+          dc_split(r0, r1, xb);
+          dc_kstep<7>(pw, xb, u);
+          end_slice();
+        }
+        // D layout -> stage[node][column]
+#pragma unroll
+        for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb];
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ================= P2: the sweep of (e, g) over the tile's rows, one node per 16-lane row =================
+      {
+        const float* __restrict__ ep = Sw.edge_params + g * GGNN_EDGE_PARAM_ROWS * C;
+        f3 wv[6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          const float* w = ep + ch + (cc < 3 ? cc : CH2 + cc - 3);
+          wv[cc] = {w[0], w[C], w[2 * C]};
+        }
+        const float* __restrict__ vbase = Sw.v_src + Sw.v_off + g * C + ch;
+        const float* __restrict__ hbase = Sw.h_src + ch;
+        const float* __restrict__ einfo = Sw.einfo;
+        const uint32_t ldv = (uint32_t)Sw.ldv, ldh = (uint32_t)Sw.ldh_src;
+        const int* __restrict__ rp = csr + e * (17 + DC_CW);
+        const int* __restrict__ colw = rp + 17;
+        const int pbase = rp[0], e_last = max((int)Sw.E - 1, 0);
+        const bool has_edges = Sw.E > 0;
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          const int n = 4 * it + kq;                       // tile row of this DPP row
+          const float* __restrict__ su = stage + n * DC_S;
+          const f3 uh0 = {su[ch], su[ch + 1], su[ch + 2]};
+          const f3 uh1 = {su[CH2 + ch], su[CH2 + ch + 1], su[CH2 + ch + 2]};
+          const float u4 = su[C + lr];
+          const int nl = min(row0 + n, n_dst - 1) - row0;  // (n_dst < 16: rows past the end repeat the last node)
+          int p = rp[nl];
+          const int pe = rp[nl + 1];
+          float mx = -INFINITY, den = 0.f, sae = 0.f;
+          float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          do {
+            f3 hh[GGNN_UNIT_EDGES][2], vv[GGNN_UNIT_EDGES][2];
+            float x4[GGNN_UNIT_EDGES];
+            f32x4 ed[GGNN_UNIT_EDGES];
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {   // unconditional (clamped) gathers, back to back
+              const int pt = min(p + t, e_last);
+              const int idx = max(pt - pbase, 0);
+              int j = colw[min(idx, DC_CW - 1)];
+              if (idx >= DC_CW && has_edges) j = Sw.col[pt];   // a tile with more than DC_CW in-edges (hubs)
+              if (!has_edges) j = 0;
+              hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
+              hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
+              x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
+              ed[t] = *reinterpret_cast<const f32x4*>(einfo + (uint32_t)pt * GGNN_EINFO_ROW + 16);
+              vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
+              vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
+            }
+            const int nact = min(max(pe - p, 0), GGNN_UNIT_EDGES);
+            if (nact > 0) {
+              float s[GGNN_UNIT_EDGES];
+              float mnew = mx;
+#pragma unroll
+              for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+                s[t] = -INFINITY;
+                if (t < nact) {
+                  const float part = u4 * x4[t] + uh0.x * hh[t][0].x + uh0.y * hh[t][0].y + uh0.z * hh[t][0].z +
+                                     uh1.x * hh[t][1].x + uh1.y * hh[t][1].y + uh1.z * hh[t][1].z;
+                  s[t] = row_sum(part);   // 1 / sqrt(96) is folded into u
+                  mnew = fmaxf(mnew, s[t]);
+                }
+              }
+              const float scale = __expf(mx - mnew);   // exp(-inf) = 0 on a row's first unit
+              den *= scale;
+              sae *= scale;
+#pragma unroll
+              for (int cc = 0; cc < 6; ++cc) acc[cc] *= scale;
+#pragma unroll
+              for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+                if (t < nact) {
+                  const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z;
+                  const float pw_ = __expf(s[t] - mnew);
+                  den += pw_;
+                  sae += pw_ * ed[t].w;
+                  const float v[6] = {vv[t][0].x, vv[t][0].y, vv[t][0].z, vv[t][1].x, vv[t][1].y, vv[t][1].z};
+#pragma unroll
+                  for (int cc = 0; cc < 6; ++cc)
+                    acc[cc] += pw_ * fmaxf(v[cc] + wv[cc].x * rx + wv[cc].y * ry + wv[cc].z * rz, 0.f);
+                }
+              }
+              mx = mnew;
+            }
+            p += GGNN_UNIT_EDGES;
+          } while (__builtin_amdgcn_ballot_w64(p < pe) != 0);
+          // the row's aggregate over the u it was computed from (already in registers)
+          const float inv = 1.0f / (den + 1e-16f);   // PyG softmax denominator
+          float* __restrict__ so = stage + n * DC_S;
+          so[ch] = acc[0] * inv;
+          so[ch + 1] = acc[1] * inv;
+          so[ch + 2] = acc[2] * inv;
+          so[CH2 + ch] = acc[3] * inv;
+          so[CH2 + ch + 1] = acc[4] * inv;
+          so[CH2 + ch + 2] = acc[5] * inv;
+          if (lr == 0) {
+            so[C] = den * inv;
+            so[C + 1] = sae * inv;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
+      {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const u32x4* pw = begin_slice();
+          const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
+          u32x4 xb[3];
+          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), xb);
+          dc_kstep<6>(pw, xb, pre);
+          end_slice();
+        }
+        const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
+        const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ct * 64], xt, pre[ct], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ================= P4: the summed skip term + gate bias of gate g =================
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4* pw = begin_slice();
+      f32x4 r0, r1;
+      if (ks < 3) {
+        r0 = xh[ks][0];
+        r1 = xh[ks][1];
+      } else {
+        const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
+        r0 = *reinterpret_cast<const f32x4*>(fr);
+        r1 = *reinterpret_cast<const f32x4*>(fr + 4);
+        if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      u32x4 xb[3];
+      dc_split(r0, r1, xb);
+      dc_kstep<6>(pw, xb, pre);
+      end_slice();
+    }
+
+    // ================= LSTM update, folded in gate by gate (heteropgclstm.py:140-146) =================
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = pre[ct][r];
+        if (gi == 0) run[ct][r] = sigmoidf_(z);
+        else if (gi == 1) run[ct][r] *= tanhf_(z);
+        else if (gi == 2) run[ct][r] = sigmoidf_(z) * cin[ct][r] + run[ct][r];
+        else pre[ct][r] = sigmoidf_(z) * tanhf_(run[ct][r]);
+      }
+    }
+    if (gi == 2) {
+      float* crow = A.c_out + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(crow + 16 * ct) = run[ct];
+    }
+    if (gi == 3) {
+      float* hrow = A.h_out + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(hrow + 16 * ct) = pre[ct];
+    }
+  }
+}
+
+__global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCellBatch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[DC_LDS];
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
+  const int nwg = B.wg_off[k + 1] - B.wg_off[k];
+  // workgroups that share an XCD take one contiguous range of tile sets: neighbouring rows, whose in-edges
+  // come from the same source rows, meet in the same L2 (speed only)
+  const int ts = xcd_remap((int)blockIdx.x - B.wg_off[k], nwg);
+  dec_cell_body(B.a[k], ts, s_raw);
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_problems < 1 || n_problems > DC_MAX_PROBLEMS) return GGNN_EINVAL;
+  DecCellBatch B;
+  B.n = n_problems;
+  B.wg_off[0] = 0;
+  for (int k = 0; k < DC_MAX_PROBLEMS; ++k) {
+    B.a[k] = args[k < n_problems ? k : 0];
+    if (k >= n_problems) {
+      B.wg_off[k + 1] = B.wg_off[k];
+      continue;
+    }
+    const ggnn_dec_cell_args& A = B.a[k];
+    if (A.n_in < 1 || A.n_in > 2 || A.n_dst <= 0 || A.f_dst < 1 || A.f_dst > 12 || A.ldx < A.f_dst) return GGNN_EINVAL;
+    if (!A.x_dst || !A.h_dst || !A.c_in || !A.h_out || !A.c_out || !A.wstream || !A.w2_tail) return GGNN_EINVAL;
+    if (A.ldh < C || (A.ldh & 3) || !aligned16(A.h_dst) || !aligned16(A.c_in) || !aligned16(A.h_out) ||
+        !aligned16(A.c_out) || !aligned16(A.wstream))
+      return GGNN_EINVAL;
+    if (A.n_dst >= INT32_MAX - 64) return GGNN_EINVAL;
+    for (int e = 0; e < A.n_in; ++e) {
+      const ggnn_dec_cell_sweep& Sw = A.in[e];
+      if (!Sw.rowptr || !Sw.einfo || !Sw.h_src || !Sw.v_src || !Sw.edge_params || !aligned16(Sw.einfo)) return GGNN_EINVAL;
+      if (Sw.E < 0 || Sw.n_src <= 0 || (Sw.E > 0 && !Sw.col)) return GGNN_EINVAL;
+      if (Sw.ldh_src < C || Sw.v_off < 0 || Sw.v_off + 4 * C > Sw.ldv) return GGNN_EINVAL;
+      if (Sw.n_src * Sw.ldh_src >= INT32_MAX || Sw.n_src * Sw.ldv >= INT32_MAX ||
+          (Sw.E + GGNN_UNIT_EDGES) * GGNN_EINFO_ROW >= INT32_MAX)
+        return GGNN_EINVAL;  // gathered rows are addressed with 32-bit offsets
+    }
+    const int64_t n_ts = (A.n_dst + 16 * DC_WAVES - 1) / (16 * DC_WAVES);
+    if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
+    B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
+  }
+  hipLaunchKernelGGL(dec_cell_kernel, dim3((unsigned)B.wg_off[DC_MAX_PROBLEMS]), dim3(DC_WAVES * 64), 0,
+                     (hipStream_t)stream, B);
+  return launch_status();
+}

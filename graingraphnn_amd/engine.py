@@ -141,10 +141,10 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     c_out), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
     launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
-    Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros).  `after_projection`: called right behind the
-    projection launch -- for a decoder cell the last launch of the forward that reads x -- and `after_sweeps`
+    Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros).  `after_projection`: called right behind the last
+    launch of the cell that reads x (the projection; with the fused decoder cell, that kernel) and `after_sweeps`
     behind the last launch that reads the edge records (a caller may record stream events there)."""
-    projs, sweeps, enc_sweeps, gates, enc_cells = [], [], [], [], []
+    projs, sweeps, enc_sweeps, gates, enc_cells, dec_cells = [], [], [], [], [], []
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
         if pc.wvb and getattr(backend, "fused_encoder", False):
@@ -156,6 +156,18 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                     enc_cells.append(([(graph.csr[et], einfo[et], pc.wvb[et], pc.u4s[et], lay[et[0]].F)
                                        for et in lay[nt].dst_ets], proj[nt], x[nt], pc.wst[nt], pc.w2[nt], pc.w2f[nt],
                                       _pre_view(agg[nt], len(lay[nt].dst_ets)), h_out[nt], c_out[nt]))
+            continue
+        if pc.dcs and getattr(backend, "fused_decoder", False):
+            # decoder: everything on the destination side in one kernel (ggnn_decoder_cell_batch); the projection only
+            # emits the source-side value rows
+            for nt in NODE_TYPES:
+                if nt in pc.wpv:
+                    projs.append((x[nt], lay[nt].F, h_in[nt], pc.wpv[nt], pc.bpv[nt], proj[nt][:, :pc.wpv[nt].size(0)]))
+            for nt in NODE_TYPES:
+                if lay[nt].live:
+                    dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
+                                       for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
+                                      h_out[nt], c_out[nt]))
             continue
         for nt in NODE_TYPES:
             P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
@@ -173,7 +185,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                            lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
         gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
     backend.project_batch(projs)
-    if after_projection is not None:
+    if after_projection is not None and not dec_cells:
         after_projection()
     if enc_cells:
         backend.encoder_cell_batch(enc_cells)
@@ -181,6 +193,10 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
         backend.aggregate_enc_batch(enc_sweeps)
     if sweeps:
         backend.aggregate_batch(sweeps)
+    if dec_cells:
+        backend.decoder_cell_batch(dec_cells)   # reads the destination nodes' features: x's last reader
+        if after_projection is not None:
+            after_projection()
     if after_sweeps is not None:
         after_sweeps()
     if gates:

@@ -126,6 +126,13 @@ class PackedCell:
     bps: Dict[str, torch.Tensor] = field(default_factory=dict)
     u4s: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> tail column in that projection
     wst: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> skip_transposed [F + 1, 288]
+    # decoder, fused cell (ggnn_decoder_cell_batch): the projection only emits the source-side value rows ...
+    wpv: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [96 G n_src_ets, Kp] value rows of wp
+    bpv: Dict[str, torch.Tensor] = field(default_factory=dict)
+    vof: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> value column in that projection
+    # ... and everything on the destination side streams past the tiles as bf16 planes
+    dcs: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_stream (int16)
+    dct: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_tail [4, n_in, 6, 64]
 
 
 @torch.no_grad()
@@ -208,6 +215,78 @@ def value_fragments_bias(weights, biases, F_src: int) -> torch.Tensor:
     fr = Bp.view(4, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
     fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 2 m2 + e, lane l = 16 kq + j)
     return fr.view(-1)
+
+
+DC_SLICE_I16 = 21504 // 2   # GGNN_DC_SLICE_BYTES / 2: int16 elements per slice of the decoder cell's weight stream
+DC_GATE_ORDER = (0, 2, 1, 3)  # the fused decoder cell walks the gates i, c~, f, o (weights are indexed i, f, c, o)
+
+
+@torch.no_grad()
+def split3_bf16(w: torch.Tensor):
+    """fp32 -> three bf16 tensors with hi + mid + lo == w exactly (hi = rne(w), mid = rne(w - hi), lo =
+    rne(w - hi - mid): 3 x 8 significand bits), the split the kernels apply to the node side on the fly
+    (csrc/common.h: split_bf16x3).  Raises when the weights are not finite or the split is not exact."""
+    w = w.float()
+    if not bool(torch.isfinite(w).all()):
+        raise ValueError("weights contain non-finite values: cannot be packed")
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    resid = (hi.float() + mid.float() + lo.float() - w).abs()
+    if resid.numel() and float(resid.max()) > 2.0 ** -120:   # (only underflow below bf16's exponent range is accepted)
+        raise ValueError(f"bf16 split of the weights is not exact (residual {float(resid.max()):.3e})")
+    return hi, mid, lo
+
+
+@torch.no_grad()
+def _plane_slices(W: torch.Tensor) -> torch.Tensor:
+    """[16 NB, 32 NKS] fp32 -> [NKS, DC_SLICE_I16] int16: per k-step the slice image of include/ggnn.h
+    (ggnn_dec_cell_args.wstream): [column tile nb][plane hi, mid, lo][lane l = 16 kq + m][8 bf16] with lane (m, kq)
+    of (nb, plane) holding W[16 nb + m][32 ks + 8 kq .. + 7]; slices with fewer than 7 column tiles end in zeros."""
+    rows, K = W.shape
+    NB, NKS = rows // 16, K // 32
+    assert rows == 16 * NB and K == 32 * NKS and NB <= 7
+    planes = torch.stack([t.view(torch.int16) for t in split3_bf16(W)])        # [3, rows, K]
+    fr = planes.view(3, NB, 16, NKS, 4, 8)                                      # p nb m ks kq j
+    fr = fr.permute(3, 1, 0, 4, 2, 5).reshape(NKS, NB * 3 * 64 * 8)             # ks | nb p kq m j
+    out = torch.zeros(NKS, DC_SLICE_I16, dtype=torch.int16, device=W.device)
+    out[:, :fr.size(1)] = fr
+    return out
+
+
+@torch.no_grad()
+def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
+    """`ggnn_dec_cell_args.wstream` and `.w2_tail` of one destination node type (include/ggnn.h) from the packed
+    projection rows `wp` [ncols, Fp + 96] / `bp` and the gate weight `w2` [4, 96, Ka] of pack_cell.
+    Reduction index of the score (P1) and skip (P4) blocks: [h 0..95 | x 0..F-1 | 1 (bias) | 0 ..] = 128."""
+    F, Fp, G = lay.F, lay.Fp, lay.G
+    assert G == 4 and wp.size(1) == Fp + C and F + 1 <= 16
+    n_in = len(lay.dst_ets)
+
+    def block(rows, bias):   # [n, Fp + 96] in the projection's input order [x | h] (+ bias) -> [n, 128]
+        out = torch.zeros(rows.size(0), 128, dtype=torch.float32, device=wp.device)
+        out[:, :C] = rows[:, Fp:Fp + C]
+        out[:, C:C + F] = rows[:, :F]
+        out[:, C + F] = bias
+        return out
+
+    slices = []
+    for g in DC_GATE_ORDER:
+        for d, et in enumerate(lay.dst_ets):
+            u = slice(lay.u_off[et] + g * C, lay.u_off[et] + (g + 1) * C)
+            t = slice(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4)
+            slices.append(_plane_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))))   # P1: 4 slices
+            slices.append(_plane_slices(w2[g][:, d * C:(d + 1) * C].contiguous()))                        # P3: 3 slices
+        sk = slice(lay.s_off + g * C, lay.s_off + (g + 1) * C)
+        slices.append(_plane_slices(block(wp[sk], bp[sk])))                                                # P4: 4 slices
+    stream = torch.cat(slices).contiguous()
+    assert stream.size(0) == 4 * (7 * n_in + 4)
+    tail = torch.zeros(G, n_in, 6, 4, 16, dtype=torch.float32, device=wp.device)   # g e ct k m   (lane l = 16 k + m)
+    for d in range(n_in):
+        for k in range(2):
+            tail[:, d, :, k, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
+    return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
 
 
 def _conv(cell, gate, et):
@@ -327,8 +406,20 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             convs = [_conv(cell, gate, et) for gate in gates]
             wvb[et] = value_fragments_bias([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
                                            F_of[et[0]])
+    wpv, bpv, vof, dcs, dct = {}, {}, {}, {}, {}
+    if k2 and all(F + 1 <= 16 for F in in_channels.values()):   # decoder: the fused cell's operands
+        for nt in NODE_TYPES:
+            lay = layout[nt]
+            ets = [et for et in lay.src_ets if layout[et[-1]].live]   # value rows nobody sweeps are not projected
+            if ets:
+                idx = torch.cat([torch.arange(lay.v_off[et], lay.v_off[et] + G * C, device=dev) for et in ets])
+                wpv[nt], bpv[nt] = wp[nt][idx].contiguous(), bp[nt][idx].contiguous()
+                for k, et in enumerate(ets):
+                    vof[et] = k * G * C
+            if lay.live:
+                dcs[nt], dct[nt] = decoder_cell_stream(wp[nt], bp[nt], w2[nt], lay)
     return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, w2f=w2f, wvb=wvb,
-                      wps=wps, bps=bps, u4s=u4s, wst=wst)
+                      wps=wps, bps=bps, u4s=u4s, wst=wst, wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct)
 
 
 @torch.no_grad()

@@ -199,6 +199,61 @@ class TorchEmulatorBackend:
         want = (n_dst + 3) // 4
         return min(max(want, 1), 512) * 4
 
+    fused_decoder = True  # engine.run_cells: decoder cells through decoder_cell_batch (False: projection + sweeps + gates)
+
+    @staticmethod
+    def _decode_slices(stream, first, n_ks, n_tiles):
+        """`n_ks` consecutive slices of ggnn_dec_cell_args.wstream (include/ggnn.h) -> the fp32 block
+        [16 n_tiles, 32 n_ks] they hold: hi + mid + lo of [column tile][plane][lane 16 kq + m][8 bf16]."""
+        S = 21504 // 2
+        sl = stream.view(-1, S)[first:first + n_ks, :n_tiles * 3 * 64 * 8]
+        assert not bool(stream.view(-1, S)[first:first + n_ks, n_tiles * 3 * 64 * 8:].any())
+        fr = sl.reshape(n_ks, n_tiles, 3, 4, 16, 8).view(torch.bfloat16).float().sum(2)   # ks nb kq m j
+        return fr.permute(1, 3, 0, 2, 4).reshape(16 * n_tiles, 32 * n_ks)                  # (nb m) x (ks kq j)
+
+    def decoder_cell_batch(self, problems):
+        """ggnn_decoder_cell_batch: per gate (stream order i, c~, f, o) and incoming edge type the score operands
+        u_h | u4 = W1 [h | x | 1], the sweep, lin_l2 + (b_l2, w_edge) on the aggregates; then the skip block and the
+        LSTM update.  Everything is computed from the DECODED weight stream, so a packing error shows up here."""
+        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
+            n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
+            assert wstream.numel() * 2 == 4 * (7 * n_in + 4) * 21504 and tuple(w2_tail.shape) == (4, n_in, 6, 64)
+            xin = torch.zeros(n, 128)
+            xin[:, :C], xin[:, C:C + F], xin[:, C + F] = h_dst, x_dst, 1.0
+            pre, s = {}, 0
+            for g in (0, 2, 1, 3):
+                z = torch.zeros(n, C)
+                for d, (csr, einfo, h_src, v_src, v_off, ep) in enumerate(sweeps):
+                    W1 = self._decode_slices(wstream, s, 4, 7)        # [112, 128]
+                    W3 = self._decode_slices(wstream, s + 4, 3, 6)    # [96, 96]
+                    s += 7
+                    assert not bool(W1[:, C + F + 1:].any())
+                    u = xin @ W1.t()                                   # [n, 112]: u_h | u4
+                    rowptr = csr.rowptr.long()
+                    E = int(rowptr[-1])
+                    dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+                    src = csr.col.long()[:E]
+                    x4, reloc, a = einfo[:E, :16], einfo[:E, 16:19], einfo[:E, 19]
+                    sc = (u[dst, :C] * h_src[src, :C]).sum(-1) + (u[dst, C:] * x4).sum(-1)
+                    smax = torch.full((n,), float("-inf")).scatter_reduce(0, dst, sc, "amax")
+                    p = (sc - smax[dst]).exp()
+                    den = torch.zeros(n).index_add(0, dst, p)
+                    alpha = p / (den[dst] + 1e-16)
+                    val = torch.relu(v_src[src, v_off + g * C: v_off + (g + 1) * C] + reloc @ ep[g])
+                    A = torch.zeros(n, C).index_add(0, dst, alpha[:, None] * val)
+                    sa = torch.zeros(n).index_add(0, dst, alpha)
+                    sae = torch.zeros(n).index_add(0, dst, alpha * a)
+                    tail = w2_tail[g, d].view(6, 4, 16)                # ct k m
+                    assert not bool(tail[:, 2:].any())
+                    z = z + A @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 1].reshape(1, C)
+                W4 = self._decode_slices(wstream, s, 4, 6)             # [96, 128]
+                s += 4
+                pre[g] = z + xin @ W4.t()
+            i, f, t, o = torch.sigmoid(pre[0]), torch.sigmoid(pre[1]), torch.tanh(pre[2]), torch.sigmoid(pre[3])
+            c = f * c_in + i * t
+            c_out.copy_(c)
+            h_out.copy_(o * torch.tanh(c))
+
     def lstm_epilogue(self, agg, w2, p_dst, s_off, c_in, h_out, c_out, raw_out, n_gates, mode,
                       w2_planes=None, g_stride=0):
         Ka = w2.size(2)

@@ -977,7 +977,120 @@ def test_fused_encoder_cell_batch_of_four_equals_single_calls():
         be.encoder_cell_batch(probs + probs[:1])                    # at most four problems
 
 
-class _OneSweepPerLaunch:
+def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8):
+    """Random decoder-cell problem (ggnn_decoder_cell_batch): destination type with `F_dst` features, `ins` =
+    [(n_src, F_src, E)] incoming edge types, random weight blocks packed by packing._plane_slices in the stream's
+    order.  Returns the fused-call tuple."""
+    from graingraphnn_amd.packing import DC_GATE_ORDER, _plane_slices
+    n_in = len(ins)
+    f = lambda *shape, lo=-1.0, hi=1.0: torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32)).to(DEV)
+    xd, h_dst, c_in = f(n_dst, F_dst, lo=0.0), f(n_dst, 96), f(n_dst, 96)
+    slices = []
+    for g in DC_GATE_ORDER:
+        for d in range(n_in):
+            W1 = f(112, 128, lo=-0.15, hi=0.15)
+            W1[:, 96 + F_dst + 1:] = 0                       # reduction index: h | x | 1 | zeros
+            W1[96 + 14:, :] = 0                              # tail slots 14, 15 of u4 are always zero
+            slices += [_plane_slices(W1), _plane_slices(f(96, 96, lo=-0.2, hi=0.2))]
+        W4 = f(96, 128, lo=-0.15, hi=0.15)
+        W4[:, 96 + F_dst + 1:] = 0
+        slices.append(_plane_slices(W4))
+    wstream = torch.cat(slices).contiguous().view(-1)
+    tail = torch.zeros(4, n_in, 6, 4, 16, device=DEV)
+    tail[:, :, :, :2] = f(4, n_in, 6, 2, 16, lo=-0.2, hi=0.2)
+    sweeps = []
+    for d, (n_src, F, E) in enumerate(ins):
+        src = rs.randint(0, max(n_src - 5, 1), size=E)
+        dst = rs.randint(1 if n_dst > 1 else 0, n_dst, size=E)     # destination 0 has no in-edge
+        dst[:hub] = min(7, n_dst - 1)
+        ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
+        xs = f(n_src, F, lo=0.0)
+        ea = f(E, lo=0.01, hi=0.1)
+        csr = be.build_csr(ei, n_src, n_dst)
+        einfo = torch.zeros(E + 3, 20, device=DEV)
+        be.edge_prepare([(csr, ea, xs, xd, einfo)])
+        v_src = f(n_src, 384 * (d + 1) + 96)                         # value rows at a column offset, padded rows
+        sweeps.append((csr, einfo, f(n_src, 96), v_src, 384 * d, f(4, 3, 96)))
+    return (sweeps, xd, h_dst, c_in, wstream, tail.view(4, n_in, 6, 64).contiguous(),
+            torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV))
+
+
+@pytest.mark.parametrize("n_dst,ins,hub", [
+    (236, [(118, 11, 708), (236, 8, 708)], 0),      # junctions of the 40 um fixture: two incoming edge types
+    (118, [(236, 8, 708)], 0),                      # grains: one
+    (1, [(1, 11, 1)], 0), (5, [(9, 8, 11), (5, 8, 0)], 0), (17, [(30, 12, 60)], 0), (33, [(40, 8, 0), (33, 8, 0)], 0),
+    (50, [(70, 8, 400), (70, 11, 1300)], 37), (50, [(70, 11, 1300)], 900), (67, [(30, 8, 500)], 0),
+    (20000, [(10000, 11, 60000), (20000, 8, 60000)], 0), (10000, [(20000, 8, 60000)], 0)])
+@torch.no_grad()
+def test_fused_decoder_cell_against_its_contract(n_dst, ins, hub):
+    """ggnn_decoder_cell_batch (destination-side projections, sweep, lin_l2, skip and LSTM update of a 16-node tile
+    in one kernel, weights streamed as bf16 planes) against the torch emulation of its contract evaluated on the
+    DECODED weight stream: fixture sizes, fewer than 16 rows, ragged last tiles and surplus waves, edge types
+    without edges, 12 source features, a hub row of degree `hub` (more in-edges than the tile's LDS index window),
+    rows without edges, cfg3 sizes; bit-reproducible (no atomics)."""
+    from emulator import TorchEmulatorBackend
+    from graingraphnn_amd.backend import CSR
+    be = backend()
+    rs = np.random.RandomState(n_dst + 7 * len(ins) + hub)
+    prob = _dec_cell_problem(be, rs, n_dst, ins, hub)
+    be.decoder_cell_batch([prob])
+    h, c = prob[6], prob[7]
+    cpu = lambda t: t.cpu() if torch.is_tensor(t) else t
+    sw_cpu = [(CSR(cs.rowptr.cpu(), cs.col.cpu(), cs.perm.cpu(), cs.row.cpu(), None, None, cs.E), ei.cpu(), hs.cpu(),
+               vs.cpu(), vo, ep.cpu()) for cs, ei, hs, vs, vo, ep in prob[0]]
+    ref = [torch.empty(n_dst, 96), torch.empty(n_dst, 96)]
+    TorchEmulatorBackend().decoder_cell_batch([(sw_cpu, *[cpu(t) for t in prob[1:6]], *ref)])
+    assert_close(h, ref[0], "fused decoder cell h", 2e-5, 2e-6)
+    assert_close(c, ref[1], "fused decoder cell c", 2e-5, 2e-6)
+    keep = [h.clone(), c.clone()]
+    h.fill_(float("nan")), c.fill_(float("nan"))
+    be.decoder_cell_batch([prob])
+    assert torch.equal(keep[0], h) and torch.equal(keep[1], c)      # no atomics: bit-reproducible
+
+
+@torch.no_grad()
+def test_fused_decoder_cell_batch_of_four_equals_single_calls():
+    """Four problems (two node types x two models) in one ggnn_decoder_cell_batch = four single calls."""
+    be = backend()
+    rs = np.random.RandomState(6)
+    shapes = [(2086, [(1043, 11, 6258), (2086, 8, 6258)]), (1043, [(2086, 8, 6258)]),
+              (2086, [(1043, 11, 6258), (2086, 8, 6258)]), (1043, [(2086, 8, 6258)])]
+    probs = [_dec_cell_problem(be, rs, n, ins, F_dst=8 if len(ins) == 2 else 11) for n, ins in shapes]
+    be.decoder_cell_batch(probs)
+    batched = [[t.clone() for t in p[6:]] for p in probs]
+    for p, want in zip(probs, batched):
+        for t in p[6:]:
+            t.fill_(float("nan"))
+        be.decoder_cell_batch([p])
+        for a, b in zip(p[6:], want):
+            assert torch.equal(a, b)
+    with pytest.raises(_lib.GGNNError):
+        be.decoder_cell_batch(probs + probs[:1])                    # at most four problems
+
+
+@torch.no_grad()
+def test_fused_decoder_cell_equals_the_split_path_end_to_end():
+    """Both model forwards with the decoder cell as one kernel (default) and as projection + sweeps + gate GEMM
+    (GGNN_DEC=split: the round-2 path) on the 40 um fixture and on a ragged Voronoi structure: same outputs up
+    to fp32 re-association."""
+    be = backend()
+    assert be.fused_decoder
+    for tag in ("40", "voronoi"):
+        x, ei, ea = load_graph("40") if tag == "40" else synthetic.voronoi(150, seed=4)
+        outs = []
+        for fused in (True, False):
+            be.fused_decoder = fused
+            try:
+                R, Cm = product_models(21, 1.0, DEV)
+                X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+                outs.append({**R(X, EI, EA), **Cm(X, EI, EA)})
+            finally:
+                be.fused_decoder = True
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert_close(outs[0][k], outs[1][k], f"fused vs split decoder, {tag} {k}", 2e-5, 2e-6)
+
+
+class _OneSweepPerLaunch:class _OneSweepPerLaunch:
     """The HIP backend with ggnn_period_gat_aggregate_batch replaced by single-sweep launches."""
 
     def __init__(self, inner):
