@@ -1090,7 +1090,7 @@ def test_fused_decoder_cell_equals_the_split_path_end_to_end():
             assert_close(outs[0][k], outs[1][k], f"fused vs split decoder, {tag} {k}", 2e-5, 2e-6)
 
 
-class _OneSweepPerLaunch:class _OneSweepPerLaunch:
+class _OneSweepPerLaunch:
     """The HIP backend with ggnn_period_gat_aggregate_batch replaced by single-sweep launches."""
 
     def __init__(self, inner):
