@@ -8,7 +8,8 @@ graph_trajectory.py:901-1005 for the features) with the import stubs of tools/or
 termcolor) on the path, and stores what it pickled -- node features, the three edge lists, the edge
 lengths -- as tests/golden/generated_40_seed<S>.npz.  Data only; no reference source is stored.
 
-    python tests/golden/make_golden_generated.py [seed ...]        (default: 1 2)
+    python tests/golden/make_golden_generated.py [seed ...]        (default: seeds 1, 2 at 40 um and
+                                                                    seed 7 at 80 um with G = 10, R = 0.2)
 """
 import os
 import subprocess
@@ -23,11 +24,12 @@ REF = "/root/reference"
 STUB = os.path.join(ROOT, "tools", "oracle_stub")
 
 
-def run(seed, lxd=40):
+def run(seed, lxd=40, G=None, R=None):
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, PYTHONPATH=STUB, MPLBACKEND="Agg")
+        extra = ([f"--G={G}"] if G is not None else []) + ([f"--R={R}"] if R is not None else [])
         subprocess.run([sys.executable, "graph_trajectory.py", "--mode=generate", f"--lxd={lxd}", f"--seed={seed}",
-                        f"--save_dir={tmp}/"], cwd=REF, env=env, check=True, stdout=subprocess.DEVNULL)
+                        f"--save_dir={tmp}/"] + extra, cwd=REF, env=env, check=True, stdout=subprocess.DEVNULL)
         pkl = [f for f in os.listdir(tmp) if f.startswith(f"seed{seed}_")][0]
         sys.path[:0] = [STUB, REF]
         os.environ.setdefault("MPLBACKEND", "Agg")
@@ -46,5 +48,10 @@ def run(seed, lxd=40):
 
 
 if __name__ == "__main__":
-    for s in ([int(a) for a in sys.argv[1:]] or [1, 2]):
-        run(s)
+    if sys.argv[1:]:
+        for s in (int(a) for a in sys.argv[1:]):
+            run(s)
+    else:
+        run(1)
+        run(2)
+        run(7, lxd=80, G=10.0, R=0.2)   # four patches, another span of the (G, R) table (60)

@@ -487,8 +487,16 @@ def test_cfg3_full_size_step_and_properties():
         assert_close(pred3[k], pred[k], f"cfg3 permuted-COO {k}", 1e-5)
     assert_close(pred3["edge_event"], pred["edge_event"][torch.from_numpy(perm[JJ]).to(DEV)],
                  "cfg3 permuted-COO edge_event", 1e-5)
-    # (3) softmax normalisation: sum of alpha is 1 on every row with an in-edge
-    sa = ro.ws["R"].agg_dec["joint"].view(-1, 4, 224)[:, :, 192:196:2]
+    # (3) softmax normalisation: sum of alpha is 1 on every row with an in-edge (the fused decoder cell keeps its
+    # aggregates on the compute unit: look at them through the split path's sweep, same arithmetic)
+    be_ = backend()
+    be_.fused_decoder = False
+    try:
+        R2s, _ = product_models(0, 0.3, DEV)
+        R2s(tt(x, DEV), tt(ei, DEV), tt(ea, DEV))
+        sa = R2s._ws.agg_dec["joint"].view(-1, 4, 224)[:, :, 192:196:2]
+    finally:
+        be_.fused_decoder = True
     assert float((sa - 1).abs().max()) < 1e-5
 
 
