@@ -45,9 +45,11 @@ class HipBackend:
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
-        # decoder cell: one fused kernel behind a value-only projection (default), or GGNN_DEC=split: projection with
-        # the destination-side columns + sweeps + gate GEMM (the round-2 path; also what GGNN_GEMM=fp32 runs)
-        self.fused_decoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_DEC", "") != "split")
+        # decoder cell: projection (with the destination-side columns) + sweeps + gate GEMM (default), or
+        # GGNN_DEC=fused: ggnn_decoder_cell_batch behind a value-only projection.  The fused cell moves a third of
+        # the bytes but measured 2 % slower in the rollout (1 926 vs 1 970 steps/s, same box: DESIGN.md section 4),
+        # so it is the selectable path, fully tested, not the default.
+        self.fused_decoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_DEC", "") == "fused")
 
     # -- launch tape: the drop-in forward() issues the same dozen launches with the same arguments
     # step after step (test.py:382-383); re-issuing the recorded C calls skips the per-launch

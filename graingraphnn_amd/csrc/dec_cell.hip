@@ -19,19 +19,24 @@
 //   * the weights of a destination type are 1.25 MB as bf16 planes (joints: 2 x 4 score blocks [112 x 128],
 //     8 lin_l2 blocks, 4 skip blocks) -- eight times the LDS.  They arrive as k-step slices (one 32-deep
 //     k-step of one block: 21 KB) through a double-buffered LDS region shared by the workgroup's four waves,
-//     fetched by LDS-DMA one slice ahead, one workgroup barrier per slice.  Host-side pre-split planes: no
-//     splitting arithmetic on the weight side in the kernel (the gate kernel's split cost 44 VALU per fragment).
+//     fetched one slice ahead (16-byte loads at the top of a k-step, ds_write_b128 at its end), one workgroup
+//     barrier per slice.  Host-side pre-split planes: no splitting arithmetic on the weight side in the kernel
+//     (the gate kernel's split cost 44 VALU per fragment).
 //   * two workgroups per compute unit (80 KB of LDS each, two waves per SIMD) so that one workgroup's sweep
 //     phases (latency-bound gathers) run beside the other's matrix phases.
 // A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
 // and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
+#define GGNN_STAMP_SUFFIX _dec
+#include "stamps.h"
 
 namespace ggnn {
 
-constexpr int DC_WAVES = 4;
+constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
 constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 21 pieces of 1 KB
 constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
@@ -40,13 +45,14 @@ constexpr int DC_XF = 16 * 16 * 4;                  // feature tile [16 nodes][1
 constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
 constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
 constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
-constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 80 896 B: two workgroups per CU
-static_assert(2 * DC_LDS <= 160 * 1024, "two workgroups per compute unit");
+constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 118 784 B
+static_assert(DC_LDS <= 160 * 1024, "LDS");
 
 struct DecCellBatch {
   ggnn_dec_cell_args a[DC_MAX_PROBLEMS];
   int wg_off[DC_MAX_PROBLEMS + 1];
   int n;
+  int stagger_from, stagger_sleeps;   // workgroups >= stagger_from start stagger_sleeps x ~4 us late (speed only)
 };
 
 // LDS-DMA: every lane copies 16 bytes from its own global address to lds_base + lane * 16 (wave-uniform base
@@ -105,8 +111,6 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   float* __restrict__ stage = reinterpret_cast<float*>(wbase);
   float* __restrict__ xf = reinterpret_cast<float*>(wbase + DC_STAGE);
   int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_STAGE + DC_XF);   // [e][17 + DC_CW]
-  const uint32_t slice_lds =
-      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
 
   const int n_dst = (int)A.n_dst, n_in = A.n_in, F = A.f_dst;
   // a ragged last tile slides back over rows the previous tile also produces (identical duplicate results);
@@ -115,40 +119,69 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   const int row0 = max(0, min((tileset * DC_WAVES + wave) * 16, n_dst - 16));
   const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node in the matrix view (n_dst < 16: clamped)
 
-  // ---- the weight stream: slice s -> buffer s & 1, fetched one slice ahead by all four waves ----
-  const int per_gate = 7 * n_in + 4, n_slices = 4 * per_gate;
+  // ---- the weight stream: slice s -> buffer s & 1, fetched one slice ahead by all the workgroup's waves ----
+  // LDS-DMA, a wave's share of the next slice (its 18 or 21 one-KB pieces dealt round-robin) requested at the top
+  // of a k-step; one counted wait + one workgroup barrier per slice.  The ISSUE of a piece costs the wave ~150
+  // cycles (in-kernel stamps: 0.38 us per slice with four waves sharing a slice = 27 of a tile's 140 us), which is
+  // why the workgroup has eight waves: half the pieces per wave and slice.  (Tried: 16-byte loads to registers +
+  // ds_write_b128 at the end of the k-step -- the loads' latency then sits in front of the barrier: slower.)
   const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(A.wstream) + lane * 16;
-  auto slice_pieces = [&](int s) {   // P1 slices have 7 column tiles, P3 / P4 six
-    const int r = s % per_gate;
-    return (r < 7 * n_in && (r % 7) < 4) ? 21 : 18;
-  };
-  auto dma_slice = [&](int s) {
-    const int np = slice_pieces(s);
+  const uint32_t slice_lds =
+      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
+  int s_cur = 0;
+  [[maybe_unused]] unsigned long long st_wait = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_p4 = 0, st_lstm = 0;
+  [[maybe_unused]] unsigned long long st_dma = 0, st_t0 = 0;
+  GGNN_STAMP(0);
+  auto dma_slice = [&](int s, int np) {
     const unsigned char* src = wsrc + (size_t)s * DC_SLICE;
     const uint32_t dst = slice_lds + (s & 1) * DC_SLICE;
     for (int p = wave; p < np; p += DC_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
   };
-  int s_cur = 0;
-  auto begin_slice = [&]() -> const u32x4* {   // the slice about to be used landed at the previous end_slice
-    if (s_cur + 1 < n_slices) dma_slice(s_cur + 1);
+  // `np_next`: pieces of the slice after the current one (21: a P1 slice, 18: P3 / P4, 0: none)
+  auto begin_slice = [&](int np_next) -> const u32x4* {   // the slice about to be used landed at the previous end_slice
+    st_t0 = GGNN_STAMP_NOW();
+    if (np_next > 0) dma_slice(s_cur + 1, np_next);
+    st_dma += GGNN_STAMP_NOW() - st_t0;
     return reinterpret_cast<const u32x4*>(smem + (s_cur & 1) * DC_SLICE) + lane;
   };
   auto end_slice = [&]() {
+    [[maybe_unused]] const unsigned long long w0 = GGNN_STAMP_NOW();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice are in LDS
     __syncthreads();                                   // ... everybody's are, and nobody reads the old one any more
+    st_wait += GGNN_STAMP_NOW() - w0;
     ++s_cur;
   };
-  dma_slice(0);
+  dma_slice(0, 21);
 
   // ---- tile prologue: h rows as B fragments (kept for the whole tile), features -> LDS, CSR windows -> LDS ----
+  // the tile's h rows as B fragments: needed by P1 and P4, dead during the sweep (where every register counts), so
+  // they are fetched again behind every sweep (L1 / L2 hits, hidden under P3's matrix work)
   f32x4 xh[3][2];
-  {
-    const float* hrow = A.h_dst + (int64_t)node_m * A.ldh + 8 * kq;
+  const float* __restrict__ hrow = A.h_dst + (int64_t)node_m * A.ldh + 8 * kq;
+  auto load_xh = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       xh[ks][0] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks);
       xh[ks][1] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks + 4);
     }
+  };
+  // B-fragment planes of k-step ks of [h | x | 1 | 0]: k-steps 0..2 are the h rows, k-step 3 the 16 feature slots
+  // (k-groups 0 and 1; zeros behind)
+  auto x_planes = [&](int ks, u32x4 (&out)[3]) __attribute__((always_inline)) {
+    f32x4 r0, r1;
+    if (ks < 3) {
+      r0 = xh[ks][0];
+      r1 = xh[ks][1];
+    } else {
+      const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
+      r0 = *reinterpret_cast<const f32x4*>(fr);
+      r1 = *reinterpret_cast<const f32x4*>(fr + 4);
+      if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    dc_split(r0, r1, out);
+  };
+  {
+    load_xh();
     // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
     const int fn = lane >> 2, fq = (lane & 3) * 4;
     const float* xrow = A.x_dst + (int64_t)min(row0 + fn, n_dst - 1) * A.ldx;
@@ -172,44 +205,33 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // slice 0 is in LDS
+  GGNN_STAMP(1);
 
   f32x4 run[6];   // the LSTM update as the gates arrive: sig(i) -> sig(i) tanh(c~) -> c' -> (h')
 #pragma unroll
+  for (int ct = 0; ct < 6; ++ct) run[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
   for (int gi = 0; gi < 4; ++gi) {
     const int g = gi == 1 ? 2 : (gi == 2 ? 1 : gi);   // weights are indexed i, f, c, o; processed i, c~, f, o
-    f32x4 cin[6];
-    if (gi == 2) {   // the old cell state, in flight during the forget gate's phases
-      const float* crow = A.c_in + (int64_t)node_m * C + 4 * kq;
-#pragma unroll
-      for (int ct = 0; ct < 6; ++ct) cin[ct] = *reinterpret_cast<const f32x4*>(crow + 16 * ct);
-    }
-    f32x4 pre[6];
+    f32x4 pre[6], cin[6];
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) pre[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
+      [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
       {
         f32x4 u[7];
 #pragma unroll
         for (int nb = 0; nb < 7; ++nb) u[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 xb[2][3];
+        x_planes(0, xb[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const u32x4* pw = begin_slice();
-          f32x4 r0, r1;
-          if (ks < 3) {
-            r0 = xh[ks][0];
-            r1 = xh[ks][1];
-          } else {   // k = 96 .. 127: the 16 feature slots in k-groups 0 and 1, zeros behind
-            const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
-            r0 = *reinterpret_cast<const f32x4*>(fr);
-            r1 = *reinterpret_cast<const f32x4*>(fr + 4);
-            if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-          u32x4 xb[3];
-          dc_split(r0, r1, xb);
-          dc_kstep<7>(pw, xb, u);
+          const u32x4* pw = begin_slice(ks < 3 ? 21 : 18);   // behind P1: the sweep, then P3's first slice
+          dc_kstep<7>(pw, xb[ks & 1], u);
+          if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);   // the next k-step's split runs beside these MFMAs
           end_slice();
         }
         // D layout -> stage[node][column]
@@ -217,8 +239,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb];
       }
       __builtin_amdgcn_wave_barrier();
+      [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
 
       // ================= P2: the sweep of (e, g) over the tile's rows, one node per 16-lane row =================
+      // Two rows per 16-lane group in flight (nodes 8 half + kq and 8 half + 4 + kq): the gathers of both are issued
+      // back to back before either is folded, so a (gate, edge type) pass exposes two memory round trips, not four.
       {
         const float* __restrict__ ep = Sw.edge_params + g * GGNN_EDGE_PARAM_ROWS * C;
         f3 wv[6];
@@ -235,98 +260,155 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         const int* __restrict__ colw = rp + 17;
         const int pbase = rp[0], e_last = max((int)Sw.E - 1, 0);
         const bool has_edges = Sw.E > 0;
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-          const int n = 4 * it + kq;                       // tile row of this DPP row
+        struct Row {      // one destination row being folded
+          f3 uh0, uh1;
+          float u4, mx, den, sae, acc[6];
+          int p, pe;
+        };
+        struct Unit {     // the gathered operands of <= 3 of its in-edges
+          f3 hh[GGNN_UNIT_EDGES][2], vv[GGNN_UNIT_EDGES][2];
+          float x4[GGNN_UNIT_EDGES];
+          f3 ed[GGNN_UNIT_EDGES];   // reloc_e (the edge length a_e is slot 13 of x4: lane 13 sums alpha a_e)
+        };
+        auto open_row = [&](Row& r, int n) __attribute__((always_inline)) {
           const float* __restrict__ su = stage + n * DC_S;
-          const f3 uh0 = {su[ch], su[ch + 1], su[ch + 2]};
-          const f3 uh1 = {su[CH2 + ch], su[CH2 + ch + 1], su[CH2 + ch + 2]};
-          const float u4 = su[C + lr];
-          const int nl = min(row0 + n, n_dst - 1) - row0;  // (n_dst < 16: rows past the end repeat the last node)
-          int p = rp[nl];
-          const int pe = rp[nl + 1];
-          float mx = -INFINITY, den = 0.f, sae = 0.f;
-          float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          do {
-            f3 hh[GGNN_UNIT_EDGES][2], vv[GGNN_UNIT_EDGES][2];
-            float x4[GGNN_UNIT_EDGES];
-            f32x4 ed[GGNN_UNIT_EDGES];
+          r.uh0 = {su[ch], su[ch + 1], su[ch + 2]};
+          r.uh1 = {su[CH2 + ch], su[CH2 + ch + 1], su[CH2 + ch + 2]};
+          r.u4 = su[C + lr];
+          const int nl = min(row0 + n, n_dst - 1) - row0;   // (n_dst < 16: rows past the end repeat the last node)
+          r.p = rp[nl];
+          r.pe = rp[nl + 1];
+          r.mx = -INFINITY;
+          r.den = r.sae = 0.f;
 #pragma unroll
-            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {   // unconditional (clamped) gathers, back to back
-              const int pt = min(p + t, e_last);
-              const int idx = max(pt - pbase, 0);
-              int j = colw[min(idx, DC_CW - 1)];
-              if (idx >= DC_CW && has_edges) j = Sw.col[pt];   // a tile with more than DC_CW in-edges (hubs)
-              if (!has_edges) j = 0;
-              hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
-              hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
-              x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
-              ed[t] = *reinterpret_cast<const f32x4*>(einfo + (uint32_t)pt * GGNN_EINFO_ROW + 16);
-              vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
-              vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
-            }
-            const int nact = min(max(pe - p, 0), GGNN_UNIT_EDGES);
-            if (nact > 0) {
-              float s[GGNN_UNIT_EDGES];
-              float mnew = mx;
+          for (int cc = 0; cc < 6; ++cc) r.acc[cc] = 0.f;
+        };
+        // A tile whose in-edges fit the LDS index window (all but hub tiles) finds every source index there; a load
+        // under `if` would drag a full wait to the branch merge and serialise the edges, so the choice is made once
+        // per tile, wave-uniformly, between two straight-line variants of the gather.
+        const bool in_window = __builtin_amdgcn_readfirstlane(rp[16] - pbase) <= DC_CW;
+        auto gather = [&](const Row& r, Unit& U, auto window_tag) __attribute__((always_inline)) {   // unconditional (clamped) loads, back to back
+          constexpr bool WINDOW = decltype(window_tag)::value;
 #pragma unroll
-              for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
-                s[t] = -INFINITY;
-                if (t < nact) {
-                  const float part = u4 * x4[t] + uh0.x * hh[t][0].x + uh0.y * hh[t][0].y + uh0.z * hh[t][0].z +
-                                     uh1.x * hh[t][1].x + uh1.y * hh[t][1].y + uh1.z * hh[t][1].z;
-                  s[t] = row_sum(part);   // 1 / sqrt(96) is folded into u
-                  mnew = fmaxf(mnew, s[t]);
-                }
-              }
-              const float scale = __expf(mx - mnew);   // exp(-inf) = 0 on a row's first unit
-              den *= scale;
-              sae *= scale;
-#pragma unroll
-              for (int cc = 0; cc < 6; ++cc) acc[cc] *= scale;
-#pragma unroll
-              for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
-                if (t < nact) {
-                  const float rx = ed[t].x, ry = ed[t].y, rz = ed[t].z;
-                  const float pw_ = __expf(s[t] - mnew);
-                  den += pw_;
-                  sae += pw_ * ed[t].w;
-                  const float v[6] = {vv[t][0].x, vv[t][0].y, vv[t][0].z, vv[t][1].x, vv[t][1].y, vv[t][1].z};
-#pragma unroll
-                  for (int cc = 0; cc < 6; ++cc)
-                    acc[cc] += pw_ * fmaxf(v[cc] + wv[cc].x * rx + wv[cc].y * ry + wv[cc].z * rz, 0.f);
-                }
-              }
-              mx = mnew;
-            }
-            p += GGNN_UNIT_EDGES;
-          } while (__builtin_amdgcn_ballot_w64(p < pe) != 0);
-          // the row's aggregate over the u it was computed from (already in registers)
-          const float inv = 1.0f / (den + 1e-16f);   // PyG softmax denominator
-          float* __restrict__ so = stage + n * DC_S;
-          so[ch] = acc[0] * inv;
-          so[ch + 1] = acc[1] * inv;
-          so[ch + 2] = acc[2] * inv;
-          so[CH2 + ch] = acc[3] * inv;
-          so[CH2 + ch + 1] = acc[4] * inv;
-          so[CH2 + ch + 2] = acc[5] * inv;
-          if (lr == 0) {
-            so[C] = den * inv;
-            so[C + 1] = sae * inv;
+          for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+            const int pt = min(r.p + t, e_last);
+            int j;
+            if constexpr (WINDOW) j = colw[min(max(pt - pbase, 0), DC_CW - 1)];
+            else j = has_edges ? Sw.col[pt] : 0;
+            if (!has_edges) j = 0;
+            U.hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
+            U.hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
+            U.x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
+            U.ed[t] = ld3(einfo + (uint32_t)pt * GGNN_EINFO_ROW + 16);
+            U.vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
+            U.vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
           }
-        }
+        };
+        auto fold = [&](Row& r, const Unit& U) __attribute__((always_inline)) {
+          // Every product-sum is an explicit fma and contraction is off: the two variants of the sweep (and a row
+          // computed by two overlapping tiles of a ragged end) must give the same bits, whatever the compiler would
+          // have chosen to fuse in each inlined copy.
+#pragma clang fp contract(off)
+          const int nact = min(max(r.pe - r.p, 0), GGNN_UNIT_EDGES);
+          if (nact > 0) {
+            float s[GGNN_UNIT_EDGES];
+            float mnew = r.mx;
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+              s[t] = -INFINITY;
+              if (t < nact) {
+                float part = r.u4 * U.x4[t];
+                part = __builtin_fmaf(r.uh0.x, U.hh[t][0].x, part);
+                part = __builtin_fmaf(r.uh0.y, U.hh[t][0].y, part);
+                part = __builtin_fmaf(r.uh0.z, U.hh[t][0].z, part);
+                part = __builtin_fmaf(r.uh1.x, U.hh[t][1].x, part);
+                part = __builtin_fmaf(r.uh1.y, U.hh[t][1].y, part);
+                part = __builtin_fmaf(r.uh1.z, U.hh[t][1].z, part);
+                s[t] = row_sum(part);   // 1 / sqrt(96) is folded into u
+                mnew = fmaxf(mnew, s[t]);
+              }
+            }
+            const float scale = __expf(r.mx - mnew);   // exp(-inf) = 0 on a row's first unit
+            r.den = r.den * scale;
+            r.sae = r.sae * scale;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) r.acc[cc] = r.acc[cc] * scale;
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+              if (t < nact) {
+                const float rx = U.ed[t].x, ry = U.ed[t].y, rz = U.ed[t].z;
+                const float pw_ = __expf(s[t] - mnew);
+                r.den = r.den + pw_;
+                r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);   // lane 13: sum alpha a_e (other lanes: unused)
+                const float v[6] = {U.vv[t][0].x, U.vv[t][0].y, U.vv[t][0].z, U.vv[t][1].x, U.vv[t][1].y, U.vv[t][1].z};
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                  const float val = __builtin_fmaf(wv[cc].z, rz, __builtin_fmaf(wv[cc].y, ry, __builtin_fmaf(wv[cc].x, rx, v[cc])));
+                  r.acc[cc] = __builtin_fmaf(pw_, fmaxf(val, 0.f), r.acc[cc]);
+                }
+              }
+            }
+            r.mx = mnew;
+          }
+          r.p += GGNN_UNIT_EDGES;
+        };
+        auto close_row = [&](const Row& r, int n) __attribute__((always_inline)) {  // the row's aggregate over the u it was computed from
+#pragma clang fp contract(off)
+          const float inv = 1.0f / (r.den + 1e-16f);   // PyG softmax denominator
+          float* __restrict__ so = stage + n * DC_S;
+          so[ch] = r.acc[0] * inv;
+          so[ch + 1] = r.acc[1] * inv;
+          so[ch + 2] = r.acc[2] * inv;
+          so[CH2 + ch] = r.acc[3] * inv;
+          so[CH2 + ch + 1] = r.acc[4] * inv;
+          so[CH2 + ch + 2] = r.acc[5] * inv;
+          if (lr == 0) so[C] = r.den * inv;
+          if (lr == 13) so[C + 1] = r.sae * inv;
+        };
+        auto sweep = [&](auto window_tag) __attribute__((always_inline)) {
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {
+            const int na = 8 * half + kq, nb = na + 4;     // tile rows of this DPP row
+            Row ra, rb;
+            open_row(ra, na);
+            open_row(rb, nb);
+            do {
+              Unit ua, ub;
+              gather(ra, ua, window_tag);
+              gather(rb, ub, window_tag);
+              fold(ra, ua);
+              fold(rb, ub);
+            } while (__builtin_amdgcn_ballot_w64(ra.p < ra.pe || rb.p < rb.pe) != 0);
+            close_row(ra, na);
+            close_row(rb, nb);
+          }
+        };
+        if (in_window) sweep(std::true_type{});
+        else sweep(std::false_type{});
       }
       __builtin_amdgcn_wave_barrier();
+      [[maybe_unused]] const unsigned long long t_c = GGNN_STAMP_NOW();
+      load_xh();
+      if (e == n_in - 1) {   // the old cell state, in flight during the gate's last matrix phases (only the forget
+        // gate uses it; fetched by every gate so that it is live from here to the update and nowhere else)
+        const float* crow = A.c_in + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) cin[ct] = *reinterpret_cast<const f32x4*>(crow + 16 * ct);
+      }
 
       // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
       {
+        u32x4 xb[2][3];
+        auto a_planes = [&](int ks, u32x4 (&out)[3]) __attribute__((always_inline)) {
+          const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
+          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out);
+        };
+        a_planes(0, xb[0]);
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const u32x4* pw = begin_slice();
-          const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
-          u32x4 xb[3];
-          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), xb);
-          dc_kstep<6>(pw, xb, pre);
+          const u32x4* pw = begin_slice(ks < 2 ? 18 : (e + 1 < n_in ? 21 : 18));   // next: P3, the next edge type's P1, or P4
+          dc_kstep<6>(pw, xb[ks & 1], pre);
+          if (ks + 1 < 3) a_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();
         }
         const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
@@ -335,39 +417,51 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ct * 64], xt, pre[ct], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
+      [[maybe_unused]] const unsigned long long t_d = GGNN_STAMP_NOW();
+      st_p1 += t_b - t_a;
+      st_p2 += t_c - t_b;
+      st_p3 += t_d - t_c;
     }
+    [[maybe_unused]] const unsigned long long t_e = GGNN_STAMP_NOW();
 
     // ================= P4: the summed skip term + gate bias of gate g =================
+    {
+      u32x4 xb[2][3];
+      x_planes(0, xb[0]);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const u32x4* pw = begin_slice();
-      f32x4 r0, r1;
-      if (ks < 3) {
-        r0 = xh[ks][0];
-        r1 = xh[ks][1];
-      } else {
-        const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
-        r0 = *reinterpret_cast<const f32x4*>(fr);
-        r1 = *reinterpret_cast<const f32x4*>(fr + 4);
-        if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4* pw = begin_slice(ks < 3 ? 18 : (gi < 3 ? 21 : 0));   // next: P4, the next gate's P1, or nothing
+        dc_kstep<6>(pw, xb[ks & 1], pre);
+        if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
+        end_slice();
       }
-      u32x4 xb[3];
-      dc_split(r0, r1, xb);
-      dc_kstep<6>(pw, xb, pre);
-      end_slice();
     }
 
+    [[maybe_unused]] const unsigned long long t_f = GGNN_STAMP_NOW();
+    st_p4 += t_f - t_e;
     // ================= LSTM update, folded in gate by gate (heteropgclstm.py:140-146) =================
+    // (the gate loop is a real loop -- unrolled four times the register allocator gave up --: the four updates sit
+    // behind wave-uniform branches)
+    if (gi == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) {
+      for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z = pre[ct][r];
-        if (gi == 0) run[ct][r] = sigmoidf_(z);
-        else if (gi == 1) run[ct][r] *= tanhf_(z);
-        else if (gi == 2) run[ct][r] = sigmoidf_(z) * cin[ct][r] + run[ct][r];
-        else pre[ct][r] = sigmoidf_(z) * tanhf_(run[ct][r]);
-      }
+        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pre[ct][r]);
+    } else if (gi == 1) {
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) run[ct][r] *= tanhf_(pre[ct][r]);
+    } else if (gi == 2) {
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pre[ct][r]) * cin[ct][r] + run[ct][r];
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre[ct][r] = sigmoidf_(pre[ct][r]) * tanhf_(run[ct][r]);
     }
     if (gi == 2) {
       float* crow = A.c_out + (int64_t)node_m * C + 4 * kq;
@@ -379,7 +473,17 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(hrow + 16 * ct) = pre[ct];
     }
+    st_lstm += GGNN_STAMP_NOW() - t_f;
   }
+  GGNN_STAMP_VAL(4, st_wait);
+  GGNN_STAMP_VAL(5, st_p1);
+  GGNN_STAMP_VAL(6, st_p2);
+  GGNN_STAMP_VAL(7, st_p3);
+  GGNN_STAMP_VAL(8, st_p4);
+  GGNN_STAMP_VAL(9, st_lstm);
+  GGNN_STAMP_VAL(10, n_in);
+  GGNN_STAMP_VAL(11, st_dma);
+  GGNN_STAMP(16);
 }
 
 __global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCellBatch B) {
@@ -390,6 +494,11 @@ __global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCel
   // workgroups that share an XCD take one contiguous range of tile sets: neighbouring rows, whose in-edges
   // come from the same source rows, meet in the same L2 (speed only)
   const int ts = xcd_remap((int)blockIdx.x - B.wg_off[k], nwg);
+  // The two workgroups of a compute unit run the same program: started together they would be in their matrix
+  // phases together and in their sweeps together.  The second round of workgroups (observed: dispatched behind
+  // one per compute unit) starts half a phase late, so that one's sweep runs beside the other's GEMMs.
+  if ((int)blockIdx.x >= B.stagger_from)
+    for (int i = 0; i < B.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
   dec_cell_body(B.a[k], ts, s_raw);
 }
 
@@ -427,7 +536,17 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
     if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
     B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
   }
-  hipLaunchKernelGGL(dec_cell_kernel, dim3((unsigned)B.wg_off[DC_MAX_PROBLEMS]), dim3(DC_WAVES * 64), 0,
+  static const int stagger = [] {
+    const char* e = getenv("GGNN_DC_STAGGER");   // development knob: sleeps of 127 x 64 clocks (~4 us each)
+    return e ? atoi(e) : 0;
+  }();
+  B.stagger_from = num_cu();
+  B.stagger_sleeps = stagger;
+  static const unsigned pad_lds = [] {   // development knob: extra dynamic LDS, i.e. one workgroup per compute unit
+    const char* e = getenv("GGNN_DC_PAD_LDS");
+    return e ? (unsigned)atoi(e) : 0u;
+  }();
+  hipLaunchKernelGGL(dec_cell_kernel, dim3((unsigned)B.wg_off[DC_MAX_PROBLEMS]), dim3(DC_WAVES * 64), pad_lds,
                      (hipStream_t)stream, B);
   return launch_status();
 }

@@ -490,13 +490,14 @@ def test_cfg3_full_size_step_and_properties():
     # (3) softmax normalisation: sum of alpha is 1 on every row with an in-edge (the fused decoder cell keeps its
     # aggregates on the compute unit: look at them through the split path's sweep, same arithmetic)
     be_ = backend()
+    keep_ = be_.fused_decoder
     be_.fused_decoder = False
     try:
         R2s, _ = product_models(0, 0.3, DEV)
         R2s(tt(x, DEV), tt(ei, DEV), tt(ea, DEV))
         sa = R2s._ws.agg_dec["joint"].view(-1, 4, 224)[:, :, 192:196:2]
     finally:
-        be_.fused_decoder = True
+        be_.fused_decoder = keep_
     assert float((sa - 1).abs().max()) < 1e-5
 
 
@@ -985,7 +986,7 @@ def test_fused_encoder_cell_batch_of_four_equals_single_calls():
         be.encoder_cell_batch(probs + probs[:1])                    # at most four problems
 
 
-def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8):
+def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
     """Random decoder-cell problem (ggnn_decoder_cell_batch): destination type with `F_dst` features, `ins` =
     [(n_src, F_src, E)] incoming edge types, random weight blocks packed by packing._plane_slices in the stream's
     order.  Returns the fused-call tuple."""
@@ -1011,6 +1012,8 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8):
         src = rs.randint(0, max(n_src - 5, 1), size=E)
         dst = rs.randint(1 if n_dst > 1 else 0, n_dst, size=E)     # destination 0 has no in-edge
         dst[:hub] = min(7, n_dst - 1)
+        if edges is not None:                                       # a given structure (timing tools): [2, E] per edge type
+            src, dst = edges[d][0], edges[d][1]
         ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
         xs = f(n_src, F, lo=0.0)
         ea = f(E, lo=0.01, hi=0.1)
@@ -1082,7 +1085,7 @@ def test_fused_decoder_cell_equals_the_split_path_end_to_end():
     (GGNN_DEC=split: the round-2 path) on the 40 um fixture and on a ragged Voronoi structure: same outputs up
     to fp32 re-association."""
     be = backend()
-    assert be.fused_decoder
+    default = be.fused_decoder
     for tag in ("40", "voronoi"):
         x, ei, ea = load_graph("40") if tag == "40" else synthetic.voronoi(150, seed=4)
         outs = []
@@ -1093,7 +1096,7 @@ def test_fused_decoder_cell_equals_the_split_path_end_to_end():
                 X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
                 outs.append({**R(X, EI, EA), **Cm(X, EI, EA)})
             finally:
-                be.fused_decoder = True
+                be.fused_decoder = default
         for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
             assert_close(outs[0][k], outs[1][k], f"fused vs split decoder, {tag} {k}", 2e-5, 2e-6)
 

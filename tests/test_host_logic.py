@@ -130,8 +130,9 @@ def test_layout_offsets():
     assert dead.ncols == 384 and dead.dst_ets == [] and dead.v_off == {EDGE_TYPES[0]: 0}
 
 
-def _run_model_emulated(model, x, ei, ea):
+def _run_model_emulated(model, x, ei, ea, fused_decoder=True):
     be = TorchEmulatorBackend()
+    be.fused_decoder = fused_decoder
     n_nodes = {nt: v.shape[0] for nt, v in x.items()}
     graph = engine.GraphCSR(be, ei, n_nodes)
     enc = model.gclstm_encoder.cell_list[0].packed(True)
@@ -141,10 +142,13 @@ def _run_model_emulated(model, x, ei, ea):
     return be, graph, h
 
 
+@pytest.mark.parametrize("fused_decoder", [False, True])
 @pytest.mark.parametrize("tag,seed,scale", [("cfg1_s1", 10020, 1.0), ("cfg1_s3", 10020, 3.0),
                                             ("cfg2_s1", 0, 1.0)])
 @torch.no_grad()
-def test_packing_and_plan_reproduce_golden_forward(tag, seed, scale):
+def test_packing_and_plan_reproduce_golden_forward(tag, seed, scale, fused_decoder):
+    """Both decoder plans through the emulator: projection + sweeps + gate GEMM (the default) and the fused
+    decoder cell (GGNN_DEC=fused), whose weight stream the emulator decodes back from its bf16 planes."""
     if tag.startswith("cfg1"):
         x, ei, ea = load_graph("40")
     else:
@@ -153,14 +157,14 @@ def test_packing_and_plan_reproduce_golden_forward(tag, seed, scale):
     g = golden(tag)
     R, Cm = product_models(seed, scale)
     X, EI, EA = tt(x), tt(ei), tt(ea)
-    be, graph, h = _run_model_emulated(R, X, EI, EA)
+    be, graph, h = _run_model_emulated(R, X, EI, EA, fused_decoder)
     w, b = packing.pack_regressor_heads(R.linear)
     yj, yg, area = torch.empty(X["joint"].size(0), 2), torch.empty(X["grain"].size(0), 2), torch.empty(X["grain"].size(0))
     be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
     assert_close(yj, g["R_joint"], f"{tag} R joint", TOL)
     assert_close(yg, g["R_grain"], f"{tag} R grain", TOL)
     assert_close(area, g["R_grain_area"], f"{tag} R area", TOL)
-    be, graph, h = _run_model_emulated(Cm, X, EI, EA)
+    be, graph, h = _run_model_emulated(Cm, X, EI, EA, fused_decoder)
     wn, we = packing.pack_classifier_heads(Cm.lin1, Cm.lin2)
     E = EI[EDGE_TYPES[2]].size(1)
     ev, ed, tmp = torch.empty(E), torch.empty(E, 2), torch.empty(X["joint"].size(0), 8)
