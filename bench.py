@@ -123,13 +123,28 @@ class EventTimedBackend:
         if problems[0][2] is None:  # encoder (K <= 12): store-bound, not a GEMM worth grading
             return self.inner.project_batch(problems)
         flops = sum(2.0 * x.size(0) * (F + h.size(1)) * wp.size(0) for x, F, h, wp, bp, out in problems)
-        self._timed("dec_project", self.inner.project_batch, problems, (flops, len(problems)))
+        nbytes = sum(4.0 * (x.size(0) * (F + h.size(1) + wp.size(0)) + wp.numel() + bp.numel())
+                     for x, F, h, wp, bp, out in problems)     # node rows in, weights once, projected rows out
+        self._timed("dec_project", self.inner.project_batch, problems, (flops, len(problems), nbytes))
 
     def lstm_epilogue_batch(self, problems):
         if problems[0][9] != 0:  # GGNN_MODE_LSTM only (decoder)
             return self.inner.lstm_epilogue_batch(problems)
         flops = sum(2.0 * p[0].size(0) * p[8] * 96 * p[1].size(2) for p in problems)
-        self._timed("dec_gates", self.inner.lstm_epilogue_batch, problems, (flops, len(problems)))
+        # aggregates + skip rows + old cell state in, weights once, h and c out
+        nbytes = sum(4.0 * (p[0].size(0) * (p[8] * p[1].size(2) + p[8] * 96 + 96 + 2 * 96) + p[1].numel()) for p in problems)
+        self._timed("dec_gates", self.inner.lstm_epilogue_batch, problems, (flops, len(problems), nbytes))
+
+    def decoder_cell_batch(self, problems):
+        # (sweeps [(csr, einfo, h_src, v_src, v_off, ep)], x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
+        flops = nbytes = 0.0
+        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
+            n, n_in = x_dst.size(0), len(sweeps)
+            flops += 2.0 * n * 4 * (n_in * (128 * 112 + 98 * 96) + 128 * 96)
+            nbytes += 4.0 * n * (x_dst.size(1) + 96 + 96 + 2 * 96) + 2.0 * wstream.numel()
+            for csr, einfo, h_src, v_src, v_off, ep in sweeps:   # value rows + hidden rows of the sources, edge records
+                nbytes += 4.0 * (h_src.size(0) * (4 * 96 + 96) + csr.E * 20 + csr.E + n + 1)
+        self._timed("dec_cell", self.inner.decoder_cell_batch, problems, (flops, len(problems), nbytes))
 
     def summary(self, key):
         evs = self.events.get(key)
@@ -141,6 +156,7 @@ class EventTimedBackend:
         overhead = float(np.median(null1 - (null2 - null1)))     # bracket minus the null kernel itself
         return {"avg_us": float(np.mean(bracket)) - overhead, "bracket_us": float(np.mean(bracket)),
                 "overhead_us": overhead, "work": float(np.mean([ev[5][0] for ev in evs])),
+                "work2": float(np.mean([ev[5][2] if len(ev[5]) > 2 else 0.0 for ev in evs])),
                 "per_launch": round(float(np.mean([ev[5][1] for ev in evs])), 2), "n": len(evs)}
 
 
@@ -161,12 +177,13 @@ def measure_roofline(ro, n_steps):
         ro.be, ro._side, ro.joint_launches = timed.inner, side, joint
     roof = enc = None
     gemm = []
+    fused_plan = bool(getattr(timed.inner, "fused_decoder", False))
     d = timed.summary("dec_sweep")
     if d:
         achieved = d["work"] / d["avg_us"] / 1e3
         roof = {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(d["per_launch"]), "avg_launch_us": round(d["avg_us"], 2),
+                "traffic": pmc_traffic("ggnn::aggregate_kernel<4, true>"), "avg_launch_us": round(d["avg_us"], 2),
                 "event_bracket_us": round(d["bracket_us"], 2), "bracket_overhead_us": round(d["overhead_us"], 2),
                 "algorithmic_bytes_per_launch": int(d["work"]), "launches_timed": d["n"],
                 "sweeps_per_launch": d["per_launch"]}
@@ -186,50 +203,56 @@ def measure_roofline(ro, n_steps):
         enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (+ enc_lstm_kernel, in the same bracket)",
                "achieved": round(busy * FP32_MFMA_PEAK_TFLOPS, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": round(busy, 4), "avg_launch_us": round(c["avg_us"], 2), "problems_per_launch": c["per_launch"],
+               "traffic": (lambda a, b: None if a is None or b is None else a + b)(
+                   pmc_traffic("ggnn::enc_cell_kernel"), pmc_traffic("ggnn::enc_lstm_kernel")),
                "mfma_cycles_per_launch": int(c["work"]),
                "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, bf16 MFMAs of the "
                        "gate GEMM at 16) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
                        "kernel is bound by instruction issue (profiles/README.md)"}
-    for key, name in (("dec_project", "ggnn::project_x6_kernel (decoder projection, both node types of a model)"),
-                      ("dec_gates", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, live node types of a model)")):
+    for key, kname, name in (
+            ("dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection, both node types of a model)"),
+            ("dec_gates", "ggnn::gates_x6_kernel<4, 0>", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, live node types of a model)"),
+            ("dec_cell", "ggnn::dec_cell_kernel", "ggnn::dec_cell_kernel (fused decoder cell, GGNN_DEC=fused)")):
         g = timed.summary(key)
         if g:
-            tf = g["work"] / g["avg_us"] / 1e6
-            gemm.append({"bound": "mfma", "kernel": name, "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "frac_of_bf16_pipe": round(6 * tf / 2500.0, 4),
-                         "note": "fp32-equivalent rate against the fp32 matrix peak (a value above 1 means the exact "
-                                 "bf16 split beats what native fp32 MFMA could deliver at all); frac_of_bf16_pipe = the "
-                                 "6 bf16 products per fp32 product against the 2.5 PFLOP/s dense bf16 peak",
-                         "gflop_per_launch": round(g["work"] / 1e9, 3), "avg_launch_us": round(g["avg_us"], 2),
+            flops, nbytes = g["work"], g["work2"]
+            gbs = nbytes / g["avg_us"] / 1e3
+            tf = flops / g["avg_us"] / 1e6
+            gemm.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(kname, "fused" if key == "dec_cell" or (key == "dec_project" and fused_plan) else "split"),
+                         "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": round(g["avg_us"], 2),
                          "problems_per_launch": g["per_launch"],
-                         "flops": "fp32-equivalent, as launched: 2 M (F + 96) ncols per projection problem, "
-                                  "2 N n_gates 96 Ka per gate problem (each product runs as 6 bf16 MFMA products)"})
+                         "fp32_equivalent_tflops": round(tf, 1), "frac_of_bf16_pipe": round(6 * tf / 2500.0, 4),
+                         "note": "graded against HBM: every operand row read once + every output row written once, fp32, as "
+                                 "launched (the matrix work runs as 6 bf16 MFMA products per fp32 product: "
+                                 "frac_of_bf16_pipe = 6 x fp32-equivalent rate / 2.5 PFLOP/s dense bf16 peak)"})
     return roof, enc, gemm
 
 
 def kernel_source_hash():
-    """What a PMC record is tied to: the ABI version of the loaded library + the sources of the sweep."""
+    """What a PMC record is tied to: the ABI version of the loaded library + the sources of the kernels it
+    describes (the sweep, the decoder GEMMs, the fused cells)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("aggregate.hip", "common.h"):
+    for name in ("aggregate.hip", "project_x6.hip", "gates_x6.hip", "enc_cell.hip", "dec_cell.hip", "common.h"):
         with open(os.path.join(ROOT, "graingraphnn_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return f"abi{default_backend().lib.ggnn_version()}-{h.hexdigest()[:16]}"
 
 
-def pmc_traffic(sweeps_per_launch):
-    """HBM bytes per aggregate_kernel<4, true> launch from the rocprofv3 --pmc passes recorded in
-    profiles/r2_pmc_aggregate.json (PMC collection cannot run inside this process; the file says
-    how it was taken and corrected, tools/pmc_aggregate.py).  The record is stamped with the ABI
-    version and a hash of the sweep's sources and with the launch shape it was taken on: None when
-    the file is absent or does not describe the kernel that is running."""
+def pmc_traffic(kernel, plan="split"):
+    """HBM-side bytes per launch of `kernel` from the rocprofv3 --pmc passes recorded in
+    profiles/r3_pmc_kernels.json (PMC collection cannot run inside this process; the file says how it was taken
+    and corrected, tools/pmc_kernels.py).  The record is stamped with the ABI version and a hash of the kernels'
+    sources: None when the file is absent or does not describe the library that is running."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_aggregate.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_kernels.json")) as f:
             doc = json.load(f)
-        if doc["kernel_source_hash"] != kernel_source_hash() or abs(doc["sweeps_per_launch"] - sweeps_per_launch) > 1e-6:
+        if doc["kernel_source_hash"] != kernel_source_hash():
             return None
-        return int(doc["traffic_bytes_per_launch"])
+        rec = doc["plans"][plan][kernel]
+        return int(rec["read_bytes"] + rec["written_bytes"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -251,32 +274,38 @@ def cpu_baseline(inputs, seed=0, scale=0.3, budget_s=12.0):
     X, EI, EA = synthetic.to_torch(x, ei, ea, "cpu")
     default_threads = torch.get_num_threads()
     model, physical, hw_threads = host_cpu()
-    cands = sorted({1} | {t for t in (8, 16, 32) if t <= hw_threads})
+    cands = sorted({1} | {t for t in (8, 16, 32) if t <= hw_threads} | {min(physical, hw_threads)})
     trial = {}
+
+    def timed_step():
+        nonlocal EA
+        t0 = time.perf_counter()
+        _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
+        return time.perf_counter() - t0
+
     try:
-        for t in cands:
+        for t in cands:     # one warm-up + one timed step per candidate: only to pick the thread count
             torch.set_num_threads(t)
-            oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)  # warm-up at this thread count
-            t0 = time.perf_counter()
-            _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
-            trial[t] = time.perf_counter() - t0
+            timed_step()
+            trial[t] = timed_step()
         best = min(trial, key=trial.get)
         torch.set_num_threads(best)
-        oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
-        t0 = time.perf_counter()
-        n = 0
-        while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
-            _, EA = oracle.rollout_step(R, Cm, X, EI, EA, SPAN, centres=centres)
-            n += 1
-        dt = time.perf_counter() - t0
+        timed_step()
+        t_start, steps = time.perf_counter(), []
+        while len(steps) < 5 or (time.perf_counter() - t_start < budget_s and len(steps) < 50):
+            steps.append(timed_step())
     finally:
         torch.set_num_threads(default_threads)
-    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": best, "threads": best,
+    med = float(np.median(steps))
+    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": best, "threads": best,
+            "statistic": f"median of {len(steps)} consecutive steps (min {1 / max(steps):.3f}, max {1 / min(steps):.3f} steps/s)",
             "physical_cores": physical, "hardware_threads": hw_threads, "cpu_model": model,
+            "all_physical_cores_steps_per_s": round(1 / trial[min(physical, hw_threads)], 4),
             "one_thread_steps_per_s": round(1 / trial[1], 4), "kind": "port",
-            "sample": f"{n} steps of the same 10k-grain workload at the fastest of "
+            "sample": f"{len(steps)} steps of the same 10k-grain workload at the fastest of "
                       f"{{{', '.join(f'{t} threads: {1 / v:.2f} steps/s' for t, v in sorted(trial.items()))}}} "
-                      "(one timed step each after a warm-up step)"}
+                      "(one timed step each after a warm-up step; the all-physical-cores entry is SURVEY 8d's figure: "
+                      "PyTorch's intra-op threading loses to its own synchronisation beyond ~16 threads on this workload)"}
 
 
 def host_cpu():
