@@ -22,7 +22,7 @@
 //             a fixed grid, so the result is reproducible);
 //   src pass  one wave per source row over the REVERSE (source-grouped) CSR: gathers the
 //             destination rows' g_out / u_h and the edge records, writes dV_j and dh_j.
-// First correct version: one edge per iteration, no unit table, no prefetch.
+// Round 3: both passes take the edges in units of three with all loads of a unit in flight together.
 #include "common.h"
 
 namespace ggnn {
@@ -56,10 +56,16 @@ __device__ __forceinline__ void st6(float* p, const float (&v)[6]) {
   st3(p + C / 2, {v[3], v[4], v[5]});
 }
 
+// Destination pass, round 3: the in-edges of a row are taken in UNITS of three with every load of a unit issued
+// back to back and unconditionally (clamped indices: a load under `if` drags a wait to the branch merge), so a
+// row of degree <= 3 -- every junction -- costs two memory round trips (hidden rows + tails, then values + records)
+// instead of six; the scores of such a row stay in registers between the two halves.  Rows of higher degree run the
+// same unit code twice (online max / sum, then the gradients).  Arithmetic and summation order of the first version.
 template <int G, bool HAS_H>
 __global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggregate_bwd_args A) {
   const BwdLane L = bwd_lane<G>();
   const int64_t w = (int64_t)blockIdx.x * AB_WAVES + L.wave, n_w = (int64_t)gridDim.x * AB_WAVES;
+  constexpr int U = GGNN_UNIT_EDGES;
   float wv[6][3];
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
@@ -67,6 +73,9 @@ __global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggre
     wv[c][0] = e[0], wv[c][1] = e[C], wv[c][2] = e[2 * C];
   }
   float dwv[6][3] = {};
+  const int e_last = (int)max(A.E - 1, (int64_t)0);
+  const float* __restrict__ vsrc = A.p_src + A.v_off + L.gc * C + L.ch;
+  const float* __restrict__ hsrc = A.h_src + L.ch;
   for (int64_t i = w; i < A.n_dst; i += n_w) {
     const int beg = A.rowptr[i], end = A.rowptr[i + 1];
     float uh[6] = {}, u4 = 0.f, go[6] = {}, out[6] = {}, gden = 0.f, gsae = 0.f, oden = 0.f, osae = 0.f;
@@ -80,58 +89,94 @@ __global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggre
       gden = A.g_agg[o + A.sc_off], gsae = A.g_agg[o + A.sc_off + 1];
       oden = A.agg[o + A.sc_off], osae = A.agg[o + A.sc_off + 1];
     }
-    // scores: online max and sum
+    // ---- scores: online max and sum over the units ----
     float mx = -INFINITY, den = 0.f;
-    for (int p = beg; p < end; ++p) {
-      const int64_t j = A.col[p];
-      float part = u4 * A.einfo[(int64_t)p * GGNN_EINFO_ROW + L.l16];
-      if (HAS_H) {
-        float h[6];
-        ld6(A.h_src + j * A.ldh_src + L.ch, h);
+    float h[U][6], x4[U], sc[U];
+    int64_t jj[U];
+    auto load_scores = [&](int p0) {   // hidden rows and score tails of the unit at p0
 #pragma unroll
-        for (int c = 0; c < 6; ++c) part += uh[c] * h[c];
+      for (int t = 0; t < U; ++t) {
+        const int p = min(p0 + t, e_last);
+        jj[t] = A.E > 0 ? (int64_t)A.col[p] : 0;
+        x4[t] = A.einfo[(int64_t)p * GGNN_EINFO_ROW + L.l16];
+        if (HAS_H) ld6(hsrc + jj[t] * A.ldh_src, h[t]);
       }
-      const float s = row_sum(part);
-      const float mn = fmaxf(mx, s);
-      den = den * __expf(mx - mn) + __expf(s - mn);
-      mx = mn;
+    };
+    auto unit_scores = [&](int p0) {
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        float part = u4 * x4[t];
+        if (HAS_H) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) part += uh[c] * h[t][c];
+        }
+        sc[t] = row_sum(part);
+        if (p0 + t < end) {
+          const float mn = fmaxf(mx, sc[t]);
+          den = den * __expf(mx - mn) + __expf(sc[t] - mn);
+          mx = mn;
+        }
+      }
+    };
+    const bool one_unit = end - beg <= U;
+    for (int p0 = beg; p0 < end; p0 += U) {
+      load_scores(p0);
+      unit_scores(p0);
     }
     const float inv = 1.0f / (den + 1e-16f);
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < 6; ++c) dot += go[c] * out[c];
     const float S = row_sum(dot) + gden * oden + gsae * osae;
+    // ---- gradients, unit by unit (a single unit still has its hidden rows, tails and scores in registers) ----
     float du4 = 0.f, duh[6] = {};
-    for (int p = beg; p < end; ++p) {
-      const int64_t j = A.col[p];
-      const float* rec = A.einfo + (int64_t)p * GGNN_EINFO_ROW;
-      const float x4 = rec[L.l16], rx = rec[16], ry = rec[17], rz = rec[18], ae = rec[19];
-      float h[6] = {}, v[6];
-      if (HAS_H) ld6(A.h_src + j * A.ldh_src + L.ch, h);
-      ld6(A.p_src + j * A.ldp_src + A.v_off + L.gc * C + L.ch, v);
-      float part = u4 * x4;
+    for (int p0 = beg; p0 < end; p0 += U) {
+      float v[U][6], rec[U][4];
+      if (!one_unit) load_scores(p0);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) part += uh[c] * h[c];
-      const float alpha = __expf(row_sum(part) - mx) * inv;
-      float gv[6], dpart = 0.f;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const float val = v[c] + wv[c][0] * rx + wv[c][1] * ry + wv[c][2] * rz;
-        gv[c] = val > 0.f ? go[c] : 0.f;  // g_out masked by the relu
-        dpart += gv[c] * val;
+      for (int t = 0; t < U; ++t) {
+        const int p = min(p0 + t, e_last);
+        const float* r = A.einfo + (int64_t)p * GGNN_EINFO_ROW + 16;
+        rec[t][0] = r[0], rec[t][1] = r[1], rec[t][2] = r[2], rec[t][3] = r[3];
+        ld6(vsrc + jj[t] * A.ldp_src, v[t]);
       }
-      const float dalpha = row_sum(dpart) + gden + gsae * ae;
-      const float ds = alpha * (dalpha - S);
-      du4 += ds * x4;
+      if (!one_unit) {   // (scores again, without touching the softmax state)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        duh[c] += ds * h[c];
-        const float t = alpha * gv[c];
-        dwv[c][0] += t * rx, dwv[c][1] += t * ry, dwv[c][2] += t * rz;
+        for (int t = 0; t < U; ++t) {
+          float part = u4 * x4[t];
+          if (HAS_H) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) part += uh[c] * h[t][c];
+          }
+          sc[t] = row_sum(part);
+        }
       }
-      if (L.active && L.l16 == 0) {
-        A.edge_alpha[(int64_t)p * G + L.g] = alpha;
-        A.edge_ds[(int64_t)p * G + L.g] = ds;
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int p = p0 + t;
+        const bool live = p < end;
+        const float rx = rec[t][0], ry = rec[t][1], rz = rec[t][2], ae = rec[t][3];
+        const float alpha = live ? __expf(sc[t] - mx) * inv : 0.f;
+        float gv[6], dpart = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float val = v[t][c] + wv[c][0] * rx + wv[c][1] * ry + wv[c][2] * rz;
+          gv[c] = val > 0.f ? go[c] : 0.f;  // g_out masked by the relu
+          dpart += gv[c] * val;
+        }
+        const float dalpha = row_sum(dpart) + gden + gsae * ae;
+        const float ds = live ? alpha * (dalpha - S) : 0.f;
+        du4 += ds * x4[t];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          if (HAS_H) duh[c] += ds * h[t][c];
+          const float tt = alpha * gv[c];
+          dwv[c][0] += tt * rx, dwv[c][1] += tt * ry, dwv[c][2] += tt * rz;
+        }
+        if (live && L.active && L.l16 == 0) {
+          A.edge_alpha[(int64_t)p * G + L.g] = alpha;
+          A.edge_ds[(int64_t)p * G + L.g] = ds;
+        }
       }
     }
     if (L.active) {
@@ -149,38 +194,54 @@ __global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggre
   }
 }
 
+// Source pass, round 3: the out-edges of a source row in units of three, every load of a unit in flight together
+// (the reverse-CSR entries first, then the destination rows' g_out / u_h and the edge records they point to).
 template <int G, bool HAS_H>
 __global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggregate_bwd_args A) {
   const BwdLane L = bwd_lane<G>();
   const int64_t w = (int64_t)blockIdx.x * AB_WAVES + L.wave, n_w = (int64_t)gridDim.x * AB_WAVES;
+  constexpr int U = GGNN_UNIT_EDGES;
   float wv[6][3];
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const float* e = A.edge_params + L.gc * GGNN_EDGE_PARAM_ROWS * C + L.ch + (c < 3 ? c : C / 2 + c - 3);
     wv[c][0] = e[0], wv[c][1] = e[C], wv[c][2] = e[2 * C];
   }
+  const int e_last = (int)max(A.E - 1, (int64_t)0);
+  const float* __restrict__ gagg = A.g_agg + (int64_t)L.gc * A.a_gstride + A.a_off + L.ch;
+  const float* __restrict__ udst = A.p_dst + A.u_off + L.gc * C + L.ch;
   for (int64_t j = w; j < A.n_src; j += n_w) {
     const int beg = A.r_rowptr[j], end = A.r_rowptr[j + 1];
     float v[6], dv[6] = {}, dh[6] = {};
     ld6(A.p_src + j * A.ldp_src + A.v_off + L.gc * C + L.ch, v);
-    for (int q = beg; q < end; ++q) {
-      const int64_t p = A.r_slot[q], i = A.r_dst[q];
-      const float* rec = A.einfo + p * GGNN_EINFO_ROW;
-      const float rx = rec[16], ry = rec[17], rz = rec[18];
-      const float alpha = L.active ? A.edge_alpha[p * G + L.gc] : 0.f;
-      const float ds = L.active ? A.edge_ds[p * G + L.gc] : 0.f;
-      float go[6];
-      ld6(A.g_agg + i * A.ld_agg + (int64_t)L.gc * A.a_gstride + A.a_off + L.ch, go);
+    for (int q0 = beg; q0 < end; q0 += U) {
+      int64_t pp[U], ii[U];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const float val = v[c] + wv[c][0] * rx + wv[c][1] * ry + wv[c][2] * rz;
-        dv[c] += val > 0.f ? alpha * go[c] : 0.f;
+      for (int t = 0; t < U; ++t) {
+        const int q = min(q0 + t, e_last);
+        pp[t] = A.E > 0 ? (int64_t)A.r_slot[q] : 0;
+        ii[t] = A.E > 0 ? (int64_t)A.r_dst[q] : 0;
       }
-      if (HAS_H) {
-        float uh[6];
-        ld6(A.p_dst + i * A.ldp_dst + A.u_off + L.gc * C + L.ch, uh);
+      float rec[U][3], alpha[U], ds[U], go[U][6], uh[U][6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) dh[c] += ds * uh[c];
+      for (int t = 0; t < U; ++t) {
+        const float* r = A.einfo + pp[t] * GGNN_EINFO_ROW + 16;
+        rec[t][0] = r[0], rec[t][1] = r[1], rec[t][2] = r[2];
+        alpha[t] = A.edge_alpha[pp[t] * G + L.gc];
+        ds[t] = A.edge_ds[pp[t] * G + L.gc];
+        ld6(gagg + ii[t] * A.ld_agg, go[t]);
+        if (HAS_H) ld6(udst + ii[t] * A.ldp_dst, uh[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const bool live = q0 + t < end && L.active;
+        const float al = live ? alpha[t] : 0.f, dd = live ? ds[t] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float val = v[c] + wv[c][0] * rec[t][0] + wv[c][1] * rec[t][1] + wv[c][2] * rec[t][2];
+          dv[c] += val > 0.f ? al * go[t][c] : 0.f;
+          if (HAS_H) dh[c] += dd * uh[t][c];
+        }
       }
     }
     if (L.active) st6(A.g_p_src + j * A.ldp_src + A.v_off + L.g * C + L.ch, dv);

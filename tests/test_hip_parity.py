@@ -1199,6 +1199,10 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
         assert len(replays) == n
         yb = R2(tt({k: v.cpu().numpy() for k, v in X.items()}, DEV), tt(ei, DEV), EA)
         assert torch.equal(ya["joint"], yb["joint"])
+        # (the fresh-tensor forwards above pushed this topology out of the CSR cache: the call that re-recorded built
+        # a new one, whose exact block balance arrives with ITS second forward and re-records once more)
+        assert torch.equal(R(X, EI, EA)["joint"], ya["joint"])
+        n = len(replays)
         assert torch.equal(R(X, EI, EA)["joint"], ya["joint"]) and len(replays) == n + 1
         # another stream -> re-record (the stream handle is part of every recorded call)
         side = torch.cuda.Stream()
