@@ -165,24 +165,23 @@ def span_for(G: float, R: float) -> int:
 
 
 def generate(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, span: int = None,
-             grain_size: float = 4.0, noise: float = 0.01, shuffle_edges: bool = False):
-    """Initial grain structure with the interface of the reference's generator
-    (`graph_trajectory.py --mode=generate --lxd --seed --G --R`, :1289-1333): a `lxd` x `lxd` um
-    periodic domain seeded with a hexagonal lattice of mean grain size `grain_size` um and Gaussian
-    jitter, tessellated into grains (Voronoi cells) and junctions (Voronoi vertices).
-    The lattice is the reference's (graph_datastruct.py:118-160, 207-260): spacing dx = grain_size /
-    lxd, points ((col + (row % 2) / 2) sqrt(3) dx + 0.1 dx, row dx / 2 + 0.25 dx), jitter variance
-    noise / lxd / (lxd / 40) per coordinate, the points that land in the unit box are kept (the
-    lattice is not commensurate with the box: the seam grains are irregular, as in the reference).
-    Features as graph_trajectory.py:901-1005 writes them at frame 0: grain (centre x, y, z = 0, area as a
-    fraction of one 40 um patch, extraV = 0, cos / sin of the two misorientation angles, span / 120,
-    0), joint (x, y, 0, 1 - G / 10, R / 2, span / 120, 0, 0); edge lengths test.py:562-575.
-    What is NOT the reference: the random streams (the reference draws its jitter and angles from
-    numpy's global generator in its own order, and reads `span` from its (G, R) lookup table
-    GR_train_grid.pkl -- here `span` is an argument), and areas are exact polygon areas where the
-    reference counts pixels of a 0.08 um raster.  Same distribution, not the same sample:
-    tests/test_host_logic.py compares counts, degree histograms, areas and edge lengths with
-    fixtures the reference generator produced (tests/golden/generated_40_seed*.npz)."""
+             grain_size: float = 4.0, noise: float = 0.01):
+    """The reference's `graph_trajectory.py --mode=generate --lxd --seed --G --R` (:1289-1333): an `lxd` x `lxd` um
+    periodic initial grain structure, and for a given seed THE SAME SAMPLE the reference pickles -- junction
+    numbering, the three edge lists column for column, every feature -- see `generator.reference_sample`, which this
+    is.  `span`: None = the reference's (G, R) lookup (`span_for`).  Needs scipy and Pillow (as the reference does).
+    For structures with exact polygon areas, other seed distributions or shuffled edge lists see `voronoi`."""
+    from .generator import reference_sample
+    return reference_sample(lxd, seed, G, R, span, grain_size, noise)
+
+
+def lattice_structure(lxd: float = 40.0, seed: int = 0, G: float = 2.0, R: float = 0.4, span: int = None,
+                      grain_size: float = 4.0, noise: float = 0.01, shuffle_edges: bool = False):
+    """The reference's lattice (graph_datastruct.py:118-160: spacing grain_size / lxd, jitter variance noise / lxd /
+    (lxd / 40), seeds inside the unit box) tessellated by this package's own periodic Voronoi construction
+    (`_from_seeds`): exact polygon areas instead of the reference's 0.08 um raster, an own random stream, junctions
+    numbered by position.  Same distribution as `generate`, not the same sample (round 2's generator, kept for
+    structures whose areas must tile the domain exactly)."""
     if span is None:
         span = span_for(G, R)
     rs = np.random.RandomState(seed)

@@ -364,60 +364,66 @@ def test_span_lookup_matches_the_reference_expression():
     assert synthetic.span_for(10.0, 0.2) == 60 and np.all(x["grain"][:, 9] == want) and np.all(x["joint"][:, 5] == want)
 
 
-def test_generator_against_the_reference_generator_fixtures():
-    """`synthetic.generate` has the interface and the construction of the reference's
-    `graph_trajectory.py --mode=generate` (:1289-1333) but its own random streams, so it is compared
-    with what the reference generator produced (tests/golden/generated_40_seed{1,2}.npz, made by
-    make_golden_generated.py) property by property.
-    EXACT: schema, N_j = 2 N_g, E = 3 N_j for every edge type, 3 grains + 3 junctions at every
-    junction, mean grain degree 6, grain->joint the flip of joint->grain, the constant feature
-    columns, areas filling the domain, unit orientation vectors.
-    STATISTICAL (same lattice, other sample): grain count within 3 %, variance of the grain degree
-    within a factor 2, coefficient of variation of the areas within 30 %, mean edge lengths within 3 %."""
-    refs = []
-    for s in (1, 2):
-        g = np.load(os.path.join(GOLDEN, f"generated_40_seed{s}.npz"))
-        x = {"grain": g["x_grain"], "joint": g["x_joint"]}
-        ei = {et: g["ei_" + etk(et)] for et in EDGE_TYPES}
-        ea = {et: g["ea_" + etk(et)] for et in EDGE_TYPES}
-        refs.append((x, ei, ea, float(g["span"]), float(g["G"]), float(g["R"])))
-    ref_stats = [_structure_stats(x, ei, ea) for x, ei, ea, *_ in refs]
+def _reference_generated(tag):
+    g = np.load(os.path.join(GOLDEN, f"generated_{tag}.npz"))
+    x = {"grain": g["x_grain"], "joint": g["x_joint"]}
+    ei = {et: g["ei_" + etk(et)] for et in EDGE_TYPES}
+    ea = {et: g["ea_" + etk(et)] for et in EDGE_TYPES}
+    return x, ei, ea, float(g["span"]), float(g["G"]), float(g["R"])
+
+
+@pytest.mark.parametrize("tag,lxd,seed", [("40_seed1", 40, 1), ("40_seed2", 40, 2), ("80_seed7", 80, 7)])
+def test_generate_reproduces_the_reference_sample_bit_for_bit(tag, lxd, seed):
+    """`synthetic.generate(lxd, seed, G, R)` IS the reference's `graph_trajectory.py --mode=generate`
+    sample of that seed (:1289-1333): the fixtures were pickled by the unmodified reference
+    (tests/golden/make_golden_generated.py; the 80 um one with G = 10, R = 0.2, i.e. span 60 from the lookup table).
+    Index work is held to bit-exactness -- the three edge lists column for column, hence the junction and grain
+    numbering --, and so are the fp32 features and edge lengths (same arithmetic in float64, one cast)."""
+    rx, rei, rea, span, G, R = _reference_generated(tag)
+    x, ei, ea = synthetic.generate(lxd=lxd, seed=seed, G=G, R=R)      # span: from the (G, R) lookup, as the reference
+    assert float(x["grain"][0, 9]) == np.float32(span / 120)
+    for et in EDGE_TYPES:
+        assert ei[et].dtype == np.int64 and np.array_equal(ei[et], rei[et]), et
+        assert ea[et].dtype == np.float32 and np.array_equal(ea[et], rea[et]), et
+    for nt in ("grain", "joint"):
+        assert x[nt].dtype == np.float32 and np.array_equal(x[nt], rx[nt]), nt
+
+
+def test_generated_structure_invariants_and_the_polygon_variant():
+    """What every generated structure satisfies (reference sample or `lattice_structure`, the round-2 construction
+    with exact polygon areas and an own random stream): N_j = 2 N_g, E = 3 N_j, 3 grains + 3 junctions at every
+    junction, mean grain degree 6, grain->joint the flip of joint->grain, unit orientation vectors; and the two
+    constructions agree statistically (grain count within 3 %, degree variance within a factor 2, area spread within
+    30 %, mean edge lengths within 3 %)."""
+    refs = [_reference_generated(t)[:3] for t in ("40_seed1", "40_seed2")]
+    ref_stats = [_structure_stats(x, ei, ea) for x, ei, ea in refs]
     mean = lambda k: float(np.mean([st[k] for st in ref_stats]))
-    span, G, R = refs[0][3:]
     ours = []
     for seed in range(6):
-        x, ei, ea = synthetic.generate(lxd=40, seed=seed, G=G, R=R, span=span)
-        n_g, n_j = x["grain"].shape[0], x["joint"].shape[0]
-        for (rx, rei, _, *_), (cx, cei) in [(refs[0], (x, ei))]:
-            assert cx["grain"].shape[1] == rx["grain"].shape[1] == 11 and cx["joint"].shape[1] == rx["joint"].shape[1] == 8
-            assert cx["grain"].dtype == np.float32 and cei[EDGE_TYPES[0]].dtype == np.int64
-        assert n_j == 2 * n_g
-        for et in EDGE_TYPES:
-            assert ei[et].shape == (2, 3 * n_j) and ea[et].shape[0] == 3 * n_j
-        assert np.array_equal(np.bincount(ei[EDGE_TYPES[0]][1], minlength=n_j), np.full(n_j, 3))   # 3 grains per junction
-        assert np.array_equal(np.bincount(ei[EDGE_TYPES[2]][1], minlength=n_j), np.full(n_j, 3))   # 3 junctions per junction
-        assert np.bincount(ei[EDGE_TYPES[1]][1], minlength=n_g).mean() == 6.0
-        assert np.array_equal(ei[EDGE_TYPES[0]], ei[EDGE_TYPES[1]][::-1])
-        # constant columns, exactly what the reference wrote for the same (G, R, span)
-        rx = refs[0][0]
-        for col in (2, 4, 9, 10):
-            assert np.all(x["grain"][:, col] == rx["grain"][0, col]), col
-        for col in (2, 3, 4, 5, 6, 7):
-            assert np.all(x["joint"][:, col] == rx["joint"][0, col]), col
-        assert abs(x["grain"][:, 3].astype(np.float64).sum() - 1.0) < 1e-5          # polygons tile the 40 um domain
-        assert np.allclose(x["grain"][:, 5] ** 2 + x["grain"][:, 6] ** 2, 1, atol=1e-6)
-        assert np.allclose(x["grain"][:, 7] ** 2 + x["grain"][:, 8] ** 2, 1, atol=1e-6)
-        ours.append(_structure_stats(x, ei, ea))
+        for fn in (synthetic.generate, synthetic.lattice_structure):
+            x, ei, ea = fn(lxd=40, seed=seed, G=2.0, R=0.4)
+            n_g, n_j = x["grain"].shape[0], x["joint"].shape[0]
+            assert x["grain"].shape[1] == 11 and x["joint"].shape[1] == 8 and x["grain"].dtype == np.float32
+            assert n_j == 2 * n_g
+            for et in EDGE_TYPES:
+                assert ei[et].shape == (2, 3 * n_j) and ea[et].shape[0] == 3 * n_j and ei[et].dtype == np.int64
+            assert np.array_equal(np.bincount(ei[EDGE_TYPES[0]][1], minlength=n_j), np.full(n_j, 3))   # 3 grains per junction
+            assert np.array_equal(np.bincount(ei[EDGE_TYPES[2]][1], minlength=n_j), np.full(n_j, 3))   # 3 junctions per junction
+            assert np.bincount(ei[EDGE_TYPES[1]][1], minlength=n_g).mean() == 6.0
+            assert np.array_equal(ei[EDGE_TYPES[0]], ei[EDGE_TYPES[1]][::-1])
+            assert np.allclose(x["grain"][:, 5] ** 2 + x["grain"][:, 6] ** 2, 1, atol=1e-6)
+            assert np.allclose(x["grain"][:, 7] ** 2 + x["grain"][:, 8] ** 2, 1, atol=1e-6)
+            if fn is synthetic.lattice_structure:
+                assert abs(x["grain"][:, 3].astype(np.float64).sum() - 1.0) < 1e-5   # polygons tile the 40 um domain
+                ours.append(_structure_stats(x, ei, ea))
     omean = lambda k: float(np.mean([st[k] for st in ours]))
     assert abs(omean("n_g") - mean("n_g")) <= 0.03 * mean("n_g")
     assert 0.5 * mean("deg_var") <= omean("deg_var") <= 2.0 * mean("deg_var")
     assert abs(omean("area_cv") - mean("area_cv")) <= 0.3 * mean("area_cv")
     assert abs(omean("len_gj") - mean("len_gj")) <= 0.03 * mean("len_gj")
     assert abs(omean("len_jj") - mean("len_jj")) <= 0.03 * mean("len_jj")
-    # the reference's raster areas fill the domain to within its pixel size
-    assert all(abs(st["area_sum"] - 1.0) < 0.02 for st in ref_stats)
-    # bigger domains: the density is kept (lxd = 120 -> 9 patches)
-    x, ei, ea = synthetic.generate(lxd=120, seed=0)
+    assert all(abs(st["area_sum"] - 1.0) < 0.02 for st in ref_stats)   # the raster areas fill the domain to a pixel
+    x, ei, ea = synthetic.lattice_structure(lxd=120, seed=0)            # bigger domains keep the density (9 patches)
     assert abs(x["grain"].shape[0] / 9 - mean("n_g")) <= 0.05 * mean("n_g")
     assert abs(float(x["grain"][:, 3].astype(np.float64).sum()) - 9.0) < 1e-4
 
