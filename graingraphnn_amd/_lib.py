@@ -19,6 +19,7 @@ GGNN_EINFO_ROW = 20
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 3
 GGNN_DC_SLICE_BYTES = 21504
+GGNN_PRECISION_BF16 = 1
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
@@ -59,7 +60,7 @@ class ProjectArgs(Structure):
     _fields_ = [
         ("X", c_void_p), ("H", c_void_p), ("Wp", c_void_p), ("bias", c_void_p), ("out", c_void_p),
         ("ldx", c_int64), ("ldh", c_int64), ("M", c_int64), ("ldo", c_int64),
-        ("F", c_int32), ("k2", c_int32), ("ncols", c_int32), ("reserved", c_int32),
+        ("F", c_int32), ("k2", c_int32), ("ncols", c_int32), ("precision", c_int32),
     ]
 
 

@@ -126,12 +126,13 @@ class HipBackend:
 
     def project_batch(self, problems):
         """Up to four projections in one launch (ggnn_project_batch); each item is the argument tuple
-        of `project`: (x, F, h, wp, bp, out).  All with h or all without."""
+        of `project`: (x, F, h, wp, bp, out[, precision]).  All with h or all without."""
         arr = (ProjectArgs * len(problems))()
-        if len({h is None for _, _, h, _, _, _ in problems}) > 1:
+        if len({pr[2] is None for pr in problems}) > 1:
             raise _lib.GGNNError("ggnn_project_batch: every problem with a hidden state or none of them "
                                  "(problems with k2 = 96 and k2 = 0 cannot share a launch)")
-        for a, (x, F, h, wp, bp, out) in zip(arr, problems):
+        for a, (x, F, h, wp, bp, out, *rest) in zip(arr, problems):
+            a.precision = rest[0] if rest else 0   # optional 7th element: _lib.GGNN_PRECISION_BF16 (training, autocast)
             _require_cuda(x, h, wp, bp, out)
             # what the C side cannot see behind a raw pointer: dtypes, unit column strides, the weight's shape
             k2 = 0 if h is None else h.size(1)

@@ -31,7 +31,9 @@ struct ProjectX6Lds {
   __attribute__((aligned(16))) float x[PX_WAVES][PX_BM * PX_LD];
 };
 
-template <int FP>
+// NPROD = 6: the exact split (fp32-equivalent); NPROD = 1 (GGNN_PRECISION_BF16): only the leading bf16 piece of both
+// operands, one product per k-step -- bf16 arithmetic with fp32 accumulation, as autocast defines a linear.
+template <int FP, int NPROD>
 __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int blk, int m_splits, ProjectX6Lds& L) {
   constexpr int KP = FP + 96;  // row length of Wp: [X(FP) | H(96)]
   auto& s_w = L.w;
@@ -194,14 +196,18 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
           wf[nxt][p] = pw[(p * PX_BN + ct1 * 16) * 16 + ((4 * ks1 + kq) ^ lr)];
         if (ks1 == 0) acc_next = s_b[ct1 * 4 + kq];
       }
-      acc = mfma_x6(wf[cur], xb[ks], acc);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      if constexpr (NPROD == 6) {
+        acc = mfma_x6(wf[cur], xb[ks], acc);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      } else {
+        acc = mfma_bf16(wf[cur][0], xb[ks][0], acc);
+      }
       if (ks == PX_KS - 1) {
         *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
         acc = acc_next;
@@ -220,9 +226,15 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(const Proj
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
   const ggnn_project_args& A = B.a[k];
   const int blk = (int)blockIdx.x - B.wg_off[k], Fp = (A.F + 3) & ~3;
-  if (Fp == 4) project_x6_body<4>(A, blk, B.m_splits[k], lds);
-  else if (Fp == 8) project_x6_body<8>(A, blk, B.m_splits[k], lds);
-  else project_x6_body<12>(A, blk, B.m_splits[k], lds);
+  if (A.precision == GGNN_PRECISION_BF16) {
+    if (Fp == 4) project_x6_body<4, 1>(A, blk, B.m_splits[k], lds);
+    else if (Fp == 8) project_x6_body<8, 1>(A, blk, B.m_splits[k], lds);
+    else project_x6_body<12, 1>(A, blk, B.m_splits[k], lds);
+    return;
+  }
+  if (Fp == 4) project_x6_body<4, 6>(A, blk, B.m_splits[k], lds);
+  else if (Fp == 8) project_x6_body<8, 6>(A, blk, B.m_splits[k], lds);
+  else project_x6_body<12, 6>(A, blk, B.m_splits[k], lds);
 }
 
 }  // namespace ggnn

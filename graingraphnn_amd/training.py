@@ -17,15 +17,17 @@ and the module is in training mode, i.e. inside the reference's loop (train.py:1
     + `ggnn_wgrad` backward); the classifier's pair heads are `_RowLinear` (weight gradient through `ggnn_wgrad`)
     and a few recorded pointwise ops.
 
-Everything inside the cell is fp32, also under bf16 autocast.  Same results as the inference path up to fp32
-re-association.
+Under `torch.autocast(bfloat16)` (BASELINE config 5) the decoder cell's projection runs in real bf16 arithmetic on
+the HIP kernel (operands rounded to bf16, one MFMA product per k-step, fp32 accumulate: GGNN_PRECISION_BF16), as do
+the recorded 2-D GEMMs around the cells; the sweep, the softmax, the LSTM update and every gradient stay fp32.
+Without autocast everything is fp32-equivalent: same results as the inference path up to fp32 re-association.
 """
 from typing import Dict
 
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _pins
+from . import _lib, _pins
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
 from .packing import C, EDGE_TYPES, NODE_TYPES
@@ -102,12 +104,12 @@ class _PackedCell(torch.autograd.Function):
 
     Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j) with the packed matrices as
     train_pack.packed_weights lays them out (wp [ncols, Fp + k2], w2 [G, 96, Kg]); h / c None = zero state
-    (encoder, 3 gates).  x carries no gradient (data).  Everything is fp32, also under bf16 autocast."""
+    (encoder, 3 gates).  x carries no gradient (data).  `bf16`: the caller ran under bf16 autocast."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep_gj, ep_jg, ep_jj, w2_g, w2_j,
-                backend, topo, einfo, layout, G):
+                backend, topo, einfo, layout, G, bf16=False):
         x = {"grain": x_g.contiguous(), "joint": x_j.contiguous()}
         sees_h = h_g is not None
         h = {"grain": h_g.contiguous() if sees_h else None, "joint": h_j.contiguous() if sees_h else None}
@@ -122,7 +124,11 @@ class _PackedCell(torch.autograd.Function):
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
             P[nt] = torch.empty(n, lay.ncols, **f32)
-            problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt]))
+            # under torch.autocast(bfloat16) the decoder projection -- the cell's big linear, [x | h] Wp^T -- runs as
+            # bf16 operands / one MFMA product per k-step / fp32 accumulate (GGNN_PRECISION_BF16); the encoder's K <= 12
+            # projection, the sweep and the softmax stay fp32
+            prec = _lib.GGNN_PRECISION_BF16 if (bf16 and sees_h) else 0
+            problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt], prec))
             # the sweeps write every aggregate and scalar column of every row; the pad columns behind them meet zero
             # columns of w2 and only have to be finite
             agg[nt] = torch.empty(n, G * lay.Kg, **f32)
@@ -208,7 +214,7 @@ class _PackedCell(torch.autograd.Function):
             g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, Fp:]) if sees_h else None     # [N, 96]
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
-                g_w2["grain"], g_w2["joint"], None, None, None, None, None)
+                g_w2["grain"], g_w2["joint"], None, None, None, None, None, None)
 
 
 def cell_forward(cell, backend, topo, einfo, x, h, c):
@@ -218,13 +224,14 @@ def cell_forward(cell, backend, topo, einfo, x, h, c):
     gates = "ifco" if h is not None else "ico"
     G = len(gates)
     F = cell.in_channels_dict
+    bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
     with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
         layout, wp, bp, ep, w2 = packed_weights(cell, gates, F, h is not None)
     hg, cg, hj, cj = _PackedCell.apply(
         x["grain"], x["joint"], None if h is None else h["grain"], None if h is None else h["joint"],
         None if c is None else c["grain"], None if c is None else c["joint"], wp["grain"], wp["joint"], bp["grain"],
         bp["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]], ep[EDGE_TYPES[2]], w2["grain"], w2["joint"], backend, topo,
-        einfo, layout, G)
+        einfo, layout, G, bf16)
     return {"grain": hg, "joint": hj}, {"grain": cg, "joint": cj}
 
 

@@ -131,7 +131,10 @@ typedef struct ggnn_project_args {
   const float* bias;
   float* out;
   int64_t ldx, ldh, M, ldo;
-  int32_t F, k2, ncols, reserved;
+  int32_t F, k2, ncols;
+  int32_t precision; /* 0: fp32-equivalent (exact 3-piece bf16 split, 6 products per k-step; the inference path);
+                        GGNN_PRECISION_BF16 (k2 == 96 only): operands rounded to bf16, ONE bf16 MFMA product per
+                        k-step, fp32 accumulate -- what torch.autocast(bfloat16) asks of a linear (training path) */
 } ggnn_project_args;
 int ggnn_project_batch(const ggnn_project_args* args, int n_problems, ggnn_stream_t stream);
 
@@ -377,6 +380,7 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  *             ([ct][l] = k < 2 ? tail[16 ct + (l & 15)][k = l >> 4] : 0)
  * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
+#define GGNN_PRECISION_BF16 1
 #define GGNN_DC_SLICE_BYTES 21504 /* 7 column tiles x 3 planes x 1 KB */
 typedef struct ggnn_dec_cell_sweep {
   const int32_t* rowptr;     /* [n_dst + 1] */

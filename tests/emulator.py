@@ -314,8 +314,14 @@ class TorchEmulatorBackend:
                             @ torch.as_strided(fb, (K, Nc), (ldb, 1), ob + k * b_bstride) for k in range(batch)])
 
     def project_batch(self, problems):
-        for prob in problems:
-            self.project(*prob)
+        """(x, F, h, wp, bp, out[, precision]); precision GGNN_PRECISION_BF16: both operands rounded to bf16, products
+        accumulated in fp32 (what the HIP kernel's single-product mode computes)."""
+        for x, F, h, wp, bp, out, *rest in problems:
+            if rest and rest[0] == 1:
+                r = lambda t: None if t is None else t.to(torch.bfloat16).float()
+                self.project(r(x), F, r(h), r(wp), bp, out)
+            else:
+                self.project(x, F, h, wp, bp, out)
 
     def lstm_epilogue_batch(self, problems):
         for prob in problems:

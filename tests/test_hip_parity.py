@@ -98,6 +98,35 @@ def test_project_matches_fp32_matmul(M, F, k2, ncols):
     assert_close(out, ref, f"project M={M} F={F} k2={k2} ncols={ncols}", 2e-6)
 
 
+@pytest.mark.parametrize("M,F,ncols", [(63, 11, 192), (1000, 8, 2112), (777, 11, 1248), (16, 3, 96)])
+def test_project_bf16_precision_is_one_rounded_product(M, F, ncols):
+    """GGNN_PRECISION_BF16 (the training path under torch.autocast(bfloat16)): both operands rounded to bf16 (round
+    to nearest even), ONE MFMA product per k-step, fp32 accumulation -- against the float64 product of the rounded
+    operands (every product of two bf16 values is exact, so only the accumulation differs), and refused where it does
+    not exist (encoder shape)."""
+    rs = np.random.RandomState(M + F)
+    Fp = (F + 3) & ~3
+    x = torch.from_numpy(rs.uniform(-1, 1, (M, F)).astype(np.float32))
+    h = torch.from_numpy(rs.uniform(-1, 1, (M, 96)).astype(np.float32))
+    wp = torch.from_numpy(rs.uniform(-0.3, 0.3, (ncols, Fp + 96)).astype(np.float32))
+    wp[:, F:Fp] = 0
+    bp = torch.from_numpy(rs.uniform(-1, 1, ncols).astype(np.float32))
+    r = lambda t: t.to(torch.bfloat16).double()
+    xin = torch.zeros(M, Fp + 96, dtype=torch.float64)
+    xin[:, :F], xin[:, Fp:] = r(x), r(h)
+    ref = (xin @ r(wp).t() + bp.double()).float()
+    out = torch.full((M, ncols), float("nan"), device=DEV)
+    be = backend()
+    be.project_batch([(x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV), out, _lib.GGNN_PRECISION_BF16)])
+    assert_close(out, ref, f"bf16 project M={M} F={F} ncols={ncols}", 2e-6)
+    exact = torch.empty_like(out)
+    be.project_batch([(x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV), exact)])
+    assert 1e-4 < rel_err(out, exact) < 2e-2          # it IS a different arithmetic: ~2^-9 per operand
+    with pytest.raises(_lib.GGNNError):               # no single-product mode for the K <= 12 encoder projection
+        be.project_batch([(x.to(DEV), F, None, wp[:96, :Fp].contiguous().to(DEV), bp[:96].to(DEV), out[:, :96],
+                           _lib.GGNN_PRECISION_BF16)])
+
+
 def test_gemm_arithmetic_is_fp32_equivalent():
     """The decoder GEMMs run by default as 3 x bf16 split / 6 MFMA products (GGNN_GEMM_BF16X6).
     Their error against an fp64 product, normalised by sum_k |x_k||w_k| (the quantity fp32
