@@ -101,7 +101,9 @@ def main():
         import json
         print(json.dumps({"workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
                           "launch": "hipGraph replay (training.GraphedTrainStep recipe)" if args.graph else "eager",
-                          "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; fp32",
+                          "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; " +
+                                  ("torch.autocast(bfloat16): the decoder projection in bf16 MFMA arithmetic "
+                                   "(GGNN_PRECISION_BF16), sweeps / softmax / LSTM / gradients fp32" if args.bf16 else "fp32"),
                           "optimizer": "torch.optim.Adam(fused=True)" if args.fused else "torch.optim.Adam (default: foreach)",
                           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}))
         return
