@@ -73,14 +73,17 @@ U4 = 16  # width of the per-(destination, gate) tail record: u[0:F_src], s1 @12,
 
 
 def node_layout(node_type: str, F: int, G: int, edge_types=EDGE_TYPES, live: bool = True,
-                sees_h: bool = True, with_values: bool = True) -> NodeLayout:
+                sees_h: bool = True, with_values: bool = True, live_types=NODE_TYPES) -> NodeLayout:
     """`live=False`: the new (h, c) of this node type is never read (the classifier's decoder only
     feeds h_joint to its head, models.py:595-609), so the type keeps only its role as a message
     SOURCE: no score / skip columns, no aggregation into it, no gate update.
     `sees_h=False` (encoder, h = 0): the hidden-state part of u is not needed.
     `with_values=False` (encoder): no value columns -- the encoder sweep forms the values from the
-    edge records on the matrix cores (ggnn_period_gat_aggregate_enc_batch)."""
-    src_ets = [tuple(et) for et in edge_types if et[0] == node_type]
+    edge records on the matrix cores (ggnn_period_gat_aggregate_enc_batch).
+    `live_types`: the node types that are live in this cell (value rows towards a dead type are not projected:
+    the classifier's decoder never sweeps joint -> grain)."""
+    # value rows only for edge types somebody sweeps: a dead destination type (`live_types`) takes no messages
+    src_ets = [tuple(et) for et in edge_types if et[0] == node_type and et[-1] in live_types]
     dst_ets = [tuple(et) for et in edge_types if et[-1] == node_type] if live else []
     lay = NodeLayout(F=F, G=G, src_ets=src_ets, dst_ets=dst_ets, live=live)
     off = 0
@@ -306,7 +309,7 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
     F_of = dict(in_channels)
     # encoder: the sweep forms the values from the edge records (no value columns in the projection)
     enc_mfma = encoder and all(F <= 11 for F in in_channels.values())
-    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, not encoder, not enc_mfma)
+    layout = {nt: node_layout(nt, in_channels[nt], G, edge_types, nt in live, not encoder, not enc_mfma, tuple(live))
               for nt in NODE_TYPES}
     wp, bp, w2, ep = {}, {}, {}, {}
 

@@ -11,7 +11,7 @@ for g in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $OUT/pmc/$i -- python3 bench.py --steps 5 --warmup 2 --profile --no-graph --serial > $OUT/pmc_$i.log 2>&1
 done
-python3 tools/pmc_aggregate.py $OUT/pmc $OUT/r2_pmc_aggregate.json > $OUT/pmc_aggregate.log 2>&1
+python3 tools/pmc_aggregate.py $OUT/pmc $OUT/r3_pmc_aggregate_sweep.json > $OUT/pmc_aggregate.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]
@@ -36,7 +36,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default
 find $OUT/default -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/default_command_kernel_stats.csv
 rm -rf $OUT/default
 python3 tools/kernel_table.py $OUT/serial_kernel_stats.csv $OUT/joint_kernel_stats.csv > $OUT/kernel_table.txt
-cp $OUT/r2_pmc_aggregate.json profiles/r2_pmc_aggregate.json 2>/dev/null   # so that the bench line below quotes it
+cp $OUT/r3_pmc_aggregate_sweep.json profiles/r3_pmc_aggregate_sweep.json 2>/dev/null   # so that the bench line below quotes it
 timeout 600 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench_driver_command.err
 tail -1 $OUT/bench_default.json | cut -c1-400
