@@ -29,7 +29,23 @@ def main(paths):
     for p in paths:
         plan = "fused" if "fused" in os.path.basename(p) else "split"
         rows = {}
-        for r in csv.DictReader(open(p)):
+        raw = list(csv.DictReader(open(p)))
+        if raw and "counter" in raw[0]:   # tools/profile_round.sh's long format: kernel, counter, mean_per_launch, launches
+            per = {}
+            for r in raw:
+                per.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_launch"])
+            raw = []
+            for kn, c in per.items():
+                g = lambda k: c.get(k, 0.0)
+                rd = 32 * g("TCC_EA0_RDREQ_32B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 128 * g("TCC_EA0_RDREQ_128B_sum")
+                rd += 64 * max(g("TCC_EA0_RDREQ_sum") - g("TCC_EA0_RDREQ_32B_sum") - g("TCC_EA0_RDREQ_64B_sum") - g("TCC_EA0_RDREQ_128B_sum"), 0)
+                wr = 64 * g("TCC_EA0_WRREQ_64B_sum") + 32 * max(g("TCC_EA0_WRREQ_sum") - g("TCC_EA0_WRREQ_64B_sum"), 0)
+                wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+                raw.append({"kernel": kn, "read_MB_per_launch": rd / 1e6, "write_MB_per_launch": wr / 1e6,
+                            "valu_per_mfma": g("SQ_INSTS_VALU") / max(g("SQ_INSTS_MFMA"), 1.0),
+                            "mfma_busy_Mcycles": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1e6,
+                            "wait_any_frac": g("SQ_WAIT_ANY") / wc, "wait_inst_frac": g("SQ_WAIT_INST_ANY") / wc})
+        for r in raw:
             if float(r["read_MB_per_launch"]) + float(r["write_MB_per_launch"]) < 5:
                 continue
             rows[r["kernel"]] = {"read_bytes": int(float(r["read_MB_per_launch"]) * 1e6),
@@ -39,6 +55,15 @@ def main(paths):
                                  "wait_any_frac": float(r["wait_any_frac"]), "wait_inst_frac": float(r["wait_inst_frac"])}
         doc["plans"][plan] = rows
     out = os.path.join(ROOT, "profiles", "r3_pmc_kernels.json")
+    if os.path.exists(out) and len(doc["plans"]) < 2:   # keep the other plan's record of an earlier run (its own stamp)
+        try:
+            old = json.load(open(out))
+            for plan, rows in old.get("plans", {}).items():
+                if plan not in doc["plans"]:
+                    doc["plans"][plan] = rows
+                    doc.setdefault("other_plan_stamp", {})[plan] = old.get("kernel_source_hash")
+        except (OSError, ValueError):
+            pass
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(out, {k: list(v) for k, v in doc["plans"].items()})
