@@ -127,7 +127,8 @@ class _PackedCell(torch.autograd.Function):
             # under torch.autocast(bfloat16) the decoder projection -- the cell's big linear, [x | h] Wp^T -- runs as
             # bf16 operands / one MFMA product per k-step / fp32 accumulate (GGNN_PRECISION_BF16); the encoder's K <= 12
             # projection, the sweep and the softmax stay fp32
-            prec = _lib.GGNN_PRECISION_BF16 if (bf16 and sees_h) else 0
+            x6 = getattr(getattr(backend, "lib", None), "ggnn_gemm_mode", lambda: 1)() == 1   # (not under GGNN_GEMM=fp32)
+            prec = _lib.GGNN_PRECISION_BF16 if (bf16 and sees_h and x6) else 0
             problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt], prec))
             # the sweeps write every aggregate and scalar column of every row; the pad columns behind them meet zero
             # columns of w2 and only have to be finite

@@ -117,6 +117,10 @@ def test_project_bf16_precision_is_one_rounded_product(M, F, ncols):
     ref = (xin @ r(wp).t() + bp.double()).float()
     out = torch.full((M, ncols), float("nan"), device=DEV)
     be = backend()
+    if be.lib.ggnn_gemm_mode() == 0:   # GGNN_GEMM=fp32: the native-fp32 kernels have no bf16 mode and say so
+        with pytest.raises(_lib.GGNNError):
+            be.project_batch([(x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV), out, _lib.GGNN_PRECISION_BF16)])
+        return
     be.project_batch([(x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV), out, _lib.GGNN_PRECISION_BF16)])
     assert_close(out, ref, f"bf16 project M={M} F={F} ncols={ncols}", 2e-6)
     exact = torch.empty_like(out)
