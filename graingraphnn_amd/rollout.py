@@ -92,6 +92,16 @@ class GrainRollout:
         self.steps_done = 0
         self.use_graph = use_graph
 
+    @torch.no_grad()
+    def set_process_parameters(self, G: float, R: float):
+        """The reference's `--temporal` schedule (test.py:345-346, 376-378): thermal gradient G and pulling speed R
+        of the step to come, written into the junction features (`x_joint[:, 3] = 1 - G / 10`, `x_joint[:, 4] = R / 2`)
+        before the forwards.  The edge records of the next step carry the sources' features, so they are rebuilt: the
+        in-place write bumps the tensor's version counter, which step() / run() check (`_ensure_edge_records`).  The
+        values themselves (graph_trajectory.py:129-175, GR_seq_from_time) are the caller's: call this between steps."""
+        self.x["joint"][:, 3] = 1.0 - float(G) / 10.0
+        self.x["joint"][:, 4] = float(R) / 2.0
+
     def _pack_weights(self):
         """Fused device weights of both models, and the parameter versions they were packed from."""
         self._wver = (_param_version(self.rmodel), _param_version(self.cmodel))

@@ -1252,6 +1252,31 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
         be.replay = orig
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@torch.no_grad()
+def test_temporal_process_parameters_between_steps(use_graph):
+    """test.py:376-378 (`--temporal`): G and R of the step to come are written into the junction features between
+    steps.  `GrainRollout.set_process_parameters` + step() against the oracle stepping the same schedule; the edge
+    records (which carry the sources' features) are rebuilt because the write is detected, also between replays of
+    a captured step."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(31, 1.0, DEV)
+    oR, oC = oracle_models(31, 1.0)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=use_graph, concurrent=True, joint_launches=False)
+    for G, Rp in ((2.0, 0.4), (7.5, 1.6), (7.5, 1.6), (0.9, 0.25)):
+        ro.set_process_parameters(G, Rp)
+        oX["joint"][:, 3], oX["joint"][:, 4] = 1.0 - G / 10.0, Rp / 2.0
+        pred = {k: v.clone() for k, v in ro.step().items()}
+        opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert_close(pred[k], opred[k], f"temporal G={G} R={Rp} {k}")
+    for nt in x:
+        assert_close(X[nt], oX[nt], f"temporal x {nt}")
+
+
 @torch.no_grad()
 def test_run_with_multi_step_graph_equals_single_steps():
     """GrainRollout.run(n) replays graphs of RUN_UNROLL steps: bit-identical to n x step()."""
