@@ -502,6 +502,8 @@ __global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCel
   dec_cell_body(B.a[k], ts, s_raw);
 }
 
+int dec_cell_ws_launch(const ggnn_dec_cell_args* args, int n_problems, hipStream_t stream);   // dec_cell_ws.hip
+
 }  // namespace ggnn
 
 extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream) {
@@ -536,6 +538,11 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
     if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
     B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
   }
+  static const bool specialised = [] {   // development switch: the specialised-wave kernel (dec_cell_ws.hip)
+    const char* e = getenv("GGNN_DC_KERNEL");
+    return e && e[0] == 'w';
+  }();
+  if (specialised) return dec_cell_ws_launch(args, n_problems, (hipStream_t)stream);
   static const int stagger = [] {
     const char* e = getenv("GGNN_DC_STAGGER");   // development knob: sleeps of 127 x 64 clocks (~4 us each)
     return e ? atoi(e) : 0;

@@ -241,6 +241,21 @@ def test_native_fp32_gemm_mode_in_a_subprocess():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_specialised_wave_decoder_cell_in_a_subprocess():
+    """GGNN_DC_KERNEL=ws (csrc/dec_cell_ws.hip: matrix, sweep and weight-stream waves of one workgroup handing
+    tiles to each other through LDS generation counters) is fixed per process: the fused decoder cell's contract
+    tests once more under it.  A protocol fault there raises NaN in the outputs (bounded spins), never a hang."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GGNN_DC_KERNEL") == "ws":
+        return
+    env = dict(os.environ, GGNN_DC_KERNEL="ws")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "fused_decoder"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------
 # op level: PeriodConv and HeteroPGCLSTM against the reference's golden vectors (cfg1)
 # ---------------------------------------------------------------------------------------
