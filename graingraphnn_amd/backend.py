@@ -49,7 +49,13 @@ class HipBackend:
         # GGNN_DEC=fused: ggnn_decoder_cell_batch behind a value-only projection.  The fused cell moves a third of
         # the bytes but measured 2 % slower in the rollout (1 926 vs 1 970 steps/s, same box: DESIGN.md section 4),
         # so it is the selectable path, fully tested, not the default.
-        self.fused_decoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_DEC", "") == "fused")
+        # True: every decoder cell through ggnn_decoder_cell_batch; "classifier" / "regressor": that model's only (the
+        # other keeps projection + sweeps + gate GEMM: in the two-stream rollout one model's latency-bound fused cell
+        # then runs beside the other's bandwidth-bound kernels); False: none
+        dec = os.environ.get("GGNN_DEC", "")
+        self.fused_decoder = False
+        if self.lib.ggnn_gemm_mode() == 1 and dec.startswith("fused"):
+            self.fused_decoder = {"fused": True, "fused-classifier": "classifier", "fused-regressor": "regressor"}.get(dec, False)
 
     # -- launch tape: the drop-in forward() issues the same dozen launches with the same arguments
     # step after step (test.py:382-383); re-issuing the recorded C calls skips the per-launch

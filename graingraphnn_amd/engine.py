@@ -157,7 +157,10 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                                        for et in lay[nt].dst_ets], proj[nt], x[nt], pc.wst[nt], pc.w2[nt], pc.w2f[nt],
                                       _pre_view(agg[nt], len(lay[nt].dst_ets)), h_out[nt], c_out[nt]))
             continue
-        if pc.dcs and getattr(backend, "fused_decoder", False):
+        fd = getattr(backend, "fused_decoder", False)
+        if fd not in (False, True):   # one model's decoder only: the classifier's has one live destination type
+            fd = fd == ("classifier" if sum(bool(lay[nt].live) for nt in NODE_TYPES) == 1 else "regressor")
+        if pc.dcs and fd:
             # decoder: everything on the destination side in one kernel (ggnn_decoder_cell_batch); the projection only
             # emits the source-side value rows
             for nt in NODE_TYPES:
