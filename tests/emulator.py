@@ -215,6 +215,7 @@ class TorchEmulatorBackend:
         """ggnn_decoder_cell_batch: per gate (stream order i, c~, f, o) and incoming edge type the score operands
         u_h | u4 = W1 [h | x | 1], the sweep, lin_l2 + (b_l2, w_edge) on the aggregates; then the skip block and the
         LSTM update.  Everything is computed from the DECODED weight stream, so a packing error shows up here."""
+        self.calls = getattr(self, "calls", []) + ["decoder_cell_batch"]   # (which plan ran: test_decoder_plan_per_model)
         for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
             n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
             assert wstream.numel() * 2 == 4 * (7 * n_in + 4) * 21504 and tuple(w2_tail.shape) == (4, n_in, 6, 64)

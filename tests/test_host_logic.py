@@ -142,6 +142,20 @@ def _run_model_emulated(model, x, ei, ea, fused_decoder=True):
     return be, graph, h
 
 
+@torch.no_grad()
+def test_decoder_plan_per_model():
+    """GGNN_DEC=fused-classifier / fused-regressor (backend.fused_decoder = "classifier" / "regressor"): the fused
+    decoder cell for that model only -- told apart by the number of live destination types of its decoder."""
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    for which, fused_for in (("classifier", {"C"}), ("regressor", {"R"}), (True, {"R", "C"}), (False, set())):
+        for name, model in (("R", R), ("C", Cm)):
+            be, _, _ = _run_model_emulated(model, X, EI, EA, which)
+            used_fused = "decoder_cell_batch" in getattr(be, "calls", [])
+            assert used_fused == (name in fused_for), (which, name)
+
+
 @pytest.mark.parametrize("fused_decoder", [False, True])
 @pytest.mark.parametrize("tag,seed,scale", [("cfg1_s1", 10020, 1.0), ("cfg1_s3", 10020, 3.0),
                                             ("cfg2_s1", 0, 1.0)])
