@@ -13,12 +13,12 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 17
+GGNN_ABI_VERSION = 18
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 3
-GGNN_DC_SLICE_BYTES = 21504
+GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 

@@ -12,6 +12,7 @@ from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, DecCellArg
                    RefreshEdge, check, ptr)
 
 
+
 class CSR:
     """Destination-grouped edge list of one edge type (all int32, device resident)."""
     __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E", "n_blocks")
@@ -46,13 +47,10 @@ class HipBackend:
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
         # decoder cell: projection (with the destination-side columns) + sweeps + gate GEMM (default), or
-        # GGNN_DEC=fused: ggnn_decoder_cell_batch behind a value-only projection.  The fused cell moves a third of
-        # the bytes but measured 2 % slower in the rollout (1 926 vs 1 970 steps/s, same box: DESIGN.md section 4),
-        # so it is the selectable path, fully tested, not the default.
-        # True: every decoder cell through ggnn_decoder_cell_batch; "classifier" / "regressor": that model's only (the
-        # other keeps projection + sweeps + gate GEMM: in the two-stream rollout one model's latency-bound fused cell
-        # then runs beside the other's bandwidth-bound kernels); False: none
-        dec = os.environ.get("GGNN_DEC", "")
+        # The decoder cell of a model: ONE kernel (ggnn_decoder_cell_batch, the default with the bf16 / fp16 matrix-core
+        # GEMM mode) or projection + sweeps + gate GEMM (GGNN_DEC=split; always under GGNN_GEMM=fp32).
+        # GGNN_DEC=fused-classifier / fused-regressor: the fused cell for that model only (development).
+        dec = os.environ.get("GGNN_DEC", "fused")
         self.fused_decoder = False
         if self.lib.ggnn_gemm_mode() == 1 and dec.startswith("fused"):
             self.fused_decoder = {"fused": True, "fused-classifier": "classifier", "fused-regressor": "regressor"}.get(dec, False)

@@ -86,6 +86,33 @@ __device__ __forceinline__ f32x4 mfma_x6(const u32x4 (&w)[3], const u32x4 (&x)[3
   return c;
 }
 
+// ---- the same GEMMs with TWO fp16 pieces and THREE products (development: dec_cell.hip -DDC_F16X2) ----
+// x = hi + lo' / 2^11 + e with hi = rne16(x), lo' = rne16((x - hi) 2^11): 2 x 11 significand bits, |e| <= 2^-22 |x|;
+// the scaling keeps the residual in fp16's normal range down to |x| ~ 2^-13.  x*w ~ hi*hi + (hi*lo' + lo'*hi) / 2^11:
+// the cross terms go to a second accumulator that is folded in once, after the k-loop.  Against an fp64 product,
+// normalised by sum |x||w|: 4.6e-8 .. 6e-8 (K = 104 / 196), the six-product bf16 split 2e-8, a plain fp32 fma chain
+// 2e-7 -- half the MFMAs and two thirds of the weight bytes of the bf16 split.  |x| > 65504 saturates (clamped).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+constexpr float F16X2_SCALE = 2048.0f;
+__device__ __forceinline__ void split_f16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
+  b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+  const f16x2_ h = {(_Float16)a, (_Float16)b};
+  const f16x2_ l = {(_Float16)((a - (float)h[0]) * F16X2_SCALE), (_Float16)((b - (float)h[1]) * F16X2_SCALE)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the three kept products of one k-step: main += hi hi, cross += hi lo' + lo' hi
+__device__ __forceinline__ void mfma_x3h(const u32x4 (&w)[2], const u32x4 (&x)[2], f32x4& main, f32x4& cross) {
+  cross = mfma_f16(w[0], x[1], cross);
+  cross = mfma_f16(w[1], x[0], cross);
+  main = mfma_f16(w[0], x[0], main);
+}
+
 // Sum over the 16 lanes of a DPP row, result in every lane of the row (four v_add_f32 with DPP).
 __device__ __forceinline__ float row_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

@@ -16,14 +16,19 @@
 //     all gates were kept at once: the gates are walked ONE AFTER THE OTHER (i, c~, f, o) and the LSTM update is
 //     folded in as they arrive (sig(i) -> sig(i) tanh(c~) -> c' -> h'), so a wave holds one gate's 16 x 96
 //     pre-activations (24 VGPRs) plus the running LSTM term (24), never four;
-//   * the weights of a destination type are 1.25 MB as bf16 planes (joints: 2 x 4 score blocks [112 x 128],
-//     8 lin_l2 blocks, 4 skip blocks) -- eight times the LDS.  They arrive as k-step slices (one 32-deep
-//     k-step of one block: 21 KB) through a double-buffered LDS region shared by the workgroup's four waves,
-//     fetched one slice ahead (16-byte loads at the top of a k-step, ds_write_b128 at its end), one workgroup
-//     barrier per slice.  Host-side pre-split planes: no splitting arithmetic on the weight side in the kernel
-//     (the gate kernel's split cost 44 VALU per fragment).
-//   * two workgroups per compute unit (80 KB of LDS each, two waves per SIMD) so that one workgroup's sweep
-//     phases (latency-bound gathers) run beside the other's matrix phases.
+//   * the weights of a destination type are 0.84 MB as two fp16 planes (joints: 2 x 4 score blocks [112 x 128],
+//     8 lin_l2 blocks, 4 skip blocks) -- five times the LDS.  They arrive as k-step slices (one 32-deep
+//     k-step of one block: 14 KB) through a double-buffered LDS region shared by the workgroup's eight waves,
+//     fetched one slice ahead by LDS-DMA, one workgroup barrier per slice.  Host-side pre-split planes: no
+//     splitting arithmetic on the weight side in the kernel (the gate kernel's split cost 44 VALU per fragment).
+//   * arithmetic: every fp32 operand as TWO fp16 pieces (hi = rne16(x), lo' = rne16((x - hi) 2^11)) and THREE MFMA
+//     products per k-step (hi hi into the main accumulator; hi lo' + lo' hi into a cross accumulator that is folded
+//     in with 2^-11 behind the k-loop): 22 significand bits per operand, against an fp64 product 5e-8 of sum |x||w|
+//     (a plain fp32 fma chain: 2e-7; the six-product bf16 split of the other GEMM kernels: 2e-8) -- common.h.  Until
+//     round 3's last version this kernel used the bf16 split too: 21 KB slices, 42 MFMAs per P1 slice, 144 us per
+//     launch at the 10k-grain graph against 122 us now.
+//   * the tile's input rows [h | x | 1 | 0] stay in LDS for the whole tile (B operand of P1 and P4 of every
+//     gate): as registers they had to be reloaded behind every sweep, in front of P3's first slice.
 // A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
 // and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
 #include <algorithm>
@@ -38,14 +43,17 @@ namespace ggnn {
 
 constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
-constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 21 pieces of 1 KB
+constexpr int DC_PL = 2;                            // weight / operand planes: fp16 hi and scaled residual (common.h)
+constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
+static_assert(DC_SLICE == 7 * DC_PL * 1024, "slice = 7 column tiles x planes x 1 KB");
+constexpr int DC_NP1 = 7 * DC_PL, DC_NP3 = 6 * DC_PL;   // pieces of a P1 slice / of a P3 or P4 slice
 constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
 constexpr int DC_STAGE = 16 * DC_S * 4;             // 7 424 B
-constexpr int DC_XF = 16 * 16 * 4;                  // feature tile [16 nodes][16]
+constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [16 nodes][h 96 | x F | 1 | 0 ..]: B operand of P1 / P4
 constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
 constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
 constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
-constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 118 784 B
+constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 155 648 B
 static_assert(DC_LDS <= 160 * 1024, "LDS");
 
 struct DecCellBatch {
@@ -66,36 +74,41 @@ __device__ __forceinline__ void dc_dma16(const void* gsrc, uint32_t lds_base) {
                : "memory");
 }
 
-__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[3]) {
+__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[DC_PL]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const f32x4 h = e < 2 ? r0 : r1;
-    uint32_t q0, q1, q2;
-    split_bf16x3(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1, q2);
+    uint32_t q0, q1;
+    split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
     xb[0][e] = q0;
     xb[1][e] = q1;
-    xb[2][e] = q2;
   }
 }
 
 // One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
 // lane; piece (nb, plane) at (nb * 3 + plane) * 64).  The three weight fragments of tile nb + 1 are read while the
 // six MFMAs of tile nb run.
+// An accumulator of a 16 x 16 output tile: one register set for the bf16 split, main + cross for the fp16 one.
+struct DcAcc {
+  f32x4 m, c;
+  __device__ __forceinline__ void zero() { m = c = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ f32x4 value() const { return m + c * (1.0f / F16X2_SCALE); }
+};
 template <int NB>
-__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[3], f32x4 (&acc)[NB]) {
-  u32x4 wf[2][3];
+__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
+  u32x4 wf[2][DC_PL];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) wf[0][p] = pw[p * 64];
-  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+  for (int p = 0; p < DC_PL; ++p) wf[0][p] = pw[p * 64];
+  __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     if (nb + 1 < NB) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[(nb + 1) & 1][p] = pw[((nb + 1) * 3 + p) * 64];
+      for (int p = 0; p < DC_PL; ++p) wf[(nb + 1) & 1][p] = pw[((nb + 1) * DC_PL + p) * 64];
     }
-    acc[nb] = mfma_x6(wf[nb & 1], xb, acc[nb]);
-    if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                   // MFMA
+    mfma_x3h(wf[nb & 1], xb, acc[nb].m, acc[nb].c);
+    if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * DC_PL - (DC_PL == 2 ? 1 : 0), 0);   // MFMA (6 or 3)
   }
 }
 
@@ -151,37 +164,27 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     st_wait += GGNN_STAMP_NOW() - w0;
     ++s_cur;
   };
-  dma_slice(0, 21);
+  dma_slice(0, DC_NP1);
 
-  // ---- tile prologue: h rows as B fragments (kept for the whole tile), features -> LDS, CSR windows -> LDS ----
-  // the tile's h rows as B fragments: needed by P1 and P4, dead during the sweep (where every register counts), so
-  // they are fetched again behind every sweep (L1 / L2 hits, hidden under P3's matrix work)
-  f32x4 xh[3][2];
-  const float* __restrict__ hrow = A.h_dst + (int64_t)node_m * A.ldh + 8 * kq;
-  auto load_xh = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      xh[ks][0] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks);
-      xh[ks][1] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks + 4);
-    }
-  };
+  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS (read as B fragments by P1 and P4 of every
+  // gate: registers are what the sweep is short of, and a reload from memory behind every sweep sat in front of
+  // P3's first slice -- in-kernel stamps: 1.57 us per P3 slice against 0.6-0.7 for P1 / P4), CSR windows -> LDS ----
+  float* __restrict__ xin = xf;
   // B-fragment planes of k-step ks of [h | x | 1 | 0]: k-steps 0..2 are the h rows, k-step 3 the 16 feature slots
   // (k-groups 0 and 1; zeros behind)
-  auto x_planes = [&](int ks, u32x4 (&out)[3]) __attribute__((always_inline)) {
-    f32x4 r0, r1;
-    if (ks < 3) {
-      r0 = xh[ks][0];
-      r1 = xh[ks][1];
-    } else {
-      const float* fr = &xf[lr * 16 + 8 * (kq & 1)];
-      r0 = *reinterpret_cast<const f32x4*>(fr);
-      r1 = *reinterpret_cast<const f32x4*>(fr + 4);
-      if (kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+  auto x_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
+    const float* fr = &xin[lr * DC_S + 32 * ks + 8 * (ks < 3 ? kq : (kq & 1))];
+    f32x4 r0 = *reinterpret_cast<const f32x4*>(fr);
+    f32x4 r1 = *reinterpret_cast<const f32x4*>(fr + 4);
+    if (ks == 3 && kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     dc_split(r0, r1, out);
   };
   {
-    load_xh();
+    for (int q = lane; q < 16 * 24; q += 64) {   // lane l copies the 16-byte pieces l, l + 64, .. of the 16 x 24 of h
+      const int n = q / 24, c4 = (q - n * 24) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(A.h_dst + (int64_t)min(row0 + n, n_dst - 1) * A.ldh + c4);
+      *reinterpret_cast<f32x4*>(&xin[n * DC_S + c4]) = v;
+    }
     // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
     const int fn = lane >> 2, fq = (lane & 3) * 4;
     const float* xrow = A.x_dst + (int64_t)min(row0 + fn, n_dst - 1) * A.ldx;
@@ -191,7 +194,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       const float xv = xrow[min(fq + j, F - 1)];   // unconditional (clamped) load
       v[j] = fq + j < F ? xv : (fq + j == F ? 1.0f : 0.0f);
     }
-    *reinterpret_cast<f32x4*>(&xf[fn * 16 + fq]) = v;
+    *reinterpret_cast<f32x4*>(&xin[fn * DC_S + C + fq]) = v;
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       int* __restrict__ rp = csr + e * (17 + DC_CW);
@@ -222,21 +225,21 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
       [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
       {
-        f32x4 u[7];
+        DcAcc u[7];
 #pragma unroll
-        for (int nb = 0; nb < 7; ++nb) u[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        u32x4 xb[2][3];
+        for (int nb = 0; nb < 7; ++nb) u[nb].zero();
+        u32x4 xb[2][DC_PL];
         x_planes(0, xb[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const u32x4* pw = begin_slice(ks < 3 ? 21 : 18);   // behind P1: the sweep, then P3's first slice
+          const u32x4* pw = begin_slice(ks < 3 ? DC_NP1 : DC_NP3);   // behind P1: the sweep, then P3's first slice
           dc_kstep<7>(pw, xb[ks & 1], u);
           if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);   // the next k-step's split runs beside these MFMAs
           end_slice();
         }
         // D layout -> stage[node][column]
 #pragma unroll
-        for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb];
+        for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb].value();
       }
       __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
@@ -388,29 +391,26 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       }
       __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_c = GGNN_STAMP_NOW();
-      load_xh();
-      if (e == n_in - 1) {   // the old cell state, in flight during the gate's last matrix phases (only the forget
-        // gate uses it; fetched by every gate so that it is live from here to the update and nowhere else)
-        const float* crow = A.c_in + (int64_t)node_m * C + 4 * kq;
-#pragma unroll
-        for (int ct = 0; ct < 6; ++ct) cin[ct] = *reinterpret_cast<const f32x4*>(crow + 16 * ct);
-      }
-
       // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
       {
-        u32x4 xb[2][3];
-        auto a_planes = [&](int ks, u32x4 (&out)[3]) __attribute__((always_inline)) {
+        u32x4 xb[2][DC_PL];
+        auto a_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
           const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
           dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out);
         };
         a_planes(0, xb[0]);
+        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const u32x4* pw = begin_slice(ks < 2 ? 18 : (e + 1 < n_in ? 21 : 18));   // next: P3, the next edge type's P1, or P4
-          dc_kstep<6>(pw, xb[ks & 1], pre);
+          const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (e + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
+          dc_kstep<6>(pw, xb[ks & 1], part);
           if (ks + 1 < 3) a_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();
         }
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
         const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
         const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
 #pragma unroll
@@ -424,17 +424,28 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     }
     [[maybe_unused]] const unsigned long long t_e = GGNN_STAMP_NOW();
 
+    // the old cell state (only the forget gate uses it): in flight during P4, live nowhere else
+    if (gi == 2) {
+      const float* crow = A.c_in + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) cin[ct] = *reinterpret_cast<const f32x4*>(crow + 16 * ct);
+    }
     // ================= P4: the summed skip term + gate bias of gate g =================
     {
-      u32x4 xb[2][3];
+      u32x4 xb[2][DC_PL];
       x_planes(0, xb[0]);
+      DcAcc part[6];
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const u32x4* pw = begin_slice(ks < 3 ? 18 : (gi < 3 ? 21 : 0));   // next: P4, the next gate's P1, or nothing
-        dc_kstep<6>(pw, xb[ks & 1], pre);
+        const u32x4* pw = begin_slice(ks < 3 ? DC_NP3 : (gi < 3 ? DC_NP1 : 0));   // next: P4, the next gate's P1, or nothing
+        dc_kstep<6>(pw, xb[ks & 1], part);
         if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
         end_slice();
       }
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
     }
 
     [[maybe_unused]] const unsigned long long t_f = GGNN_STAMP_NOW();
@@ -442,26 +453,27 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     // ================= LSTM update, folded in gate by gate (heteropgclstm.py:140-146) =================
     // (the gate loop is a real loop -- unrolled four times the register allocator gave up --: the four updates sit
     // behind wave-uniform branches)
+    f32x4 (&pv)[6] = pre;
     if (gi == 0) {
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pre[ct][r]);
+        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pv[ct][r]);
     } else if (gi == 1) {
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) run[ct][r] *= tanhf_(pre[ct][r]);
+        for (int r = 0; r < 4; ++r) run[ct][r] *= tanhf_(pv[ct][r]);
     } else if (gi == 2) {
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pre[ct][r]) * cin[ct][r] + run[ct][r];
+        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pv[ct][r]) * cin[ct][r] + run[ct][r];
     } else {
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre[ct][r] = sigmoidf_(pre[ct][r]) * tanhf_(run[ct][r]);
+        for (int r = 0; r < 4; ++r) pv[ct][r] = sigmoidf_(pv[ct][r]) * tanhf_(run[ct][r]);
     }
     if (gi == 2) {
       float* crow = A.c_out + (int64_t)node_m * C + 4 * kq;
@@ -471,7 +483,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     if (gi == 3) {
       float* hrow = A.h_out + (int64_t)node_m * C + 4 * kq;
 #pragma unroll
-      for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(hrow + 16 * ct) = pre[ct];
+      for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(hrow + 16 * ct) = pv[ct];
     }
     st_lstm += GGNN_STAMP_NOW() - t_f;
   }
@@ -501,8 +513,6 @@ __global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCel
     for (int i = 0; i < B.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
   dec_cell_body(B.a[k], ts, s_raw);
 }
-
-int dec_cell_ws_launch(const ggnn_dec_cell_args* args, int n_problems, hipStream_t stream);   // dec_cell_ws.hip
 
 }  // namespace ggnn
 
@@ -538,11 +548,6 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
     if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
     B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
   }
-  static const bool specialised = [] {   // development switch: the specialised-wave kernel (dec_cell_ws.hip)
-    const char* e = getenv("GGNN_DC_KERNEL");
-    return e && e[0] == 'w';
-  }();
-  if (specialised) return dec_cell_ws_launch(args, n_problems, (hipStream_t)stream);
   static const int stagger = [] {
     const char* e = getenv("GGNN_DC_STAGGER");   // development knob: sleeps of 127 x 64 clocks (~4 us each)
     return e ? atoi(e) : 0;

@@ -133,7 +133,7 @@ class PackedCell:
     wpv: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [96 G n_src_ets, Kp] value rows of wp
     bpv: Dict[str, torch.Tensor] = field(default_factory=dict)
     vof: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> value column in that projection
-    # ... and everything on the destination side streams past the tiles as bf16 planes
+    # ... and everything on the destination side streams past the tiles as fp16 planes
     dcs: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_stream (int16)
     dct: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_tail [4, n_in, 6, 64]
 
@@ -220,39 +220,36 @@ def value_fragments_bias(weights, biases, F_src: int) -> torch.Tensor:
     return fr.view(-1)
 
 
-DC_SLICE_I16 = 21504 // 2   # GGNN_DC_SLICE_BYTES / 2: int16 elements per slice of the decoder cell's weight stream
+DC_PLANES = 2               # fp16 planes of the decoder cell's weight stream: hi, (w - hi) 2^11 (csrc/common.h)
+DC_LO_SCALE = 2048.0
+DC_SLICE_I16 = 7 * DC_PLANES * 1024 // 2   # GGNN_DC_SLICE_BYTES / 2: int16 elements per slice of the decoder cell's weight stream
 DC_GATE_ORDER = (0, 2, 1, 3)  # the fused decoder cell walks the gates i, c~, f, o (weights are indexed i, f, c, o)
 
 
 @torch.no_grad()
-def split3_bf16(w: torch.Tensor):
-    """fp32 -> three bf16 tensors with hi + mid + lo == w exactly (hi = rne(w), mid = rne(w - hi), lo =
-    rne(w - hi - mid): 3 x 8 significand bits), the split the kernels apply to the node side on the fly
-    (csrc/common.h: split_bf16x3).  Raises when the weights are not finite or the split is not exact."""
+def split2_f16(w: torch.Tensor):
+    """fp32 -> the two fp16 pieces of the decoder cell's arithmetic (csrc/common.h: split_f16x2): hi = rne16(w),
+    lo' = rne16((w - hi) 2^11); w = hi + lo' / 2^11 up to 2^-22 |w|.  Raises when a weight is not finite or beyond
+    fp16's range (the kernel would saturate it)."""
     w = w.float()
-    if not bool(torch.isfinite(w).all()):
-        raise ValueError("weights contain non-finite values: cannot be packed")
-    hi = w.to(torch.bfloat16)
-    r1 = w - hi.float()
-    mid = r1.to(torch.bfloat16)
-    lo = (r1 - mid.float()).to(torch.bfloat16)
-    resid = (hi.float() + mid.float() + lo.float() - w).abs()
-    if resid.numel() and float(resid.max()) > 2.0 ** -120:   # (only underflow below bf16's exponent range is accepted)
-        raise ValueError(f"bf16 split of the weights is not exact (residual {float(resid.max()):.3e})")
-    return hi, mid, lo
+    if not bool(torch.isfinite(w).all()) or (w.numel() and float(w.abs().max()) >= 65504.0):
+        raise ValueError("weights are not finite or beyond fp16's range: cannot be packed for the decoder cell")
+    hi = w.half()
+    return hi, ((w - hi.float()) * DC_LO_SCALE).half()
 
 
 @torch.no_grad()
 def _plane_slices(W: torch.Tensor) -> torch.Tensor:
     """[16 NB, 32 NKS] fp32 -> [NKS, DC_SLICE_I16] int16: per k-step the slice image of include/ggnn.h
-    (ggnn_dec_cell_args.wstream): [column tile nb][plane hi, mid, lo][lane l = 16 kq + m][8 bf16] with lane (m, kq)
+    (ggnn_dec_cell_args.wstream): [column tile nb][plane hi, lo'][lane l = 16 kq + m][8 fp16] with lane (m, kq)
     of (nb, plane) holding W[16 nb + m][32 ks + 8 kq .. + 7]; slices with fewer than 7 column tiles end in zeros."""
     rows, K = W.shape
     NB, NKS = rows // 16, K // 32
     assert rows == 16 * NB and K == 32 * NKS and NB <= 7
-    planes = torch.stack([t.view(torch.int16) for t in split3_bf16(W)])        # [3, rows, K]
-    fr = planes.view(3, NB, 16, NKS, 4, 8)                                      # p nb m ks kq j
-    fr = fr.permute(3, 1, 0, 4, 2, 5).reshape(NKS, NB * 3 * 64 * 8)             # ks | nb p kq m j
+    planes = torch.stack([t.view(torch.int16) for t in split2_f16(W)])          # [2, rows, K]
+    P = planes.size(0)
+    fr = planes.view(P, NB, 16, NKS, 4, 8)                                      # p nb m ks kq j
+    fr = fr.permute(3, 1, 0, 4, 2, 5).reshape(NKS, NB * P * 64 * 8)             # ks | nb p kq m j
     out = torch.zeros(NKS, DC_SLICE_I16, dtype=torch.int16, device=W.device)
     out[:, :fr.size(1)] = fr
     return out

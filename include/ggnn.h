@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 17
+#define GGNN_ABI_VERSION 18
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -372,16 +372,19 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  *   x_dst [n_dst, ldx], h_dst [n_dst, ldh] (the encoder's h), c_in [n_dst, 96]; h_out, c_out [n_dst, 96]
  *   wstream : the weight slices in the order the kernel consumes them (packing.decoder_cell_stream):
  *             for g in (i, c~, f, o): for e: 4 slices P1(e, g) | 3 slices P3(e, g); then 4 slices P4(g).
- *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, mid, lo][64 lanes][8 bf16] --
+ *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, lo'][64 lanes][8 fp16] -- the two
+ *             fp16 pieces of a weight w are hi = rne16(w) and lo' = rne16((w - hi) * 2048) (finite, |w| < 65504) --
  *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles
  *             (u_h 0..95 | u4 96..111), P3 / P4 six (the tail of their slice is unused).  The reduction index
- *             of P1 / P4 is [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128, of P3 the 96 aggregate channels
+ *             of P1 / P4 is [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128, of P3 the 96 aggregate channels.
+ *             The kernel splits its own operands the same way (magnitudes beyond 65504 saturate) and keeps three of
+ *             the four products: against an fp64 product 5e-8 of sum |x||w| (a plain fp32 fma chain: 2e-7).
  *   w2_tail : [4][n_in][6][64] fp32: (b_l2, w_edge) of (g, e) as v_mfma_f32_16x16x4_f32 A fragments
  *             ([ct][l] = k < 2 ? tail[16 ct + (l & 15)][k = l >> 4] : 0)
  * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
 #define GGNN_PRECISION_BF16 1
-#define GGNN_DC_SLICE_BYTES 21504 /* 7 column tiles x 3 planes x 1 KB */
+#define GGNN_DC_SLICE_BYTES 14336 /* 7 column tiles x 2 planes x 1 KB */
 typedef struct ggnn_dec_cell_sweep {
   const int32_t* rowptr;     /* [n_dst + 1] */
   const int32_t* col;        /* [E] source node of every edge, CSR order */

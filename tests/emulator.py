@@ -204,11 +204,13 @@ class TorchEmulatorBackend:
     @staticmethod
     def _decode_slices(stream, first, n_ks, n_tiles):
         """`n_ks` consecutive slices of ggnn_dec_cell_args.wstream (include/ggnn.h) -> the fp32 block
-        [16 n_tiles, 32 n_ks] they hold: hi + mid + lo of [column tile][plane][lane 16 kq + m][8 bf16]."""
-        S = 21504 // 2
-        sl = stream.view(-1, S)[first:first + n_ks, :n_tiles * 3 * 64 * 8]
-        assert not bool(stream.view(-1, S)[first:first + n_ks, n_tiles * 3 * 64 * 8:].any())
-        fr = sl.reshape(n_ks, n_tiles, 3, 4, 16, 8).view(torch.bfloat16).float().sum(2)   # ks nb kq m j
+        [16 n_tiles, 32 n_ks] they hold: hi + lo' / 2^11 of [column tile][plane][lane 16 kq + m][8 fp16]."""
+        from graingraphnn_amd.packing import DC_LO_SCALE, DC_PLANES, DC_SLICE_I16
+        S, P = DC_SLICE_I16, DC_PLANES
+        sl = stream.view(-1, S)[first:first + n_ks, :n_tiles * P * 64 * 8]
+        assert not bool(stream.view(-1, S)[first:first + n_ks, n_tiles * P * 64 * 8:].any())
+        fr = sl.reshape(n_ks, n_tiles, P, 4, 16, 8).view(torch.float16).float()            # ks nb p kq m j
+        fr = fr[:, :, 0] + fr[:, :, 1] / DC_LO_SCALE
         return fr.permute(1, 3, 0, 2, 4).reshape(16 * n_tiles, 32 * n_ks)                  # (nb m) x (ks kq j)
 
     def decoder_cell_batch(self, problems):
@@ -218,7 +220,8 @@ class TorchEmulatorBackend:
         self.calls = getattr(self, "calls", []) + ["decoder_cell_batch"]   # (which plan ran: test_decoder_plan_per_model)
         for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
             n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
-            assert wstream.numel() * 2 == 4 * (7 * n_in + 4) * 21504 and tuple(w2_tail.shape) == (4, n_in, 6, 64)
+            from graingraphnn_amd.packing import DC_SLICE_I16
+            assert wstream.numel() == 4 * (7 * n_in + 4) * DC_SLICE_I16 and tuple(w2_tail.shape) == (4, n_in, 6, 64)
             xin = torch.zeros(n, 128)
             xin[:, :C], xin[:, C:C + F], xin[:, C + F] = h_dst, x_dst, 1.0
             pre, s = {}, 0
