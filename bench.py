@@ -137,14 +137,17 @@ class EventTimedBackend:
 
     def decoder_cell_batch(self, problems):
         # (sweeps [(csr, einfo, h_src, v_src, v_off, ep)], x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
-        flops = nbytes = 0.0
+        flops = nbytes = canon = 0.0
+        n_sweeps = 0
         for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
             n, n_in = x_dst.size(0), len(sweeps)
             flops += 2.0 * n * 4 * (n_in * (128 * 112 + 98 * 96) + 128 * 96)
             nbytes += 4.0 * n * (x_dst.size(1) + 96 + 96 + 2 * 96) + 2.0 * wstream.numel()
             for csr, einfo, h_src, v_src, v_off, ep in sweeps:   # value rows + hidden rows of the sources, edge records
                 nbytes += 4.0 * (h_src.size(0) * (4 * 96 + 96) + csr.E * 20 + csr.E + n + 1)
-        self._timed("dec_cell", self.inner.decoder_cell_batch, problems, (flops, len(problems), nbytes))
+                canon += algorithmic_bytes(h_src.size(0), n, csr.E, 4)   # what the cell's sweeps are defined to move
+                n_sweeps += 1
+        self._timed("dec_cell", self.inner.decoder_cell_batch, problems, (flops, len(problems), nbytes, canon, n_sweeps))
 
     def summary(self, key):
         evs = self.events.get(key)
@@ -157,6 +160,8 @@ class EventTimedBackend:
         return {"avg_us": float(np.mean(bracket)) - overhead, "bracket_us": float(np.mean(bracket)),
                 "overhead_us": overhead, "work": float(np.mean([ev[5][0] for ev in evs])),
                 "work2": float(np.mean([ev[5][2] if len(ev[5]) > 2 else 0.0 for ev in evs])),
+                "work3": float(np.mean([ev[5][3] if len(ev[5]) > 3 else 0.0 for ev in evs])),
+                "work4": float(np.mean([ev[5][4] if len(ev[5]) > 4 else 0.0 for ev in evs])),
                 "per_launch": round(float(np.mean([ev[5][1] for ev in evs])), 2), "n": len(evs)}
 
 
@@ -164,30 +169,78 @@ def measure_roofline(ro, n_steps):
     """Average durations of the heavy kernels inside real rollout steps (eager launches, one set
     per model on ONE stream, so that no other kernel shares the chip with the launch being timed;
     HIP events on the launch stream, minus the bracket overhead calibrated on a null kernel).
-    Returns (roofline of the decoder sweep, roofline of the encoder sweep, GEMM records)."""
+    Returns (roofline of the default plan's dominant decoder kernel, roofline of the encoder cell, GEMM records,
+    roofline of the three-kernel plan's sweep when the default plan is the fused cell)."""
     timed = EventTimedBackend(ro.be)
     timed.null = torch.zeros(64, device="cuda")
-    ro.be, side, joint = timed, ro._side, ro.joint_launches
-    ro._side, ro.joint_launches = None, False
-    try:
-        for _ in range(n_steps):
-            ro._enqueue_step()
-        torch.cuda.synchronize()
-    finally:
-        ro.be, ro._side, ro.joint_launches = timed.inner, side, joint
-    roof = enc = None
+    inner = timed.inner
+    fused_plan = bool(getattr(inner, "fused_decoder", False))
+
+    def timed_steps():
+        nonlocal n_steps
+        ro.be, side, joint = timed, ro._side, ro.joint_launches
+        ro._side, ro.joint_launches = None, False
+        try:
+            for _ in range(n_steps):
+                ro._enqueue_step()
+            torch.cuda.synchronize()
+        finally:
+            ro.be, ro._side, ro.joint_launches = inner, side, joint
+
+    timed_steps()
+    plans = {"fused" if fused_plan else "split": timed.events}
+    if fused_plan:
+        # the default plan runs the decoder cell as ONE kernel: the three kernels of the other plan (GGNN_DEC=split),
+        # among them the sweep that earlier rounds' `roofline` described, are timed in a second pass of the same steps
+        keep_plan, inner.fused_decoder = inner.fused_decoder, False
+        try:
+            n_keep, n_steps = n_steps, 2
+            timed_steps()          # untimed in effect: the other plan's buffers and code objects are touched for the first time
+            n_steps = n_keep
+            timed.events = {}
+            timed_steps()
+        finally:
+            inner.fused_decoder = keep_plan
+        plans["split"] = timed.events
+
+    def summary(plan, key):
+        timed.events = plans.get(plan, {})
+        return timed.summary(key)
+
+    default_plan = "fused" if fused_plan else "split"
+    roof = enc = sweep = None
     gemm = []
-    fused_plan = bool(getattr(timed.inner, "fused_decoder", False))
-    d = timed.summary("dec_sweep")
+    d = summary("split", "dec_sweep")
     if d:
         achieved = d["work"] / d["avg_us"] / 1e3
-        roof = {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("ggnn::aggregate_kernel<4, true>"), "avg_launch_us": round(d["avg_us"], 2),
-                "event_bracket_us": round(d["bracket_us"], 2), "bracket_overhead_us": round(d["overhead_us"], 2),
-                "algorithmic_bytes_per_launch": int(d["work"]), "launches_timed": d["n"],
-                "sweeps_per_launch": d["per_launch"]}
-    e = timed.summary("enc_sweep")
+        sweep = {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "plan": "GGNN_DEC=split",
+                 "achieved": round(achieved, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                 "traffic": pmc_traffic("ggnn::aggregate_kernel<4, true>"), "avg_launch_us": round(d["avg_us"], 2),
+                 "event_bracket_us": round(d["bracket_us"], 2), "bracket_overhead_us": round(d["overhead_us"], 2),
+                 "algorithmic_bytes_per_launch": int(d["work"]), "launches_timed": d["n"],
+                 "sweeps_per_launch": d["per_launch"]}
+    f = summary("fused", "dec_cell")
+    if f:
+        # the fused decoder cell: graded like the sweeps it contains (SURVEY 8(d) bytes of its 2-3 sweeps per launch /
+        # its duration) although it also runs the cell's three GEMMs and the LSTM update in that time; what it
+        # actually has to move (value / hidden rows of the sources once, edge records, x / h / c in, h / c out, the
+        # weight stream once) is `bytes_as_built_per_launch`, what it did move is `traffic`
+        achieved = f["work3"] / f["avg_us"] / 1e3
+        roof = {"bound": "hbm", "kernel": "ggnn::dec_cell_kernel", "plan": "default (GGNN_DEC=fused)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ggnn::dec_cell_kernel", "fused"),
+                "avg_launch_us": round(f["avg_us"], 2), "event_bracket_us": round(f["bracket_us"], 2),
+                "bracket_overhead_us": round(f["overhead_us"], 2), "algorithmic_bytes_per_launch": int(f["work3"]),
+                "bytes_as_built_per_launch": int(f["work2"]), "launches_timed": f["n"],
+                "sweeps_per_launch": f["work4"], "problems_per_launch": f["per_launch"],
+                "fp32_equivalent_tflops": round(f["work"] / f["avg_us"] / 1e6, 1),
+                "note": "one launch = the whole decoder cell of a model (destination-side projections, its 2-3 sweeps, "
+                        "lin_l2, skip, LSTM); algorithmic bytes = SURVEY 8(d) for those sweeps, the same unit of work as "
+                        "`roofline_split_sweep` (the sweep kernel of the three-kernel plan, timed in the same run)"}
+    else:
+        roof = sweep
+    e = summary(default_plan, "enc_sweep")
     if e:
         achieved = e["work"] / e["avg_us"] / 1e3
         enc = {"bound": "hbm", "kernel": "ggnn::aggregate_enc_kernel<3>", "achieved": round(achieved, 1),
@@ -197,7 +250,7 @@ def measure_roofline(ro, n_steps):
                "bytes": "what the kernel as built must move, per sweep: 80 E (edge records) + 4 (n_dst + 1) + 32 "
                         "n_units (unit table) + 64 G n_dst (score tails) + 392 G n_dst (rows written); the "
                         "SURVEY 8(d) formula does not apply (no K / V / Q rows exist)"}
-    c = timed.summary("enc_cell")
+    c = summary(default_plan, "enc_cell")
     if c:  # the fused encoder cell: matrix-pipe cycles as launched against the chip's 1024 SIMDs at 2.4 GHz
         busy = c["work"] / (1024 * 2400.0 * c["avg_us"])
         enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (+ enc_lstm_kernel, in the same bracket)",
@@ -209,25 +262,25 @@ def measure_roofline(ro, n_steps):
                "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, bf16 MFMAs of the "
                        "gate GEMM at 16) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
                        "kernel is bound by instruction issue (profiles/README.md)"}
-    for key, kname, name in (
-            ("dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection, both node types of a model)"),
-            ("dec_gates", "ggnn::gates_x6_kernel<4, 0>", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, live node types of a model)"),
-            ("dec_cell", "ggnn::dec_cell_kernel", "ggnn::dec_cell_kernel (fused decoder cell, GGNN_DEC=fused)")):
-        g = timed.summary(key)
+    for plan, key, kname, name in (
+            ("fused", "dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection of the default plan: value rows only)"),
+            ("split", "dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection, GGNN_DEC=split: both node types of a model)"),
+            ("split", "dec_gates", "ggnn::gates_x6_kernel<4, 0>", "ggnn::gates_x6_kernel<4, 0> (decoder gate GEMM + LSTM, GGNN_DEC=split)")):
+        g = summary(plan, key)
         if g:
             flops, nbytes = g["work"], g["work2"]
             gbs = nbytes / g["avg_us"] / 1e3
             tf = flops / g["avg_us"] / 1e6
-            gemm.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(kname, "fused" if key == "dec_cell" or (key == "dec_project" and fused_plan) else "split"),
+            gemm.append({"bound": "hbm", "kernel": name, "plan": plan, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, plan),
                          "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": round(g["avg_us"], 2),
                          "problems_per_launch": g["per_launch"],
                          "fp32_equivalent_tflops": round(tf, 1), "frac_of_bf16_pipe": round(6 * tf / 2500.0, 4),
                          "note": "graded against HBM: every operand row read once + every output row written once, fp32, as "
                                  "launched (the matrix work runs as 6 bf16 MFMA products per fp32 product: "
                                  "frac_of_bf16_pipe = 6 x fp32-equivalent rate / 2.5 PFLOP/s dense bf16 peak)"})
-    return roof, enc, gemm
+    timed.events = {}
+    return roof, enc, gemm, (sweep if fused_plan else None)
 
 
 def kernel_source_hash():
@@ -547,7 +600,7 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for g in gathered for v in g.values())
 
     if rank == 0:
-        roof, roof_enc, roof_gemm = (None, None, []) if args.profile else measure_roofline(ro, 10)
+        roof, roof_enc, roof_gemm, roof_sweep = (None, None, [], None) if args.profile else measure_roofline(ro, 10)
         # forward-only rate beside the full step (eager launches, R then C on one stream)
         forward_only = 0.0
         with torch.no_grad():
@@ -589,6 +642,7 @@ def main():
                                       "stopped": ev_state["stopped"]}}
                           if args.events else {})},
             "roofline": roof,
+            "roofline_split_sweep": roof_sweep,
             "roofline_encoder_cell": roof_enc,
             "roofline_gemm": roof_gemm,
         }

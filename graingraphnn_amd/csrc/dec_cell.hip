@@ -402,6 +402,14 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) part[ct].zero();
+        // the exact fp32 tail's weight fragments: requested here, used behind the three slices (requested there,
+        // their round trip stood in front of the tail's MFMAs in every phase)
+        float wtail[6];
+        {
+          const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
+#pragma unroll
+          for (int ct = 0; ct < 6; ++ct) wtail[ct] = wt[ct * 64];
+        }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
           const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (e + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
@@ -412,9 +420,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
         const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
-        const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
 #pragma unroll
-        for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ct * 64], xt, pre[ct], 0, 0, 0);
+        for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[ct], xt, pre[ct], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_d = GGNN_STAMP_NOW();
