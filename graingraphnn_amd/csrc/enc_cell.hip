@@ -5,8 +5,8 @@
 // lin_edge term, lin_skip and the cell update of heteropgclstm.py:111-146), but organised around the
 // gate GEMM's weights instead of around an aggregate buffer:
 //   * a PeriodConv of one (edge type, gate) is independent of every other up to the sum HeteroConv
-//     takes over the edge types and the LSTM update over the gates, and its lin_l2 weights as three
-//     bf16 planes (96 x 96 x 6 B = 54 KB) fit the LDS: a workgroup belongs to one (problem, edge type,
+//     takes over the edge types and the LSTM update over the gates, and its lin_l2 weights as two
+//     fp16 planes (96 x 96 x 4 B = 36 KB; hi and scaled residual, common.h) fit the LDS: a workgroup belongs to one (problem, edge type,
 //     gate), splits those weights into LDS ONCE and never streams a weight again -- no k-step slices,
 //     no workgroup barrier after the prologue, the four waves (one per SIMD) run independently;
 //   * a wave owns whole 16-node tiles: it sweeps the tile's in-edges (4 units per block as in
@@ -15,8 +15,8 @@
 //     features are two k-steps, scores on one more MFMA chain, online-max softmax per row), leaves the
 //     tile's 16 x 98 aggregate block in a wave-private LDS stage, reads it back as MFMA B fragments
 //     (row stride = 8 mod 16 floats and k-groups interleaved by 4: conflict-free ds_read_b128), splits
-//     every fragment once into bf16 planes and multiplies it with the resident weights (6 exact bf16
-//     products per k-step: common.h); the two rank-1 columns go through one exact fp32 MFMA; the
+//     every fragment once into two fp16 pieces and multiplies it with the resident weights (three
+//     products per k-step, main + cross accumulators: common.h); the two rank-1 columns go through one exact fp32 MFMA; the
 //     16 x 96 block of partial pre-activations is stored;
 //   * the operands of a block (16 edge records, 4 score tails) arrive by LDS-DMA in a per-wave ring
 //     of EC_U slots, requested EC_U blocks ahead of their use ACROSS tile boundaries -- a wave alone on
@@ -53,11 +53,12 @@ constexpr int EC_G = 3;                      // i, c, o
 constexpr int EC_S = 104;                    // stage row stride in floats: 8 mod 16
 constexpr int EC_U = EC_CFG_U;               // ring slots per wave = blocks in flight
 constexpr int EC_SLOT = 1024 + 256 + 32;     // 16 records x 64 B | 4 tails x 64 B | control words
-constexpr int EC_PLANES = 3 * 18 * 1024;     // 55 296 B
+constexpr int EC_PL = 2;                     // fp16 pieces per operand (common.h: split_f16x2 / mfma_x3h)
+constexpr int EC_PLANES = EC_PL * 18 * 1024; // 36 864 B
 constexpr int EC_HMAX = EC_CFG_HMAX, EC_HR = EC_HMAX + 1 + (EC_HMAX & 1);  // tiles fetched ahead of the front cursor, header ring slots
 constexpr int EC_HSLOT = 80;                 // 17 rowptr entries
 constexpr int EC_WAVE_LDS = 16 * EC_S * 4 + EC_U * EC_SLOT + EC_HR * EC_HSLOT;  // 6 656 + 5 248 + 640
-constexpr int EC_LDS_BYTES = EC_PLANES + EC_WAVES * EC_WAVE_LDS;  // 155 648
+constexpr int EC_LDS_BYTES = EC_PLANES + EC_WAVES * EC_WAVE_LDS;  // 137 216
 static_assert(EC_LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(2 * (EC_U - 2) < 64 && 2 * EC_HMAX > 2 * (EC_U - 2) + 4, "vmcnt is a 6-bit counter; headers land in time");
 static_assert(EC_HMAX >= EC_U && EC_HMAX < EC_HR, "a header must be requested a ring length ahead of its use");
@@ -118,7 +119,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   const int c = lane & 15, q = lane >> 4;
   const int qa = c >> 2, ra = c & 3;       // sweep: A row / score column c belongs to unit qa, edge ra
   const int src_sm = (20 * q) * 4;         // lane 16 q + 4 q: the softmax lane of group q (ds_bpermute)
-  u32x4* __restrict__ wpl = reinterpret_cast<u32x4*>(smem);  // [3][6][3][64]: lin_l2 of (edge type, gate) as bf16 planes
+  u32x4* __restrict__ wpl = reinterpret_cast<u32x4*>(smem);  // [3][6][2][64]: lin_l2 of (edge type, gate) as two fp16 planes
   unsigned char* __restrict__ wbase = smem + EC_PLANES + wave * EC_WAVE_LDS;
   float* __restrict__ stage = reinterpret_cast<float*>(wbase);   // wave-private [16][EC_S]
   unsigned char* __restrict__ ring = wbase + 16 * EC_S * 4;                       // wave-private [EC_U][EC_SLOT]
@@ -151,24 +152,23 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   int h_idx = 0;                 // next tile whose header has not been requested yet
   for (; h_idx < EC_HMAX; ++h_idx) hdr_issue(h_idx);  // in flight while the weights are staged
   GGNN_STAMP(0);
-  // ---- prologue: lin_l2 of this (edge type, gate) -> three bf16 planes in LDS (once per workgroup) ----
+  // ---- prologue: lin_l2 of this (edge type, gate) -> two fp16 planes in LDS (once per workgroup) ----
   {
     const f32x4* __restrict__ wf =
         reinterpret_cast<const f32x4*>(A.w2_frag) + (size_t)((g * nks_all + 3 * d) * 6) * 2 * 64;
     for (int f = wave; f < 18; f += EC_WAVES) {
       const f32x4 h0 = wf[(f * 2) * 64 + lane], h1 = wf[(f * 2 + 1) * 64 + lane];
-      u32x4 pl[3];
+      u32x4 pl[EC_PL];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 h = e < 2 ? h0 : h1;
-        uint32_t q0, q1, q2;
-        split_bf16x3(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1, q2);
+        uint32_t q0, q1;
+        split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
         pl[0][e] = q0;
         pl[1][e] = q1;
-        pl[2][e] = q2;
       }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wpl[(f * 3 + p) * 64 + lane] = pl[p];
+      for (int p = 0; p < EC_PL; ++p) wpl[(f * EC_PL + p) * 64 + lane] = pl[p];
     }
     // the stage starts as zeros (rows of a tile that do not exist are never written)
     for (int i = lane; i < 16 * EC_S / 4; i += 64) reinterpret_cast<f32x4*>(stage)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -244,43 +244,45 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     }
   };
 
-  // ---- the GEMM of a finished tile: stage -> B fragments -> 6 x bf16 products against the resident planes ----
+  // ---- the GEMM of a finished tile: stage -> B fragments -> two fp16 pieces, three products against the resident
+  // planes (main + cross accumulators: common.h; until round 3's last version three bf16 pieces and six products) ----
   auto gemm = [&](int row0) {
-    f32x4 acc[6];
+    f32x4 acc[6], accx[6];
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 6; ++ct) acc[ct] = accx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ srow = stage + c * EC_S + 4 * q;  // node c of the tile, k-group q
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(srow + 32 * ks);
       const f32x4 r1 = *reinterpret_cast<const f32x4*>(srow + 32 * ks + 16);
-      u32x4 xb[3];
+      u32x4 xb[EC_PL];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 h = e < 2 ? r0 : r1;
-        uint32_t q0, q1, q2;
-        split_bf16x3(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1, q2);
+        uint32_t q0, q1;
+        split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
         xb[0][e] = q0;
         xb[1][e] = q1;
-        xb[2][e] = q2;
       }
-      const u32x4* __restrict__ pw = wpl + (ks * 18) * 64 + lane;
-      // the three weight fragments of column tile ct + 1 are read while the six MFMAs of ct run
-      u32x4 wf[2][3];
+      const u32x4* __restrict__ pw = wpl + (ks * 6 * EC_PL) * 64 + lane;
+      // the weight fragments of column tile ct + 1 are read while the three MFMAs of ct run
+      u32x4 wf[2][EC_PL];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[0][p] = pw[p * 64];
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS reads of ct = 0, then [reads ct + 1 | MFMAs ct] ...
+      for (int p = 0; p < EC_PL; ++p) wf[0][p] = pw[p * 64];
+      __builtin_amdgcn_sched_group_barrier(0x100, EC_PL, 0);  // DS reads of ct = 0, then [reads ct + 1 | MFMAs ct] ...
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct) {
         if (ct + 1 < 6) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) wf[(ct + 1) & 1][p] = pw[((ct + 1) * 3 + p) * 64];
+          for (int p = 0; p < EC_PL; ++p) wf[(ct + 1) & 1][p] = pw[((ct + 1) * EC_PL + p) * 64];
         }
-        acc[ct] = mfma_x6(wf[ct & 1], xb, acc[ct]);
-        if (ct + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                  // MFMA
+        mfma_x3h(wf[ct & 1], xb, acc[ct], accx[ct]);
+        if (ct + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, EC_PL, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                      // MFMA
       }
     }
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[ct] += accx[ct] * (1.0f / F16X2_SCALE);
     const float xt = q < 2 ? stage[c * EC_S + 96 + q] : 0.f;
     const bool ok = row0 + c < n_dst;
     float* __restrict__ o = pre + (int64_t)(row0 + (ok ? c : 0)) * (EC_G * C) + 4 * q;
