@@ -271,7 +271,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         struct Unit {     // the gathered operands of <= 3 of its in-edges
           f3 hh[GGNN_UNIT_EDGES][2], vv[GGNN_UNIT_EDGES][2];
           float x4[GGNN_UNIT_EDGES];
-          f3 ed[GGNN_UNIT_EDGES];   // reloc_e (the edge length a_e is slot 13 of x4: lane 13 sums alpha a_e)
+          // (reloc_e = slots 0..2 of the edge record, i.e. x4 of the row's lanes 0..2: broadcast at fold time, no load
+          // and no register of its own; the edge length a_e is slot 13: lane 13 sums alpha a_e)
         };
         auto open_row = [&](Row& r, int n) __attribute__((always_inline)) {
           const float* __restrict__ su = stage + n * DC_S;
@@ -302,7 +303,6 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
             U.hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
             U.hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
             U.x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
-            U.ed[t] = ld3(einfo + (uint32_t)pt * GGNN_EINFO_ROW + 16);
             U.vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
             U.vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
           }
@@ -339,7 +339,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
             for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
               if (t < nact) {
-                const float rx = U.ed[t].x, ry = U.ed[t].y, rz = U.ed[t].z;
+                // lane k of every 16-lane row -> the whole row (ds_swizzle bit mode: and 0x10, or k)
+                const int xi = __builtin_bit_cast(int, U.x4[t]);
+                const float rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (0 << 5) | 0x10));
+                const float ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (1 << 5) | 0x10));
+                const float rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (2 << 5) | 0x10));
                 const float pw_ = __expf(s[t] - mnew);
                 r.den = r.den + pw_;
                 r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);   // lane 13: sum alpha a_e (other lanes: unused)
