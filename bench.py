@@ -630,8 +630,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({ro.RUN_UNROLL} steps per graph)") + (", R+C in the same launches (13 per step)" if ro.joint_launches else
                                   ", R|C on two streams" if ro.concurrent else ", R then C on one stream"),
-                       "gemm": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-step, fp32 accumulate "
-                                "(error vs fp64 2.7e-7 of sum|x||w|; native fp32 MFMA 7.0e-7)"
+                       "decoder_plan": ("one kernel per decoder cell (ggnn_decoder_cell_batch)"
+                                        if getattr(default_backend(), "fused_decoder", False) is True else
+                                        f"fused_decoder={getattr(default_backend(), 'fused_decoder', False)!r}: projection + sweeps + gate "
+                                        "GEMM where not fused (GGNN_DEC)"),
+                       "gemm": ("fp32 operands as exact pieces on the matrix cores, fp32 accumulate: fused decoder cell and encoder "
+                                "gate GEMM 2 fp16 pieces / 3 products per k-step (error vs fp64 5e-8 of sum|x||w|, numpy emulation); "
+                                "decoder projection (and the three-kernel plan's gate GEMM) 3 bf16 pieces / 6 products (2.7e-7 "
+                                "measured on the GPU; native fp32 MFMA chain 7.0e-7)"
                                 if default_backend().lib.ggnn_gemm_mode() == 1 else "native fp32 MFMA (GGNN_GEMM=fp32)"),
                        "results_finite": finite, "untimed_steps": untimed_steps,
                        "forward_only": {"steps_per_s_per_gpu": round(forward_only * (units_per_step // world), 2),
