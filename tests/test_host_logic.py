@@ -142,6 +142,35 @@ def _run_model_emulated(model, x, ei, ea, fused_decoder=True):
     return be, graph, h
 
 
+def test_fp16_two_piece_split_is_fp32_equivalent():
+    """The arithmetic of the fused decoder cell and of the encoder cell's gate GEMM (csrc/common.h: split_f16x2,
+    mfma_x3h; packing.split2_f16): x = hi + lo' / 2^11 with two fp16 pieces, three of the four products, the cross
+    terms in their own accumulator.  Emulated here with exact products (float64) rounded to fp32 per accumulator:
+    its error against the fp64 product, normalised by sum |x||w|, stays below a plain fp32 fma chain's."""
+    rs = np.random.RandomState(3)
+    for K, wscale, xscale in ((104, 0.3, 1.0), (196, 0.3, 3.0), (104, 1e-2, 1e-3)):
+        X = torch.from_numpy((np.tanh(rs.randn(128, K)) * xscale).astype(np.float32))
+        W = torch.from_numpy((rs.randn(96, K) * wscale).astype(np.float32))
+        xh, xl = packing.split2_f16(X)
+        wh, wl = packing.split2_f16(W)
+        assert float((xh.float() + xl.float() / packing.DC_LO_SCALE - X).abs().max()) <= 2.0 ** -21 * float(X.abs().max())
+        d = lambda a, b: a.double() @ b.double().t()
+        main = d(xh, wh).float()
+        cross = (d(xh, wl) + d(xl, wh)).float()
+        got = (main + cross / packing.DC_LO_SCALE).double()
+        ref, norm = d(X, W), d(X.abs(), W.abs())
+        err = float(((got - ref).abs() / norm).max())
+        chain = torch.zeros(128, 96)
+        for k in range(K):                       # what fp32 hardware arithmetic gives: one rounding per term
+            chain = chain + X[:, k:k + 1] * W[:, k][None, :]
+        err_chain = float(((chain.double() - ref).abs() / norm).max())
+        assert err <= 1.2e-7 and err < err_chain, (K, err, err_chain)
+    with pytest.raises(ValueError):
+        packing.split2_f16(torch.tensor([1.0e5]))         # beyond fp16's range: refused at packing time
+    with pytest.raises(ValueError):
+        packing.split2_f16(torch.tensor([float("nan")]))
+
+
 @torch.no_grad()
 def test_decoder_plan_per_model():
     """GGNN_DEC=fused-classifier / fused-regressor (backend.fused_decoder = "classifier" / "regressor"): the fused
