@@ -114,9 +114,9 @@ class EventTimedBackend:
                 nu = torch.clamp((deg + 2) // 3, min=1)
                 nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)  # units per (tile, lane group)
                 blocks = int(nu.max(1).values.sum())
-                # per gate: fp32 MFMAs of 32 cycles per block (4 score + 6 per value k-step), per tile 108 bf16
-                # MFMAs of 16 cycles + 6 fp32 ones for the rank-1 columns
-                cycles += 3 * (blocks * (4 + 6 * (3 if f_src > 8 else 2)) * 32 + n_t * (108 * 16 + 6 * 32))
+                # per gate: fp32 MFMAs of 32 cycles per block (4 score + 6 per value k-step), per tile 54 fp16
+                # MFMAs of 16 cycles (3 k-steps x 6 column tiles x 3 products) + 6 fp32 ones for the rank-1 columns
+                cycles += 3 * (blocks * (4 + 6 * (3 if f_src > 8 else 2)) * 32 + n_t * (54 * 16 + 6 * 32))
         self._timed("enc_cell", self.inner.encoder_cell_batch, problems, (cycles, len(problems)))
 
     def project_batch(self, problems):
@@ -259,8 +259,8 @@ def measure_roofline(ro, n_steps):
                "traffic": (lambda a, b: None if a is None or b is None else a + b)(
                    pmc_traffic("ggnn::enc_cell_kernel"), pmc_traffic("ggnn::enc_lstm_kernel")),
                "mfma_cycles_per_launch": int(c["work"]),
-               "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, bf16 MFMAs of the "
-                       "gate GEMM at 16) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
+               "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, fp16 MFMAs of the "
+                       "gate GEMM at 16: half as many as with the bf16 split of round 2) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
                        "kernel is bound by instruction issue (profiles/README.md)"}
     for plan, key, kname, name in (
             ("fused", "dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection of the default plan: value rows only)"),
