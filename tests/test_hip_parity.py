@@ -241,6 +241,22 @@ def test_native_fp32_gemm_mode_in_a_subprocess():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_three_kernel_decoder_plan_in_a_subprocess():
+    """GGNN_DEC=split (projection + sweeps + gate GEMM per decoder cell instead of the fused decoder cell) is fixed per
+    process: the cell, forward and rollout goldens and the launch-tape test once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GGNN_DEC") == "split":
+        assert backend().fused_decoder is False
+        return
+    env = dict(os.environ, GGNN_DEC="split")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "cell_golden or forward_golden or rollout_golden or tape or three_kernel"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------
 # op level: PeriodConv and HeteroPGCLSTM against the reference's golden vectors (cfg1)
 # ---------------------------------------------------------------------------------------
