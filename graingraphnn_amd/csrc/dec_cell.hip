@@ -41,7 +41,15 @@
 
 namespace ggnn {
 
-constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
+#ifndef DC_WAVES_
+#define DC_WAVES_ 8
+#endif
+#ifdef DC_ABL_ONEBUF
+#define DC_NBUF 1
+#else
+#define DC_NBUF 2
+#endif
+constexpr int DC_WAVES = DC_WAVES_;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
 constexpr int DC_PL = 2;                            // weight / operand planes: fp16 hi and scaled residual (common.h)
 constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
@@ -53,7 +61,7 @@ constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [16
 constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
 constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
 constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
-constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 155 648 B
+constexpr int DC_LDS = DC_NBUF * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 155 648 B
 static_assert(DC_LDS <= 160 * 1024, "LDS");
 
 struct DecCellBatch {
@@ -79,7 +87,11 @@ __device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (
   for (int e = 0; e < 4; ++e) {
     const f32x4 h = e < 2 ? r0 : r1;
     uint32_t q0, q1;
+#ifdef DC_ABL_NOSPLIT
+    q0 = __builtin_bit_cast(uint32_t, h[2 * (e & 1)]); q1 = __builtin_bit_cast(uint32_t, h[2 * (e & 1) + 1]);
+#else
     split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
+#endif
     xb[0][e] = q0;
     xb[1][e] = q1;
   }
@@ -96,6 +108,10 @@ struct DcAcc {
 };
 template <int NB>
 __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
+#ifdef DC_ABL_NOGEMM
+  acc[0].m[0] += __builtin_bit_cast(float, xb[0][0] ^ xb[1][3]);
+  return;
+#endif
   u32x4 wf[2][DC_PL];
 #pragma unroll
   for (int p = 0; p < DC_PL; ++p) wf[0][p] = pw[p * 64];
@@ -120,7 +136,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   const int ch = 3 * lr;                     // sweep view: lane lr of DPP row kq owns channels ch..ch+2, 48+ch..
   constexpr int CH2 = C / 2;
 
-  unsigned char* __restrict__ wbase = smem + 2 * DC_SLICE + wave * DC_WAVE_LDS;
+  unsigned char* __restrict__ wbase = smem + DC_NBUF * DC_SLICE + wave * DC_WAVE_LDS;
   float* __restrict__ stage = reinterpret_cast<float*>(wbase);
   float* __restrict__ xf = reinterpret_cast<float*>(wbase + DC_STAGE);
   int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_STAGE + DC_XF);   // [e][17 + DC_CW]
@@ -147,20 +163,24 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   GGNN_STAMP(0);
   auto dma_slice = [&](int s, int np) {
     const unsigned char* src = wsrc + (size_t)s * DC_SLICE;
-    const uint32_t dst = slice_lds + (s & 1) * DC_SLICE;
+    const uint32_t dst = slice_lds + (s & (DC_NBUF - 1)) * DC_SLICE;
+#ifndef DC_ABL_NODMA
     for (int p = wave; p < np; p += DC_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
+#endif
   };
   // `np_next`: pieces of the slice after the current one (21: a P1 slice, 18: P3 / P4, 0: none)
   auto begin_slice = [&](int np_next) -> const u32x4* {   // the slice about to be used landed at the previous end_slice
     st_t0 = GGNN_STAMP_NOW();
     if (np_next > 0) dma_slice(s_cur + 1, np_next);
     st_dma += GGNN_STAMP_NOW() - st_t0;
-    return reinterpret_cast<const u32x4*>(smem + (s_cur & 1) * DC_SLICE) + lane;
+    return reinterpret_cast<const u32x4*>(smem + (s_cur & (DC_NBUF - 1)) * DC_SLICE) + lane;
   };
   auto end_slice = [&]() {
     [[maybe_unused]] const unsigned long long w0 = GGNN_STAMP_NOW();
+#ifndef DC_ABL_NOBAR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice are in LDS
     __syncthreads();                                   // ... everybody's are, and nobody reads the old one any more
+#endif
     st_wait += GGNN_STAMP_NOW() - w0;
     ++s_cur;
   };
@@ -390,8 +410,10 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
             close_row(rb, nb);
           }
         };
+#ifndef DC_ABL_NOSWEEP
         if (in_window) sweep(std::true_type{});
         else sweep(std::false_type{});
+#endif
       }
       __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_c = GGNN_STAMP_NOW();
