@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_build_csr",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
-    "ggnn_decoder_cell_batch", "ggnn_hidden_planes",
+    "ggnn_decoder_cell_batch",
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
@@ -111,9 +111,9 @@ class EncCellArgs(Structure):
 class DecCellSweep(Structure):
     """Mirror of `ggnn_dec_cell_sweep`."""
     _fields_ = [
-        ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p), ("hp_src", c_void_p), ("v_src", c_void_p),
+        ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p), ("h_src", c_void_p), ("v_src", c_void_p),
         ("edge_params", c_void_p),
-        ("E", c_int64), ("n_src", c_int64), ("ldv", c_int64),
+        ("E", c_int64), ("n_src", c_int64), ("ldh_src", c_int64), ("ldv", c_int64),
         ("v_off", c_int32), ("reserved", c_int32),
     ]
 
@@ -122,9 +122,9 @@ class DecCellArgs(Structure):
     """Mirror of `ggnn_dec_cell_args`."""
     _fields_ = [
         ("sweeps", DecCellSweep * 2),
-        ("x_dst", c_void_p), ("hp_dst", c_void_p), ("c_in", c_void_p), ("h_out", c_void_p), ("c_out", c_void_p),
+        ("x_dst", c_void_p), ("h_dst", c_void_p), ("c_in", c_void_p), ("h_out", c_void_p), ("c_out", c_void_p),
         ("wstream", c_void_p), ("w2_tail", c_void_p), ("flags", c_void_p),
-        ("n_dst", c_int64), ("ldx", c_int64),
+        ("n_dst", c_int64), ("ldx", c_int64), ("ldh", c_int64),
         ("n_in", c_int32), ("f_dst", c_int32),
     ]
 
@@ -210,8 +210,6 @@ def _declare(lib):
     lib.ggnn_encoder_cell_batch.argtypes = [POINTER(EncCellArgs), c_int, c_void_p]
     lib.ggnn_decoder_cell_batch.restype = c_int
     lib.ggnn_decoder_cell_batch.argtypes = [POINTER(DecCellArgs), c_int, c_void_p]
-    lib.ggnn_hidden_planes.restype = c_int
-    lib.ggnn_hidden_planes.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
     lib.ggnn_aggregate_bwd_partials.restype = c_int64
     lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
     lib.ggnn_period_gat_aggregate_backward.restype = c_int

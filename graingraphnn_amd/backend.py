@@ -252,36 +252,22 @@ class HipBackend:
         self._launch(self.lib.ggnn_encoder_cell_batch, "ggnn_encoder_cell_batch", arr, len(problems),
                      _lib.current_stream())
 
-    def hidden_planes(self, h, out=None):
-        """ggnn_hidden_planes: fp32 rows [n, >= 96] -> the two fp16 planes [n, 2, 96] of the decoder cell's arithmetic
-        (hi = rne16(h), lo' = rne16((h - hi) 2048)); magnitudes beyond fp16's range are clamped and raise the
-        backend's range flag (`range_flag`)."""
-        _require_cuda(h)
-        if h.dtype != torch.float32 or h.dim() != 2 or h.size(1) < 96 or h.stride(1) != 1:
-            raise _lib.GGNNError("ggnn_hidden_planes: h must be float32 [n, >= 96] with unit column stride")
-        if out is None:
-            out = torch.empty(h.size(0), 2, 96, dtype=torch.float16, device=h.device)
-        elif out.dtype != torch.float16 or tuple(out.shape) != (h.size(0), 2, 96) or not out.is_contiguous():
-            raise _lib.GGNNError("ggnn_hidden_planes: planes must be contiguous float16 [n, 2, 96]")
-        if h.size(0):
-            self._launch(self.lib.ggnn_hidden_planes, "ggnn_hidden_planes", h.data_ptr(), h.size(0), h.stride(0),
-                         out.data_ptr(), self.range_flag(h.device).data_ptr(), _lib.current_stream())
-        return out
-
     def range_flag(self, device):
         """The device word the two-piece fp16 kernels OR GGNN_FLAG_F16_RANGE into when they clamp an activation
         (include/ggnn.h, OPERAND RANGE); one per device, never cleared by the kernels."""
         key = torch.device(device)
+        if key.index is None:
+            key = torch.device(key.type, torch.cuda.current_device())
         flag = self._range_flags.get(key)
         if flag is None:
             flag = self._range_flags[key] = torch.zeros(1, dtype=torch.int32, device=key)
         return flag
 
-    def range_exceeded(self, device, clear=True) -> bool:
-        """Reads (one host sync) and optionally clears the range flag of `device`."""
-        flag = self._range_flags.get(torch.device(device))
-        if flag is None:
-            return False
+    def range_exceeded(self, device="cuda", clear=True) -> bool:
+        """True when a fused cell has clamped an activation to fp16's range since the flag was last cleared: its
+        results are then NOT the reference's (re-run with GGNN_DEC=split / GGNN_ENC=split, whose bf16 x 3 split
+        covers fp32's range).  One host sync."""
+        flag = self.range_flag(device)
         hit = bool(int(flag.item()) & _lib.GGNN_FLAG_F16_RANGE)
         if hit and clear:
             flag.zero_()
@@ -289,56 +275,52 @@ class HipBackend:
 
     def decoder_cell_batch(self, problems):
         """ggnn_decoder_cell_batch (include/ggnn.h): the decoder cell of up to four (model, destination node type)
-        problems in one launch.  Each item: (sweeps, x_dst, hp_dst, c_in, wstream, w2_tail, h_out, c_out) with
-        sweeps = [(csr, einfo, hp_src, v_src, v_off, edge_params)] for the 1 or 2 incoming edge types; hp_*: hidden
-        states as fp16 planes [n, 2, 96] (hidden_planes); wstream / w2_tail: packing.decoder_cell_stream."""
+        problems in one launch.  Each item: (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out) with
+        sweeps = [(csr, einfo, h_src, v_src, v_off, edge_params)] for the 1 or 2 incoming edge types; wstream /
+        w2_tail: packing.decoder_cell_stream."""
         arr = (DecCellArgs * len(problems))()
-        for a, (sweeps, x_dst, hp_dst, c_in, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
-            _require_cuda(x_dst, hp_dst, c_in, wstream, w2_tail, h_out, c_out)
+        for a, (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
+            _require_cuda(x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
             n, n_in = x_dst.size(0), len(sweeps)
-            for t, name in ((x_dst, "x_dst"), (c_in, "c_in"), (h_out, "h_out"), (c_out, "c_out"), (w2_tail, "w2_tail")):
+            for t, name in ((x_dst, "x_dst"), (h_dst, "h_dst"), (c_in, "c_in"), (h_out, "h_out"), (c_out, "c_out"),
+                            (w2_tail, "w2_tail")):
                 if t.dtype != torch.float32 or t.dim() < 2 or t.stride(-1) != 1:
                     raise _lib.GGNNError(f"ggnn_decoder_cell_batch: {name} must be float32 with unit column stride")
-            if n_in not in (1, 2) or tuple(c_in.shape) != (n, 96) \
+            if n_in not in (1, 2) or tuple(h_dst.shape) != (n, 96) or tuple(c_in.shape) != (n, 96) \
                     or not c_in.is_contiguous() or tuple(h_out.shape) != (n, 96) or not h_out.is_contiguous() \
                     or tuple(c_out.shape) != (n, 96) or not c_out.is_contiguous():
-                raise _lib.GGNNError("ggnn_decoder_cell_batch: c_in / h_out / c_out must be contiguous [n_dst, 96], "
-                                     "1 or 2 incoming edge types")
-            if hp_dst.dtype != torch.float16 or tuple(hp_dst.shape) != (n, 2, 96) or not hp_dst.is_contiguous():
-                raise _lib.GGNNError("ggnn_decoder_cell_batch: hp_dst must be contiguous float16 planes [n_dst, 2, 96]")
+                raise _lib.GGNNError("ggnn_decoder_cell_batch: h_dst / c_in / h_out / c_out must be [n_dst, 96] "
+                                     "(c_in, h_out, c_out contiguous), 1 or 2 incoming edge types")
             if wstream.dtype != torch.int16 or not wstream.is_contiguous() \
                     or wstream.numel() * 2 != 4 * (7 * n_in + 4) * _lib.GGNN_DC_SLICE_BYTES:
                 raise _lib.GGNNError("ggnn_decoder_cell_batch: wstream is not packing.decoder_cell_stream of this "
                                      "number of incoming edge types")
             if tuple(w2_tail.shape) != (4, n_in, 6, 64) or not w2_tail.is_contiguous():
                 raise _lib.GGNNError("ggnn_decoder_cell_batch: w2_tail must be contiguous [4, n_in, 6, 64]")
-            for sw, (csr, einfo, hp_src, v_src, v_off, ep) in zip(a.sweeps, sweeps):
-                _require_cuda(csr.rowptr, csr.col, einfo, hp_src, v_src, ep)
+            for sw, (csr, einfo, h_src, v_src, v_off, ep) in zip(a.sweeps, sweeps):
+                _require_cuda(csr.rowptr, csr.col, einfo, h_src, v_src, ep)
                 if csr.rowptr.numel() != n + 1:
                     raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
                 if einfo.dtype != torch.float32 or not einfo.is_contiguous() or einfo.dim() != 2 \
                         or einfo.size(1) != _lib.GGNN_EINFO_ROW or einfo.size(0) < csr.E + _lib.GGNN_UNIT_EDGES:
                     raise _lib.GGNNError("einfo must be contiguous float32 [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
-                if hp_src.dtype != torch.float16 or hp_src.dim() != 3 or tuple(hp_src.shape[1:]) != (2, 96) \
-                        or not hp_src.is_contiguous():
-                    raise _lib.GGNNError("ggnn_decoder_cell_batch: hp_src must be contiguous float16 planes [n_src, 2, 96]")
-                if v_src.dtype != torch.float32 or v_src.dim() != 2 or v_src.stride(1) != 1 \
-                        or v_src.size(0) != hp_src.size(0):
-                    raise _lib.GGNNError("ggnn_decoder_cell_batch: v_src must be float32 [n_src, *] with unit column "
-                                         "stride")
-                if v_off < 0 or v_off + 4 * 96 > v_src.size(1) or v_off % 4 or v_src.stride(0) % 4:
-                    raise _lib.GGNNError("ggnn_decoder_cell_batch: the four gates' value rows must lie inside a v_src "
-                                         "row; v_off and the row stride must be multiples of 4")
+                for t, name in ((h_src, "h_src"), (v_src, "v_src")):
+                    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.size(0) != h_src.size(0):
+                        raise _lib.GGNNError(f"ggnn_decoder_cell_batch: {name} must be float32 [n_src, *] with unit "
+                                             "column stride")
+                if h_src.size(1) < 96 or v_off < 0 or v_off + 4 * 96 > v_src.size(1):
+                    raise _lib.GGNNError("ggnn_decoder_cell_batch: h_src needs 96 columns, the four gates' value rows "
+                                         "must lie inside a v_src row")
                 if ep.dtype != torch.float32 or not ep.is_contiguous() or tuple(ep.shape) != (4, 3, 96):
                     raise _lib.GGNNError("edge_params must be contiguous float32 [4, 3, 96]")
                 sw.rowptr, sw.col, sw.einfo = csr.rowptr.data_ptr(), csr.col.data_ptr(), einfo.data_ptr()
-                sw.hp_src, sw.v_src, sw.edge_params = hp_src.data_ptr(), v_src.data_ptr(), ep.data_ptr()
-                sw.E, sw.n_src, sw.ldv, sw.v_off = csr.E, hp_src.size(0), v_src.stride(0), v_off
-            a.x_dst, a.hp_dst, a.c_in = x_dst.data_ptr(), hp_dst.data_ptr(), c_in.data_ptr()
+                sw.h_src, sw.v_src, sw.edge_params = h_src.data_ptr(), v_src.data_ptr(), ep.data_ptr()
+                sw.E, sw.n_src, sw.ldh_src, sw.ldv, sw.v_off = csr.E, h_src.size(0), h_src.stride(0), v_src.stride(0), v_off
+            a.x_dst, a.h_dst, a.c_in = x_dst.data_ptr(), h_dst.data_ptr(), c_in.data_ptr()
             a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
             a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()
             a.flags = self.range_flag(x_dst.device).data_ptr()
-            a.n_dst, a.ldx, a.n_in, a.f_dst = n, x_dst.stride(0), n_in, x_dst.size(1)
+            a.n_dst, a.ldx, a.ldh, a.n_in, a.f_dst = n, x_dst.stride(0), h_dst.stride(0), n_in, x_dst.size(1)
         self._launch(self.lib.ggnn_decoder_cell_batch, "ggnn_decoder_cell_batch", arr, len(problems),
                      _lib.current_stream())
 

@@ -2,31 +2,35 @@
 // (ggnn_decoder_cell_batch, include/ggnn.h): the destination-side projections (u_h | u4 per edge type and
 // gate, the summed skip term), the periodic-boundary GAT sweep (PeriodConv.message, periodGATconv.py:204-236,
 // + propagate's gather / scatter-add), lin_l2 + the value-side lin_edge term, HeteroConv's sum over the edge
-// types and the LSTM update (heteropgclstm.py:111-146).
+// types and the LSTM update (heteropgclstm.py:111-146).  Replaces two thirds of the decoder projection's
+// columns, ggnn_period_gat_aggregate_batch and ggnn_lstm_epilogue_batch: per model forward at the 10k-grain
+// graph 142 MB of u_h / u4 / S rows and 92 MB of aggregates that were written and read back once each.
 //
-// Round 4: the tile never leaves the matrix layouts.  Timing ablations of the round-3 kernel (sweep / GEMMs /
-// weight stream / barriers compiled out one at a time, profiles/r4_dec_cell_ablations.txt) showed a wave's life to
-// be ONE dependency chain that nothing on the chip contends with -- two workgroups per compute unit in antiphase
-// ran no faster than in phase -- and the sweep's share of it (52 of 145 us) to be its sixteen exposed gather round
-// trips: the 16-lanes-per-row sweep needed u and the aggregates in another layout than the GEMMs (an LDS stage
-// each way) and 78 landing registers per half tile, so its gathers could only be issued behind P1 and in two
-// halves.  Now a lane (node lr = l & 15, k-group kq = l >> 4) owns 24 channels of ONE node throughout:
-//   * P1 leaves u[node][column 16 nb + 4 kq + i] in lane (node, kq): with the rows of the score weights permuted
-//     on the host that IS an A fragment of u (k = hidden channel 32 ks + 8 kq + j), so the 48 scores of a tile and
-//     edge type are 36 more MFMAs -- D[node][edge], edge tile t = the t-th in-edge of every node, the wanted
-//     entries on the diagonal -- against B fragments of the SOURCE rows: hidden states arrive as the two fp16
-//     planes of the arithmetic (ggnn_hidden_planes; 2 x 192 B per node = the bytes of the fp32 row), gathered
-//     as 16-byte pieces that need no splitting and, not depending on u, issued in front of P1;
-//   * the value rows are gathered ONCE per (edge type, gate) for all 16 nodes (16-byte pieces of the lane's
-//     channels 16 nb + 4 kq ..+3, straight into the C operand of an exact fp32 MFMA that adds W_value[:, 0:3] . reloc),
-//     requested right behind P1's last k-step: their round trip runs beside the score MFMAs and the softmax;
-//   * relu, alpha-weighted sum and normalisation happen in that D layout, which -- with the columns of lin_l2
-//     permuted on the host -- is the B fragment of P3.  No LDS stage, no CSR window: the tile's LDS is its own
-//     input planes (8 KB per wave).
-// What stays: one 16-node tile per wave, eight waves per workgroup in step on a double-buffered LDS-DMA stream of
-// pre-split fp16 weight slices (72 for a tile with two incoming edge types), gates walked i, c~, f, o with the LSTM
-// update folded in as they arrive, two fp16 pieces / three products per fp32 operand (common.h), explicit fmas with
-// contraction off so that a row computed by two overlapping tiles of a ragged end gets the same bits.
+// Why it is organised around a 16-node tile per WAVE with the weights streaming past:
+//   * the three GEMMs of a destination node (score weights K = 104, lin_l2 K = 96, skip K = 104) chain through
+//     the MFMA layouts without a transpose when the NODES are the B operand: D[out][node] leaves lane
+//     (node l & 15, out rows 4 (l >> 4) ..+3), and a B fragment wants lane (node l & 15, k = 8 (l >> 4) ..+7);
+//   * the sweep wants the other layout (a node's 96 channels across the 16 lanes of a DPP row: whole 384-byte
+//     rows per gather, dot products closed with four DPP adds), so u and the aggregates cross a wave-private
+//     LDS stage ([16][116] floats) once each way -- 7 KB per wave instead of 57 + 50 KB of u / agg per tile if
+//     all gates were kept at once: the gates are walked ONE AFTER THE OTHER (i, c~, f, o) and the LSTM update is
+//     folded in as they arrive (sig(i) -> sig(i) tanh(c~) -> c' -> h'), so a wave holds one gate's 16 x 96
+//     pre-activations (24 VGPRs) plus the running LSTM term (24), never four;
+//   * the weights of a destination type are 0.84 MB as two fp16 planes (joints: 2 x 4 score blocks [112 x 128],
+//     8 lin_l2 blocks, 4 skip blocks) -- five times the LDS.  They arrive as k-step slices (one 32-deep
+//     k-step of one block: 14 KB) through a double-buffered LDS region shared by the workgroup's eight waves,
+//     fetched one slice ahead by LDS-DMA, one workgroup barrier per slice.  Host-side pre-split planes: no
+//     splitting arithmetic on the weight side in the kernel (the gate kernel's split cost 44 VALU per fragment).
+//   * arithmetic: every fp32 operand as TWO fp16 pieces (hi = rne16(x), lo' = rne16((x - hi) 2^11)) and THREE MFMA
+//     products per k-step (hi hi into the main accumulator; hi lo' + lo' hi into a cross accumulator that is folded
+//     in with 2^-11 behind the k-loop): 22 significand bits per operand, against an fp64 product 5e-8 of sum |x||w|
+//     (a plain fp32 fma chain: 2e-7; the six-product bf16 split of the other GEMM kernels: 2e-8) -- common.h.  Until
+//     round 3's last version this kernel used the bf16 split too: 21 KB slices, 42 MFMAs per P1 slice, 144 us per
+//     launch at the 10k-grain graph against 122 us now.
+//   * the tile's input rows [h | x | 1 | 0] stay in LDS for the whole tile (B operand of P1 and P4 of every
+//     gate): as registers they had to be reloaded behind every sweep, in front of P3's first slice.
+// A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
+// and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -37,29 +41,25 @@
 
 namespace ggnn {
 
-#ifndef DC_WAVES_
-#define DC_WAVES_ 8
-#endif
-constexpr int DC_WAVES = DC_WAVES_;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
+constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
 constexpr int DC_PL = 2;                            // weight / operand planes: fp16 hi and scaled residual (common.h)
 constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
 static_assert(DC_SLICE == 7 * DC_PL * 1024, "slice = 7 column tiles x planes x 1 KB");
 constexpr int DC_NP1 = 7 * DC_PL, DC_NP3 = 6 * DC_PL;   // pieces of a P1 slice / of a P3 or P4 slice
-constexpr int DC_XP = 3 * DC_PL * 1024 + DC_PL * 512;             // a tile's input planes: [k-step][plane][lane] 16 B (B operand of P1 / P4)
-constexpr int DC_PARK = 6 * 1024;                  // the running LSTM term of the tile, parked while a (edge type, gate) pass needs the registers
-constexpr int DC_WAVE_LDS = DC_XP + DC_PARK;
-constexpr int DC_NBUF = 3;                          // slice buffers: the stream runs two slices ahead of the one in use
-constexpr int DC_LDS = DC_NBUF * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 143 360 B
+constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
+constexpr int DC_STAGE = 16 * DC_S * 4;             // 7 424 B
+constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [16 nodes][h 96 | x F | 1 | 0 ..]: B operand of P1 / P4
+constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
+constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
+constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
+constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 155 648 B
 static_assert(DC_LDS <= 160 * 1024, "LDS");
-constexpr int DC_HP_ROW = 2 * C * 2;                // bytes of a node's hidden planes: [hi | lo'][96] fp16
-constexpr int UE = GGNN_UNIT_EDGES;                 // edge tiles (t-th in-edge of every node) handled together
 
 struct DecCellBatch {
   ggnn_dec_cell_args a[DC_MAX_PROBLEMS];
   int wg_off[DC_MAX_PROBLEMS + 1];
   int n;
-  int stagger;   // start delay of workgroup b: ((b >> 3) & 7) * stagger * ~1 us (speed only; see the kernel)
 };
 
 // LDS-DMA: every lane copies 16 bytes from its own global address to lds_base + lane * 16 (wave-uniform base
@@ -73,42 +73,29 @@ __device__ __forceinline__ void dc_dma16(const void* gsrc, uint32_t lds_base) {
                : "memory");
 }
 
-// eight fp32 values (r0 | r1) -> the two fp16 planes of an MFMA operand fragment; `amax` follows the largest
-// magnitude that went through a split (range flag, ggnn.h)
+// eight fp32 values -> the two fp16 planes of a B fragment; `amax` follows the largest magnitude that went through a
+// split (range flag, ggnn.h)
 __device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[DC_PL], float& amax) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const f32x4 h = e < 2 ? r0 : r1;
-    const float a = h[2 * (e & 1)], b = h[2 * (e & 1) + 1];
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
     uint32_t q0, q1;
-    split_f16x2(a, b, q0, q1);
+    amax = fmaxf(amax, fmaxf(__builtin_fabsf(h[2 * (e & 1)]), __builtin_fabsf(h[2 * (e & 1) + 1])));
+    split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
     xb[0][e] = q0;
     xb[1][e] = q1;
   }
-}
-__device__ __forceinline__ void dc_split_half(const f32x4 r0, u32x4 (&xb)[DC_PL], float& amax) {   // r1 = 0
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float a = r0[2 * e], b = r0[2 * e + 1];
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
-    uint32_t q0, q1;
-    split_f16x2(a, b, q0, q1);
-    xb[0][e] = q0;
-    xb[1][e] = q1;
-  }
-  xb[0][2] = xb[0][3] = xb[1][2] = xb[1][3] = 0u;
 }
 
-// An accumulator of a 16 x 16 output tile: main + cross terms of the fp16 split.
+// One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
+// lane; piece (nb, plane) at (nb * 3 + plane) * 64).  The three weight fragments of tile nb + 1 are read while the
+// six MFMAs of tile nb run.
+// An accumulator of a 16 x 16 output tile: one register set for the bf16 split, main + cross for the fp16 one.
 struct DcAcc {
   f32x4 m, c;
   __device__ __forceinline__ void zero() { m = c = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ f32x4 value() const { return m + c * (1.0f / F16X2_SCALE); }
 };
-// One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
-// lane; piece (nb, plane) at (nb * 2 + plane) * 64).  The weight fragments of tile nb + 1 are read while the
-// three MFMAs of tile nb run.
 template <int NB>
 __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
   u32x4 wf[2][DC_PL];
@@ -123,130 +110,102 @@ __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32
     }
     mfma_x3h(wf[nb & 1], xb, acc[nb].m, acc[nb].c);
     if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                        // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * DC_PL - (DC_PL == 2 ? 1 : 0), 0);   // MFMA (6 or 3)
   }
 }
-
-__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ f32x4 ld16f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const int tileset,
                                               unsigned char* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, kq = lane >> 4;   // node lr of the tile; k-group of a B / A fragment = output rows 4 kq .. of a D tile
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, kq = lane >> 4;  // matrix view: node lr of the tile, k-group / output rows 4 kq ..
+  const int ch = 3 * lr;                     // sweep view: lane lr of DPP row kq owns channels ch..ch+2, 48+ch..
+  constexpr int CH2 = C / 2;
 
-  // this lane's 16-byte slot in every 1 KB piece of the wave's input planes
-  unsigned char* __restrict__ xpl = smem + DC_NBUF * DC_SLICE + wave * DC_WAVE_LDS + lane * 16;
+  unsigned char* __restrict__ wbase = smem + 2 * DC_SLICE + wave * DC_WAVE_LDS;
+  float* __restrict__ stage = reinterpret_cast<float*>(wbase);
+  float* __restrict__ xf = reinterpret_cast<float*>(wbase + DC_STAGE);
+  int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_STAGE + DC_XF);   // [e][17 + DC_CW]
 
   const int n_dst = (int)A.n_dst, n_in = A.n_in, F = A.f_dst;
   // a ragged last tile slides back over rows the previous tile also produces (identical duplicate results);
   // tiles past the end (a workgroup's surplus waves) repeat the last one: every wave runs the whole program,
   // so the workgroup barriers of the slice stream need no special case
   const int row0 = max(0, min((tileset * DC_WAVES + wave) * 16, n_dst - 16));
-  const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node (n_dst < 16: the last node repeats)
+  const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node in the matrix view (n_dst < 16: clamped)
 
   // ---- the weight stream: slice s -> buffer s & 1, fetched one slice ahead by all the workgroup's waves ----
-  // LDS-DMA, a wave's share of the next slice (its 14 or 12 one-KB pieces dealt round-robin) requested at the top
-  // of a k-step; one counted wait + one workgroup barrier per slice.
+  // LDS-DMA, a wave's share of the next slice (the slice's 14 or 12 one-KB pieces dealt round-robin) requested at the top
+  // of a k-step; one counted wait + one workgroup barrier per slice.  The ISSUE of a piece costs the wave ~150
+  // cycles (in-kernel stamps: 0.38 us per slice with four waves sharing a slice = 27 of a tile's 140 us), which is
+  // why the workgroup has eight waves: half the pieces per wave and slice.  (Tried: 16-byte loads to registers +
+  // ds_write_b128 at the end of the k-step -- the loads' latency then sits in front of the barrier: slower.)
   const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(A.wstream) + lane * 16;
   const uint32_t slice_lds =
       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
   int s_cur = 0;
   [[maybe_unused]] unsigned long long st_wait = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_p4 = 0, st_lstm = 0;
-  [[maybe_unused]] unsigned long long st_dma = 0, st_t0 = 0, st_k[4] = {0, 0, 0, 0}, st_split = 0, st_score = 0, st_fold = 0;
+  [[maybe_unused]] unsigned long long st_dma = 0, st_t0 = 0;
   GGNN_STAMP(0);
-  // slice s -> buffer s % 3, requested TWO slices ahead: at the top of the k-step on slice s every wave requests its
-  // share of slice s + 2 (into the buffer slice s - 1 left at the last barrier); at the end of the k-step it waits
-  // for its pieces of slice s + 1 -- requested a whole k-step earlier -- with a COUNTED wait that leaves this k-step's
-  // own requests in flight, then the workgroup barrier.
-  const int n_slices = 4 * (7 * n_in + 4);
-  auto pieces_of = [&](int s) {   // 14: a P1 slice (7 column tiles), 12: P3 / P4, 0: past the end
-    const int r = s % (7 * n_in + 4);
-    return s >= n_slices ? 0 : ((r < 7 * n_in && (r % 7) < 4) ? DC_NP1 : DC_NP3);
-  };
-  auto dma_slice = [&](int s) {
-    const int np = pieces_of(s);
+  auto dma_slice = [&](int s, int np) {
     const unsigned char* src = wsrc + (size_t)s * DC_SLICE;
-    const uint32_t dst = slice_lds + (s % DC_NBUF) * DC_SLICE;
+    const uint32_t dst = slice_lds + (s & 1) * DC_SLICE;
     for (int p = wave; p < np; p += DC_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
   };
-  auto begin_slice = [&]() -> const u32x4* {   // the slice about to be used landed at the previous end_slice
-    return reinterpret_cast<const u32x4*>(smem + (s_cur % DC_NBUF) * DC_SLICE) + lane;
-  };
-  // Issue order inside a k-step: the k-step's own register loads (gathers) FIRST, then request_next().  At its end,
-  // `younger` = the number of those register loads: with the <= 2 pieces just requested they may stay in flight.
-  auto request_next = [&]() {
+  // `np_next`: pieces of the slice after the current one (14: a P1 slice, 12: P3 / P4, 0: none)
+  auto begin_slice = [&](int np_next) -> const u32x4* {   // the slice about to be used landed at the previous end_slice
     st_t0 = GGNN_STAMP_NOW();
-    dma_slice(s_cur + 2);
+    if (np_next > 0) dma_slice(s_cur + 1, np_next);
     st_dma += GGNN_STAMP_NOW() - st_t0;
+    return reinterpret_cast<const u32x4*>(smem + (s_cur & 1) * DC_SLICE) + lane;
   };
-  auto end_slice = [&](auto younger) {
+  auto end_slice = [&]() {
     [[maybe_unused]] const unsigned long long w0 = GGNN_STAMP_NOW();
-    // everything older than (this k-step's register loads + one piece) has landed: in particular this wave's pieces
-    // of slice s + 1 (a wave that requested two pieces of slice s + 2 waits for the first of them too: harmless)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(younger)::value + 1) : "memory");
-    __syncthreads();                                   // ... everybody's have, and nobody reads slice s any more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice are in LDS
+    __syncthreads();                                   // ... everybody's are, and nobody reads the old one any more
     st_wait += GGNN_STAMP_NOW() - w0;
     ++s_cur;
   };
-  constexpr std::integral_constant<int, 0> none{};
-  dma_slice(0);
-  dma_slice(1);
-
+  dma_slice(0, DC_NP1);
   float amax = 0.f;   // largest magnitude this lane has split into fp16 pieces
 
-  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] as B-fragment planes -> LDS (B operand of P1 and P4 of
-  // every gate; a lane only ever reads the slots it wrote); this node's CSR row and first in-edges -> registers ----
-  {
-    const unsigned char* hp = reinterpret_cast<const unsigned char*>(A.hp_dst) + (int64_t)node_m * DC_HP_ROW + 16 * kq;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p)
-        *reinterpret_cast<u32x4*>(xpl + (ks * DC_PL + p) * 1024) = ld16(hp + p * (C * 2) + 64 * ks);
-    // k-step 3: the 16 slots [x_0 .. x_{F-1}, 1 (bias), 0 ..] in k-groups 0 and 1, zeros behind
-    const float* xrow = A.x_dst + (int64_t)node_m * A.ldx;
-    f32x4 r[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int sl = 8 * (kq & 1) + j;
-      const float xv = xrow[min(sl, F - 1)];   // unconditional (clamped) load
-      r[j >> 2][j & 3] = kq >= 2 ? 0.f : (sl < F ? xv : (sl == F ? 1.0f : 0.0f));
-    }
-    u32x4 xb[DC_PL];
-    dc_split(r[0], r[1], xb, amax);
-    if (kq < 2) {
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512) = xb[p];
-    }
-  }
+  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS (read as B fragments by P1 and P4 of every
+  // gate: registers are what the sweep is short of, and a reload from memory behind every sweep sat in front of
+  // P3's first slice -- in-kernel stamps: 1.57 us per P3 slice against 0.6-0.7 for P1 / P4), CSR windows -> LDS ----
+  float* __restrict__ xin = xf;
+  // B-fragment planes of k-step ks of [h | x | 1 | 0]: k-steps 0..2 are the h rows, k-step 3 the 16 feature slots
+  // (k-groups 0 and 1; zeros behind)
   auto x_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
-    if (ks < 3) {
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p) out[p] = *reinterpret_cast<const u32x4*>(xpl + (ks * DC_PL + p) * 1024);
-    } else {   // the feature slots: k-groups 0 and 1 (512 B per plane), zeros behind
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512 - (kq >= 2 ? 512 : 0));
-        out[p] = kq < 2 ? v : (u32x4){0u, 0u, 0u, 0u};
-      }
-    }
+    const float* fr = &xin[lr * DC_S + 32 * ks + 8 * (ks < 3 ? kq : (kq & 1))];
+    f32x4 r0 = *reinterpret_cast<const f32x4*>(fr);
+    f32x4 r1 = *reinterpret_cast<const f32x4*>(fr + 4);
+    if (ks == 3 && kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dc_split(r0, r1, out, amax);
   };
-  int p_first[2], p_end[2], j_first[2][UE];
+  {
+    for (int q = lane; q < 16 * 24; q += 64) {   // lane l copies the 16-byte pieces l, l + 64, .. of the 16 x 24 of h
+      const int n = q / 24, c4 = (q - n * 24) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(A.h_dst + (int64_t)min(row0 + n, n_dst - 1) * A.ldh + c4);
+      *reinterpret_cast<f32x4*>(&xin[n * DC_S + c4]) = v;
+    }
+    // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
+    const int fn = lane >> 2, fq = (lane & 3) * 4;
+    const float* xrow = A.x_dst + (int64_t)min(row0 + fn, n_dst - 1) * A.ldx;
+    f32x4 v;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    p_first[e] = p_end[e] = 0;
-#pragma unroll
-    for (int t = 0; t < UE; ++t) j_first[e][t] = 0;
-    if (e < n_in) {
+    for (int j = 0; j < 4; ++j) {
+      const float xv = xrow[min(fq + j, F - 1)];   // unconditional (clamped) load
+      v[j] = fq + j < F ? xv : (fq + j == F ? 1.0f : 0.0f);
+    }
+    *reinterpret_cast<f32x4*>(&xin[fn * DC_S + C + fq]) = v;
+    for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
-      p_first[e] = Sw.rowptr[node_m];
-      p_end[e] = Sw.rowptr[node_m + 1];
+      int* __restrict__ rp = csr + e * (17 + DC_CW);
+      if (lane < 17) rp[lane] = Sw.rowptr[min(row0 + lane, n_dst)];
+      __builtin_amdgcn_wave_barrier();
+      const int pbase = rp[0], e_last = (int)Sw.E - 1;
       if (Sw.E > 0) {
-#pragma unroll
-        for (int t = 0; t < UE; ++t) j_first[e][t] = Sw.col[min(p_first[e] + t, (int)Sw.E - 1)];
+        for (int k = lane; k < DC_CW; k += 64) rp[17 + k] = Sw.col[min(pbase + k, e_last)];
       }
     }
   }
@@ -254,63 +213,20 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   __syncthreads();   // slice 0 is in LDS
   GGNN_STAMP(1);
 
-  // the diagonal of a score tile D[node][edge]: node lr's entry sits in lane (lr, kq = lr >> 2), register lr & 3
-  const int diag_addr = 4 * (16 * (lr >> 2) + lr), diag_sub = lr & 3;
-
-  // the LSTM update as the gates arrive: sig(i) -> sig(i) tanh(c~) -> c' -> (h'); lives in this lane's LDS slots
-  // between the gates (24 registers the gather landing zones need)
-  f32x4* __restrict__ park = reinterpret_cast<f32x4*>(xpl + DC_XP);   // + ct * 64
+  f32x4 run[6];   // the LSTM update as the gates arrive: sig(i) -> sig(i) tanh(c~) -> c' -> (h')
+#pragma unroll
+  for (int ct = 0; ct < 6; ++ct) run[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int gi = 0; gi < 4; ++gi) {
     const int g = gi == 1 ? 2 : (gi == 2 ? 1 : gi);   // weights are indexed i, f, c, o; processed i, c~, f, o
     f32x4 pre[6], cin[6];
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) pre[ct] = zero4;
+    for (int ct = 0; ct < 6; ++ct) pre[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
-      [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
-      const unsigned char* __restrict__ hsrc = reinterpret_cast<const unsigned char*>(Sw.hp_src) + 16 * kq;
-      const float* __restrict__ einfo = Sw.einfo;
-      const float* __restrict__ vbase = Sw.v_src + Sw.v_off + g * C + 4 * kq;
-      const uint32_t ldv = (uint32_t)Sw.ldv;
-      const int e_last = max((int)Sw.E - 1, 0);
-      const bool has_edges = Sw.E > 0;
-      const int pe = e == 0 ? p_end[0] : p_end[1];
-      int p = e == 0 ? p_first[0] : p_first[1];
-
-      // The gathered operands of one unit = the t-th in-edges (t = 0..2 from p) of the tile's 16 nodes:
-      struct Land {               // ... what the scores need: B fragments of the source's hidden planes, the edge record
-        u32x4 hb[UE][3][DC_PL];
-        f32x4 x4[UE];             // record slots 4 kq ..+3 (k-step 3 of the score)
-        float rel[UE];            // record slot 16 + kq: reloc_x, reloc_y, reloc_z | edge length
-      };
-      struct VLand {              // ... and the value rows: channels 16 nb + 4 kq ..+3 (C operand of the reloc MFMA)
-        f32x4 v[UE][6];
-      };
-      auto load_scores = [&](int p_, const int (&j)[UE], Land& L, const int t) __attribute__((always_inline)) {   // 8 loads
-        const unsigned char* hrow = hsrc + (uint32_t)j[t] * (uint32_t)DC_HP_ROW;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-          for (int pl = 0; pl < DC_PL; ++pl) L.hb[t][ks][pl] = ld16(hrow + pl * (C * 2) + 64 * ks);
-        const float* er = einfo + (uint32_t)min(p_ + t, e_last) * GGNN_EINFO_ROW;
-        L.x4[t] = ld16f(er + 4 * kq);
-        L.rel[t] = er[16 + kq];
-      };
-      auto load_values = [&](const int (&j)[UE], VLand& V, const int t) __attribute__((always_inline)) {
-        const float* vr = vbase + (uint32_t)j[t] * ldv;
-#pragma unroll
-        for (int nb = 0; nb < 6; ++nb) V.v[t][nb] = ld16f(vr + 16 * nb);
-      };
-
-      int j0[UE];
-#pragma unroll
-      for (int t = 0; t < UE; ++t) j0[t] = e == 0 ? j_first[0][t] : j_first[1][t];
-      Land L;
       // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
-      u32x4 ua[4][DC_PL];   // ... as the A fragments of the score MFMAs
+      [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
       {
         DcAcc u[7];
 #pragma unroll
@@ -319,150 +235,202 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         x_planes(0, xb[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          [[maybe_unused]] const unsigned long long tk0 = GGNN_STAMP_NOW();
-          const u32x4* pw = begin_slice();
-          // the first unit's score operands do not depend on u: one edge tile's eight loads per k-step, requested
-          // BEHIND the k-step's slice pieces -- they stay in flight across its barrier (the address unit of the
-          // compute unit takes ~40 cycles per gather instruction: all at once, the eight waves' requests stood in
-          // front of the next slice's pieces for 3.6 us)
-          if (ks < UE) load_scores(p, j0, L, ks);
-          request_next();
-          if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
+          const u32x4* pw = begin_slice(ks < 3 ? DC_NP1 : DC_NP3);   // behind P1: the sweep, then P3's first slice
           dc_kstep<7>(pw, xb[ks & 1], u);
-          if (ks < UE) end_slice(std::integral_constant<int, 8>{});
-          else end_slice(none);
-          st_k[ks] += GGNN_STAMP_NOW() - tk0;
+          if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);   // the next k-step's split runs beside these MFMAs
+          end_slice();
         }
-        [[maybe_unused]] const unsigned long long ts0 = GGNN_STAMP_NOW();
+        // D layout -> stage[node][column]
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) dc_split(u[2 * ks].value(), u[2 * ks + 1].value(), ua[ks], amax);
-        dc_split_half(u[6].value(), ua[3], amax);
-        st_split += GGNN_STAMP_NOW() - ts0;
+        for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb].value();
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
 
-      // ================= P2: scores, softmax, values -- all in the matrix layouts =================
-      // the exact fp32 fragments of this (e, g): W_value[:, 0:3] as A operand (lane (channel 16 nb + lr, k = kq))
-      float w3[6];
+      // ================= P2: the sweep of (e, g) over the tile's rows, one node per 16-lane row =================
+      // Two rows per 16-lane group in flight (nodes 8 half + kq and 8 half + 4 + kq): the gathers of both are issued
+      // back to back before either is folded, so a (gate, edge type) pass exposes two memory round trips, not four.
       {
-        const float* __restrict__ ep = Sw.edge_params + g * GGNN_EDGE_PARAM_ROWS * C + min(kq, 2) * C + lr;
+        const float* __restrict__ ep = Sw.edge_params + g * GGNN_EDGE_PARAM_ROWS * C;
+        f3 wv[6];
 #pragma unroll
-        for (int nb = 0; nb < 6; ++nb) {
-          const float w = ep[16 * nb];
-          w3[nb] = kq < 3 ? w : 0.f;
+        for (int cc = 0; cc < 6; ++cc) {
+          const float* w = ep + ch + (cc < 3 ? cc : CH2 + cc - 3);
+          wv[cc] = {w[0], w[C], w[2 * C]};
         }
-      }
-      // the value rows: one round trip for the whole tile, requested edge tile by edge tile as the score MFMAs
-      // free the landing registers of the hidden planes
-      VLand V;
-      float mx = -INFINITY, den = 0.f, sae = 0.f;
-      f32x4 acc[6];
+        const float* __restrict__ vbase = Sw.v_src + Sw.v_off + g * C + ch;
+        const float* __restrict__ hbase = Sw.h_src + ch;
+        const float* __restrict__ einfo = Sw.einfo;
+        const uint32_t ldv = (uint32_t)Sw.ldv, ldh = (uint32_t)Sw.ldh_src;
+        const int* __restrict__ rp = csr + e * (17 + DC_CW);
+        const int* __restrict__ colw = rp + 17;
+        const int pbase = rp[0], e_last = max((int)Sw.E - 1, 0);
+        const bool has_edges = Sw.E > 0;
+        struct Row {      // one destination row being folded
+          f3 uh0, uh1;
+          float u4, mx, den, sae, acc[6];
+          int p, pe;
+        };
+        struct Unit {     // the gathered operands of <= 3 of its in-edges
+          f3 hh[GGNN_UNIT_EDGES][2], vv[GGNN_UNIT_EDGES][2];
+          float x4[GGNN_UNIT_EDGES];
+          // (reloc_e = slots 0..2 of the edge record, i.e. x4 of the row's lanes 0..2: broadcast at fold time, no load
+          // and no register of its own; the edge length a_e is slot 13: lane 13 sums alpha a_e)
+        };
+        auto open_row = [&](Row& r, int n) __attribute__((always_inline)) {
+          const float* __restrict__ su = stage + n * DC_S;
+          r.uh0 = {su[ch], su[ch + 1], su[ch + 2]};
+          r.uh1 = {su[CH2 + ch], su[CH2 + ch + 1], su[CH2 + ch + 2]};
+          r.u4 = su[C + lr];
+          const int nl = min(row0 + n, n_dst - 1) - row0;   // (n_dst < 16: rows past the end repeat the last node)
+          r.p = rp[nl];
+          r.pe = rp[nl + 1];
+          r.mx = -INFINITY;
+          r.den = r.sae = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < 6; ++nb) acc[nb] = zero4;
-
-      auto scores = [&](const Land& L_, float (&s)[UE], const int (&j)[UE], VLand& V_) __attribute__((always_inline)) {
+          for (int cc = 0; cc < 6; ++cc) r.acc[cc] = 0.f;
+        };
+        // A tile whose in-edges fit the LDS index window (all but hub tiles) finds every source index there; a load
+        // under `if` would drag a full wait to the branch merge and serialise the edges, so the choice is made once
+        // per tile, wave-uniformly, between two straight-line variants of the gather.
+        const bool in_window = __builtin_amdgcn_readfirstlane(rp[16] - pbase) <= DC_CW;
+        auto gather = [&](const Row& r, Unit& U, auto window_tag) __attribute__((always_inline)) {   // unconditional (clamped) loads, back to back
+          constexpr bool WINDOW = decltype(window_tag)::value;
 #pragma unroll
-        for (int t = 0; t < UE; ++t) {
-          load_values(j, V_, t);
-          asm volatile("" ::: "memory");
-          DcAcc S;
-          S.zero();
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) mfma_x3h(ua[ks], L_.hb[t][ks], S.m, S.c);
-          u32x4 xb4[DC_PL];
-          dc_split_half(L_.x4[t], xb4, amax);
-          mfma_x3h(ua[3], xb4, S.m, S.c);
-          const f32x4 sv = S.value();   // (1 / sqrt(96) is folded into u)
-          const float sel = diag_sub == 0 ? sv[0] : (diag_sub == 1 ? sv[1] : (diag_sub == 2 ? sv[2] : sv[3]));
-          s[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, sel)));
-        }
-      };
-      // online-max softmax over the units of a row; every product-sum is an explicit fma and contraction is off: a
-      // row computed by two overlapping tiles of a ragged end must give the same bits
-      auto fold = [&](const float (&s)[UE], const Land& L_, const VLand& V_, const int nact, auto first_tag) __attribute__((always_inline)) {
-#pragma clang fp contract(off)
-        constexpr bool FIRST = decltype(first_tag)::value;
-        float mnew = mx;
-#pragma unroll
-        for (int t = 0; t < UE; ++t) mnew = t < nact ? fmaxf(mnew, s[t]) : mnew;
-        if constexpr (!FIRST) {
-          const float scale = nact > 0 ? __expf(mx - mnew) : 1.0f;
-          den = den * scale;
-          sae = sae * scale;
-#pragma unroll
-          for (int nb = 0; nb < 6; ++nb) acc[nb] = acc[nb] * scale;
-        }
-#pragma unroll
-        for (int t = 0; t < UE; ++t) {
-          const float pw_ = t < nact ? __expf(s[t] - mnew) : 0.f;
-          den = den + pw_;
-          sae = __builtin_fmaf(pw_, L_.rel[t], sae);   // k-group 3 holds the edge length: sum alpha a_e there
-#pragma unroll
-          for (int nb = 0; nb < 6; ++nb) {
-            const f32x4 val = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[nb], L_.rel[t], V_.v[t][nb], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[nb][i] = __builtin_fmaf(pw_, fmaxf(val[i], 0.f), acc[nb][i]);
+          for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+            const int pt = min(r.p + t, e_last);
+            int j;
+            if constexpr (WINDOW) j = colw[min(max(pt - pbase, 0), DC_CW - 1)];
+            else j = has_edges ? Sw.col[pt] : 0;
+            if (!has_edges) j = 0;
+            U.hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
+            U.hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
+            U.x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
+            U.vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
+            U.vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
           }
-        }
-        mx = mnew;
-      };
-      {
-        float s[UE];
-        [[maybe_unused]] const unsigned long long tq0 = GGNN_STAMP_NOW();
-        scores(L, s, j0, V);
-        [[maybe_unused]] const unsigned long long tq1 = GGNN_STAMP_NOW();
-        fold(s, L, V, min(max(pe - p, 0), UE), std::true_type{});
-        st_score += tq1 - tq0;
-        st_fold += GGNN_STAMP_NOW() - tq1;
-      }
-      p += UE;
-      // rows of more than three in-edges (grains; hubs): further units, their loads exposed
-      while (__builtin_amdgcn_ballot_w64(p < pe) != 0) {
-        int j[UE];
+        };
+        auto fold = [&](Row& r, const Unit& U) __attribute__((always_inline)) {
+          // Every product-sum is an explicit fma and contraction is off: the two variants of the sweep (and a row
+          // computed by two overlapping tiles of a ragged end) must give the same bits, whatever the compiler would
+          // have chosen to fuse in each inlined copy.
+#pragma clang fp contract(off)
+          const int nact = min(max(r.pe - r.p, 0), GGNN_UNIT_EDGES);
+          if (nact > 0) {
+            float s[GGNN_UNIT_EDGES];
+            float mnew = r.mx;
 #pragma unroll
-        for (int t = 0; t < UE; ++t) j[t] = has_edges ? Sw.col[min(p + t, e_last)] : 0;
-        Land L2;
-        VLand V2;
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+              s[t] = -INFINITY;
+              if (t < nact) {
+                float part = r.u4 * U.x4[t];
+                part = __builtin_fmaf(r.uh0.x, U.hh[t][0].x, part);
+                part = __builtin_fmaf(r.uh0.y, U.hh[t][0].y, part);
+                part = __builtin_fmaf(r.uh0.z, U.hh[t][0].z, part);
+                part = __builtin_fmaf(r.uh1.x, U.hh[t][1].x, part);
+                part = __builtin_fmaf(r.uh1.y, U.hh[t][1].y, part);
+                part = __builtin_fmaf(r.uh1.z, U.hh[t][1].z, part);
+                s[t] = row_sum(part);   // 1 / sqrt(96) is folded into u
+                mnew = fmaxf(mnew, s[t]);
+              }
+            }
+            const float scale = __expf(r.mx - mnew);   // exp(-inf) = 0 on a row's first unit
+            r.den = r.den * scale;
+            r.sae = r.sae * scale;
 #pragma unroll
-        for (int t = 0; t < UE; ++t) load_scores(p, j, L2, t);
-        float s[UE];
-        scores(L2, s, j, V2);
-        fold(s, L2, V2, min(max(pe - p, 0), UE), std::false_type{});
-        p += UE;
+            for (int cc = 0; cc < 6; ++cc) r.acc[cc] = r.acc[cc] * scale;
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+              if (t < nact) {
+                // lane k of every 16-lane row -> the whole row (ds_swizzle bit mode: and 0x10, or k)
+                const int xi = __builtin_bit_cast(int, U.x4[t]);
+                const float rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (0 << 5) | 0x10));
+                const float ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (1 << 5) | 0x10));
+                const float rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (2 << 5) | 0x10));
+                const float pw_ = __expf(s[t] - mnew);
+                r.den = r.den + pw_;
+                r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);   // lane 13: sum alpha a_e (other lanes: unused)
+                const float v[6] = {U.vv[t][0].x, U.vv[t][0].y, U.vv[t][0].z, U.vv[t][1].x, U.vv[t][1].y, U.vv[t][1].z};
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                  const float val = __builtin_fmaf(wv[cc].z, rz, __builtin_fmaf(wv[cc].y, ry, __builtin_fmaf(wv[cc].x, rx, v[cc])));
+                  r.acc[cc] = __builtin_fmaf(pw_, fmaxf(val, 0.f), r.acc[cc]);
+                }
+              }
+            }
+            r.mx = mnew;
+          }
+          r.p += GGNN_UNIT_EDGES;
+        };
+        auto close_row = [&](const Row& r, int n) __attribute__((always_inline)) {  // the row's aggregate over the u it was computed from
+#pragma clang fp contract(off)
+          const float inv = 1.0f / (r.den + 1e-16f);   // PyG softmax denominator
+          float* __restrict__ so = stage + n * DC_S;
+          so[ch] = r.acc[0] * inv;
+          so[ch + 1] = r.acc[1] * inv;
+          so[ch + 2] = r.acc[2] * inv;
+          so[CH2 + ch] = r.acc[3] * inv;
+          so[CH2 + ch + 1] = r.acc[4] * inv;
+          so[CH2 + ch + 2] = r.acc[5] * inv;
+          if (lr == 0) so[C] = r.den * inv;
+          if (lr == 13) so[C + 1] = r.sae * inv;
+        };
+        auto sweep = [&](auto window_tag) __attribute__((always_inline)) {
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {
+            const int na = 8 * half + kq, nb = na + 4;     // tile rows of this DPP row
+            Row ra, rb;
+            open_row(ra, na);
+            open_row(rb, nb);
+            do {
+              Unit ua, ub;
+              gather(ra, ua, window_tag);
+              gather(rb, ub, window_tag);
+              fold(ra, ua);
+              fold(rb, ub);
+            } while (__builtin_amdgcn_ballot_w64(ra.p < ra.pe || rb.p < rb.pe) != 0);
+            close_row(ra, na);
+            close_row(rb, nb);
+          }
+        };
+        if (in_window) sweep(std::true_type{});
+        else sweep(std::false_type{});
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_c = GGNN_STAMP_NOW();
-
       // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
       {
-        u32x4 ab[3][DC_PL];
-        float xt, wtail[6];   // the (b_l2, w_edge) tail of lin_l2: requested here, used behind the three slices
+        u32x4 xb[2][DC_PL];
+        auto a_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
+          const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
+          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out, amax);
+        };
+        a_planes(0, xb[0]);
+        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
+        // the exact fp32 tail's weight fragments: requested here, used behind the three slices (requested there,
+        // their round trip stood in front of the tail's MFMAs in every phase)
+        float wtail[6];
         {
           const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
 #pragma unroll
           for (int ct = 0; ct < 6; ++ct) wtail[ct] = wt[ct * 64];
         }
-        {
-#pragma clang fp contract(off)
-          const float inv = 1.0f / (den + 1e-16f);   // PyG softmax denominator
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) dc_split(acc[2 * ks] * inv, acc[2 * ks + 1] * inv, ab[ks], amax);
-          xt = kq == 0 ? den * inv : (kq == 3 ? sae * inv : 0.f);
-        }
-        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
-#pragma unroll
-        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const u32x4* pw = begin_slice();
-          request_next();
-          dc_kstep<6>(pw, ab[ks], part);
-          end_slice(none);
+          const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (e + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
+          dc_kstep<6>(pw, xb[ks & 1], part);
+          if (ks + 1 < 3) a_planes(ks + 1, xb[(ks + 1) & 1]);
+          end_slice();
         }
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
+        const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[ct], xt, pre[ct], 0, 0, 0);
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_d = GGNN_STAMP_NOW();
       st_p1 += t_b - t_a;
       st_p2 += t_c - t_b;
@@ -485,11 +453,10 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const u32x4* pw = begin_slice();
-        request_next();
-        if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
+        const u32x4* pw = begin_slice(ks < 3 ? DC_NP3 : (gi < 3 ? DC_NP1 : 0));   // next: P4, the next gate's P1, or nothing
         dc_kstep<6>(pw, xb[ks & 1], part);
-        end_slice(none);
+        if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
+        end_slice();
       }
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
@@ -501,11 +468,6 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     // (the gate loop is a real loop -- unrolled four times the register allocator gave up --: the four updates sit
     // behind wave-uniform branches)
     f32x4 (&pv)[6] = pre;
-    f32x4 run[6];
-    if (gi > 0) {
-#pragma unroll
-      for (int ct = 0; ct < 6; ++ct) run[ct] = park[ct * 64];
-    }
     if (gi == 0) {
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct)
@@ -526,10 +488,6 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[ct][r] = sigmoidf_(pv[ct][r]) * tanhf_(run[ct][r]);
-    }
-    if (gi < 3) {
-#pragma unroll
-      for (int ct = 0; ct < 6; ++ct) park[ct * 64] = run[ct];
     }
     if (gi == 2) {
       float* crow = A.c_out + (int64_t)node_m * C + 4 * kq;
@@ -553,17 +511,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   GGNN_STAMP_VAL(9, st_lstm);
   GGNN_STAMP_VAL(10, n_in);
   GGNN_STAMP_VAL(11, st_dma);
-  GGNN_STAMP_VAL(12, st_k[0]);
-  GGNN_STAMP_VAL(13, st_k[1]);
-  GGNN_STAMP_VAL(14, st_k[2]);
-  GGNN_STAMP_VAL(15, st_k[3]);
-  GGNN_STAMP_VAL(17, st_split);
-  GGNN_STAMP_VAL(18, st_score);
-  GGNN_STAMP_VAL(19, st_fold);
   GGNN_STAMP(16);
 }
 
-__global__ __launch_bounds__(DC_WAVES * 64, DC_WAVES == 4 ? 2 : 1) void dec_cell_kernel(const DecCellBatch B) {
+// (155 648 B of LDS: one workgroup per compute unit, two waves per SIMD, <= 256 registers)
+__global__ __launch_bounds__(DC_WAVES * 64) void dec_cell_kernel(const DecCellBatch B) {
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[DC_LDS];
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
@@ -571,43 +523,10 @@ __global__ __launch_bounds__(DC_WAVES * 64, DC_WAVES == 4 ? 2 : 1) void dec_cell
   // workgroups that share an XCD take one contiguous range of tile sets: neighbouring rows, whose in-edges
   // come from the same source rows, meet in the same L2 (speed only)
   const int ts = xcd_remap((int)blockIdx.x - B.wg_off[k], nwg);
-  // Every workgroup runs the same program from the same start: left alone, the whole chip gathers in the same
-  // microseconds and sits in its GEMM phases in the same microseconds.  A start delay that differs between the
-  // workgroups of an XCD spreads the gather bursts over the period of one (edge type, gate) pass.
-  for (int i = ((int)(blockIdx.x >> 3) & 7) * B.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);
   dec_cell_body(B.a[k], ts, s_raw);
 }
 
-// fp32 rows -> the two fp16 planes of the decoder cell's arithmetic, [n][hi | lo'][96]; one thread per channel pair
-__global__ __launch_bounds__(256) void hidden_planes_kernel(const float* __restrict__ h, int64_t n, int64_t ldh,
-                                                            uint32_t* __restrict__ out, int32_t* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool over = false;
-  if (i < n * (C / 2)) {
-    const int64_t node = i / (C / 2);
-    const int c2 = (int)(i - node * (C / 2));
-    const float a = h[node * ldh + 2 * c2], b = h[node * ldh + 2 * c2 + 1];
-    over = !(fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)) < 65504.0f);
-    uint32_t hi, lo;
-    split_f16x2(a, b, hi, lo);
-    out[node * C + c2] = hi;
-    out[node * C + C / 2 + c2] = lo;
-  }
-  if (flags != nullptr && __builtin_amdgcn_ballot_w64(over) != 0 && (threadIdx.x & 63) == 0) atomicOr(flags, GGNN_FLAG_F16_RANGE);
-}
-
 }  // namespace ggnn
-
-extern "C" int ggnn_hidden_planes(const float* h, int64_t n, int64_t ldh, void* planes, int32_t* flags,
-                                  ggnn_stream_t stream) {
-  using namespace ggnn;
-  if (!h || !planes || n <= 0 || ldh < C || !aligned16(planes)) return GGNN_EINVAL;
-  const int64_t nblk = (n * (C / 2) + 255) / 256;
-  if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  hipLaunchKernelGGL(hidden_planes_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, h, n, ldh,
-                     reinterpret_cast<uint32_t*>(planes), flags);
-  return launch_status();
-}
 
 extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream) {
   using namespace ggnn;
@@ -623,17 +542,17 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
     }
     const ggnn_dec_cell_args& A = B.a[k];
     if (A.n_in < 1 || A.n_in > 2 || A.n_dst <= 0 || A.f_dst < 1 || A.f_dst > 12 || A.ldx < A.f_dst) return GGNN_EINVAL;
-    if (!A.x_dst || !A.hp_dst || !A.c_in || !A.h_out || !A.c_out || !A.wstream || !A.w2_tail) return GGNN_EINVAL;
-    if (!aligned16(A.hp_dst) || !aligned16(A.c_in) || !aligned16(A.h_out) || !aligned16(A.c_out) || !aligned16(A.wstream))
+    if (!A.x_dst || !A.h_dst || !A.c_in || !A.h_out || !A.c_out || !A.wstream || !A.w2_tail) return GGNN_EINVAL;
+    if (A.ldh < C || (A.ldh & 3) || !aligned16(A.h_dst) || !aligned16(A.c_in) || !aligned16(A.h_out) ||
+        !aligned16(A.c_out) || !aligned16(A.wstream))
       return GGNN_EINVAL;
     if (A.n_dst >= INT32_MAX - 64) return GGNN_EINVAL;
     for (int e = 0; e < A.n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
-      if (!Sw.rowptr || !Sw.einfo || !Sw.hp_src || !Sw.v_src || !Sw.edge_params) return GGNN_EINVAL;
-      if (!aligned16(Sw.einfo) || !aligned16(Sw.hp_src) || !aligned16(Sw.v_src)) return GGNN_EINVAL;
+      if (!Sw.rowptr || !Sw.einfo || !Sw.h_src || !Sw.v_src || !Sw.edge_params || !aligned16(Sw.einfo)) return GGNN_EINVAL;
       if (Sw.E < 0 || Sw.n_src <= 0 || (Sw.E > 0 && !Sw.col)) return GGNN_EINVAL;
-      if (Sw.v_off < 0 || Sw.v_off + 4 * C > Sw.ldv || (Sw.v_off & 3) || (Sw.ldv & 3)) return GGNN_EINVAL;   // 16-byte pieces
-      if (Sw.n_src * DC_HP_ROW >= INT32_MAX || Sw.n_src * Sw.ldv >= INT32_MAX ||
+      if (Sw.ldh_src < C || Sw.v_off < 0 || Sw.v_off + 4 * C > Sw.ldv) return GGNN_EINVAL;
+      if (Sw.n_src * Sw.ldh_src >= INT32_MAX || Sw.n_src * Sw.ldv >= INT32_MAX ||
           (Sw.E + GGNN_UNIT_EDGES) * GGNN_EINFO_ROW >= INT32_MAX)
         return GGNN_EINVAL;  // gathered rows are addressed with 32-bit offsets
     }
@@ -641,11 +560,6 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
     if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
     B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
   }
-  static const int stagger = [] {
-    const char* e = getenv("GGNN_DC_STAGGER");
-    return e ? atoi(e) : 0;
-  }();
-  B.stagger = stagger;
   hipLaunchKernelGGL(dec_cell_kernel, dim3((unsigned)B.wg_off[DC_MAX_PROBLEMS]), dim3(DC_WAVES * 64), 0,
                      (hipStream_t)stream, B);
   return launch_status();

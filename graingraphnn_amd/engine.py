@@ -102,8 +102,6 @@ class Workspace:
             self.agg_dec[nt] = torch.zeros(n, dec.G * dec.layout[nt].Kg, **f32)
             for d in (self.h1, self.c1, self.h2, self.c2):
                 d[nt] = torch.empty(n, C, **f32)
-        # the encoder's hidden state as the two fp16 planes the fused decoder cell computes with (ggnn_hidden_planes)
-        self.h1p = {nt: torch.empty(n_nodes[nt], 2, C, dtype=torch.float16, device=device) for nt in NODE_TYPES}
 
 
 def _edge_attr_1d(t: torch.Tensor) -> torch.Tensor:
@@ -140,14 +138,14 @@ def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
 def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo: Dict[ET, torch.Tensor],
               after_projection=None, after_sweeps=None):
     """One HeteroPGCLSTM.forward for every entry of `cells` -- (pc, h_in, c_in, proj, agg, h_out,
-    c_out[, h_in_planes]), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
+    c_out), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
     launches: all projections, all aggregation sweeps, all gate GEMM + LSTM epilogues.
     Encoder cells (pc.k2 == 0) ignore h_in / c_in (zeros).  `after_projection`: called right behind the last
     launch of the cell that reads x (the projection; with the fused decoder cell, that kernel) and `after_sweeps`
     behind the last launch that reads the edge records (a caller may record stream events there)."""
     projs, sweeps, enc_sweeps, gates, enc_cells, dec_cells = [], [], [], [], [], []
-    for pc, h_in, c_in, proj, agg, h_out, c_out, *rest in cells:
+    for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
         if pc.wvb and getattr(backend, "fused_encoder", False):
             # encoder: sweep and gate GEMM of a node type in one kernel; the projection only emits the score
@@ -168,13 +166,10 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
             for nt in NODE_TYPES:
                 if nt in pc.wpv:
                     projs.append((x[nt], lay[nt].F, h_in[nt], pc.wpv[nt], pc.bpv[nt], proj[nt][:, :pc.wpv[nt].size(0)]))
-            # the hidden states as fp16 planes: the caller's (a workspace fills them once per forward) or made here
-            hp = rest[0] if rest and rest[0] is not None else {}
-            hp = {nt: hp[nt] if nt in hp else backend.hidden_planes(h_in[nt]) for nt in NODE_TYPES}
             for nt in NODE_TYPES:
                 if lay[nt].live:
-                    dec_cells.append(([(graph.csr[et], einfo[et], hp[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
-                                       for et in lay[nt].dst_ets], x[nt], hp[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
+                    dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
+                                       for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
                                       h_out[nt], c_out[nt]))
             continue
         for nt in NODE_TYPES:
@@ -256,13 +251,5 @@ def run_encoder_decoder_multi(backend, models, graph: GraphCSR, x: Dict[str, tor
               graph, x, einfo)
     # (x_read / einfo_read: called once the last launch that reads x -- the decoder projection -- / the edge
     # records -- the decoder sweeps -- is enqueued)
-    fused = getattr(backend, "fused_decoder", False)
-    planes = []
-    for _, dec, ws in models:
-        if fused and dec.dcs:   # the fused decoder cell takes the encoder's h as fp16 planes
-            planes.append({nt: backend.hidden_planes(ws.h1[nt], ws.h1p[nt]) for nt in NODE_TYPES})
-        else:
-            planes.append(None)
-    run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2, hp)
-                        for (_, dec, ws), hp in zip(models, planes)],
+    run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2) for _, dec, ws in models],
               graph, x, einfo, after_projection=x_read, after_sweeps=einfo_read)

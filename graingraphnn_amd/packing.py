@@ -224,11 +224,6 @@ DC_PLANES = 2               # fp16 planes of the decoder cell's weight stream: h
 DC_LO_SCALE = 2048.0
 DC_SLICE_I16 = 7 * DC_PLANES * 1024 // 2   # GGNN_DC_SLICE_BYTES / 2: int16 elements per slice of the decoder cell's weight stream
 DC_GATE_ORDER = (0, 2, 1, 3)  # the fused decoder cell walks the gates i, c~, f, o (weights are indexed i, f, c, o)
-# The two index permutations of include/ggnn.h (GGNN_DC_P1_CHANNEL / GGNN_DC_P3_CHANNEL) that let the kernel's register
-# layouts chain without a transpose: row r of a P1 block holds the u_h row of hidden channel DC_P1_CHANNEL[r]; column k
-# of a P3 block holds the lin_l2 column of aggregate channel DC_P3_CHANNEL[k].
-DC_P1_CHANNEL = tuple(32 * (r // 32) + 8 * ((r % 16) // 4) + 4 * ((r // 16) % 2) + r % 4 for r in range(96))
-DC_P3_CHANNEL = tuple(32 * (k // 32) + 16 * ((k % 8) // 4) + 4 * ((k % 32) // 8) + k % 4 for k in range(96))
 
 
 @torch.no_grad()
@@ -277,22 +272,20 @@ def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
         return out
 
     slices = []
-    p1 = torch.tensor(DC_P1_CHANNEL, device=wp.device)
-    p3 = torch.tensor(DC_P3_CHANNEL, device=wp.device)
     for g in DC_GATE_ORDER:
         for d, et in enumerate(lay.dst_ets):
-            u = p1 + (lay.u_off[et] + g * C)
+            u = slice(lay.u_off[et] + g * C, lay.u_off[et] + (g + 1) * C)
             t = slice(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4)
             slices.append(_plane_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))))   # P1: 4 slices
-            slices.append(_plane_slices(w2[g][:, p3 + d * C].contiguous()))                               # P3: 3 slices
+            slices.append(_plane_slices(w2[g][:, d * C:(d + 1) * C].contiguous()))                        # P3: 3 slices
         sk = slice(lay.s_off + g * C, lay.s_off + (g + 1) * C)
         slices.append(_plane_slices(block(wp[sk], bp[sk])))                                                # P4: 4 slices
     stream = torch.cat(slices).contiguous()
     assert stream.size(0) == 4 * (7 * n_in + 4)
     tail = torch.zeros(G, n_in, 6, 4, 16, dtype=torch.float32, device=wp.device)   # g e ct k m   (lane l = 16 k + m)
     for d in range(n_in):
-        for k, slot in enumerate((0, 3)):   # b_l2 meets sum alpha in k-group 0, w_edge meets sum alpha a_e in k-group 3
-            tail[:, d, :, slot, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
+        for k in range(2):
+            tail[:, d, :, k, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
     return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
 
 

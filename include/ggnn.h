@@ -354,83 +354,71 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * A workgroup of eight waves owns 128 consecutive destination nodes, one 16-node tile per wave, and walks the
  * gates in the order i, c~, f, o (the LSTM update is folded in as the gates arrive).  Per gate g and incoming
  * edge type e a wave (P1) multiplies its tile's [h | x | 1] rows with the (e, g) score weights -> u_h | u4 of its
- * 16 nodes, (P2) forms the scores of the tile's in-edges of that edge type on the matrix cores (u against the
- * gathered hidden planes and edge records of the sources), runs the online-max softmax, adds the periodic
- * min-image correction W_value[:, 0:3] . reloc to the gathered value rows with an exact fp32 MFMA, relu,
- * alpha-weighted sum -- ggnn_period_gat_aggregate's sums up to fp32 re-association --, (P3) multiplies the
- * 16 x 98 aggregate block with lin_l2 | (b_l2, w_edge) of (e, g) into the gate's pre-activation, then (P4) adds the
- * summed skip term of the gate.  Arithmetic of P1, the scores, P3 and P4: every fp32 operand as TWO fp16 pieces,
- * hi = rne16(x) and lo' = rne16((x - hi) * 2048), and three of the four products (hi hi + (hi lo' + lo' hi) / 2048)
- * accumulated in fp32 on v_mfma_f32_16x16x32_f16: 22 significand bits per operand, against an fp64 product 5e-8 of
- * sum |x||w| (a plain fp32 fma chain: 2e-7).  OPERAND RANGE: finite and |x| < 65504 for weights, hidden states,
- * features, edge records, the score operands u and the aggregates; the residual of an operand below 2^-13 in
- * magnitude is subnormal (absolute resolution 2^-36).  A weight beyond the range cannot be packed
- * (packing.split2_f16 refuses); an activation beyond it is clamped to +-65504 AND reported: the kernel ORs
- * GGNN_FLAG_F16_RANGE into *flags (when given), so a caller can re-run the cell on the three-kernel plan.
- * Weights arrive as k-step slices of pre-split planes through a double-buffered LDS region shared by the eight
- * waves (LDS-DMA).
+ * 16 nodes, (P2) sweeps the tile's in-edges of that edge type (gathers of h_src and V rows, periodic min-image
+ * correction, online-max softmax, relu, alpha-weighted sum: exactly ggnn_period_gat_aggregate's arithmetic),
+ * (P3) multiplies the 16 x 98 aggregate block with lin_l2 | (b_l2, w_edge) of (e, g) into the gate's
+ * pre-activation, then (P4) adds the summed skip term of the gate.  Arithmetic of the three GEMMs: every fp32
+ * operand as TWO fp16 pieces, hi = rne16(x) and lo' = rne16((x - hi) * 2048), and three of the four products
+ * (hi hi + (hi lo' + lo' hi) / 2048) accumulated in fp32 on v_mfma_f32_16x16x32_f16: 22 significand bits per
+ * operand, against an fp64 product 5e-8 of sum |x||w| (a plain fp32 fma chain: 2e-7); the rank-1 columns
+ * (b_l2, w_edge) run on one exact fp32 MFMA.  The weights arrive as k-step slices of host-side pre-split planes
+ * through a double-buffered LDS region shared by the eight waves (LDS-DMA).
+ * OPERAND RANGE of the two-piece arithmetic: finite and |x| < 65504 for the weights, the tile's [h | x] rows and the
+ * aggregates; the residual of an operand below 2^-13 in magnitude is subnormal (absolute resolution 2^-36).  A
+ * weight outside the range cannot be packed (packing.split2_f16 refuses; packing.pack_cell then leaves the fused
+ * operands out and the cell runs on projection + sweeps + gate GEMM, whose bf16 x 3 split covers fp32's range); an
+ * activation outside it is clamped to +-65504 AND reported: the kernel ORs GGNN_FLAG_F16_RANGE into *flags (when
+ * given), which graingraphnn_amd's backend reads at the end of a rollout / on request (range_exceeded).
  *
  * Per incoming edge type:
  *   rowptr, col : destination-grouped CSR of the edge type (ggnn_build_csr)
  *   einfo       : edge records in CSR order (ggnn_edge_prepare)
- *   hp_src      : [n_src][2][96] fp16: the hidden state of the source node type as the two planes above
- *                 (ggnn_hidden_planes, or the encoder cell's own output), 16-byte aligned
+ *   h_src       : [n_src, ldh_src] hidden state of the source node type
  *   v_src       : [n_src, ldv] projection of the source node type; columns v_off + g * 96 .. + 95 = the value
- *                 rows of gate g for this edge type (first three input columns zeroed, as for the sweep);
- *                 16-byte aligned, ldv and v_off multiples of 4
+ *                 rows of gate g for this edge type (first three input columns zeroed, as for the sweep)
  *   edge_params : [4][GGNN_EDGE_PARAM_ROWS][96] = W_value[:, 0..2] per gate
  * per problem (one destination node type of one model):
- *   x_dst [n_dst, ldx], hp_dst [n_dst][2][96] fp16 (the encoder's h as planes), c_in [n_dst, 96]; h_out, c_out [n_dst, 96]
+ *   x_dst [n_dst, ldx], h_dst [n_dst, ldh] (the encoder's h), c_in [n_dst, 96]; h_out, c_out [n_dst, 96]
  *   wstream : the weight slices in the order the kernel consumes them (packing.decoder_cell_stream):
  *             for g in (i, c~, f, o): for e: 4 slices P1(e, g) | 3 slices P3(e, g); then 4 slices P4(g).
- *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, lo'][64 lanes][8 fp16];
- *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles,
- *             P3 / P4 six (the tail of their slice is unused).  The reduction index of P1 / P4 is
- *             [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128.  Two index permutations make the kernel's
- *             register layouts chain without a transpose:
- *               P1 row r < 96  = the u_h row of hidden channel GGNN_DC_P1_CHANNEL(r) (rows 96..111: u4, in order);
- *               P3 column k    = the lin_l2 column of aggregate channel GGNN_DC_P3_CHANNEL(k).
+ *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, lo'][64 lanes][8 fp16] -- the two
+ *             fp16 pieces of a weight w are hi = rne16(w) and lo' = rne16((w - hi) * 2048) (finite, |w| < 65504) --
+ *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles
+ *             (u_h 0..95 | u4 96..111), P3 / P4 six (the tail of their slice is unused).  The reduction index
+ *             of P1 / P4 is [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128, of P3 the 96 aggregate channels.
+ *             The kernel splits its own operands the same way (OPERAND RANGE above).
  *   w2_tail : [4][n_in][6][64] fp32: (b_l2, w_edge) of (g, e) as v_mfma_f32_16x16x4_f32 A fragments
- *             ([ct][l]: k = l >> 4; k = 0 -> b_l2[16 ct + (l & 15)], k = 3 -> w_edge[16 ct + (l & 15)], else 0)
+ *             ([ct][l] = k < 2 ? tail[16 ct + (l & 15)][k = l >> 4] : 0)
  *   flags   : optional int32 device word, see OPERAND RANGE
  * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
 #define GGNN_PRECISION_BF16 1
 #define GGNN_DC_SLICE_BYTES 14336 /* 7 column tiles x 2 planes x 1 KB */
 #define GGNN_FLAG_F16_RANGE 1     /* an activation at or beyond +-65504 was clamped in a two-piece fp16 split */
-/* row r = 16 nb + 4 kq + i of a P1 block <-> hidden channel 32 (nb / 2) + 8 kq + 4 (nb % 2) + i */
-#define GGNN_DC_P1_CHANNEL(r) (32 * ((r) / 32) + 8 * (((r) % 16) / 4) + 4 * (((r) / 16) % 2) + (r) % 4)
-/* column k = 32 ks + 8 kq + j of a P3 block <-> aggregate channel 32 ks + 16 (j / 4) + 4 kq + j % 4 */
-#define GGNN_DC_P3_CHANNEL(k) (32 * ((k) / 32) + 16 * (((k) % 8) / 4) + 4 * (((k) % 32) / 8) + (k) % 4)
 typedef struct ggnn_dec_cell_sweep {
   const int32_t* rowptr;     /* [n_dst + 1] */
   const int32_t* col;        /* [E] source node of every edge, CSR order */
   const float* einfo;        /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] */
-  const void* hp_src;        /* [n_src][2][96] fp16 */
+  const float* h_src;        /* [n_src, ldh_src] */
   const float* v_src;        /* [n_src, ldv] */
   const float* edge_params;  /* [4][GGNN_EDGE_PARAM_ROWS][96] */
-  int64_t E, n_src, ldv;
+  int64_t E, n_src, ldh_src, ldv;
   int32_t v_off, reserved;
 } ggnn_dec_cell_sweep;
 typedef struct ggnn_dec_cell_args {
   ggnn_dec_cell_sweep in[2];
   const float* x_dst;    /* [n_dst, ldx] */
-  const void* hp_dst;    /* [n_dst][2][96] fp16 */
+  const float* h_dst;    /* [n_dst, ldh] */
   const float* c_in;     /* [n_dst, 96] */
   float* h_out;          /* [n_dst, 96] */
   float* c_out;          /* [n_dst, 96] */
   const void* wstream;   /* [n_slices][GGNN_DC_SLICE_BYTES], n_slices = 4 * (7 n_in + 4) */
   const float* w2_tail;  /* [4][n_in][6][64] */
-  int32_t* flags;        /* optional */
-  int64_t n_dst, ldx;
+  int32_t* flags;        /* optional: range flag word */
+  int64_t n_dst, ldx, ldh;
   int32_t n_in, f_dst;
 } ggnn_dec_cell_args;
 int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
-
-/* fp32 rows h [n, ldh] (first 96 columns) -> planes [n][2][96] fp16 of the decoder cell's arithmetic:
- * plane 0 = rne16(h), plane 1 = rne16((h - plane 0) * 2048); |h| >= 65504 is clamped and ORs GGNN_FLAG_F16_RANGE
- * into *flags (optional). */
-int ggnn_hidden_planes(const float* h, int64_t n, int64_t ldh, void* planes, int32_t* flags, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads.

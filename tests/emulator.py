@@ -213,51 +213,25 @@ class TorchEmulatorBackend:
         fr = fr[:, :, 0] + fr[:, :, 1] / DC_LO_SCALE
         return fr.permute(1, 3, 0, 2, 4).reshape(16 * n_tiles, 32 * n_ks)                  # (nb m) x (ks kq j)
 
-    def hidden_planes(self, h, out=None):
-        """ggnn_hidden_planes: [n, >= 96] fp32 -> [n, 2, 96] fp16 planes (hi = rne16(h), lo' = rne16((h - hi) 2048))."""
-        from graingraphnn_amd.packing import split2_f16
-        hi, lo = split2_f16(h[:, :C])
-        planes = torch.stack([hi, lo], 1).contiguous()
-        if out is not None:
-            out.copy_(planes)
-            return out
-        return planes
-
-    @staticmethod
-    def _planes_value(hp):
-        """What the kernel computes with: hi + lo' / 2048."""
-        return hp[:, 0].float() + hp[:, 1].float() / 2048.0
-
     def decoder_cell_batch(self, problems):
         """ggnn_decoder_cell_batch: per gate (stream order i, c~, f, o) and incoming edge type the score operands
         u_h | u4 = W1 [h | x | 1], the sweep, lin_l2 + (b_l2, w_edge) on the aggregates; then the skip block and the
-        LSTM update.  Everything is computed from the DECODED weight stream and the DECODED hidden planes, with the
-        index permutations of include/ggnn.h written out here independently of packing.py, so a packing error shows
-        up here."""
+        LSTM update.  Everything is computed from the DECODED weight stream, so a packing error shows up here."""
         self.calls = getattr(self, "calls", []) + ["decoder_cell_batch"]   # (which plan ran: test_decoder_plan_per_model)
-        # include/ggnn.h: GGNN_DC_P1_CHANNEL(r), GGNN_DC_P3_CHANNEL(k)
-        p1 = torch.tensor([32 * (r // 32) + 8 * ((r % 16) // 4) + 4 * ((r // 16) % 2) + r % 4 for r in range(C)])
-        p3 = torch.tensor([32 * (k // 32) + 16 * ((k % 8) // 4) + 4 * ((k % 32) // 8) + k % 4 for k in range(C)])
-        for sweeps, x_dst, hp_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
+        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
             n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
             from graingraphnn_amd.packing import DC_SLICE_I16
             assert wstream.numel() == 4 * (7 * n_in + 4) * DC_SLICE_I16 and tuple(w2_tail.shape) == (4, n_in, 6, 64)
-            assert hp_dst.dtype == torch.float16 and tuple(hp_dst.shape) == (n, 2, C)
             xin = torch.zeros(n, 128)
-            xin[:, :C], xin[:, C:C + F], xin[:, C + F] = self._planes_value(hp_dst), x_dst, 1.0
+            xin[:, :C], xin[:, C:C + F], xin[:, C + F] = h_dst, x_dst, 1.0
             pre, s = {}, 0
             for g in (0, 2, 1, 3):
                 z = torch.zeros(n, C)
-                for d, (csr, einfo, hp_src, v_src, v_off, ep) in enumerate(sweeps):
-                    W1p = self._decode_slices(wstream, s, 4, 7)       # [112, 128], rows 0..95 permuted
-                    W3p = self._decode_slices(wstream, s + 4, 3, 6)   # [96, 96], columns permuted
+                for d, (csr, einfo, h_src, v_src, v_off, ep) in enumerate(sweeps):
+                    W1 = self._decode_slices(wstream, s, 4, 7)        # [112, 128]
+                    W3 = self._decode_slices(wstream, s + 4, 3, 6)    # [96, 96]
                     s += 7
-                    W1 = torch.empty_like(W1p)
-                    W1[p1], W1[C:] = W1p[:C], W1p[C:]                  # row r of the block = u_h row of channel p1[r]
-                    W3 = torch.empty_like(W3p)
-                    W3[:, p3] = W3p                                    # column k of the block = lin_l2 column of channel p3[k]
                     assert not bool(W1[:, C + F + 1:].any())
-                    h_src = self._planes_value(hp_src)
                     u = xin @ W1.t()                                   # [n, 112]: u_h | u4
                     rowptr = csr.rowptr.long()
                     E = int(rowptr[-1])
@@ -273,9 +247,9 @@ class TorchEmulatorBackend:
                     A = torch.zeros(n, C).index_add(0, dst, alpha[:, None] * val)
                     sa = torch.zeros(n).index_add(0, dst, alpha)
                     sae = torch.zeros(n).index_add(0, dst, alpha * a)
-                    tail = w2_tail[g, d].view(6, 4, 16)                # ct k m: k = 0 b_l2, k = 3 w_edge
-                    assert not bool(tail[:, 1:3].any())
-                    z = z + A @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 3].reshape(1, C)
+                    tail = w2_tail[g, d].view(6, 4, 16)                # ct k m
+                    assert not bool(tail[:, 2:].any())
+                    z = z + A @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 1].reshape(1, C)
                 W4 = self._decode_slices(wstream, s, 4, 6)             # [96, 128]
                 s += 4
                 pre[g] = z + xin @ W4.t()

@@ -1049,14 +1049,13 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
             W1 = f(112, 128, lo=-0.15, hi=0.15)
             W1[:, 96 + F_dst + 1:] = 0                       # reduction index: h | x | 1 | zeros
             W1[96 + 14:, :] = 0                              # tail slots 14, 15 of u4 are always zero
-            slices += [_plane_slices(W1), _plane_slices(f(96, 96, lo=-0.2, hi=0.2))]   # (random blocks: the index
-            # permutations of the real packing are the emulator's and test_host_logic's business)
+            slices += [_plane_slices(W1), _plane_slices(f(96, 96, lo=-0.2, hi=0.2))]
         W4 = f(96, 128, lo=-0.15, hi=0.15)
         W4[:, 96 + F_dst + 1:] = 0
         slices.append(_plane_slices(W4))
     wstream = torch.cat(slices).contiguous().view(-1)
     tail = torch.zeros(4, n_in, 6, 4, 16, device=DEV)
-    tail[:, :, :, 0], tail[:, :, :, 3] = f(4, n_in, 6, 16, lo=-0.2, hi=0.2), f(4, n_in, 6, 16, lo=-0.2, hi=0.2)
+    tail[:, :, :, :2] = f(4, n_in, 6, 2, 16, lo=-0.2, hi=0.2)
     sweeps = []
     for d, (n_src, F, E) in enumerate(ins):
         src = rs.randint(0, max(n_src - 5, 1), size=E)
@@ -1071,8 +1070,8 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
         einfo = torch.zeros(E + 3, 20, device=DEV)
         be.edge_prepare([(csr, ea, xs, xd, einfo)])
         v_src = f(n_src, 384 * (d + 1) + 96)                         # value rows at a column offset, padded rows
-        sweeps.append((csr, einfo, be.hidden_planes(f(n_src, 96)), v_src, 384 * d, f(4, 3, 96)))
-    return (sweeps, xd, be.hidden_planes(h_dst), c_in, wstream, tail.view(4, n_in, 6, 64).contiguous(),
+        sweeps.append((csr, einfo, f(n_src, 96), v_src, 384 * d, f(4, 3, 96)))
+    return (sweeps, xd, h_dst, c_in, wstream, tail.view(4, n_in, 6, 64).contiguous(),
             torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV))
 
 

@@ -190,8 +190,8 @@ def test_decoder_plan_per_model():
                                             ("cfg2_s1", 0, 1.0)])
 @torch.no_grad()
 def test_packing_and_plan_reproduce_golden_forward(tag, seed, scale, fused_decoder):
-    """Both decoder plans through the emulator: projection + sweeps + gate GEMM (the default) and the fused
-    decoder cell (GGNN_DEC=fused), whose weight stream the emulator decodes back from its bf16 planes."""
+    """Both decoder plans through the emulator: the fused decoder cell (the default), whose weight stream the
+    emulator decodes back from its two fp16 planes, and projection + sweeps + gate GEMM (GGNN_DEC=split)."""
     if tag.startswith("cfg1"):
         x, ei, ea = load_graph("40")
     else:

@@ -22,7 +22,8 @@ from graingraphnn_amd import synthetic
 _, hei, _ = synthetic.honeycomb(100, 10, 0)          # the benchmark's structure: neighbours are near in index
 GJ, JG, JJ = synthetic.EDGE_TYPES
 EDGES = {2: [hei[GJ], hei[JJ]], 1: [hei[JG]]}
-for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classifier (joint), honeycomb", [J])):
+for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classifier (joint), honeycomb", [J]),
+                     ("regressor, random sources", [J, Gr])):
     probs = [_dec_cell_problem(be, rs, n, ins, F_dst=8 if len(ins) == 2 else 11,
                                edges=None if "random" in name else EDGES[len(ins)]) for n, ins in shapes]
     for _ in range(3):
@@ -48,8 +49,6 @@ for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classi
         life = us(m[:, 16] - m[:, 0])
         print(f"  wave life        med {np.median(life):7.2f}  max {life.max():7.2f} us")
         for i, nm in ((5, "sum P1 (scores)"), (6, "sum P2 (sweep)"), (7, "sum P3 (lin_l2)"), (8, "sum P4 (skip)"),
-                      (9, "sum LSTM"), (4, "  of which slice wait + barrier"), (11, "  of which slice DMA issue"),
-                      (12, "  P1 k-step 0"), (13, "  P1 k-step 1 (+ gather issue)"), (14, "  P1 k-step 2"), (15, "  P1 k-step 3"),
-                      (17, "  P1 fold + split of u"), (18, "  P2 scores"), (19, "  P2 softmax + values")):
+                      (9, "sum LSTM"), (4, "  of which slice wait + barrier"), (11, "  of which slice DMA issue")):
             r = us(m[:, i])
             print(f"  {nm:32s} med {np.median(r):7.2f}  max {r.max():7.2f} us")
