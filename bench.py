@@ -53,6 +53,7 @@ def build(device, n=100, fold=10, seed=0, scale=0.3):
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak
 
 
 class EventTimedBackend:
@@ -104,19 +105,20 @@ class EventTimedBackend:
         self._timed("enc_sweep", self.inner.aggregate_enc_batch, sweeps, (real, len(sweeps)))
 
     def encoder_cell_batch(self, problems):
-        # (sweeps [(csr, einfo, wv_frag, u4_off, f_src)], p_dst, x_dst, ws_t, w2, w2_frag, pre, h_out, c_out)
+        # (sweeps [(csr, einfo)], x_dst, wstream, w2_tail, h_out, c_out): matrix-pipe cycles as launched
         cycles = 0.0
-        for sweeps, p_dst, *_ in problems:
-            n = p_dst.size(0)
+        for sweeps, x_dst, *_ in problems:
+            n = x_dst.size(0)
             n_t = (n + 15) // 16
-            for csr, _, _, _, f_src in sweeps:
+            per_gate = n_t * 18 * 16                                   # skip: 6 column tiles x 3 products, one k-step
+            for csr, _ in sweeps:
                 deg = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
                 nu = torch.clamp((deg + 2) // 3, min=1)
-                nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)  # units per (tile, lane group)
-                blocks = int(nu.max(1).values.sum())
-                # per gate: fp32 MFMAs of 32 cycles per block (4 score + 6 per value k-step), per tile 54 fp16
-                # MFMAs of 16 cycles (3 k-steps x 6 column tiles x 3 products) + 6 fp32 ones for the rank-1 columns
-                cycles += 3 * (blocks * (4 + 6 * (3 if f_src > 8 else 2)) * 32 + n_t * (54 * 16 + 6 * 32))
+                units = int(torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 16).max(1).values.sum())
+                # per tile: u4 (3 fp16 MFMAs of 16 cycles) + lin_l2 (3 k-steps x 6 column tiles x 3 products) + 6 fp32
+                # MFMAs of 32 cycles for the rank-1 columns; per unit of <= 3 in-edges per node: 9 score + 54 value MFMAs
+                per_gate += n_t * ((3 + 54) * 16 + 6 * 32) + units * 63 * 16
+            cycles += 3 * per_gate
         self._timed("enc_cell", self.inner.encoder_cell_batch, problems, (cycles, len(problems)))
 
     def project_batch(self, problems):
@@ -253,15 +255,15 @@ def measure_roofline(ro, n_steps):
     c = summary(default_plan, "enc_cell")
     if c:  # the fused encoder cell: matrix-pipe cycles as launched against the chip's 1024 SIMDs at 2.4 GHz
         busy = c["work"] / (1024 * 2400.0 * c["avg_us"])
-        enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (+ enc_lstm_kernel, in the same bracket)",
-               "achieved": round(busy * FP32_MFMA_PEAK_TFLOPS, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (the whole encoder cell of a model: one launch)",
+               "achieved": round(busy * FP16_MFMA_PEAK_TFLOPS, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": round(busy, 4), "avg_launch_us": round(c["avg_us"], 2), "problems_per_launch": c["per_launch"],
-               "traffic": (lambda a, b: None if a is None or b is None else a + b)(
-                   pmc_traffic("ggnn::enc_cell_kernel"), pmc_traffic("ggnn::enc_lstm_kernel")),
+               "traffic": pmc_traffic("ggnn::enc_cell_kernel", "fused"),
                "mfma_cycles_per_launch": int(c["work"]),
-               "note": "frac = matrix-pipe cycles of the launch (fp32 MFMAs of the sweep at 32 cycles, fp16 MFMAs of the "
-                       "gate GEMM at 16: half as many as with the bf16 split of round 2) / (1024 SIMDs x 2.4 GHz x duration); achieved = frac x the fp32 matrix peak; the "
-                       "kernel is bound by instruction issue (profiles/README.md)"}
+               "note": "frac = matrix-pipe cycles of the launch (fp16 MFMAs at 16 cycles: three per fp32 product, half of "
+                       "every 16-slot k-step's 32-deep reduction is padding; six fp32 MFMAs of 32 cycles per pass) / "
+                       "(1024 SIMDs x 2.4 GHz x duration); achieved = frac x the dense fp16 matrix peak; the kernel is "
+                       "bound by vector + matrix instruction issue at two waves per SIMD (profiles/README.md)"}
     for plan, key, kname, name in (
             ("fused", "dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection of the default plan: value rows only)"),
             ("split", "dec_project", "ggnn::project_x6_kernel", "ggnn::project_x6_kernel (decoder projection, GGNN_DEC=split: both node types of a model)"),

@@ -91,20 +91,17 @@ class AggregateEncArgs(Structure):
 
 class EncCellSweep(Structure):
     """Mirror of `ggnn_enc_cell_sweep`."""
-    _fields_ = [
-        ("rowptr", c_void_p), ("einfo", c_void_p), ("wv_frag", c_void_p),
-        ("E", c_int64), ("u4_off", c_int32), ("f_src", c_int32), ("n_blocks", c_int64),
-    ]
+    _fields_ = [("rowptr", c_void_p), ("einfo", c_void_p), ("E", c_int64)]
 
 
 class EncCellArgs(Structure):
     """Mirror of `ggnn_enc_cell_args`."""
     _fields_ = [
         ("sweeps", EncCellSweep * 2),
-        ("p_dst", c_void_p), ("w2_frag", c_void_p), ("w2", c_void_p), ("pre", c_void_p),
-        ("h_out", c_void_p), ("c_out", c_void_p), ("x_dst", c_void_p), ("ws_t", c_void_p),
-        ("ldp", c_int64), ("n_dst", c_int64), ("ldx", c_int64),
-        ("n_in", c_int32), ("f_dst", c_int32), ("Ka", c_int32), ("reserved", c_int32),
+        ("x_dst", c_void_p), ("h_out", c_void_p), ("c_out", c_void_p), ("wstream", c_void_p), ("w2_tail", c_void_p),
+        ("flags", c_void_p),
+        ("n_dst", c_int64), ("ldx", c_int64),
+        ("n_in", c_int32), ("f_dst", c_int32),
     ]
 
 

@@ -15,12 +15,11 @@ from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, DecCellArg
 
 class CSR:
     """Destination-grouped edge list of one edge type (all int32, device resident)."""
-    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E", "n_blocks")
+    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E")
 
     def __init__(self, rowptr, col, perm, row, unit_ptr, units, E):
         self.rowptr, self.col, self.perm, self.row = rowptr, col, perm, row
         self.unit_ptr, self.units, self.E = unit_ptr, units, E
-        self.n_blocks = 0   # sweep blocks of the fused encoder cell (engine.GraphCSR fills it in; 0 = unknown)
 
 
 def _require_cuda(*tensors):
@@ -210,45 +209,38 @@ class HipBackend:
                      len(sweeps), _lib.current_stream())
 
     def encoder_cell_batch(self, problems):
-        """Encoder cells (h = c = 0) of up to four (node type, model) problems with sweep and gate GEMM
-        fused (ggnn_encoder_cell_batch).  Each item: (sweeps, p_dst, x_dst, ws_t, w2, w2_frag, pre, h_out, c_out)
-        with sweeps = [(csr, einfo, wv_frag, u4_off, f_src)] for the 1 or 2 incoming edge types; ws_t:
-        packing.skip_transposed ([F_dst + 1, 288])."""
+        """ggnn_encoder_cell_batch (include/ggnn.h): the encoder cell (h = c = 0) of up to four (model, destination
+        node type) problems in one launch.  Each item: (sweeps, x_dst, wstream, w2_tail, h_out, c_out) with sweeps =
+        [(csr, einfo)] for the 1 or 2 incoming edge types; wstream / w2_tail: packing.encoder_cell_stream."""
         arr = (EncCellArgs * len(problems))()
-        for a, (sweeps, p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out) in zip(arr, problems):
-            _require_cuda(p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out)
-            if ws_t.dtype != torch.float32 or ws_t.dim() != 2 or ws_t.size(1) != 288 or not ws_t.is_contiguous() \
-                    or x_dst.dtype != torch.float32 or x_dst.size(0) != p_dst.size(0) or x_dst.stride(1) != 1 \
-                    or x_dst.size(1) < ws_t.size(0) - 1:
-                raise _lib.GGNNError("ws_t must be contiguous [F_dst + 1, 288] and x_dst [n_dst, >= F_dst]")
-            if p_dst.dtype != torch.float32 or p_dst.dim() != 2 or p_dst.stride(1) != 1:
-                raise _lib.GGNNError("p_dst must be float32 [n_dst, ldp] with unit column stride")
-            n_in, n = len(sweeps), p_dst.size(0)
-            if w2.dim() != 3 or w2.size(0) != 3 or w2.size(2) != 96 * n_in + 4 or not w2.is_contiguous():
-                raise _lib.GGNNError("w2 must be contiguous [3, 96, 96 * n_in + 4]")
-            if w2f.dtype != torch.float32 or w2f.numel() != 3 * 96 * 96 * n_in:
-                raise _lib.GGNNError("w2_frag does not match w2 (see packing.gate_fragments)")
-            if tuple(pre.shape) != (n_in, n, 288) or not pre.is_contiguous() or tuple(h_out.shape) != (n, 96) \
-                    or tuple(c_out.shape) != (n, 96) or not h_out.is_contiguous() or not c_out.is_contiguous():
-                raise _lib.GGNNError("pre / h_out / c_out must be contiguous [n_in, n_dst, 288] / [n_dst, 96]")
-            for sw, (csr, einfo, wvb, u4_off, f_src) in zip(a.sweeps, sweeps):
-                _require_cuda(csr.rowptr, einfo, wvb)
-                if wvb.dtype != torch.float32 or wvb.numel() != 3 * 6 * 4 * 64:
-                    raise _lib.GGNNError("wv_frag must be packing.value_fragments_bias of three gates")
+        for a, (sweeps, x_dst, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
+            _require_cuda(x_dst, wstream, w2_tail, h_out, c_out)
+            n, n_in = x_dst.size(0), len(sweeps)
+            for t, name in ((x_dst, "x_dst"), (h_out, "h_out"), (c_out, "c_out"), (w2_tail, "w2_tail")):
+                if t.dtype != torch.float32 or t.dim() < 2 or t.stride(-1) != 1:
+                    raise _lib.GGNNError(f"ggnn_encoder_cell_batch: {name} must be float32 with unit column stride")
+            if n_in not in (1, 2) or tuple(h_out.shape) != (n, 96) or not h_out.is_contiguous() \
+                    or tuple(c_out.shape) != (n, 96) or not c_out.is_contiguous():
+                raise _lib.GGNNError("ggnn_encoder_cell_batch: h_out / c_out must be contiguous [n_dst, 96], 1 or 2 "
+                                     "incoming edge types")
+            if wstream.dtype != torch.int16 or not wstream.is_contiguous() \
+                    or wstream.numel() * 2 != 3 * (4 * n_in + 1) * _lib.GGNN_DC_SLICE_BYTES:
+                raise _lib.GGNNError("ggnn_encoder_cell_batch: wstream is not packing.encoder_cell_stream of this "
+                                     "number of incoming edge types")
+            if tuple(w2_tail.shape) != (3, n_in, 6, 64) or not w2_tail.is_contiguous():
+                raise _lib.GGNNError("ggnn_encoder_cell_batch: w2_tail must be contiguous [3, n_in, 6, 64]")
+            for sw, (csr, einfo) in zip(a.sweeps, sweeps):
+                _require_cuda(csr.rowptr, einfo)
                 if csr.rowptr.numel() != n + 1:
                     raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
                 if einfo.dtype != torch.float32 or not einfo.is_contiguous() or einfo.dim() != 2 \
                         or einfo.size(1) != _lib.GGNN_EINFO_ROW or einfo.size(0) < csr.E + _lib.GGNN_UNIT_EDGES:
                     raise _lib.GGNNError("einfo must be contiguous float32 [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW]")
-                if u4_off < 0 or u4_off + 3 * 16 > p_dst.stride(0):
-                    raise _lib.GGNNError("u4_off: the three gates' score tails must lie inside a p_dst row")
-                sw.rowptr, sw.einfo = csr.rowptr.data_ptr(), einfo.data_ptr()
-                sw.wv_frag, sw.E, sw.u4_off, sw.f_src = wvb.data_ptr(), csr.E, u4_off, f_src
-                sw.n_blocks = getattr(csr, "n_blocks", 0) or 0
-            a.p_dst, a.w2_frag, a.w2, a.pre = p_dst.data_ptr(), w2f.data_ptr(), w2.data_ptr(), pre.data_ptr()
-            a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
-            a.x_dst, a.ws_t, a.ldx, a.f_dst = x_dst.data_ptr(), ws_t.data_ptr(), x_dst.stride(0), ws_t.size(0) - 1
-            a.ldp, a.n_dst, a.n_in, a.Ka = p_dst.stride(0), n, n_in, w2.size(2)
+                sw.rowptr, sw.einfo, sw.E = csr.rowptr.data_ptr(), einfo.data_ptr(), csr.E
+            a.x_dst, a.h_out, a.c_out = x_dst.data_ptr(), h_out.data_ptr(), c_out.data_ptr()
+            a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()
+            a.flags = self.range_flag(x_dst.device).data_ptr()
+            a.n_dst, a.ldx, a.n_in, a.f_dst = n, x_dst.stride(0), n_in, x_dst.size(1)
         self._launch(self.lib.ggnn_encoder_cell_batch, "ggnn_encoder_cell_batch", arr, len(problems),
                      _lib.current_stream())
 

@@ -32,10 +32,10 @@
 // A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
 // and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
+#include "cell_common.h"
 #define GGNN_STAMP_SUFFIX _dec
 #include "stamps.h"
 
@@ -43,7 +43,6 @@ namespace ggnn {
 
 constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
-constexpr int DC_PL = 2;                            // weight / operand planes: fp16 hi and scaled residual (common.h)
 constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
 static_assert(DC_SLICE == 7 * DC_PL * 1024, "slice = 7 column tiles x planes x 1 KB");
 constexpr int DC_NP1 = 7 * DC_PL, DC_NP3 = 6 * DC_PL;   // pieces of a P1 slice / of a P3 or P4 slice
@@ -61,58 +60,6 @@ struct DecCellBatch {
   int wg_off[DC_MAX_PROBLEMS + 1];
   int n;
 };
-
-// LDS-DMA: every lane copies 16 bytes from its own global address to lds_base + lane * 16 (wave-uniform base
-// in M0).  Not tracked by the compiler: completion = s_waitcnt vmcnt (in issue order with every other
-// vector-memory operation of the wave).
-__device__ __forceinline__ void dc_dma16(const void* gsrc, uint32_t lds_base) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
-               : "memory");
-}
-
-// eight fp32 values -> the two fp16 planes of a B fragment; `amax` follows the largest magnitude that went through a
-// split (range flag, ggnn.h)
-__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[DC_PL], float& amax) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const f32x4 h = e < 2 ? r0 : r1;
-    uint32_t q0, q1;
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(h[2 * (e & 1)]), __builtin_fabsf(h[2 * (e & 1) + 1])));
-    split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
-    xb[0][e] = q0;
-    xb[1][e] = q1;
-  }
-}
-
-// One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
-// lane; piece (nb, plane) at (nb * 3 + plane) * 64).  The three weight fragments of tile nb + 1 are read while the
-// six MFMAs of tile nb run.
-// An accumulator of a 16 x 16 output tile: one register set for the bf16 split, main + cross for the fp16 one.
-struct DcAcc {
-  f32x4 m, c;
-  __device__ __forceinline__ void zero() { m = c = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  __device__ __forceinline__ f32x4 value() const { return m + c * (1.0f / F16X2_SCALE); }
-};
-template <int NB>
-__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
-  u32x4 wf[2][DC_PL];
-#pragma unroll
-  for (int p = 0; p < DC_PL; ++p) wf[0][p] = pw[p * 64];
-  __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    if (nb + 1 < NB) {
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p) wf[(nb + 1) & 1][p] = pw[((nb + 1) * DC_PL + p) * 64];
-    }
-    mfma_x3h(wf[nb & 1], xb, acc[nb].m, acc[nb].c);
-    if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * DC_PL - (DC_PL == 2 ? 1 : 0), 0);   // MFMA (6 or 3)
-  }
-}
 
 __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const int tileset,
                                               unsigned char* __restrict__ smem) {
@@ -167,7 +114,12 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     ++s_cur;
   };
   dma_slice(0, DC_NP1);
-  float amax = 0.f;   // largest magnitude this lane has split into fp16 pieces
+  // Range flag (ggnn.h, OPERAND RANGE): the operands of the two-piece fp16 split are checked where they are made --
+  // the tile's input rows here in the prologue, the aggregates when a row is closed -- and reported at once: no
+  // state is carried (the kernel has no register to spare).
+  auto report_range = [&](bool bad) __attribute__((always_inline)) {
+    if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
+  };
 
   // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS (read as B fragments by P1 and P4 of every
   // gate: registers are what the sweep is short of, and a reload from memory behind every sweep sat in front of
@@ -180,13 +132,15 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     f32x4 r0 = *reinterpret_cast<const f32x4*>(fr);
     f32x4 r1 = *reinterpret_cast<const f32x4*>(fr + 4);
     if (ks == 3 && kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dc_split(r0, r1, out, amax);
+    dc_split(r0, r1, out);
   };
   {
+    float in_max = 0.f;
     for (int q = lane; q < 16 * 24; q += 64) {   // lane l copies the 16-byte pieces l, l + 64, .. of the 16 x 24 of h
       const int n = q / 24, c4 = (q - n * 24) * 4;
       const f32x4 v = *reinterpret_cast<const f32x4*>(A.h_dst + (int64_t)min(row0 + n, n_dst - 1) * A.ldh + c4);
       *reinterpret_cast<f32x4*>(&xin[n * DC_S + c4]) = v;
+      in_max = fmaxf(fmaxf(in_max, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
     }
     // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
     const int fn = lane >> 2, fq = (lane & 3) * 4;
@@ -198,6 +152,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       v[j] = fq + j < F ? xv : (fq + j == F ? 1.0f : 0.0f);
     }
     *reinterpret_cast<f32x4*>(&xin[fn * DC_S + C + fq]) = v;
+    in_max = fmaxf(fmaxf(in_max, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    report_range(!(in_max < 65504.0f));
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       int* __restrict__ rp = csr + e * (17 + DC_CW);
@@ -374,6 +330,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
           so[CH2 + ch + 2] = r.acc[5] * inv;
           if (lr == 0) so[C] = r.den * inv;
           if (lr == 13) so[C + 1] = r.sae * inv;
+          const float amx = fmaxf(fmaxf(fmaxf(r.acc[0], r.acc[1]), fmaxf(r.acc[2], r.acc[3])), fmaxf(r.acc[4], r.acc[5])) * inv;
+          report_range(!(amx < 65504.0f));   // (aggregates are sums of relu outputs: non-negative)
         };
         auto sweep = [&](auto window_tag) __attribute__((always_inline)) {
 #pragma unroll 1
@@ -403,7 +361,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         u32x4 xb[2][DC_PL];
         auto a_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
           const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
-          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out, amax);
+          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out);
         };
         a_planes(0, xb[0]);
         DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
@@ -501,8 +459,6 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     }
     st_lstm += GGNN_STAMP_NOW() - t_f;
   }
-  // range flag: an operand at or beyond fp16's range was clamped somewhere in this tile
-  if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(!(amax < 65504.0f)) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
   GGNN_STAMP_VAL(4, st_wait);
   GGNN_STAMP_VAL(5, st_p1);
   GGNN_STAMP_VAL(6, st_p2);
@@ -515,7 +471,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 }
 
 // (155 648 B of LDS: one workgroup per compute unit, two waves per SIMD, <= 256 registers)
-__global__ __launch_bounds__(DC_WAVES * 64) void dec_cell_kernel(const DecCellBatch B) {
+__global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCellBatch B) {
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[DC_LDS];
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;

@@ -1,502 +1,351 @@
-// Encoder cell (h = c = 0) with the aggregation sweep and the gate GEMM in ONE kernel: the
-// aggregates never leave the compute unit.  Same arithmetic as ggnn_period_gat_aggregate_enc_batch
-// (aggregate_enc.hip: PeriodConv.message, periodGATconv.py:204-236, + propagate's gather / scatter-add
-// for h = 0) followed by ggnn_lstm_epilogue in GGNN_MODE_LSTM_H0 (gates_x6.hip: lin_l2, the value-side
-// lin_edge term, lin_skip and the cell update of heteropgclstm.py:111-146), but organised around the
-// gate GEMM's weights instead of around an aggregate buffer:
-//   * a PeriodConv of one (edge type, gate) is independent of every other up to the sum HeteroConv
-//     takes over the edge types and the LSTM update over the gates, and its lin_l2 weights as two
-//     fp16 planes (96 x 96 x 4 B = 36 KB; hi and scaled residual, common.h) fit the LDS: a workgroup belongs to one (problem, edge type,
-//     gate), splits those weights into LDS ONCE and never streams a weight again -- no k-step slices,
-//     no workgroup barrier after the prologue, the four waves (one per SIMD) run independently;
-//   * a wave owns whole 16-node tiles: it sweeps the tile's in-edges (4 units per block as in
-//     aggregate_enc.hip: edge records = the 16 rows of an fp32 MFMA A operand, the value weights of
-//     the gate stationary in registers, bias as the accumulator's initial value so that 8 source
-//     features are two k-steps, scores on one more MFMA chain, online-max softmax per row), leaves the
-//     tile's 16 x 98 aggregate block in a wave-private LDS stage, reads it back as MFMA B fragments
-//     (row stride = 8 mod 16 floats and k-groups interleaved by 4: conflict-free ds_read_b128), splits
-//     every fragment once into two fp16 pieces and multiplies it with the resident weights (three
-//     products per k-step, main + cross accumulators: common.h); the two rank-1 columns go through one exact fp32 MFMA; the
-//     16 x 96 block of partial pre-activations is stored;
-//   * the operands of a block (16 edge records, 4 score tails) arrive by LDS-DMA in a per-wave ring
-//     of EC_U slots, requested EC_U blocks ahead of their use ACROSS tile boundaries -- a wave alone on
-//     its SIMD has nobody to hide a memory round trip behind, registers are not held while the loads
-//     fly, and the ring is the only vector-memory traffic of the loop besides the output stores, so
-//     its completion is one counted s_waitcnt vmcnt per pair of blocks; a group of 16 lanes walks
-//     FOUR CONSECUTIVE rows of the tile, cutting them into units of <= 3 edges arithmetically from the
-//     17 rowptr entries of the tile, which arrive by LDS-DMA as well (a header ring, fetched EC_HMAX
-//     tiles ahead): no scalar load and no register-destination load in the loop (a scalar load would
-//     share lgkmcnt with the LDS traffic: every LDS wait would also wait for it);
-//   * a second, element-wise launch sums the partial pre-activations over the incoming edge types,
-//     adds the skip term and applies the LSTM update.
-// What it saves against sweep + gate kernel: the aggregate round trip (69 MB written and read per
-// model at cfg3), the weight stream (every CU streamed all weights of all gates per pass), one
-// barrier per k-step, and the prologue / epilogue of a second full-chip launch.
+// Encoder HeteroPGCLSTM cell (h = c = 0: models.py:422-424, heteropgclstm.py:148-183 without the forget gate) with
+// EVERYTHING of a destination node in ONE kernel and ONE launch (ggnn_encoder_cell_batch, include/ggnn.h): the
+// score tails u4, the periodic-boundary GAT sweep of every incoming edge type (PeriodConv.message,
+// periodGATconv.py:204-236), lin_l2 + the value-side lin_edge term, HeteroConv's sum over the edge types, the
+// summed skip term and the LSTM update.  Round 4: replaces the round-2 pair enc_cell_kernel + enc_lstm_kernel
+// (a workgroup per (edge type, gate), 57.6 MB of partial pre-activations per model written by one launch and
+// summed by the next) and the slim encoder projection (u4 tails through memory).
+//
+// With h = 0 a PeriodConv of the encoder sees nothing but 16-float rows: the destination's features and, per
+// in-edge, the record ggnn_edge_prepare made of the source's features (reloc, x_j[3:F], 1, edge length).  So the
+// whole cell is matrix-core work on operands a lane already holds -- the layouts are those of the round-4 decoder
+// experiment (profiles/r4_dec_cell_ablations.txt), which lost to its gathers; the encoder has none:
+//   * a wave owns a 16-node tile; lane (node lr = l & 15, k-group kq = l >> 4) keeps four of the 16 slots of its
+//     node's feature row, and of the record of its node's t-th in-edge (t = 0..2: one "unit"), as the two fp16 planes
+//     of a B fragment (k slot 8 kq + j = row slot 4 kq + j, j < 4) -- loaded and split ONCE per tile, reused by all
+//     three gates;
+//   * per (edge type e, gate g) ONE weight slice holds [value rows 0..95 | u4 rows 96..111] x 16 slots: the u4 column
+//     tile against the tile's feature planes gives u4[node] in lane (node, kq) = the A fragment of the score MFMA
+//     against the edge planes -> D[node][edge], the wanted entries on the diagonal (ds_bpermute); the six value
+//     column tiles against the SAME edge planes give relu's argument W_value x~_e + b_value in lane (edge = node lr,
+//     channels 16 nb + 4 kq ..+3); softmax (online over units for rows of more than three in-edges), relu,
+//     alpha-weighted sum and normalisation stay in that layout, which -- lin_l2's columns permuted on the host -- is
+//     the B fragment of the three lin_l2 k-steps that follow; the pre-activations of a gate accumulate over the
+//     edge types in registers, the skip term is one more k-step against the feature planes, the LSTM update is
+//     folded in gate by gate (i, c~, o);
+//   * weights: 3 (4 n_in + 1) slices of pre-split fp16 planes per destination type in dec_cell.hip's slice image,
+//     streamed by LDS-DMA in GROUPS: the 4 slices of a (e, g) pass (5 with the gate's skip slice behind its last edge
+//     type) are requested together, one whole pass ahead, into one of two 70 KB buffers shared by the workgroup's
+//     waves -- one barrier per pass (9 per joint tile, where a barrier per slice would be 27) and ~4 us for a group
+//     to land.  The kernel's only other LDS traffic is ds_bpermute.
+// Arithmetic: two fp16 pieces / three products per fp32 operand (common.h), the rank-1 columns (b_l2, w_edge) on one
+// exact fp32 MFMA; explicit fmas with contraction off wherever a row could be computed twice (ragged last tile).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
+#include "cell_common.h"
 #define GGNN_STAMP_SUFFIX _enc
 #include "stamps.h"
 
 namespace ggnn {
 
-#ifndef EC_CFG_WAVES       // (development: make VARIANT=.. EXTRA="-DEC_CFG_WAVES=.. -DEC_CFG_U=.. -DEC_CFG_HMAX=.. -DEC_CFG_MINW=..")
-#define EC_CFG_WAVES 8
-#define EC_CFG_U 4
-#define EC_CFG_HMAX 6
-#define EC_CFG_MINW 2
+#ifndef EC_WAVES_
+#define EC_WAVES_ 8
 #endif
-constexpr int EC_WAVES = EC_CFG_WAVES;       // two per SIMD: a wave alone issues one instruction per >= 4 cycles
+constexpr int EC_WAVES = EC_WAVES_;                 // 16-node tiles per workgroup
 constexpr int EC_MAX_PROBLEMS = 4;
-constexpr int EC_MAX_COMBOS = EC_MAX_PROBLEMS * 2 * 3;  // (problem, incoming edge type, gate)
-constexpr int EC_G = 3;                      // i, c, o
-constexpr int EC_S = 104;                    // stage row stride in floats: 8 mod 16
-constexpr int EC_U = EC_CFG_U;               // ring slots per wave = blocks in flight
-constexpr int EC_SLOT = 1024 + 256 + 32;     // 16 records x 64 B | 4 tails x 64 B | control words
-constexpr int EC_PL = 2;                     // fp16 pieces per operand (common.h: split_f16x2 / mfma_x3h)
-constexpr int EC_PLANES = EC_PL * 18 * 1024; // 36 864 B
-constexpr int EC_HMAX = EC_CFG_HMAX, EC_HR = EC_HMAX + 1 + (EC_HMAX & 1);  // tiles fetched ahead of the front cursor, header ring slots
-constexpr int EC_HSLOT = 80;                 // 17 rowptr entries
-constexpr int EC_WAVE_LDS = 16 * EC_S * 4 + EC_U * EC_SLOT + EC_HR * EC_HSLOT;  // 6 656 + 5 248 + 640
-constexpr int EC_LDS_BYTES = EC_PLANES + EC_WAVES * EC_WAVE_LDS;  // 137 216
-static_assert(EC_LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(2 * (EC_U - 2) < 64 && 2 * EC_HMAX > 2 * (EC_U - 2) + 4, "vmcnt is a 6-bit counter; headers land in time");
-static_assert(EC_HMAX >= EC_U && EC_HMAX < EC_HR, "a header must be requested a ring length ahead of its use");
+constexpr int EC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
+constexpr int EC_NPA = 7 * DC_PL, EC_NP3 = 6 * DC_PL;   // pieces of a value | u4 slice / of a lin_l2 or skip slice
+constexpr int EC_GROUP = 5;                         // slices of a group: value | u4, 3 x lin_l2, (skip)
+constexpr int EC_LDS = 2 * EC_GROUP * EC_SLICE;     // 143 360 B
+static_assert(EC_LDS <= 160 * 1024, "LDS");
+constexpr int EU = GGNN_UNIT_EDGES;                 // edge tiles (t-th in-edge of every node) handled together
 
 struct EncCellBatch {
   ggnn_enc_cell_args a[EC_MAX_PROBLEMS];
-  int wg_off[EC_MAX_COMBOS + 1];  // first workgroup of every combination
-  int combo[EC_MAX_COMBOS];       // problem | edge type << 2 | gate << 3
-  int n;                          // combinations
+  int wg_off[EC_MAX_PROBLEMS + 1];
+  int n;
 };
 
-typedef int ec_i32x4 __attribute__((ext_vector_type(4)));
-typedef int ec_i32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float ec_bperm(int byte_addr, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ float ec_relu(float x) {  // one v_max_f32
-  float y;
-  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
-}
-__device__ __forceinline__ int ec_group_max(int v) {  // max over the four 16-lane groups of a group-uniform value
-  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ float ec_quad_lane3(float v) {  // value of the quad's 4th lane in all four
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
-}
-// LDS-DMA: every lane copies 16 / 4 bytes from its own global address to lds_base + lane * 16 / 4
-// (wave-uniform base in M0, written and restored inside the statement).  Not tracked by the compiler:
-// completion is awaited with ec_dma_wait<N>() (LDS-DMA completes in issue order).
-__device__ __forceinline__ void ec_dma16(const void* gsrc, uint32_t lds_base) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
-               : "memory");
-}
-__device__ __forceinline__ void ec_dma4(const void* gsrc, uint32_t lds_base) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base))
-               : "memory");
-}
-template <int N> __device__ __forceinline__ void ec_dma_wait() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const int d, const int g, const int wg,
-                                              const int nwg, unsigned char* __restrict__ smem) {
-  const ggnn_enc_cell_sweep& Sw = A.in[d];
+__device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const int tileset,
+                                              unsigned char* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
-  const int qa = c >> 2, ra = c & 3;       // sweep: A row / score column c belongs to unit qa, edge ra
-  const int src_sm = (20 * q) * 4;         // lane 16 q + 4 q: the softmax lane of group q (ds_bpermute)
-  u32x4* __restrict__ wpl = reinterpret_cast<u32x4*>(smem);  // [3][6][2][64]: lin_l2 of (edge type, gate) as two fp16 planes
-  unsigned char* __restrict__ wbase = smem + EC_PLANES + wave * EC_WAVE_LDS;
-  float* __restrict__ stage = reinterpret_cast<float*>(wbase);   // wave-private [16][EC_S]
-  unsigned char* __restrict__ ring = wbase + 16 * EC_S * 4;                       // wave-private [EC_U][EC_SLOT]
-  const unsigned char* __restrict__ hdr = ring + EC_U * EC_SLOT;                   // wave-private [EC_HR][EC_HSLOT]
-  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring)));
-  const uint32_t hdr_lds = ring_lds + EC_U * EC_SLOT;
-  const int n_dst = (int)A.n_dst;
-  const int nks_all = 3 * A.n_in;          // k-steps of the whole gate weight (96 columns per incoming edge type)
-  const int kmt = 96 * A.n_in;
+  const int lr = lane & 15, kq = lane >> 4;   // node lr of the tile; k-group of a fragment = output rows 4 kq .. of a D tile
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---- this wave's tiles: t_lo + wave, + EC_WAVES, ... < t_hi ----
-  const int n_t = (n_dst + 15) >> 4;
-  const int t_lo = (int)((int64_t)wg * n_t / nwg), t_hi = (int)((int64_t)(wg + 1) * n_t / nwg);
-  const int row_last = max(n_dst - 16, 0);  // a ragged last tile slides back (identical duplicate results)
-  const int e_last = (int)Sw.E + GGNN_UNIT_EDGES - 1;
-  const bool nk3 = Sw.f_src > 8;
-  const int32_t* __restrict__ rowptr = Sw.rowptr;
-  const float* __restrict__ einfo = Sw.einfo;
-  const float* __restrict__ tails = A.p_dst + Sw.u4_off + 16 * g;
-  const int ldp32 = (int)A.ldp;            // n_dst * ldp < 2^31 (checked by the host)
-  float* __restrict__ pre = A.pre + (int64_t)d * n_dst * (EC_G * C) + g * C;
-  const int src_grp = (16 * qa) * 4;       // byte address of a lane of group qa (ds_bpermute)
+  const int n_dst = (int)A.n_dst, n_in = A.n_in, F = A.f_dst;
+  // a ragged last tile slides back over rows the previous tile also produces (identical duplicate results);
+  // tiles past the end (a workgroup's surplus waves) repeat the last one: every wave runs the whole program,
+  // so the workgroup barriers of the weight stream need no special case
+  const int row0 = max(0, min((tileset * EC_WAVES + wave) * 16, n_dst - 16));
+  const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node (n_dst < 16: the last node repeats)
 
-  // ---- tile headers: rowptr[row0 .. row0 + 16] of the wave's idx-th tile -> header ring (one DMA) ----
-  auto hdr_issue = [&](int idx) {
-    const int tile = t_lo + wave + EC_WAVES * idx;
-    const int row0 = tile < t_hi ? min(tile * 16, row_last) : 0;
-    if (lane < 17) ec_dma4(rowptr + min(row0 + lane, n_dst), hdr_lds + (idx % EC_HR) * EC_HSLOT);
-  };
-  int h_idx = 0;                 // next tile whose header has not been requested yet
-  for (; h_idx < EC_HMAX; ++h_idx) hdr_issue(h_idx);  // in flight while the weights are staged
+  // ---- the weight stream: group q = (gate g, edge type e) -> buffer q & 1, requested one group ahead ----
+  const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(A.wstream) + lane * 16;
+  const uint32_t slice_lds =
+      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
+  const int per_gate = 4 * n_in + 1, n_groups = 3 * n_in;
+  int q_cur = 0;
+  [[maybe_unused]] unsigned long long st_wait = 0, st_a = 0, st_p3 = 0, st_p4 = 0, st_lstm = 0;
   GGNN_STAMP(0);
-  // ---- prologue: lin_l2 of this (edge type, gate) -> two fp16 planes in LDS (once per workgroup) ----
-  {
-    const f32x4* __restrict__ wf =
-        reinterpret_cast<const f32x4*>(A.w2_frag) + (size_t)((g * nks_all + 3 * d) * 6) * 2 * 64;
-    for (int f = wave; f < 18; f += EC_WAVES) {
-      const f32x4 h0 = wf[(f * 2) * 64 + lane], h1 = wf[(f * 2 + 1) * 64 + lane];
-      u32x4 pl[EC_PL];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 h = e < 2 ? h0 : h1;
-        uint32_t q0, q1;
-        split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
-        pl[0][e] = q0;
-        pl[1][e] = q1;
-      }
-#pragma unroll
-      for (int p = 0; p < EC_PL; ++p) wpl[(f * EC_PL + p) * 64 + lane] = pl[p];
+  auto dma_group = [&](int q) {
+    if (q >= n_groups) return;
+    const int g = q / n_in, e = q - g * n_in;
+    const int s0 = g * per_gate + 4 * e;                  // first slice of the group in the stream
+    const int ns = 4 + (e == n_in - 1 ? 1 : 0);           // ... and their number (the gate's skip slice rides with its last pass)
+    const int np = EC_NPA + (ns - 1) * EC_NP3;
+    const unsigned char* src = wsrc + (size_t)s0 * EC_SLICE;
+    const uint32_t dst = slice_lds + (q & 1) * (EC_GROUP * EC_SLICE);
+    for (int p = wave; p < np; p += EC_WAVES) {
+      // piece p of the group: the 14 pieces of its first slice, then 12 per slice (the last 2 KB of those are unused)
+      const int sl = p < EC_NPA ? 0 : 1 + (p - EC_NPA) / EC_NP3;
+      const int off = sl * EC_SLICE + (p < EC_NPA ? p : (p - EC_NPA) % EC_NP3) * 1024;
+      dc_dma16(src + off, dst + off);
     }
-    // the stage starts as zeros (rows of a tile that do not exist are never written)
-    for (int i = lane; i < 16 * EC_S / 4; i += 64) reinterpret_cast<f32x4*>(stage)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto begin_group = [&]() -> const u32x4* {   // the group about to be used landed at the previous end_group
+    dma_group(q_cur + 1);
+    return reinterpret_cast<const u32x4*>(smem + (q_cur & 1) * (EC_GROUP * EC_SLICE)) + lane;
+  };
+  auto end_group = [&]() {
+    [[maybe_unused]] const unsigned long long w0 = GGNN_STAMP_NOW();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next group are in LDS
+    __syncthreads();                                   // ... everybody's are, and nobody reads the old one any more
+    st_wait += GGNN_STAMP_NOW() - w0;
+    ++q_cur;
+  };
+  dma_group(0);
+
+  float amax = 0.f;   // largest magnitude this lane has split into fp16 pieces (range flag)
+
+  // ---- tile prologue: this node's feature slots and the records of its first in-edges, as B-fragment planes ----
+  // slots of a feature row: x_0 .. x_{F-1}, 0 .., 1 at 12 (bias), 0 ..; of an edge record: ggnn_edge_prepare's
+  // (reloc, x_j[3:F_src), 0 .., 1 at 12, edge length at 13, ..): lane (., kq) holds slots 4 kq ..+3 in k slots 8 kq ..+3
+  u32x4 xs[DC_PL];
+  {
+    const float* xrow = A.x_dst + (int64_t)node_m * A.ldx;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sl = 4 * kq + j;
+      const float xv = xrow[min(sl, F - 1)];   // unconditional (clamped) load
+      v[j] = sl < F ? xv : (sl == 12 ? 1.0f : 0.0f);
+    }
+    dc_split_half(v, xs, amax);
   }
-  // value weights of this gate (B fragments, 16x16x4: k = 4 s + q, column c of tile t) and bias, stationary
-  float bw[6][3], bb[6];
+  // First units of both incoming edge types (or, with ONE incoming edge type, its first two units): a joint's three
+  // in-edges per edge type and a grain's first six never touch memory again.
+  int p_first[2], p_end[2];
+  uint32_t xr[2][EU][DC_PL][2];   // [set][edge tile][plane][packed pair]: the two non-zero dwords of a fragment
+  float ael[2][EU];               // record slot 4 kq + 1: the edge length in k-group 3
+  auto load_unit = [&](const ggnn_enc_cell_sweep& Sw, int p_, uint32_t (&r)[EU][DC_PL][2], float (&al)[EU]) __attribute__((always_inline)) {
+    const int e_last = max((int)Sw.E - 1, 0);
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    const float* __restrict__ w = Sw.wv_frag + (size_t)((g * 6 + t) * 4) * 64 + lane;
+    for (int t = 0; t < EU; ++t) {
+      const f32x4 rec = ld16f(Sw.einfo + (uint32_t)min(p_ + t, e_last) * GGNN_EINFO_ROW + 4 * kq);
+      u32x4 pl[DC_PL];
+      dc_split_half(rec, pl, amax);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bw[t][s] = w[s * 64];
-    bb[t] = w[3 * 64];
+      for (int q = 0; q < DC_PL; ++q) {
+        r[t][q][0] = pl[q][0];
+        r[t][q][1] = pl[q][1];
+      }
+      al[t] = rec[1];
+    }
+  };
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const ggnn_enc_cell_sweep& Sw = A.in[e < n_in ? e : 0];
+    p_first[e] = Sw.rowptr[node_m];
+    p_end[e] = Sw.rowptr[node_m + 1];
+    load_unit(Sw, p_first[e] + (e < n_in ? 0 : EU), xr[e], ael[e]);
   }
-  // weight side of the exact fp32 tail (b_l2 and w_edge of this edge type), 16x16x4 A fragments, k = q < 2
-  float wt[6];
-#pragma unroll
-  for (int ct = 0; ct < 6; ++ct)
-    wt[ct] = q < 2 ? A.w2[(size_t)(g * C + ct * 16 + c) * A.Ka + kmt + 2 * d + q] : 0.f;
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // group 0 is in LDS
   GGNN_STAMP(1);
 
-  // ---- front cursor: EC_U blocks ahead of the compute.  Group q walks rows row0 + 4 q .. + 3 of the tile,
-  // row k in units of <= 3 edges (rows without edges: one empty unit, so that zeros are stored) ----
-  int f_idx = 0, f_b = 0, f_nblk = 0, f_row0 = 0;
-  bool f_ok = false;
-  const int* hp = reinterpret_cast<const int*>(hdr) + 4 * q;  // rowptr of the group's rows in the cursor's header slot
-  int f_k = 0, f_j = 0;          // row / unit inside the row at the cursor (group-uniform)
-  auto units_of = [](int deg) { return max(1, (deg + GGNN_UNIT_EDGES - 1) / GGNN_UNIT_EDGES); };
-  auto enter_tile = [&]() {      // header of tile f_idx -> cursor state (the header landed a ring length ago)
-    const int tile = t_lo + wave + EC_WAVES * f_idx;
-    f_ok = tile < t_hi;
-    f_row0 = min(tile * 16, row_last);
-    hp = reinterpret_cast<const int*>(hdr + (f_idx % EC_HR) * EC_HSLOT) + 4 * q;
-    int tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) tot += units_of(hp[k + 1] - hp[k]);
-    f_nblk = ec_group_max(tot);
-    f_b = 0;
-    f_k = f_j = 0;
-  };
-  // fills ring slot `slot` with the block at the cursor (two LDS-DMAs + the control words), requests one
-  // more header, then advances the cursor
-  auto issue = [&](int slot) {
-    const bool alive = f_ok && f_k < 4;
-    const int rpk = hp[f_k], rpk1 = hp[f_k + 1];   // (f_k == 4, a finished group: inside the slot, unused)
-    const int nuk = units_of(rpk1 - rpk);
-    const int p0 = alive ? rpk + GGNN_UNIT_EDGES * f_j : 0;
-    const int nact = min(max(rpk1 - p0, 0), GGNN_UNIT_EDGES);
-    const int rowl = 4 * q + f_k;
-    // row inside the tile | nact << 4 | first << 6 | last << 7
-    const int word = alive ? (rowl | (nact << 4) | ((f_j == 0) << 6) | ((f_j + 1 == nuk) << 7)) : 0;
-    const int i_q = alive ? min(f_row0 + rowl, n_dst - 1) : 0;
-    const int meta = f_ok ? (f_row0 | ((f_b + 1 == f_nblk) << 28) | (1 << 30)) : 0;
-    const uint32_t base = ring_lds + slot * EC_SLOT;
-    const int p0_a = __builtin_amdgcn_ds_bpermute(src_grp, p0);
-    // record of edge ra of unit qa (slot 3 is padding: whatever record follows, clamped to the buffer), piece q
-    ec_dma16(einfo + (uint32_t)min(p0_a + ra, e_last) * GGNN_EINFO_ROW + 4 * q, base);
-    // score tail of unit q's row, element c
-    ec_dma4(tails + (uint32_t)(i_q * ldp32 + c), base + 1024);
-    int* __restrict__ cw = reinterpret_cast<int*>(ring + slot * EC_SLOT + 1280);
-    if (c == 0) cw[q] = word;
-    if (lane == 0) cw[4] = meta;
-    // headers are requested as the cursor moves on (one per tile in the steady state): the loop's counted
-    // wait assumes none in its window, so a recent one only makes it wait for one DMA more than needed
-    if (h_idx - f_idx < EC_HMAX) hdr_issue(h_idx++);
-    // advance
-    const bool row_done = alive && f_j + 1 == nuk;
-    f_j = row_done ? 0 : f_j + (alive ? 1 : 0);
-    f_k += row_done ? 1 : 0;
-    if (f_ok && ++f_b == f_nblk) {
-      ++f_idx;
-      enter_tile();
-    }
-  };
+  // the diagonal of a score tile D[node][edge]: node lr's entry sits in lane (lr, kq = lr >> 2), register lr & 3
+  const int diag_addr = 4 * (16 * (lr >> 2) + lr), diag_sub = lr & 3;
 
-  // ---- the GEMM of a finished tile: stage -> B fragments -> two fp16 pieces, three products against the resident
-  // planes (main + cross accumulators: common.h; until round 3's last version three bf16 pieces and six products) ----
-  auto gemm = [&](int row0) {
-    f32x4 acc[6], accx[6];
+  f32x4 run[6];   // the LSTM update as the gates arrive: sig(i) -> sig(i) tanh(c~) = c' -> (h')
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[ct] = accx[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ srow = stage + c * EC_S + 4 * q;  // node c of the tile, k-group q
+  for (int ct = 0; ct < 6; ++ct) run[ct] = zero4;
+#pragma unroll 1
+  for (int g = 0; g < 3; ++g) {   // gates i, c~, o (the encoder's weights are indexed in that order)
+    f32x4 pre[6];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      const f32x4 r0 = *reinterpret_cast<const f32x4*>(srow + 32 * ks);
-      const f32x4 r1 = *reinterpret_cast<const f32x4*>(srow + 32 * ks + 16);
-      u32x4 xb[EC_PL];
+    for (int ct = 0; ct < 6; ++ct) pre[ct] = zero4;
+
+#pragma unroll 1
+    for (int e = 0; e < n_in; ++e) {
+      const ggnn_enc_cell_sweep& Sw = A.in[e];
+      [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
+      const int pe = e == 0 ? p_end[0] : p_end[1];
+      int p = e == 0 ? p_first[0] : p_first[1];
+      float wtail[6];   // the (b_l2, w_edge) tail of lin_l2: requested here, used behind the three lin_l2 k-steps
+      {
+        const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 h = e < 2 ? r0 : r1;
-        uint32_t q0, q1;
-        split_f16x2(h[2 * (e & 1)], h[2 * (e & 1) + 1], q0, q1);
-        xb[0][e] = q0;
-        xb[1][e] = q1;
+        for (int ct = 0; ct < 6; ++ct) wtail[ct] = wt[ct * 64];
       }
-      const u32x4* __restrict__ pw = wpl + (ks * 6 * EC_PL) * 64 + lane;
-      // the weight fragments of column tile ct + 1 are read while the three MFMAs of ct run
-      u32x4 wf[2][EC_PL];
+      const u32x4* pw = begin_group();
+
+      // ================= slice A: u4 of the tile, scores, softmax, values of (e, g) =================
+      float mx = -INFINITY, den = 0.f, sae = 0.f;
+      f32x4 acc[6];
 #pragma unroll
-      for (int p = 0; p < EC_PL; ++p) wf[0][p] = pw[p * 64];
-      __builtin_amdgcn_sched_group_barrier(0x100, EC_PL, 0);  // DS reads of ct = 0, then [reads ct + 1 | MFMAs ct] ...
+      for (int nb = 0; nb < 6; ++nb) acc[nb] = zero4;
+      {
+        u32x4 ua[DC_PL];   // u4[node][4 kq ..+3] as an A fragment (1 / sqrt(96) is folded into the weights)
+        {
+          u32x4 wf[DC_PL];
+#pragma unroll
+          for (int q = 0; q < DC_PL; ++q) wf[q] = pw[(6 * DC_PL + q) * 64];
+          DcAcc U;
+          U.zero();
+          mfma_x3h(wf, xs, U.m, U.c);
+          dc_split_half(U.value(), ua, amax);
+        }
+        // one unit = the t-th in-edges (t = 0..2 from p) of the tile's 16 nodes, records as planes `r`
+        auto unit = [&](const uint32_t (&r)[EU][DC_PL][2], const float (&al)[EU], const int nact, auto first_tag) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+          constexpr bool FIRST = decltype(first_tag)::value;
+          u32x4 xb[EU][DC_PL];
+          float s[EU];
+#pragma unroll
+          for (int t = 0; t < EU; ++t) {
+#pragma unroll
+            for (int q = 0; q < DC_PL; ++q) xb[t][q] = (u32x4){r[t][q][0], r[t][q][1], 0u, 0u};
+            DcAcc S;
+            S.zero();
+            mfma_x3h(ua, xb[t], S.m, S.c);
+            const f32x4 sv = S.value();
+            const float sel = diag_sub == 0 ? sv[0] : (diag_sub == 1 ? sv[1] : (diag_sub == 2 ? sv[2] : sv[3]));
+            s[t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(diag_addr, __builtin_bit_cast(int, sel)));
+          }
+          // online-max softmax over the units of a row (PyG's softmax: exp(s - max) / (sum + 1e-16))
+          float mnew = mx;
+#pragma unroll
+          for (int t = 0; t < EU; ++t) mnew = t < nact ? fmaxf(mnew, s[t]) : mnew;
+          if constexpr (!FIRST) {
+            const float scale = nact > 0 ? __expf(mx - mnew) : 1.0f;
+            den = den * scale;
+            sae = sae * scale;
+#pragma unroll
+            for (int nb = 0; nb < 6; ++nb) acc[nb] = acc[nb] * scale;
+          }
+          float pw_[EU];
+#pragma unroll
+          for (int t = 0; t < EU; ++t) {
+            pw_[t] = t < nact ? __expf(s[t] - mnew) : 0.f;
+            den = den + pw_[t];
+            sae = __builtin_fmaf(pw_[t], al[t], sae);   // k-group 3 holds the edge length: sum alpha a_e there
+          }
+          mx = mnew;
+          // values: relu(W_value x~_e + b_value) in lane (edge = node lr, channels 16 nb + 4 kq ..+3)
+#pragma unroll
+          for (int nb = 0; nb < 6; ++nb) {
+            u32x4 wf[DC_PL];
+#pragma unroll
+            for (int q = 0; q < DC_PL; ++q) wf[q] = pw[(nb * DC_PL + q) * 64];
+#pragma unroll
+            for (int t = 0; t < EU; ++t) {
+              DcAcc Vv;
+              Vv.zero();
+              mfma_x3h(wf, xb[t], Vv.m, Vv.c);
+              const f32x4 val = Vv.value();
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[nb][i] = __builtin_fmaf(pw_[t], fmaxf(val[i], 0.f), acc[nb][i]);
+            }
+          }
+        };
+        if (e == 0) unit(xr[0], ael[0], min(max(pe - p, 0), EU), std::true_type{});
+        else unit(xr[1], ael[1], min(max(pe - p, 0), EU), std::true_type{});
+        p += EU;
+        // rows of more than three in-edges (grains; hubs): further units.  With one incoming edge type the second
+        // unit's records are in the registers the second edge type does not need.
+        bool second = n_in == 1;
+        while (__builtin_amdgcn_ballot_w64(p < pe) != 0) {
+          if (second) {
+            unit(xr[1], ael[1], min(max(pe - p, 0), EU), std::false_type{});
+          } else {
+            uint32_t r2[EU][DC_PL][2];
+            float al2[EU];
+            load_unit(Sw, p, r2, al2);
+            unit(r2, al2, min(max(pe - p, 0), EU), std::false_type{});
+          }
+          second = false;
+          p += EU;
+        }
+      }
+      [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
+
+      // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
+      {
+        u32x4 ab[3][DC_PL];
+        float xt;
+        {
+#pragma clang fp contract(off)
+          const float inv = 1.0f / (den + 1e-16f);   // PyG softmax denominator
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) dc_split(acc[2 * ks] * inv, acc[2 * ks + 1] * inv, ab[ks], amax);
+          xt = kq == 0 ? den * inv : (kq == 3 ? sae * inv : 0.f);
+        }
+        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) dc_kstep<6>(pw + (1 + ks) * (EC_SLICE / 16), ab[ks], part);
+        // ... and, behind the gate's last edge type, P4: the summed skip term + gate bias (16 feature slots: one k-step)
+        if (e == n_in - 1) dc_kstep<6>(pw + 4 * (EC_SLICE / 16), xs, part);
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[ct], xt, pre[ct], 0, 0, 0);
+      }
+      end_group();
+      st_a += t_b - t_a;
+      st_p3 += GGNN_STAMP_NOW() - t_b;
+    }
+    [[maybe_unused]] const unsigned long long t_f = GGNN_STAMP_NOW();
+
+    // ================= LSTM update with c = 0 (heteropgclstm.py:140-146), folded in gate by gate =================
+    if (g == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) run[ct][r] = sigmoidf_(pre[ct][r]);
+    } else if (g == 1) {
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) run[ct][r] *= tanhf_(pre[ct][r]);
+      float* crow = A.c_out + (int64_t)node_m * C + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) *reinterpret_cast<f32x4*>(crow + 16 * ct) = run[ct];
+    } else {
+      float* hrow = A.h_out + (int64_t)node_m * C + 4 * kq;
 #pragma unroll
       for (int ct = 0; ct < 6; ++ct) {
-        if (ct + 1 < 6) {
+        f32x4 h;
 #pragma unroll
-          for (int p = 0; p < EC_PL; ++p) wf[(ct + 1) & 1][p] = pw[((ct + 1) * EC_PL + p) * 64];
-        }
-        mfma_x3h(wf[ct & 1], xb, acc[ct], accx[ct]);
-        if (ct + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, EC_PL, 0);  // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                      // MFMA
+        for (int r = 0; r < 4; ++r) h[r] = sigmoidf_(pre[ct][r]) * tanhf_(run[ct][r]);
+        *reinterpret_cast<f32x4*>(hrow + 16 * ct) = h;
       }
     }
-#pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[ct] += accx[ct] * (1.0f / F16X2_SCALE);
-    const float xt = q < 2 ? stage[c * EC_S + 96 + q] : 0.f;
-    const bool ok = row0 + c < n_dst;
-    float* __restrict__ o = pre + (int64_t)(row0 + (ok ? c : 0)) * (EC_G * C) + 4 * q;
-#pragma unroll
-    for (int ct = 0; ct < 6; ++ct) {
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ct], xt, acc[ct], 0, 0, 0);
-      if (ok) *reinterpret_cast<f32x4*>(o + 16 * ct) = acc[ct];
-    }
-  };
-
-  // ---- start-up: the first EC_HMAX headers have landed by now; then the ring (blocks 0 .. EC_U - 1) ----
-  ec_dma_wait<0>();
-  GGNN_STAMP(2);
-  enter_tile();
-  for (int r = 0; r < EC_U; ++r) issue(r);
-  GGNN_STAMP(3);
-  [[maybe_unused]] unsigned long long st_wait = 0, st_comp = 0, st_issue = 0, st_gemm = 0, st_n = 0, st_t = 0;
-
-  float mx = -INFINITY, den = 0.f, sae = 0.f;  // softmax state of the row group q is folding (mx: lane 4 q)
-  float acc[6];
-#pragma unroll
-  for (int t = 0; t < 6; ++t) acc[t] = 0.f;
-
-  // Two blocks per iteration: their MFMA chains are independent (a wave is bound by the latency of its own
-  // chain -- LDS round trips, dependent MFMAs --, not by the SIMD), only the softmax fold is sequential.
-  static_assert(EC_U % 2 == 0, "two blocks per iteration");
-  for (int slot = 0;; slot = slot + 2 == EC_U ? 0 : slot + 2) {
-    [[maybe_unused]] const unsigned long long st0 = GGNN_STAMP_NOW();
-    // everything but the two DMAs of each of the EC_U - 2 blocks issued after these two (a header DMA issued
-    // EC_HMAX tiles ahead of its use has >= 2 EC_HMAX younger DMAs by then: complete as well)
-    ec_dma_wait<2 * (EC_U - 2)>();
-    [[maybe_unused]] const unsigned long long st1 = GGNN_STAMP_NOW();
-    const unsigned char* __restrict__ sl = ring + slot * EC_SLOT;
-    int my[2], meta[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int* __restrict__ cwp = reinterpret_cast<const int*>(sl + j * EC_SLOT + 1280);
-      my[j] = cwp[q];
-      meta[j] = __builtin_amdgcn_readfirstlane(cwp[4]);
-    }
-    if (!((meta[0] >> 30) & 1)) break;
-    // (a block past the end -- only the second of a pair can be one -- has real operands, no edges and
-    // neither first nor last: it changes nothing)
-    f32x4 sc[2], v[2][6];
-    float ae[2][3];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float* __restrict__ sa = reinterpret_cast<const float*>(sl + j * EC_SLOT) + 4 * c + q;
-      const float* __restrict__ sb = reinterpret_cast<const float*>(sl + j * EC_SLOT + 1024) + 16 * qa + q;
-      float a[4], bs[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = sa[64 * s];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bs[s] = sb[4 * s];  // (score columns other than 4 u: never read)
-      // a_e = x4[13] of the three edges of unit q: piece 3 of records 4 q + r (group-uniform reads)
-#pragma unroll
-      for (int r = 0; r < 3; ++r) ae[j][r] = reinterpret_cast<const float*>(sl + j * EC_SLOT)[4 * (48 + 4 * q + r) + 1];
-      // scores: D[edge 4 q + r][column c]; lane c = 4 q holds unit q's scores
-      sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) sc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bs[s], sc[j], 0, 0, 0);
-      // values: per column tile D[edge 4 q + r][column c] = W x~ + b
-#pragma unroll
-      for (int t = 0; t < 6; ++t) v[j][t] = (f32x4){bb[t], bb[t], bb[t], bb[t]};
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int t = 0; t < 6; ++t) v[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[t][s], v[j][t], 0, 0, 0);
-      if (nk3) {
-#pragma unroll
-        for (int t = 0; t < 6; ++t) v[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bw[t][2], v[j][t], 0, 0, 0);
-      }
-    }
-    [[maybe_unused]] const unsigned long long st2 = GGNN_STAMP_NOW();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row0 = meta[j] & 0x7FFFFF;
-      const int rowl = my[j] & 15, nact = (my[j] >> 4) & 3;
-      const bool first = (my[j] >> 6) & 1, last = (my[j] >> 7) & 1;
-      if (first) {
-        mx = -INFINITY;
-        den = sae = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) acc[t] = 0.f;
-      }
-      const float s0 = nact > 0 ? sc[j][0] : -INFINITY, s1 = nact > 1 ? sc[j][1] : -INFINITY,
-                  s2 = nact > 2 ? sc[j][2] : -INFINITY;
-      const float mnew = fmaxf(fmaxf(mx, s0), fmaxf(s1, s2));
-      const bool any = nact > 0;  // (an empty row has one unit with nact == 0: zeros are stored)
-      const float scale_l = any ? __expf(mx - mnew) : 1.0f;  // exp(-inf) = 0 on a row's first unit
-      const float p0_l = any ? __expf(s0 - mnew) : 0.f, p1_l = any ? __expf(s1 - mnew) : 0.f,
-                  p2_l = any ? __expf(s2 - mnew) : 0.f;
-      if (any) mx = mnew;
-      const float scale = ec_bperm(src_sm, scale_l), p0 = ec_bperm(src_sm, p0_l), p1 = ec_bperm(src_sm, p1_l),
-                  p2 = ec_bperm(src_sm, p2_l);
-      const float e0 = ae[j][0], e1 = ae[j][1], e2 = ae[j][2];
-      den = den * scale + (p0 + p1 + p2);
-      sae = sae * scale + (p0 * e0 + p1 * e1 + p2 * e2);
-      // relu, alpha-weighted sum
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-        acc[t] = acc[t] * scale + (p0 * ec_relu(v[j][t][0]) + p1 * ec_relu(v[j][t][1]) + p2 * ec_relu(v[j][t][2]));
-      if (last) {  // the row's 96 aggregate channels -> stage (8 bytes per lane: 128 per group)
-        const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // PyG softmax denominator (v_rcp_f32: 1 ulp)
-        float* __restrict__ srow = stage + rowl * EC_S;
-#pragma unroll
-        for (int m = 0; m < 6; m += 2) {
-          const f32x2_ w2 = {acc[m] * inv, acc[m + 1] * inv};
-          *reinterpret_cast<f32x2_*>(srow + 2 * c + 16 * m) = w2;
-        }
-        if (c == 0) {
-          const f32x2_ t2 = {den * inv, sae * inv};
-          *reinterpret_cast<f32x2_*>(srow + 96) = t2;
-        }
-      }
-      if ((meta[j] >> 28) & 1) {
-        [[maybe_unused]] const unsigned long long sg0 = GGNN_STAMP_NOW();
-        gemm(row0);
-        st_gemm += GGNN_STAMP_NOW() - sg0;
-        ++st_t;
-      }
-    }
-    // ---- the two slots are free: blocks n + EC_U, n + EC_U + 1 take them over ----
-    [[maybe_unused]] const unsigned long long st3 = GGNN_STAMP_NOW();
-    issue(slot);
-    issue(slot + 1);
-    [[maybe_unused]] const unsigned long long st4 = GGNN_STAMP_NOW();
-    st_wait += st1 - st0;
-    st_comp += st3 - st1;
-    st_issue += st4 - st3;
-    st_n += 2;
+    st_lstm += GGNN_STAMP_NOW() - t_f;
   }
-  ec_dma_wait<0>();  // no LDS-DMA may outlive the wave
+  // range flag: an operand at or beyond fp16's range was clamped somewhere in this tile
+  if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(!(amax < 65504.0f)) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
   GGNN_STAMP_VAL(4, st_wait);
-  GGNN_STAMP_VAL(5, st_comp);
-  GGNN_STAMP_VAL(6, st_issue);
-  GGNN_STAMP_VAL(7, st_gemm);
-  GGNN_STAMP_VAL(8, st_n);
-  GGNN_STAMP_VAL(9, st_t);
+  GGNN_STAMP_VAL(5, st_a);
+  GGNN_STAMP_VAL(7, st_p3);
+  GGNN_STAMP_VAL(8, st_p4);
+  GGNN_STAMP_VAL(9, st_lstm);
+  GGNN_STAMP_VAL(10, n_in);
   GGNN_STAMP(16);
 }
 
-__global__ __launch_bounds__(EC_WAVES * 64, EC_CFG_MINW) void enc_cell_kernel(const EncCellBatch B) {
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[EC_LDS_BYTES];
+// (143 360 B of LDS: one workgroup per compute unit, two waves per SIMD, <= 256 registers)
+__global__ __launch_bounds__(EC_WAVES * 64) void enc_cell_kernel(const EncCellBatch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[EC_LDS];
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
-  const int wg = (int)blockIdx.x - B.wg_off[k], nwg = B.wg_off[k + 1] - B.wg_off[k];
-  const int cb = B.combo[k];
-  enc_cell_body(B.a[cb & 3], (cb >> 2) & 1, cb >> 3, wg, nwg, s_raw);
-}
-
-// ---- LSTM update from zero state (heteropgclstm.py:111-146 with h = c = 0): c' = sig(i) tanh(c~),
-// h' = sig(o) tanh(c'); pre-activation = sum over the incoming edge types of the gate GEMM results + the
-// summed skip / gate-bias term, which is formed HERE from the node's 8 / 11 features (weights in LDS)
-// instead of being written and read back as 288 projection columns ----
-struct EncLstmBatch {
-  ggnn_enc_cell_args a[EC_MAX_PROBLEMS];
-  int blk_off[EC_MAX_PROBLEMS + 1];
-  int n;
-};
-constexpr int EL_MAXF = 12;
-
-// (Tried: no LDS, the weight table through the vector cache, so that this launch of one model could share
-// compute units with the other model's enc_cell_kernel in the two-stream rollout, whose workgroups leave 8 KB of
-// LDS: 26.8 instead of 20.4 us alone, and no overlap gained -- the issue-bound encoder cell starves it anyway.)
-__global__ __launch_bounds__(256) void enc_lstm_kernel(const EncLstmBatch B) {
-  __shared__ __attribute__((aligned(16))) float s_w[(EL_MAXF + 1) * EC_G * C];  // [k][288] skip weights, then the bias row
-  int k = 0;
-  while (k + 1 < B.n && (int)blockIdx.x >= B.blk_off[k + 1]) ++k;
-  const ggnn_enc_cell_args& A = B.a[k];
-  const int F = A.f_dst;
-  for (int t = threadIdx.x; t < (F + 1) * EC_G * C; t += 256) s_w[t] = A.ws_t[t];
-  __syncthreads();
-  // a workgroup keeps the weights for a whole range of nodes: (node, 4-channel) quads, 256 per pass
-  const int nblk = B.blk_off[k + 1] - B.blk_off[k], blk = (int)blockIdx.x - B.blk_off[k];
-  const int64_t n_q = A.n_dst * 24, per = (n_q + nblk - 1) / nblk;
-  const int64_t q_hi = min(n_q, (int64_t)(blk + 1) * per);
-  const int64_t part = A.n_dst * (int64_t)(EC_G * C);  // one partial per incoming edge type (HeteroConv sums them)
-  for (int64_t t = (int64_t)blk * per + threadIdx.x; t < q_hi; t += 256) {
-    const int64_t node = t / 24;
-    const int c4 = (int)(t - node * 24);
-    const float* __restrict__ pr = A.pre + node * (EC_G * C) + 4 * c4;
-    f32x4 p[EC_G];
-#pragma unroll
-    for (int g = 0; g < EC_G; ++g) {
-      p[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + g * C)) +
-             *reinterpret_cast<const f32x4*>(&s_w[F * EC_G * C + g * C + 4 * c4]);
-      if (A.n_in == 2) p[g] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + part + g * C));
-    }
-    const float* __restrict__ x = A.x_dst + node * A.ldx;
-    float xv[EL_MAXF];  // all features requested at once (clamped index: no load under a branch)
-#pragma unroll
-    for (int f = 0; f < EL_MAXF; ++f) xv[f] = x[min(f, F - 1)];
-#pragma unroll
-    for (int f = 0; f < EL_MAXF; ++f) {
-      if (f < F) {
-#pragma unroll
-        for (int g = 0; g < EC_G; ++g) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(&s_w[f * EC_G * C + g * C + 4 * c4]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p[g][r] = fmaf(xv[f], w[r], p[g][r]);
-        }
-      }
-    }
-    f32x4 hn, cn;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float cv = sigmoidf_(p[0][r]) * tanhf_(p[1][r]);
-      cn[r] = cv;
-      hn[r] = sigmoidf_(p[2][r]) * tanhf_(cv);
-    }
-    *reinterpret_cast<f32x4*>(A.c_out + node * C + 4 * c4) = cn;
-    *reinterpret_cast<f32x4*>(A.h_out + node * C + 4 * c4) = hn;
-  }
+  const int nwg = B.wg_off[k + 1] - B.wg_off[k];
+  const int ts = xcd_remap((int)blockIdx.x - B.wg_off[k], nwg);
+  enc_cell_body(B.a[k], ts, s_raw);
 }
 
 }  // namespace ggnn
@@ -505,79 +354,29 @@ extern "C" int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_pro
   using namespace ggnn;
   if (!args || n_problems < 1 || n_problems > EC_MAX_PROBLEMS) return GGNN_EINVAL;
   EncCellBatch B;
-  EncLstmBatch L;
-  L.n = n_problems;
-  double cost[EC_MAX_COMBOS];   // relative time of one (problem, edge type) sweep + GEMM, per gate
-  int64_t n_t[EC_MAX_COMBOS];
-  int kd[EC_MAX_COMBOS];
-  int n_kd = 0;
-  double total = 0.0;
+  B.n = n_problems;
+  B.wg_off[0] = 0;
   for (int k = 0; k < EC_MAX_PROBLEMS; ++k) {
-    B.a[k] = L.a[k] = args[k < n_problems ? k : 0];
-    if (k >= n_problems) continue;
+    B.a[k] = args[k < n_problems ? k : 0];
+    if (k >= n_problems) {
+      B.wg_off[k + 1] = B.wg_off[k];
+      continue;
+    }
     const ggnn_enc_cell_args& A = B.a[k];
-    if (A.n_in < 1 || A.n_in > 2 || A.n_dst <= 0 || A.Ka != 96 * A.n_in + 4) return GGNN_EINVAL;
-    if (!A.p_dst || !A.w2_frag || !A.w2 || !A.pre || !A.h_out || !A.c_out || !A.x_dst || !A.ws_t) return GGNN_EINVAL;
-    if (!aligned16(A.p_dst) || !aligned16(A.w2_frag) || !aligned16(A.pre) || !aligned16(A.h_out) || !aligned16(A.c_out))
-      return GGNN_EINVAL;
-    if (A.ldp <= 0 || A.f_dst < 1 || A.f_dst > EL_MAXF || A.ldx < A.f_dst || !aligned16(A.ws_t)) return GGNN_EINVAL;
-    if (A.n_dst >= (1 << 23) || A.n_dst * A.ldp >= INT32_MAX) return GGNN_EINVAL;  // row0 field of the meta word
+    if (A.n_in < 1 || A.n_in > 2 || A.n_dst <= 0 || A.f_dst < 1 || A.f_dst > 12 || A.ldx < A.f_dst) return GGNN_EINVAL;
+    if (!A.x_dst || !A.h_out || !A.c_out || !A.wstream || !A.w2_tail) return GGNN_EINVAL;
+    if (!aligned16(A.h_out) || !aligned16(A.c_out) || !aligned16(A.wstream)) return GGNN_EINVAL;
+    if (A.n_dst >= INT32_MAX - 64) return GGNN_EINVAL;
     for (int e = 0; e < A.n_in; ++e) {
       const ggnn_enc_cell_sweep& Sw = A.in[e];
-      if (!Sw.rowptr || !Sw.einfo || !Sw.wv_frag || !aligned16(Sw.einfo)) return GGNN_EINVAL;
-      if (Sw.E < 0 || Sw.f_src < 3 || Sw.f_src > 12 || Sw.u4_off < 0 || Sw.u4_off + EC_G * 16 > A.ldp)
-        return GGNN_EINVAL;
-      if ((Sw.E + GGNN_UNIT_EDGES + 1) * GGNN_EINFO_ROW >= INT32_MAX) return GGNN_EINVAL;
-      n_t[n_kd] = (A.n_dst + 15) / 16;
-      // time of the combination in units of one sweep block (four units; measured: the loop is bound by
-      // instruction issue, a third k-step adds ~12 %, a tile's GEMM costs ~1.6 blocks); a row has
-      // max(1, ceil(deg / 3)) units: ~ max(n_dst, E / 3) for the degrees of a grain structure
-      const double blocks = Sw.n_blocks > 0 ? (double)Sw.n_blocks
-                                            : (double)std::max<int64_t>(A.n_dst, Sw.E / GGNN_UNIT_EDGES) / 4.0;
-      cost[n_kd] = blocks * (Sw.f_src > 8 ? 1.12 : 1.0) +
-                   (double)n_t[n_kd] * 1.6;
-      total += EC_G * cost[n_kd];
-      kd[n_kd++] = k | (e << 2);
+      if (!Sw.rowptr || !Sw.einfo || !aligned16(Sw.einfo) || Sw.E < 0) return GGNN_EINVAL;
+      if ((Sw.E + GGNN_UNIT_EDGES) * GGNN_EINFO_ROW >= INT32_MAX) return GGNN_EINVAL;  // 32-bit record offsets
     }
+    const int64_t n_ts = (A.n_dst + 16 * EC_WAVES - 1) / (16 * EC_WAVES);
+    if (B.wg_off[k] + n_ts >= INT32_MAX) return GGNN_EINVAL;
+    B.wg_off[k + 1] = B.wg_off[k] + (int)n_ts;
   }
-  // One persistent workgroup per compute unit, dealt to the (problem, edge type, gate) combinations in
-  // proportion to their matrix-core work; never more workgroups than tiles.
-  const int ncu = num_cu();
-  int nwg[EC_MAX_COMBOS];
-  int used = 0;
-  for (int j = 0; j < n_kd; ++j) {
-    nwg[j] = (int)std::min<int64_t>(n_t[j], std::max<int64_t>(1, (int64_t)(ncu * cost[j] / total)));
-    used += EC_G * nwg[j];
-  }
-  for (;;) {  // left-over compute units go to the combination with the most work per workgroup
-    int best = -1;
-    for (int j = 0; j < n_kd; ++j)
-      if (nwg[j] < n_t[j] && (best < 0 || cost[j] / nwg[j] > cost[best] / nwg[best])) best = j;
-    if (best < 0 || used + EC_G > ncu) break;
-    ++nwg[best];
-    used += EC_G;
-  }
-  B.n = EC_G * n_kd;
-  B.wg_off[0] = 0;
-  for (int j = 0; j < EC_MAX_COMBOS; ++j) {
-    const int jj = j / EC_G, g = j % EC_G;
-    B.combo[j] = jj < n_kd ? (kd[jj] | (g << 3)) : 0;
-    B.wg_off[j + 1] = B.wg_off[j] + (jj < n_kd ? nwg[jj] : 0);
-  }
-  // LSTM launch: at most eight workgroups per compute unit in all, dealt by node count, 256 quads per pass
-  int64_t quads = 0;
-  for (int k = 0; k < n_problems; ++k) quads += B.a[k].n_dst * 24;
-  L.blk_off[0] = 0;
-  for (int k = 0; k < EC_MAX_PROBLEMS; ++k) {
-    int64_t nb = 0;
-    if (k < n_problems) {
-      const int64_t full = (B.a[k].n_dst * 24 + 255) / 256;
-      nb = std::max<int64_t>(1, std::min<int64_t>(full, (int64_t)8 * ncu * (B.a[k].n_dst * 24) / quads));
-    }
-    L.blk_off[k + 1] = L.blk_off[k] + (int)nb;
-  }
-  hipLaunchKernelGGL(enc_cell_kernel, dim3((unsigned)B.wg_off[EC_MAX_COMBOS]), dim3(EC_WAVES * 64), 0,
+  hipLaunchKernelGGL(enc_cell_kernel, dim3((unsigned)B.wg_off[EC_MAX_PROBLEMS]), dim3(EC_WAVES * 64), 0,
                      (hipStream_t)stream, B);
-  hipLaunchKernelGGL(enc_lstm_kernel, dim3((unsigned)L.blk_off[EC_MAX_PROBLEMS]), dim3(256), 0, (hipStream_t)stream, L);
   return launch_status();
 }

@@ -30,36 +30,9 @@ class GraphCSR:
             ei = edge_index_dict[et]
             self.edge_index[et] = ei.contiguous()
             self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
-        self._balanced = False
 
     def n_edges(self, et):
         return self.edge_index[et].size(1)
-
-    def balance(self):
-        """Exact block counts of the fused encoder cell's sweeps (csr.n_blocks; 0 = the kernel's own estimate from
-        n_dst and E) for its workgroup deal: three small reductions and ONE read-back.  For topologies that stay: a
-        rollout whose edge lists change every few steps (events) keeps the estimate -- the read-back would cost more
-        (1.7 ms per edge type behind a busy stream) than the balance gains."""
-        if not self._balanced:
-            counts = torch.stack([_sweep_blocks(self.csr[et].rowptr) for et in EDGE_TYPES]).tolist()
-            for et, n in zip(EDGE_TYPES, counts):
-                self.csr[et].n_blocks = int(n)
-            self._balanced = True
-        return self
-
-
-def _sweep_blocks(rowptr: torch.Tensor) -> torch.Tensor:
-    """Blocks the fused encoder cell walks for this edge type (a 0-d int64 tensor on the device): per 16-row tile
-    the largest unit count (units of <= 3 edges, an empty row = one unit) among its four groups of 4 rows.  Only
-    used to balance the workgroups."""
-    n = rowptr.numel() - 1
-    if n <= 0:
-        return torch.zeros((), dtype=torch.int64, device=rowptr.device)
-    n_t = (n + 15) // 16
-    deg = (rowptr[1:] - rowptr[:-1]).long()
-    nu = torch.clamp((deg + 2) // 3, min=1)
-    nu = torch.nn.functional.pad(nu, (0, n_t * 16 - n)).view(n_t, 4, 4).sum(2)
-    return nu.max(1).values.sum()
 
 
 _graph_cache: Dict[tuple, GraphCSR] = {}
@@ -73,8 +46,6 @@ def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
                  tuple(edge_index_dict[et].shape)) for et in EDGE_TYPES if et in edge_index_dict)
     key = key + tuple(sorted(n_nodes.items()))
     g = _graph_cache.get(key)
-    if g is not None and not torch.cuda.is_current_stream_capturing():
-        g.balance()   # seen before: this topology stays for a while (one read-back: never inside a capture)
     if g is None:
         g = GraphCSR(backend, edge_index_dict, n_nodes)
         if len(_graph_cache) >= _GRAPH_CACHE_MAX:
@@ -147,15 +118,13 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     projs, sweeps, enc_sweeps, gates, enc_cells, dec_cells = [], [], [], [], [], []
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
-        if pc.wvb and getattr(backend, "fused_encoder", False):
-            # encoder: sweep and gate GEMM of a node type in one kernel; the projection only emits the score
-            # tails (the skip term is formed in the LSTM launch); `agg` = {node type: pre-activation scratch}
+        if pc.ecs and getattr(backend, "fused_encoder", False):
+            # encoder: everything of a destination node type in one kernel (ggnn_encoder_cell_batch): no projection, no
+            # aggregate or pre-activation buffer
             for nt in NODE_TYPES:
                 if lay[nt].live:
-                    projs.append((x[nt], lay[nt].F, None, pc.wps[nt], pc.bps[nt], proj[nt][:, :pc.wps[nt].size(0)]))
-                    enc_cells.append(([(graph.csr[et], einfo[et], pc.wvb[et], pc.u4s[et], lay[et[0]].F)
-                                       for et in lay[nt].dst_ets], proj[nt], x[nt], pc.wst[nt], pc.w2[nt], pc.w2f[nt],
-                                      _pre_view(agg[nt], len(lay[nt].dst_ets)), h_out[nt], c_out[nt]))
+                    enc_cells.append(([(graph.csr[et], einfo[et]) for et in lay[nt].dst_ets], x[nt], pc.ecs[nt],
+                                      pc.ect[nt], h_out[nt], c_out[nt]))
             continue
         fd = getattr(backend, "fused_decoder", False)
         if fd not in (False, True):   # one model's decoder only: the classifier's has one live destination type
@@ -187,7 +156,8 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                            pc.ep[et], agg[d], lay[s].v_off[et], lay[d].u_off.get(et, 0), lay[d].u4_off[et],
                            lay[d].a_off[et], lay[d].Kg, lay[d].sc_off[et], pc.G))
         gates += gate_problems(pc, proj, agg, c_in, h_out, c_out)
-    backend.project_batch(projs)
+    if projs:
+        backend.project_batch(projs)
     if after_projection is not None and not dec_cells:
         after_projection()
     if enc_cells:
@@ -204,15 +174,6 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
         after_sweeps()
     if gates:
         backend.lstm_epilogue_batch(gates)
-
-
-def _pre_view(agg: torch.Tensor, n_in: int) -> torch.Tensor:
-    """[n_in, n, 3 * 96] partial pre-activation scratch of the fused encoder cell inside the (otherwise
-    unused) aggregate buffer of the node type."""
-    n = agg.size(0)
-    if agg.numel() < n_in * n * 3 * C:
-        raise _lib.GGNNError("aggregate buffer too small for the fused encoder cell's scratch")
-    return agg.view(-1)[:n_in * n * 3 * C].view(n_in, n, 3 * C)
 
 
 def run_cell(backend, pc: PackedCell, graph: GraphCSR, x: Dict[str, torch.Tensor],

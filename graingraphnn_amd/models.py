@@ -73,8 +73,7 @@ class _GrainNNBase(nn.Module):
         for et in EDGE_TYPES:
             ws.ea[et].copy_(ea[et])
         key = (graph, enc, dec, ws, torch.cuda.current_stream().cuda_stream,
-               tuple((x_dict[nt].data_ptr(), x_dict[nt].stride(0)) for nt in NODE_TYPES),
-               graph._balanced)   # the exact block balance arrives on a topology's second forward: re-record then
+               tuple((x_dict[nt].data_ptr(), x_dict[nt].stride(0)) for nt in NODE_TYPES))
         t = self._tape
         if t is not None and all(a is b for a, b in zip(t[0][:4], key[:4])) and t[0][4:] == key[4:]:
             be.replay(t[1])

@@ -121,19 +121,14 @@ class PackedCell:
     w2: Dict[str, torch.Tensor]     # node type -> [G, 96, Ka]
     w2p: Dict[str, torch.Tensor] = field(default_factory=dict)  # node type -> fragment-ordered w2 (bf16_planes)
     wvf: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # encoder: edge type -> value_fragments
-    # encoder, fused cell (ggnn_encoder_cell_batch): node type -> gate_fragments(w2), edge type -> value_fragments_bias
-    w2f: Dict[str, torch.Tensor] = field(default_factory=dict)
-    wvb: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)
-    # ... whose projection only emits the score tails (the skip term is formed in the LSTM launch):
-    wps: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [roundup96(16 G n_in), Fp] tail rows of wp
-    bps: Dict[str, torch.Tensor] = field(default_factory=dict)
-    u4s: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> tail column in that projection
-    wst: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> skip_transposed [F + 1, 288]
     # decoder, fused cell (ggnn_decoder_cell_batch): the projection only emits the source-side value rows ...
     wpv: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [96 G n_src_ets, Kp] value rows of wp
     bpv: Dict[str, torch.Tensor] = field(default_factory=dict)
     vof: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> value column in that projection
     # ... and everything on the destination side streams past the tiles as fp16 planes
+    # encoder, ONE-kernel cell (ggnn_encoder_cell_batch): node type -> encoder_cell_stream / its (b_l2, w_edge) tails
+    ecs: Dict[str, torch.Tensor] = field(default_factory=dict)
+    ect: Dict[str, torch.Tensor] = field(default_factory=dict)
     dcs: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_stream (int16)
     dct: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_tail [4, n_in, 6, 64]
 
@@ -183,40 +178,6 @@ def value_fragments(weights, biases, F_src: int) -> torch.Tensor:
         Bp[11, g * C:(g + 1) * C] = biases[g].detach().float()
     fr = Bp.view(3, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
     fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 6 g + 2 m2 + e, lane l = 16 kq + j)
-    return fr.view(-1)
-
-
-@torch.no_grad()
-def gate_fragments(w2: torch.Tensor) -> torch.Tensor:
-    """`ggnn_enc_cell_args.w2_frag` (include/ggnn.h): w2[:, :, :Ka-4] as fp32 MFMA A fragments in the
-    fused encoder cell's k order, [G][(Ka-4)/32][6][2][64][4]: element [g][ks][ct][h][l][j] =
-    w2[g][16 ct + (l & 15)][32 ks + 16 h + 4 (l >> 4) + j].  The kernel splits every value into three
-    bf16 pieces on the fly; exactness of that split is checked as in bf16_planes."""
-    bf16_planes(w2)  # raises on non-finite / unsplittable weights
-    G, nch, Ka = w2.shape
-    KM = Ka - 4
-    fr = w2[:, :, :KM].float().reshape(G, 6, 16, KM // 32, 2, 4, 4)   # g ct i ks h kq j
-    fr = fr.permute(0, 3, 1, 4, 5, 2, 6).contiguous()                 # g ks ct h kq i j   (lane l = 16 kq + i)
-    return fr.view(-1)
-
-
-@torch.no_grad()
-def value_fragments_bias(weights, biases, F_src: int) -> torch.Tensor:
-    """`ggnn_enc_cell_sweep.wv_frag` (include/ggnn.h): lin_value of the G gates of one edge type
-    (weights[g]: [96, >= F_src], biases[g]: [96]) as [G][6][4][64]: for gate g and column tile t the
-    k-steps s = 0..2 of the MFMA B fragments, [s][l] = W_g[ch][4 s + (l >> 4)] (0 for k >= F_src) with
-    ch = 32 (t / 2) + 2 (l & 15) + t % 2, and as entry s = 3 the bias b_g[ch] (the accumulator's
-    initial value: 8 source features are two k-steps)."""
-    G = len(weights)
-    if F_src > 12:
-        raise ValueError("the fused encoder cell reads at most 12 source features")
-    dev = weights[0].device
-    Bp = torch.zeros(16, G * C, dtype=torch.float32, device=dev)   # rows 0..11: W^T, rows 12..15: bias
-    for g in range(G):
-        Bp[:F_src, g * C:(g + 1) * C] = weights[g].detach().float()[:, :F_src].t()
-        Bp[12:16, g * C:(g + 1) * C] = biases[g].detach().float()
-    fr = Bp.view(4, 4, G, 3, 16, 2)                  # s kq g m2 j e   (k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e)
-    fr = fr.permute(2, 3, 5, 0, 1, 4).contiguous()   # g m2 e s kq j   (tile t = 2 m2 + e, lane l = 16 kq + j)
     return fr.view(-1)
 
 
@@ -286,6 +247,61 @@ def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
     for d in range(n_in):
         for k in range(2):
             tail[:, d, :, k, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
+    return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
+
+
+# Aggregate channel a lin_l2 column of the fused ENCODER cell's stream multiplies (include/ggnn.h, GGNN_CELL_P3_CHANNEL):
+# the kernel's aggregates leave the value MFMAs in lane (node, k-group kq) as channels 16 nb + 4 kq ..+3, nb = 0..5, and
+# feed the lin_l2 k-steps as they stand.
+CELL_P3_CHANNEL = tuple(32 * (k // 32) + 16 * ((k % 8) // 4) + 4 * ((k % 32) // 8) + k % 4 for k in range(96))
+
+
+def _spread16(S: torch.Tensor) -> torch.Tensor:
+    """[rows, 16 slots] -> [rows, 32]: one k-step of the encoder cell's 16-slot products, k = 8 q + j holds slot
+    4 q + j for j < 4 and zero for j >= 4 (a lane's fragment: its four slots in the low half)."""
+    out = torch.zeros(S.size(0), 32, dtype=S.dtype, device=S.device)
+    out.view(-1, 4, 8)[:, :, :4] = S.view(-1, 4, 4)
+    return out
+
+
+@torch.no_grad()
+def encoder_cell_stream(wp, bp, w2, lay: "NodeLayout", values, F_src):
+    """`ggnn_enc_cell_args.wstream` and `.w2_tail` of one destination node type (include/ggnn.h) from the packed
+    projection rows `wp` [ncols, Fp] / `bp` (score tails u4, summed skip) and the gate weight `w2` [3, 96, Ka] of
+    pack_cell; `values[et][g]` = (lin_value.weight [96, F_src], lin_value.bias) of the incoming edge types, `F_src[et]`
+    their source feature counts.  Slot 12 of a feature row / edge record is 1: the bias column."""
+    F, G = lay.F, lay.G
+    assert G == 3 and F <= 12
+    n_in = len(lay.dst_ets)
+    dev = wp.device
+
+    def dst_block(rows):   # packed projection rows (input = the destination's features) -> [n, 16 slots]
+        out = torch.zeros(rows.numel(), 16, dtype=torch.float32, device=dev)
+        out[:, :F] = wp[rows][:, :F]
+        out[:, 12] = bp[rows]
+        return out
+
+    p3 = torch.tensor(CELL_P3_CHANNEL, device=dev)
+    slices = []
+    for g in range(G):
+        for d, et in enumerate(lay.dst_ets):
+            Fs = F_src[et]
+            assert Fs <= 12
+            wv, bv = values[et][g]
+            V = torch.zeros(C, 16, dtype=torch.float32, device=dev)
+            V[:, :Fs] = wv.detach().float()[:, :Fs]     # record slots 0..2 = reloc, 3..Fs-1 = x_src[3:Fs]
+            V[:, 12] = bv.detach().float()
+            T = dst_block(torch.arange(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4, device=dev))
+            slices.append(_plane_slices(_spread16(torch.cat([V, T]))))                      # A(e, g): 1 slice
+            slices.append(_plane_slices(w2[g][:, p3 + d * C].contiguous()))                  # lin_l2(e, g): 3 slices
+        slices.append(_plane_slices(_spread16(dst_block(torch.arange(lay.s_off + g * C, lay.s_off + (g + 1) * C,
+                                                                     device=dev)))))        # S(g): 1 slice
+    stream = torch.cat(slices).contiguous()
+    assert stream.size(0) == G * (4 * n_in + 1)
+    tail = torch.zeros(G, n_in, 6, 4, 16, dtype=torch.float32, device=dev)   # g e ct k m   (lane l = 16 k + m)
+    for d in range(n_in):
+        for k, slot in enumerate((0, 3)):   # b_l2 meets sum alpha in k-group 0, w_edge meets sum alpha a_e in k-group 3
+            tail[:, d, :, slot, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
     return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
 
 
@@ -384,28 +400,18 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             convs = [_conv(cell, gate, et) for gate in gates]
             wvf[et] = value_fragments([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
                                       F_of[et[0]])
-    w2f, wvb, wps, bps, u4s, wst = {}, {}, {}, {}, {}, {}
-    if enc_mfma:  # fused cell: fragments in its own k order, value bias apart
-        w2f = {nt: gate_fragments(t) for nt, t in w2.items() if layout[nt].live}
-        for nt in NODE_TYPES:
-            lay = layout[nt]
-            if not lay.live:
-                continue
-            rows = [torch.arange(lay.u4_off[et], lay.u4_off[et] + G * U4, device=dev) for et in lay.dst_ets]
-            idx = torch.cat(rows)
-            ncs = (idx.numel() + C - 1) // C * C
-            wps[nt] = torch.zeros(ncs, wp[nt].size(1), dtype=dt, device=dev)
-            bps[nt] = torch.zeros(ncs, dtype=dt, device=dev)
-            wps[nt][:idx.numel()], bps[nt][:idx.numel()] = wp[nt][idx], bp[nt][idx]
-            for k, et in enumerate(lay.dst_ets):
-                u4s[et] = k * G * U4
-            # skip term: [F + 1, G * 96], rows = input features, last row = bias (the cell sees no h: k2 = 0)
-            wst[nt] = torch.cat([wp[nt][lay.s_off:lay.s_off + G * C, :lay.F].t(),
-                                 bp[nt][lay.s_off:lay.s_off + G * C].view(1, -1)]).contiguous()
-        for et in ep:
-            convs = [_conv(cell, gate, et) for gate in gates]
-            wvb[et] = value_fragments_bias([cv.lin_value.weight for cv in convs], [cv.lin_value.bias for cv in convs],
-                                           F_of[et[0]])
+    ecs, ect = {}, {}
+    if encoder and all(F <= 12 for F in in_channels.values()):   # the encoder cell as ONE kernel: its weight stream
+        try:
+            for nt in NODE_TYPES:
+                lay = layout[nt]
+                if lay.live:
+                    vals = {et: [(_conv(cell, gate, et).lin_value.weight, _conv(cell, gate, et).lin_value.bias)
+                                 for gate in gates] for et in lay.dst_ets}
+                    ecs[nt], ect[nt] = encoder_cell_stream(wp[nt], bp[nt], w2[nt], lay, vals,
+                                                           {et: F_of[et[0]] for et in lay.dst_ets})
+        except ValueError:   # a weight beyond fp16's range (or not finite): sweep + gate GEMM launches instead
+            ecs, ect = {}, {}
     wpv, bpv, vof, dcs, dct = {}, {}, {}, {}, {}
     if k2 and all(F + 1 <= 16 for F in in_channels.values()):   # decoder: the fused cell's operands
         for nt in NODE_TYPES:
@@ -422,8 +428,8 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
                     dcs[nt], dct[nt] = decoder_cell_stream(wp[nt], bp[nt], w2[nt], layout[nt])
         except ValueError:   # a weight that is not finite or beyond fp16's range: the cell runs on the three-kernel
             dcs, dct = {}, {}   # plan (projection + sweeps + gate GEMM, bf16 x 3: the full fp32 range, NaNs propagate)
-    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, w2f=w2f, wvb=wvb,
-                      wps=wps, bps=bps, u4s=u4s, wst=wst, wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct)
+    return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, ecs=ecs, ect=ect,
+                      wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct)
 
 
 @torch.no_grad()

@@ -125,13 +125,10 @@ class GrainRollout:
     def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
         buffers (refreshed in place every step), the per-edge geometry records and the per-edge
-        outputs.  Called once at construction and after every topological event (`lasting=False`: the
-        next event may be a step away, the exact workgroup balance is not worth its read-back)."""
+        outputs.  Called once at construction and after every topological event."""
         dev = self.x["joint"].device
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
         self.graph = graph_for(self.be, self.edge_index, self.n_nodes)
-        if lasting:
-            self.graph.balance()
         if edge_attr_dict is not None:
             self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
                               for et in EDGE_TYPES}
@@ -352,7 +349,6 @@ class GrainRollout:
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
         if self.use_graph and self._quiet_steps >= 2:
             if getattr(self, attr) is None:
-                self.graph.balance()   # quiet for two steps: worth the read-back now
                 st = torch.cuda.Stream()
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):

@@ -413,8 +413,6 @@ class GraphedTrainStep:
         with torch.cuda.stream(s), _pins.collect(self._pins):
             for _ in range(warmup):
                 self._eager()
-            # the topology's exact block balance is one read-back: take it now, never inside the capture
-            graph_for(default_backend(), self.ei, {nt: self.x[nt].size(0) for nt in NODE_TYPES}).balance()
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):

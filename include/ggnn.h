@@ -289,58 +289,57 @@ int ggnn_lstm_epilogue_batch(const ggnn_epilogue_args* args, int n_problems, ggn
 
 /* ------------------------------------------------------------------------------------
  * Encoder cell (h = c = 0; HeteroPGCLSTM.forward on the zero state of models.py:422,
- * heteropgclstm.py:101-183) with sweep and gate GEMM fused: replaces
- * ggnn_period_gat_aggregate_enc_batch + ggnn_lstm_epilogue_batch(GGNN_MODE_LSTM_H0) -- same sums up to
- * fp32 re-association, but the aggregates stay in the compute unit's LDS instead of an [N, 3 * 224]
- * buffer.  One problem = one destination node type of one model, with its 1 or 2 incoming edge types
- * (HeteroConv sums them, heteropgclstm.py:113-138); up to four problems (two node types x regressor
- * and classifier, test.py:382-383) per call.  Per incoming edge type:
- *   rowptr  : [n_dst + 1] destination-grouped CSR row pointers (ggnn_build_csr)
- *   einfo   : as ggnn_aggregate_enc_args
- *   wv_frag : [3][6][4][64] fp32: per gate g and column tile t, k-steps s = 0..2 of the MFMA B
- *             fragments of lin_value ([s][l] = W_value_g[ch][4 s + (l >> 4)], 0 for k >= f_src, with
- *             ch = 32 (t / 2) + 2 (l & 15) + t % 2) and, as entry s = 3, the bias b_value_g[ch]
- *   u4_off  : column of the edge type's score tails in p_dst (as ggnn_aggregate_enc_args)
- *   f_src   : features of the source node type (3..12)
- * and per problem
- *   p_dst   : [n_dst, ldp] destination projections: the u4 tails (ggnn_project)
- *   x_dst   : [n_dst, ldx] features of the destination nodes (first f_dst columns)
- *   ws_t    : [f_dst + 1][288] fp32: lin_skip summed over the incoming edge types (HeteroConv aggr 'sum'),
- *             transposed -- row k, column g*96 + ch = sum_et W_skip_{et,g}[ch][k] -- and, as the last row,
- *             the summed skip biases + b_{i,c,o}: the skip term is formed in the LSTM launch
- *   w2      : [3][96][Ka], Ka = 96 n_in + 4, as ggnn_epilogue_args (only the four tail columns are read)
- *   w2_frag : w2[:, :, 0:Ka-4] as MFMA A fragments, fp32, [3][(Ka-4)/32][6][2][64][4]: element
- *             [g][ks][ct][h][l][j] = w2[g][16 ct + (l & 15)][32 ks + 16 h + 4 (l >> 4) + j]
- *             (the k-groups of a step are interleaved by four: conflict-free LDS fragment reads)
- *   pre     : [n_in, n_dst, 288] scratch: per incoming edge type the gates' partial pre-activations
- *             (lin_l2 of the aggregate + b_l2 sum alpha + w_edge sum alpha a)
+ * heteropgclstm.py:101-183: no forget gate) with EVERYTHING that belongs to a destination node in one kernel and
+ * one launch: the score tails u4, the sweeps of the incoming edge types (PeriodConv.message,
+ * periodGATconv.py:204-236), lin_l2 + the lin_edge value term, HeteroConv's sum over the edge types
+ * (heteropgclstm.py:113-138), the summed skip term and the LSTM update.  Replaces the encoder's share of
+ * ggnn_project_batch, ggnn_period_gat_aggregate_enc_batch and ggnn_lstm_epilogue_batch(GGNN_MODE_LSTM_H0) -- same
+ * sums up to fp32 re-association; nothing but x, the edge records and the weights is read, nothing but (h, c) is
+ * written.  One problem = one destination node type of one model, with its 1 or 2 incoming edge types; up to four
+ * problems (two node types x regressor and classifier, test.py:382-383) per call.
+ *
+ * With h = 0 a PeriodConv only sees 16-slot rows: of a destination node (x_0 .. x_{f_dst-1}, 0 .., 1 at slot 12)
+ * and of an in-edge (ggnn_edge_prepare's record: reloc, x_src[3 .. f_src), 0 .., 1 at 12, edge length at 13).
+ * A workgroup of eight waves owns 128 consecutive destination nodes, one 16-node tile per wave, and walks the
+ * gates i, c~, o; per gate g and incoming edge type e: u4[node] = T(e, g) . feature slots; score of an in-edge =
+ * u4[node] . record; online-max softmax over the node's in-edges (PyG: exp(s - max) / (sum + 1e-16)); value of an
+ * in-edge = relu(V(e, g) . record) (its row 12 column is b_value); aggregate = sum alpha value; pre-activation +=
+ * lin_l2(e, g) . aggregate + b_l2 sum alpha + w_edge sum alpha a_e; then + S(g) . feature slots (summed lin_skip +
+ * gate bias); i = sig, c' = i tanh(c~), h' = sig(o) tanh(c').  Arithmetic and OPERAND RANGE as for
+ * ggnn_decoder_cell_batch (two fp16 pieces, three products; |x| < 65504, reported through *flags).
+ *
+ * Per incoming edge type: rowptr [n_dst + 1] (ggnn_build_csr), einfo (ggnn_edge_prepare), E.
+ * Per problem:
+ *   x_dst   : [n_dst, ldx] features of the destination nodes (first f_dst <= 12 columns)
+ *   wstream : the weight slices in the order the kernel consumes them (packing.encoder_cell_stream):
+ *             for g in (i, c~, o): for e: 1 slice A(e, g) | 3 slices lin_l2(e, g); then 1 slice S(g).
+ *             Every slice is GGNN_DC_SLICE_BYTES in ggnn_dec_cell_args.wstream's image
+ *             ([column tile nb][plane hi, lo'][64 lanes][8 fp16], lane l = 16 kq + m of (nb, plane) holds
+ *             W[16 nb + m][32 ks + 8 kq .. + 7]).  A(e, g) = [V(e, g) rows 0..95 | T(e, g) rows 96..111] and S(g)
+ *             [96 rows] are ONE k-step over the 16 slots: k = 8 q + j holds slot 4 q + j for j < 4 and zero for
+ *             j >= 4.  lin_l2(e, g) is [96 x 96] in three k-steps, column k = the lin_l2 column of aggregate
+ *             channel GGNN_CELL_P3_CHANNEL(k).
+ *   w2_tail : [3][n_in][6][64] fp32: (b_l2, w_edge) of (g, e) as v_mfma_f32_16x16x4_f32 A fragments
+ *             ([ct][l]: k = l >> 4; k = 0 -> b_l2[16 ct + (l & 15)], k = 3 -> w_edge[16 ct + (l & 15)], else 0)
  *   h_out, c_out : [n_dst, 96]
- * n_dst < 2^23.  Two launches: the fused sweep + GEMM (one persistent workgroup per compute unit, each
- * owning one (problem, edge type, gate): that PeriodConv's lin_l2 stays in LDS as bf16 planes, the
- * operands of the sweep arrive through a per-wave LDS-DMA ring), then the element-wise sum over the
- * edge types + skip + LSTM update. */
+ *   flags   : optional int32 device word (GGNN_FLAG_F16_RANGE) */
+/* column k = 32 ks + 8 kq + j of a lin_l2 block <-> aggregate channel 32 ks + 16 (j / 4) + 4 kq + j % 4 */
+#define GGNN_CELL_P3_CHANNEL(k) (32 * ((k) / 32) + 16 * (((k) % 8) / 4) + 4 * (((k) % 32) / 8) + (k) % 4)
 typedef struct ggnn_enc_cell_sweep {
   const int32_t* rowptr;   /* [n_dst + 1] */
   const float* einfo;      /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] */
-  const float* wv_frag;    /* [3][6][4][64] */
   int64_t E;
-  int32_t u4_off, f_src;
-  int64_t n_blocks;        /* optional: sweep blocks of this edge type (sum over the 16-row tiles of the largest
-                              unit count among the four 4-row groups); 0 = estimated from n_dst and E.  Only
-                              used to deal the workgroups: affects speed, never results */
 } ggnn_enc_cell_sweep;
 typedef struct ggnn_enc_cell_args {
   ggnn_enc_cell_sweep in[2];
-  const float* p_dst;   /* [n_dst, ldp] */
-  const float* w2_frag; /* [3][(Ka-4)/32][6][2][64][4] */
-  const float* w2;      /* [3][96][Ka] */
-  float* pre;           /* [n_in, n_dst, 288] */
+  const float* x_dst;   /* [n_dst, ldx] */
   float* h_out;         /* [n_dst, 96] */
   float* c_out;         /* [n_dst, 96] */
-  const float* x_dst;   /* [n_dst, ldx] */
-  const float* ws_t;    /* [f_dst + 1][288] */
-  int64_t ldp, n_dst, ldx;
-  int32_t n_in, f_dst, Ka, reserved;
+  const void* wstream;  /* [3 * (4 n_in + 1)][GGNN_DC_SLICE_BYTES] */
+  const float* w2_tail; /* [3][n_in][6][64] */
+  int32_t* flags;       /* optional */
+  int64_t n_dst, ldx;
+  int32_t n_in, f_dst;
 } ggnn_enc_cell_args;
 int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn_stream_t stream);
 

@@ -80,45 +80,59 @@ class TorchEmulatorBackend:
                 agg[:, base + sc_off + 1] = torch.zeros(n_dst).index_add(0, dst, alpha * a)
 
     def encoder_cell_batch(self, problems):
-        """ggnn_encoder_cell_batch: sweep of every incoming edge type (values relu(W x4[:12] + b) from the
-        edge records), gate GEMM on [A_et0 | A_et1 | sum alpha, sum alpha a per edge type], skip, LSTM from
-        zero state.  The fragment tensors must decode to the plain weights exactly."""
-        for sweeps, p_dst, x_dst, ws_t, w2, w2f, pre, h_out, c_out in problems:
-            G, n_in, n_dst = 3, len(sweeps), p_dst.size(0)
-            Ka, KM = w2.size(2), w2.size(2) - 4
-            assert KM == 96 * n_in
-            fr = w2f.view(G, KM // 32, 6, 2, 4, 16, 4)                      # g ks ct h kq i j
-            assert torch.equal(fr.permute(0, 2, 5, 1, 3, 4, 6).reshape(G, 96, KM), w2[:, :, :KM])
-            agg = torch.zeros(G, n_dst, Ka)
-            for d, (csr, einfo, wvb, u4_off, f_src) in enumerate(sweeps):
-                rowptr = csr.rowptr.long()
-                E = int(rowptr[-1])
-                dst = torch.repeat_interleave(torch.arange(n_dst), rowptr[1:] - rowptr[:-1])
-                fb = wvb.view(G, 3, 2, 4, 4, 16)                            # g m2 e s kq j
-                Bp = fb.permute(3, 4, 0, 1, 5, 2).reshape(16, G * C)        # k = 4 s + kq, column = g*96 + 32 m2 + 2 j + e
-                assert torch.equal(Bp[12], Bp[13]) and torch.equal(Bp[12], Bp[15]) and not bool(Bp[f_src:12].any())
-                nk = 12 if f_src > 8 else 8
-                x4, a = einfo[:E, :16], einfo[:E, 19]
-                val = torch.relu(x4[:, :nk] @ Bp[:nk] + Bp[12])             # [E, G * 96]
-                for g in range(G):
-                    s = (p_dst[dst, u4_off + g * 16: u4_off + (g + 1) * 16] * x4).sum(-1)
-                    smax = torch.full((n_dst,), float("-inf")).scatter_reduce(0, dst, s, "amax")
-                    p = (s - smax[dst]).exp()
-                    den = torch.zeros(n_dst).index_add(0, dst, p)
+        """ggnn_encoder_cell_batch (include/ggnn.h): per gate (i, c~, o) and incoming edge type the score tails
+        u4 = T [x | 1], the sweep with values relu(V record) from the edge records, lin_l2 + (b_l2, w_edge) on the
+        aggregates; then the skip block and the LSTM update from the zero state.  Everything is computed from the
+        DECODED weight stream (16-slot k-steps un-spread, lin_l2's columns un-permuted as the header states), so a
+        packing error shows up here."""
+        self.calls = getattr(self, "calls", []) + ["encoder_cell_batch"]
+        p3 = torch.tensor([32 * (k // 32) + 16 * ((k % 8) // 4) + 4 * ((k % 32) // 8) + k % 4 for k in range(C)])
+
+        def unspread(blk):   # [rows, 32] -> [rows, 16 slots]: k = 8 q + j holds slot 4 q + j for j < 4, zero for j >= 4
+            v = blk.view(-1, 4, 8)
+            assert not bool(v[:, :, 4:].any())
+            return v[:, :, :4].reshape(-1, 16)
+
+        for sweeps, x_dst, wstream, w2_tail, h_out, c_out in problems:
+            n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
+            from graingraphnn_amd.packing import DC_SLICE_I16
+            assert wstream.numel() == 3 * (4 * n_in + 1) * DC_SLICE_I16 and tuple(w2_tail.shape) == (3, n_in, 6, 64)
+            xs = torch.zeros(n, 16)
+            xs[:, :F], xs[:, 12] = x_dst[:, :F], 1.0
+            pre, s = {}, 0
+            for g in range(3):
+                z = torch.zeros(n, C)
+                for d, (csr, einfo) in enumerate(sweeps):
+                    A = unspread(self._decode_slices(wstream, s, 1, 7))      # [112, 16]: value rows | u4 rows
+                    W3p = self._decode_slices(wstream, s + 1, 3, 6)          # [96, 96], columns permuted
+                    s += 4
+                    W3 = torch.empty_like(W3p)
+                    W3[:, p3] = W3p                                          # column k of the block = lin_l2 column of channel p3[k]
+                    V, T = A[:C], A[C:]
+                    u4 = xs @ T.t()                                           # [n, 16]
+                    rowptr = csr.rowptr.long()
+                    E = int(rowptr[-1])
+                    dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+                    x4 = einfo[:E, :16]
+                    a = x4[:, 13]                                             # the edge length, where the kernel reads it
+                    sc = (u4[dst] * x4).sum(-1)
+                    smax = torch.full((n,), float("-inf")).scatter_reduce(0, dst, sc, "amax")
+                    p = (sc - smax[dst]).exp()
+                    den = torch.zeros(n).index_add(0, dst, p)
                     alpha = p / (den[dst] + 1e-16)
-                    agg[g, :, d * C:(d + 1) * C] = torch.zeros(n_dst, C).index_add(0, dst, alpha[:, None] * val[:, g * C:(g + 1) * C])
-                    agg[g, :, KM + 2 * d] = torch.zeros(n_dst).index_add(0, dst, alpha)
-                    agg[g, :, KM + 2 * d + 1] = torch.zeros(n_dst).index_add(0, dst, alpha * a)
-            raw = torch.zeros(n_dst, G * C)
-            for d in range(n_in):  # one partial per incoming edge type: its 96 aggregate columns and its two scalars
-                cols = list(range(d * C, (d + 1) * C)) + [KM + 2 * d, KM + 2 * d + 1]
-                pre[d].copy_(torch.cat([agg[g][:, cols] @ w2[g][:, cols].t() for g in range(G)], 1))
-                raw = raw + pre[d]
-            F_dst = ws_t.size(0) - 1
-            z = raw + x_dst[:, :F_dst] @ ws_t[:F_dst] + ws_t[F_dst]
-            c = torch.sigmoid(z[:, :C]) * torch.tanh(z[:, C:2 * C])
+                    val = torch.relu(x4 @ V.t())
+                    Ag = torch.zeros(n, C).index_add(0, dst, alpha[:, None] * val)
+                    sa = torch.zeros(n).index_add(0, dst, alpha)
+                    sae = torch.zeros(n).index_add(0, dst, alpha * a)
+                    tail = w2_tail[g, d].view(6, 4, 16)                       # ct k m: k = 0 b_l2, k = 3 w_edge
+                    assert not bool(tail[:, 1:3].any())
+                    z = z + Ag @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 3].reshape(1, C)
+                Sg = unspread(self._decode_slices(wstream, s, 1, 6))         # [96, 16]
+                s += 1
+                pre[g] = z + xs @ Sg.t()
+            c = torch.sigmoid(pre[0]) * torch.tanh(pre[1])
             c_out.copy_(c)
-            h_out.copy_(torch.sigmoid(z[:, 2 * C:]) * torch.tanh(c))
+            h_out.copy_(torch.sigmoid(pre[2]) * torch.tanh(c))
 
     @staticmethod
     def _aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates):

@@ -932,23 +932,29 @@ def test_encoder_sweep_on_matrix_cores_equals_the_gathering_sweep(n_src, n_dst, 
     assert torch.equal(got, again)                                  # no atomics: bit-reproducible
 
 
-def _enc_cell_problem(be, rs, n_dst, ins, hub=0, regular=False):
-    """Random encoder-cell problem: destination type with 8 features, `ins` = [(n_src, F_src, E)] incoming
-    edge types.  Returns the fused-call tuple, the split-path tuples and the emulator inputs."""
-    from graingraphnn_amd.packing import bf16_planes, gate_fragments, value_fragments, value_fragments_bias
+def _enc_cell_problem(be, rs, n_dst, ins, hub=0, regular=False, F_dst=8, edges=None):
+    """Random encoder-cell problem (ggnn_encoder_cell_batch): destination type with `F_dst` features, `ins` =
+    [(n_src, F_src, E)] incoming edge types, random plain weights.  Returns the fused-call tuple (weight stream packed
+    with packing's slice image), the split path's sweep tuples (ggnn_period_gat_aggregate_enc_batch, where the source
+    has <= 11 features) and its gate-epilogue tuple, all from the same weights."""
+    from graingraphnn_amd.packing import CELL_P3_CHANNEL, _plane_slices, _spread16, bf16_planes, value_fragments
     G, n_in = 3, len(ins)
     Ka = 96 * n_in + 4
     Kg = (Ka + 31) // 32 * 32
     ncols = 16 * G * n_in + 96 * G
-    xd = torch.from_numpy(rs.uniform(0, 1, (n_dst, 8)).astype(np.float32)).to(DEV)
-    ws_t = torch.from_numpy(rs.uniform(-0.5, 0.5, (9, 96 * G)).astype(np.float32)).to(DEV)
-    p_dst = torch.from_numpy(rs.uniform(-2, 2, (n_dst, ncols)).astype(np.float32)).to(DEV)
-    p_dst[:, :16 * G * n_in].view(n_dst, G * n_in, 16)[:, :, 11] = 0   # the score tail is 0 in the bias slot
-    s_off = 16 * G * n_in
-    p_dst[:, s_off:] = xd @ ws_t[:8] + ws_t[8]                          # the skip term, as the split path reads it
-    w2 = torch.from_numpy(rs.uniform(-0.2, 0.2, (G, 96, Ka)).astype(np.float32)).to(DEV)
+    f = lambda *shape, lo=-1.0, hi=1.0: torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32)).to(DEV)
+    xd = f(n_dst, F_dst, lo=0.0)
+    xs16 = torch.zeros(n_dst, 16, device=DEV)
+    xs16[:, :F_dst], xs16[:, 12] = xd, 1.0
+    S = torch.zeros(G, 96, 16, device=DEV)                          # summed skip + gate bias on the 16 feature slots
+    S[:, :, :F_dst], S[:, :, 12] = f(G, 96, F_dst, lo=-0.5, hi=0.5), f(G, 96, lo=-0.5, hi=0.5)
+    w2 = f(G, 96, Ka, lo=-0.2, hi=0.2)
     w2[:, :, 96 * n_in + 2 * n_in:] = 0
-    fused_sweeps, split_sweeps = [], []
+    p3 = torch.tensor(CELL_P3_CHANNEL, device=DEV)
+    p_dst = torch.zeros(n_dst, ncols, device=DEV)                   # what the split path's projection would hold
+    s_off = 16 * G * n_in
+    p_dst[:, s_off:] = (xs16 @ S.reshape(G * 96, 16).t())
+    fused_sweeps, split_sweeps, blocks = [], [], {}
     agg = torch.zeros(n_dst, G * Kg, device=DEV)
     for d, (n_src, F, E) in enumerate(ins):
         src = rs.randint(0, max(n_src - 5, 1), size=E)
@@ -956,20 +962,43 @@ def _enc_cell_problem(be, rs, n_dst, ins, hub=0, regular=False):
         dst[:hub] = min(7, n_dst - 1)
         if regular:                                                 # every destination the same in-degree (timing tools)
             dst = rs.permutation(np.repeat(np.arange(n_dst), E // n_dst))
+        if edges is not None:                                       # a given structure (timing tools): [2, E] per edge type
+            src, dst = edges[d][0], edges[d][1]
         ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
-        xs = torch.from_numpy(rs.uniform(0, 1, (n_src, F)).astype(np.float32)).to(DEV)
-        ea = torch.from_numpy(rs.uniform(0.01, 0.1, E).astype(np.float32)).to(DEV)
-        Wv = [torch.from_numpy(rs.uniform(-1, 1, (96, F)).astype(np.float32)).to(DEV) for _ in range(G)]
-        bv = [torch.from_numpy(rs.uniform(-1, 1, 96).astype(np.float32)).to(DEV) for _ in range(G)]
+        xs = f(n_src, F, lo=0.0)
+        ea = f(E, lo=0.01, hi=0.1)
+        Wv = [f(96, F) for _ in range(G)]
+        bv = [f(96) for _ in range(G)]
         csr = be.build_csr(ei, n_src, n_dst)
         einfo = torch.zeros(E + 3, 20, device=DEV)
         be.edge_prepare([(csr, ea, xs, xd, einfo)])
-        fused_sweeps.append((csr, einfo, value_fragments_bias(Wv, bv, F), 16 * G * d, F))
+        fused_sweeps.append((csr, einfo))
+        for g in range(G):
+            T = torch.zeros(16, 16, device=DEV)                     # u4 = T [x | 1]: rows = record slots the tail meets
+            T[:, :F_dst], T[:, 12] = f(16, F_dst, lo=-2.0, hi=2.0), f(16, lo=-2.0, hi=2.0)
+            T[14:] = 0                                              # tail slots 14, 15 are always zero
+            if F <= 11:
+                T[11] = 0                                           # ... and so is the slot that holds 1 for the value bias
+            V = torch.zeros(96, 16, device=DEV)
+            V[:, :F], V[:, 12] = Wv[g], bv[g]
+            blocks[(g, d)] = (_plane_slices(_spread16(torch.cat([V, T]))),
+                              _plane_slices(w2[g][:, p3 + 96 * d].contiguous()))
+            p_dst[:, 16 * (G * d + g): 16 * (G * d + g + 1)] = xs16 @ T.t()
         if F <= 11:
             split_sweeps.append((csr, einfo, p_dst, value_fragments(Wv, bv, F), agg, 16 * G * d, 96 * d, Kg,
                                  96 * n_in + 2 * d, G))
-    out = [torch.empty(n_in, n_dst, 288, device=DEV), torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV)]
-    fused = (fused_sweeps, p_dst, xd, ws_t, w2, gate_fragments(w2), *out)
+    slices = []
+    for g in range(G):
+        for d in range(n_in):
+            slices += list(blocks[(g, d)])
+        slices.append(_plane_slices(_spread16(S[g])))
+    wstream = torch.cat(slices).contiguous().view(-1)
+    tail = torch.zeros(G, n_in, 6, 4, 16, device=DEV)
+    for d in range(n_in):
+        tail[:, d, :, 0] = w2[:, :, 96 * n_in + 2 * d].view(G, 6, 16)
+        tail[:, d, :, 3] = w2[:, :, 96 * n_in + 2 * d + 1].view(G, 6, 16)
+    out = [torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV)]
+    fused = (fused_sweeps, xd, wstream, tail.view(G, n_in, 6, 64).contiguous(), *out)
     h_s, c_s = torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV)
     gate = (agg, w2, p_dst, s_off, None, h_s, c_s, None, G, 1, bf16_planes(w2), Kg)
     return fused, split_sweeps, gate
@@ -979,40 +1008,40 @@ def _enc_cell_problem(be, rs, n_dst, ins, hub=0, regular=False):
     (236, [(118, 11, 708), (236, 8, 708)], 0),      # junctions of the 40 um fixture: two incoming edge types
     (118, [(236, 8, 708)], 0),                      # grains: one
     (1, [(1, 11, 1)], 0), (5, [(9, 8, 11), (5, 8, 0)], 0), (17, [(30, 12, 60)], 0), (33, [(40, 8, 0), (33, 8, 0)], 0),
-    (50, [(70, 8, 400), (70, 11, 1300)], 37), (50, [(70, 11, 1300)], 900),
+    (50, [(70, 8, 400), (70, 11, 1300)], 37), (50, [(70, 11, 1300)], 900), (67, [(30, 8, 500)], 0),
     (20000, [(10000, 11, 60000), (20000, 8, 60000)], 0), (10000, [(20000, 8, 60000)], 0)])
 @torch.no_grad()
-def test_fused_encoder_cell_equals_sweep_plus_gate_epilogue(n_dst, ins, hub):
-    """ggnn_encoder_cell_batch (sweep and gate GEMM in one kernel, aggregates in LDS) against the torch
-    emulation of its contract and against ggnn_period_gat_aggregate_enc_batch + ggnn_lstm_epilogue: the
-    fixture sizes, fewer than 16 rows, a ragged last tile, edge types without edges, 12 source features, a hub
-    row of degree `hub`, rows without edges, cfg3 sizes; bit-reproducible."""
+def test_fused_encoder_cell_against_its_contract(n_dst, ins, hub):
+    """ggnn_encoder_cell_batch (round 4: score tails, sweeps, lin_l2, skip and LSTM update of a 16-node tile in ONE
+    kernel, nothing but x, the edge records and the weight stream read) against the torch emulation of its contract
+    evaluated on the DECODED weight stream, and against ggnn_period_gat_aggregate_enc_batch + ggnn_lstm_epilogue on
+    the same weights: the fixture sizes, fewer than 16 rows, ragged last tiles and surplus waves, edge types without
+    edges, 12 source features, a hub row of degree `hub` (300 units), rows without edges, cfg3 sizes;
+    bit-reproducible (no atomics)."""
     from emulator import TorchEmulatorBackend
+    from graingraphnn_amd.backend import CSR
     be = backend()
     rs = np.random.RandomState(n_dst + 7 * len(ins) + hub)
     fused, split_sweeps, gate = _enc_cell_problem(be, rs, n_dst, ins, hub)
     be.encoder_cell_batch([fused])
-    pre, h, c = fused[6:]
-    # CPU emulation of the documented contract
+    h, c = fused[4:]
     cpu = lambda t: t.cpu() if torch.is_tensor(t) else t
-    from graingraphnn_amd.backend import CSR
-    sw_cpu = [(CSR(cs.rowptr.cpu(), cs.col.cpu(), cs.perm.cpu(), cs.row.cpu(), None, None, cs.E), ei.cpu(), wv.cpu(), u4, F)
-              for cs, ei, wv, u4, F in fused[0]]
-    ref = [torch.empty(len(ins), n_dst, 288), torch.empty(n_dst, 96), torch.empty(n_dst, 96)]
-    TorchEmulatorBackend().encoder_cell_batch([(sw_cpu, *[cpu(t) for t in fused[1:6]], *ref)])
-    for name, got, want in zip(("pre", "h", "c"), (pre, h, c), ref):
-        assert_close(got, want, f"fused encoder cell {name}", 1e-5, 2e-6)
+    sw_cpu = [(CSR(cs.rowptr.cpu(), cs.col.cpu(), cs.perm.cpu(), cs.row.cpu(), None, None, cs.E), ei.cpu())
+              for cs, ei in fused[0]]
+    ref = [torch.empty(n_dst, 96), torch.empty(n_dst, 96)]
+    TorchEmulatorBackend().encoder_cell_batch([(sw_cpu, *[cpu(t) for t in fused[1:4]], *ref)])
+    assert_close(h, ref[0], "fused encoder cell h", 2e-5, 2e-6)
+    assert_close(c, ref[1], "fused encoder cell c", 2e-5, 2e-6)
     if len(split_sweeps) == len(ins):
         be.aggregate_enc_batch(split_sweeps)
         be.lstm_epilogue(*gate)
-        assert_close(h, gate[5], "fused vs split h", 1e-5, 2e-6)
-        assert_close(c, gate[6], "fused vs split c", 1e-5, 2e-6)
-    keep = [t.clone() for t in (pre, h, c)]
-    for t in (pre, h, c):
-        t.fill_(float("nan"))
+        assert_close(h, gate[5], "fused vs split h", 2e-5, 2e-6)
+        assert_close(c, gate[6], "fused vs split c", 2e-5, 2e-6)
+    keep = [h.clone(), c.clone()]
+    h.fill_(float("nan")), c.fill_(float("nan"))
     be.encoder_cell_batch([fused])
-    for a, b in zip(keep, (pre, h, c)):
-        assert torch.equal(a, b)                                    # no atomics: bit-reproducible
+    assert torch.equal(keep[0], h) and torch.equal(keep[1], c)      # no atomics: bit-reproducible
+    assert not be.range_exceeded(DEV)                               # O(1) operands: nothing was clamped
 
 
 @torch.no_grad()
@@ -1020,16 +1049,16 @@ def test_fused_encoder_cell_batch_of_four_equals_single_calls():
     """Four problems (two node types x two models) in one ggnn_encoder_cell_batch = four single calls."""
     be = backend()
     rs = np.random.RandomState(5)
-    shapes = [(2086, [(1043, 11, 6258), (2086, 8, 6258)]), (1043, [(2086, 8, 6258)]),
-              (2086, [(1043, 11, 6258), (2086, 8, 6258)]), (1043, [(2086, 8, 6258)])]
-    probs = [_enc_cell_problem(be, rs, n, ins)[0] for n, ins in shapes]
+    shapes = [(2086, [(1043, 11, 6258), (2086, 8, 6258)], 8), (1043, [(2086, 8, 6258)], 11),
+              (2086, [(1043, 11, 6258), (2086, 8, 6258)], 8), (1043, [(2086, 8, 6258)], 11)]
+    probs = [_enc_cell_problem(be, rs, n, ins, F_dst=F)[0] for n, ins, F in shapes]
     be.encoder_cell_batch(probs)
-    batched = [[t.clone() for t in p[6:]] for p in probs]
+    batched = [[t.clone() for t in p[4:]] for p in probs]
     for p, want in zip(probs, batched):
-        for t in p[6:]:
+        for t in p[4:]:
             t.fill_(float("nan"))
         be.encoder_cell_batch([p])
-        for a, b in zip(p[6:], want):
+        for a, b in zip(p[4:], want):
             assert torch.equal(a, b)
     with pytest.raises(_lib.GGNNError):
         be.encoder_cell_batch(probs + probs[:1])                    # at most four problems
@@ -1238,8 +1267,8 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
         # second forward -- the classifier's first call -- and is part of the tape key, so the regressor's tape of
         # step 0 (recorded with the estimate) is recorded again at step 1; results are the same either way.
         # (the fused decoder cell -- the default plan -- is projection + one kernel instead of projection + sweeps + gates)
-        n_launches = 7 - (1 if be.fused_encoder else 0) - (1 if be.fused_decoder else 0)
-        assert replays == [n_launches] * 5, replays
+        n_launches = 7 - (2 if be.fused_encoder else 0) - (1 if be.fused_decoder else 0)
+        assert replays == [n_launches] * 6, replays
         # new weights -> the tape is dropped and re-recorded
         R.linear["joint"].bias.add_(0.5)
         R.gclstm_decoder.cell_list[0].b_i["joint"].add_(0.1)
