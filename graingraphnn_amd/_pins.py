@@ -25,4 +25,7 @@ def collect(sink: list):
     try:
         yield sink
     finally:
-        _sinks.remove(sink)
+        for i in range(len(_sinks) - 1, -1, -1):   # by identity: two sinks that hold the same notes compare equal
+            if _sinks[i] is sink:
+                del _sinks[i]
+                break

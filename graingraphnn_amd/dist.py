@@ -29,31 +29,40 @@ def _staging(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().cpu() if dist.get_backend() == "gloo" else t.contiguous()
 
 
+def pack_state(state: Dict[str, torch.Tensor]):
+    """A dict of tensors as ONE byte buffer (keys in sorted order, every segment 16-byte aligned so that it can be
+    viewed back as its own dtype) + the layout needed to take it apart again: (packed uint8 tensor, keys, sizes)."""
+    keys = sorted(state)
+    flat, sizes = [], []
+    for k in keys:
+        b = state[k].contiguous().view(-1).view(torch.uint8)
+        sizes.append(b.numel())
+        pad = -b.numel() % 16
+        flat.append(torch.cat([b, b.new_zeros(pad)]) if pad else b)
+    return (torch.cat(flat) if len(flat) > 1 else flat[0]), keys, sizes
+
+
+def unpack_state(buf: torch.Tensor, keys, sizes, like: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Inverse of pack_state on a (received) buffer: tensors with the device, dtype and shape of `like`'s."""
+    d, off = {}, 0
+    for k, n in zip(keys, sizes):
+        ref = like[k]
+        d[k] = buf[off:off + n].to(ref.device).view(ref.dtype).view(ref.shape)
+        off += n + (-n % 16)
+    return d
+
+
 def gather_states(state: Dict[str, torch.Tensor], world: int) -> List[Dict[str, torch.Tensor]]:
     """All-gather a dict of tensors whose shapes and dtypes agree across ranks; returns one dict per
     rank (rank order).  ONE collective whatever the number of keys: the tensors travel as one packed
     byte buffer (a collective per key would pay the launch + ring latency of a small message each)."""
     if world <= 1 or not dist.is_initialized():
         return [state]
-    keys = sorted(state)
-    flat, sizes = [], []
-    for k in keys:
-        b = state[k].contiguous().view(-1).view(torch.uint8)
-        sizes.append(b.numel())
-        pad = -b.numel() % 16  # every segment starts 16-byte aligned: it is viewed back as its own dtype
-        flat.append(torch.cat([b, b.new_zeros(pad)]) if pad else b)
-    packed = _staging(torch.cat(flat) if len(flat) > 1 else flat[0])
+    packed, keys, sizes = pack_state(state)
+    packed = _staging(packed)
     bufs = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(bufs, packed)
-    out = []
-    for r in range(world):
-        d, off = {}, 0
-        for k, n in zip(keys, sizes):
-            ref = state[k]
-            d[k] = bufs[r][off:off + n].to(ref.device).view(ref.dtype).view(ref.shape)
-            off += n + (-n % 16)
-        out.append(d)
-    return out
+    return [unpack_state(bufs[r], keys, sizes, state) for r in range(world)]
 
 
 def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, world: int,

@@ -454,8 +454,18 @@ class GrainRollout:
             self.step()
         return self.pred
 
+    def range_exceeded(self, clear=True) -> bool:
+        """True when a fused cell has clamped an activation to fp16's range since the last check (include/ggnn.h,
+        OPERAND RANGE): the trajectory since then is NOT the reference's -- re-run with GGNN_DEC=split GGNN_ENC=split.
+        state() checks it (it synchronises anyway); one 4-byte read-back."""
+        return self.be.range_exceeded(self.x["joint"].device, clear)
+
     def state(self):
-        """Final state a caller gathers across ranks: joint xy and grain (area, extraV)."""
+        """Final state a caller gathers across ranks: joint xy and grain (area, extraV).  Raises when the fused
+        cells reported an operand beyond their arithmetic's range on the way here."""
+        if self.range_exceeded():
+            raise _lib.GGNNError("an activation reached fp16's range (+-65504) in a fused cell: this trajectory was computed "
+                            "with clamped operands; re-run with GGNN_DEC=split GGNN_ENC=split (full fp32 range)")
         return {"joint_xy": self.x["joint"][:, :2].clone(), "grain_area_v": self.x["grain"][:, 3:5].clone()}
 
     def edge_attr_dict(self):

@@ -8,6 +8,9 @@ nearest neighbour.  This script, run in THIS container only (needs /root/referen
 
   * graingraphnn_amd/data/gr_span_grid.npz -- the table itself (data: G, R, span, G_min, G_max, R_min, R_max),
     which `synthetic.span_for(G, R)` reads;
+  (ONE-OFF, sandbox only: `dill.load` of that pickle executes whatever it contains -- never run this on a machine or a
+  pickle you do not trust; the shipped .npz is the artefact, nobody needs to re-run this.)
+
   * tests/golden/gr_span_pins.npz -- (G, R) pairs with the span the reference's own expression
     (`scipy.interpolate.griddata(..., method='nearest')` on the unpickled dict, evaluated here) returns for them.
 

@@ -1,8 +1,9 @@
 """Child process of tests/test_training.py::test_ddp_over_rccl_as_the_reference_wraps_it: the RCCL ('nccl')
 process group of dist_train.py:76-82 on ONE GPU (world size 1) -- init_process_group('nccl', device_id=cuda:0),
-graingraphnn_amd.dist.gather_states on device tensors (one packed all-gather), and
-DistributedDataParallel(model, device_ids=[0]) for two iterations whose gradients must equal the unwrapped
-model's bit for bit.  Its own process, so that no communicator lives inside the pytest process.
+the pieces of graingraphnn_amd.dist.gather_states' multi-rank branch (pack_state -> all_gather -> unpack_state) on
+device buffers through the communicator, and DistributedDataParallel(model, device_ids=[0]) for two iterations whose
+gradients must equal the unwrapped model's bit for bit.  (Two ranks over RCCL: tests/rccl_worker2.py, which needs
+two GPUs.)  Its own process, so that no communicator lives inside the pytest process.
 Prints 'RCCL_OK ...' on success; any failure is an exception (non-zero exit)."""
 import os
 import sys
@@ -18,7 +19,7 @@ from torch.nn.parallel import DistributedDataParallel  # noqa: E402
 
 from helpers import load_graph, product_models, tt  # noqa: E402
 from graingraphnn_amd import training  # noqa: E402
-from graingraphnn_amd.dist import gather_states  # noqa: E402
+from graingraphnn_amd.dist import gather_states, pack_state, unpack_state  # noqa: E402
 from test_training import _targets  # noqa: E402
 
 
@@ -38,15 +39,20 @@ def main():
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
         assert dist.get_backend() == "nccl"
-        # the packed all-gather on DEVICE buffers, through the communicator (world 2 is claimed so that
-        # gather_states does not take its single-rank shortcut; the group itself has one rank)
+        # gather_states' multi-rank branch piece by piece on DEVICE buffers through the communicator (the group has
+        # one rank, for which gather_states itself returns [state] by contract): mixed dtypes, segments that start at
+        # 16-byte offsets inside the packed buffer
         state = {"joint_xy": X["joint"][:, :2].clone(), "grain_area_v": X["grain"][:, 3:5].clone(),
-                 "step": torch.tensor([7], dtype=torch.int64, device=dev)}
-        packed = torch.cat([state[k].contiguous().view(-1).view(torch.uint8) for k in sorted(state)])
+                 "step": torch.tensor([7], dtype=torch.int64, device=dev),
+                 "flags": torch.tensor([1, 0, 1], dtype=torch.uint8, device=dev),
+                 "half": torch.arange(5, device=dev).to(torch.float16)}
+        packed, keys, sizes = pack_state(state)
+        assert packed.is_cuda and packed.numel() % 16 == 0
         bufs = [torch.empty_like(packed)]
         dist.all_gather(bufs, packed)
         torch.cuda.synchronize()
-        assert bufs[0].is_cuda and torch.equal(bufs[0], packed)
+        back = unpack_state(bufs[0], keys, sizes, state)
+        assert all(back[k].is_cuda and back[k].dtype == state[k].dtype and torch.equal(back[k], state[k]) for k in state)
         got = gather_states(state, dist.get_world_size())     # world 1: identity by contract
         assert len(got) == 1 and all(torch.equal(got[0][k], state[k]) for k in state)
         t = torch.ones(4, device=dev)

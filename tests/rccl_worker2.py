@@ -1,0 +1,88 @@
+"""One of the TWO ranks of tests/test_training.py::test_two_ranks_* (its own process per rank, as torchrun would start
+them; dist_train.py:76-93's pattern): init_process_group(backend, device_id=...), then on the HIP path
+  1. graingraphnn_amd.dist.gather_states through its multi-rank branch on DEVICE tensors of mixed dtypes,
+  2. BASELINE config 4 in small: 8 perturbed copies of the 40 um fixture sharded over the two ranks
+     (dist.rollout_trajectories: round-robin shards, one disjoint-union rollout per rank, one all-gather of the results)
+     -- rank 0 also rolls all 8 out alone and the gathered result must equal it bit for bit,
+  3. DistributedDataParallel(model, device_ids=[dev]) on rank-specific mini-batches: the gradients must be the mean of
+     the two ranks' local gradients (each computed here without DDP, exchanged with an all-gather).
+    python rccl_worker2.py PORT RANK BACKEND N_DEVICES
+BACKEND 'nccl' (RCCL; needs one GPU per rank: N_DEVICES >= 2) or 'gloo' (both ranks on cuda:0 -- the same code with host
+staging of the collectives: validates this file on a one-GPU box).  Prints 'RANK<r>_OK' on success."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from torch.nn.parallel import DistributedDataParallel  # noqa: E402
+
+from helpers import load_graph, product_models, tt  # noqa: E402
+from graingraphnn_amd import synthetic, training  # noqa: E402
+from graingraphnn_amd.dist import gather_states, rollout_trajectories  # noqa: E402
+from test_training import _targets  # noqa: E402
+
+WORLD = 2
+
+
+def main():
+    port, rank, backend, n_dev = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    dev = torch.device("cuda", rank % n_dev)
+    torch.cuda.set_device(dev)
+    torch.set_num_threads(1)
+    kw = dict(device_id=dev) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=WORLD, **kw)
+    try:
+        assert dist.get_backend() == backend and dist.get_world_size() == WORLD
+        # 1. the packed all-gather, multi-rank branch, device tensors
+        state = {"a": torch.full((5, 2), float(rank + 1), device=dev),
+                 "step": torch.tensor([10 + rank], dtype=torch.int64, device=dev),
+                 "flags": torch.tensor([rank, 1, rank], dtype=torch.uint8, device=dev)}
+        got = gather_states(state, WORLD)
+        assert len(got) == WORLD
+        for r in range(WORLD):
+            assert got[r]["a"].device == dev and torch.equal(got[r]["a"], torch.full((5, 2), float(r + 1), device=dev))
+            assert int(got[r]["step"]) == 10 + r and got[r]["flags"].tolist() == [r, 1, r]
+        # 2. config 4 in small: trajectories sharded over the ranks == all of them on one rank
+        x0, ei0, ea0 = load_graph("40")
+        graphs = [(synthetic.perturbed_copy(x0, 1e-3, 1000 + t), ei0, ea0) for t in range(8)]
+        R, Cm = product_models(10020, 0.3, dev)
+        sharded = rollout_trajectories(R, Cm, graphs, span=6, n_steps=5, rank=rank, world=WORLD, device=dev)
+        if rank == 0:
+            alone = rollout_trajectories(R, Cm, graphs, span=6, n_steps=5, rank=0, world=1, device=dev)
+            for k in alone:
+                assert sharded[k].shape == alone[k].shape and torch.equal(sharded[k], alone[k]), k
+        dist.barrier()
+        # 3. DDP: gradients = mean over the ranks of the local gradients
+        x, ei, ea, _ = synthetic.disjoint_union(
+            [(synthetic.perturbed_copy(x0, 1e-3, 2000 + 4 * rank + t), ei0, ea0) for t in range(4)])
+        y_np, m_np = _targets(x, ei)
+        y, mask = tt(y_np, dev), tt(m_np, dev)
+        X, EI, EA = tt(x, dev), tt(ei, dev), tt(ea, dev)
+        Rt, _ = product_models(4, 1.0, dev)
+        Rt.train()
+        training.regressor_loss(y, Rt(X, EI, EA), mask).backward()
+        local = {n: p.grad.clone() for n, p in Rt.named_parameters()}
+        Rt.zero_grad()
+        model = DistributedDataParallel(Rt, device_ids=[dev.index])
+        for _ in range(2):
+            model.zero_grad()
+            training.regressor_loss(y, model(X, EI, EA), mask).backward()
+        torch.cuda.synchronize()
+        both = gather_states(local, WORLD)
+        for n, p in Rt.named_parameters():
+            mean = (both[0][n] + both[1][n]) / 2
+            tol = 1e-6 * max(float(mean.abs().max()), 1e-6)
+            assert float((p.grad - mean).abs().max()) <= tol, n
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    print(f"RANK{rank}_OK {backend}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

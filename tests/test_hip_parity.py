@@ -1064,6 +1064,232 @@ def test_fused_encoder_cell_batch_of_four_equals_single_calls():
         be.encoder_cell_batch(probs + probs[:1])                    # at most four problems
 
 
+def _wide(rs, shape, lo, hi, signed=True):
+    """Magnitudes 10^U(lo, hi), element by element (a dynamic range no single scale has), random signs."""
+    v = 10.0 ** rs.uniform(lo, hi, shape)
+    if signed:
+        v = v * rs.choice([-1.0, 1.0], shape)
+    return torch.from_numpy(v.astype(np.float32))
+
+
+def _cell_reference(kind, P, dtype):
+    """One HeteroPGCLSTM cell of the contract (include/ggnn.h), evaluated on the CPU in `dtype` from the ORIGINAL fp32
+    operands and weights of `P` -- nothing decoded from a weight stream: what the reference formulation computes.
+    kind = "dec" (h, c given; four gates) or "enc" (zero state; three gates)."""
+    t = lambda v: v.cpu().to(dtype)
+    x, n = t(P["x_dst"]), P["x_dst"].size(0)
+    G = 4 if kind == "dec" else 3
+    if kind == "dec":
+        xin = torch.cat([t(P["h_dst"]), x, torch.ones(n, 1, dtype=dtype)], 1)                  # [h | x | 1]
+    else:
+        xin = torch.cat([x, torch.ones(n, 1, dtype=dtype)], 1)                                # [x | 1]
+    pre = []
+    for g in range(G):
+        z = xin @ t(P["skip"][g]).t()
+        for d, sw in enumerate(P["sweeps"]):
+            rowptr = sw["rowptr"].cpu().long()
+            E = int(rowptr[-1])
+            dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+            src = sw["col"].cpu().long()[:E]
+            einfo = t(sw["einfo"])
+            x4, reloc, a = einfo[:E, :16], einfo[:E, 16:19], einfo[:E, 19]
+            u = xin @ t(sw["score"][g]).t()                                                    # dec: [n, 96 + 16]; enc: [n, 16]
+            if kind == "dec":
+                sc = (u[dst, :96] * t(sw["h_src"])[src]).sum(-1) + (u[dst, 96:] * x4).sum(-1)
+                val = torch.relu(t(sw["v_src"])[src][:, sw["v_off"] + g * 96: sw["v_off"] + (g + 1) * 96] + reloc @ t(sw["ep"])[g])
+            else:
+                sc = (u[dst] * x4).sum(-1)
+                val = torch.relu(x4 @ t(sw["value"][g]).t())
+            smax = torch.full((n,), float("-inf"), dtype=dtype).scatter_reduce(0, dst, sc, "amax")
+            p = (sc - smax[dst]).exp()
+            den = torch.zeros(n, dtype=dtype).index_add(0, dst, p)
+            alpha = p / (den[dst] + 1e-16)
+            A = torch.zeros(n, 96, dtype=dtype).index_add(0, dst, alpha[:, None] * val)
+            sa = torch.zeros(n, dtype=dtype).index_add(0, dst, alpha)
+            sae = torch.zeros(n, dtype=dtype).index_add(0, dst, alpha * a)
+            z = z + A @ t(sw["l2"][g]).t() + sa[:, None] * t(sw["b_l2"][g])[None] + sae[:, None] * t(sw["w_edge"][g])[None]
+        pre.append(z)
+    if kind == "dec":
+        c = torch.sigmoid(pre[1]) * t(P["c_in"]) + torch.sigmoid(pre[0]) * torch.tanh(pre[2])
+        return torch.sigmoid(pre[3]) * torch.tanh(c), c
+    c = torch.sigmoid(pre[0]) * torch.tanh(pre[1])
+    return torch.sigmoid(pre[2]) * torch.tanh(c), c
+
+
+def _wide_cell_problem(be, kind, rs, n_dst, ins, F_dst, with_edges=True):
+    """A decoder / encoder cell problem whose operands span 1e-4 .. 1e2 element by element, with weights scaled so that
+    the pre-activations stay O(1).  Returns (the C-ABI call tuple, the dict of ORIGINAL fp32 operands and weights)."""
+    G = 4 if kind == "dec" else 3
+    d_ = lambda v: v.to(DEV)
+    xd = _wide(rs, (n_dst, F_dst), -4, 2, signed=False)
+    P = {"x_dst": d_(xd), "sweeps": []}
+    K = (96 if kind == "dec" else 0) + F_dst + 1
+    if kind == "dec":
+        P["h_dst"] = d_(torch.tanh(_wide(rs, (n_dst, 96), -4, 0.5)))
+        P["c_in"] = d_(_wide(rs, (n_dst, 96), -4, 0.3))
+    # every weight row is scaled by what it multiplies, so that sum |x||w| ~ 1 .. 10 per output
+    feat_scale = 1.0 / (float(xd.abs().mean()) * F_dst + (30.0 if kind == "dec" else 0.0) + 1.0)
+    wrow = lambda rows, cols, s: _wide(rs, (rows, cols), -2, 0) * s
+    P["skip"] = [d_(wrow(96, K, feat_scale)) for _ in range(G)]
+    for d, (n_src, F, E) in enumerate(ins):
+        E = E if with_edges else 0
+        src = rs.randint(0, max(n_src - 5, 1), size=E)
+        dst = rs.randint(1 if n_dst > 1 else 0, n_dst, size=E)
+        ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV)
+        xs = _wide(rs, (n_src, F), -4, 2, signed=False)
+        xs[:, :3] = torch.from_numpy(rs.uniform(0, 1, (n_src, 3)).astype(np.float32))   # coordinates stay in the unit box
+        ea = torch.from_numpy(rs.uniform(0.01, 0.1, E).astype(np.float32)).to(DEV)
+        csr = be.build_csr(ei, n_src, n_dst)
+        einfo = torch.zeros(E + 3, 20, device=DEV)
+        be.edge_prepare([(csr, ea, d_(xs), P["x_dst"], einfo)])
+        rec_scale = 1.0 / (float(xs[:, 3:].abs().mean()) * max(F - 3, 1) + 2.0)
+        sw = {"rowptr": csr.rowptr, "col": csr.col, "einfo": einfo, "csr": csr,
+              "l2": [d_(wrow(96, 96, 0.05)) for _ in range(G)], "b_l2": [d_(wrow(96, 1, 0.3)[:, 0]) for _ in range(G)],
+              "w_edge": [d_(wrow(96, 1, 0.3)[:, 0]) for _ in range(G)]}
+        if kind == "dec":
+            sw["h_src"] = d_(torch.tanh(_wide(rs, (n_src, 96), -4, 0.5)))
+            sw["v_src"] = d_(_wide(rs, (n_src, 384 * (d + 1) + 96), -4, 1))
+            sw["v_off"] = 384 * d
+            sw["ep"] = d_(_wide(rs, (4, 3, 96), -2, 0))
+            score = []
+            for g in range(G):
+                W1 = torch.zeros(112, K)
+                W1[:96] = wrow(96, K, 0.02 * feat_scale)            # u_h rows (they meet h_src in (-1, 1))
+                W1[96:110] = wrow(14, K, rec_scale * feat_scale)     # u4 rows (they meet the edge record)
+                score.append(d_(W1))
+            sw["score"] = score
+        else:
+            score, value = [], []
+            for g in range(G):
+                T = torch.zeros(16, K)
+                T[:14] = wrow(14, K, rec_scale * feat_scale)
+                if F <= 11:
+                    T[11] = 0
+                V = torch.zeros(96, 16)
+                V[:, :F], V[:, 12] = wrow(96, F, rec_scale), wrow(96, 1, 0.3)[:, 0]
+                score.append(d_(T))
+                value.append(d_(V))
+            sw["score"], sw["value"] = score, value
+        P["sweeps"].append(sw)
+    return _rebuild_wide_call(be, kind, P)
+
+
+@pytest.mark.parametrize("kind", ["dec", "enc"])
+@torch.no_grad()
+def test_fused_cells_are_fp32_equivalent_on_wide_range_operands(kind):
+    """The two-piece fp16 arithmetic of the fused cells (csrc/common.h: split_f16x2, three MFMA products) pinned ON THE
+    GPU: operands spanning 1e-4 .. 1e2 element by element through ggnn_decoder_cell_batch / ggnn_encoder_cell_batch
+    against an fp64 evaluation of the same cell from the ORIGINAL fp32 weights (not the decoded stream, so the weight
+    split is inside the comparison).  (i) Whole cells: the error of (h, c) must not exceed that of a plain fp32
+    evaluation of the same formulas (torch CPU float32) by more than a factor two.  (ii) One GEMM in isolation -- a
+    cell without in-edges is its skip product, and with the other gates' weights zero c' = tanh(pre) / 2 can be
+    inverted: normalised by sum |x||w| the product must be within 2e-7 of fp64 (a plain fp32 fma chain: 2e-7 .. 7e-7).
+    Nothing is clamped on the way (range flag)."""
+    be = backend()
+    rs = np.random.RandomState(11 if kind == "dec" else 12)
+    ins = [(3000, 11, 18000), (6000, 8, 18000)]
+    call, P = _wide_cell_problem(be, kind, rs, 6000, ins, 8)
+    run = be.decoder_cell_batch if kind == "dec" else be.encoder_cell_batch
+    run([call])
+    h, c = call[-2].cpu().double(), call[-1].cpu().double()
+    r64 = _cell_reference(kind, P, torch.float64)
+    r32 = _cell_reference(kind, P, torch.float32)
+    for name, got, ref, f32 in (("h", h, r64[0], r32[0]), ("c", c, r64[1], r32[1])):
+        scale = float(ref.abs().max())
+        e_hip = float((got - ref).abs().max()) / scale
+        e_f32 = float((f32.double() - ref).abs().max()) / scale
+        assert e_hip <= 2.0 * e_f32 + 5e-7, f"{kind} cell {name}: HIP {e_hip:.2e} vs plain fp32 {e_f32:.2e} of max|ref|"
+        assert e_hip < 1e-5, f"{kind} cell {name}: {e_hip:.2e}"
+    # (ii) the skip GEMM alone: no edges; gates i and o with zero weights -> c' = tanh(pre_c) / 2
+    call, P = _wide_cell_problem(be, kind, rs, 4096, ins, 8, with_edges=False)
+    gc = 2 if kind == "dec" else 1                                          # the cell gate's index (i, f, c, o | i, c, o)
+    for g in range(len(P["skip"])):
+        if g != gc:
+            P["skip"][g].zero_()
+    if kind == "dec":
+        P["c_in"].zero_()
+    n = P["x_dst"].size(0)
+    xin = torch.cat(([P["h_dst"].cpu().double()] if kind == "dec" else []) + [P["x_dst"].cpu().double(), torch.ones(n, 1, dtype=torch.float64)], 1)
+    P["skip"][gc].mul_(1.5 / float((xin.abs() @ P["skip"][gc].cpu().double().abs().t()).median()))   # sum |x||w| ~ 1.5
+    call, _ = _rebuild_wide_call(be, kind, P)
+    run([call])
+    c = call[-1].cpu().double()
+    W = P["skip"][gc].cpu().double()
+    ref, norm = xin @ W.t(), xin.abs() @ W.abs().t()
+    ok = ref.abs() < 1.0                                                    # where atanh(2 c') is well conditioned
+    assert float(ok.double().mean()) > 0.25
+    pre = torch.atanh((2.0 * c).clamp(-0.999, 0.999))
+    # the read-out itself -- c' = tanh(pre) / 2 formed on the hardware exp / rcp units (absolute error <= ~3e-7,
+    # common.h) and stored as fp32 -- has a floor of 3e-7 d pre / d c' = 6e-7 / (1 - tanh(pre)^2)
+    floor = 6e-7 / (1.0 - torch.tanh(ref) ** 2)
+    err = float((((pre - ref).abs() - floor).clamp(min=0) / norm)[ok].max())
+    assert err < 2e-7, f"{kind} cell, skip product alone: {err:.2e} of sum |x||w|"
+    assert not be.range_exceeded(DEV)
+
+
+def _rebuild_wide_call(be, kind, P):
+    """(call tuple, P): the operands and ORIGINAL weights of `P` in the kernels' weight-stream image; again after an
+    in-place edit of the weights."""
+    from graingraphnn_amd.packing import CELL_P3_CHANNEL, DC_GATE_ORDER, _plane_slices, _spread16
+    G = 4 if kind == "dec" else 3
+    n_dst, F_dst = P["x_dst"].shape
+    n_in = len(P["sweeps"])
+    K = (96 if kind == "dec" else 0) + F_dst + 1
+    p3 = torch.tensor(CELL_P3_CHANNEL, device=DEV)
+
+    def in128(W):
+        out = torch.zeros(W.size(0), 128, device=DEV)
+        out[:, :K] = W
+        return out
+
+    def slots16(W):
+        out = torch.zeros(W.size(0), 16, device=DEV)
+        out[:, :F_dst], out[:, 12] = W[:, :F_dst], W[:, F_dst]
+        return out
+
+    slices = []
+    for g in (DC_GATE_ORDER if kind == "dec" else range(3)):
+        for sw in P["sweeps"]:
+            if kind == "dec":
+                slices += [_plane_slices(in128(sw["score"][g])), _plane_slices(sw["l2"][g])]
+            else:
+                slices += [_plane_slices(_spread16(torch.cat([sw["value"][g], slots16(sw["score"][g])]))),
+                           _plane_slices(sw["l2"][g][:, p3].contiguous())]
+        slices.append(_plane_slices(in128(P["skip"][g]) if kind == "dec" else _spread16(slots16(P["skip"][g]))))
+    wstream = torch.cat(slices).contiguous().view(-1)
+    tail = torch.zeros(G, n_in, 6, 4, 16, device=DEV)
+    for d, sw in enumerate(P["sweeps"]):
+        for g in range(G):
+            tail[g, d, :, 0] = sw["b_l2"][g].view(6, 16)
+            tail[g, d, :, 1 if kind == "dec" else 3] = sw["w_edge"][g].view(6, 16)
+    tail = tail.view(G, n_in, 6, 64).contiguous()
+    out = [torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV)]
+    if kind == "dec":
+        return ([(sw["csr"], sw["einfo"], sw["h_src"], sw["v_src"], sw["v_off"], sw["ep"]) for sw in P["sweeps"]],
+                P["x_dst"], P["h_dst"], P["c_in"], wstream, tail, *out), P
+    return ([(sw["csr"], sw["einfo"]) for sw in P["sweeps"]], P["x_dst"], wstream, tail, *out), P
+
+
+@pytest.mark.parametrize("kind", ["dec", "enc"])
+@torch.no_grad()
+def test_fused_cells_report_an_activation_beyond_fp16_range(kind):
+    """include/ggnn.h, OPERAND RANGE: an activation at or beyond 65504 is clamped by the two-piece split AND reported
+    through the flag word (backend.range_exceeded); in-range operands leave the flag alone."""
+    be = backend()
+    rs = np.random.RandomState(3)
+    ins = [(118, 11, 708), (236, 8, 708)]
+    call, P = _wide_cell_problem(be, kind, rs, 236, ins, 8)
+    run = be.decoder_cell_batch if kind == "dec" else be.encoder_cell_batch
+    be.range_exceeded(DEV)                     # clear
+    run([call])
+    assert not be.range_exceeded(DEV)
+    P["x_dst"][17, 5] = 7.0e4                  # one feature beyond fp16's range
+    run([call])
+    assert be.range_exceeded(DEV)              # reported (and cleared by the read)
+    assert not be.range_exceeded(DEV)
+    assert bool(torch.isfinite(call[-2]).all())   # clamped, not poisoned
+
+
 def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
     """Random decoder-cell problem (ggnn_decoder_cell_batch): destination type with `F_dst` features, `ins` =
     [(n_src, F_src, E)] incoming edge types, random weight blocks packed by packing._plane_slices in the stream's

@@ -142,6 +142,33 @@ def _run_model_emulated(model, x, ei, ea, fused_decoder=True):
     return be, graph, h
 
 
+@torch.no_grad()
+def test_weights_beyond_fp16_range_fall_back_to_the_unfused_plans():
+    """include/ggnn.h, OPERAND RANGE: the fused cells compute with two fp16 pieces per operand, so a weight at or beyond
+    65504 (or a non-finite one) cannot be packed for them.  pack_cell then leaves their streams out (no exception) and
+    the cell runs on sweep + gate GEMM launches, whose bf16 x 3 split covers fp32's range: same outputs as the oracle."""
+    x, ei, ea = load_graph("40")
+    R, _ = product_models(4, 1.0)
+    Ro, _ = oracle_models(4, 1.0)
+    for model in (R, Ro):   # one huge (finite) weight in an encoder value layer and in a decoder skip layer
+        enc = model.gclstm_encoder.cell_list[0].conv_i.convs["grain__push__joint"]
+        dec = model.gclstm_decoder.cell_list[0].conv_o.convs["joint__connect__joint"]
+        enc.lin_value.weight[5, 4] = 1.0e5
+        dec.lin_skip.weight[7, 3] = -2.0e5
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    enc_pc = R.gclstm_encoder.cell_list[0].packed(True)
+    dec_pc = R.gclstm_decoder.cell_list[0].packed(False, R._live_out)
+    assert not enc_pc.ecs and not dec_pc.dcs                  # no fused operands: the weights cannot be split
+    be, graph, h = _run_model_emulated(R, X, EI, EA)
+    assert "encoder_cell_batch" not in getattr(be, "calls", []) and "decoder_cell_batch" not in getattr(be, "calls", [])
+    w, b = packing.pack_regressor_heads(R.linear)
+    yj, yg, area = torch.empty(X["joint"].size(0), 2), torch.empty(X["grain"].size(0), 2), torch.empty(X["grain"].size(0))
+    be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
+    want = Ro(X, EI, EA)
+    assert_close(yj, want["joint"], "range fallback joint", TOL)
+    assert_close(yg, want["grain"], "range fallback grain", TOL)
+
+
 def test_fp16_two_piece_split_is_fp32_equivalent():
     """The arithmetic of the fused decoder cell and of the encoder cell's gate GEMM (csrc/common.h: split_f16x2,
     mfma_x3h; packing.split2_f16): x = hi + lo' / 2^11 with two fp16 pieces, three of the four products, the cross

@@ -330,6 +330,56 @@ def test_ddp_over_rccl_as_the_reference_wraps_it():
     print(r.stdout.strip().splitlines()[-1])
 
 
+def _run_two_ranks(backend, n_dev):
+    """Start tests/rccl_worker2.py twice (ranks 0 and 1, as torchrun would) and wait for both."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker2.py")
+    procs = [subprocess.Popen([sys.executable, script, str(port), str(r), backend, str(n_dev)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK{r}_OK" in so, (r, so[-2000:], se[-4000:])
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_shard_trajectories_and_average_gradients():
+    """tests/rccl_worker2.py with both ranks on cuda:0 (RCCL refuses two ranks per device: the group is gloo, the
+    collectives are staged through the host): gather_states' multi-rank branch on device tensors, config 4 in small
+    sharded over two ranks == one rank bit for bit, DDP gradients == the mean of the ranks' local gradients.  The
+    RCCL run of the same file needs two GPUs (next test)."""
+    _run_two_ranks("gloo", 1)
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """The same two-rank worker over RCCL ('nccl', init_process_group(device_id=...), one GPU per rank, device-buffer
+    collectives over xGMI) and `bench.py --gpus 2` reporting two RCCL ranks.  Skipped on a one-GPU box."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one RCCL rank per device)")
+    _run_two_ranks("nccl", 2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+
+
 def _ddp_gpu_worker(rank, world, port, out):
     """One of two ranks that share cuda:0 (the GPU box has one device and RCCL refuses two ranks
     per device, so the process group is gloo; DistributedDataParallel, the bucketed gradient

@@ -1,5 +1,6 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 OUT=gpurun_out/pmclds
 mkdir -p $OUT
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_]*LDS[A-Z_]*\|SQ_INSTS_LDS\|SQ_WAIT_INST_LDS\|SQ_ACTIVE_INST_LDS" | sort -u > $OUT/avail.txt

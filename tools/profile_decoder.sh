@@ -2,8 +2,9 @@
 # Decoder cell, fused vs split (gpurun -- bash tools/profile_decoder.sh TAG): per-kernel rocprofv3 stats and
 # HBM-side request counters (separate --pmc passes) of `bench.py --profile --no-graph --serial` with the decoder
 # as one fused kernel (GGNN_DEC=fused) and as projection + sweeps + gate GEMM (default).  -> gpurun_out/TAG/
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 OUT=gpurun_out/${1:-decoder}
 mkdir -p $OUT
 for mode in fused split; do

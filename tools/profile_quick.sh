@@ -1,8 +1,9 @@
 #!/bin/bash
 # Quick per-kernel table of the step (gpurun -- bash tools/profile_quick.sh TAG [extra bench flags]):
 # rocprofv3 --kernel-trace --stats of `bench.py --profile --no-graph --serial` -> gpurun_out/TAG_kernel_table.txt
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 TAG=${1:-quick}
 shift
 OUT=gpurun_out/$TAG

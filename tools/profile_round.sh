@@ -3,8 +3,9 @@
 # plans (default = fused decoder cell; GGNN_DEC=split = projection + sweeps + gate GEMM, with tools/pmc_aggregate.py
 # for its sweep), per-kernel rocprofv3 stats of the step in its launch modes, and the bench lines.
 # Everything lands in gpurun_out/TAG/.
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 OUT=gpurun_out/${1:-round}
 mkdir -p $OUT
 for plan in fused split; do

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Training-step kernel table (gpurun -- bash tools/profile_train.sh TAG): rocprofv3 kernel trace (rocpd .db) of
 # `tests/bench_train_step.py --cfg3 --steps 20 --no-cpu` -> gpurun_out/TAG/train_kernel_table.txt + the wall figure.
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 OUT=gpurun_out/${1:-train}
 mkdir -p $OUT
 timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/tr -- python3 tests/bench_train_step.py --cfg3 --steps 20 --no-cpu > $OUT/train.log 2>&1
