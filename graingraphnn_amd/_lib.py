@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
-    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_heads_regressor_backward",
+    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -132,6 +132,17 @@ class WgradArgs(Structure):
         ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("a_bstride", c_int64), ("b_bstride", c_int64), ("K", c_int64),
         ("M", c_int32), ("Nc", c_int32), ("batch", c_int32), ("n_split", c_int32),
+    ]
+
+
+class RowGemmArgs(Structure):
+    """Mirror of `ggnn_rowgemm_args`."""
+    _fields_ = [
+        ("a", c_void_p), ("w", c_void_p), ("c", c_void_p), ("c_in", c_void_p), ("workspace", c_void_p),
+        ("workspace_bytes", c_size_t),
+        ("M", c_int64), ("lda", c_int64), ("ldc", c_int64), ("a_bstride", c_int64), ("c_bstride", c_int64),
+        ("w_bstride", c_int64), ("w_nstride", c_int64), ("w_kstride", c_int64),
+        ("K", c_int32), ("n_out", c_int32), ("batch", c_int32), ("precision", c_int32),
     ]
 
 
@@ -235,6 +246,10 @@ def _declare(lib):
     lib.ggnn_wgrad_splits.argtypes = [c_int64, c_int, c_int, c_int]
     lib.ggnn_wgrad.restype = c_int
     lib.ggnn_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
+    lib.ggnn_rowgemm_workspace_bytes.restype = c_size_t
+    lib.ggnn_rowgemm_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.ggnn_rowgemm.restype = c_int
+    lib.ggnn_rowgemm.argtypes = [POINTER(RowGemmArgs), c_void_p]
     lib.ggnn_heads_regressor_backward.restype = c_int
     lib.ggnn_heads_regressor_backward.argtypes = [c_int64, c_int64] + [c_void_p] * 11
     lib.ggnn_heads_classifier.restype = c_int

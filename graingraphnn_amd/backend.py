@@ -43,6 +43,7 @@ class HipBackend:
         self.lib = _lib.load()
         self._tape = None  # while a list: every hot-path launch is also recorded as (cfunc, name, cargs)
         self._range_flags = {}  # device -> int32 word the fp16 two-piece kernels report clamped activations in
+        self._rowgemm_ws = {}   # (device, bytes) -> weight-plane workspace of ggnn_rowgemm
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
@@ -445,6 +446,47 @@ class HipBackend:
         w.M, w.Nc, w.batch, w.n_split = M, Nc, batch, S
         self._launch(self.lib.ggnn_wgrad, "ggnn_wgrad", ctypes.byref(w), _lib.current_stream())
         return partial.sum(0) if S > 1 else partial[0]
+
+    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False):
+        """ggnn_rowgemm (include/ggnn.h): out[b] = a[b] . W[b]^T (+ c_in[b]) for b < batch.
+        `a`   : [M, lda] (batch 1) or [batch, M, lda] float32 view with unit column stride: the first K columns;
+        `w`   : [batch, n_out, >= K] (transposed=False: W[b] = w[b][:, :K]) or [batch, K, >= n_out] (transposed=True:
+                W[b] = w[b][:, :n_out]^T -- a gradient uses the transpose of the forward's weight), or 2-D for batch 1;
+        `out` : [M, ldc] / [batch, M, ldc] float32 view with unit column stride: its first n_out columns are written;
+        `c_in`: optional, same layout as out (may be out itself)."""
+        _require_cuda(a, w, out, c_in)
+        if a.dim() == 2:
+            a = a.unsqueeze(0)
+        if out.dim() == 2:
+            out = out.unsqueeze(0)
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        if c_in is not None and c_in.dim() == 2:
+            c_in = c_in.unsqueeze(0)
+        for t, name in ((a, "a"), (w, "w"), (out, "out"), (c_in, "c_in")):
+            if t is not None and (t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1):
+                raise _lib.GGNNError(f"ggnn_rowgemm: {name} must be a float32 [batch, rows, cols] view with unit column stride")
+        M = a.size(1)
+        if a.size(0) != batch or out.size(0) != batch or w.size(0) != batch or out.size(1) != M or a.size(2) < K \
+                or out.size(2) < n_out or (c_in is not None and (c_in.shape != out.shape or c_in.stride() != out.stride())):
+            raise _lib.GGNNError("ggnn_rowgemm: operand shapes do not match (batch, M, K, n_out)")
+        if (transposed and (w.size(1) < K or w.size(2) < n_out)) or (not transposed and (w.size(1) < n_out or w.size(2) < K)):
+            raise _lib.GGNNError("ggnn_rowgemm: w does not hold [n_out, K] (or its transpose)")
+        nbytes = self.lib.ggnn_rowgemm_workspace_bytes(K, n_out, batch)
+        ws = self._rowgemm_ws.get((a.device, nbytes))
+        if ws is None:   # one plane buffer per (device, size): the calls of a step are stream-ordered
+            ws = self._rowgemm_ws[(a.device, nbytes)] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
+        g = _lib.RowGemmArgs()
+        g.a, g.w, g.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        g.c_in = None if c_in is None else c_in.data_ptr()
+        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+        g.M, g.lda, g.ldc = M, a.stride(1), out.stride(1)
+        g.a_bstride, g.c_bstride, g.w_bstride = a.stride(0) if batch > 1 else 0, out.stride(0) if batch > 1 else 0, \
+            w.stride(0) if batch > 1 else 0
+        g.w_nstride, g.w_kstride = (1, w.stride(1)) if transposed else (w.stride(1), 1)
+        g.K, g.n_out, g.batch, g.precision = K, n_out, batch, _lib.GGNN_PRECISION_BF16 if bf16 else 0
+        self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
+        return out
 
     # -- heads -------------------------------------------------------------------------
     def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):

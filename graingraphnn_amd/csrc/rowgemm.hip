@@ -1,0 +1,235 @@
+// Training path: the three dense products of a HeteroPGCLSTM cell that round 2 left to the BLAS
+// library -- the gate GEMM z_g = agg_g W2_g^T (forward), its input gradient g_agg_g = g_z_g W2_g and the hidden-state
+// gradient g_h += gP Wp[:, h] (training.py) -- as one hand-written kernel: C[b] = A[b] . W[b]^T (+ C_in) for a TALL
+// A [M, K] (M = nodes: 10^4 .. 10^5, K = 96 .. 2112) and a SMALL W [n_out <= 224, K].
+//
+// Same machinery as the fused cells (cell_common.h): a wave owns ONE 16-row tile of A for the whole reduction and
+// keeps its 16 x n_out output tile in registers; the weights stream past as k-step slices of pre-split planes
+// ([column tile][plane][64 lanes][8 halfs], packed once per call from the fp32 parameters by rowgemm_pack_kernel:
+// they change with every optimizer step) through a double-buffered LDS region shared by the workgroup's eight
+// waves (LDS-DMA one slice ahead, one barrier per slice); the rows arrive as B-fragment-shaped 32-byte pieces
+// (the four k-groups of a row = one 128-byte line), one k-step ahead in registers.
+// Arithmetic: fp32 mode = two fp16 pieces / three products per operand pair (common.h: 5e-8 of sum |a||w| against
+// fp64, an fp32 fma chain: 2e-7); GGNN_PRECISION_BF16 (torch.autocast(bfloat16), BASELINE config 5) = ONE bf16 plane,
+// one product, fp32 accumulation: a third of the matrix work and half the weight bytes.
+#include <algorithm>
+
+#include "common.h"
+#include "cell_common.h"
+
+namespace ggnn {
+
+constexpr int RG_WAVES = 8;
+constexpr int RG_MAX_CT = 14;                 // n_out <= 224
+
+// lane l = 16 kq + m of piece (b, ks, ct, plane): W[b][16 ct + m][32 ks + 8 kq .. +7]
+template <bool BF16>
+__global__ __launch_bounds__(256) void rowgemm_pack_kernel(const ggnn_rowgemm_args A, u32x4* __restrict__ out, int nks,
+                                                           int nct) {
+  constexpr int P = BF16 ? 1 : 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b, ks, ct, lane)
+  if (i >= (int64_t)A.batch * nks * nct * 64) return;
+  const int lane = (int)(i & 63);
+  int64_t r = i >> 6;
+  const int ct = (int)(r % nct);
+  r /= nct;
+  const int ks = (int)(r % nks), b = (int)(r / nks);
+  const int n = 16 * ct + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+  const float* w = A.w + (int64_t)b * A.w_bstride + (int64_t)n * A.w_nstride;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (n < A.n_out && k0 + j < A.K) ? w[(int64_t)(k0 + j) * A.w_kstride] : 0.f;
+  u32x4* dst = out + ((((int64_t)b * nks + ks) * nct + ct) * P) * 64 + lane;
+  if constexpr (BF16) {
+    u32x4 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = pack_bf16(v[2 * e], v[2 * e + 1]);
+    dst[0] = q;
+  } else {
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t q0, q1;
+      split_f16x2(v[2 * e], v[2 * e + 1], q0, q1);
+      hi[e] = q0;
+      lo[e] = q1;
+    }
+    dst[0] = hi;
+    dst[64] = lo;
+  }
+}
+
+// Weight slices (one k-step each) travel in GROUPS of GS: one barrier and one counted wait per group, and the rows of
+// the whole NEXT group (GS x 32 bytes per lane) are requested at the top of the current one -- ~100 KB of rows in
+// flight per compute unit: the kernel streams A from HBM once, and a request per k-step (the first version) had
+// every k-step wait out a full memory round trip (125 us for the 169 MB of the joints' g_h; the library: 102).
+template <int NCT, bool BF16>
+__global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowgemm_args A, const u32x4* __restrict__ planes,
+                                                                const int nks) {
+  constexpr int P = BF16 ? 1 : 2;
+  constexpr int SLICE = NCT * P * 1024;
+  // k-steps per group: 4 (n_out <= 128); n_out = 224: 2 in bf16, 1 in fp32 mode (112 accumulator registers: no room for
+  // more rows in flight; its reductions are 3 k-steps long)
+  constexpr int GS = NCT > 8 ? (BF16 ? 2 : 1) : 4;
+  static_assert(2 * GS * SLICE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GS * SLICE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  const int64_t M = A.M;
+  // a ragged last tile slides back over rows the previous tile also produces (identical duplicate stores); surplus
+  // waves repeat the last tile: every wave runs the whole program (the group barriers need no special case)
+  const int64_t row0 = std::max<int64_t>(0, std::min<int64_t>(((int64_t)blockIdx.x * RG_WAVES + wave) * 16, M - 16));
+  const int64_t row = std::min<int64_t>(row0 + lr, M - 1);
+
+  const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(planes) + lane * 16;
+  const uint32_t slice_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
+  const int gpb = (nks + GS - 1) / GS;             // groups per batch entry (the last one may be short)
+  const int n_groups = A.batch * gpb;
+  auto group_steps = [&](int q) { return std::min(GS, nks - (q % gpb) * GS); };
+  auto dma_group = [&](int q) {
+    if (q >= n_groups) return;
+    const int b = q / gpb, ks0 = (q - b * gpb) * GS;
+    const unsigned char* src = wsrc + (size_t)(b * nks + ks0) * SLICE;       // the slices of a batch entry are contiguous
+    const uint32_t dst = slice_lds + (q & 1) * (GS * SLICE);
+    const int np = group_steps(q) * NCT * P;
+    for (int p = wave; p < np; p += RG_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
+  };
+  f32x4 rows[2][GS][2];                            // [parity][k-step of the group][half]: this lane's 32-byte row pieces
+  auto load_rows = [&](int q, f32x4 (&r)[GS][2]) __attribute__((always_inline)) {
+    const int qq = std::min(q, n_groups - 1);      // (past the end: a harmless repeat of the last group's loads)
+    const int b = qq / gpb, ks0 = (qq - b * gpb) * GS;
+    const float* __restrict__ arow = A.a + (int64_t)b * A.a_bstride + row * A.lda + 8 * kq;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int ks = std::min(ks0 + i, nks - 1);   // (a short last group repeats its last k-step: loaded, not used)
+      r[i][0] = ld16f(arow + 32 * ks);
+      r[i][1] = ld16f(arow + 32 * ks + 4);
+    }
+  };
+  dma_group(0);
+  load_rows(0, rows[0]);
+  float unused_amax = 0.f;
+
+  int q = 0;
+  for (int b = 0; b < A.batch; ++b) {
+    float* __restrict__ crow = A.c + (int64_t)b * A.c_bstride + row * A.ldc + 4 * kq;
+    DcAcc acc[NCT];   // (bf16 mode: the cross terms stay zero and the compiler drops them)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct].zero();
+    if (A.c_in != nullptr) {
+      const float* __restrict__ cin = A.c_in + (int64_t)b * A.c_bstride + row * A.ldc + 4 * kq;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        if (16 * ct < A.n_out) acc[ct].m = ld16f(cin + 16 * ct);
+    }
+    for (int g = 0; g < gpb; ++g, ++q) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of group q and its rows have landed
+      __syncthreads();                                   // ... everybody's have; nobody reads group q - 1 any more
+      dma_group(q + 1);
+      const u32x4* pw = reinterpret_cast<const u32x4*>(smem + (q & 1) * (GS * SLICE)) + lane;
+      const int ns = group_steps(q);
+      auto run_group = [&](f32x4 (&cur)[GS][2], f32x4 (&nxt)[GS][2]) __attribute__((always_inline)) {
+        load_rows(q + 1, nxt);                           // the next group's rows: in flight during this group's MFMAs
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+          if (i < ns) {
+            u32x4 xb[DC_PL];
+            if constexpr (BF16) {
+              xb[0] = (u32x4){pack_bf16(cur[i][0][0], cur[i][0][1]), pack_bf16(cur[i][0][2], cur[i][0][3]),
+                              pack_bf16(cur[i][1][0], cur[i][1][1]), pack_bf16(cur[i][1][2], cur[i][1][3])};
+            } else {
+              dc_split(cur[i][0], cur[i][1], xb, unused_amax);
+            }
+            const u32x4* ps = pw + i * (SLICE / 16);
+            if constexpr (BF16) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct) {
+                acc[ct].m = mfma_bf16(ps[ct * 64], xb[0], acc[ct].m);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              }
+            } else {
+              dc_kstep<NCT>(ps, xb, acc);
+            }
+          }
+        }
+      };
+      if (q & 1) run_group(rows[1], rows[0]);
+      else run_group(rows[0], rows[1]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (16 * ct < A.n_out) {
+        *reinterpret_cast<f32x4*>(crow + 16 * ct) = BF16 ? acc[ct].m : acc[ct].value();
+      }
+    }
+  }
+}
+
+template <int NCT>
+static int rowgemm_launch(const ggnn_rowgemm_args& A, const u32x4* planes, int nks, hipStream_t st) {
+  const int64_t n_wg = (A.M + 16 * RG_WAVES - 1) / (16 * RG_WAVES);
+  if (n_wg >= INT32_MAX) return GGNN_EINVAL;
+  if (A.precision == GGNN_PRECISION_BF16)
+    hipLaunchKernelGGL((rowgemm_kernel<NCT, true>), dim3((unsigned)n_wg), dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+  else
+    hipLaunchKernelGGL((rowgemm_kernel<NCT, false>), dim3((unsigned)n_wg), dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+  return launch_status();
+}
+
+}  // namespace ggnn
+
+// column tiles per weight slice: the kernel is instantiated for 6, 8 and 14 (n_out = 96, 128, 224: the shapes of the
+// training path); other widths run on the next larger one (their surplus column tiles are zero planes, never stored)
+static int rowgemm_tiles(int n_out) {
+  const int nct = (n_out + 15) / 16;
+  return nct <= 6 ? 6 : (nct <= 8 ? 8 : 14);
+}
+
+extern "C" size_t ggnn_rowgemm_workspace_bytes(int32_t K, int32_t n_out, int32_t batch) {
+  if (K <= 0 || n_out <= 0 || n_out > 16 * ggnn::RG_MAX_CT || batch <= 0) return 0;
+  return (size_t)batch * ((size_t)(K + 31) / 32) * rowgemm_tiles(n_out) * 2 * 1024;
+}
+
+extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  const ggnn_rowgemm_args& A = *args;
+  if (!A.a || !A.w || !A.c || !A.workspace || A.M <= 0 || A.batch < 1) return GGNN_EINVAL;
+  if (A.K <= 0 || (A.K & 31) || A.n_out <= 0 || (A.n_out & 15) || A.n_out > 16 * RG_MAX_CT) return GGNN_EINVAL;
+  if (A.lda < A.K || A.ldc < A.n_out || (A.lda & 3) || (A.ldc & 3) || (A.a_bstride & 3) || (A.c_bstride & 3)) return GGNN_EINVAL;
+  if (!aligned16(A.a) || !aligned16(A.c) || !aligned16(A.workspace) || (A.c_in && !aligned16(A.c_in))) return GGNN_EINVAL;
+  if (A.precision != 0 && A.precision != GGNN_PRECISION_BF16) return GGNN_EINVAL;
+  if (A.workspace_bytes < ggnn_rowgemm_workspace_bytes(A.K, A.n_out, A.batch)) return GGNN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (A.precision == 0 && A.n_out > 128) {
+    // fp32 mode wider than 8 column tiles: 14 x (main + cross) accumulators leave no registers for rows in flight
+    // (82 spilled, slower than the library) -- two passes over column halves instead (A is read twice: the wide shape
+    // is the gate GEMM's input gradient, whose reduction is 96 long)
+    ggnn_rowgemm_args H = A;
+    const int half = ((A.n_out / 16 + 1) / 2) * 16;
+    H.n_out = half;
+    int rc = ggnn_rowgemm(&H, stream);
+    if (rc != GGNN_OK) return rc;
+    H.n_out = A.n_out - half;
+    H.w = A.w + (int64_t)half * A.w_nstride;
+    H.c = A.c + half;
+    H.c_in = A.c_in ? A.c_in + half : nullptr;
+    return ggnn_rowgemm(&H, stream);
+  }
+  const int nks = A.K / 32, nct = rowgemm_tiles(A.n_out);
+  u32x4* planes = reinterpret_cast<u32x4*>(A.workspace);
+  const int64_t n_pack = ((int64_t)A.batch * nks * nct * 64 + 255) / 256;
+  if (A.precision == GGNN_PRECISION_BF16)
+    hipLaunchKernelGGL((rowgemm_pack_kernel<true>), dim3((unsigned)n_pack), dim3(256), 0, st, A, planes, nks, nct);
+  else
+    hipLaunchKernelGGL((rowgemm_pack_kernel<false>), dim3((unsigned)n_pack), dim3(256), 0, st, A, planes, nks, nct);
+  if (launch_status() != GGNN_OK) return GGNN_ELAUNCH;
+  switch (nct) {
+    case 6: return rowgemm_launch<6>(A, planes, nks, st);
+    case 8: return rowgemm_launch<8>(A, planes, nks, st);
+    case 14: return rowgemm_launch<14>(A, planes, nks, st);
+    default: return GGNN_EINVAL;
+  }
+}

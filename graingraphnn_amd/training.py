@@ -12,14 +12,16 @@ and the module is in training mode, i.e. inside the reference's loop (train.py:1
     periodGATconv.py:174-175, 204-236) with their hand-written backward `ggnn_period_gat_aggregate_backward`
     (segment-softmax backward, relu mask, atomics-free scatter to the source rows), the LSTM update
     `ggnn_lstm_train_forward / _backward`, every weight gradient through the split-K `ggnn_wgrad`; the gate GEMM,
-    its input gradient and the hidden-state gradient of the projection are library GEMMs;
+    its input gradient and the hidden-state gradient of the projection through `ggnn_rowgemm` (round 4: they were
+    library GEMMs) -- no BLAS call is left inside a cell;
   * the regressor's heads are `_RegressorHeads` (the inference head kernel forward, `ggnn_heads_regressor_backward`
     + `ggnn_wgrad` backward); the classifier's pair heads are `_RowLinear` (weight gradient through `ggnn_wgrad`)
     and a few recorded pointwise ops.
 
-Under `torch.autocast(bfloat16)` (BASELINE config 5) the decoder cell's projection runs in real bf16 arithmetic on
-the HIP kernel (operands rounded to bf16, one MFMA product per k-step, fp32 accumulate: GGNN_PRECISION_BF16), as do
-the recorded 2-D GEMMs around the cells; the sweep, the softmax, the LSTM update and every gradient stay fp32.
+Under `torch.autocast(bfloat16)` (BASELINE config 5) the cells' dense products -- the decoder projection, the gate
+GEMM, its input gradient, the hidden-state gradient -- run in real bf16 arithmetic on the HIP kernels (operands rounded
+to bf16, ONE MFMA product per k-step instead of three or six, fp32 accumulate: GGNN_PRECISION_BF16), as do the recorded
+2-D GEMMs around the cells; the sweep, the softmax, the LSTM update and the weight gradients stay fp32.
 Without autocast everything is fp32-equivalent: same results as the inference path up to fp32 re-association.
 """
 from typing import Dict
@@ -93,14 +95,14 @@ class _PackedCell(torch.autograd.Function):
 
       forward   P[nt] = [x | h] Wp^T + bp             ggnn_project_batch (the inference kernel; one launch)
                 agg   = sweeps(P, h)                   ggnn_period_gat_aggregate_batch (one launch)
-                z     = agg W2^T (per gate, batched)   library GEMM
+                z     = agg W2^T (per gate, batched)   ggnn_rowgemm
                 h', c' = LSTM(z + skip(P), c)          ggnn_lstm_train_forward
       backward  g_z, gP[skip], g_c                     ggnn_lstm_train_backward
                 g_W2 = g_z^T agg                       ggnn_wgrad (reduction over the nodes, split over the chip)
-                g_agg = g_z W2                         library GEMM
+                g_agg = g_z W2                         ggnn_rowgemm
                 gP[u, u4, v], g_h (source side), g_ep  ggnn_period_gat_aggregate_backward per edge type
                 g_[Wp | bp] = gP^T [x | h | 1]         ggnn_wgrad
-                g_h += gP Wp[:, h columns]             library GEMM
+                g_h += gP Wp[:, h columns]             ggnn_rowgemm
 
     Inputs (x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep x 3, w2_g, w2_j) with the packed matrices as
     train_pack.packed_weights lays them out (wp [ncols, Fp + k2], w2 [G, 96, Kg]); h / c None = zero state
@@ -147,7 +149,10 @@ class _PackedCell(torch.autograd.Function):
         z, out = {}, []
         for nt in NODE_TYPES:
             lay, n = layout[nt], x[nt].size(0)
-            z[nt] = torch.bmm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt].transpose(1, 2))    # [G, N, 96]
+            # the gate GEMM z_g = agg_g W2_g^T (ggnn_rowgemm: two-piece fp16 = fp32-equivalent; one bf16 product under
+            # torch.autocast(bfloat16))
+            z[nt] = torch.empty(G, n, C, **f32)
+            backend.rowgemm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt], z[nt], lay.Kg, C, batch=G, bf16=bf16)
             h_new, c_new = torch.empty(n, C, **f32), torch.empty(n, C, **f32)
             backend.lstm_train_forward(z[nt], P[nt], lay.s_off, c[nt], h_new, c_new)
             out += [h_new, c_new]
@@ -155,7 +160,7 @@ class _PackedCell(torch.autograd.Function):
         for nt in NODE_TYPES:
             saved += [x[nt], h[nt], c[nt], wp[nt], w2[nt], P[nt], agg[nt], z[nt]]
         ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES])
-        ctx.misc = (backend, topo, layout, G, sees_h)
+        ctx.misc = (backend, topo, layout, G, sees_h, bf16)
         ctx.set_materialize_grads(False)
         return tuple(out)                                           # h_grain, c_grain, h_joint, c_joint
 
@@ -163,7 +168,7 @@ class _PackedCell(torch.autograd.Function):
     @once_differentiable   # (a second derivative through the hand-written backward fails loudly)
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_hg, g_cg, g_hj, g_cj):
-        backend, topo, layout, G, sees_h = ctx.misc
+        backend, topo, layout, G, sees_h, bf16 = ctx.misc
         t = ctx.saved_tensors
         x, h, c, wp, w2, P, agg, z, c_new = {}, {}, {}, {}, {}, {}, {}, {}, {}
         for k, nt in enumerate(NODE_TYPES):
@@ -189,7 +194,8 @@ class _PackedCell(torch.autograd.Function):
             g_w2[nt] = backend.wgrad(g_z, agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
                                      b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
-            torch.bmm(g_z, w2[nt], out=g_agg[nt].view(n, G, lay.Kg).transpose(0, 1))
+            backend.rowgemm(g_z, w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
+                            transposed=True, bf16=bf16)                                        # g_agg_g = g_z_g W2_g
         gh_src = {nt: None for nt in NODE_TYPES}
         # the per-wave partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
         n_part = [backend.aggregate_bwd_partials(x[et[-1]].size(0)) for et in EDGE_TYPES]
@@ -212,7 +218,10 @@ class _PackedCell(torch.autograd.Function):
             xin = torch.cat(parts + [_ones(P[nt].device, n, 1 + (-(Kp + 1)) % 4)], 1)   # [.. | 1 | 0 ..]: 4 k columns
             g_wpb = _wgrad2d(backend, gP[nt], xin)                                          # [ncols, Kp + 1 + pad]
             g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
-            g_h[nt] = torch.addmm(gh_src[nt], gP[nt], wp[nt][:, Fp:]) if sees_h else None     # [N, 96]
+            g_h[nt] = None
+            if sees_h:   # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]                 [N, 96]
+                g_h[nt] = backend.rowgemm(gP[nt], wp[nt][:, Fp:Fp + C], torch.empty(n, C, **f32), lay.ncols, C,
+                                          c_in=gh_src[nt], transposed=True, bf16=bf16)
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
                 g_w2["grain"], g_w2["joint"], None, None, None, None, None, None)

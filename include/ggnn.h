@@ -420,6 +420,33 @@ typedef struct ggnn_dec_cell_args {
 int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training path: C[b] = A[b] . W[b]^T (+ C_in[b]) for a TALL A and a SMALL W -- the gate GEMM of a cell
+ * (z_g = agg_g W2_g^T), its input gradient (g_agg_g = g_z_g W2_g) and the hidden-state gradient
+ * (g_h += gP Wp[:, h columns]) of graingraphnn_amd/training.py, which replaces torch.bmm / torch.addmm there.
+ *   a        : element (b, m, k) at a + b * a_bstride + m * lda + k        (M rows, K % 32 == 0, lda % 4 == 0)
+ *   w        : element (b, n, k) at w + b * w_bstride + n * w_nstride + k * w_kstride  (n_out <= 224, n_out % 16 == 0;
+ *              either orientation of a stored matrix: a gradient uses the transpose of the forward's weight)
+ *   c, c_in  : element (b, m, n) at c + b * c_bstride + m * ldc + n; c_in optional (may equal c)
+ *   precision: 0 = fp32-equivalent (two fp16 pieces per operand, three MFMA products; |a|, |w| < 65504);
+ *              GGNN_PRECISION_BF16 = one bf16 product, fp32 accumulation (what torch.autocast(bfloat16) defines)
+ *   workspace: ggnn_rowgemm_workspace_bytes(K, n_out, batch) bytes, 16-byte aligned: the weights as MFMA operand
+ *              planes (re-packed by every call: they change with every optimizer step)
+ * a, c, c_in 16-byte aligned.  Two launches (pack, product); the product keeps a wave's 16 x n_out output tile in
+ * registers and streams the weight planes through LDS. */
+typedef struct ggnn_rowgemm_args {
+  const float* a;
+  const float* w;
+  float* c;
+  const float* c_in;
+  void* workspace;
+  size_t workspace_bytes;
+  int64_t M, lda, ldc, a_bstride, c_bstride, w_bstride, w_nstride, w_kstride;
+  int32_t K, n_out, batch, precision;
+} ggnn_rowgemm_args;
+size_t ggnn_rowgemm_workspace_bytes(int32_t K, int32_t n_out, int32_t batch);
+int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Output heads.
  * Regressor (models.py:433-452): y_joint = tanh(W_j h_j + b_j); y_grain = W_g h_g + b_g;
  * grain_area = tanh(y_grain[:,0])/20 + x_grain[:,3]; y_grain[:,0] = tanh; y_grain[:,1] = relu.

@@ -331,6 +331,24 @@ class TorchEmulatorBackend:
         return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), oa + k * a_bstride).t()
                             @ torch.as_strided(fb, (K, Nc), (ldb, 1), ob + k * b_bstride) for k in range(batch)])
 
+    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False):
+        """ggnn_rowgemm: out[b][:, :n_out] = a[b][:, :K] W[b]^T (+ c_in[b]); W[b] = w[b][:n_out, :K] or, transposed,
+        w[b][:K, :n_out]^T.  (bf16: the product of bf16-rounded operands, fp32 accumulation.)"""
+        a3 = a if a.dim() == 3 else a.unsqueeze(0)
+        w3 = w if w.dim() == 3 else w.unsqueeze(0)
+        o3 = out if out.dim() == 3 else out.unsqueeze(0)
+        c3 = None if c_in is None else (c_in if c_in.dim() == 3 else c_in.unsqueeze(0))
+        for b in range(batch):
+            W = w3[b][:K, :n_out].t() if transposed else w3[b][:n_out, :K]
+            A = a3[b][:, :K]
+            if bf16:
+                A, W = A.bfloat16().float(), W.bfloat16().float()
+            res = A @ W.t()
+            if c3 is not None:
+                res = res + c3[b][:, :n_out]
+            o3[b][:, :n_out] = res
+        return out
+
     def project_batch(self, problems):
         """(x, F, h, wp, bp, out[, precision]); precision GGNN_PRECISION_BF16: both operands rounded to bf16, products
         accumulated in fp32 (what the HIP kernel's single-product mode computes)."""

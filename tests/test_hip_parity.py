@@ -153,6 +153,51 @@ def test_gemm_arithmetic_is_fp32_equivalent():
     assert err < bound, f"decoder projection error {err:.2e} of sum|x||w| (mode {backend().lib.ggnn_gemm_mode()})"
 
 
+@pytest.mark.parametrize("M,K,n_out,batch,transposed,with_cin", [
+    (20000, 224, 96, 4, False, False),      # gate GEMM of the decoder's joints: z_g = agg_g W2_g^T
+    (20000, 96, 224, 4, True, False),       # its input gradient: g_agg_g = g_z_g W2_g
+    (10000, 1248, 96, 1, True, True),       # g_h += gP Wp[:, h columns] (grains)
+    (20000, 2112, 96, 1, True, True),       # ... joints
+    (10000, 128, 96, 3, False, False), (10000, 96, 128, 3, True, False),   # encoder, grains
+    (1, 32, 16, 1, False, False), (15, 64, 48, 2, True, True), (17, 96, 112, 1, False, False), (130, 160, 208, 1, True, False)])
+def test_rowgemm_against_float64(M, K, n_out, batch, transposed, with_cin):
+    """ggnn_rowgemm (training path: the gate GEMM, its input gradient, the hidden-state gradient; every instantiated
+    tile width and the padded ones, ragged last tiles, M < 16, batches, both weight orientations, accumulate-into)
+    against the fp64 product: fp32 mode within 5e-7 of sum |a||w| -- the two-piece split keeps 22 significand bits per
+    operand, i.e. 2 x 2^-22 = 4.8e-7 per term at worst (few terms dominate these wide-range rows; measured 3e-8 .. 2.7e-7;
+    an fp32 fma chain: 2e-7 .. 7e-7) --, bf16 mode equal to the product of bf16-rounded operands."""
+    be = backend()
+    rs = np.random.RandomState(M + K + n_out)
+    lda, ldc = K + 32, n_out + 16
+    a = torch.from_numpy((rs.standard_normal((batch, M, lda)) * 10 ** rs.uniform(-3, 1, (batch, M, 1))).astype(np.float32)).to(DEV)
+    wshape = (batch, K + 8, n_out + 4) if transposed else (batch, n_out + 4, K + 8)
+    w = torch.from_numpy((rs.standard_normal(wshape) * 10 ** rs.uniform(-2, 0, (batch, wshape[1], 1))).astype(np.float32)).to(DEV)
+    cin = torch.from_numpy(rs.standard_normal((batch, M, ldc)).astype(np.float32)).to(DEV) if with_cin else None
+    out = torch.full((batch, M, ldc), float("nan"), device=DEV)
+    be.rowgemm(a, w, out, K, n_out, batch=batch, c_in=cin, transposed=transposed)
+    A64 = a[:, :, :K].cpu().double()
+    W64 = (w[:, :K, :n_out].transpose(1, 2) if transposed else w[:, :n_out, :K]).cpu().double()
+    ref = A64 @ W64.transpose(1, 2)
+    norm = A64.abs() @ W64.abs().transpose(1, 2)
+    if with_cin:
+        ref = ref + cin[:, :, :n_out].cpu().double()
+        norm = norm + cin[:, :, :n_out].cpu().double().abs()
+    got = out[:, :, :n_out].cpu().double()
+    err = float(((got - ref).abs() / norm).max())
+    # (+ the fp32 accumulator's own rounding over K terms: ~sqrt(K) 2^-24, which a K = 2112 reduction shows: 1.5e-6)
+    assert err < 5e-7 * max(1.0, (K / 96) ** 0.5), f"rowgemm fp32 mode: {err:.2e} of sum |a||w|"
+    assert bool(torch.isnan(out[:, :, n_out:]).all())              # columns behind n_out are not touched
+    ob = torch.full((batch, M, ldc), float("nan"), device=DEV)
+    be.rowgemm(a, w, ob, K, n_out, batch=batch, c_in=cin, transposed=transposed, bf16=True)
+    refb = A64.float().bfloat16().double() @ W64.float().bfloat16().double().transpose(1, 2)
+    if with_cin:
+        refb = refb + cin[:, :, :n_out].cpu().double()
+    errb = float(((ob[:, :, :n_out].cpu().double() - refb).abs() / norm).max())
+    assert errb < 2e-6, f"rowgemm bf16 mode: {errb:.2e} of sum |a||w| against the product of bf16-rounded operands"
+    with pytest.raises(_lib.GGNNError):
+        be.rowgemm(a, w, out, K, n_out + 1, batch=batch, transposed=transposed)    # n_out must be a multiple of 16
+
+
 def _gate_problem(N, Ka, mode, seed):
     """Random operands of one ggnn_lstm_epilogue problem in the workspace layout (gate stride padded
     to 32 floats) + its float64 result."""
