@@ -64,23 +64,30 @@ struct DcAcc {
   __device__ __forceinline__ f32x4 value() const { return m + c * (1.0f / F16X2_SCALE); }
 };
 // One k-step of a GEMM phase: acc[nb] += W[nb] . x for the NB column tiles of the slice at `pw` (= slice base +
-// lane; piece (nb, plane) at (nb * 2 + plane) * 64).  The weight fragments of tile nb + 1 are read while the
-// three MFMAs of tile nb run.
+// lane; piece (nb, plane) at (nb * 2 + plane) * 64).  The weight fragments are read AHEAD column tiles in front of
+// the three MFMAs that use them (1: measured the same as 2 and 3 on both cell kernels -- the k-step is not bound by the
+// latency of its fragment reads -- and 2 costs the encoder cell 8 spilled registers).
+#ifndef GGNN_KSTEP_AHEAD
+#define GGNN_KSTEP_AHEAD 1
+#endif
 template <int NB>
 __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
-  u32x4 wf[2][DC_PL];
+  constexpr int AH = GGNN_KSTEP_AHEAD < NB ? GGNN_KSTEP_AHEAD : NB - 1;
+  u32x4 wf[AH + 1][DC_PL];
 #pragma unroll
-  for (int p = 0; p < DC_PL; ++p) wf[0][p] = pw[p * 64];
-  __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);
+  for (int a = 0; a < AH; ++a)
+#pragma unroll
+    for (int p = 0; p < DC_PL; ++p) wf[a][p] = pw[(a * DC_PL + p) * 64];
+  __builtin_amdgcn_sched_group_barrier(0x100, AH * DC_PL, 0);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    if (nb + 1 < NB) {
+    if (nb + AH < NB) {
 #pragma unroll
-      for (int p = 0; p < DC_PL; ++p) wf[(nb + 1) & 1][p] = pw[((nb + 1) * DC_PL + p) * 64];
+      for (int p = 0; p < DC_PL; ++p) wf[(nb + AH) % (AH + 1)][p] = pw[((nb + AH) * DC_PL + p) * 64];
     }
-    mfma_x3h(wf[nb & 1], xb, acc[nb].m, acc[nb].c);
-    if (nb + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                        // MFMA
+    mfma_x3h(wf[nb % (AH + 1)], xb, acc[nb].m, acc[nb].c);
+    if (nb + AH < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                         // MFMA
   }
 }
 

@@ -48,7 +48,7 @@ static_assert(DC_SLICE == 7 * DC_PL * 1024, "slice = 7 column tiles x planes x 1
 constexpr int DC_NP1 = 7 * DC_PL, DC_NP3 = 6 * DC_PL;   // pieces of a P1 slice / of a P3 or P4 slice
 constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
 constexpr int DC_STAGE = 16 * DC_S * 4;             // 7 424 B
-constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [16 nodes][h 96 | x F | 1 | 0 ..]: B operand of P1 / P4
+constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [h 96 | x F | 1 | 0 ..] as B-fragment planes (7 KB used): B operand of P1 / P4
 constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
 constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
 constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
@@ -121,38 +121,57 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
   };
 
-  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS (read as B fragments by P1 and P4 of every
-  // gate: registers are what the sweep is short of, and a reload from memory behind every sweep sat in front of
-  // P3's first slice -- in-kernel stamps: 1.57 us per P3 slice against 0.6-0.7 for P1 / P4), CSR windows -> LDS ----
-  float* __restrict__ xin = xf;
-  // B-fragment planes of k-step ks of [h | x | 1 | 0]: k-steps 0..2 are the h rows, k-step 3 the 16 feature slots
-  // (k-groups 0 and 1; zeros behind)
+  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS AS THE TWO fp16 PLANES of their B fragments
+  // (read by P1 and P4 of every gate: 12 x 4 k-steps per tile; split once here instead of at every read -- round 4:
+  // the splits were ~100 vector instructions per k-step, 9 us of a tile's 120).  A lane (node lr, k-group kq) only ever
+  // reads the 16-byte slots it writes: [k-step 0..2][plane][lane] and, for the 16 feature slots, [plane][lanes of
+  // k-groups 0 and 1] = 7 KB of the wave's DC_XF bytes.  CSR windows -> LDS. ----
+  unsigned char* __restrict__ xpl = reinterpret_cast<unsigned char*>(xf) + lane * 16;
   auto x_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
-    const float* fr = &xin[lr * DC_S + 32 * ks + 8 * (ks < 3 ? kq : (kq & 1))];
-    f32x4 r0 = *reinterpret_cast<const f32x4*>(fr);
-    f32x4 r1 = *reinterpret_cast<const f32x4*>(fr + 4);
-    if (ks == 3 && kq >= 2) r0 = r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dc_split(r0, r1, out);
+    if (ks < 3) {
+#pragma unroll
+      for (int p = 0; p < DC_PL; ++p) out[p] = *reinterpret_cast<const u32x4*>(xpl + (ks * DC_PL + p) * 1024);
+    } else {   // the feature slots: k-groups 0 and 1 (512 B per plane), zeros behind
+#pragma unroll
+      for (int p = 0; p < DC_PL; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512 - (kq >= 2 ? 512 : 0));
+        out[p] = kq < 2 ? v : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
   };
   {
     float in_max = 0.f;
-    for (int q = lane; q < 16 * 24; q += 64) {   // lane l copies the 16-byte pieces l, l + 64, .. of the 16 x 24 of h
-      const int n = q / 24, c4 = (q - n * 24) * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(A.h_dst + (int64_t)min(row0 + n, n_dst - 1) * A.ldh + c4);
-      *reinterpret_cast<f32x4*>(&xin[n * DC_S + c4]) = v;
-      in_max = fmaxf(fmaxf(in_max, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
-    }
-    // features: lane l -> node l >> 2, slots 4 (l & 3) ..+3 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
-    const int fn = lane >> 2, fq = (lane & 3) * 4;
-    const float* xrow = A.x_dst + (int64_t)min(row0 + fn, n_dst - 1) * A.ldx;
-    f32x4 v;
+    const float* hrow = A.h_dst + (int64_t)min(row0 + lr, n_dst - 1) * A.ldh + 8 * kq;
+    f32x4 hv[3][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xv = xrow[min(fq + j, F - 1)];   // unconditional (clamped) load
-      v[j] = fq + j < F ? xv : (fq + j == F ? 1.0f : 0.0f);
+    for (int ks = 0; ks < 3; ++ks) {
+      hv[ks][0] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks);
+      hv[ks][1] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks + 4);
     }
-    *reinterpret_cast<f32x4*>(&xin[fn * DC_S + C + fq]) = v;
-    in_max = fmaxf(fmaxf(in_max, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    // features: slots 8 (kq & 1) ..+7 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
+    const float* xrow = A.x_dst + (int64_t)min(row0 + lr, n_dst - 1) * A.ldx;
+    f32x4 xv[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sl = 8 * (kq & 1) + j;
+      const float v = xrow[min(sl, F - 1)];   // unconditional (clamped) load
+      xv[j >> 2][j & 3] = sl < F ? v : (sl == F ? 1.0f : 0.0f);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 r0 = ks < 3 ? hv[ks][0] : xv[0], r1 = ks < 3 ? hv[ks][1] : xv[1];
+      in_max = fmaxf(fmaxf(in_max, fmaxf(fmaxf(__builtin_fabsf(r0[0]), __builtin_fabsf(r0[1])), fmaxf(__builtin_fabsf(r0[2]), __builtin_fabsf(r0[3])))),
+                     fmaxf(fmaxf(__builtin_fabsf(r1[0]), __builtin_fabsf(r1[1])), fmaxf(__builtin_fabsf(r1[2]), __builtin_fabsf(r1[3]))));
+      u32x4 pl[DC_PL];
+      dc_split(r0, r1, pl);
+      if (ks < 3) {
+#pragma unroll
+        for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + (ks * DC_PL + p) * 1024) = pl[p];
+      } else if (kq < 2) {
+#pragma unroll
+        for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512) = pl[p];
+      }
+    }
     report_range(!(in_max < 65504.0f));
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
@@ -193,7 +212,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         for (int ks = 0; ks < 4; ++ks) {
           const u32x4* pw = begin_slice(ks < 3 ? DC_NP1 : DC_NP3);   // behind P1: the sweep, then P3's first slice
           dc_kstep<7>(pw, xb[ks & 1], u);
-          if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);   // the next k-step's split runs beside these MFMAs
+          if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();
         }
         // D layout -> stage[node][column]
