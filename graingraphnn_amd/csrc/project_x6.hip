@@ -225,7 +225,10 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(const Proj
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
   const ggnn_project_args& A = B.a[k];
-  const int blk = (int)blockIdx.x - B.wg_off[k], Fp = (A.F + 3) & ~3;
+  // The column tiles of one row split are consecutive logical blocks; dealt to the XCDs in contiguous ranges
+  // (xcd_remap) they run side by side behind ONE L2, which then reads their node rows from memory once instead of once
+  // per column tile (speed only).
+  const int blk = xcd_remap((int)blockIdx.x - B.wg_off[k], B.wg_off[k + 1] - B.wg_off[k]), Fp = (A.F + 3) & ~3;
   if (A.precision == GGNN_PRECISION_BF16) {
     if (Fp == 4) project_x6_body<4, 1>(A, blk, B.m_splits[k], lds);
     else if (Fp == 8) project_x6_body<8, 1>(A, blk, B.m_splits[k], lds);
