@@ -56,6 +56,43 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) pea
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak
 
 
+class _HipEvent:
+    """A HIP event recorded on the launch stream, created without the system-scope release fence
+    (hipEventDisableSystemFence): a time stamp in the stream and nothing else.  (Measured: the fence is not what made
+    round 4's first brackets read high -- the Python wrapper inside them was, see EventTimedBackend._timed.)"""
+    _hip = None
+    DISABLE_SYSTEM_FENCE = 0x20000000
+
+    def __init__(self):
+        import ctypes
+        if _HipEvent._hip is None:
+            _HipEvent._hip = ctypes.CDLL("libamdhip64.so")
+        self._c = ctypes
+        self.h = ctypes.c_void_p()
+        rc = _HipEvent._hip.hipEventCreateWithFlags(ctypes.byref(self.h), ctypes.c_uint(self.DISABLE_SYSTEM_FENCE))
+        if rc != 0:
+            raise RuntimeError(f"hipEventCreateWithFlags: {rc}")
+
+    def record(self):
+        rc = _HipEvent._hip.hipEventRecord(self.h, self._c.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord: {rc}")
+
+    def elapsed_time(self, other):
+        ms = self._c.c_float()
+        _HipEvent._hip.hipEventSynchronize(other.h)
+        rc = _HipEvent._hip.hipEventElapsedTime(self._c.byref(ms), self.h, other.h)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime: {rc}")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _HipEvent._hip.hipEventDestroy(self.h)
+        except Exception:
+            pass
+
+
 class EventTimedBackend:
     """Wraps the HIP backend so that the launches of the four heavy kernel families are bracketed by
     HIP events recorded on the launch stream: the decoder sweep (aggregate_kernel<4, true>, the
@@ -77,10 +114,26 @@ class EventTimedBackend:
         return getattr(self.inner, name)
 
     def _timed(self, key, fn, arg, meta):
-        e0, e1, c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
-        e0.record()
-        fn(arg)
-        e1.record()
+        """Bracket the C-ABI call itself: the backend's Python wrapper (argument checks, ctypes structs: 50-100 us for
+        a cell) runs BEFORE e0 is recorded -- with the encoder cell at 39 us the GPU is no longer behind the host in the
+        eager pass, and a bracket around the wrapper counted its preparation as kernel time (136 against 109 us for
+        the decoder cell in rocprofv3's trace of the same launches)."""
+        e0, e1, c0, c1, c2 = (_HipEvent() for _ in range(5))   # HIP events on the launch stream, no cache-flushing fence
+        inner, n_calls = self.inner, [0]
+        launch = inner._launch
+
+        def bracketed(cfn, name, *cargs):
+            n_calls[0] += 1
+            e0.record()
+            launch(cfn, name, *cargs)
+            e1.record()
+
+        inner._launch = bracketed
+        try:
+            fn(arg)
+        finally:
+            del inner._launch            # back to the class's method
+        assert n_calls[0] == 1, "one C-ABI launch per timed call"
         c0.record()
         self.null.zero_()
         c1.record()
@@ -183,6 +236,12 @@ def measure_roofline(ro, n_steps):
         ro.be, side, joint = timed, ro._side, ro.joint_launches
         ro._side, ro.joint_launches = None, False
         try:
+            # Keep the GPU behind the host for the whole pass: an event bracket spans from the GPU reaching e0 to the GPU
+            # reaching e1, so a launch the host is still preparing when the GPU gets to e0 counts its preparation as
+            # kernel time (round 4: with 39 us encoder cells the eager host path -- ~25 us per C-ABI call -- fell behind
+            # and every bracket read 13-30 us high against rocprofv3).  A spin kernel in front lets the host queue the
+            # pass's ~12 launches per step ahead; the kernels then run back to back as they do in the captured step.
+            torch.cuda._sleep(int(12e6) * n_steps)
             for _ in range(n_steps):
                 ro._enqueue_step()
             torch.cuda.synchronize()
