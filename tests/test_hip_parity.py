@@ -1384,7 +1384,7 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
 @torch.no_grad()
 def test_fused_decoder_cell_against_its_contract(n_dst, ins, hub):
     """ggnn_decoder_cell_batch (destination-side projections, sweep, lin_l2, skip and LSTM update of a 16-node tile
-    in one kernel, weights streamed as bf16 planes) against the torch emulation of its contract evaluated on the
+    in one kernel, weights streamed as two fp16 planes) against the torch emulation of its contract evaluated on the
     DECODED weight stream: fixture sizes, fewer than 16 rows, ragged last tiles and surplus waves, edge types
     without edges, 12 source features, a hub row of degree `hub` (more in-edges than the tile's LDS index window),
     rows without edges, cfg3 sizes; bit-reproducible (no atomics)."""
