@@ -198,7 +198,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) pre[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int e = 0; e < n_in; ++e) {
+    // the edge types are walked forwards for the first and third gate of the stream and backwards for the second and
+    // fourth: the hidden rows and edge records a pass gathered are gathered again by the very next pass (the same edge
+    // type, the next gate) while the XCD's L2 still holds them -- in a fixed order every re-gather came two passes later
+    for (int ei = 0; ei < n_in; ++ei) {
+      const int e = (gi & 1) ? n_in - 1 - ei : ei;
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
       [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
@@ -396,7 +400,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (e + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
+          const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (ei + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
           dc_kstep<6>(pw, xb[ks & 1], part);
           if (ks + 1 < 3) a_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();

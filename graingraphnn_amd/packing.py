@@ -187,6 +187,13 @@ DC_SLICE_I16 = 7 * DC_PLANES * 1024 // 2   # GGNN_DC_SLICE_BYTES / 2: int16 elem
 DC_GATE_ORDER = (0, 2, 1, 3)  # the fused decoder cell walks the gates i, c~, f, o (weights are indexed i, f, c, o)
 
 
+def dc_edge_order(gi: int, items):
+    """(index, item) pairs in the order the fused decoder cell walks its incoming edge types for the gi-th gate of the
+    stream: forwards for gi = 0, 2, backwards for gi = 1, 3 (a pass re-gathers what the pass before it gathered)."""
+    seq = list(enumerate(items))
+    return seq[::-1] if gi & 1 else seq
+
+
 @torch.no_grad()
 def split2_f16(w: torch.Tensor):
     """fp32 -> the two fp16 pieces of the decoder cell's arithmetic (csrc/common.h: split_f16x2): hi = rne16(w),
@@ -233,8 +240,8 @@ def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
         return out
 
     slices = []
-    for g in DC_GATE_ORDER:
-        for d, et in enumerate(lay.dst_ets):
+    for gi, g in enumerate(DC_GATE_ORDER):
+        for d, et in dc_edge_order(gi, lay.dst_ets):
             u = slice(lay.u_off[et] + g * C, lay.u_off[et] + (g + 1) * C)
             t = slice(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4)
             slices.append(_plane_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))))   # P1: 4 slices

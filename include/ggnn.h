@@ -379,7 +379,9 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * per problem (one destination node type of one model):
  *   x_dst [n_dst, ldx], h_dst [n_dst, ldh] (the encoder's h), c_in [n_dst, 96]; h_out, c_out [n_dst, 96]
  *   wstream : the weight slices in the order the kernel consumes them (packing.decoder_cell_stream):
- *             for g in (i, c~, f, o): for e: 4 slices P1(e, g) | 3 slices P3(e, g); then 4 slices P4(g).
+ *             for g in (i, c~, f, o): for e: 4 slices P1(e, g) | 3 slices P3(e, g); then 4 slices P4(g) -- with e running
+ *             FORWARDS over the incoming edge types for the first and third gate and BACKWARDS for the second and fourth
+ *             (a pass re-gathers the hidden rows and edge records the pass before it gathered while L2 still holds them).
  *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, lo'][64 lanes][8 fp16] -- the two
  *             fp16 pieces of a weight w are hi = rne16(w) and lo' = rne16((w - hi) * 2048) (finite, |w| < 65504) --
  *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles

@@ -239,9 +239,10 @@ class TorchEmulatorBackend:
             xin = torch.zeros(n, 128)
             xin[:, :C], xin[:, C:C + F], xin[:, C + F] = h_dst, x_dst, 1.0
             pre, s = {}, 0
-            for g in (0, 2, 1, 3):
+            for gi, g in enumerate((0, 2, 1, 3)):
                 z = torch.zeros(n, C)
-                for d, (csr, einfo, h_src, v_src, v_off, ep) in enumerate(sweeps):
+                order = list(enumerate(sweeps))
+                for d, (csr, einfo, h_src, v_src, v_off, ep) in (order[::-1] if gi & 1 else order):   # ggnn.h: backwards for the 2nd and 4th gate
                     W1 = self._decode_slices(wstream, s, 4, 7)        # [112, 128]
                     W3 = self._decode_slices(wstream, s + 4, 3, 6)    # [96, 96]
                     s += 7

@@ -1293,8 +1293,8 @@ def _rebuild_wide_call(be, kind, P):
         return out
 
     slices = []
-    for g in (DC_GATE_ORDER if kind == "dec" else range(3)):
-        for sw in P["sweeps"]:
+    for gi, g in enumerate(DC_GATE_ORDER if kind == "dec" else range(3)):
+        for sw in (P["sweeps"][::-1] if kind == "dec" and gi & 1 else P["sweeps"]):   # decoder: backwards for the 2nd / 4th gate
             if kind == "dec":
                 slices += [_plane_slices(in128(sw["score"][g])), _plane_slices(sw["l2"][g])]
             else:
@@ -1344,8 +1344,8 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
     f = lambda *shape, lo=-1.0, hi=1.0: torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32)).to(DEV)
     xd, h_dst, c_in = f(n_dst, F_dst, lo=0.0), f(n_dst, 96), f(n_dst, 96)
     slices = []
-    for g in DC_GATE_ORDER:
-        for d in range(n_in):
+    for gi, g in enumerate(DC_GATE_ORDER):
+        for d in (range(n_in - 1, -1, -1) if gi & 1 else range(n_in)):   # (random blocks: only their count matters here)
             W1 = f(112, 128, lo=-0.15, hi=0.15)
             W1[:, 96 + F_dst + 1:] = 0                       # reduction index: h | x | 1 | zeros
             W1[96 + 14:, :] = 0                              # tail slots 14, 15 of u4 are always zero
