@@ -627,9 +627,12 @@ def main():
         step()
     untimed_steps = args.warmup
     if not args.events:
-        # steps per hipGraph (measured, cfg3, 20 / 500 timed steps: 4 -> 0.591 / 0.564 ms per step,
-        # 10 -> 0.587 / 0.582, 20 -> 0.606 / 0.580)
-        ro.RUN_UNROLL = max(1, min(args.steps, int(os.environ.get("GGNN_BENCH_UNROLL", "4"))))
+        # steps per hipGraph (GrainRollout.RUN_UNROLL, the product's knob; its default is 4): the largest divisor of
+        # --steps up to 16, so that the timed region is whole replays of ONE captured graph (round 4, cfg3, 20 / 500
+        # timed steps: 4 -> 2 649-2 699 / 2 867 steps/s, 10 -> 2 689-2 729 / 2 897: a graph-to-graph boundary costs
+        # ~10 us on the GPU); GGNN_BENCH_UNROLL overrides
+        auto_unroll = max([d for d in range(4, 17) if args.steps % d == 0] or [4])
+        ro.RUN_UNROLL = max(1, min(args.steps, int(os.environ.get("GGNN_BENCH_UNROLL", str(auto_unroll)))))
         # untimed: captures the multi-step graph and replays it a few times -- a freshly instantiated graph and a
         # memory system that has seen 5 steps run the first replays ~4 % slower than the steady state the metric
         # is about (measured with --steps 20: 1 872-1 889 steps/s without, 1 940-1 981 with a longer warm-up);
@@ -689,7 +692,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({ro.RUN_UNROLL} steps per graph)") + (", R+C in the same launches (13 per step)" if ro.joint_launches else
+            "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({ro.RUN_UNROLL} steps per graph)") + (", R+C in the same launches" if ro.joint_launches else
                                   ", R|C on two streams" if ro.concurrent else ", R then C on one stream"),
                        "decoder_plan": ("one kernel per decoder cell (ggnn_decoder_cell_batch)"
                                         if getattr(default_backend(), "fused_decoder", False) is True else
