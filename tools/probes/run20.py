@@ -1,5 +1,8 @@
+"""Development probe (round 4; see profiles/r4_dec_cell_ablations.txt / DESIGN.md section 7).  Not part of the product."""
+import os
 import sys, time, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from helpers import product_models, tt
 from graingraphnn_amd import GrainRollout, synthetic
