@@ -509,7 +509,7 @@ def train_step_records():
     import subprocess
     script = os.path.join(ROOT, "tests", "bench_train_step.py")
     out = []
-    for extra in (["--graph", "--fused"], ["--graph", "--fused", "--cfg3"], ["--graph", "--fused", "--cfg3", "--bf16"],
+    for extra in (["--graph", "--fused"], ["--graph", "--fused", "--cfg3", "--roofline"], ["--graph", "--fused", "--cfg3", "--bf16"],
                   ["--graph", "--cfg3"], ["--cfg3"]):
         try:
             r = subprocess.run([sys.executable, script, "--no-cpu", "--json", "--steps", "20"] + extra,

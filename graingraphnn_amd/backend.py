@@ -363,8 +363,8 @@ class HipBackend:
         a.n_src, a.n_dst, a.E, a.n_partials = p_src.size(0), p_dst.size(0), E, n_part
         a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
-        check(self.lib.ggnn_period_gat_aggregate_backward(ctypes.byref(a), _lib.current_stream()),
-              "ggnn_period_gat_aggregate_backward")
+        self._launch(self.lib.ggnn_period_gat_aggregate_backward, "ggnn_period_gat_aggregate_backward", ctypes.byref(a),
+                     _lib.current_stream())
         return g_p_dst, g_p_src, g_h_src, (ep_partial.sum(0) if ep_partial_out is None else None)
 
     def aggregate_bwd_partials(self, n_dst):

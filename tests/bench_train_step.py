@@ -67,6 +67,75 @@ def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fus
     return dt, [float(v.detach()) for v in losses]
 
 
+def kernel_rooflines(model, X, EI, EA, y, mask, autocast):
+    """Live durations of the training path's heavy C-ABI calls inside real (eager) training steps: HIP events on the
+    launch stream bracketing the C call itself (the backend's `_launch`), a spin kernel in front so that the GPU stays
+    behind the host.  Returns one record per call kind: the weight-gradient GEMM against the fp32 matrix pipe it runs on,
+    the sweep's backward and the row GEMMs against HBM (what they touch at least once)."""
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    launch = be._launch
+    rec = {}
+
+    def timed_launch(fn, name, *cargs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch(fn, name, *cargs)
+        e1.record()
+        rec.setdefault(name, []).append((e0, e1, cargs))
+
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    be._launch = timed_launch
+    try:
+        for it in range(4):
+            if it == 1:
+                rec.clear()          # the first step allocates and packs
+            torch.cuda._sleep(int(4e7))
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                loss = training.regressor_loss(y, model(X, EI, EA), mask)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+    finally:
+        del be._launch
+    n_j, n_g = X["joint"].size(0), X["grain"].size(0)
+    out = []
+    for name, evs in sorted(rec.items()):
+        us = [e0.elapsed_time(e1) * 1e3 for e0, e1, _ in evs]
+        r = {"call": name, "calls_per_step": round(len(evs) / 3.0, 1), "avg_us": round(sum(us) / len(us), 1),
+             "us_per_step": round(sum(us) / 3.0, 1)}
+        if name == "ggnn_wgrad":
+            # C = A^T B over the nodes: 2 K M Nc batch flops per call, exact fp32 MFMA (157.3 TFLOP/s dense)
+            fl = [2.0 * a[0]._obj.K * a[0]._obj.M * a[0]._obj.Nc * a[0]._obj.batch for _, _, a in evs]
+            tf = sum(fl) / sum(us) / 1e6
+            r.update(bound="mfma", achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4))
+        elif name == "ggnn_period_gat_aggregate_backward":
+            # per sweep: the destination pass reads u / agg / g_agg rows and per edge the source's value + hidden rows,
+            # writes the destination-side gradients and (alpha, ds) records; the source pass gathers them back:
+            # >= 4 G 96 (3 n_dst + 2 n_src) + 4 E (2 G 96 + 2 G) bytes touched at least once
+            by = []
+            for _, _, a in evs:
+                o = a[0]._obj
+                by.append(4.0 * o.n_gates * 96 * (3 * o.n_dst + 2 * o.n_src) + 4.0 * o.E * (2 * o.n_gates * 96 + 2 * o.n_gates))
+            gbs = sum(by) / sum(us) / 1e3
+            r.update(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4))
+        elif name == "ggnn_rowgemm":
+            by = [4.0 * a[0]._obj.M * a[0]._obj.batch * (a[0]._obj.K + a[0]._obj.n_out) for _, _, a in evs]   # A in, C out
+            gbs = sum(by) / sum(us) / 1e3
+            r.update(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4))
+        if name in ("ggnn_rowgemm", "ggnn_wgrad"):
+            shapes = {}
+            for (e0, e1, a) in evs:
+                o = a[0]._obj
+                key = "M%d K%d N%d b%d" % (o.M, o.K, o.n_out if name == "ggnn_rowgemm" else o.Nc, o.batch)
+                shapes.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)
+            r["shapes"] = {k: [len(v) // 3, round(sum(v) / len(v), 1)] for k, v in shapes.items()}
+        out.append(r)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
@@ -77,6 +146,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of ~40")
     ap.add_argument("--json", action="store_true", help="print one JSON line instead of text (bench.py's train_step record)")
+    ap.add_argument("--roofline", action="store_true", help="with --json: add live per-call roofline records (an eager pass)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
     args = ap.parse_args()
@@ -99,7 +169,8 @@ def main():
     dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph, args.fused)
     if args.json:
         import json
-        print(json.dumps({"workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
+        extra = {"kernel_rooflines": kernel_rooflines(R, X, EI, EA, Y, M, args.bf16)} if args.roofline else {}
+        print(json.dumps({**extra, "workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
                           "launch": "hipGraph replay (training.GraphedTrainStep recipe)" if args.graph else "eager",
                           "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; " +
                                   ("torch.autocast(bfloat16): the decoder projection in bf16 MFMA arithmetic "
