@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 19
+GGNN_ABI_VERSION = 20
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -21,6 +21,8 @@ GGNN_EDGE_PARAM_ROWS = 3
 GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
 GGNN_FLAG_F16_RANGE = 1
+GGNN_ADAM_CHUNK, GGNN_ADAM_MAX_TENSORS, GGNN_ADAM_MAX_GROUPS = 4096, 384, 8
+GGNN_MSE_MAX_TERMS, GGNN_MSE_BLOCKS = 4, 64
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
@@ -34,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
+    "ggnn_adam_step", "ggnn_masked_mse",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -146,6 +149,28 @@ class RowGemmArgs(Structure):
     ]
 
 
+class AdamTensor(Structure):
+    """Mirror of `ggnn_adam_tensor` (one entry of the DEVICE table of ggnn_adam_step)."""
+    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64), ("group", c_int32),
+                ("reserved", c_int32)]
+
+
+class AdamArgs(Structure):
+    """Mirror of `ggnn_adam_args`."""
+    _fields_ = [("table", c_void_p), ("chunk_tensor", c_void_p), ("chunk_index", c_void_p), ("step", c_void_p),
+                ("counter", c_void_p), ("grad", c_void_p * GGNN_ADAM_MAX_TENSORS), ("lr", c_float * GGNN_ADAM_MAX_GROUPS),
+                ("weight_decay", c_float * GGNN_ADAM_MAX_GROUPS), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("n_chunks", c_int32), ("n_tensors", c_int32)]
+
+
+class MseArgs(Structure):
+    """Mirror of `ggnn_mse_args`."""
+    _fields_ = [("pred", c_void_p * GGNN_MSE_MAX_TERMS), ("target", c_void_p * GGNN_MSE_MAX_TERMS),
+                ("mask", c_void_p * GGNN_MSE_MAX_TERMS), ("g_pred", c_void_p * GGNN_MSE_MAX_TERMS),
+                ("n", c_int64 * GGNN_MSE_MAX_TERMS), ("mask_div", c_int64 * GGNN_MSE_MAX_TERMS),
+                ("workspace", c_void_p), ("loss", c_void_p), ("scale", c_float), ("n_terms", c_int32)]
+
+
 class AggregateBwdArgs(Structure):
     """Mirror of `ggnn_aggregate_bwd_args`."""
     _fields_ = [
@@ -250,6 +275,10 @@ def _declare(lib):
     lib.ggnn_rowgemm_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
     lib.ggnn_rowgemm.restype = c_int
     lib.ggnn_rowgemm.argtypes = [POINTER(RowGemmArgs), c_void_p]
+    lib.ggnn_adam_step.restype = c_int
+    lib.ggnn_adam_step.argtypes = [POINTER(AdamArgs), c_void_p]
+    lib.ggnn_masked_mse.restype = c_int
+    lib.ggnn_masked_mse.argtypes = [POINTER(MseArgs), c_void_p]
     lib.ggnn_heads_regressor_backward.restype = c_int
     lib.ggnn_heads_regressor_backward.argtypes = [c_int64, c_int64] + [c_void_p] * 11
     lib.ggnn_heads_classifier.restype = c_int

@@ -44,6 +44,7 @@ class HipBackend:
         self._tape = None  # while a list: every hot-path launch is also recorded as (cfunc, name, cargs)
         self._range_flags = {}  # device -> int32 word the fp16 two-piece kernels report clamped activations in
         self._rowgemm_ws = {}   # (device, bytes) -> weight-plane workspace of ggnn_rowgemm
+        self._mse_ws = {}       # device -> partial sums + arrival counter of ggnn_masked_mse
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
@@ -324,7 +325,7 @@ class HipBackend:
         edge_index (grouped by source), `r_slot` [E] int32: forward CSR slot of every reverse slot.
         Returns (g_p_dst, g_p_src, g_h_src or None, g_ep [n_gates, 3, 96]); the gradient tensors
         have the layout of their operands, columns the sweep does not read are zero.
-        `ep_partial_out` [>= aggregate_bwd_partials(n_dst), n_gates, 3, 96]: the per-wave partial sums of g_ep go
+        `ep_partial_out` [>= aggregate_bwd_partials(n_dst), n_gates, 3, 96]: the per-workgroup partial sums of g_ep go
         there and g_ep is returned as None -- the caller sums them (one reduction for the sweeps of a cell)."""
         _require_cuda(csr.rowptr, rcsr.rowptr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg)
         dev = p_src.device
@@ -487,6 +488,40 @@ class HipBackend:
         g.K, g.n_out, g.batch, g.precision = K, n_out, batch, _lib.GGNN_PRECISION_BF16 if bf16 else 0
         self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
         return out
+
+    def adam_step(self, args):
+        """ggnn_adam_step (include/ggnn.h) on a filled `_lib.AdamArgs` (training.FusedAdam builds it)."""
+        self._launch(self.lib.ggnn_adam_step, "ggnn_adam_step", ctypes.byref(args), _lib.current_stream())
+
+    def masked_mse(self, terms, scale, loss, want_grad=True):
+        """ggnn_masked_mse: `terms` = [(pred, target, mask or None)], contiguous float32 CUDA tensors; mask has the shape
+        of pred or one entry per leading row of it.  Returns the gradients [g_pred] (None each with want_grad=False)."""
+        a = _lib.MseArgs()
+        if not 1 <= len(terms) <= _lib.GGNN_MSE_MAX_TERMS:
+            raise _lib.GGNNError("ggnn_masked_mse: 1..%d terms" % _lib.GGNN_MSE_MAX_TERMS)
+        grads = []
+        for k, (p, y, m) in enumerate(terms):
+            _require_cuda(p, y, m)
+            for t in (p, y, m):
+                if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise _lib.GGNNError("ggnn_masked_mse: operands must be contiguous float32 tensors")
+            if y.shape != p.shape:
+                raise _lib.GGNNError("ggnn_masked_mse: pred and target differ in shape")
+            div = 1
+            if m is not None and m.numel() != p.numel():
+                if p.dim() < 1 or m.numel() != p.size(0) or p.numel() % max(m.numel(), 1):
+                    raise _lib.GGNNError("ggnn_masked_mse: mask must match pred or its leading dimension")
+                div = p.numel() // m.numel()
+            g = torch.empty_like(p) if want_grad else None
+            grads.append(g)
+            a.pred[k], a.target[k], a.mask[k], a.g_pred[k] = p.data_ptr(), y.data_ptr(), ptr(m), ptr(g)
+            a.n[k], a.mask_div[k] = p.numel(), div
+        ws = self._mse_ws.get(loss.device)
+        if ws is None:
+            ws = self._mse_ws[loss.device] = torch.zeros(_lib.GGNN_MSE_BLOCKS + 1, dtype=torch.float64, device=loss.device)
+        a.workspace, a.loss, a.scale, a.n_terms = ws.data_ptr(), loss.data_ptr(), scale, len(terms)
+        self._launch(self.lib.ggnn_masked_mse, "ggnn_masked_mse", ctypes.byref(a), _lib.current_stream())
+        return grads
 
     # -- heads -------------------------------------------------------------------------
     def heads_regressor(self, h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area):

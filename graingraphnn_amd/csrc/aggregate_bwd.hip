@@ -185,12 +185,22 @@ __global__ __launch_bounds__(256) void aggregate_bwd_dst_kernel(const ggnn_aggre
       if (HAS_H) st6(gd + A.u_off + L.g * C + L.ch, duh);
     }
   }
-  if (L.active && w < A.n_partials) {  // this wave's share of dW3, [n_partials][G][3][96]
-    float* o = A.ep_partial + (w * G + L.g) * (int64_t)(GGNN_EDGE_PARAM_ROWS * C) + L.ch;
+  // this workgroup's share of dW3, [n_partials = workgroups][G][3][96]: the four waves' sums are added in wave order
+  // through LDS (a fixed grid and a fixed order: the caller's reduction over the partials is reproducible)
+  __shared__ float red[AB_WAVES][G][GGNN_EDGE_PARAM_ROWS * C];
+  if (L.active) {
+    float* o = &red[L.wave][L.g][L.ch];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int c = 0; c < 6; ++c) o[k * C + (c < 3 ? c : C / 2 + c - 3)] = dwv[c][k];
+  }
+  __syncthreads();
+  constexpr int NP = G * GGNN_EDGE_PARAM_ROWS * C;
+  float* __restrict__ po = A.ep_partial + (int64_t)blockIdx.x * NP;
+  for (int idx = threadIdx.x; idx < NP; idx += 256) {
+    const float* r = &red[0][0][0] + idx;
+    po[idx] = ((r[0] + r[NP]) + r[2 * NP]) + r[3 * NP];
   }
 }
 
@@ -258,9 +268,11 @@ __global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggre
 
 }  // namespace ggnn
 
+// = workgroups of the destination pass: three per compute unit (the pass is a chain of dependent gathers per row and
+// holds ~160 registers: twelve waves per compute unit are what fits, and all of them should be resident at once)
 extern "C" int64_t ggnn_aggregate_bwd_partials(int64_t n_dst) {
   const int64_t want = (n_dst + ggnn::AB_WAVES - 1) / ggnn::AB_WAVES;
-  return (want < 512 ? (want > 0 ? want : 1) : 512) * ggnn::AB_WAVES;
+  return want < 768 ? (want > 0 ? want : 1) : 768;
 }
 
 extern "C" int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream) {
@@ -289,7 +301,7 @@ extern "C" int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args*
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
   if (A.n_partials != ggnn_aggregate_bwd_partials(A.n_dst)) return GGNN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid_d((unsigned)(A.n_partials / AB_WAVES));
+  const dim3 grid_d((unsigned)A.n_partials);
   const int64_t want_s = (A.n_src + AB_WAVES - 1) / AB_WAVES;
   const dim3 grid_s((unsigned)(want_s < 2048 ? want_s : 2048));
 #define GGNN_AB_LAUNCH(G_)                                                                          \

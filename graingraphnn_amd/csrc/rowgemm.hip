@@ -167,6 +167,115 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
   }
 }
 
+// Short reductions (K <= 128 .. 256: the gate GEMM and its input gradient -- eight of the ten products of a training
+// step): the planes of ONE batch entry's W fit the LDS (K / 32 slices), so a workgroup fetches them once and its waves
+// then stream row tiles with no barrier at all -- the next tile's rows (K / 32 x 32 bytes per lane) are requested before
+// the current tile's MFMAs.  Grid = (row chunks, batch): the streamed kernel above walked the batch entries inside one
+// workgroup per 128 rows, 79 / 157 workgroups on 256 compute units at the 10k-grain graph.
+template <int NCT, int NKSM, bool BF16>
+__global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_resident_kernel(const ggnn_rowgemm_args A,
+                                                                         const u32x4* __restrict__ planes, const int nks) {
+  constexpr int P = BF16 ? 1 : 2;
+  constexpr int SLICE = NCT * P * 1024;
+  static_assert(NKSM * SLICE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NKSM * SLICE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const int64_t M = A.M, n_tiles = (M + 15) / 16, stride = (int64_t)gridDim.x * RG_WAVES;
+  {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(planes) + (size_t)b * nks * SLICE + lane * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
+    const int np = nks * NCT * P;
+    for (int p = wave; p < np; p += RG_WAVES) dc_dma16(src + p * 1024, dst + p * 1024);
+  }
+  const float* __restrict__ abase = A.a + (int64_t)b * A.a_bstride + 8 * kq;
+  // a ragged last tile slides back over rows the previous tile also produces (identical duplicate stores)
+  auto tile_row = [&](int64_t t) { return std::min<int64_t>(std::max<int64_t>(0, std::min<int64_t>(t * 16, M - 16)) + lr, M - 1); };
+  auto load_rows = [&](int64_t t, f32x4 (&r)[NKSM][2]) __attribute__((always_inline)) {
+    const float* __restrict__ arow = abase + tile_row(std::min(t, n_tiles - 1)) * A.lda;   // (past the end: a harmless repeat)
+    // unconditional (clamped) loads: a load under `if` makes the compiler wait for EVERYTHING at the branch merge, the
+    // next tile's rows included
+#pragma unroll
+    for (int i = 0; i < NKSM; ++i) {
+      const int ic = std::min(i, nks - 1);
+      r[i][0] = ld16f(arow + 32 * ic);
+      r[i][1] = ld16f(arow + 32 * ic + 4);
+    }
+  };
+  f32x4 rows[2][NKSM][2];
+  int64_t t = (int64_t)blockIdx.x * RG_WAVES + wave;
+  load_rows(t, rows[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // W[b] is in LDS; from here on the waves run free
+  const u32x4* pw = reinterpret_cast<const u32x4*>(smem) + lane;
+  float unused_amax = 0.f;
+  auto run_tile = [&](f32x4 (&cur)[NKSM][2], f32x4 (&nxt)[NKSM][2]) __attribute__((always_inline)) {
+    load_rows(t + stride, nxt);
+    const int64_t row = tile_row(t);
+    DcAcc acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct].zero();
+#pragma unroll
+    for (int i = 0; i < NKSM; ++i) {
+      if (i < nks) {
+        u32x4 xb[DC_PL];
+        const u32x4* ps = pw + i * (SLICE / 16);
+        if constexpr (BF16) {
+          xb[0] = (u32x4){pack_bf16(cur[i][0][0], cur[i][0][1]), pack_bf16(cur[i][0][2], cur[i][0][3]),
+                          pack_bf16(cur[i][1][0], cur[i][1][1]), pack_bf16(cur[i][1][2], cur[i][1][3])};
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            acc[ct].m = mfma_bf16(ps[ct * 64], xb[0], acc[ct].m);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        } else {
+          dc_split(cur[i][0], cur[i][1], xb, unused_amax);
+          dc_kstep<NCT>(ps, xb, acc);
+        }
+      }
+    }
+    // (n_out = 16 NCT on this path: no store under a branch)
+    const int64_t coff = (int64_t)b * A.c_bstride + row * A.ldc + 4 * kq;
+    f32x4 cin[NCT];
+    if (A.c_in != nullptr) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) cin[ct] = ld16f(A.c_in + coff + 16 * ct);
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) cin[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+      *reinterpret_cast<f32x4*>(A.c + coff + 16 * ct) = (BF16 ? acc[ct].m : acc[ct].value()) + cin[ct];
+  };
+  while (t < n_tiles) {
+    run_tile(rows[0], rows[1]);
+    t += stride;
+    if (t >= n_tiles) break;
+    run_tile(rows[1], rows[0]);
+    t += stride;
+  }
+}
+
+template <int NCT, int NKSM>
+static int rowgemm_resident_launch(const ggnn_rowgemm_args& A, const u32x4* planes, int nks, hipStream_t st) {
+  // row tiles per wave so that the whole grid is resident at once (one workgroup per compute unit: the planes take most
+  // of the LDS), the waves of a batch entry sharing its tiles evenly
+  const int64_t n_tiles = (A.M + 15) / 16;
+  const int64_t per_wave = std::max<int64_t>(1, (n_tiles * A.batch + RG_WAVES * 256 - 1) / (RG_WAVES * 256));
+  const int64_t n_wg = (n_tiles + RG_WAVES * per_wave - 1) / (RG_WAVES * per_wave);
+  if (n_wg >= INT32_MAX || A.batch > 65535) return GGNN_EINVAL;
+  const dim3 grid((unsigned)n_wg, (unsigned)A.batch);
+  if (A.precision == GGNN_PRECISION_BF16)
+    hipLaunchKernelGGL((rowgemm_resident_kernel<NCT, NKSM, true>), grid, dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+  else
+    hipLaunchKernelGGL((rowgemm_resident_kernel<NCT, NKSM, false>), grid, dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+  return launch_status();
+}
+
 template <int NCT>
 static int rowgemm_launch(const ggnn_rowgemm_args& A, const u32x4* planes, int nks, hipStream_t st) {
   const int64_t n_wg = (A.M + 16 * RG_WAVES - 1) / (16 * RG_WAVES);
@@ -203,7 +312,9 @@ extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream)
   if (A.precision != 0 && A.precision != GGNN_PRECISION_BF16) return GGNN_EINVAL;
   if (A.workspace_bytes < ggnn_rowgemm_workspace_bytes(A.K, A.n_out, A.batch)) return GGNN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (A.precision == 0 && A.n_out > 128) {
+  // W[b]'s planes fit the LDS (and n_out is one of the instantiated widths)
+  const bool resident = A.n_out == 16 * rowgemm_tiles(A.n_out) && A.K / 32 <= (A.n_out == 96 ? 8 : 4);
+  if (A.precision == 0 && A.n_out > 128 && !resident) {
     // fp32 mode wider than 8 column tiles: 14 x (main + cross) accumulators leave no registers for rows in flight
     // (82 spilled, slower than the library) -- two passes over column halves instead (A is read twice: the wide shape
     // is the gate GEMM's input gradient, whose reduction is 96 long)
@@ -226,6 +337,14 @@ extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream)
   else
     hipLaunchKernelGGL((rowgemm_pack_kernel<false>), dim3((unsigned)n_pack), dim3(256), 0, st, A, planes, nks, nct);
   if (launch_status() != GGNN_OK) return GGNN_ELAUNCH;
+  if (resident) {
+    switch (nct) {
+      case 6: return rowgemm_resident_launch<6, 8>(A, planes, nks, st);
+      case 8: return rowgemm_resident_launch<8, 4>(A, planes, nks, st);
+      case 14: return rowgemm_resident_launch<14, 4>(A, planes, nks, st);
+      default: return GGNN_EINVAL;
+    }
+  }
   switch (nct) {
     case 6: return rowgemm_launch<6>(A, planes, nks, st);
     case 8: return rowgemm_launch<8>(A, planes, nks, st);

@@ -1,0 +1,122 @@
+// Training path, the two ends of a step that are not a cell: the loss (train.py:31-37: the masked
+// squared error of the regressor, with its gradient) and the optimizer (train.py:82-91: torch.optim.Adam, possibly with
+// per-group learning rates) -- each ONE launch where the recorded ops are ~30 (loss forward + backward) and the
+// multi-tensor library kernels 14 (the model has ~150 parameter tensors; a launch of theirs carries at most ~30 tensors
+// in its kernel arguments).  Here the tensors' fixed description is a table in DEVICE memory and a launch carries only the
+// gradients' addresses.
+#include "common.h"
+
+namespace ggnn {
+
+constexpr int AD_THREADS = 256;
+constexpr int AD_CHUNK = GGNN_ADAM_CHUNK;   // elements per workgroup
+
+// step[t]: updates tensor t has had so far (a float per tensor, as torch keeps it: a tensor without a gradient in some step
+// does not advance); *counter: arrival counter of the running launch (0 between launches).  Every workgroup reads its tensor's
+// count before it announces itself; the last workgroup to arrive advances the counts of the tensors that had a gradient.
+// What changes from step to step -- the gradients' addresses, the learning rates -- travels in the kernel arguments (3 KB):
+// nothing is staged through host memory that a later step could overwrite while an earlier one is still queued.
+__global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A) {
+  const int ti = A.chunk_tensor[blockIdx.x];
+  const ggnn_adam_tensor T = A.table[ti];
+  const float* __restrict__ grad = A.grad[ti];
+  const int64_t i0 = (int64_t)A.chunk_index[blockIdx.x] * AD_CHUNK;
+  const float s = A.step[ti] + 1.0f;
+  if (grad != nullptr) {
+    // torch.optim.Adam (single-tensor formulation): step_size = lr / (1 - beta1^s); denom = sqrt(v) / sqrt(1 - beta2^s) + eps
+    const float lr = A.lr[T.group], wd = A.weight_decay[T.group];
+    const float bc1 = 1.0f - powf(A.beta1, s), bc2 = 1.0f - powf(A.beta2, s);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const int64_t i1 = min(T.n, i0 + AD_CHUNK);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += AD_THREADS) {
+      float p = T.param[i], g = grad[i];
+      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
+      const float m = __builtin_fmaf(A.beta1, T.exp_avg[i], (1.0f - A.beta1) * g);
+      const float v = __builtin_fmaf(A.beta2, T.exp_avg_sq[i], (1.0f - A.beta2) * g * g);
+      T.exp_avg[i] = m;
+      T.exp_avg_sq[i] = v;
+      T.param[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + A.eps));
+    }
+  }
+  __shared__ bool last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(A.counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {
+    for (int t = threadIdx.x; t < A.n_tensors; t += AD_THREADS)
+      if (A.grad[t] != nullptr) A.step[t] += 1.0f;
+    if (threadIdx.x == 0) *A.counter = 0u;
+  }
+}
+
+// loss = scale * sum_k mean_i(mask_k[i / mask_div_k] * (pred_k[i] - target_k[i])^2), g_pred_k = d loss / d pred_k.
+// GGNN_MSE_BLOCKS workgroups, each over a fixed share of the elements; their partial sums (doubles) go through the
+// workspace and the last workgroup to arrive adds them in index order: the result does not depend on the arrival order.
+constexpr int MSE_THREADS = 256;
+__global__ __launch_bounds__(MSE_THREADS) void masked_mse_kernel(const ggnn_mse_args A) {
+  __shared__ double red[MSE_THREADS / 64];
+  const int64_t gtid = (int64_t)blockIdx.x * MSE_THREADS + threadIdx.x, gstride = (int64_t)GGNN_MSE_BLOCKS * MSE_THREADS;
+  double total = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < A.n_terms; ++k) {
+    const int64_t n = A.n[k];
+    if (n <= 0) continue;
+    const float* __restrict__ p = A.pred[k];
+    const float* __restrict__ y = A.target[k];
+    const float* __restrict__ m = A.mask[k];
+    float* __restrict__ g = A.g_pred[k];
+    const int64_t div = A.mask_div[k];
+    const float gs = 2.0f * A.scale / (float)n;
+    float acc = 0.f;
+    for (int64_t i = gtid; i < n; i += gstride) {
+      const float d = p[i] - y[i], w = m ? m[div == 1 ? i : i / div] : 1.0f;
+      acc = __builtin_fmaf(w * d, d, acc);
+      if (g) g[i] = gs * w * d;
+    }
+    total += (double)acc / (double)n;
+  }
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < MSE_THREADS / 64; ++w) t += red[w];
+    A.workspace[blockIdx.x] = t;
+    __threadfence();
+    unsigned* counter = reinterpret_cast<unsigned*>(A.workspace + GGNN_MSE_BLOCKS);
+    if (atomicAdd(counter, 1u) == GGNN_MSE_BLOCKS - 1) {
+      __threadfence();
+      double sum = 0.0;   // (device-scope loads: the other workgroups' partial sums come from L2)
+      for (int b = 0; b < GGNN_MSE_BLOCKS; ++b) sum += __hip_atomic_load(A.workspace + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *A.loss = (float)(sum * (double)A.scale);
+      *counter = 0u;
+    }
+  }
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  const ggnn_adam_args& A = *args;
+  if (!A.table || !A.chunk_tensor || !A.chunk_index || !A.step || !A.counter || A.n_chunks <= 0) return GGNN_EINVAL;
+  if (A.n_tensors < 1 || A.n_tensors > GGNN_ADAM_MAX_TENSORS) return GGNN_EINVAL;
+  if (!(A.beta1 >= 0.f && A.beta1 < 1.f) || !(A.beta2 >= 0.f && A.beta2 < 1.f) || !(A.eps >= 0.f)) return GGNN_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)A.n_chunks), dim3(AD_THREADS), 0, (hipStream_t)stream, A);
+  return launch_status();
+}
+
+extern "C" int ggnn_masked_mse(const ggnn_mse_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || !args->loss || !args->workspace || args->n_terms < 1 || args->n_terms > GGNN_MSE_MAX_TERMS) return GGNN_EINVAL;
+  for (int k = 0; k < args->n_terms; ++k) {
+    if (args->n[k] < 0 || (args->n[k] > 0 && (!args->pred[k] || !args->target[k]))) return GGNN_EINVAL;
+    if (args->mask[k] && args->mask_div[k] < 1) return GGNN_EINVAL;
+  }
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(GGNN_MSE_BLOCKS), dim3(MSE_THREADS), 0, (hipStream_t)stream, *args);
+  return launch_status();
+}

@@ -197,7 +197,7 @@ class _PackedCell(torch.autograd.Function):
             backend.rowgemm(g_z, w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
                             transposed=True, bf16=bf16)                                        # g_agg_g = g_z_g W2_g
         gh_src = {nt: None for nt in NODE_TYPES}
-        # the per-wave partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
+        # the per-workgroup partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
         n_part = [backend.aggregate_bwd_partials(x[et[-1]].size(0)) for et in EDGE_TYPES]
         ep_part = (torch.empty if len(set(n_part)) == 1 else torch.zeros)(len(EDGE_TYPES), max(n_part), G, 3, C, **f32)
         for k, et in enumerate(EDGE_TYPES):
@@ -345,8 +345,46 @@ def classifier_forward(model, x_dict, edge_index_dict, edge_attr):
     return {"edge_event": y[:, 2].contiguous(), "edge": torch.tanh(y[:, :2])}
 
 
+class _MaskedMSE(torch.autograd.Function):
+    """100 * sum_k mean(mask_k (y_k - p_k)^2) with its gradient from ONE launch (`ggnn_masked_mse`): the recorded ops are
+    ten kernels forward and twenty backward for a scalar."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, scale, backend, n_terms, *tensors):
+        preds, ys, masks = tensors[:n_terms], tensors[n_terms:2 * n_terms], tensors[2 * n_terms:]
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=preds[0].device)
+        grads = backend.masked_mse([(c(p), c(y), c(m)) for p, y, m in zip(preds, ys, masks)], scale, loss,
+                                   want_grad=any(ctx.needs_input_grad[3:3 + n_terms]))
+        ctx.n_terms = n_terms
+        ctx.save_for_backward(*[g for g in grads if g is not None])
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss):
+        grads = ctx.saved_tensors
+        out = [g * g_loss if ctx.needs_input_grad[3 + k] else None for k, g in enumerate(grads)] if grads else []
+        out += [None] * (ctx.n_terms - len(out))
+        return (None, None, None, *out, *([None] * (2 * ctx.n_terms)))
+
+
 def regressor_loss(y_dict, pred, mask):
-    """train.py:31-37 (edge_len off): 100 * (mean(mask_j (y_j - p_j)^2) + mean(mask_g (y_g - p_g)^2))."""
+    """train.py:31-37 (edge_len off): 100 * (mean(mask_j (y_j - p_j)^2) + mean(mask_g (y_g - p_g)^2)).  On the GPU one
+    launch computes the loss and its gradient (`_MaskedMSE`); `regressor_loss_recorded` is the same expression as recorded
+    torch ops."""
+    pj, pg = pred["joint"], pred["grain"]
+    mj, mg = mask["joint"], mask["grain"]
+    fits = lambda m, p: m.shape == p.shape or (m.dim() >= 1 and m.numel() == p.size(0))   # elementwise or one per row
+    if pj.is_cuda and pj.dtype == torch.float32 and pg.dtype == torch.float32 and fits(mj, pj) and fits(mg, pg) \
+            and y_dict["joint"].shape == pj.shape and y_dict["grain"].shape == pg.shape \
+            and not (y_dict["joint"].requires_grad or y_dict["grain"].requires_grad or mj.requires_grad or mg.requires_grad):
+        return _MaskedMSE.apply(100.0, default_backend(), 2, pj, pg, y_dict["joint"], y_dict["grain"], mj, mg)
+    return regressor_loss_recorded(y_dict, pred, mask)
+
+
+def regressor_loss_recorded(y_dict, pred, mask):
     return 100 * (torch.mean(mask["joint"] * (y_dict["joint"] - pred["joint"]) ** 2)
                   + torch.mean(mask["grain"] * (y_dict["grain"] - pred["grain"]) ** 2))
 
@@ -357,6 +395,112 @@ def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
     keep = y > -1
     return torch.nn.functional.binary_cross_entropy_with_logits(
         z[keep], y[keep].to(z.dtype), pos_weight=torch.tensor(pos_weight, device=z.device, dtype=z.dtype))
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (train.py:82-91: per-group learning rates, StepLR on top) with the update of ALL parameter tensors
+    in ONE launch (`ggnn_adam_step`): the model has ~150 small parameter tensors, which torch's multi-tensor kernels take
+    in 14 launches (~0.1 ms of a 2 ms training step at the 10k-grain graph).  What is fixed about a tensor (addresses of
+    the parameter and its moments, size, group) sits in a table in device memory; what changes from step to step -- the
+    gradients' addresses (new tensors after every backward), the groups' learning rates (a scheduler edits
+    `param_groups[i]["lr"]`) -- travels in the launch's arguments.  The step count lives on the device and the launch
+    increments it itself, so `step()` can be captured in a hipGraph (`GraphedTrainStep`); a captured step replays the
+    learning rates it was captured with, as torch's capturable Adam does with a float `lr`.
+
+    Same arithmetic as torch.optim.Adam(amsgrad=False, maximize=False): tests compare the two.  State per parameter
+    (`state_dict`): "step", "exp_avg", "exp_avg_sq" -- views of three flat device buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or eps < 0.0 or lr < 0.0 or weight_decay < 0.0:
+            raise ValueError("FusedAdam: lr, eps, weight_decay >= 0 and betas in [0, 1)")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        if len({(tuple(g["betas"]), g["eps"]) for g in self.param_groups}) != 1:
+            raise ValueError("FusedAdam: betas and eps must be the same in every parameter group (lr and weight_decay may differ)")
+        if len(self.param_groups) > _lib.GGNN_ADAM_MAX_GROUPS:
+            raise ValueError("FusedAdam: at most %d parameter groups" % _lib.GGNN_ADAM_MAX_GROUPS)
+        self._built = None
+
+    def _build(self):
+        import ctypes
+        import numpy as np
+        ps = [(p, gi) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.requires_grad]
+        if not ps:
+            raise ValueError("FusedAdam: no parameter requires a gradient")
+        dev = ps[0][0].device
+        for p, _ in ps:
+            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.GGNNError("FusedAdam: parameters must be contiguous float32 tensors on one MI355X device "
+                                     "(no CPU fallback exists)")
+        sizes = [p.numel() for p, _ in ps]
+        offs = np.concatenate([[0], np.cumsum([-(-n // 4) * 4 for n in sizes])])   # 16-byte aligned views
+        m, v = torch.zeros(int(offs[-1]), device=dev), torch.zeros(int(offs[-1]), device=dev)
+        step = torch.zeros(len(ps), device=dev)   # a count per tensor, as torch keeps it
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        table = np.zeros(len(ps), dtype=np.dtype([("param", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("n", "<i8"),
+                                                  ("group", "<i4"), ("reserved", "<i4")]))
+        assert table.itemsize == ctypes.sizeof(_lib.AdamTensor)
+        for k, ((p, gi), n) in enumerate(zip(ps, sizes)):
+            o = int(offs[k])
+            self.state[p] = {"step": step[k], "exp_avg": m[o:o + n].view_as(p), "exp_avg_sq": v[o:o + n].view_as(p)}
+            table[k] = (p.data_ptr(), m.data_ptr() + 4 * o, v.data_ptr() + 4 * o, n, gi, 0)
+        dev_table = torch.from_numpy(table.view(np.uint8)).to(dev)
+        launches = []   # a launch takes GGNN_ADAM_MAX_TENSORS tensors: (first tensor, count, chunk maps)
+        for t0 in range(0, len(ps), _lib.GGNN_ADAM_MAX_TENSORS):
+            cnt = min(_lib.GGNN_ADAM_MAX_TENSORS, len(ps) - t0)
+            ct, ci = [], []
+            for k in range(cnt):
+                nc = -(-sizes[t0 + k] // _lib.GGNN_ADAM_CHUNK)
+                ct += [k] * nc
+                ci += list(range(nc))
+            launches.append((t0, cnt, torch.tensor(ct, dtype=torch.int32, device=dev),
+                             torch.tensor(ci, dtype=torch.int32, device=dev)))
+        self._built = dict(ps=ps, m=m, v=v, step=step, counter=counter, dev_table=dev_table, launches=launches, params_at=[p.data_ptr() for p, _ in ps])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._built is None:
+            self._build()
+        b = self._built
+        be = default_backend()
+        g0 = self.param_groups[0]
+        for t0, cnt, ct, ci in b["launches"]:
+            a = _lib.AdamArgs()
+            a.table = b["dev_table"].data_ptr() + t0 * ctypes.sizeof(_lib.AdamTensor)
+            a.chunk_tensor, a.chunk_index = ct.data_ptr(), ci.data_ptr()
+            a.step, a.counter = b["step"].data_ptr() + 4 * t0, b["counter"].data_ptr()
+            for k in range(cnt):
+                p = b["ps"][t0 + k][0]
+                gr = p.grad
+                if p.data_ptr() != b["params_at"][t0 + k]:
+                    raise _lib.GGNNError("FusedAdam: a parameter's storage moved after the first step (model.to(...) / "
+                                         "p.data = ...): build a new optimizer")
+                if gr is not None and (gr.dtype != torch.float32 or gr.is_sparse or not gr.is_contiguous() or gr.device != p.device):
+                    raise _lib.GGNNError("FusedAdam: gradients must be dense contiguous float32 tensors on the parameters' device")
+                a.grad[k] = None if gr is None else gr.data_ptr()
+            for gi, g in enumerate(self.param_groups):
+                a.lr[gi], a.weight_decay[gi] = g["lr"], g["weight_decay"]
+            a.beta1, a.beta2, a.eps = g0["betas"][0], g0["betas"][1], g0["eps"]
+            a.n_chunks, a.n_tensors = ct.numel(), cnt
+            be.adam_step(a)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """The loaded moments and step counts are copied INTO the flat buffers (the device table points there)."""
+        super().load_state_dict(state_dict)
+        loaded = {p: dict(self.state[p]) for p in list(self.state)}
+        self._built = None
+        self._build()
+        with torch.no_grad():
+            for p, st in loaded.items():
+                if p in self.state and "exp_avg" in st:
+                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                    self.state[p]["step"].copy_(torch.as_tensor(st["step"]).to(torch.float32))
 
 
 _warned_eval_grad = False

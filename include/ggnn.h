@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 19
+#define GGNN_ABI_VERSION 20
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -240,7 +240,7 @@ typedef struct ggnn_aggregate_bwd_args {
   int64_t ldp_src, ldp_dst, ld_agg, ldh_src, n_src, n_dst, E, n_partials;
   int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
 } ggnn_aggregate_bwd_args;
-int64_t ggnn_aggregate_bwd_partials(int64_t n_dst); /* rows of ep_partial the call writes */
+int64_t ggnn_aggregate_bwd_partials(int64_t n_dst); /* rows of ep_partial the call writes (one per workgroup of its destination pass) */
 int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -573,6 +573,61 @@ typedef struct ggnn_wgrad_args {
 } ggnn_wgrad_args;
 int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch);
 int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
+
+/* Training path: torch.optim.Adam's update (train.py:82-91; amsgrad / maximize off) for up to GGNN_ADAM_MAX_TENSORS parameter
+ * tensors in one launch.  `table` (DEVICE memory, n_tensors entries, built once) holds what is fixed: the addresses of a
+ * parameter and its two moment buffers, its size, its parameter group.  Workgroup c of the launch updates elements
+ * [chunk_index[c] * GGNN_ADAM_CHUNK, +GGNN_ADAM_CHUNK) of tensor chunk_tensor[c] (DEVICE arrays of n_chunks entries, built once
+ * from the sizes).  What changes per step comes by value: grad[t] (NULL: tensor t is skipped), lr / weight_decay per group.
+ * step (DEVICE, n_tensors floats, 0 before the first call): step[t] = updates tensor t has had so far -- read for the bias
+ * corrections and incremented by the launch itself where grad[t] != NULL (torch keeps a count per parameter: one without a
+ * gradient does not advance), so a captured launch replays correctly; counter (DEVICE, one zero word): scratch.  A model with
+ * more tensors takes several calls per update, each on its own slice of the table and of step.  Per element:
+ *   g += weight_decay p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+ *   p -= lr / (1 - b1^s) * m / (sqrt(v) / sqrt(1 - b2^s) + eps),   s = step[t] + 1. */
+#define GGNN_ADAM_CHUNK 4096
+#define GGNN_ADAM_MAX_TENSORS 384
+#define GGNN_ADAM_MAX_GROUPS 8
+typedef struct ggnn_adam_tensor {
+  float* param;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  int32_t group, reserved;
+} ggnn_adam_tensor;
+typedef struct ggnn_adam_args {
+  const ggnn_adam_tensor* table;
+  const int32_t* chunk_tensor;
+  const int32_t* chunk_index;
+  float* step;
+  uint32_t* counter;
+  const float* grad[GGNN_ADAM_MAX_TENSORS];
+  float lr[GGNN_ADAM_MAX_GROUPS], weight_decay[GGNN_ADAM_MAX_GROUPS];
+  float beta1, beta2, eps;
+  int32_t n_chunks, n_tensors;
+} ggnn_adam_args;
+int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream);
+
+/* Training path: the regressor's loss (train.py:31-37, edge_len off) with its gradient in one launch:
+ *   loss = scale * sum_k mean_i(mask_k[i / mask_div_k] (pred_k[i] - target_k[i])^2),   g_pred_k[i] = d loss / d pred_k[i]
+ * over n_terms <= GGNN_MSE_MAX_TERMS terms of n[k] elements (mask NULL = ones; mask_div = elements of pred per mask entry;
+ * g_pred NULL = not wanted).  workspace: GGNN_MSE_BLOCKS + 1 doubles of DEVICE memory, zero before the first call (the call
+ * leaves its last entry zero again).  The sum is taken in a fixed order. */
+#define GGNN_MSE_MAX_TERMS 4
+#define GGNN_MSE_BLOCKS 64
+typedef struct ggnn_mse_args {
+  const float* pred[GGNN_MSE_MAX_TERMS];
+  const float* target[GGNN_MSE_MAX_TERMS];
+  const float* mask[GGNN_MSE_MAX_TERMS];
+  float* g_pred[GGNN_MSE_MAX_TERMS];
+  int64_t n[GGNN_MSE_MAX_TERMS];
+  int64_t mask_div[GGNN_MSE_MAX_TERMS];
+  double* workspace;
+  float* loss; /* [1] out */
+  float scale;
+  int32_t n_terms;
+} ggnn_mse_args;
+int ggnn_masked_mse(const ggnn_mse_args* args, ggnn_stream_t stream);
 
 /* Bytes of device scratch one model forward needs (projections + aggregates + h/c), so a
  * caller can size a single arena; the Python host allocates the same amounts as tensors. */

@@ -24,17 +24,24 @@ from graingraphnn_amd.models import GrainNN_regressor  # noqa: E402
 from graingraphnn_amd.seeding import load_seeded  # noqa: E402
 
 
-def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fused=False):
+def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fused=False, whatif=()):
+    """`whatif` (development): pieces left out to see what they cost -- "noopt" (no optimizer step), "sumloss" (the loss
+    replaced by a plain sum of the predictions)."""
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph, **({"fused": True} if fused else {}))
+    if fused == "ggnn":
+        opt = training.FusedAdam(model.parameters(), lr=5e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph, **({"fused": True} if fused else {}))
     losses = []
 
     def one():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            loss = training.regressor_loss(y, model(X, EI, EA), mask)
+            pred = model(X, EI, EA)
+            loss = (pred["joint"].sum() + pred["grain"].sum()) if "sumloss" in whatif else training.regressor_loss(y, pred, mask)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        opt.step()
+        if "noopt" not in whatif:
+            opt.step()
         return loss
     if not graph:
         for _ in range(3):
@@ -144,8 +151,10 @@ def main():
     ap.add_argument("--cfg3", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
-    ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of ~40")
+    ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): 14 optimizer launches instead of ~40")
+    ap.add_argument("--ggnn-adam", action="store_true", help="training.FusedAdam: the whole update in one launch (ggnn_adam_step)")
     ap.add_argument("--json", action="store_true", help="print one JSON line instead of text (bench.py's train_step record)")
+    ap.add_argument("--whatif", default="", help="development: comma list of noopt, sumloss")
     ap.add_argument("--roofline", action="store_true", help="with --json: add live per-call roofline records (an eager pass)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the CPU oracle leg (16 is its best on the 2 x 64-core GPU box)")
@@ -166,7 +175,8 @@ def main():
     X, EI, EA = synthetic.to_torch(x, ei, ea, dev)
     Y = {k: torch.from_numpy(v).to(dev) for k, v in y.items()}
     M = {k: torch.from_numpy(v).to(dev) for k, v in mask.items()}
-    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph, args.fused)
+    dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph, "ggnn" if args.ggnn_adam else args.fused,
+                     tuple(w for w in args.whatif.split(",") if w))
     if args.json:
         import json
         extra = {"kernel_rooflines": kernel_rooflines(R, X, EI, EA, Y, M, args.bf16)} if args.roofline else {}
@@ -175,11 +185,11 @@ def main():
                           "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; " +
                                   ("torch.autocast(bfloat16): the decoder projection in bf16 MFMA arithmetic "
                                    "(GGNN_PRECISION_BF16), sweeps / softmax / LSTM / gradients fp32" if args.bf16 else "fp32"),
-                          "optimizer": "torch.optim.Adam(fused=True)" if args.fused else "torch.optim.Adam (default: foreach)",
+                          "optimizer": "training.FusedAdam (ggnn_adam_step)" if args.ggnn_adam else "torch.optim.Adam(fused=True)" if args.fused else "torch.optim.Adam (default: foreach)",
                           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}))
         return
     print(f"{name}: HIP training path{' (bf16 autocast GEMMs)' if args.bf16 else ''}"
-          f"{' (hipGraph replay)' if args.graph else ''}{' (fused Adam)' if args.fused else ''}: {dt * 1e3:.2f} ms/step, "
+          f"{' (hipGraph replay)' if args.graph else ''}{' (ggnn_adam_step)' if args.ggnn_adam else ' (fused Adam)' if args.fused else ''}: {dt * 1e3:.2f} ms/step, "
           f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     if not args.no_cpu:
         from oracle import grainnn_oracle as oracle

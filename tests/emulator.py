@@ -211,7 +211,7 @@ class TorchEmulatorBackend:
     @staticmethod
     def aggregate_bwd_partials(n_dst):
         want = (n_dst + 3) // 4
-        return min(max(want, 1), 512) * 4
+        return min(max(want, 1), 768)
 
     fused_decoder = True  # engine.run_cells: decoder cells through decoder_cell_batch (False: projection + sweeps + gates)
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 19
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 20
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4
@@ -52,7 +52,7 @@ def test_argument_validation_returns_einval_without_launching():
     assert lib.ggnn_period_gat_aggregate_backward(None, None) == -1
     b = _lib.AggregateBwdArgs()
     assert lib.ggnn_period_gat_aggregate_backward(ctypes.byref(b), None) == -1
-    assert lib.ggnn_aggregate_bwd_partials(20000) == 2048 and lib.ggnn_aggregate_bwd_partials(5) == 8
+    assert lib.ggnn_aggregate_bwd_partials(20000) == 768 and lib.ggnn_aggregate_bwd_partials(5) == 2
     assert lib.ggnn_build_csr(None, 5, 3, 0, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.ggnn_csr_max_units(60000, 20000) == 40001
     assert lib.ggnn_edge_prepare(None, 1, None) == -1

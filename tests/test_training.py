@@ -495,7 +495,7 @@ def test_sweep_backward_full_size_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "ggnn"])
 def test_graphed_train_step_follows_the_eager_step(fused):
     """training.GraphedTrainStep (forward, loss, backward, Adam replayed from one hipGraph) against the same
     steps run eagerly on a second copy of the model: losses and parameters agree (same kernels, same
@@ -514,7 +514,10 @@ def test_graphed_train_step_follows_the_eager_step(fused):
           for _ in range(2)]
     mask = {nt: torch.ones(x[nt].shape[0], 1, device=dev) for nt in x}
     loss_fn = lambda pred, y: training.regressor_loss(y, pred, mask)
-    optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True, **({"fused": True} if fused else {}))
+    if fused == "ggnn":   # (the whole update in one ggnn_adam_step launch)
+        optA = training.FusedAdam(A.parameters(), lr=1e-3)
+    else:
+        optA = torch.optim.Adam(A.parameters(), lr=1e-3, capturable=True, **({"fused": True} if fused else {}))
     optB = torch.optim.Adam(B.parameters(), lr=1e-3, capturable=True)
     step = training.GraphedTrainStep(A, optA, loss_fn, X, EI, EA, Ys[0], warmup=3)
     B.train()
@@ -549,6 +552,83 @@ def test_graphed_train_step_follows_the_eager_step(fused):
         assert pa.grad is not None and bool(torch.isfinite(pa.grad).all()), n
         if not fused:  # (fused: the parameters already differ by up to a step in the noise directions)
             assert torch.allclose(pa.grad, pb.grad, rtol=1e-3, atol=1e-5 * gmax), n
+
+
+@pytest.mark.gpu
+def test_fused_adam_follows_torch_adam():
+    """training.FusedAdam (ggnn_adam_step: every tensor in one launch, step count on the device) against torch.optim.Adam
+    on copies of the same tensors: two groups with their own learning rate and weight decay, a learning rate changed
+    between steps (StepLR does that), a tensor without a gradient in some steps, sizes around the 4096-element chunk; the
+    state dict round-trips into a fresh optimizer that continues identically."""
+    from graingraphnn_amd import training
+    dev = "cuda"
+    rs = np.random.RandomState(3)
+    shapes = [(1,), (7,), (4096,), (4097,), (96, 104), (3, 96, 224), (2112, 108), (5,)]
+    mk = lambda: [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(sh).astype(np.float32)).to(dev)) for sh in shapes]
+    rs = np.random.RandomState(3)
+    pa = mk()
+    rs = np.random.RandomState(3)
+    pb = mk()
+    groups = lambda ps: [{"params": ps[:3], "lr": 2e-3, "weight_decay": 0.01}, {"params": ps[3:]}]
+    oa = training.FusedAdam(groups(pa), lr=1e-3, betas=(0.9, 0.99), eps=1e-8)
+    ob = torch.optim.Adam(groups(pb), lr=1e-3, betas=(0.9, 0.99), eps=1e-8)
+
+    def steps(oa, pa, ob, pb, n, seed):
+        rg = np.random.RandomState(seed)
+        for k in range(n):
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                if i == 4 and k % 2 == 1:
+                    a.grad = b.grad = None
+                    continue
+                g = torch.from_numpy((rg.standard_normal(a.shape) * 10.0 ** rg.uniform(-6, 0)).astype(np.float32)).to(dev)
+                a.grad, b.grad = g.clone(), g.clone()
+            if k == 2:
+                for o in (oa, ob):
+                    o.param_groups[1]["lr"] *= 0.5
+            oa.step()
+            ob.step()
+    steps(oa, pa, ob, pb, 5, 11)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (i, float((a - b).abs().max()))
+        assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-30), i
+    assert float(oa.state[pa[0]]["step"]) == 5.0 and float(oa.state[pa[4]]["step"]) == 3.0   # (no gradient in steps 1, 3)
+    # state dict -> a fresh optimizer over the same parameters continues the same trajectory
+    sd = oa.state_dict()
+    oc = training.FusedAdam(groups(pa), lr=1e-3, betas=(0.9, 0.99), eps=1e-8)
+    oc.load_state_dict(sd)
+    assert oc.param_groups[1]["lr"] == oa.param_groups[1]["lr"] == 5e-4
+    steps(oc, pa, ob, pb, 3, 12)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=4e-6, atol=4e-7), (i, float((a - b).abs().max()))
+    assert float(oc.state[pa[0]]["step"]) == 8.0 and float(oc.state[pa[4]]["step"]) == 5.0
+    with pytest.raises(Exception, match="MI355X|CPU"):
+        training.FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3).step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("row_mask", [True, False])
+def test_fused_regressor_loss_equals_the_recorded_expression(row_mask):
+    """training.regressor_loss on the GPU (ggnn_masked_mse: loss and gradient in one launch, a fixed summation order)
+    against the same expression as recorded torch ops (train.py:31-37), with a mask per row (the reference's) and per
+    element, an upstream gradient other than one, and bit-identical repeats."""
+    from graingraphnn_amd import training
+    dev = "cuda"
+    rs = np.random.RandomState(5)
+    n = {"joint": 20011, "grain": 9973}
+    f = lambda *sh: torch.from_numpy(rs.uniform(-1, 1, sh).astype(np.float32)).to(dev)
+    y = {nt: f(n[nt], 2) for nt in n}
+    mask = {nt: (f(n[nt], 1) > -0.5).float() if row_mask else (f(n[nt], 2) > -0.5).float() for nt in n}
+    res = []
+    for fn in (training.regressor_loss, training.regressor_loss_recorded, training.regressor_loss):
+        rs2 = np.random.RandomState(6)
+        pred = {nt: torch.from_numpy(rs2.uniform(-1, 1, (n[nt], 2)).astype(np.float32)).to(dev).requires_grad_() for nt in n}
+        loss = fn(y, pred, mask)
+        (loss * 0.37).backward()
+        res.append((loss.detach(), pred["joint"].grad, pred["grain"].grad))
+    (la, gja, gga), (lb, gjb, ggb), (lc, gjc, ggc) = res
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb)), (float(la), float(lb))
+    assert torch.allclose(gja, gjb, rtol=1e-5, atol=1e-9) and torch.allclose(gga, ggb, rtol=1e-5, atol=1e-9)
+    assert torch.equal(la, lc) and torch.equal(gja, gjc) and torch.equal(gga, ggc)
 
 
 @pytest.mark.gpu
