@@ -132,7 +132,7 @@ class DecCellArgs(Structure):
 class WgradArgs(Structure):
     """Mirror of `ggnn_wgrad_args`."""
     _fields_ = [
-        ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p),
+        ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p), ("out", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("a_bstride", c_int64), ("b_bstride", c_int64), ("K", c_int64),
         ("M", c_int32), ("Nc", c_int32), ("batch", c_int32), ("n_split", c_int32),
     ]

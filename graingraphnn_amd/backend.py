@@ -441,12 +441,13 @@ class HipBackend:
                 raise _lib.GGNNError("wgrad: operands must be contiguous float32 tensors that hold every addressed row")
         S = self.lib.ggnn_wgrad_splits(K, M, Nc, batch)
         partial = torch.empty(S, batch, M, Nc, dtype=torch.float32, device=a.device)
+        out = torch.empty(batch, M, Nc, dtype=torch.float32, device=a.device) if S > 1 else None
         w = _lib.WgradArgs()
-        w.a, w.b, w.partial = a.data_ptr(), b.data_ptr(), partial.data_ptr()
+        w.a, w.b, w.partial, w.out = a.data_ptr(), b.data_ptr(), partial.data_ptr(), ptr(out)
         w.lda, w.ldb, w.a_bstride, w.b_bstride, w.K = lda, ldb, a_bstride, b_bstride, K
         w.M, w.Nc, w.batch, w.n_split = M, Nc, batch, S
         self._launch(self.lib.ggnn_wgrad, "ggnn_wgrad", ctypes.byref(w), _lib.current_stream())
-        return partial.sum(0) if S > 1 else partial[0]
+        return out if S > 1 else partial[0]
 
     def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False):
         """ggnn_rowgemm (include/ggnn.h): out[b] = a[b] . W[b]^T (+ c_in[b]) for b < batch.

@@ -28,14 +28,31 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A
     const float bc1 = 1.0f - powf(A.beta1, s), bc2 = 1.0f - powf(A.beta2, s);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const int64_t i1 = min(T.n, i0 + AD_CHUNK);
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += AD_THREADS) {
-      float p = T.param[i], g = grad[i];
-      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
-      const float m = __builtin_fmaf(A.beta1, T.exp_avg[i], (1.0f - A.beta1) * g);
-      const float v = __builtin_fmaf(A.beta2, T.exp_avg_sq[i], (1.0f - A.beta2) * g * g);
-      T.exp_avg[i] = m;
-      T.exp_avg_sq[i] = v;
-      T.param[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + A.eps));
+    // a thread's 16 elements in two batches of 8 with every load of a batch requested before the first use: one element at
+    // a time the kernel was a chain of 16 memory round trips per thread (37 us for the model's 1.3 M parameters)
+    constexpr int NB = 8;
+    static_assert(AD_CHUNK % (NB * AD_THREADS) == 0, "chunk = whole batches");
+#pragma unroll 1
+    for (int64_t base = i0 + threadIdx.x; base < i1; base += NB * AD_THREADS) {
+      float p[NB], g[NB], m[NB], v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int64_t i = min(base + j * AD_THREADS, i1 - 1);   // (clamped: loaded, not stored)
+        p[j] = T.param[i], g[j] = grad[i], m[j] = T.exp_avg[i], v[j] = T.exp_avg_sq[i];
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int64_t i = base + j * AD_THREADS;
+        if (i < i1) {
+          float gg = g[j];
+          if (wd != 0.f) gg = __builtin_fmaf(wd, p[j], gg);
+          const float mn = __builtin_fmaf(A.beta1, m[j], (1.0f - A.beta1) * gg);
+          const float vn = __builtin_fmaf(A.beta2, v[j], (1.0f - A.beta2) * gg * gg);
+          T.exp_avg[i] = mn;
+          T.exp_avg_sq[i] = vn;
+          T.param[i] = p[j] - step_size * (mn / (sqrtf(vn) * inv_sqrt_bc2 + A.eps));
+        }
+      }
     }
   }
   __shared__ bool last;

@@ -182,6 +182,26 @@ static WgradPlan wgrad_plan(int64_t K, int M, int Nc, int batch) {
   return p;
 }
 
+// out[i] = sum_s partial[s][i], s in index order (a fixed order: reproducible), four elements per thread, the loads of
+// eight splits in flight together.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int64_t n4, int n_split) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(partial) + i;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= n_split; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(s + j) * n4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; s < n_split; ++s) acc += p[(int64_t)s * n4];
+  reinterpret_cast<f32x4*>(out)[i] = acc;
+}
+
 }  // namespace ggnn
 
 extern "C" int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch) {
@@ -203,9 +223,16 @@ extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffff) return GGNN_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (W.out && !aligned16(W.out)) return GGNN_EINVAL;
   if (p.ta == 4)
     hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
   else
     hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
+  if (hipGetLastError() != hipSuccess) return GGNN_ELAUNCH;
+  if (W.out) {   // (M, Nc multiples of 4: whole float4s)
+    const int64_t n4 = (int64_t)W.batch * W.M * W.Nc / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, W.partial, W.out, n4,
+                       W.n_split);
+  }
   return hipGetLastError() == hipSuccess ? 0 : GGNN_ELAUNCH;
 }

@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, graph_for, prepare_edges, run_cell
-from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, pack_conv
+from .packing import C, EDGE_TYPES, NODE_TYPES, bf16_planes, et_key, pack_cell, pack_conv, padded_cell, padded_conv
 
 
 def _param_version(module: nn.Module):
@@ -40,8 +40,8 @@ class PeriodConv(nn.Module):
         super().__init__()
         if isinstance(in_channels, int):
             in_channels = (in_channels, in_channels)
-        if out_channels != C:
-            raise NotImplementedError(f"the HIP path is built for layer_size {C} (got {out_channels})")
+        if not 1 <= out_channels <= C:
+            raise NotImplementedError(f"the HIP path is built for layer_size <= {C} (got {out_channels})")
         self.in_channels = tuple(in_channels)
         self.out_channels = out_channels
         self.lin_key = nn.Linear(in_channels[0], out_channels)
@@ -53,18 +53,21 @@ class PeriodConv(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, edge_index, edge_attr=None):
-        """x: Tensor or (x_src, x_dst), rows = cat[features, h] (width F + 96) or bare
-        features (width F <= 12); edge_index [2, E] int64; edge_attr [E, 1].  -> [N_dst, 96]."""
+        """x: Tensor or (x_src, x_dst), rows = cat[features, h] (width F + layer_size) or bare
+        features (width F <= 12); edge_index [2, E] int64; edge_attr [E, 1].  -> [N_dst, layer_size].
+        (layer_size < 96: on the 96-wide kernels with zero-padded parameters and hidden columns, packing.padded_conv.)"""
         be = default_backend()
         x_src, x_dst = (x, x) if isinstance(x, torch.Tensor) else x
         Ds, Dd = self.in_channels
+        c = self.out_channels
         k2 = C if Ds > 12 else 0
-        Fs, Fd = Ds - k2, Dd - k2
-        wps, bps, wpd, bpd, ep, w2 = pack_conv(self, Fs, Fd, k2)
+        Fs, Fd = (Ds - c, Dd - c) if k2 else (Ds, Dd)
+        wps, bps, wpd, bpd, ep, w2 = pack_conv(self if c == C else padded_conv(self, c), Fs, Fd, k2)
         dev = x_src.device
         xs, xd = x_src[:, :Fs].contiguous(), x_dst[:, :Fd].contiguous()
-        hs = x_src[:, Fs:].contiguous() if k2 else None
-        hd = x_dst[:, Fd:].contiguous() if k2 else None
+        widen = lambda h: h.contiguous() if c == C else torch.nn.functional.pad(h, (0, C - c)).contiguous()
+        hs = widen(x_src[:, Fs:]) if k2 else None
+        hd = widen(x_dst[:, Fd:]) if k2 else None
         ps = torch.empty(x_src.size(0), C, device=dev)          # [V]
         pd = torch.empty(x_dst.size(0), 3 * C, device=dev)      # [u_h | S | u4, zero rows]
         be.project(xs, Fs, hs, wps, bps, ps)
@@ -76,7 +79,7 @@ class PeriodConv(nn.Module):
         be.aggregate(csr, einfo, ps, pd, hs, ep, agg, 0, 0, 2 * C, 0, 100, C, 1)
         out = torch.empty(x_dst.size(0), C, device=dev)
         be.lstm_epilogue(agg, w2, pd, C, None, None, None, out, 1, _lib.MODE_RAW, bf16_planes(w2))
-        return out
+        return out if c == C else out[:, :c].contiguous()
 
 
 class HeteroConv(nn.Module):
@@ -91,8 +94,8 @@ class HeteroPGCLSTM(nn.Module):
 
     def __init__(self, in_channels_dict, out_channels, metadata, bias=True, device="cpu"):
         super().__init__()
-        if out_channels != C:
-            raise NotImplementedError(f"the HIP path is built for layer_size {C} (got {out_channels})")
+        if not 1 <= out_channels <= C:
+            raise NotImplementedError(f"the HIP path is built for layer_size <= {C} (got {out_channels})")
         self.in_channels_dict = dict(in_channels_dict)
         self.out_channels = out_channels
         self.metadata = metadata
@@ -105,10 +108,11 @@ class HeteroPGCLSTM(nn.Module):
                 raise NotImplementedError(f"{nt}: feature width {F} outside the supported 3..12")
         self.edge_types = edge_types
         for g in "ifco":
+            c = out_channels
             setattr(self, "conv_" + g, HeteroConv({
-                et: PeriodConv((in_channels_dict[et[0]] + C, in_channels_dict[et[-1]] + C), C, bias)
+                et: PeriodConv((in_channels_dict[et[0]] + c, in_channels_dict[et[-1]] + c), c, bias)
                 for et in edge_types}))
-            b = nn.ParameterDict({nt: nn.Parameter(torch.empty(1, C)) for nt in in_channels_dict})
+            b = nn.ParameterDict({nt: nn.Parameter(torch.empty(1, c)) for nt in in_channels_dict})
             for p in b.values():
                 bound = math.sqrt(6.0 / (p.size(-2) + p.size(-1)))  # glorot, heteropgclstm.py:90-99
                 nn.init.uniform_(p, -bound, bound)
@@ -122,7 +126,9 @@ class HeteroPGCLSTM(nn.Module):
         key = (encoder, tuple(live))
         hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, pack_cell(self, self.in_channels_dict, encoder, live=tuple(live)))
+            # (layer_size < 96: the 96-wide kernels on zero-padded parameters, packing.padded_cell)
+            src = self if self.out_channels == C else padded_cell(self, self.out_channels)
+            hit = (ver, pack_cell(src, self.in_channels_dict, encoder, live=tuple(live)))
             self._packed[key] = hit
         return hit[1]
 
@@ -142,13 +148,18 @@ class HeteroPGCLSTM(nn.Module):
         h_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
         c_out = {nt: torch.empty(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
+        cw = self.out_channels
+        widen = lambda t: t.contiguous() if cw == C else torch.nn.functional.pad(t, (0, C - cw)).contiguous()
         if not encoder:
             if c_dict is None:
-                c_dict = {nt: torch.zeros(n_nodes[nt], C, **f32) for nt in NODE_TYPES}
-            h_dict = {nt: h_dict[nt].contiguous() for nt in NODE_TYPES}
-            c_dict = {nt: c_dict[nt].contiguous() for nt in NODE_TYPES}
+                c_dict = {nt: torch.zeros(n_nodes[nt], cw, **f32) for nt in NODE_TYPES}
+            h_dict = {nt: widen(h_dict[nt]) for nt in NODE_TYPES}
+            c_dict = {nt: widen(c_dict[nt]) for nt in NODE_TYPES}
         einfo = prepare_edges(be, graph, x_dict, ea, None)
         run_cell(be, pc, graph, x_dict, einfo, h_dict, c_dict, proj, agg, h_out, c_out)
+        if cw != C:   # (the padded channels are exactly zero)
+            h_out = {nt: t[:, :cw].contiguous() for nt, t in h_out.items()}
+            c_out = {nt: t[:, :cw].contiguous() for nt, t in c_out.items()}
         return h_out, c_out
 
 

@@ -316,6 +316,68 @@ def _conv(cell, gate, et):
     return getattr(cell, "conv_" + gate).convs[et_key(et)]
 
 
+# ---- layer_size < 96 (parameters.py:19: the regressor's grid also holds 64 and 32) ---------------------------------
+# The kernels are built for 96 hidden channels.  A narrower model runs on them ZERO-PADDED: every [c]-sized axis of a
+# parameter (output rows, the hidden-state part of the input columns) is padded to 96, and the query side is scaled by
+# sqrt(96 / c) (periodGATconv.py:226 divides the scores by sqrt(out_channels); the packed weights fold in 1 / sqrt(96)).
+# The padded channels stay exactly zero through a cell -- zero rows of lin_value / lin_skip / lin_l2 / lin_edge and a
+# zero gate bias give pre-activations 0: i = f = o = 1/2, c~ = 0, so c' = c / 2 = 0 and h' = tanh(0) / 2 = 0 -- and meet
+# zero columns everywhere they are read.  Same results as the c-wide model up to fp32 summation order; same speed as
+# the 96-wide one.
+class _Holder:
+    """Attribute bag standing in for an nn.Module in the packers (`.weight`, `.bias`, `.convs[...]`, ...)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _pad_axis(t, dim, c, F=None):
+    """Zero-pad axis `dim` of `t` from c to C; with F: the axis is [F features | c hidden] -> [F | C]."""
+    if t is None:
+        return None
+    t = t.detach()
+    lead = 0 if F is None else F
+    if t.size(dim) != lead + c:
+        raise ValueError(f"parameter axis of {t.size(dim)} entries, expected {lead + c}")
+    shape = list(t.shape)
+    shape[dim] = lead + C
+    out = t.new_zeros(shape)
+    out.narrow(dim, 0, lead + c).copy_(t)
+    return out
+
+
+def padded_conv(conv, c: int):
+    """A PeriodConv of width c < 96 as a holder of 96-wide tensors (see above)."""
+    Ds, Dd = conv.in_channels
+    has_h = Ds > 12
+    Fs, Fd = (Ds - c, Dd - c) if has_h else (Ds, Dd)
+    q = math.sqrt(C / c)
+
+    def lin(m, F, scale=1.0, square=False):
+        w = _pad_axis(m.weight, 0, c)
+        if square:
+            w = _pad_axis(w, 1, c)
+        elif has_h and F is not None:
+            w = _pad_axis(w, 1, c, F)
+        b = _pad_axis(m.bias, 0, c) if m.bias is not None else None
+        return _Holder(weight=w * scale, bias=None if b is None else b * scale)
+    return _Holder(in_channels=(Fs + C, Fd + C) if has_h else (Ds, Dd), out_channels=C,
+                   lin_key=lin(conv.lin_key, Fs), lin_query=lin(conv.lin_query, Fd, q), lin_value=lin(conv.lin_value, Fs),
+                   lin_l2=lin(conv.lin_l2, None, square=True), lin_edge=lin(conv.lin_edge, None),
+                   lin_skip=lin(conv.lin_skip, Fd))
+
+
+@torch.no_grad()
+def padded_cell(cell, c: int):
+    """A HeteroPGCLSTM of width c < 96 as a holder tree of 96-wide tensors with the attribute names pack_cell reads."""
+    out = _Holder()
+    for g in "ifco":
+        hc = getattr(cell, "conv_" + g)
+        setattr(out, "conv_" + g, _Holder(convs={k: padded_conv(m, c) for k, m in hc.convs.items()}))
+        setattr(out, "b_" + g, {nt: _pad_axis(b, 1, c) for nt, b in getattr(cell, "b_" + g).items()})
+    return out
+
+
 @torch.no_grad()
 def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_TYPES,
               live=NODE_TYPES) -> PackedCell:
@@ -491,16 +553,24 @@ def pack_conv(conv, F_src: int, F_dst: int, k2: int):
 
 @torch.no_grad()
 def pack_regressor_heads(linear):
-    """`linear` = ModuleDict {'grain','joint'} of Linear(96, 2) (models.py:393-394)."""
-    w = torch.stack([linear["joint"].weight, linear["grain"].weight]).detach().float().contiguous()
+    """`linear` = ModuleDict {'grain','joint'} of Linear(layer_size, 2) (models.py:393-394); narrower than 96: zero
+    columns for the padded channels."""
+    c = linear["joint"].weight.size(1)
+    wj, wg = (_pad_axis(linear[nt].weight, 1, c) if c != C else linear[nt].weight for nt in ("joint", "grain"))
+    w = torch.stack([wj, wg]).detach().float().contiguous()
     b = torch.cat([linear["joint"].bias, linear["grain"].bias]).detach().float().contiguous()
     return w, b  # [2, 2, 96], [4]
 
 
 @torch.no_grad()
 def pack_classifier_heads(lin1, lin2):
-    """lin1: Linear(193, 2), lin2: Linear(193, 1) (models.py:568-569)."""
+    """lin1: Linear(2 layer_size + 1, 2), lin2: Linear(2 layer_size + 1, 1) (models.py:568-569); input order
+    [h_src | h_dst | edge length].  Narrower than 96: zero columns for the padded channels of both hidden blocks."""
     w1, w2 = lin1.weight.detach().float(), lin2.weight.detach().float()
+    c = (w1.size(1) - 1) // 2
+    if c != C:
+        widen = lambda w: torch.cat([_pad_axis(w[:, :c], 1, c), _pad_axis(w[:, c:2 * c], 1, c), w[:, 2 * c:]], 1)
+        w1, w2 = widen(w1), widen(w2)
     w_node = torch.stack([w1[0, :C], w1[1, :C], w2[0, :C], w1[0, C:2 * C], w1[1, C:2 * C], w2[0, C:2 * C]])
     w_edge = torch.stack([w1[0, 2 * C], w1[1, 2 * C], w2[0, 2 * C], lin1.bias[0].detach().float(),
                           lin1.bias[1].detach().float(), lin2.bias[0].detach().float()])

@@ -230,7 +230,9 @@ class _PackedCell(torch.autograd.Function):
 def cell_forward(cell, backend, topo, einfo, x, h, c):
     """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation: the packed
     weights are assembled from the parameters by recorded torch ops, the cell itself is _PackedCell.
-    h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped)."""
+    h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped).
+    (Measured and dropped, round 4: the decoder's packed weights assembled on a side stream beside the encoder cell -- a
+    replayed hipGraph ran the two branches one after the other, with launch gaps between their small kernels.)"""
     gates = "ifco" if h is not None else "ico"
     G = len(gates)
     F = cell.in_channels_dict
@@ -519,7 +521,12 @@ def wants_autograd(model, x_dict=None) -> bool:
         raise NotImplementedError("gradients with respect to x_dict are not built (the reference's training "
                                   "loop never asks for them, train.py:158-166): detach the inputs")
     if model.training:
-        return any(p.requires_grad for p in model.parameters())
+        if any(p.requires_grad for p in model.parameters()):
+            if getattr(model, "out_channels", C) != C:
+                raise NotImplementedError(f"the training path is built for layer_size {C} only (the narrower models of "
+                                          "parameters.py:19 run inference on zero-padded weights, packing.padded_cell)")
+            return True
+        return False
     if not _warned_eval_grad and any(p.requires_grad for p in model.parameters()):
         _warned_eval_grad = True
         import warnings

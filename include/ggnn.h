@@ -562,12 +562,13 @@ int ggnn_heads_regressor_backward(int64_t n_joint, int64_t n_grain, const float*
  * M x Nc result -- the gradient of a packed projection ([ncols, F + 97]) or gate ([96, Kg] per gate) weight
  * matrix, replacing the BLAS call autograd would make for x.t() @ g (which does not split K).  The reduction is
  * split over the chip in a fixed way; the call writes partial[s][b][M][Nc], s < ggnn_wgrad_splits(K, M, Nc, batch),
- * and the caller sums over s.  Exact fp32 products (v_mfma_f32_16x16x4_f32).  M, Nc, lda, ldb, a_bstride,
+ * and sums over s into `out` (in index order; out == NULL: left to the caller).  Exact fp32 products (v_mfma_f32_16x16x4_f32).  M, Nc, lda, ldb, a_bstride,
  * b_bstride multiples of 4 (pad B with zero columns otherwise); a, b 16-byte aligned. */
 typedef struct ggnn_wgrad_args {
   const float* a;  /* [batch] x [K, lda] row-major, first M columns used; batch b starts at a + b * a_bstride */
   const float* b;  /* [batch] x [K, ldb], first Nc columns used; batch b starts at b + b * b_bstride */
   float* partial;  /* [n_split, batch, M, Nc] out */
+  float* out;      /* [batch, M, Nc] out: the sum over the splits, or NULL (16-byte aligned) */
   int64_t lda, ldb, a_bstride, b_bstride, K;
   int32_t M, Nc, batch, n_split;
 } ggnn_wgrad_args;

@@ -491,6 +491,47 @@ def test_tiny_graphs_against_oracle(n_g, n_j):
         assert_close(yc[k], oyc[k], f"tiny ({n_g}, {n_j}) classifier {k}")
 
 
+@pytest.mark.parametrize("layer_size", [64, 32])
+@torch.no_grad()
+def test_narrow_layer_sizes_forward_and_rollout_against_oracle(layer_size):
+    """parameters.py:19: layer_size 64 / 32 on the 96-wide kernels through zero-padded packed weights
+    (packing.padded_cell): both forwards on the 40 um fixture, a three-step rollout (two streams, hipGraph) on the folded
+    120 um fixture, the module-level cell call with a caller-held hidden state -- each against the oracle of that width."""
+    from graingraphnn_amd import GrainRollout
+    from test_host_logic import _narrow_models
+    (R, Cm), (oR, oC) = _narrow_models(layer_size, 31, DEV)
+    x, ei, ea = load_graph("40")
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    yr, yc = R(X, EI, EA), Cm(X, EI, EA)
+    oyr, oyc = oR(tt(x), tt(ei), tt(ea)), oC(tt(x), tt(ei), tt(ea))
+    for k in ("joint", "grain", "grain_area"):
+        assert_close(yr[k], oyr[k], f"layer_size {layer_size} regressor {k}")
+    for k in ("edge_event", "edge"):
+        assert_close(yc[k], oyc[k], f"layer_size {layer_size} classifier {k}")
+    # the cell as a module: (h, c) of the caller's width in and out
+    cell, ocell = R.gclstm_decoder.cell_list[0], oR.gclstm_decoder.cell_list[0]
+    rs = np.random.RandomState(2)
+    h0 = {nt: rs.uniform(-1, 1, (x[nt].shape[0], layer_size)).astype(np.float32) for nt in x}
+    c0 = {nt: rs.uniform(-1, 1, (x[nt].shape[0], layer_size)).astype(np.float32) for nt in x}
+    h1, c1 = cell(X, EI, EA, tt(h0, DEV), tt(c0, DEV))
+    oh1, oc1 = ocell(tt(x), tt(ei), tt(ea), tt(h0), tt(c0))
+    for nt in x:
+        assert h1[nt].shape == (x[nt].shape[0], layer_size)
+        assert_close(h1[nt], oh1[nt], f"layer_size {layer_size} cell h {nt}")
+        assert_close(c1[nt], oc1[nt], f"layer_size {layer_size} cell c {nt}")
+    # rollout
+    x, ei, ea = load_graph("120")
+    x, ea = fold_120(x, ea)
+    X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=True)
+    for step in range(3):
+        pred = {k: v.clone() for k, v in ro.step().items()}
+        opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert_close(pred[k], opred[k], f"layer_size {layer_size} step {step} {k}")
+
+
 @torch.no_grad()
 def test_voronoi_graph_rollout_against_oracle():
     """A random Voronoi structure (grain degrees 3..11: rows of up to four units, triangles) through

@@ -169,6 +169,63 @@ def test_weights_beyond_fp16_range_fall_back_to_the_unfused_plans():
     assert_close(yg, want["grain"], "range fallback grain", TOL)
 
 
+def _narrow_models(layer_size, seed, device="cpu"):
+    """(product regressor, classifier), (oracle regressor, classifier) of parameters.py:19's narrower layer sizes."""
+    from oracle import grainnn_oracle as oracle
+    from graingraphnn_amd import synthetic
+    from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor
+    from graingraphnn_amd.seeding import load_seeded
+    out = []
+    for R_cls, C_cls, dev in ((GrainNN_regressor, GrainNN_classifier, device),
+                              (oracle.GrainNN_regressor, oracle.GrainNN_classifier, "cpu")):
+        hp = synthetic.default_hyper(dev)
+        hp.layer_size = layer_size
+        R = R_cls(hp)
+        Cm = C_cls(hp, R)
+        load_seeded(R, seed, 2.0).eval()
+        load_seeded(Cm, seed + 1, 2.0).eval()
+        out.append((R.to(dev), Cm.to(dev)))
+    return out
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("layer_size", [64, 32])
+def test_narrow_layer_sizes_run_zero_padded_on_the_96_wide_path(layer_size):
+    """parameters.py:19: the regressor's grid also holds layer_size 64 and 32.  The kernels are 96 wide; a narrower model
+    is packed zero-padded (packing.padded_cell: padded rows / hidden columns, query side scaled by sqrt(96 / c)) and its
+    padded channels stay exactly zero.  Through the emulator of the C ABI: the 284-tensor state dict has the reference's
+    shapes, both models' outputs equal the oracle's of the same width, the hidden state's padding is exactly zero."""
+    (R, Cm), (Ro, Co) = _narrow_models(layer_size, 21)
+    x, ei, ea = load_graph("40")
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    sd, sdo = R.state_dict(), Ro.state_dict()
+    assert list(sd) == list(sdo) and all(sd[k].shape == sdo[k].shape for k in sd) and len(sd) == 284
+    c = layer_size
+    assert sd["gclstm_decoder.cell_list.0.conv_i.convs.joint__connect__joint.lin_key.weight"].shape == (c, 8 + c)
+    be, graph, h = _run_model_emulated(R, X, EI, EA)
+    for nt in h:
+        assert h[nt].shape[1] == 96 and float(h[nt][:, c:].abs().max()) == 0.0 and float(h[nt][:, :c].abs().max()) > 0
+    w, b = packing.pack_regressor_heads(R.linear)
+    yj, yg, area = torch.empty(X["joint"].size(0), 2), torch.empty(X["grain"].size(0), 2), torch.empty(X["grain"].size(0))
+    be.heads_regressor(h["joint"], h["grain"], X["grain"], w, b, yj, yg, area)
+    want = Ro(X, EI, EA)
+    assert_close(yj, want["joint"], f"layer_size {c} joint", TOL)
+    assert_close(yg, want["grain"], f"layer_size {c} grain", TOL)
+    assert_close(area, want["grain_area"], f"layer_size {c} area", TOL)
+    _, graph, hc = _run_model_emulated(Cm, X, EI, EA)
+    w_node, w_edge = packing.pack_classifier_heads(Cm.lin1, Cm.lin2)
+    E = EI[EDGE_TYPES[2]].size(1)
+    ev, ed, tmp = torch.empty(E), torch.empty(E, 2), torch.empty(X["joint"].size(0), 6)
+    be.heads_classifier(hc["joint"], graph.edge_index[EDGE_TYPES[2]], EA[EDGE_TYPES[2]].reshape(-1), w_node, w_edge, tmp, ev, ed)
+    wantc = Co(X, EI, EA)
+    assert_close(ev, wantc["edge_event"], f"layer_size {c} edge_event", TOL)
+    assert_close(ed, wantc["edge"], f"layer_size {c} edge", TOL)
+    # the training path is 96-wide only and says so
+    R.train()
+    with torch.enable_grad(), pytest.raises(NotImplementedError, match="layer_size 96"):
+        R(X, EI, EA)
+
+
 def test_fp16_two_piece_split_is_fp32_equivalent():
     """The arithmetic of the fused decoder cell and of the encoder cell's gate GEMM (csrc/common.h: split_f16x2,
     mfma_x3h; packing.split2_f16): x = hi + lo' / 2^11 with two fp16 pieces, three of the four products, the cross
