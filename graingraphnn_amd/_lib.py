@@ -158,7 +158,7 @@ class AdamTensor(Structure):
 class AdamArgs(Structure):
     """Mirror of `ggnn_adam_args`."""
     _fields_ = [("table", c_void_p), ("chunk_tensor", c_void_p), ("chunk_index", c_void_p), ("step", c_void_p),
-                ("counter", c_void_p), ("grad", c_void_p * GGNN_ADAM_MAX_TENSORS), ("lr", c_float * GGNN_ADAM_MAX_GROUPS),
+                ("grad", c_void_p * GGNN_ADAM_MAX_TENSORS), ("lr", c_float * GGNN_ADAM_MAX_GROUPS),
                 ("weight_decay", c_float * GGNN_ADAM_MAX_GROUPS), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("n_chunks", c_int32), ("n_tensors", c_int32)]
 

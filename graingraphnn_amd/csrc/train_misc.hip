@@ -12,10 +12,8 @@ constexpr int AD_THREADS = 256;
 constexpr int AD_CHUNK = GGNN_ADAM_CHUNK;   // elements per workgroup
 
 // step[t]: updates tensor t has had so far (a float per tensor, as torch keeps it: a tensor without a gradient in some step
-// does not advance); *counter: arrival counter of the running launch (0 between launches).  Every workgroup reads its tensor's
-// count before it announces itself; the last workgroup to arrive advances the counts of the tensors that had a gradient.
-// What changes from step to step -- the gradients' addresses, the learning rates -- travels in the kernel arguments (3 KB):
-// nothing is staged through host memory that a later step could overwrite while an earlier one is still queued.
+// does not advance).  What changes from step to step -- the gradients' addresses, the learning rates -- travels in the kernel
+// arguments (3 KB): nothing is staged through host memory that a later step could overwrite while an earlier one is queued.
 __global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A) {
   const int ti = A.chunk_tensor[blockIdx.x];
   const ggnn_adam_tensor T = A.table[ti];
@@ -29,7 +27,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const int64_t i1 = min(T.n, i0 + AD_CHUNK);
     // a thread's 16 elements in two batches of 8 with every load of a batch requested before the first use: one element at
-    // a time the kernel was a chain of 16 memory round trips per thread (37 us for the model's 1.3 M parameters)
+    // a time the kernel was a chain of 16 memory round trips per thread
     constexpr int NB = 8;
     static_assert(AD_CHUNK % (NB * AD_THREADS) == 0, "chunk = whole batches");
 #pragma unroll 1
@@ -55,18 +53,13 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A
       }
     }
   }
-  __shared__ bool last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(A.counter, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (last) {
-    for (int t = threadIdx.x; t < A.n_tensors; t += AD_THREADS)
-      if (A.grad[t] != nullptr) A.step[t] += 1.0f;
-    if (threadIdx.x == 0) *A.counter = 0u;
-  }
+}
+
+// ... and the counts advance in a launch of their own behind it (one workgroup).  (First version: the last workgroup of the
+// update to arrive at a counter advanced them -- 580 atomics on one address, 17 of the kernel's 26 us.)
+__global__ __launch_bounds__(AD_THREADS) void adam_advance_kernel(const ggnn_adam_args A) {
+  for (int t = threadIdx.x; t < A.n_tensors; t += AD_THREADS)
+    if (A.grad[t] != nullptr) A.step[t] += 1.0f;
 }
 
 // loss = scale * sum_k mean_i(mask_k[i / mask_div_k] * (pred_k[i] - target_k[i])^2), g_pred_k = d loss / d pred_k.
@@ -120,10 +113,11 @@ extern "C" int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream) 
   using namespace ggnn;
   if (!args) return GGNN_EINVAL;
   const ggnn_adam_args& A = *args;
-  if (!A.table || !A.chunk_tensor || !A.chunk_index || !A.step || !A.counter || A.n_chunks <= 0) return GGNN_EINVAL;
+  if (!A.table || !A.chunk_tensor || !A.chunk_index || !A.step || A.n_chunks <= 0) return GGNN_EINVAL;
   if (A.n_tensors < 1 || A.n_tensors > GGNN_ADAM_MAX_TENSORS) return GGNN_EINVAL;
   if (!(A.beta1 >= 0.f && A.beta1 < 1.f) || !(A.beta2 >= 0.f && A.beta2 < 1.f) || !(A.eps >= 0.f)) return GGNN_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)A.n_chunks), dim3(AD_THREADS), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(AD_THREADS), 0, (hipStream_t)stream, A);
   return launch_status();
 }
 

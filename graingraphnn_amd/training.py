@@ -405,8 +405,8 @@ class FusedAdam(torch.optim.Optimizer):
     in 14 launches (~0.1 ms of a 2 ms training step at the 10k-grain graph).  What is fixed about a tensor (addresses of
     the parameter and its moments, size, group) sits in a table in device memory; what changes from step to step -- the
     gradients' addresses (new tensors after every backward), the groups' learning rates (a scheduler edits
-    `param_groups[i]["lr"]`) -- travels in the launch's arguments.  The step count lives on the device and the launch
-    increments it itself, so `step()` can be captured in a hipGraph (`GraphedTrainStep`); a captured step replays the
+    `param_groups[i]["lr"]`) -- travels in the launch's arguments.  The step counts live on the device and the call
+    increments them itself, so `step()` can be captured in a hipGraph (`GraphedTrainStep`); a captured step replays the
     learning rates it was captured with, as torch's capturable Adam does with a float `lr`.
 
     Same arithmetic as torch.optim.Adam(amsgrad=False, maximize=False): tests compare the two.  State per parameter
@@ -437,7 +437,6 @@ class FusedAdam(torch.optim.Optimizer):
         offs = np.concatenate([[0], np.cumsum([-(-n // 4) * 4 for n in sizes])])   # 16-byte aligned views
         m, v = torch.zeros(int(offs[-1]), device=dev), torch.zeros(int(offs[-1]), device=dev)
         step = torch.zeros(len(ps), device=dev)   # a count per tensor, as torch keeps it
-        counter = torch.zeros(1, dtype=torch.int32, device=dev)
         table = np.zeros(len(ps), dtype=np.dtype([("param", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("n", "<i8"),
                                                   ("group", "<i4"), ("reserved", "<i4")]))
         assert table.itemsize == ctypes.sizeof(_lib.AdamTensor)
@@ -456,7 +455,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ci += list(range(nc))
             launches.append((t0, cnt, torch.tensor(ct, dtype=torch.int32, device=dev),
                              torch.tensor(ci, dtype=torch.int32, device=dev)))
-        self._built = dict(ps=ps, m=m, v=v, step=step, counter=counter, dev_table=dev_table, launches=launches, params_at=[p.data_ptr() for p, _ in ps])
+        self._built = dict(ps=ps, m=m, v=v, step=step, dev_table=dev_table, launches=launches, params_at=[p.data_ptr() for p, _ in ps])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -474,7 +473,7 @@ class FusedAdam(torch.optim.Optimizer):
             a = _lib.AdamArgs()
             a.table = b["dev_table"].data_ptr() + t0 * ctypes.sizeof(_lib.AdamTensor)
             a.chunk_tensor, a.chunk_index = ct.data_ptr(), ci.data_ptr()
-            a.step, a.counter = b["step"].data_ptr() + 4 * t0, b["counter"].data_ptr()
+            a.step = b["step"].data_ptr() + 4 * t0
             for k in range(cnt):
                 p = b["ps"][t0 + k][0]
                 gr = p.grad

@@ -581,9 +581,9 @@ int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
  * [chunk_index[c] * GGNN_ADAM_CHUNK, +GGNN_ADAM_CHUNK) of tensor chunk_tensor[c] (DEVICE arrays of n_chunks entries, built once
  * from the sizes).  What changes per step comes by value: grad[t] (NULL: tensor t is skipped), lr / weight_decay per group.
  * step (DEVICE, n_tensors floats, 0 before the first call): step[t] = updates tensor t has had so far -- read for the bias
- * corrections and incremented by the launch itself where grad[t] != NULL (torch keeps a count per parameter: one without a
- * gradient does not advance), so a captured launch replays correctly; counter (DEVICE, one zero word): scratch.  A model with
- * more tensors takes several calls per update, each on its own slice of the table and of step.  Per element:
+ * corrections and incremented by the call itself (a second small launch) where grad[t] != NULL (torch keeps a count per
+ * parameter: one without a gradient does not advance), so a captured call replays correctly.  A model with more tensors
+ * takes several calls per update, each on its own slice of the table and of step.  Per element:
  *   g += weight_decay p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
  *   p -= lr / (1 - b1^s) * m / (sqrt(v) / sqrt(1 - b2^s) + eps),   s = step[t] + 1. */
 #define GGNN_ADAM_CHUNK 4096
@@ -601,7 +601,6 @@ typedef struct ggnn_adam_args {
   const int32_t* chunk_tensor;
   const int32_t* chunk_index;
   float* step;
-  uint32_t* counter;
   const float* grad[GGNN_ADAM_MAX_TENSORS];
   float lr[GGNN_ADAM_MAX_GROUPS], weight_decay[GGNN_ADAM_MAX_GROUPS];
   float beta1, beta2, eps;
