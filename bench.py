@@ -503,14 +503,16 @@ def train_step_records():
     """BASELINE config 5's kernel path beside the headline: one optimisation step of the regressor (forward, loss,
     backward, Adam) on the HIP training path, for a collated batch of four 40 um graphs (train.py:365-366's batch) and
     for the 10k-grain graph, eager and replayed from a hipGraph, with the reference's optimizer call
-    (torch.optim.Adam(...): the foreach implementation, ~40 launches over 284 tensors) and with Adam(fused=True) (the
-    same update in one launch).  Child processes (tests/bench_train_step.py); a failure leaves a string in the
-    record and never touches the headline."""
+    (torch.optim.Adam(...): the foreach implementation, ~40 launches over 284 tensors), with Adam(fused=True) (14
+    launches) and with training.FusedAdam (ggnn_adam_step: the same update in two launches); the cfg3 record of the
+    fastest configuration carries live per-call roofline records of the weight-gradient GEMM, the sweep backward and
+    the row GEMMs (`kernel_rooflines`).  Child processes (tests/bench_train_step.py); a failure leaves a string in
+    the record and never touches the headline."""
     import subprocess
     script = os.path.join(ROOT, "tests", "bench_train_step.py")
     out = []
-    for extra in (["--graph", "--fused"], ["--graph", "--fused", "--cfg3", "--roofline"], ["--graph", "--fused", "--cfg3", "--bf16"],
-                  ["--graph", "--cfg3"], ["--cfg3"]):
+    for extra in (["--graph", "--ggnn-adam"], ["--graph", "--ggnn-adam", "--cfg3", "--roofline"],
+                  ["--graph", "--ggnn-adam", "--cfg3", "--bf16"], ["--graph", "--fused", "--cfg3"], ["--graph", "--cfg3"], ["--cfg3"]):
         try:
             r = subprocess.run([sys.executable, script, "--no-cpu", "--json", "--steps", "20"] + extra,
                                capture_output=True, text=True, timeout=300)
