@@ -22,6 +22,7 @@ GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
 GGNN_FLAG_F16_RANGE = 1
 GGNN_ADAM_CHUNK, GGNN_ADAM_MAX_TENSORS, GGNN_ADAM_MAX_GROUPS = 4096, 384, 8
+GGNN_ROWGEMM_MAX_PACK = 8
 GGNN_MSE_MAX_TERMS, GGNN_MSE_BLOCKS = 4, 64
 MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 
@@ -35,8 +36,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
-    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
-    "ggnn_adam_step", "ggnn_masked_mse",
+    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
+    "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -145,7 +146,7 @@ class RowGemmArgs(Structure):
         ("workspace_bytes", c_size_t),
         ("M", c_int64), ("lda", c_int64), ("ldc", c_int64), ("a_bstride", c_int64), ("c_bstride", c_int64),
         ("w_bstride", c_int64), ("w_nstride", c_int64), ("w_kstride", c_int64),
-        ("K", c_int32), ("n_out", c_int32), ("batch", c_int32), ("precision", c_int32),
+        ("K", c_int32), ("n_out", c_int32), ("batch", c_int32), ("precision", c_int32), ("prepacked", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -273,10 +274,14 @@ def _declare(lib):
     lib.ggnn_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     lib.ggnn_rowgemm_workspace_bytes.restype = c_size_t
     lib.ggnn_rowgemm_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.ggnn_rowgemm_pack.restype = c_int
+    lib.ggnn_rowgemm_pack.argtypes = [POINTER(RowGemmArgs), c_int, c_void_p]
     lib.ggnn_rowgemm.restype = c_int
     lib.ggnn_rowgemm.argtypes = [POINTER(RowGemmArgs), c_void_p]
     lib.ggnn_adam_step.restype = c_int
     lib.ggnn_adam_step.argtypes = [POINTER(AdamArgs), c_void_p]
+    lib.ggnn_sum_rows.restype = c_int
+    lib.ggnn_sum_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p]
     lib.ggnn_masked_mse.restype = c_int
     lib.ggnn_masked_mse.argtypes = [POINTER(MseArgs), c_void_p]
     lib.ggnn_heads_regressor_backward.restype = c_int

@@ -43,7 +43,7 @@ class HipBackend:
         self.lib = _lib.load()
         self._tape = None  # while a list: every hot-path launch is also recorded as (cfunc, name, cargs)
         self._range_flags = {}  # device -> int32 word the fp16 two-piece kernels report clamped activations in
-        self._rowgemm_ws = {}   # (device, bytes) -> weight-plane workspace of ggnn_rowgemm
+        self._rowgemm_ws = {}   # (device, stream, bytes) -> weight-plane workspace of ggnn_rowgemm
         self._mse_ws = {}       # device -> partial sums + arrival counter of ggnn_masked_mse
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
@@ -449,45 +449,87 @@ class HipBackend:
         self._launch(self.lib.ggnn_wgrad, "ggnn_wgrad", ctypes.byref(w), _lib.current_stream())
         return out if S > 1 else partial[0]
 
-    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False):
+    @staticmethod
+    def _rowgemm_weight(g, w, K, n_out, batch, transposed, bf16):
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        if w.dtype != torch.float32 or w.dim() != 3 or w.stride(2) != 1 or w.size(0) != batch:
+            raise _lib.GGNNError("ggnn_rowgemm: w must be a float32 [batch, rows, cols] view with unit column stride")
+        if (transposed and (w.size(1) < K or w.size(2) < n_out)) or (not transposed and (w.size(1) < n_out or w.size(2) < K)):
+            raise _lib.GGNNError("ggnn_rowgemm: w does not hold [n_out, K] (or its transpose)")
+        g.w, g.w_bstride = w.data_ptr(), (w.stride(0) if batch > 1 else 0)
+        g.w_nstride, g.w_kstride = (1, w.stride(1)) if transposed else (w.stride(1), 1)
+        g.K, g.n_out, g.batch, g.precision = K, n_out, batch, _lib.GGNN_PRECISION_BF16 if bf16 else 0
+
+    def rowgemm_pack(self, weights):
+        """ggnn_rowgemm_pack: the weight planes of several ggnn_rowgemm products in ONE launch.  `weights` = [(w, K, n_out,
+        batch, transposed, bf16)] as `rowgemm` takes them; returns one plane tensor per product for `rowgemm(..., planes=)`
+        (fresh tensors: they may be kept until the backward pass)."""
+        out = []
+        for i0 in range(0, len(weights), _lib.GGNN_ROWGEMM_MAX_PACK):
+            chunk = weights[i0:i0 + _lib.GGNN_ROWGEMM_MAX_PACK]
+            arr = (_lib.RowGemmArgs * len(chunk))()
+            for g, (w, K, n_out, batch, transposed, bf16) in zip(arr, chunk):
+                _require_cuda(w)
+                self._rowgemm_weight(g, w, K, n_out, batch, transposed, bf16)
+                nbytes = self.lib.ggnn_rowgemm_workspace_bytes(K, n_out, batch)
+                ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=w.device)
+                g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+                out.append(ws)
+            self._launch(self.lib.ggnn_rowgemm_pack, "ggnn_rowgemm_pack", arr, len(chunk), _lib.current_stream())
+        return out
+
+    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False, planes=None):
         """ggnn_rowgemm (include/ggnn.h): out[b] = a[b] . W[b]^T (+ c_in[b]) for b < batch.
         `a`   : [M, lda] (batch 1) or [batch, M, lda] float32 view with unit column stride: the first K columns;
         `w`   : [batch, n_out, >= K] (transposed=False: W[b] = w[b][:, :K]) or [batch, K, >= n_out] (transposed=True:
                 W[b] = w[b][:, :n_out]^T -- a gradient uses the transpose of the forward's weight), or 2-D for batch 1;
         `out` : [M, ldc] / [batch, M, ldc] float32 view with unit column stride: its first n_out columns are written;
-        `c_in`: optional, same layout as out (may be out itself)."""
+        `c_in`: optional, same layout as out (may be out itself);
+        `planes`: the weight planes of exactly this (w, K, n_out, batch, transposed, bf16) from `rowgemm_pack`."""
         _require_cuda(a, w, out, c_in)
         if a.dim() == 2:
             a = a.unsqueeze(0)
         if out.dim() == 2:
             out = out.unsqueeze(0)
-        if w.dim() == 2:
-            w = w.unsqueeze(0)
         if c_in is not None and c_in.dim() == 2:
             c_in = c_in.unsqueeze(0)
-        for t, name in ((a, "a"), (w, "w"), (out, "out"), (c_in, "c_in")):
+        for t, name in ((a, "a"), (out, "out"), (c_in, "c_in")):
             if t is not None and (t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1):
                 raise _lib.GGNNError(f"ggnn_rowgemm: {name} must be a float32 [batch, rows, cols] view with unit column stride")
         M = a.size(1)
-        if a.size(0) != batch or out.size(0) != batch or w.size(0) != batch or out.size(1) != M or a.size(2) < K \
+        if a.size(0) != batch or out.size(0) != batch or out.size(1) != M or a.size(2) < K \
                 or out.size(2) < n_out or (c_in is not None and (c_in.shape != out.shape or c_in.stride() != out.stride())):
             raise _lib.GGNNError("ggnn_rowgemm: operand shapes do not match (batch, M, K, n_out)")
-        if (transposed and (w.size(1) < K or w.size(2) < n_out)) or (not transposed and (w.size(1) < n_out or w.size(2) < K)):
-            raise _lib.GGNNError("ggnn_rowgemm: w does not hold [n_out, K] (or its transpose)")
-        nbytes = self.lib.ggnn_rowgemm_workspace_bytes(K, n_out, batch)
-        ws = self._rowgemm_ws.get((a.device, nbytes))
-        if ws is None:   # one plane buffer per (device, size): the calls of a step are stream-ordered
-            ws = self._rowgemm_ws[(a.device, nbytes)] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
         g = _lib.RowGemmArgs()
-        g.a, g.w, g.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
+        self._rowgemm_weight(g, w, K, n_out, batch, transposed, bf16)
+        nbytes = self.lib.ggnn_rowgemm_workspace_bytes(K, n_out, batch)
+        if planes is not None:
+            if planes.dtype != torch.uint8 or planes.numel() < nbytes or planes.device != a.device:
+                raise _lib.GGNNError("ggnn_rowgemm: `planes` is not the rowgemm_pack output of this product")
+            ws, g.prepacked = planes, 1
+        else:
+            # one plane buffer per (device, stream, size): the calls on a stream are ordered
+            key = (a.device, torch.cuda.current_stream(a.device).cuda_stream, nbytes)
+            ws = self._rowgemm_ws.get(key)
+            if ws is None:
+                ws = self._rowgemm_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
+        g.a, g.c = a.data_ptr(), out.data_ptr()
         g.c_in = None if c_in is None else c_in.data_ptr()
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
         g.M, g.lda, g.ldc = M, a.stride(1), out.stride(1)
-        g.a_bstride, g.c_bstride, g.w_bstride = a.stride(0) if batch > 1 else 0, out.stride(0) if batch > 1 else 0, \
-            w.stride(0) if batch > 1 else 0
-        g.w_nstride, g.w_kstride = (1, w.stride(1)) if transposed else (w.stride(1), 1)
-        g.K, g.n_out, g.batch, g.precision = K, n_out, batch, _lib.GGNN_PRECISION_BF16 if bf16 else 0
+        g.a_bstride, g.c_bstride = a.stride(0) if batch > 1 else 0, out.stride(0) if batch > 1 else 0
         self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
+        return out
+
+    def sum_rows(self, t):
+        """ggnn_sum_rows: [batch, rows, cols] contiguous float32 -> [batch, cols], the sum over the rows in a fixed order."""
+        _require_cuda(t)
+        if t.dtype != torch.float32 or t.dim() != 3 or not t.is_contiguous() or t.size(2) % 4:
+            raise _lib.GGNNError("ggnn_sum_rows: a contiguous float32 [batch, rows, cols] tensor with cols % 4 == 0")
+        out = torch.empty(t.size(0), t.size(2), dtype=torch.float32, device=t.device)
+        self._launch(self.lib.ggnn_sum_rows, "ggnn_sum_rows", t.data_ptr(), out.data_ptr(), t.size(1), t.size(2), t.size(0),
+                     _lib.current_stream())
         return out
 
     def adam_step(self, args):

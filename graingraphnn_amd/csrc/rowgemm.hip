@@ -23,11 +23,15 @@ constexpr int RG_WAVES = 8;
 constexpr int RG_MAX_CT = 14;                 // n_out <= 224
 
 // lane l = 16 kq + m of piece (b, ks, ct, plane): W[b][16 ct + m][32 ks + 8 kq .. +7]
-template <bool BF16>
-__global__ __launch_bounds__(256) void rowgemm_pack_kernel(const ggnn_rowgemm_args A, u32x4* __restrict__ out, int nks,
-                                                           int nct) {
-  constexpr int P = BF16 ? 1 : 2;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b, ks, ct, lane)
+// ... for several products in one launch (ggnn_rowgemm_pack): workgroup -> product through the offsets
+struct RowGemmPackBatch {
+  ggnn_rowgemm_args a[GGNN_ROWGEMM_MAX_PACK];
+  int blk_off[GGNN_ROWGEMM_MAX_PACK + 1];
+  int nks[GGNN_ROWGEMM_MAX_PACK], nct[GGNN_ROWGEMM_MAX_PACK];
+  int n;
+};
+__device__ __forceinline__ void rowgemm_pack_item(const ggnn_rowgemm_args& A, u32x4* __restrict__ out, int nks, int nct,
+                                                  int64_t i, bool bf16) {
   if (i >= (int64_t)A.batch * nks * nct * 64) return;
   const int lane = (int)(i & 63);
   int64_t r = i >> 6;
@@ -39,8 +43,9 @@ __global__ __launch_bounds__(256) void rowgemm_pack_kernel(const ggnn_rowgemm_ar
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (n < A.n_out && k0 + j < A.K) ? w[(int64_t)(k0 + j) * A.w_kstride] : 0.f;
+  const int P = bf16 ? 1 : 2;
   u32x4* dst = out + ((((int64_t)b * nks + ks) * nct + ct) * P) * 64 + lane;
-  if constexpr (BF16) {
+  if (bf16) {
     u32x4 q;
 #pragma unroll
     for (int e = 0; e < 4; ++e) q[e] = pack_bf16(v[2 * e], v[2 * e + 1]);
@@ -57,6 +62,13 @@ __global__ __launch_bounds__(256) void rowgemm_pack_kernel(const ggnn_rowgemm_ar
     dst[0] = hi;
     dst[64] = lo;
   }
+}
+__global__ __launch_bounds__(256) void rowgemm_pack_batch_kernel(const RowGemmPackBatch B) {
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.blk_off[k + 1]) ++k;
+  const ggnn_rowgemm_args& A = B.a[k];
+  rowgemm_pack_item(A, reinterpret_cast<u32x4*>(A.workspace), B.nks[k], B.nct[k],
+                    (int64_t)(blockIdx.x - B.blk_off[k]) * 256 + threadIdx.x, A.precision == GGNN_PRECISION_BF16);
 }
 
 // Weight slices (one k-step each) travel in GROUPS of GS: one barrier and one counted wait per group, and the rows of
@@ -301,20 +313,53 @@ extern "C" size_t ggnn_rowgemm_workspace_bytes(int32_t K, int32_t n_out, int32_t
   return (size_t)batch * ((size_t)(K + 31) / 32) * rowgemm_tiles(n_out) * 2 * 1024;
 }
 
+static int rowgemm_check_weights(const ggnn_rowgemm_args& A) {
+  using namespace ggnn;
+  if (!A.workspace || A.batch < 1 || !aligned16(A.workspace)) return GGNN_EINVAL;
+  if (A.K <= 0 || (A.K & 31) || A.n_out <= 0 || (A.n_out & 15) || A.n_out > 16 * RG_MAX_CT) return GGNN_EINVAL;
+  if (A.precision != 0 && A.precision != GGNN_PRECISION_BF16) return GGNN_EINVAL;
+  if (A.workspace_bytes < ggnn_rowgemm_workspace_bytes(A.K, A.n_out, A.batch)) return GGNN_EINVAL;
+  return GGNN_OK;
+}
+
+extern "C" int ggnn_rowgemm_pack(const ggnn_rowgemm_args* args, int n_products, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args || n_products < 1 || n_products > GGNN_ROWGEMM_MAX_PACK) return GGNN_EINVAL;
+  RowGemmPackBatch B;
+  B.n = n_products;
+  B.blk_off[0] = 0;
+  for (int k = 0; k < GGNN_ROWGEMM_MAX_PACK; ++k) {
+    B.a[k] = args[k < n_products ? k : 0];
+    B.nks[k] = B.nct[k] = 0;
+    if (k >= n_products) {
+      B.blk_off[k + 1] = B.blk_off[k];
+      continue;
+    }
+    const ggnn_rowgemm_args& A = B.a[k];
+    if (!A.w || rowgemm_check_weights(A) != GGNN_OK) return GGNN_EINVAL;
+    B.nks[k] = A.K / 32;
+    B.nct[k] = rowgemm_tiles(A.n_out);
+    const int64_t nb = ((int64_t)A.batch * B.nks[k] * B.nct[k] * 64 + 255) / 256;
+    if (B.blk_off[k] + nb >= INT32_MAX) return GGNN_EINVAL;
+    B.blk_off[k + 1] = B.blk_off[k] + (int)nb;
+  }
+  hipLaunchKernelGGL(rowgemm_pack_batch_kernel, dim3((unsigned)B.blk_off[GGNN_ROWGEMM_MAX_PACK]), dim3(256), 0,
+                     (hipStream_t)stream, B);
+  return launch_status();
+}
+
 extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!args) return GGNN_EINVAL;
   const ggnn_rowgemm_args& A = *args;
-  if (!A.a || !A.w || !A.c || !A.workspace || A.M <= 0 || A.batch < 1) return GGNN_EINVAL;
-  if (A.K <= 0 || (A.K & 31) || A.n_out <= 0 || (A.n_out & 15) || A.n_out > 16 * RG_MAX_CT) return GGNN_EINVAL;
+  if (!A.a || (!A.w && !A.prepacked) || !A.c || A.M <= 0 || rowgemm_check_weights(A) != GGNN_OK) return GGNN_EINVAL;
   if (A.lda < A.K || A.ldc < A.n_out || (A.lda & 3) || (A.ldc & 3) || (A.a_bstride & 3) || (A.c_bstride & 3)) return GGNN_EINVAL;
-  if (!aligned16(A.a) || !aligned16(A.c) || !aligned16(A.workspace) || (A.c_in && !aligned16(A.c_in))) return GGNN_EINVAL;
-  if (A.precision != 0 && A.precision != GGNN_PRECISION_BF16) return GGNN_EINVAL;
-  if (A.workspace_bytes < ggnn_rowgemm_workspace_bytes(A.K, A.n_out, A.batch)) return GGNN_EINVAL;
+  if (!aligned16(A.a) || !aligned16(A.c) || (A.c_in && !aligned16(A.c_in))) return GGNN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // W[b]'s planes fit the LDS (and n_out is one of the instantiated widths)
   const bool resident = A.n_out == 16 * rowgemm_tiles(A.n_out) && A.K / 32 <= (A.n_out == 96 ? 8 : 4);
   if (A.precision == 0 && A.n_out > 128 && !resident) {
+    if (A.prepacked) return GGNN_EINVAL;   // (the halves have plane images of their own)
     // fp32 mode wider than 8 column tiles: 14 x (main + cross) accumulators leave no registers for rows in flight
     // (82 spilled, slower than the library) -- two passes over column halves instead (A is read twice: the wide shape
     // is the gate GEMM's input gradient, whose reduction is 96 long)
@@ -331,12 +376,10 @@ extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream)
   }
   const int nks = A.K / 32, nct = rowgemm_tiles(A.n_out);
   u32x4* planes = reinterpret_cast<u32x4*>(A.workspace);
-  const int64_t n_pack = ((int64_t)A.batch * nks * nct * 64 + 255) / 256;
-  if (A.precision == GGNN_PRECISION_BF16)
-    hipLaunchKernelGGL((rowgemm_pack_kernel<true>), dim3((unsigned)n_pack), dim3(256), 0, st, A, planes, nks, nct);
-  else
-    hipLaunchKernelGGL((rowgemm_pack_kernel<false>), dim3((unsigned)n_pack), dim3(256), 0, st, A, planes, nks, nct);
-  if (launch_status() != GGNN_OK) return GGNN_ELAUNCH;
+  if (!A.prepacked) {
+    const int rc = ggnn_rowgemm_pack(&A, 1, stream);
+    if (rc != GGNN_OK) return rc;
+  }
   if (resident) {
     switch (nct) {
       case 6: return rowgemm_resident_launch<6, 8>(A, planes, nks, st);

@@ -107,7 +107,49 @@ __global__ __launch_bounds__(MSE_THREADS) void masked_mse_kernel(const ggnn_mse_
   }
 }
 
+// out[b][j] = sum_r in[b][r][j] for a TALL stack of short rows (the sweep backward's per-workgroup partial sums of the
+// edge-parameter gradient: 768 rows of 1 152 floats per edge type).  A workgroup owns 32 columns (8 float4) of one batch
+// entry: 32 row groups x 8 column quads; a thread adds every 32nd row, eight loads in flight, and the row groups are
+// combined through LDS in index order -- a fixed summation tree.
+constexpr int SR_QUADS = 8, SR_GROUPS = 32;
+__global__ __launch_bounds__(SR_QUADS * SR_GROUPS) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                         int64_t n_rows, int64_t n_cols) {
+  __shared__ f32x4 red[SR_GROUPS][SR_QUADS];
+  const int q = threadIdx.x % SR_QUADS, rg = threadIdx.x / SR_QUADS;
+  const int64_t n4 = n_cols / 4, col = (int64_t)blockIdx.x * SR_QUADS + q;
+  const bool live = col < n4;
+  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(in) + (int64_t)blockIdx.y * n_rows * n4 + (live ? col : 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = rg;
+  for (; r + 7 * SR_GROUPS < n_rows; r += 8 * SR_GROUPS) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(r + j * SR_GROUPS) * n4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; r < n_rows; r += SR_GROUPS) acc += p[r * n4];
+  red[rg][q] = acc;
+  __syncthreads();
+  if (rg == 0 && live) {
+    f32x4 t = red[0][q];
+    for (int g = 1; g < SR_GROUPS; ++g) t += red[g][q];
+    reinterpret_cast<f32x4*>(out)[(int64_t)blockIdx.y * n4 + col] = t;
+  }
+}
+
 }  // namespace ggnn
+
+extern "C" int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!in || !out || n_rows <= 0 || n_cols <= 0 || (n_cols & 3) || batch < 1 || batch > 65535) return GGNN_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return GGNN_EINVAL;
+  const int64_t nb = (n_cols / 4 + SR_QUADS - 1) / SR_QUADS;
+  if (nb >= INT32_MAX) return GGNN_EINVAL;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(SR_QUADS * SR_GROUPS), 0, (hipStream_t)stream, in,
+                     out, n_rows, n_cols);
+  return launch_status();
+}
 
 extern "C" int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream) {
   using namespace ggnn;

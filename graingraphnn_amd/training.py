@@ -146,13 +146,21 @@ class _PackedCell(torch.autograd.Function):
                            layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et], layout[d].Kg,
                            layout[d].sc_off[et], G))
         backend.aggregate_batch(sweeps)
+        # the weight planes of the cell's row GEMMs -- the gate GEMM of both node types now, its input gradient and the
+        # hidden-state gradient in the backward pass -- packed by ONE launch (they were ten small launches per step)
+        specs = [(w2[nt], layout[nt].Kg, C, G, False, bf16) for nt in NODE_TYPES] \
+            + [(w2[nt], C, layout[nt].Kg, G, True, bf16) for nt in NODE_TYPES]
+        if sees_h:
+            specs += [(wp[nt][:, layout[nt].Fp:layout[nt].Fp + C], layout[nt].ncols, C, 1, True, bf16) for nt in NODE_TYPES]
+        planes = backend.rowgemm_pack(specs) if hasattr(backend, "rowgemm_pack") else [None] * len(specs)
         z, out = {}, []
-        for nt in NODE_TYPES:
+        for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             # the gate GEMM z_g = agg_g W2_g^T (ggnn_rowgemm: two-piece fp16 = fp32-equivalent; one bf16 product under
             # torch.autocast(bfloat16))
             z[nt] = torch.empty(G, n, C, **f32)
-            backend.rowgemm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt], z[nt], lay.Kg, C, batch=G, bf16=bf16)
+            backend.rowgemm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt], z[nt], lay.Kg, C, batch=G, bf16=bf16,
+                            planes=planes[k])
             h_new, c_new = torch.empty(n, C, **f32), torch.empty(n, C, **f32)
             backend.lstm_train_forward(z[nt], P[nt], lay.s_off, c[nt], h_new, c_new)
             out += [h_new, c_new]
@@ -160,7 +168,7 @@ class _PackedCell(torch.autograd.Function):
         for nt in NODE_TYPES:
             saved += [x[nt], h[nt], c[nt], wp[nt], w2[nt], P[nt], agg[nt], z[nt]]
         ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES])
-        ctx.misc = (backend, topo, layout, G, sees_h, bf16)
+        ctx.misc = (backend, topo, layout, G, sees_h, bf16, planes[2:])   # (the backward's planes: held until then)
         ctx.set_materialize_grads(False)
         return tuple(out)                                           # h_grain, c_grain, h_joint, c_joint
 
@@ -168,7 +176,7 @@ class _PackedCell(torch.autograd.Function):
     @once_differentiable   # (a second derivative through the hand-written backward fails loudly)
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_hg, g_cg, g_hj, g_cj):
-        backend, topo, layout, G, sees_h, bf16 = ctx.misc
+        backend, topo, layout, G, sees_h, bf16, planes = ctx.misc
         t = ctx.saved_tensors
         x, h, c, wp, w2, P, agg, z, c_new = {}, {}, {}, {}, {}, {}, {}, {}, {}
         for k, nt in enumerate(NODE_TYPES):
@@ -180,7 +188,7 @@ class _PackedCell(torch.autograd.Function):
         g_c_out = {"grain": g_cg, "joint": g_cj}
         f32 = dict(dtype=torch.float32, device=P["joint"].device)
         gP, g_agg, g_w2, g_c = {}, {}, {}, {}
-        for nt in NODE_TYPES:
+        for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             gP[nt] = torch.empty_like(P[nt])
             used = max(lay.u4_off[et] + G * 16 for et in lay.dst_ets)   # columns behind it are padding
@@ -195,7 +203,7 @@ class _PackedCell(torch.autograd.Function):
                                      b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
             backend.rowgemm(g_z, w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
-                            transposed=True, bf16=bf16)                                        # g_agg_g = g_z_g W2_g
+                            transposed=True, bf16=bf16, planes=planes[k])                      # g_agg_g = g_z_g W2_g
         gh_src = {nt: None for nt in NODE_TYPES}
         # the per-workgroup partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
         n_part = [backend.aggregate_bwd_partials(x[et[-1]].size(0)) for et in EDGE_TYPES]
@@ -208,9 +216,9 @@ class _PackedCell(torch.autograd.Function):
                 layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s], ep_partial_out=ep_part[k])
             if g_h is not None:
                 gh_src[s] = g_h if gh_src[s] is None else gh_src[s].add_(g_h)
-        g_ep = dict(zip(EDGE_TYPES, ep_part.sum(1)))
+        g_ep = dict(zip(EDGE_TYPES, backend.sum_rows(ep_part.view(len(EDGE_TYPES), max(n_part), -1)).view(-1, G, 3, C)))
         g_wp, g_bp, g_h = {}, {}, {}
-        for nt in NODE_TYPES:
+        for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             F, Fp = lay.F, lay.Fp
             Kp = Fp + (C if sees_h else 0)                              # columns of wp: [x (F) | 0 (Fp - F) | h]
@@ -221,7 +229,7 @@ class _PackedCell(torch.autograd.Function):
             g_h[nt] = None
             if sees_h:   # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]                 [N, 96]
                 g_h[nt] = backend.rowgemm(gP[nt], wp[nt][:, Fp:Fp + C], torch.empty(n, C, **f32), lay.ncols, C,
-                                          c_in=gh_src[nt], transposed=True, bf16=bf16)
+                                          c_in=gh_src[nt], transposed=True, bf16=bf16, planes=planes[2 + k])
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
                 g_w2["grain"], g_w2["joint"], None, None, None, None, None, None)

@@ -432,9 +432,13 @@ int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn
  *   precision: 0 = fp32-equivalent (two fp16 pieces per operand, three MFMA products; |a|, |w| < 65504);
  *              GGNN_PRECISION_BF16 = one bf16 product, fp32 accumulation (what torch.autocast(bfloat16) defines)
  *   workspace: ggnn_rowgemm_workspace_bytes(K, n_out, batch) bytes, 16-byte aligned: the weights as MFMA operand
- *              planes (re-packed by every call: they change with every optimizer step)
- * a, c, c_in 16-byte aligned.  Two launches (pack, product); the product keeps a wave's 16 x n_out output tile in
- * registers and streams the weight planes through LDS. */
+ *              planes (they change with every optimizer step).  prepacked == 0: the call packs them itself (two launches:
+ *              pack, product); prepacked != 0: `workspace` already holds the planes of exactly this (w, K, n_out, batch,
+ *              precision) from ggnn_rowgemm_pack -- one launch packs the weights of up to GGNN_ROWGEMM_MAX_PACK products
+ *              (a training step packs the five products of a cell at once), `w` is not read.  (Not for fp32 products
+ *              with n_out > 128 and K > 128, which run as two passes over column halves.)
+ * a, c, c_in 16-byte aligned.  The product keeps a wave's 16 x n_out output tile in registers; the weight planes stay in
+ * LDS for the whole launch (K <= 128, or <= 256 with n_out = 96) or stream through it. */
 typedef struct ggnn_rowgemm_args {
   const float* a;
   const float* w;
@@ -444,8 +448,11 @@ typedef struct ggnn_rowgemm_args {
   size_t workspace_bytes;
   int64_t M, lda, ldc, a_bstride, c_bstride, w_bstride, w_nstride, w_kstride;
   int32_t K, n_out, batch, precision;
+  int32_t prepacked, reserved;
 } ggnn_rowgemm_args;
+#define GGNN_ROWGEMM_MAX_PACK 8
 size_t ggnn_rowgemm_workspace_bytes(int32_t K, int32_t n_out, int32_t batch);
+int ggnn_rowgemm_pack(const ggnn_rowgemm_args* args, int n_products, ggnn_stream_t stream); /* reads w, K, n_out, batch, precision, workspace */
 int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -574,6 +581,11 @@ typedef struct ggnn_wgrad_args {
 } ggnn_wgrad_args;
 int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch);
 int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
+
+/* Training path: out[b][j] = sum_r in[b][r][j], b < batch -- the caller's reduction over the partial sums of
+ * ggnn_period_gat_aggregate_backward (ep_partial: n_rows = ggnn_aggregate_bwd_partials rows of n_cols = n_gates * 288 floats
+ * per edge type), in a fixed order.  in: [batch, n_rows, n_cols] contiguous, n_cols % 4 == 0, 16-byte aligned. */
+int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream);
 
 /* Training path: torch.optim.Adam's update (train.py:82-91; amsgrad / maximize off) for up to GGNN_ADAM_MAX_TENSORS parameter
  * tensors in one launch.  `table` (DEVICE memory, n_tensors entries, built once) holds what is fixed: the addresses of a

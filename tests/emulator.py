@@ -332,7 +332,11 @@ class TorchEmulatorBackend:
         return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), oa + k * a_bstride).t()
                             @ torch.as_strided(fb, (K, Nc), (ldb, 1), ob + k * b_bstride) for k in range(batch)])
 
-    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False):
+    @staticmethod
+    def sum_rows(t):
+        return t.sum(1)
+
+    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False, planes=None):
         """ggnn_rowgemm: out[b][:, :n_out] = a[b][:, :K] W[b]^T (+ c_in[b]); W[b] = w[b][:n_out, :K] or, transposed,
         w[b][:K, :n_out]^T.  (bf16: the product of bf16-rounded operands, fp32 accumulation.)"""
         a3 = a if a.dim() == 3 else a.unsqueeze(0)

@@ -196,6 +196,18 @@ def test_rowgemm_against_float64(M, K, n_out, batch, transposed, with_cin):
     assert errb < 2e-6, f"rowgemm bf16 mode: {errb:.2e} of sum |a||w| against the product of bf16-rounded operands"
     with pytest.raises(_lib.GGNNError):
         be.rowgemm(a, w, out, K, n_out + 1, batch=batch, transposed=transposed)    # n_out must be a multiple of 16
+    # weight planes packed ahead (ggnn_rowgemm_pack: both precisions of this product in one launch): the same bits
+    pf, pb = be.rowgemm_pack([(w, K, n_out, batch, transposed, False), (w, K, n_out, batch, transposed, True)])
+    two_pass = n_out > 128 and K > 128          # fp32 products that run as two column halves pack per half
+    o2 = torch.full((batch, M, ldc), float("nan"), device=DEV)
+    if two_pass:
+        with pytest.raises(_lib.GGNNError):
+            be.rowgemm(a, w, o2, K, n_out, batch=batch, c_in=cin, transposed=transposed, planes=pf)
+    else:
+        be.rowgemm(a, w, o2, K, n_out, batch=batch, c_in=cin, transposed=transposed, planes=pf)
+        assert torch.equal(o2[:, :, :n_out], out[:, :, :n_out])
+    be.rowgemm(a, w, o2, K, n_out, batch=batch, c_in=cin, transposed=transposed, bf16=True, planes=pb)
+    assert torch.equal(o2[:, :, :n_out], ob[:, :, :n_out])
 
 
 def _gate_problem(N, Ka, mode, seed):

@@ -603,6 +603,21 @@ def test_fused_adam_follows_torch_adam():
     assert float(oc.state[pa[0]]["step"]) == 8.0 and float(oc.state[pa[4]]["step"]) == 5.0
     with pytest.raises(Exception, match="MI355X|CPU"):
         training.FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3).step()
+    # more tensors than one call carries (GGNN_ADAM_MAX_TENSORS = 384): two calls per update, each advancing its own counts
+    rs = np.random.RandomState(8)
+    many_a = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(1 + k % 37).astype(np.float32)).to(dev)) for k in range(500)]
+    many_b = [torch.nn.Parameter(p.detach().clone()) for p in many_a]
+    oa, ob = training.FusedAdam(many_a, lr=3e-3), torch.optim.Adam(many_b, lr=3e-3)
+    for k in range(3):
+        for a, b in zip(many_a, many_b):
+            g = torch.from_numpy(rs.standard_normal(a.shape).astype(np.float32)).to(dev)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    assert len(oa._built["launches"]) == 2
+    for i, (a, b) in enumerate(zip(many_a, many_b)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), i
+    assert float(oa.state[many_a[499]]["step"]) == 3.0
 
 
 @pytest.mark.gpu
