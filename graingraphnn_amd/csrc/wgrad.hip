@@ -159,6 +159,174 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const ggnn_wgrad_args W, 
   }
 }
 
+// ---- the same product on the bf16 matrix cores (round 4; the default: GGNN_GEMM=fp32 keeps the kernel above) ----
+// v_mfma_f32_16x16x4_f32 made every large weight gradient matrix-pipe bound (101 TFLOP/s of the 157 the fp32 pipe has: 90 us
+// for the joints' [2112 x 108] over 20 000 rows, whose operands are 169 MB).  Here both operands are split in registers into
+// three bf16 pieces and multiplied with six 16x16x32 products per tile pair (common.h: fp32-equivalent, 2e-8 of sum |a||b|,
+// fp32's range -- gradients of 1e-8 keep their 24 bits, which the two-piece fp16 split of the cells would not give them):
+// 6 x 16 cycles per 32 rows where the fp32 MFMA needs 8 x 32.  Same decomposition, loads and output layout as above; what
+// differs is the row -> lane map (a lane holds rows k0 + 8 (lane / 16) .. +7 of its columns: the 8 k-values of a 32-deep MFMA
+// operand) and the pipeline: a wave owns a 32 x 112 block (TA = 2: 56 accumulator registers), the raw rows of a 32-row group
+// live in 72 registers and every piece of them is re-requested for the NEXT group as soon as its last reader has issued --
+// A behind the A split, B's dwordx4 part behind column tile 3, the dwordx2 part behind tile 5, the dword part behind tile 6 --
+// so each wait leaves the 24 younger loads in flight (s_waitcnt vmcnt(24) at all four places).
+constexpr int WX_TA = 2;
+#ifndef WX_CFG_WAVES
+#define WX_CFG_WAVES 2048
+#endif
+constexpr int WX_WAVES = WX_CFG_WAVES;
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const ggnn_wgrad_args W, int n_mt, int n_nb, int64_t chunk) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  int64_t w = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t total = (int64_t)W.batch * n_nb * W.n_split * n_mt;
+  if (w >= total) return;
+  const int mt = (int)(w % n_mt);
+  w /= n_mt;
+  const int nb = (int)(w % n_nb);
+  w /= n_nb;
+  const int b = (int)(w % W.batch), s = (int)(w / W.batch);
+  const int m0 = mt * 16 * WX_TA, n0 = nb * WG_NB;
+  const int64_t k_begin = s * chunk, k_end = min(W.K, k_begin + chunk);
+
+  const int ca = min(m0 + WX_TA * li, W.M - WX_TA);
+  const int cb4 = min(n0 + 4 * li, W.Nc - 4), cb2 = min(n0 + 64 + 2 * li, W.Nc - 2), cb1 = min(n0 + 96 + li, W.Nc - 1);
+  const float* A = W.a + (int64_t)b * W.a_bstride + (int64_t)(8 * lq) * W.lda + ca;
+  const float* B = W.b + (int64_t)b * W.b_bstride + (int64_t)(8 * lq) * W.ldb;
+
+  f32x4 acc[WX_TA][WG_TB];
+#pragma unroll
+  for (int t = 0; t < WX_TA; ++t)
+#pragma unroll
+    for (int u = 0; u < WG_TB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x2 ra[8];
+  f32x4 rb4[8];
+  f32x2 rb2[8];
+  float rb1[8];
+  // rows k + 8 lq + j, j < 8 (clamped below k_end: a ragged last group zeroes what it clamped)
+  auto row_of = [&](int64_t k, int j) { return min(k + j, k_end - 1 - 8 * lq); };
+  auto load_a = [&](int64_t k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ra[j]) : "v"(A + row_of(k, j) * W.lda));
+  };
+  auto load_b4 = [&](int64_t k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4[j]) : "v"(B + row_of(k, j) * W.ldb + cb4));
+  };
+  auto load_b2 = [&](int64_t k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rb2[j]) : "v"(B + row_of(k, j) * W.ldb + cb2));
+  };
+  auto load_b1 = [&](int64_t k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(rb1[j]) : "v"(B + row_of(k, j) * W.ldb + cb1));
+  };
+  // eight k-values of one column -> the three bf16 planes of an MFMA operand
+  auto split8 = [&](const float (&v)[8], u32x4 (&f)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h, m, l;
+      split_bf16x3(v[2 * e], v[2 * e + 1], h, m, l);
+      f[0][e] = h, f[1][e] = m, f[2][e] = l;
+    }
+  };
+#define WX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WX_WAIT24()                                      \
+  do {                                                   \
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");    \
+    WX_FENCE();                                          \
+  } while (0)
+  // one 32-row group at k; `next`: the group whose rows are requested as the registers come free (k_end: none left --
+  // the requests then repeat the last rows, harmlessly, so that the waits keep their count)
+  auto group = [&](int64_t k, int64_t next, bool ragged) __attribute__((always_inline)) {
+    u32x4 fa[WX_TA][3];
+    WX_WAIT24();   // A of this group (B4, B2, B1 may still be in flight)
+#pragma unroll
+    for (int t = 0; t < WX_TA; ++t) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (!ragged || k + 8 * lq + j < k_end) ? ra[j][t] : 0.f;
+      split8(v, fa[t]);
+    }
+    WX_FENCE();
+    load_a(next);
+    WX_FENCE();
+    auto tile = [&](int u, const float (&v)[8]) __attribute__((always_inline)) {
+      u32x4 fb[3];
+      split8(v, fb);
+#pragma unroll
+      for (int t = 0; t < WX_TA; ++t) acc[t][u] = mfma_x6(fa[t], fb, acc[t][u]);
+    };
+    WX_WAIT24();   // B4
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rb4[j][u];
+      tile(u, v);
+    }
+    WX_FENCE();
+    load_b4(next);
+    WX_FENCE();
+    WX_WAIT24();   // B2
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rb2[j][u];
+      tile(4 + u, v);
+    }
+    WX_FENCE();
+    load_b2(next);
+    WX_FENCE();
+    WX_WAIT24();   // B1
+    {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rb1[j];
+      tile(6, v);
+    }
+    WX_FENCE();
+    load_b1(next);
+    WX_FENCE();
+  };
+  // (rows a ragged group clamped carry garbage in B too: their A values are zero, and 0 x finite = 0 -- operands are
+  // finite by contract, as everywhere on this path)
+  int64_t k = k_begin;
+  load_a(k);
+  load_b4(k);
+  load_b2(k);
+  load_b1(k);
+  WX_FENCE();
+  for (; k + 32 <= k_end; k += 32) group(k, min(k + 32, k_end - 1), false);
+  if (k < k_end) group(k, k, true);
+  // The last group's re-requests: nothing reads them, but their destination registers must stay reserved until they have
+  // landed -- the compiler only sees `asm` statements that define values; values nobody uses would hand their registers to
+  // the address arithmetic of the very next loads while the memory system still owes them data.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ra[j]), "v"(rb4[j]), "v"(rb2[j]), "v"(rb1[j]));
+#undef WX_WAIT24
+#undef WX_FENCE
+
+  float* out = W.partial + ((int64_t)s * W.batch + b) * W.M * W.Nc;
+#pragma unroll
+  for (int u = 0; u < WG_TB; ++u) {
+    const int n = u < 4 ? n0 + 4 * li + u : u < 6 ? n0 + 64 + 2 * li + (u - 4) : n0 + 96 + li;
+    if (n >= W.Nc) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mrow = m0 + WX_TA * (4 * lq + r);
+      if (mrow >= W.M) continue;
+#pragma unroll
+      for (int t = 0; t < WX_TA; ++t) out[(int64_t)(mrow + t) * W.Nc + n] = acc[t][u][r];
+    }
+  }
+}
+
+static bool wgrad_uses_x6(int M) { return ggnn::gemm_mode() == 1 && M >= 512; }
+
 struct WgradPlan {
   int ta, n_mt, n_nb, n_split;
   int64_t chunk;
@@ -166,17 +334,23 @@ struct WgradPlan {
 
 static WgradPlan wgrad_plan(int64_t K, int M, int Nc, int batch) {
   WgradPlan p;
-  p.ta = M % 64 == 0 || M >= 512 ? 4 : 2;
+  // bf16 x 3 pieces on the matrix cores for the TALL results (the packed projection's gradient: M = 672 .. 2112 rows --
+  // matrix-pipe bound on the fp32 MFMA: 107 -> 92 us for [2112 x 108] over 20 000 rows, 46 -> 41 for [1248 x 112] over 10 000);
+  // the 96-row results (gate weights) are not bound by the pipe and stay on the exact fp32 MFMA, as everything does under
+  // GGNN_GEMM=fp32
+  const bool x6 = wgrad_uses_x6(M);
+  p.ta = x6 ? WX_TA : (M % 64 == 0 || M >= 512 ? 4 : 2);
   p.n_mt = (M + 16 * p.ta - 1) / (16 * p.ta);
   p.n_nb = (Nc + WG_NB - 1) / WG_NB;
   const int64_t tiles = (int64_t)batch * p.n_mt * p.n_nb;
   // one wave per SIMD of a 256-CU part (the kernel is bound by the matrix pipe: a second wave per SIMD only
   // shares it), the K ranges at least 64 rows long
-  int64_t want = WG_WAVES / tiles;
+  int64_t want = (x6 ? WX_WAVES : WG_WAVES) / tiles;
   const int64_t most = (K + 63) / 64;
   if (want > most) want = most;
   if (want < 1) want = 1;
-  p.chunk = ((K + want - 1) / want + 3) / 4 * 4;
+  const int64_t q = x6 ? 32 : 4;   // whole row groups per K range (the last range takes the ragged end)
+  p.chunk = ((K + want - 1) / want + q - 1) / q * q;
   p.n_split = (int)((K + p.chunk - 1) / p.chunk);
   if (p.n_split < 1) p.n_split = 1;
   return p;
@@ -224,7 +398,9 @@ extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
   if (blocks > 0x7fffffff) return GGNN_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (W.out && !aligned16(W.out)) return GGNN_EINVAL;
-  if (p.ta == 4)
+  if (wgrad_uses_x6(W.M))
+    hipLaunchKernelGGL(wgrad_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
+  else if (p.ta == 4)
     hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
   else
     hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);

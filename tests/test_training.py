@@ -725,6 +725,14 @@ def test_wgrad_is_the_transposed_product(K, M, Nc, batch):
         ref, mag = a64.t() @ b64, a64.abs().t() @ b64.abs()
         assert bool(((c[k].double() - ref).abs() <= 3e-6 * mag + 1e-30).all()), (k, float((c[k] - ref).abs().max()))
     assert torch.equal(c, be.wgrad(a, b, K, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc))
+    # gradients are small numbers: rows scaled down to 1e-12 .. 1e-6 keep the bound (the kernel splits its operands into
+    # three bf16 pieces -- fp32's range; the cells' two-piece fp16 split would lose them)
+    tiny = a * (10.0 ** torch.empty(batch, K, 1).uniform_(-12, -6, generator=g)).cuda()
+    ct = be.wgrad(tiny, b, K, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)
+    for k in range(batch):
+        a64, b64 = tiny[k, :, :M].double(), b[:, k * Nc:(k + 1) * Nc].double()
+        ref, mag = a64.t() @ b64, a64.abs().t() @ b64.abs()
+        assert bool(((ct[k].double() - ref).abs() <= 3e-6 * mag + 1e-38).all()), (k, float((ct[k] - ref).abs().max()))
     with pytest.raises(Exception):
         be.wgrad(a, b, K + 1, M, Nc, lda, ldb, batch=batch, a_bstride=K * lda, b_bstride=Nc)   # rows beyond the tensor
     with pytest.raises(Exception):

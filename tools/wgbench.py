@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from graingraphnn_amd.backend import default_backend  # noqa: E402
 
 be = default_backend()
-shapes = [(20000, 1984, 108, 1), (10000, 1248, 108, 1), (20000, 96, 224, 4), (10000, 96, 128, 4),
+shapes = [(20000, 2112, 108, 1), (10000, 1248, 112, 1), (20000, 96, 224, 4), (10000, 96, 128, 4),
           (20000, 480, 12, 1), (20000, 96, 224, 3), (20000, 4, 100, 1)]
 for K, M, Nc, batch in shapes:
     a = torch.randn(batch, K, M, device="cuda")
