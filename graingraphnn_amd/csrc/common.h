@@ -20,6 +20,10 @@ int gemm_mode();
 // persistent / one-round grids.  Affects speed only.
 int num_cu();
 
+// out[b][j] = sum_r in[b][r][j] in a fixed order, many short rows (train_misc.hip: ggnn_sum_rows; also the reduction of
+// ggnn_wgrad's partial results when there are many of them).  n_cols % 4 == 0, 16-byte aligned operands.
+int launch_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int batch, hipStream_t stream);
+
 static inline int launch_status() {
   return hipGetLastError() == hipSuccess ? GGNN_OK : GGNN_ELAUNCH;
 }

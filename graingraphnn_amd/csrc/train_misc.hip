@@ -138,17 +138,20 @@ __global__ __launch_bounds__(SR_QUADS * SR_GROUPS) void sum_rows_kernel(const fl
   }
 }
 
-}  // namespace ggnn
-
-extern "C" int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream) {
-  using namespace ggnn;
+int launch_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int batch, hipStream_t stream) {
   if (!in || !out || n_rows <= 0 || n_cols <= 0 || (n_cols & 3) || batch < 1 || batch > 65535) return GGNN_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return GGNN_EINVAL;
   const int64_t nb = (n_cols / 4 + SR_QUADS - 1) / SR_QUADS;
   if (nb >= INT32_MAX) return GGNN_EINVAL;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(SR_QUADS * SR_GROUPS), 0, (hipStream_t)stream, in,
-                     out, n_rows, n_cols);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)nb, (unsigned)batch), dim3(SR_QUADS * SR_GROUPS), 0, stream, in, out, n_rows,
+                     n_cols);
   return launch_status();
+}
+
+}  // namespace ggnn
+
+extern "C" int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream) {
+  return ggnn::launch_sum_rows(in, out, n_rows, n_cols, batch, (hipStream_t)stream);
 }
 
 extern "C" int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream) {

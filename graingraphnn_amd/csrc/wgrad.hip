@@ -159,40 +159,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const ggnn_wgrad_args W, 
   }
 }
 
-// ---- the same product on the bf16 matrix cores (round 4; the default: GGNN_GEMM=fp32 keeps the kernel above) ----
-// v_mfma_f32_16x16x4_f32 made every large weight gradient matrix-pipe bound (101 TFLOP/s of the 157 the fp32 pipe has: 90 us
-// for the joints' [2112 x 108] over 20 000 rows, whose operands are 169 MB).  Here both operands are split in registers into
-// three bf16 pieces and multiplied with six 16x16x32 products per tile pair (common.h: fp32-equivalent, 2e-8 of sum |a||b|,
-// fp32's range -- gradients of 1e-8 keep their 24 bits, which the two-piece fp16 split of the cells would not give them):
-// 6 x 16 cycles per 32 rows where the fp32 MFMA needs 8 x 32.  Same decomposition, loads and output layout as above; what
+// ---- the TALL results on the bf16 matrix cores (round 4; GGNN_GEMM=fp32 keeps the kernel above for everything) ----
+// v_mfma_f32_16x16x4_f32 made the large weight gradients matrix-pipe bound (101 TFLOP/s of the 157 the fp32 pipe has: 107 us
+// with its reduction for the joints' [2112 x 108] over 20 000 rows, whose operands are 169 MB).  Here both operands are split
+// in registers into three bf16 pieces and multiplied with six 16x16x32 products per tile pair (common.h: fp32-equivalent, 2e-8
+// of sum |a||b|, fp32's RANGE -- gradients of 1e-10 keep their 24 bits, which the two-piece fp16 split of the cells would not
+// give them): 6 x 16 cycles per 32 rows where the fp32 MFMA needs 8 x 32.  Same decomposition and output as above; what
 // differs is the row -> lane map (a lane holds rows k0 + 8 (lane / 16) .. +7 of its columns: the 8 k-values of a 32-deep MFMA
-// operand) and the pipeline: a wave owns a 32 x 112 block (TA = 2: 56 accumulator registers), the raw rows of a 32-row group
-// live in 72 registers and every piece of them is re-requested for the NEXT group as soon as its last reader has issued --
-// A behind the A split, B's dwordx4 part behind column tile 3, the dwordx2 part behind tile 5, the dword part behind tile 6 --
-// so each wait leaves the 24 younger loads in flight (s_waitcnt vmcnt(24) at all four places).
+// operand), the block (32 x 112 per wave: 56 accumulator registers) and where B comes from.
+// A first version kept B private to a wave (a register ring like the kernel above): it re-read and re-split the 32 x 112 block
+// of B once per 32-row tile of the result, 66 times for the joints' projection gradient -- 590 MB through the compute units'
+// vector-memory path for an 8.6 MB operand: 92 us.  Now a workgroup's four waves take four NEIGHBOURING 32-row tiles of the
+// result over the same K range: each wave fetches and splits a quarter of the B block (rows 8 w .. 8 w + 7 of the 32-row
+// group, two columns per lane: exactly k-group `w` of every MFMA operand fragment), parks the bf16 pieces in LDS as operand
+// fragments ([column tile][piece][64 lanes][8 values], double-buffered: one barrier per 32 rows), and all four read them
+// back with 21 ds_read_b128.  A quarter of the B traffic and of the B splitting per wave; no register ring (the next group's
+// rows are requested before this group's MFMAs and used behind them: plain loads, the compiler counts the waits); 145
+// registers: three workgroups per compute unit.  [2112 x 108] over 20 000 rows: 72-77 us with its reduction; [1248 x 112]
+// over 10 000: 36 (fp32 MFMA: 46).  The 96-row results (gate weights) gain nothing from it (41 against 43 us) and stay above.
 constexpr int WX_TA = 2;
 #ifndef WX_CFG_WAVES
-#define WX_CFG_WAVES 2048
+#define WX_CFG_WAVES 3072
 #endif
 constexpr int WX_WAVES = WX_CFG_WAVES;
-__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const ggnn_wgrad_args W, int n_mt, int n_nb, int64_t chunk) {
+constexpr int WS_LDS = WG_TB * 3 * 1024;   // one group's B fragments: 21 KB
+__global__ __launch_bounds__(256, 3) void wgrad_x6s_kernel(const ggnn_wgrad_args W, int n_mt, int n_nb, int64_t chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WS_LDS];
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  int64_t w = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t total = (int64_t)W.batch * n_nb * W.n_split * n_mt;
-  if (w >= total) return;
-  const int mt = (int)(w % n_mt);
-  w /= n_mt;
-  const int nb = (int)(w % n_nb);
-  w /= n_nb;
-  const int b = (int)(w % W.batch), s = (int)(w / W.batch);
+  const int n_mtg = (n_mt + 3) / 4;
+  int64_t g = xcd_remap(blockIdx.x, gridDim.x);          // workgroup -> (tile quad, column block, batch entry, K range)
+  const int mtg = (int)(g % n_mtg);
+  g /= n_mtg;
+  const int nb = (int)(g % n_nb);
+  g /= n_nb;
+  const int b = (int)(g % W.batch), s = (int)(g / W.batch);
+  const int mt = 4 * mtg + wave;
+  const bool active = mt < n_mt;                          // (a surplus wave still does its share of B and meets the barriers)
   const int m0 = mt * 16 * WX_TA, n0 = nb * WG_NB;
   const int64_t k_begin = s * chunk, k_end = min(W.K, k_begin + chunk);
 
   const int ca = min(m0 + WX_TA * li, W.M - WX_TA);
-  const int cb4 = min(n0 + 4 * li, W.Nc - 4), cb2 = min(n0 + 64 + 2 * li, W.Nc - 2), cb1 = min(n0 + 96 + li, W.Nc - 1);
-  const float* A = W.a + (int64_t)b * W.a_bstride + (int64_t)(8 * lq) * W.lda + ca;
-  const float* B = W.b + (int64_t)b * W.b_bstride + (int64_t)(8 * lq) * W.ldb;
+  const float* A = W.a + (int64_t)b * W.a_bstride + ca;
+  // B duty: rows 8 wave + j of a group, columns n0 + lane and n0 + 64 + lane (clamped: columns beyond Nc feed result
+  // columns that are never stored)
+  const float* Bq = W.b + (int64_t)b * W.b_bstride;
+  const int c0 = min(n0 + lane, W.Nc - 1), c1 = min(n0 + 64 + lane, W.Nc - 1);
+  // where this lane's two columns go: tile = column / 16, fragment lane = 16 wave + column % 16
+  const int frag0 = ((lane >> 4) * 3 * 64 + 16 * wave + li) * 16, frag1 = frag0 + 4 * 3 * 64 * 16;
+  const bool has_c1 = lane < WG_NB - 64;
 
   f32x4 acc[WX_TA][WG_TB];
 #pragma unroll
@@ -200,29 +216,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const ggnn_wgrad_args 
 #pragma unroll
     for (int u = 0; u < WG_TB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x2 ra[8];
-  f32x4 rb4[8];
-  f32x2 rb2[8];
-  float rb1[8];
-  // rows k + 8 lq + j, j < 8 (clamped below k_end: a ragged last group zeroes what it clamped)
-  auto row_of = [&](int64_t k, int j) { return min(k + j, k_end - 1 - 8 * lq); };
-  auto load_a = [&](int64_t k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ra[j]) : "v"(A + row_of(k, j) * W.lda));
-  };
-  auto load_b4 = [&](int64_t k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4[j]) : "v"(B + row_of(k, j) * W.ldb + cb4));
-  };
-  auto load_b2 = [&](int64_t k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rb2[j]) : "v"(B + row_of(k, j) * W.ldb + cb2));
-  };
-  auto load_b1 = [&](int64_t k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(rb1[j]) : "v"(B + row_of(k, j) * W.ldb + cb1));
-  };
-  // eight k-values of one column -> the three bf16 planes of an MFMA operand
   auto split8 = [&](const float (&v)[8], u32x4 (&f)[3]) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -231,89 +224,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const ggnn_wgrad_args 
       f[0][e] = h, f[1][e] = m, f[2][e] = l;
     }
   };
-#define WX_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define WX_WAIT24()                                      \
-  do {                                                   \
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");    \
-    WX_FENCE();                                          \
-  } while (0)
-  // one 32-row group at k; `next`: the group whose rows are requested as the registers come free (k_end: none left --
-  // the requests then repeat the last rows, harmlessly, so that the waits keep their count)
-  auto group = [&](int64_t k, int64_t next, bool ragged) __attribute__((always_inline)) {
+  struct Raw {
+    f32x2 a[8];
+    float b0[8], b1[8];
+  };
+  // rows of the group at k: A rows k + 8 lq + j for this lane's operand fragment, B rows k + 8 wave + j for the shared block
+  // (clamped below k_end; a ragged last group zeroes the A values it clamped: 0 x finite = 0)
+  auto load = [&](int64_t k, Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t rb = min(k + 8 * wave + j, k_end - 1);
+      r.b0[j] = Bq[rb * W.ldb + c0];
+      r.b1[j] = Bq[rb * W.ldb + c1];
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t ra = min(k + 8 * lq + j, k_end - 1);
+        r.a[j] = *reinterpret_cast<const f32x2*>(A + ra * W.lda);
+      }
+    }
+  };
+  auto park_b = [&](const Raw& r, int buf) __attribute__((always_inline)) {
+    unsigned char* base = smem + buf * WS_LDS;
+    u32x4 f[3];
+    split8(r.b0, f);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(base + frag0 + p * 1024) = f[p];
+    if (has_c1) {
+      split8(r.b1, f);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(base + frag1 + p * 1024) = f[p];
+    }
+  };
+  auto multiply = [&](const Raw& r, int64_t k, int buf) __attribute__((always_inline)) {
+    if (!active) return;
     u32x4 fa[WX_TA][3];
-    WX_WAIT24();   // A of this group (B4, B2, B1 may still be in flight)
 #pragma unroll
     for (int t = 0; t < WX_TA; ++t) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (!ragged || k + 8 * lq + j < k_end) ? ra[j][t] : 0.f;
+      for (int j = 0; j < 8; ++j) v[j] = k + 8 * lq + j < k_end ? r.a[j][t] : 0.f;
       split8(v, fa[t]);
     }
-    WX_FENCE();
-    load_a(next);
-    WX_FENCE();
-    auto tile = [&](int u, const float (&v)[8]) __attribute__((always_inline)) {
+    const u32x4* fbp = reinterpret_cast<const u32x4*>(smem + buf * WS_LDS) + lane;
+#pragma unroll
+    for (int u = 0; u < WG_TB; ++u) {
       u32x4 fb[3];
-      split8(v, fb);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[p] = fbp[(u * 3 + p) * 64];
 #pragma unroll
       for (int t = 0; t < WX_TA; ++t) acc[t][u] = mfma_x6(fa[t], fb, acc[t][u]);
-    };
-    WX_WAIT24();   // B4
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rb4[j][u];
-      tile(u, v);
     }
-    WX_FENCE();
-    load_b4(next);
-    WX_FENCE();
-    WX_WAIT24();   // B2
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rb2[j][u];
-      tile(4 + u, v);
-    }
-    WX_FENCE();
-    load_b2(next);
-    WX_FENCE();
-    WX_WAIT24();   // B1
-    {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rb1[j];
-      tile(6, v);
-    }
-    WX_FENCE();
-    load_b1(next);
-    WX_FENCE();
   };
-  // (rows a ragged group clamped carry garbage in B too: their A values are zero, and 0 x finite = 0 -- operands are
-  // finite by contract, as everywhere on this path)
-  int64_t k = k_begin;
-  load_a(k);
-  load_b4(k);
-  load_b2(k);
-  load_b1(k);
-  WX_FENCE();
-  for (; k + 32 <= k_end; k += 32) group(k, min(k + 32, k_end - 1), false);
-  if (k < k_end) group(k, k, true);
-  // The last group's re-requests: nothing reads them, but their destination registers must stay reserved until they have
-  // landed -- the compiler only sees `asm` statements that define values; values nobody uses would hand their registers to
-  // the address arithmetic of the very next loads while the memory system still owes them data.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ra[j]), "v"(rb4[j]), "v"(rb2[j]), "v"(rb1[j]));
-#undef WX_WAIT24
-#undef WX_FENCE
 
+  Raw cur, nxt;
+  load(k_begin, cur);
+  park_b(cur, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k = k_begin; k < k_end; k += 32, buf ^= 1) {
+    const bool more = k + 32 < k_end;
+    if (more) load(k + 32, nxt);                  // in flight during this group's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(cur, k, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) park_b(nxt, buf ^ 1);
+    __syncthreads();                              // the next group's fragments are complete; this group's are free
+    if (more) cur = nxt;
+  }
+  if (!active) return;
+
+  // acc[t][u][r]: C row = A column of (tile t, lane 4 lq + r), C column = n0 + 16 u + li
   float* out = W.partial + ((int64_t)s * W.batch + b) * W.M * W.Nc;
 #pragma unroll
   for (int u = 0; u < WG_TB; ++u) {
-    const int n = u < 4 ? n0 + 4 * li + u : u < 6 ? n0 + 64 + 2 * li + (u - 4) : n0 + 96 + li;
+    const int n = n0 + 16 * u + li;
     if (n >= W.Nc) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -325,7 +311,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const ggnn_wgrad_args 
   }
 }
 
-static bool wgrad_uses_x6(int M) { return ggnn::gemm_mode() == 1 && M >= 512; }
+#ifndef WX_MIN_M
+#define WX_MIN_M 512
+#endif
+static bool wgrad_uses_x6(int M) { return ggnn::gemm_mode() == 1 && M >= WX_MIN_M; }
 
 struct WgradPlan {
   int ta, n_mt, n_nb, n_split;
@@ -342,7 +331,8 @@ static WgradPlan wgrad_plan(int64_t K, int M, int Nc, int batch) {
   p.ta = x6 ? WX_TA : (M % 64 == 0 || M >= 512 ? 4 : 2);
   p.n_mt = (M + 16 * p.ta - 1) / (16 * p.ta);
   p.n_nb = (Nc + WG_NB - 1) / WG_NB;
-  const int64_t tiles = (int64_t)batch * p.n_mt * p.n_nb;
+  // (shared-B kernel: a workgroup = four neighbouring row tiles, surplus waves included)
+  const int64_t tiles = (int64_t)batch * (x6 ? (p.n_mt + 3) / 4 * 4 : p.n_mt) * p.n_nb;
   // one wave per SIMD of a 256-CU part (the kernel is bound by the matrix pipe: a second wave per SIMD only
   // shares it), the K ranges at least 64 rows long
   int64_t want = (x6 ? WX_WAVES : WG_WAVES) / tiles;
@@ -393,13 +383,14 @@ extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
     return GGNN_EINVAL;  // dwordx4 row pieces
   const WgradPlan p = wgrad_plan(W.K, W.M, W.Nc, W.batch);
   if (W.n_split != p.n_split) return GGNN_EINVAL;  // the caller sized `partial` with ggnn_wgrad_splits
-  const int64_t waves = (int64_t)W.batch * p.n_nb * p.n_split * p.n_mt;
+  const bool shared = wgrad_uses_x6(W.M);
+  const int64_t waves = (int64_t)W.batch * p.n_nb * p.n_split * (shared ? (p.n_mt + 3) / 4 * 4 : p.n_mt);
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffff) return GGNN_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (W.out && !aligned16(W.out)) return GGNN_EINVAL;
-  if (wgrad_uses_x6(W.M))
-    hipLaunchKernelGGL(wgrad_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
+  if (shared)
+    hipLaunchKernelGGL(wgrad_x6s_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
   else if (p.ta == 4)
     hipLaunchKernelGGL(wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, W, p.n_mt, p.n_nb, p.chunk);
   else
@@ -407,6 +398,10 @@ extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
   if (hipGetLastError() != hipSuccess) return GGNN_ELAUNCH;
   if (W.out) {   // (M, Nc multiples of 4: whole float4s)
     const int64_t n4 = (int64_t)W.batch * W.M * W.Nc / 4;
+    // many partials of a small result (the heads' [4 x 100] over 313 K ranges, the encoder's [16 x 672] over 170): a thread
+    // per result quad would walk all of them in a chain of n_split / 8 memory round trips (20 us for 0.5 MB) -- the row-sum
+    // kernel spreads the partials over 32 thread groups
+    if (W.n_split > 48 && n4 <= 16384) return launch_sum_rows(W.partial, W.out, W.n_split, 4 * n4, 1, st);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, W.partial, W.out, n4,
                        W.n_split);
   }
