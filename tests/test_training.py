@@ -647,6 +647,25 @@ def test_fused_regressor_loss_equals_the_recorded_expression(row_mask):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch,rows,cols", [(3, 768, 1152), (1, 313, 400), (2, 1, 4), (1, 31, 36), (1, 257, 8196)])
+def test_sum_rows_is_a_fixed_order_column_sum(batch, rows, cols):
+    """ggnn_sum_rows (the reduction over the sweep backward's per-workgroup partial sums and over many small ggnn_wgrad
+    partials): against the fp64 column sums within fp32 summation error, bit-identical on repeats, row counts that are not a
+    multiple of the 32 row groups, column counts that do not fill the last workgroup."""
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(rows + cols)
+    t = (torch.randn(batch, rows, cols, generator=g) * 10.0 ** torch.empty(batch, rows, 1).uniform_(-4, 0, generator=g)).cuda()
+    out = be.sum_rows(t)
+    ref, mag = t.double().sum(1), t.double().abs().sum(1)
+    assert out.shape == (batch, cols)
+    assert bool(((out.double() - ref).abs() <= 2e-6 * mag + 1e-30).all()), float((out.double() - ref).abs().max())
+    assert torch.equal(out, be.sum_rows(t))
+    with pytest.raises(Exception):
+        be.sum_rows(t[:, :, :cols - 1].contiguous())      # cols % 4 != 0
+
+
+@pytest.mark.gpu
 def test_graphed_train_step_survives_cache_eviction():
     """The captured step holds raw addresses of tensors that only evictable caches own (constant blocks of
     train_pack, the reverse CSR of training._topo_cache, the CSR tables of engine._graph_cache).  Between two
