@@ -4,11 +4,15 @@
 // A [M, K] (M = nodes: 10^4 .. 10^5, K = 96 .. 2112) and a SMALL W [n_out <= 224, K].
 //
 // Same machinery as the fused cells (cell_common.h): a wave owns ONE 16-row tile of A for the whole reduction and
-// keeps its 16 x n_out output tile in registers; the weights stream past as k-step slices of pre-split planes
-// ([column tile][plane][64 lanes][8 halfs], packed once per call from the fp32 parameters by rowgemm_pack_kernel:
-// they change with every optimizer step) through a double-buffered LDS region shared by the workgroup's eight
-// waves (LDS-DMA one slice ahead, one barrier per slice); the rows arrive as B-fragment-shaped 32-byte pieces
-// (the four k-groups of a row = one 128-byte line), one k-step ahead in registers.
+// keeps its 16 x n_out output tile in registers; the weights are k-step slices of pre-split planes ([column tile][plane]
+// [64 lanes][8 halfs], made from the fp32 parameters by ggnn_rowgemm_pack -- by the call itself or, for the five
+// products of a training cell, by one launch ahead of them: they change with every optimizer step).  Two kernels:
+//   * rowgemm_resident_kernel (K <= 128, or <= 256 with 96 outputs: eight of the ten products of a training step): the
+//     planes of one batch entry stay in LDS for the whole launch, grid = (row chunks, batch), no barrier behind the prologue;
+//   * rowgemm_kernel (longer reductions: g_h, K = 1248 / 2112): the slices stream through a double-buffered LDS region
+//     shared by the workgroup's eight waves (LDS-DMA one group of slices ahead, one barrier per group).
+// In both the rows arrive as B-fragment-shaped 32-byte pieces (the four k-groups of a row = one 128-byte line), a whole
+// tile or group ahead in registers.
 // Arithmetic: fp32 mode = two fp16 pieces / three products per operand pair (common.h: 5e-8 of sum |a||w| against
 // fp64, an fp32 fma chain: 2e-7); GGNN_PRECISION_BF16 (torch.autocast(bfloat16), BASELINE config 5) = ONE bf16 plane,
 // one product, fp32 accumulation: a third of the matrix work and half the weight bytes.
