@@ -79,8 +79,9 @@ def cell_params(cell, gates):
             slots += [(o._parameters, wb) for o in owners]
     for nt in NODE_TYPES:
         owners = [getattr(cell, "b_" + g) for g in gates]
-        table[("b", nt)] = (off, (G, C))
-        off += G * C
+        width = owners[0]._parameters[nt].numel()       # layer_size (96 in the shipped models)
+        table[("b", nt)] = (off, (G, width))
+        off += G * width
         slots += [(o._parameters, nt) for o in owners]
     cache[gates] = (slots, table, off)
     return [d[k] for d, k in slots], table, off
@@ -160,16 +161,41 @@ def packed_weights_ops(cell, gates, F, sees_h):
     return layout, wp, bp, {et: v.contiguous() for et, v in ep.items()}, w2
 
 
+def _widen(t, key, c, F):
+    """Index tensor of a stacked parameter [G, *shape] of a layer_size-c cell -> the shape it has at layer_size 96, the
+    padding reading slot -1 (the plan's zero slot): output rows c -> 96, the hidden-state part of the input columns
+    [F | c] -> [F | 96] (packing.padded_cell is the same padding on values, for the inference path)."""
+    et, kind = key
+    pad = lambda x, dim, lead=0: torch.cat(
+        [x, torch.full(x.shape[:dim] + (lead + C - x.size(dim),) + x.shape[dim + 1:], -1, dtype=x.dtype)], dim)
+    if et == "b" or kind in ("bq", "bk", "bv", "bs", "bl"):
+        return pad(t, 1)                                           # [G, c] -> [G, 96]
+    t = pad(t, 1)                                                  # output rows
+    if kind == "wl":
+        return pad(t, 2)                                           # [G, 96, c] -> [G, 96, 96]
+    if kind == "we":
+        return t                                                   # [G, 96, 1]
+    Fin = F[et[0]] if kind in ("wk", "wv") else F[et[-1]]          # (wq, ws: destination features)
+    return pad(t, 2, Fin)                                          # [G, 96, F + c] -> [G, 96, F + 96]
+
+
 class PackPlan:
-    """Index tables of one cell configuration (feature widths, gates, sees_h), built on the CPU once."""
+    """Index tables of one cell configuration (feature widths, gates, sees_h, layer_size), built on the CPU once.
+    layer_size c < 96 (parameters.py:19): the tables address the cell's c-wide parameters directly and read the zero slot
+    wherever the 96-wide layout has a padded row or hidden-state column -- the packed matrices come out zero-padded (the
+    padded channels stay exactly zero through a cell, packing.py), at no run-time cost; the score scale is 1 / sqrt(c)."""
 
     def __init__(self, cell, gates, F, sees_h, device):
         G, k2 = len(gates), (C if sees_h else 0)
+        c = getattr(cell, "out_channels", C)
         plist, table, n_flat = cell_params(cell, gates)
         self.shapes = [tuple(p.shape) for p in plist]
         self.sizes = [p.numel() for p in plist]
         self.n_flat = n_flat
-        idx_of = lambda *key: torch.arange(table[key][0], table[key][0] + math.prod(table[key][1])).view(table[key][1])
+
+        def idx_of(*key):   # (padding = -1 until the zero slot's index is known)
+            t = torch.arange(table[key][0], table[key][0] + math.prod(table[key][1])).view(table[key][1])
+            return t if c == C else _widen(t, key, c, F)
         # the products, batched over the three edge types: operands padded to common shapes (pad entries read the
         # zero slot), one bmm [3 G, r, 96] x [3 G, 96, c]; coefficient = the 1/sqrt(96) on the K side
         ops = [kq_operands(idx_of, F, k2, et) for et in EDGE_TYPES]
@@ -188,9 +214,11 @@ class PackPlan:
             mr_idx[et] = mr_all[e * G:(e + 1) * G, :K.size(1), :Q.size(2)]
         self.k_shape, self.q_shape, self.mr_shape = tuple(K_all.shape), tuple(Q_all.shape), tuple(mr_all.shape)
         self.n_k, self.n_kq = K_all.numel(), K_all.numel() + Q_all.numel()
+        K_all[K_all < 0] = Z
+        Q_all[Q_all < 0] = Z
         kq_idx = torch.cat([K_all.reshape(-1), Q_all.reshape(-1)])
-        kq_coef = torch.cat([torch.full((K_all.numel(),), SCALE), torch.ones(Q_all.numel())])
-        blank = lambda *key: torch.full(table[key][1], Z)
+        kq_coef = torch.cat([torch.full((K_all.numel(),), 1.0 / math.sqrt(c)), torch.ones(Q_all.numel())])   # periodGATconv.py:226
+        blank = lambda *key: torch.full_like(idx_of(*key), Z)
         fill = lambda *shape: torch.full(shape, Z)
         layers = []
         for layer in range(3):
@@ -207,6 +235,7 @@ class PackPlan:
         self.out_shapes = [tuple(t.shape) for t in outs[0]]
         self.out_sizes = [t.numel() for t in outs[0]]
         idx3 = torch.stack([torch.cat([t.reshape(-1) for t in o]) for o in outs], 1)      # [n_packed, 3]
+        idx3[idx3 < 0] = Z
         while idx3.size(1) > 1 and bool((idx3[:, -1] == Z).all()):
             idx3 = idx3[:, :-1]
         self.n_packed = idx3.size(0)
@@ -240,7 +269,7 @@ _plans: Dict[tuple, PackPlan] = {}
 
 
 def pack_plan(cell, gates, F, sees_h, device) -> PackPlan:
-    key = (tuple(sorted(F.items())), gates, sees_h, str(device))
+    key = (tuple(sorted(F.items())), gates, sees_h, str(device), getattr(cell, "out_channels", C))
     p = _plans.get(key)
     if p is None:
         p = _plans[key] = PackPlan(cell, gates, F, sees_h, device)

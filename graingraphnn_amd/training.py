@@ -309,6 +309,9 @@ class _RegressorHeads(torch.autograd.Function):
     def forward(ctx, h_joint, h_grain, x_grain, w_j, b_j, w_g, b_g, backend):
         h_joint, h_grain = h_joint.contiguous(), h_grain.contiguous()
         w, b = torch.stack([w_j, w_g]), torch.cat([b_j, b_g])             # [2, 2, 96], [4] (packing.pack_regressor_heads)
+        ctx.width = w.size(2)
+        if ctx.width != C:    # layer_size < 96: zero columns for the padded (exactly zero) channels of h
+            w = torch.nn.functional.pad(w, (0, C - ctx.width))
         nj, ng = h_joint.size(0), h_grain.size(0)
         f32 = dict(dtype=torch.float32, device=h_joint.device)
         y_joint, y_grain, area = torch.empty(nj, 2, **f32), torch.empty(ng, 2, **f32), torch.empty(ng, **f32)
@@ -330,7 +333,7 @@ class _RegressorHeads(torch.autograd.Function):
         for gp, h in ((gpj, h_joint), (gpg, h_grain)):   # [g_pre | 0]^T [h | 1 | 0]: weight and bias gradient in one product
             xin = torch.cat([h, _ones(h.device, h.size(0), 4)], 1)
             gw = be.wgrad(gp, xin, h.size(0), 4, C + 4, 4, C + 4)[0]
-            out += [gw[:2, :C], gw[:2, C]]
+            out += [gw[:2, :ctx.width], gw[:2, C]]
         return ghj, ghg, None, out[0], out[1], out[2], out[3], None
 
 
@@ -349,7 +352,8 @@ def classifier_forward(model, x_dict, edge_index_dict, edge_attr):
     h, graph = encoder_decoder(model, x_dict, edge_index_dict, edge_attr)
     et = ("joint", "connect", "joint")
     src, dst = graph.edge_index[et][0], graph.edge_index[et][1]
-    pair = torch.cat([h["joint"][src], h["joint"][dst], edge_attr[et].view(-1, 1)], -1)
+    hj = h["joint"] if model.out_channels == C else h["joint"][:, :model.out_channels]   # (padded channels: zero)
+    pair = torch.cat([hj[src], hj[dst], edge_attr[et].view(-1, 1)], -1)
     y = _RowLinear.apply(pair, torch.cat([model.lin1.weight, model.lin2.weight]),
                          torch.cat([model.lin1.bias, model.lin2.bias]), default_backend())   # both heads in one product
     return {"edge_event": y[:, 2].contiguous(), "edge": torch.tanh(y[:, :2])}
@@ -528,12 +532,7 @@ def wants_autograd(model, x_dict=None) -> bool:
         raise NotImplementedError("gradients with respect to x_dict are not built (the reference's training "
                                   "loop never asks for them, train.py:158-166): detach the inputs")
     if model.training:
-        if any(p.requires_grad for p in model.parameters()):
-            if getattr(model, "out_channels", C) != C:
-                raise NotImplementedError(f"the training path is built for layer_size {C} only (the narrower models of "
-                                          "parameters.py:19 run inference on zero-padded weights, packing.padded_cell)")
-            return True
-        return False
+        return any(p.requires_grad for p in model.parameters())
     if not _warned_eval_grad and any(p.requires_grad for p in model.parameters()):
         _warned_eval_grad = True
         import warnings

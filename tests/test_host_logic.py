@@ -222,10 +222,6 @@ def test_narrow_layer_sizes_run_zero_padded_on_the_96_wide_path(layer_size):
     wantc = Co(X, EI, EA)
     assert_close(ev, wantc["edge_event"], f"layer_size {c} edge_event", TOL)
     assert_close(ed, wantc["edge"], f"layer_size {c} edge", TOL)
-    # the training path is 96-wide only and says so
-    R.train()
-    with torch.enable_grad(), pytest.raises(NotImplementedError, match="layer_size 96"):
-        R(X, EI, EA)
 
 
 def test_fp16_two_piece_split_is_fp32_equivalent():

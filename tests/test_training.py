@@ -114,6 +114,33 @@ def test_training_path_on_the_emulator_matches_oracle_gradients(monkeypatch):
         R(tt(x), tt(ei), tt(ea))
 
 
+@pytest.mark.parametrize("layer_size", [64, 32])
+def test_narrow_layer_training_on_the_emulator_matches_oracle_gradients(monkeypatch, layer_size):
+    """parameters.py:19: layer_size 64 / 32.  The training path packs a narrow cell through index tables that address
+    its c-wide parameters directly and read the zero slot for every padded row / hidden-state column of the 96-wide layout
+    (train_pack.PackPlan, _widen); the score scale is 1 / sqrt(c).  Loss and all 568 parameter gradients of both models
+    against the oracle of the same width; the packed matrices equal those of the inference path's zero-padded holder."""
+    from test_host_logic import _narrow_models
+    from graingraphnn_amd import packing, train_pack
+    x, ei, ea = load_graph("40")
+    be = TorchEmulatorBackend()
+    monkeypatch.setattr(training, "default_backend", lambda: be)
+    (R, Cm), (oR, oC) = _narrow_models(layer_size, 41)
+    lr, lc, grads = _grads(R, Cm, x, ei, ea)
+    olr, olc, ref = _grads(oR, oC, x, ei, ea)
+    assert abs(lr - olr) <= 1e-5 * abs(olr) and abs(lc - olc) <= 1e-5 * abs(olc), (lr, olr, lc, olc)
+    assert all(grads[k].shape == ref[k].shape for k in ref)
+    _check_full(grads, ref)
+    for encoder, cell in ((True, R.gclstm_encoder.cell_list[0]), (False, R.gclstm_decoder.cell_list[0])):
+        gates = "ico" if encoder else "ifco"
+        _, wp, bp, ep, w2 = train_pack.packed_weights(cell, gates, cell.in_channels_dict, not encoder)
+        pc = packing.pack_cell(packing.padded_cell(cell, layer_size), cell.in_channels_dict, encoder)
+        for nt in wp:
+            n = min(wp[nt].size(0), pc.wp[nt].size(0))     # (same rows; the inference layout may drop dead columns)
+            if wp[nt].shape == pc.wp[nt].shape:
+                assert torch.allclose(wp[nt], pc.wp[nt], rtol=1e-5, atol=1e-7), (encoder, nt)
+
+
 def test_one_adam_step_on_the_emulator_follows_the_oracle(monkeypatch):
     """train.py:158-166: forward, loss, zero_grad, backward, Adam step -- same new parameters.
     (Where the exact gradient is zero -- key biases: a softmax is shift-invariant; the encoder's
@@ -165,6 +192,26 @@ def test_hip_training_gradients_match_oracle_and_reference_digests():
     yt = R(X, EI, EA)
     for k in ("joint", "grain", "grain_area"):
         assert float((yi[k] - yt[k].detach()).abs().max()) <= 1e-4 * float(yi[k].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer_size", [64, 32])
+def test_hip_training_gradients_of_narrow_layers_match_the_oracle(layer_size):
+    """layer_size 64 / 32 on the HIP training path (zero-padded packed weights through the index tables): loss and every
+    parameter gradient of both models against the oracle of that width, and one FusedAdam step."""
+    from test_host_logic import _narrow_models
+    x, ei, ea = load_graph("40")
+    (R, Cm), (oR, oC) = _narrow_models(layer_size, 43, "cuda")
+    lr, lc, grads = _grads(R, Cm, x, ei, ea, "cuda")
+    olr, olc, ref = _grads(oR, oC, x, ei, ea)
+    assert abs(lr - olr) <= 1e-5 * abs(olr) and abs(lc - olc) <= 1e-5 * abs(olc), (lr, olr, lc, olc)
+    worst = _check_full(grads, ref)
+    print(f"layer_size {layer_size}: worst per-tensor relative gradient error {worst:.2e}")
+    opt = training.FusedAdam(R.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in R.parameters()]
+    opt.step()
+    moved = [float((p.detach() - b).abs().max()) for p, b in zip(R.parameters(), before) if p.grad is not None]
+    assert moved and max(moved) <= 1.01e-3 and max(moved) > 0
 
 
 @pytest.mark.gpu
