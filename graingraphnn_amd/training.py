@@ -413,8 +413,9 @@ def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (train.py:82-91: per-group learning rates, StepLR on top) with the update of ALL parameter tensors
-    in ONE launch (`ggnn_adam_step`): the model has ~150 small parameter tensors, which torch's multi-tensor kernels take
-    in 14 launches (~0.1 ms of a 2 ms training step at the 10k-grain graph).  What is fixed about a tensor (addresses of
+    in ONE call (`ggnn_adam_step`: the update kernel + a one-workgroup launch that advances the step counts): the model has
+    284 small parameter tensors, which torch's multi-tensor kernels take in 14 launches (~0.1 ms of a 2 ms training step
+    at the 10k-grain graph).  What is fixed about a tensor (addresses of
     the parameter and its moments, size, group) sits in a table in device memory; what changes from step to step -- the
     gradients' addresses (new tensors after every backward), the groups' learning rates (a scheduler edits
     `param_groups[i]["lr"]`) -- travels in the launch's arguments.  The step counts live on the device and the call
@@ -430,8 +431,6 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         if len({(tuple(g["betas"]), g["eps"]) for g in self.param_groups}) != 1:
             raise ValueError("FusedAdam: betas and eps must be the same in every parameter group (lr and weight_decay may differ)")
-        if len(self.param_groups) > _lib.GGNN_ADAM_MAX_GROUPS:
-            raise ValueError("FusedAdam: at most %d parameter groups" % _lib.GGNN_ADAM_MAX_GROUPS)
         self._built = None
 
     def _build(self):
@@ -454,7 +453,13 @@ class FusedAdam(torch.optim.Optimizer):
         assert table.itemsize == ctypes.sizeof(_lib.AdamTensor)
         for k, ((p, gi), n) in enumerate(zip(ps, sizes)):
             o = int(offs[k])
-            self.state[p] = {"step": step[k], "exp_avg": m[o:o + n].view_as(p), "exp_avg_sq": v[o:o + n].view_as(p)}
+            new = {"step": step[k], "exp_avg": m[o:o + n].view_as(p), "exp_avg_sq": v[o:o + n].view_as(p)}
+            old = self.state.get(p)
+            if old and "exp_avg" in old:   # a rebuild (load_state_dict, add_param_group): what was there moves in
+                new["exp_avg"].copy_(old["exp_avg"])
+                new["exp_avg_sq"].copy_(old["exp_avg_sq"])
+                new["step"].copy_(torch.as_tensor(old["step"]).to(device=dev, dtype=torch.float32))
+            self.state[p] = new
             table[k] = (p.data_ptr(), m.data_ptr() + 4 * o, v.data_ptr() + 4 * o, n, gi, 0)
         dev_table = torch.from_numpy(table.view(np.uint8)).to(dev)
         launches = []   # a launch takes GGNN_ADAM_MAX_TENSORS tensors: (first tensor, count, chunk maps)
@@ -505,15 +510,15 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """The loaded moments and step counts are copied INTO the flat buffers (the device table points there)."""
         super().load_state_dict(state_dict)
-        loaded = {p: dict(self.state[p]) for p in list(self.state)}
         self._built = None
-        self._build()
         with torch.no_grad():
-            for p, st in loaded.items():
-                if p in self.state and "exp_avg" in st:
-                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
-                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
-                    self.state[p]["step"].copy_(torch.as_tensor(st["step"]).to(torch.float32))
+            self._build()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if len(self.param_groups) > _lib.GGNN_ADAM_MAX_GROUPS:
+            raise ValueError("FusedAdam: at most %d parameter groups" % _lib.GGNN_ADAM_MAX_GROUPS)
+        self._built = None   # rebuilt (state carried over) by the next step
 
 
 _warned_eval_grad = False

@@ -648,6 +648,17 @@ def test_fused_adam_follows_torch_adam():
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert torch.allclose(a, b, rtol=4e-6, atol=4e-7), (i, float((a - b).abs().max()))
     assert float(oc.state[pa[0]]["step"]) == 8.0 and float(oc.state[pa[4]]["step"]) == 5.0
+    # a parameter group added later (train.py:84-91 builds its groups up front; torch allows it afterwards): the moments
+    # of the tensors already there are carried over into the rebuilt buffers
+    extra_a = torch.nn.Parameter(torch.full((10,), 0.5, device=dev))
+    extra_b = torch.nn.Parameter(extra_a.detach().clone())
+    oc.add_param_group({"params": [extra_a], "lr": 1e-2})
+    ob.add_param_group({"params": [extra_b], "lr": 1e-2})
+    pa2, pb2 = pa + [extra_a], pb + [extra_b]
+    steps(oc, pa2, ob, pb2, 2, 13)
+    for i, (a, b) in enumerate(zip(pa2, pb2)):
+        assert torch.allclose(a, b, rtol=6e-6, atol=6e-7), (i, float((a - b).abs().max()))
+    assert float(oc.state[pa[0]]["step"]) == 10.0 and float(oc.state[extra_a]["step"]) == 2.0
     with pytest.raises(Exception, match="MI355X|CPU"):
         training.FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3).step()
     # more tensors than one call carries (GGNN_ADAM_MAX_TENSORS = 384): two calls per update, each advancing its own counts
