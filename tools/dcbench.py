@@ -8,7 +8,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
-from graingraphnn_amd import synthetic
+from graingraphnn_amd import _lib, synthetic
+if os.environ.get("GGNN_ABI"):   # timing an older build of the library (its results on this tree's stream image are not checked here)
+    _lib.GGNN_ABI_VERSION = int(os.environ["GGNN_ABI"])
 from graingraphnn_amd.backend import default_backend
 from test_hip_parity import _dec_cell_problem
 
