@@ -91,30 +91,6 @@ __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32
   }
 }
 
-// The same k-step with the operands in the other order: acc[nb] += x . W[nb] -- the tile's rows are the A operand and the
-// weight fragments (the same bytes) the B operand, so a lane holds D[row 4 (l >> 4) ..+3][column l & 15] of every
-// column tile: a node's columns across the 16 lanes of a DPP row.
-template <int NB>
-__device__ __forceinline__ void dc_kstep_xa(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
-  constexpr int AH = GGNN_KSTEP_AHEAD < NB ? GGNN_KSTEP_AHEAD : NB - 1;
-  u32x4 wf[AH + 1][DC_PL];
-#pragma unroll
-  for (int a = 0; a < AH; ++a)
-#pragma unroll
-    for (int p = 0; p < DC_PL; ++p) wf[a][p] = pw[(a * DC_PL + p) * 64];
-  __builtin_amdgcn_sched_group_barrier(0x100, AH * DC_PL, 0);
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    if (nb + AH < NB) {
-#pragma unroll
-      for (int p = 0; p < DC_PL; ++p) wf[(nb + AH) % (AH + 1)][p] = pw[((nb + AH) * DC_PL + p) * 64];
-    }
-    mfma_x3h(xb, wf[nb % (AH + 1)], acc[nb].m, acc[nb].c);
-    if (nb + AH < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                         // MFMA
-  }
-}
-
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ f32x4 ld16f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 

@@ -2,27 +2,35 @@
 // (ggnn_decoder_cell_batch, include/ggnn.h): the destination-side projections (u_h | u4 per edge type and
 // gate, the summed skip term), the periodic-boundary GAT sweep (PeriodConv.message, periodGATconv.py:204-236,
 // + propagate's gather / scatter-add), lin_l2 + the value-side lin_edge term, HeteroConv's sum over the edge
-// types and the LSTM update (heteropgclstm.py:111-146).
+// types and the LSTM update (heteropgclstm.py:111-146).  Replaces two thirds of the decoder projection's
+// columns, ggnn_period_gat_aggregate_batch and ggnn_lstm_epilogue_batch: per model forward at the 10k-grain
+// graph 142 MB of u_h / u4 / S rows and 92 MB of aggregates that were written and read back once each.
 //
-// Round 5 layout: a 16-node tile per WAVE, TWELVE waves (192 nodes) per workgroup, three waves per SIMD.  What made
-// that fit (round 4: eight waves, 246 registers, 15.9 KB of LDS per wave):
-//   * P1 (score operands u_h | u4 = W1 . [h | x | 1], K = 128) runs with the TILE'S ROWS AS THE A OPERAND and the
-//     weight fragments as B: D[node][column] leaves lane (column l & 15, nodes 4 (l >> 4) ..+3).  With the rows of the
-//     score weights permuted on the host (packing.DC_P1_ROW) that IS the sweep's layout -- a node's 96 channels across
-//     the 16 lanes of a DPP row, lane lr owning channels 3 lr ..+2 and 48 + 3 lr ..+2 -- so u never leaves the
-//     registers: DPP row kq sweeps nodes 4 kq .. 4 kq + 3 one after the other.
-//   * the aggregates come back to the matrix layout THROUGH THE MATRIX PIPE: four v_mfma_f32_16x16x4_f32 per
-//     channel slot against 0/1 selector fragments transpose a [16 nodes][16 lanes] block exactly (products with 1 and
-//     0, sums with 0), leaving lane (node l & 15, k-group l >> 4) with the 24 aggregate channels that lin_l2's
-//     k-steps -- columns permuted on the host (packing.DC_P3_COL) -- take as their B fragments.  28 MFMAs per
-//     (edge type, gate) pass on a pipe that was 12 % busy replace the 7.4 KB LDS stage per wave.
-//   * what stays in LDS per wave: the tile's input rows [h | x | 1 | 0] as the two fp16 planes of their fragments
-//     (7 KB: A operand of P1, B operand of P4, twelve uses per tile) and the CSR windows (1 KB).
-// The weights of a destination type (0.84 MB as two fp16 planes) stream past the tiles as k-step slices (14 KB)
-// through a double-buffered LDS region shared by the workgroup's waves, fetched one slice ahead by LDS-DMA, one
-// workgroup barrier per slice; the gates are walked one after the other (i, c~, f, o) with the LSTM update folded in
-// as they arrive.  Arithmetic: every fp32 operand of the three GEMMs as TWO fp16 pieces and THREE MFMA products
-// (common.h); the sweep in fp32 with explicit fmas (bit-reproducible whichever tile computes a row).
+// Why it is organised around a 16-node tile per WAVE with the weights streaming past:
+//   * the three GEMMs of a destination node (score weights K = 104, lin_l2 K = 96, skip K = 104) chain through
+//     the MFMA layouts without a transpose when the NODES are the B operand: D[out][node] leaves lane
+//     (node l & 15, out rows 4 (l >> 4) ..+3), and a B fragment wants lane (node l & 15, k = 8 (l >> 4) ..+7);
+//   * the sweep wants the other layout (a node's 96 channels across the 16 lanes of a DPP row: whole 384-byte
+//     rows per gather, dot products closed with four DPP adds), so u and the aggregates cross a wave-private
+//     LDS stage ([16][116] floats) once each way -- 7 KB per wave instead of 57 + 50 KB of u / agg per tile if
+//     all gates were kept at once: the gates are walked ONE AFTER THE OTHER (i, c~, f, o) and the LSTM update is
+//     folded in as they arrive (sig(i) -> sig(i) tanh(c~) -> c' -> h'), so a wave holds one gate's 16 x 96
+//     pre-activations (24 VGPRs) plus the running LSTM term (24), never four;
+//   * the weights of a destination type are 0.84 MB as two fp16 planes (joints: 2 x 4 score blocks [112 x 128],
+//     8 lin_l2 blocks, 4 skip blocks) -- five times the LDS.  They arrive as k-step slices (one 32-deep
+//     k-step of one block: 14 KB) through a double-buffered LDS region shared by the workgroup's eight waves,
+//     fetched one slice ahead by LDS-DMA, one workgroup barrier per slice.  Host-side pre-split planes: no
+//     splitting arithmetic on the weight side in the kernel (the gate kernel's split cost 44 VALU per fragment).
+//   * arithmetic: every fp32 operand as TWO fp16 pieces (hi = rne16(x), lo' = rne16((x - hi) 2^11)) and THREE MFMA
+//     products per k-step (hi hi into the main accumulator; hi lo' + lo' hi into a cross accumulator that is folded
+//     in with 2^-11 behind the k-loop): 22 significand bits per operand, against an fp64 product 5e-8 of sum |x||w|
+//     (a plain fp32 fma chain: 2e-7; the six-product bf16 split of the other GEMM kernels: 2e-8) -- common.h.  Until
+//     round 3's last version this kernel used the bf16 split too: 21 KB slices, 42 MFMAs per P1 slice, 144 us per
+//     launch at the 10k-grain graph against 122 us now.
+//   * the tile's input rows [h | x | 1 | 0] stay in LDS for the whole tile (B operand of P1 and P4 of every
+//     gate): as registers they had to be reloaded behind every sweep, in front of P3's first slice.
+// A tile's CSR window (17 row pointers + up to 111 source indices per edge type) is fetched once into LDS
+// and reused by the four gate passes; h_src rows are gathered once per gate (they stay in L2), V rows once.
 #include <algorithm>
 #include <type_traits>
 
@@ -33,22 +41,18 @@
 
 namespace ggnn {
 
-#ifndef DC_WAVES_
-#define DC_WAVES_ 12
-#endif
-#ifndef DC_ROWS_
-#define DC_ROWS_ 1   // rows of a 16-lane group whose gathers are in flight together (1 or 2)
-#endif
-constexpr int DC_WAVES = DC_WAVES_;                 // 16-node tiles per workgroup
+constexpr int DC_WAVES = 8;                        // one workgroup of 128 nodes per compute unit, two waves per SIMD
 constexpr int DC_MAX_PROBLEMS = 4;
 constexpr int DC_SLICE = GGNN_DC_SLICE_BYTES;       // 14 pieces of 1 KB
 static_assert(DC_SLICE == 7 * DC_PL * 1024, "slice = 7 column tiles x planes x 1 KB");
 constexpr int DC_NP1 = 7 * DC_PL, DC_NP3 = 6 * DC_PL;   // pieces of a P1 slice / of a P3 or P4 slice
-constexpr int DC_XF = 7 * 1024;                     // the tile's input rows as fragment planes
+constexpr int DC_S = 116;                           // stage row stride in floats (52 mod 64 banks: rows spread)
+constexpr int DC_STAGE = 16 * DC_S * 4;             // 7 424 B
+constexpr int DC_XF = 16 * DC_S * 4;                // the tile's input rows [h 96 | x F | 1 | 0 ..] as B-fragment planes (7 KB used): B operand of P1 / P4
 constexpr int DC_CW = 111;                          // source indices of a tile kept in LDS per edge type
 constexpr int DC_CSR = (17 + DC_CW) * 4;            // 512 B
-constexpr int DC_WAVE_LDS = DC_XF + 2 * DC_CSR;     // 8 KB
-constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 126 976 B at twelve waves
+constexpr int DC_WAVE_LDS = DC_STAGE + DC_XF + 2 * DC_CSR;
+constexpr int DC_LDS = 2 * DC_SLICE + DC_WAVES * DC_WAVE_LDS;   // 155 648 B
 static_assert(DC_LDS <= 160 * 1024, "LDS");
 
 struct DecCellBatch {
@@ -61,14 +65,14 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
                                               unsigned char* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // matrix view (P3, P4, LSTM): node lr of the tile, k-group / output rows 4 kq ..
-  // sweep view (P1's result, P2): lane lr of DPP row kq owns channels ch..ch+2, 48+ch.. of nodes 4 kq .. 4 kq + 3
-  const int lr = lane & 15, kq = lane >> 4;
-  const int ch = 3 * lr;
+  const int lr = lane & 15, kq = lane >> 4;  // matrix view: node lr of the tile, k-group / output rows 4 kq ..
+  const int ch = 3 * lr;                     // sweep view: lane lr of DPP row kq owns channels ch..ch+2, 48+ch..
   constexpr int CH2 = C / 2;
 
   unsigned char* __restrict__ wbase = smem + 2 * DC_SLICE + wave * DC_WAVE_LDS;
-  int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_XF);   // [e][17 + DC_CW]
+  float* __restrict__ stage = reinterpret_cast<float*>(wbase);
+  float* __restrict__ xf = reinterpret_cast<float*>(wbase + DC_STAGE);
+  int* __restrict__ csr = reinterpret_cast<int*>(wbase + DC_STAGE + DC_XF);   // [e][17 + DC_CW]
 
   const int n_dst = (int)A.n_dst, n_in = A.n_in, F = A.f_dst;
   // a ragged last tile slides back over rows the previous tile also produces (identical duplicate results);
@@ -78,6 +82,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   const int node_m = min(row0 + lr, n_dst - 1);    // this lane's node in the matrix view (n_dst < 16: clamped)
 
   // ---- the weight stream: slice s -> buffer s & 1, fetched one slice ahead by all the workgroup's waves ----
+  // LDS-DMA, a wave's share of the next slice (the slice's 14 or 12 one-KB pieces dealt round-robin) requested at the top
+  // of a k-step; one counted wait + one workgroup barrier per slice.  The ISSUE of a piece costs the wave ~150
+  // cycles (in-kernel stamps: 0.38 us per slice with four waves sharing a slice = 27 of a tile's 140 us), which is
+  // why the workgroup has eight waves: half the pieces per wave and slice.  (Tried: 16-byte loads to registers +
+  // ds_write_b128 at the end of the k-step -- the loads' latency then sits in front of the barrier: slower.)
   const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(A.wstream) + lane * 16;
   const uint32_t slice_lds =
       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)));
@@ -107,16 +116,17 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   dma_slice(0, DC_NP1);
   // Range flag (ggnn.h, OPERAND RANGE): the operands of the two-piece fp16 split are checked where they are made --
   // the tile's input rows here in the prologue, the aggregates when a row is closed -- and reported at once: no
-  // state is carried.  `!(|v| < 65504)` is true for NaN as well.
+  // state is carried (the kernel has no register to spare).
   auto report_range = [&](bool bad) __attribute__((always_inline)) {
     if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
   };
 
-  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS AS THE TWO fp16 PLANES of their fragments (a
-  // lane (node lr, k-group kq) holds x[node][32 ks + 8 kq ..+7]: the A fragment of P1 and the B fragment of P4 are the
-  // same registers).  A lane only ever reads the 16-byte slots it writes: [k-step 0..2][plane][lane] and, for the 16
-  // feature slots, [plane][lanes of k-groups 0 and 1] = 7 KB.  CSR windows -> LDS. ----
-  unsigned char* __restrict__ xpl = wbase + lane * 16;
+  // ---- tile prologue: the tile's input rows [h | x | 1 | 0] -> LDS AS THE TWO fp16 PLANES of their B fragments
+  // (read by P1 and P4 of every gate: 12 x 4 k-steps per tile; split once here instead of at every read -- round 4:
+  // the splits were ~100 vector instructions per k-step, 9 us of a tile's 120).  A lane (node lr, k-group kq) only ever
+  // reads the 16-byte slots it writes: [k-step 0..2][plane][lane] and, for the 16 feature slots, [plane][lanes of
+  // k-groups 0 and 1] = 7 KB of the wave's DC_XF bytes.  CSR windows -> LDS. ----
+  unsigned char* __restrict__ xpl = reinterpret_cast<unsigned char*>(xf) + lane * 16;
   auto x_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
     if (ks < 3) {
 #pragma unroll
@@ -130,8 +140,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     }
   };
   {
-    bool bad = false;
-    const float* hrow = A.h_dst + (int64_t)node_m * A.ldh + 8 * kq;
+    float in_max = 0.f;
+    const float* hrow = A.h_dst + (int64_t)min(row0 + lr, n_dst - 1) * A.ldh + 8 * kq;
     f32x4 hv[3][2];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
@@ -139,7 +149,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
       hv[ks][1] = *reinterpret_cast<const f32x4*>(hrow + 32 * ks + 4);
     }
     // features: slots 8 (kq & 1) ..+7 of [x_0 .. x_{F-1}, 1 (bias), 0 ..]
-    const float* xrow = A.x_dst + (int64_t)node_m * A.ldx;
+    const float* xrow = A.x_dst + (int64_t)min(row0 + lr, n_dst - 1) * A.ldx;
     f32x4 xv[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -150,8 +160,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const f32x4 r0 = ks < 3 ? hv[ks][0] : xv[0], r1 = ks < 3 ? hv[ks][1] : xv[1];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bad |= !(__builtin_fabsf(r0[i]) < 65504.0f) | !(__builtin_fabsf(r1[i]) < 65504.0f);
+      in_max = fmaxf(fmaxf(in_max, fmaxf(fmaxf(__builtin_fabsf(r0[0]), __builtin_fabsf(r0[1])), fmaxf(__builtin_fabsf(r0[2]), __builtin_fabsf(r0[3])))),
+                     fmaxf(fmaxf(__builtin_fabsf(r1[0]), __builtin_fabsf(r1[1])), fmaxf(__builtin_fabsf(r1[2]), __builtin_fabsf(r1[3]))));
       u32x4 pl[DC_PL];
       dc_split(r0, r1, pl);
       if (ks < 3) {
@@ -162,7 +172,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512) = pl[p];
       }
     }
-    report_range(bad);
+    report_range(!(in_max < 65504.0f));
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       int* __restrict__ rp = csr + e * (17 + DC_CW);
@@ -190,14 +200,12 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 
     // the edge types are walked forwards for the first and third gate of the stream and backwards for the second and
     // fourth: the hidden rows and edge records a pass gathered are gathered again by the very next pass (the same edge
-    // type, the next gate) while the XCD's L2 still holds them
+    // type, the next gate) while the XCD's L2 still holds them -- in a fixed order every re-gather came two passes later
     for (int ei = 0; ei < n_in; ++ei) {
       const int e = (gi & 1) ? n_in - 1 - ei : ei;
       const ggnn_dec_cell_sweep& Sw = A.in[e];
-      // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g), in the sweep's layout =================
-      // uv[cc][r] (cc < 6) = u_h[node 4 kq + r][channel ch + cc | 48 + ch + cc - 3], uv[6][r] = u4[node 4 kq + r][slot lr]
+      // ================= P1: u_h | u4 of the tile's 16 nodes for (e, g) =================
       [[maybe_unused]] const unsigned long long t_a = GGNN_STAMP_NOW();
-      f32x4 uv[7];
       {
         DcAcc u[7];
 #pragma unroll
@@ -207,19 +215,20 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const u32x4* pw = begin_slice(ks < 3 ? DC_NP1 : DC_NP3);   // behind P1: the sweep, then P3's first slice
-          dc_kstep_xa<7>(pw, xb[ks & 1], u);
+          dc_kstep<7>(pw, xb[ks & 1], u);
           if (ks + 1 < 4) x_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();
         }
+        // D layout -> stage[node][column]
 #pragma unroll
-        for (int nb = 0; nb < 7; ++nb) uv[nb] = u[nb].value();
+        for (int nb = 0; nb < 7; ++nb) *reinterpret_cast<f32x4*>(&stage[lr * DC_S + 16 * nb + 4 * kq]) = u[nb].value();
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
 
-      // ================= P2: the sweep of (e, g) over the tile's rows, one node per 16-lane row at a time ==============
-      // A row's aggregate replaces its u in place (uv[cc][r], cc < 6); ys[r] carries the row's two scalars for the
-      // rank-1 tail: sum alpha in lane 0, sum alpha a_e in lane 13 (the lane that holds the edge length).
-      f32x4 ys;
+      // ================= P2: the sweep of (e, g) over the tile's rows, one node per 16-lane row =================
+      // Two rows per 16-lane group in flight (nodes 8 half + kq and 8 half + 4 + kq): the gathers of both are issued
+      // back to back before either is folded, so a (gate, edge type) pass exposes two memory round trips, not four.
       {
         const float* __restrict__ ep = Sw.edge_params + g * GGNN_EDGE_PARAM_ROWS * C;
         f3 wv[6];
@@ -247,10 +256,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
           // (reloc_e = slots 0..2 of the edge record, i.e. x4 of the row's lanes 0..2: broadcast at fold time, no load
           // and no register of its own; the edge length a_e is slot 13: lane 13 sums alpha a_e)
         };
-        auto open_row = [&](Row& r, int n, const f3 uh0, const f3 uh1, const float u4) __attribute__((always_inline)) {
-          r.uh0 = uh0;
-          r.uh1 = uh1;
-          r.u4 = u4;
+        auto open_row = [&](Row& r, int n) __attribute__((always_inline)) {
+          const float* __restrict__ su = stage + n * DC_S;
+          r.uh0 = {su[ch], su[ch + 1], su[ch + 2]};
+          r.uh1 = {su[CH2 + ch], su[CH2 + ch + 1], su[CH2 + ch + 2]};
+          r.u4 = su[C + lr];
           const int nl = min(row0 + n, n_dst - 1) - row0;   // (n_dst < 16: rows past the end repeat the last node)
           r.p = rp[nl];
           r.pe = rp[nl + 1];
@@ -331,93 +341,77 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
           }
           r.p += GGNN_UNIT_EDGES;
         };
-        // the row's aggregate (over the u it was computed from) and its two scalars; the aggregates are sums of relu
-        // outputs (non-negative): their range check is on the largest
-        auto close_row = [&](const Row& r, float (&out)[6], float& y) __attribute__((always_inline)) {
+        auto close_row = [&](const Row& r, int n) __attribute__((always_inline)) {  // the row's aggregate over the u it was computed from
 #pragma clang fp contract(off)
           const float inv = 1.0f / (r.den + 1e-16f);   // PyG softmax denominator
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) out[cc] = r.acc[cc] * inv;
-          y = lr == 0 ? r.den * inv : (lr == 13 ? r.sae * inv : 0.f);
-          const float amx = fmaxf(fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3])), fmaxf(out[4], out[5]));
-          report_range(!(amx < 65504.0f) || !(r.den == r.den));
+          float* __restrict__ so = stage + n * DC_S;
+          so[ch] = r.acc[0] * inv;
+          so[ch + 1] = r.acc[1] * inv;
+          so[ch + 2] = r.acc[2] * inv;
+          so[CH2 + ch] = r.acc[3] * inv;
+          so[CH2 + ch + 1] = r.acc[4] * inv;
+          so[CH2 + ch + 2] = r.acc[5] * inv;
+          if (lr == 0) so[C] = r.den * inv;
+          if (lr == 13) so[C + 1] = r.sae * inv;
+          const float amx = fmaxf(fmaxf(fmaxf(r.acc[0], r.acc[1]), fmaxf(r.acc[2], r.acc[3])), fmaxf(r.acc[4], r.acc[5])) * inv;
+          report_range(!(amx < 65504.0f));   // (aggregates are sums of relu outputs: non-negative)
         };
         auto sweep = [&](auto window_tag) __attribute__((always_inline)) {
-#pragma unroll
-          for (int r0 = 0; r0 < 4; r0 += DC_ROWS_) {
-            Row rr[DC_ROWS_];
-#pragma unroll
-            for (int q = 0; q < DC_ROWS_; ++q) {
-              const int r = r0 + q;
-              open_row(rr[q], 4 * kq + r, {uv[0][r], uv[1][r], uv[2][r]}, {uv[3][r], uv[4][r], uv[5][r]}, uv[6][r]);
-            }
-            bool more;
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {
+            const int na = 8 * half + kq, nb = na + 4;     // tile rows of this DPP row
+            Row ra, rb;
+            open_row(ra, na);
+            open_row(rb, nb);
             do {
-              Unit un[DC_ROWS_];
-#pragma unroll
-              for (int q = 0; q < DC_ROWS_; ++q) gather(rr[q], un[q], window_tag);
-              more = false;
-#pragma unroll
-              for (int q = 0; q < DC_ROWS_; ++q) {
-                fold(rr[q], un[q]);
-                more |= rr[q].p < rr[q].pe;
-              }
-            } while (__builtin_amdgcn_ballot_w64(more) != 0);
-#pragma unroll
-            for (int q = 0; q < DC_ROWS_; ++q) {
-              const int r = r0 + q;
-              float out[6], y;
-              close_row(rr[q], out, y);
-#pragma unroll
-              for (int cc = 0; cc < 6; ++cc) uv[cc][r] = out[cc];
-              ys[r] = y;
-            }
+              Unit ua, ub;
+              gather(ra, ua, window_tag);
+              gather(rb, ub, window_tag);
+              fold(ra, ua);
+              fold(rb, ub);
+            } while (__builtin_amdgcn_ballot_w64(ra.p < ra.pe || rb.p < rb.pe) != 0);
+            close_row(ra, na);
+            close_row(rb, nb);
           }
         };
         if (in_window) sweep(std::true_type{});
         else sweep(std::false_type{});
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_c = GGNN_STAMP_NOW();
       // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
       {
-        // sweep layout -> matrix layout on the matrix pipe: aT[cc][i] = agg[node lr][channel slot cc of lane 4 kq + i]
-        // D[i][j] += sum_k A[i][k] B[k][j] with A[i = lr][k = kq] = agg of node 4 kq + r in lane lr and
-        // B[k][j] = (j == 4 k + r): exact (one non-zero product per element).
-        f32x4 aT[7];
+        u32x4 xb[2][DC_PL];
+        auto a_planes = [&](int ks, u32x4 (&out)[DC_PL]) __attribute__((always_inline)) {
+          const float* sr = &stage[lr * DC_S + 32 * ks + 8 * kq];
+          dc_split(*reinterpret_cast<const f32x4*>(sr), *reinterpret_cast<const f32x4*>(sr + 4), out);
+        };
+        a_planes(0, xb[0]);
+        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
 #pragma unroll
-        for (int cc = 0; cc < 7; ++cc) aT[cc] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sel = lr == 4 * kq + r ? 1.0f : 0.0f;
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) aT[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[cc][r], sel, aT[cc], 0, 0, 0);
-          aT[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(ys[r], sel, aT[6], 0, 0, 0);
-        }
-        // the exact fp32 tail's weight fragments: requested here, used behind the three slices
+        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
+        // the exact fp32 tail's weight fragments: requested here, used behind the three slices (requested there,
+        // their round trip stood in front of the tail's MFMAs in every phase)
         float wtail[6];
         {
           const float* __restrict__ wt = A.w2_tail + (size_t)((g * n_in + e) * 6) * 64 + lane;
 #pragma unroll
           for (int ct = 0; ct < 6; ++ct) wtail[ct] = wt[ct * 64];
         }
-        u32x4 ab[3][DC_PL];   // lin_l2's B fragments: k-step ks, k slot 8 kq + j = aT[2 ks + (j >> 2)][j & 3]
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) dc_split(aT[2 * ks], aT[2 * ks + 1], ab[ks]);
-        const float xt = kq == 0 ? aT[6][0] : (kq == 3 ? aT[6][1] : 0.f);   // sum alpha | sum alpha a_e of node lr
-        DcAcc part[6];   // this phase's contribution (the fp16 split's cross terms live only here)
-#pragma unroll
-        for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
           const u32x4* pw = begin_slice(ks < 2 ? DC_NP3 : (ei + 1 < n_in ? DC_NP1 : DC_NP3));   // next: P3, the next edge type's P1, or P4
-          dc_kstep<6>(pw, ab[ks], part);
+          dc_kstep<6>(pw, xb[ks & 1], part);
+          if (ks + 1 < 3) a_planes(ks + 1, xb[(ks + 1) & 1]);
           end_slice();
         }
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) pre[ct] += part[ct].value();
+        const float xt = kq < 2 ? stage[lr * DC_S + C + kq] : 0.f;
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) pre[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wtail[ct], xt, pre[ct], 0, 0, 0);
       }
+      __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const unsigned long long t_d = GGNN_STAMP_NOW();
       st_p1 += t_b - t_a;
       st_p2 += t_c - t_b;
@@ -452,7 +446,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     [[maybe_unused]] const unsigned long long t_f = GGNN_STAMP_NOW();
     st_p4 += t_f - t_e;
     // ================= LSTM update, folded in gate by gate (heteropgclstm.py:140-146) =================
-    // (the gate loop is a real loop: the four updates sit behind wave-uniform branches)
+    // (the gate loop is a real loop -- unrolled four times the register allocator gave up --: the four updates sit
+    // behind wave-uniform branches)
     f32x4 (&pv)[6] = pre;
     if (gi == 0) {
 #pragma unroll
@@ -498,19 +493,9 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
   GGNN_STAMP(16);
 }
 
-// (one workgroup per compute unit, DC_WAVES / 4 waves per SIMD)
-#ifndef DC_MINW_
-#define DC_MINW_ 1
-#endif
-#ifndef DC_DELAY_
-#define DC_DELAY_ 0
-#endif
-__global__ __launch_bounds__(DC_WAVES * 64, DC_MINW_) void dec_cell_kernel(const DecCellBatch B) {
+// (155 648 B of LDS: one workgroup per compute unit, two waves per SIMD, <= 256 registers)
+__global__ __launch_bounds__(DC_WAVES * 64, 2) void dec_cell_kernel(const DecCellBatch B) {
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[DC_LDS];
-  if (DC_DELAY_ > 0 && ((blockIdx.x >> 8) & 1)) {   // experiment: the second workgroup of a compute unit starts late
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < DC_DELAY_ * 100ull) __builtin_amdgcn_s_sleep(8);
-  }
   int k = 0;
   while (k + 1 < B.n && (int)blockIdx.x >= B.wg_off[k + 1]) ++k;
   const int nwg = B.wg_off[k + 1] - B.wg_off[k];

@@ -223,36 +223,6 @@ def _plane_slices(W: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# The fused decoder cell's layouts (include/ggnn.h, csrc/dec_cell.hip).  Its sweep runs on a node's 96 channels spread over
-# the 16 lanes of a DPP row -- lane m owns channels 3 m ..+2 and 48 + 3 m ..+2 -- and P1 (tile rows as the A operand)
-# leaves column 16 nb + m of the score block in lane m: so row 16 nb + m of a P1 block is the score row of channel
-# DC_P1_ROW[16 nb + m] (the 16 u4 rows behind stay in place).  The aggregates return to the matrix layout through 0/1
-# selector MFMAs, which leave lane (node, k-group kq) with the channels of lanes 4 kq .. 4 kq + 3: column k = 32 ks + 8 kq + j
-# of a lin_l2 block multiplies aggregate channel DC_P3_COL[k].
-def _dc_channel(m: int, cc: int) -> int:
-    return 3 * m + cc if cc < 3 else 48 + 3 * m + cc - 3
-
-
-DC_P1_ROW = tuple(_dc_channel(i % 16, i // 16) for i in range(C)) + tuple(range(C, C + 16))
-DC_P3_COL = tuple(_dc_channel(4 * ((k % 32) // 8) + k % 4, 2 * (k // 32) + (k % 8) // 4) for k in range(C))
-assert sorted(DC_P1_ROW) == list(range(C + 16)) and sorted(DC_P3_COL) == list(range(C))
-
-
-def dc_p1_slices(W1: torch.Tensor) -> torch.Tensor:
-    """The four P1 slices of a [112, 128] score block [u_h rows 0..95 | u4 rows 96..111] x [h | x | 1 | 0 ..]."""
-    return _plane_slices(W1[torch.tensor(DC_P1_ROW, device=W1.device)].contiguous())
-
-
-def dc_p3_slices(W3: torch.Tensor) -> torch.Tensor:
-    """The three P3 slices of a [96, 96] lin_l2 block (columns = aggregate channels)."""
-    return _plane_slices(W3[:, torch.tensor(DC_P3_COL, device=W3.device)].contiguous())
-
-
-def dc_p4_slices(W4: torch.Tensor) -> torch.Tensor:
-    """The four P4 slices of a [96, 128] skip block."""
-    return _plane_slices(W4)
-
-
 @torch.no_grad()
 def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
     """`ggnn_dec_cell_args.wstream` and `.w2_tail` of one destination node type (include/ggnn.h) from the packed
@@ -274,16 +244,16 @@ def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
         for d, et in dc_edge_order(gi, lay.dst_ets):
             u = slice(lay.u_off[et] + g * C, lay.u_off[et] + (g + 1) * C)
             t = slice(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4)
-            slices.append(dc_p1_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))))    # P1: 4 slices
-            slices.append(dc_p3_slices(w2[g][:, d * C:(d + 1) * C]))                                      # P3: 3 slices
+            slices.append(_plane_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))))   # P1: 4 slices
+            slices.append(_plane_slices(w2[g][:, d * C:(d + 1) * C].contiguous()))                        # P3: 3 slices
         sk = slice(lay.s_off + g * C, lay.s_off + (g + 1) * C)
-        slices.append(dc_p4_slices(block(wp[sk], bp[sk])))                                                 # P4: 4 slices
+        slices.append(_plane_slices(block(wp[sk], bp[sk])))                                                # P4: 4 slices
     stream = torch.cat(slices).contiguous()
     assert stream.size(0) == 4 * (7 * n_in + 4)
     tail = torch.zeros(G, n_in, 6, 4, 16, dtype=torch.float32, device=wp.device)   # g e ct k m   (lane l = 16 k + m)
     for d in range(n_in):
-        for k, slot in enumerate((0, 3)):   # b_l2 meets sum alpha in k-group 0, w_edge meets sum alpha a_e in k-group 3
-            tail[:, d, :, slot, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
+        for k in range(2):
+            tail[:, d, :, k, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
     return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 21
+#define GGNN_ABI_VERSION 20
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -350,15 +350,13 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * rows V (one ggnn_project_batch with the value rows alone) go through memory; the score operands, the
  * aggregates and the gates' pre-activations never leave the compute unit.
  *
- * A workgroup of twelve waves owns 192 consecutive destination nodes, one 16-node tile per wave, and walks the
+ * A workgroup of eight waves owns 128 consecutive destination nodes, one 16-node tile per wave, and walks the
  * gates in the order i, c~, f, o (the LSTM update is folded in as the gates arrive).  Per gate g and incoming
  * edge type e a wave (P1) multiplies its tile's [h | x | 1] rows with the (e, g) score weights -> u_h | u4 of its
- * 16 nodes, left in the registers in the sweep's layout (a node's 96 channels across a 16-lane row), (P2) sweeps the
- * tile's in-edges of that edge type (gathers of h_src and V rows, periodic min-image correction, online-max
- * softmax, relu, alpha-weighted sum: exactly ggnn_period_gat_aggregate's arithmetic), transposes the aggregates back
- * to the matrix layout with exact 0/1 selector products on the matrix cores, (P3) multiplies the 16 x 98 aggregate
- * block with lin_l2 | (b_l2, w_edge) of (e, g) into the gate's pre-activation, then (P4) adds the summed skip term
- * of the gate.  h_out and c_out must not overlap any input of the call (other workgroups still gather h_src rows).  Arithmetic of the three GEMMs: every fp32
+ * 16 nodes, (P2) sweeps the tile's in-edges of that edge type (gathers of h_src and V rows, periodic min-image
+ * correction, online-max softmax, relu, alpha-weighted sum: exactly ggnn_period_gat_aggregate's arithmetic),
+ * (P3) multiplies the 16 x 98 aggregate block with lin_l2 | (b_l2, w_edge) of (e, g) into the gate's
+ * pre-activation, then (P4) adds the summed skip term of the gate.  Arithmetic of the three GEMMs: every fp32
  * operand as TWO fp16 pieces, hi = rne16(x) and lo' = rne16((x - hi) * 2048), and three of the four products
  * (hi hi + (hi lo' + lo' hi) / 2048) accumulated in fp32 on v_mfma_f32_16x16x32_f16: 22 significand bits per
  * operand, against an fp64 product 5e-8 of sum |x||w| (a plain fp32 fma chain: 2e-7); the rank-1 columns
@@ -386,24 +384,18 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  *             (a pass re-gathers the hidden rows and edge records the pass before it gathered while L2 still holds them).
  *             Every slice is GGNN_DC_SLICE_BYTES: [column tile nb][plane hi, lo'][64 lanes][8 fp16] -- the two
  *             fp16 pieces of a weight w are hi = rne16(w) and lo' = rne16((w - hi) * 2048) (finite, |w| < 65504) --
- *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles,
- *             P3 / P4 six (the tail of their slice is unused).  Row 16 nb + m of a P1 block (nb < 6) is the u_h row of
- *             score channel GGNN_DC_P1_CHANNEL(16 nb + m) -- lane m of the sweep owns channels 3 m ..+2 and
- *             48 + 3 m ..+2 -- and rows 96..111 are the u4 rows in place.  The reduction index of P1 / P4 is
- *             [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128; column k of a P3 block multiplies aggregate
- *             channel GGNN_DC_P3_CHANNEL(k).  The kernel splits its own operands the same way (OPERAND RANGE above).
+ *             lane l = 16 kq + m of (nb, plane) holds W[16 nb + m][32 ks + 8 kq .. + 7]; P1 has 7 column tiles
+ *             (u_h 0..95 | u4 96..111), P3 / P4 six (the tail of their slice is unused).  The reduction index
+ *             of P1 / P4 is [h 0..95 | x 0..f_dst-1 | 1 (bias) | 0 ..] padded to 128, of P3 the 96 aggregate channels.
+ *             The kernel splits its own operands the same way (OPERAND RANGE above).
  *   w2_tail : [4][n_in][6][64] fp32: (b_l2, w_edge) of (g, e) as v_mfma_f32_16x16x4_f32 A fragments
- *             ([ct][l]: k = l >> 4; k = 0 -> b_l2[16 ct + (l & 15)], k = 3 -> w_edge[16 ct + (l & 15)], else 0)
+ *             ([ct][l] = k < 2 ? tail[16 ct + (l & 15)][k = l >> 4] : 0)
  *   flags   : optional int32 device word, see OPERAND RANGE
  * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
 #define GGNN_PRECISION_BF16 1
 #define GGNN_DC_SLICE_BYTES 14336 /* 7 column tiles x 2 planes x 1 KB */
-#define GGNN_FLAG_F16_RANGE 1     /* an activation at or beyond +-65504 (or not a number) met a two-piece fp16 split */
-/* score channel of row i < 96 of a P1 block | aggregate channel of column k of a P3 block (packing.DC_P1_ROW, DC_P3_COL) */
-#define GGNN_DC_LANE_CHANNEL(m, cc) ((cc) < 3 ? 3 * (m) + (cc) : 48 + 3 * (m) + (cc) - 3)
-#define GGNN_DC_P1_CHANNEL(i) GGNN_DC_LANE_CHANNEL((i) % 16, (i) / 16)
-#define GGNN_DC_P3_CHANNEL(k) GGNN_DC_LANE_CHANNEL(4 * (((k) % 32) / 8) + (k) % 4, 2 * ((k) / 32) + ((k) % 8) / 4)
+#define GGNN_FLAG_F16_RANGE 1     /* an activation at or beyond +-65504 was clamped in a two-piece fp16 split */
 typedef struct ggnn_dec_cell_sweep {
   const int32_t* rowptr;     /* [n_dst + 1] */
   const int32_t* col;        /* [E] source node of every edge, CSR order */

@@ -243,11 +243,8 @@ class TorchEmulatorBackend:
                 z = torch.zeros(n, C)
                 order = list(enumerate(sweeps))
                 for d, (csr, einfo, h_src, v_src, v_off, ep) in (order[::-1] if gi & 1 else order):   # ggnn.h: backwards for the 2nd and 4th gate
-                    from graingraphnn_amd.packing import DC_P1_ROW, DC_P3_COL
-                    W1 = torch.empty(112, 128)
-                    W1[list(DC_P1_ROW)] = self._decode_slices(wstream, s, 4, 7)        # rows in the sweep's lane order (ggnn.h)
-                    W3 = torch.empty(C, C)
-                    W3[:, list(DC_P3_COL)] = self._decode_slices(wstream, s + 4, 3, 6)  # columns in the transposed aggregates' order
+                    W1 = self._decode_slices(wstream, s, 4, 7)        # [112, 128]
+                    W3 = self._decode_slices(wstream, s + 4, 3, 6)    # [96, 96]
                     s += 7
                     assert not bool(W1[:, C + F + 1:].any())
                     u = xin @ W1.t()                                   # [n, 112]: u_h | u4
@@ -266,8 +263,8 @@ class TorchEmulatorBackend:
                     sa = torch.zeros(n).index_add(0, dst, alpha)
                     sae = torch.zeros(n).index_add(0, dst, alpha * a)
                     tail = w2_tail[g, d].view(6, 4, 16)                # ct k m
-                    assert not bool(tail[:, 1:3].any())
-                    z = z + A @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 3].reshape(1, C)
+                    assert not bool(tail[:, 2:].any())
+                    z = z + A @ W3.t() + sa[:, None] * tail[:, 0].reshape(1, C) + sae[:, None] * tail[:, 1].reshape(1, C)
                 W4 = self._decode_slices(wstream, s, 4, 6)             # [96, 128]
                 s += 4
                 pre[g] = z + xin @ W4.t()

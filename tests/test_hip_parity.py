@@ -1328,8 +1328,7 @@ def test_fused_cells_are_fp32_equivalent_on_wide_range_operands(kind):
 def _rebuild_wide_call(be, kind, P):
     """(call tuple, P): the operands and ORIGINAL weights of `P` in the kernels' weight-stream image; again after an
     in-place edit of the weights."""
-    from graingraphnn_amd.packing import (CELL_P3_CHANNEL, DC_GATE_ORDER, _plane_slices, _spread16, dc_p1_slices,
-                                          dc_p3_slices, dc_p4_slices)
+    from graingraphnn_amd.packing import CELL_P3_CHANNEL, DC_GATE_ORDER, _plane_slices, _spread16
     G = 4 if kind == "dec" else 3
     n_dst, F_dst = P["x_dst"].shape
     n_in = len(P["sweeps"])
@@ -1350,17 +1349,17 @@ def _rebuild_wide_call(be, kind, P):
     for gi, g in enumerate(DC_GATE_ORDER if kind == "dec" else range(3)):
         for sw in (P["sweeps"][::-1] if kind == "dec" and gi & 1 else P["sweeps"]):   # decoder: backwards for the 2nd / 4th gate
             if kind == "dec":
-                slices += [dc_p1_slices(in128(sw["score"][g])), dc_p3_slices(sw["l2"][g])]
+                slices += [_plane_slices(in128(sw["score"][g])), _plane_slices(sw["l2"][g])]
             else:
                 slices += [_plane_slices(_spread16(torch.cat([sw["value"][g], slots16(sw["score"][g])]))),
                            _plane_slices(sw["l2"][g][:, p3].contiguous())]
-        slices.append(dc_p4_slices(in128(P["skip"][g])) if kind == "dec" else _plane_slices(_spread16(slots16(P["skip"][g]))))
+        slices.append(_plane_slices(in128(P["skip"][g]) if kind == "dec" else _spread16(slots16(P["skip"][g]))))
     wstream = torch.cat(slices).contiguous().view(-1)
     tail = torch.zeros(G, n_in, 6, 4, 16, device=DEV)
     for d, sw in enumerate(P["sweeps"]):
         for g in range(G):
             tail[g, d, :, 0] = sw["b_l2"][g].view(6, 16)
-            tail[g, d, :, 3] = sw["w_edge"][g].view(6, 16)
+            tail[g, d, :, 1 if kind == "dec" else 3] = sw["w_edge"][g].view(6, 16)
     tail = tail.view(G, n_in, 6, 64).contiguous()
     out = [torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV)]
     if kind == "dec":
@@ -1393,7 +1392,7 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
     """Random decoder-cell problem (ggnn_decoder_cell_batch): destination type with `F_dst` features, `ins` =
     [(n_src, F_src, E)] incoming edge types, random weight blocks packed by packing._plane_slices in the stream's
     order.  Returns the fused-call tuple."""
-    from graingraphnn_amd.packing import DC_GATE_ORDER, dc_p1_slices, dc_p3_slices, dc_p4_slices
+    from graingraphnn_amd.packing import DC_GATE_ORDER, _plane_slices
     n_in = len(ins)
     f = lambda *shape, lo=-1.0, hi=1.0: torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32)).to(DEV)
     xd, h_dst, c_in = f(n_dst, F_dst, lo=0.0), f(n_dst, 96), f(n_dst, 96)
@@ -1403,13 +1402,13 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
             W1 = f(112, 128, lo=-0.15, hi=0.15)
             W1[:, 96 + F_dst + 1:] = 0                       # reduction index: h | x | 1 | zeros
             W1[96 + 14:, :] = 0                              # tail slots 14, 15 of u4 are always zero
-            slices += [dc_p1_slices(W1), dc_p3_slices(f(96, 96, lo=-0.2, hi=0.2))]
+            slices += [_plane_slices(W1), _plane_slices(f(96, 96, lo=-0.2, hi=0.2))]
         W4 = f(96, 128, lo=-0.15, hi=0.15)
         W4[:, 96 + F_dst + 1:] = 0
-        slices.append(dc_p4_slices(W4))
+        slices.append(_plane_slices(W4))
     wstream = torch.cat(slices).contiguous().view(-1)
     tail = torch.zeros(4, n_in, 6, 4, 16, device=DEV)
-    tail[:, :, :, (0, 3)] = f(4, n_in, 6, 2, 16, lo=-0.2, hi=0.2)   # k-group 0: b_l2, k-group 3: w_edge
+    tail[:, :, :, :2] = f(4, n_in, 6, 2, 16, lo=-0.2, hi=0.2)
     sweeps = []
     for d, (n_src, F, E) in enumerate(ins):
         src = rs.randint(0, max(n_src - 5, 1), size=E)
