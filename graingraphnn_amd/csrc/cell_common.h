@@ -18,14 +18,21 @@ __device__ __forceinline__ void dc_dma16(const void* gsrc, uint32_t lds_base) {
                : "memory");
 }
 
+// Range tracking of what goes through a split (range flag, ggnn.h): the largest |x| AS A BIT PATTERN -- for non-negative
+// floats the unsigned order of the bits is the order of the values, with +inf above every finite value and every NaN
+// above +inf (an fp max would drop a NaN) -- so one v_max3_u32 per pair keeps a non-finite operand visible.
+constexpr uint32_t DC_RANGE_LIMIT = 0x477FE000u;   // bits of 65504.0f: in range <=> tracked < limit
+__device__ __forceinline__ void dc_track(uint32_t& amax, float a, float b) {
+  amax = max(amax, max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu));
+}
 // eight fp32 values (r0 | r1) -> the two fp16 planes of an MFMA operand fragment; `amax` follows the largest
-// magnitude that went through a split (range flag, ggnn.h)
-__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[DC_PL], float& amax) {
+// magnitude that went through a split (dc_track)
+__device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (&xb)[DC_PL], uint32_t& amax) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const f32x4 h = e < 2 ? r0 : r1;
     const float a = h[2 * (e & 1)], b = h[2 * (e & 1) + 1];
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+    dc_track(amax, a, b);
     uint32_t q0, q1;
     split_f16x2(a, b, q0, q1);
     xb[0][e] = q0;
@@ -44,11 +51,11 @@ __device__ __forceinline__ void dc_split(const f32x4 r0, const f32x4 r1, u32x4 (
   }
 }
 // four fp32 values in k slots 0..3 of a fragment, zeros in slots 4..7
-__device__ __forceinline__ void dc_split_half(const f32x4 r0, u32x4 (&xb)[DC_PL], float& amax) {
+__device__ __forceinline__ void dc_split_half(const f32x4 r0, u32x4 (&xb)[DC_PL], uint32_t& amax) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const float a = r0[2 * e], b = r0[2 * e + 1];
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+    dc_track(amax, a, b);
     uint32_t q0, q1;
     split_f16x2(a, b, q0, q1);
     xb[0][e] = q0;

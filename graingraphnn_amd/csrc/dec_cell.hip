@@ -140,7 +140,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
     }
   };
   {
-    float in_max = 0.f;
+    uint32_t in_max = 0u;   // (dc_track: as bits, so that a NaN or an inf in the tile's rows is reported)
     const float* hrow = A.h_dst + (int64_t)min(row0 + lr, n_dst - 1) * A.ldh + 8 * kq;
     f32x4 hv[3][2];
 #pragma unroll
@@ -160,10 +160,8 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const f32x4 r0 = ks < 3 ? hv[ks][0] : xv[0], r1 = ks < 3 ? hv[ks][1] : xv[1];
-      in_max = fmaxf(fmaxf(in_max, fmaxf(fmaxf(__builtin_fabsf(r0[0]), __builtin_fabsf(r0[1])), fmaxf(__builtin_fabsf(r0[2]), __builtin_fabsf(r0[3])))),
-                     fmaxf(fmaxf(__builtin_fabsf(r1[0]), __builtin_fabsf(r1[1])), fmaxf(__builtin_fabsf(r1[2]), __builtin_fabsf(r1[3]))));
       u32x4 pl[DC_PL];
-      dc_split(r0, r1, pl);
+      dc_split(r0, r1, pl, in_max);
       if (ks < 3) {
 #pragma unroll
         for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + (ks * DC_PL + p) * 1024) = pl[p];
@@ -172,7 +170,7 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         for (int p = 0; p < DC_PL; ++p) *reinterpret_cast<u32x4*>(xpl + 3 * DC_PL * 1024 + p * 512) = pl[p];
       }
     }
-    report_range(!(in_max < 65504.0f));
+    report_range(in_max >= DC_RANGE_LIMIT);
     for (int e = 0; e < n_in; ++e) {
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       int* __restrict__ rp = csr + e * (17 + DC_CW);
@@ -345,16 +343,22 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma clang fp contract(off)
           const float inv = 1.0f / (r.den + 1e-16f);   // PyG softmax denominator
           float* __restrict__ so = stage + n * DC_S;
-          so[ch] = r.acc[0] * inv;
-          so[ch + 1] = r.acc[1] * inv;
-          so[ch + 2] = r.acc[2] * inv;
-          so[CH2 + ch] = r.acc[3] * inv;
-          so[CH2 + ch + 1] = r.acc[4] * inv;
-          so[CH2 + ch + 2] = r.acc[5] * inv;
+          float o[6];
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc) o[cc] = r.acc[cc] * inv;
+          so[ch] = o[0];
+          so[ch + 1] = o[1];
+          so[ch + 2] = o[2];
+          so[CH2 + ch] = o[3];
+          so[CH2 + ch + 1] = o[4];
+          so[CH2 + ch + 2] = o[5];
           if (lr == 0) so[C] = r.den * inv;
           if (lr == 13) so[C + 1] = r.sae * inv;
-          const float amx = fmaxf(fmaxf(fmaxf(r.acc[0], r.acc[1]), fmaxf(r.acc[2], r.acc[3])), fmaxf(r.acc[4], r.acc[5])) * inv;
-          report_range(!(amx < 65504.0f));   // (aggregates are sums of relu outputs: non-negative)
+          uint32_t amx = 0u;   // (aggregates are sums of relu outputs; a NaN among the gathered operands ends up here)
+          dc_track(amx, o[0], o[1]);
+          dc_track(amx, o[2], o[3]);
+          dc_track(amx, o[4], o[5]);
+          report_range(amx >= DC_RANGE_LIMIT);
         };
         auto sweep = [&](auto window_tag) __attribute__((always_inline)) {
 #pragma unroll 1

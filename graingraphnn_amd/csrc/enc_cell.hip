@@ -108,7 +108,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   };
   dma_group(0);
 
-  float amax = 0.f;   // largest magnitude this lane has split into fp16 pieces (range flag)
+  uint32_t amax = 0u;   // largest magnitude this lane has split into fp16 pieces, as bits (dc_track: NaN and inf stay visible)
 
   // ---- tile prologue: this node's feature slots and the records of its first in-edges, as B-fragment planes ----
   // slots of a feature row: x_0 .. x_{F-1}, 0 .., 1 at 12 (bias), 0 ..; of an edge record: ggnn_edge_prepare's
@@ -328,7 +328,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     st_lstm += GGNN_STAMP_NOW() - t_f;
   }
   // range flag: an operand at or beyond fp16's range was clamped somewhere in this tile
-  if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(!(amax < 65504.0f)) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
+  if (A.flags != nullptr && __builtin_amdgcn_ballot_w64(amax >= DC_RANGE_LIMIT) != 0 && lane == 0) atomicOr(A.flags, GGNN_FLAG_F16_RANGE);
   GGNN_STAMP_VAL(4, st_wait);
   GGNN_STAMP_VAL(5, st_a);
   GGNN_STAMP_VAL(7, st_p3);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
   };
   dma_group(0);
   load_rows(0, rows[0]);
-  float unused_amax = 0.f;
+  uint32_t unused_amax = 0u;
 
   int q = 0;
   for (int b = 0; b < A.batch; ++b) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_resident_kernel(const g
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // W[b] is in LDS; from here on the waves run free
   const u32x4* pw = reinterpret_cast<const u32x4*>(smem) + lane;
-  float unused_amax = 0.f;
+  uint32_t unused_amax = 0u;
   auto run_tile = [&](f32x4 (&cur)[NKSM][2], f32x4 (&nxt)[NKSM][2]) __attribute__((always_inline)) {
     load_rows(t + stride, nxt);
     const int64_t row = tile_row(t);

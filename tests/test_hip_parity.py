@@ -1386,6 +1386,18 @@ def test_fused_cells_report_an_activation_beyond_fp16_range(kind):
     assert be.range_exceeded(DEV)              # reported (and cleared by the read)
     assert not be.range_exceeded(DEV)
     assert bool(torch.isfinite(call[-2]).all())   # clamped, not poisoned
+    # a NaN is not "in range" either (an fp max would drop it: the kernels track magnitudes as bit patterns)
+    P["x_dst"][17, 5] = float("nan")
+    run([call])
+    assert be.range_exceeded(DEV)
+    P["x_dst"][17, 5] = 0.5
+    run([call])
+    assert not be.range_exceeded(DEV)
+    if kind == "dec":                           # ... nor is one among the gathered hidden rows (it reaches the aggregates)
+        src = int(P["sweeps"][0]["col"][5])
+        P["sweeps"][0]["h_src"][src, 40] = float("inf")
+        run([call])
+        assert be.range_exceeded(DEV)
 
 
 def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
