@@ -13,13 +13,14 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 20
+GGNN_ABI_VERSION = 21
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
 GGNN_EDGE_PARAM_ROWS = 3
 GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
+GGNN_PRECISION_F16X2 = 2
 GGNN_FLAG_F16_RANGE = 1
 GGNN_ADAM_CHUNK, GGNN_ADAM_MAX_TENSORS, GGNN_ADAM_MAX_GROUPS = 4096, 384, 8
 GGNN_ROWGEMM_MAX_PACK = 8

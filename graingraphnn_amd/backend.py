@@ -56,6 +56,11 @@ class HipBackend:
         if self.lib.ggnn_gemm_mode() == 1 and dec.startswith("fused"):
             self.fused_decoder = {"fused": True, "fused-classifier": "classifier", "fused-regressor": "regressor"}.get(dec, False)
 
+    def f16_projection(self) -> bool:
+        """The fused decoder plan's value projection in the cells' three-product arithmetic (GGNN_PRECISION_F16X2) when the
+        packed weights allow; GGNN_PROJ=x6 keeps the six-product split (development, A/B runs)."""
+        return os.environ.get("GGNN_PROJ", "") != "x6"
+
     # -- launch tape: the drop-in forward() issues the same dozen launches with the same arguments
     # step after step (test.py:382-383); re-issuing the recorded C calls skips the per-launch
     # Python work (argument checks, ctypes struct filling), which otherwise outweighs the kernels.

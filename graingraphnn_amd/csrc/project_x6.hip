@@ -32,7 +32,12 @@ struct ProjectX6Lds {
 };
 
 // NPROD = 6: the exact split (fp32-equivalent); NPROD = 1 (GGNN_PRECISION_BF16): only the leading bf16 piece of both
-// operands, one product per k-step -- bf16 arithmetic with fp32 accumulation, as autocast defines a linear.
+// operands, one product per k-step -- bf16 arithmetic with fp32 accumulation, as autocast defines a linear;
+// NPROD = 3 (GGNN_PRECISION_F16X2): the fused cells' arithmetic -- two fp16 pieces per operand, hi hi into the main
+// accumulator, hi lo' + lo' hi into a cross accumulator folded in with 2^-11 behind the four k-steps (common.h):
+// 5e-8 of sum |x||w| against an fp64 product for operands below 65504, at half the matrix-pipe cycles of the six-product
+// split.  At the chip's clock under this load (~1.55 GHz) the six-product sweep is 17.6 us of matrix pipe per model at the
+// 10k-grain graph, which is what kept the kernel at 26 us; with three products its 61.7 MB of stores are the bound.
 template <int FP, int NPROD>
 __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int blk, int m_splits, ProjectX6Lds& L) {
   constexpr int KP = FP + 96;  // row length of Wp: [X(FP) | H(96)]
@@ -65,12 +70,13 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
       a = w[0];
       b = w[1];
     }
-    uint32_t p0, p1, p2;
-    split_bf16x3(a, b, p0, p1, p2);
+    uint32_t p0, p1, p2 = 0u;
+    if constexpr (NPROD == 3) split_f16x2(a, b, p0, p1);
+    else split_bf16x3(a, b, p0, p1, p2);
     const int slot = (kp >> 2) ^ (r & 15), d = kp & 3;
     reinterpret_cast<uint32_t*>(&s_w[0][r][slot])[d] = p0;
     reinterpret_cast<uint32_t*>(&s_w[1][r][slot])[d] = p1;
-    reinterpret_cast<uint32_t*>(&s_w[2][r][slot])[d] = p2;
+    if constexpr (NPROD != 3) reinterpret_cast<uint32_t*>(&s_w[2][r][slot])[d] = p2;
   }
   if (tid < PX_BN / 4) s_b[tid] = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * tid);
   if (tid == 0) s_next = PX_WAVES;
@@ -144,8 +150,9 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
       if (ks == 3 && kq >= 2) v[0] = v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        uint32_t p0, p1, p2;
-        split_bf16x3(v[d >> 1][2 * (d & 1)], v[d >> 1][2 * (d & 1) + 1], p0, p1, p2);
+        uint32_t p0, p1, p2 = 0u;
+        if constexpr (NPROD == 3) split_f16x2(v[d >> 1][2 * (d & 1)], v[d >> 1][2 * (d & 1) + 1], p0, p1);
+        else split_bf16x3(v[d >> 1][2 * (d & 1)], v[d >> 1][2 * (d & 1) + 1], p0, p1, p2);
         xb[ks][0][d] = p0;
         xb[ks][1][d] = p1;
         xb[ks][2][d] = p2;
@@ -181,10 +188,12 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
     // no store predicate: see "Addressing" above
     float* orow = out + min(mt * PX_BM, m_last) * ldo + oo;
     constexpr int NSTEP = (PX_BN / 16) * PX_KS;
+    constexpr int NPL = NPROD == 3 ? 2 : 3;   // operand planes in use
     u32x4 wf[2][3];
     f32x4 acc = s_b[kq];
+    [[maybe_unused]] f32x4 cross = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wf[0][p] = pw[p * PX_BN * 16 + (kq ^ lr)];
+    for (int p = 0; p < NPL; ++p) wf[0][p] = pw[p * PX_BN * 16 + (kq ^ lr)];
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int ct = st / PX_KS, ks = st % PX_KS, cur = st & 1, nxt = cur ^ 1;
@@ -192,7 +201,7 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
       if (st + 1 < NSTEP) {
         const int ct1 = (st + 1) / PX_KS, ks1 = (st + 1) % PX_KS;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
           wf[nxt][p] = pw[(p * PX_BN + ct1 * 16) * 16 + ((4 * ks1 + kq) ^ lr)];
         if (ks1 == 0) acc_next = s_b[ct1 * 4 + kq];
       }
@@ -205,10 +214,23 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      } else if constexpr (NPROD == 3) {
+        cross = mfma_f16(wf[cur][0], xb[ks][1], cross);
+        cross = mfma_f16(wf[cur][1], xb[ks][0], cross);
+        acc = mfma_f16(wf[cur][0], xb[ks][0], acc);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       } else {
         acc = mfma_bf16(wf[cur][0], xb[ks][0], acc);
       }
       if (ks == PX_KS - 1) {
+        if constexpr (NPROD == 3) {
+          acc += cross * (1.0f / F16X2_SCALE);
+          cross = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         *reinterpret_cast<f32x4*>(orow + ct * 16) = acc;
         acc = acc_next;
       }
@@ -229,6 +251,12 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(const Proj
   // (xcd_remap) they run side by side behind ONE L2, which then reads their node rows from memory once instead of once
   // per column tile (speed only).
   const int blk = xcd_remap((int)blockIdx.x - B.wg_off[k], B.wg_off[k + 1] - B.wg_off[k]), Fp = (A.F + 3) & ~3;
+  if (A.precision == GGNN_PRECISION_F16X2) {
+    if (Fp == 4) project_x6_body<4, 3>(A, blk, B.m_splits[k], lds);
+    else if (Fp == 8) project_x6_body<8, 3>(A, blk, B.m_splits[k], lds);
+    else project_x6_body<12, 3>(A, blk, B.m_splits[k], lds);
+    return;
+  }
   if (A.precision == GGNN_PRECISION_BF16) {
     if (Fp == 4) project_x6_body<4, 1>(A, blk, B.m_splits[k], lds);
     else if (Fp == 8) project_x6_body<8, 1>(A, blk, B.m_splits[k], lds);

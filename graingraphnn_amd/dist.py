@@ -52,17 +52,74 @@ def unpack_state(buf: torch.Tensor, keys, sizes, like: Dict[str, torch.Tensor]) 
     return d
 
 
+class StateGather:
+    """The packed all-gather of a fixed state layout with every buffer allocated ONCE: the send buffer the state is
+    packed into, one flat receive buffer of world x n bytes (`all_gather_into_tensor`: one collective, one output) and
+    the per-rank result dicts as VIEWS of it (host-staged backends: one pinned host copy each way).  gather_states
+    keeps one per layout, so a rollout loop that gathers every few steps allocates nothing inside its timed region."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], world: int):
+        self.world = world
+        self.keys = sorted(state)
+        self.like = {k: (state[k].dtype, tuple(state[k].shape), state[k].device) for k in self.keys}
+        self.sizes = [state[k].numel() * state[k].element_size() for k in self.keys]
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += n + (-n % 16)   # every segment 16-byte aligned: viewable as its own dtype
+        self.nbytes = off
+        dev = state[self.keys[0]].device
+        self.host = dist.get_backend() == "gloo"   # RCCL ('nccl') moves device buffers; gloo needs host buffers
+        self.send = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.empty(world * self.nbytes, dtype=torch.uint8, device=dev)
+        if self.host:
+            pin = dev.type == "cuda"
+            self.send_h = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=pin)
+            self.recv_h = torch.empty(world * self.nbytes, dtype=torch.uint8, pin_memory=pin)
+        self.out = [{k: self.recv[r * self.nbytes + o: r * self.nbytes + o + n].view(self.like[k][0]).view(self.like[k][1])
+                     for k, o, n in zip(self.keys, self.offsets, self.sizes)} for r in range(world)]
+
+    def matches(self, state, world) -> bool:
+        return (world == self.world and sorted(state) == self.keys and
+                all((state[k].dtype, tuple(state[k].shape), state[k].device) == self.like[k] for k in self.keys))
+
+    def __call__(self, state):
+        for k, o, n in zip(self.keys, self.offsets, self.sizes):
+            self.send[o:o + n].view(self.like[k][0]).view(self.like[k][1]).copy_(state[k])
+        if self.host:
+            self.send_h.copy_(self.send)
+            _all_gather_flat(self.recv_h, self.send_h, self.world)
+            self.recv.copy_(self.recv_h)
+        else:
+            _all_gather_flat(self.recv, self.send, self.world)
+        return self.out
+
+
+def _all_gather_flat(recv: torch.Tensor, send: torch.Tensor, world: int):
+    try:
+        dist.all_gather_into_tensor(recv, send)
+    except (RuntimeError, NotImplementedError):   # a backend without the flat form: the list form on views of `recv`
+        dist.all_gather([recv[r * send.numel():(r + 1) * send.numel()] for r in range(world)], send)
+
+
+_gatherers: List[StateGather] = []
+
+
 def gather_states(state: Dict[str, torch.Tensor], world: int) -> List[Dict[str, torch.Tensor]]:
     """All-gather a dict of tensors whose shapes and dtypes agree across ranks; returns one dict per
     rank (rank order).  ONE collective whatever the number of keys: the tensors travel as one packed
-    byte buffer (a collective per key would pay the launch + ring latency of a small message each)."""
+    byte buffer (a collective per key would pay the launch + ring latency of a small message each).
+    The buffers of a layout are allocated at its first gather (StateGather) and reused: the returned
+    tensors are views of the receive buffer, valid until the next gather of the same layout."""
     if world <= 1 or not dist.is_initialized():
         return [state]
-    packed, keys, sizes = pack_state(state)
-    packed = _staging(packed)
-    bufs = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(bufs, packed)
-    return [unpack_state(bufs[r], keys, sizes, state) for r in range(world)]
+    for g in _gatherers:
+        if g.matches(state, world):
+            return g(state)
+    g = StateGather(state, world)
+    _gatherers.append(g)
+    del _gatherers[:-8]   # (a handful of layouts per process; old ones go)
+    return g(state)
 
 
 def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, world: int,

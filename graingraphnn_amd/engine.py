@@ -134,7 +134,8 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
             # emits the source-side value rows
             for nt in NODE_TYPES:
                 if nt in pc.wpv:
-                    projs.append((x[nt], lay[nt].F, h_in[nt], pc.wpv[nt], pc.bpv[nt], proj[nt][:, :pc.wpv[nt].size(0)]))
+                    projs.append((x[nt], lay[nt].F, h_in[nt], pc.wpv[nt], pc.bpv[nt], proj[nt][:, :pc.wpv[nt].size(0)],
+                                  _lib.GGNN_PRECISION_F16X2 if pc.wpv_f16 and backend.f16_projection() else 0))
             for nt in NODE_TYPES:
                 if lay[nt].live:
                     dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])

@@ -123,6 +123,7 @@ class PackedCell:
     wvf: Dict[Tuple[str, str, str], torch.Tensor] = field(default_factory=dict)  # encoder: edge type -> value_fragments
     # decoder, fused cell (ggnn_decoder_cell_batch): the projection only emits the source-side value rows ...
     wpv: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> [96 G n_src_ets, Kp] value rows of wp
+    wpv_f16: bool = False   # the value rows fit the two-piece fp16 arithmetic (finite, below 65504): GGNN_PRECISION_F16X2
     bpv: Dict[str, torch.Tensor] = field(default_factory=dict)
     vof: Dict[Tuple[str, str, str], int] = field(default_factory=dict)  # edge type -> value column in that projection
     # ... and everything on the destination side streams past the tiles as fp16 planes
@@ -497,8 +498,10 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
                     dcs[nt], dct[nt] = decoder_cell_stream(wp[nt], bp[nt], w2[nt], layout[nt])
         except ValueError:   # a weight that is not finite or beyond fp16's range: the cell runs on the three-kernel
             dcs, dct = {}, {}   # plan (projection + sweeps + gate GEMM, bf16 x 3: the full fp32 range, NaNs propagate)
+    # the value projection of the fused plan runs in the cells' arithmetic (three products) when its weights allow
+    wpv_f16 = bool(dcs) and all(bool(torch.isfinite(w).all()) and float(w.abs().max()) < 65504.0 for w in wpv.values())
     return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, ecs=ecs, ect=ect,
-                      wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct)
+                      wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct, wpv_f16=wpv_f16)
 
 
 @torch.no_grad()

@@ -437,7 +437,9 @@ class GrainRollout:
         self.steps_done += 1
         return self.pred
 
-    RUN_UNROLL = 4  # steps per graph in run(): one graph-to-graph boundary (~10 us on the GPU) per 4 steps
+    # steps per graph in run(): a graph-to-graph boundary costs ~10 us on the GPU (cfg3, 500 steps: 4 steps per graph 2 867
+    # steps/s, 10 steps per graph 2 897); bench.py measures with this default
+    RUN_UNROLL = 10
 
     def run(self, n_steps: int):
         """`n_steps` static-topology steps.  With hipGraph replay the bulk goes through a graph of

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 20
+#define GGNN_ABI_VERSION 21
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -132,7 +132,11 @@ typedef struct ggnn_project_args {
   float* out;
   int64_t ldx, ldh, M, ldo;
   int32_t F, k2, ncols;
-  int32_t precision; /* 0: fp32-equivalent (exact 3-piece bf16 split, 6 products per k-step; the inference path);
+  int32_t precision; /* 0: fp32-equivalent over fp32's whole range (exact 3-piece bf16 split, 6 products per k-step);
+                        GGNN_PRECISION_F16X2 (k2 == 96 only): fp32-equivalent for |x|, |h|, |w| < 65504 -- the fused
+                        cells' arithmetic, two fp16 pieces per operand and THREE products per k-step (operands beyond
+                        the range are clamped: the caller checks its weights, packing.pack_cell; the node rows are the
+                        ones ggnn_decoder_cell_batch checks and reports) -- the value rows of the fused decoder plan;
                         GGNN_PRECISION_BF16 (k2 == 96 only): operands rounded to bf16, ONE bf16 MFMA product per
                         k-step, fp32 accumulate -- what torch.autocast(bfloat16) asks of a linear (training path) */
 } ggnn_project_args;
@@ -394,6 +398,7 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * Gates are indexed i, f, c, o (GGNN_MODE_LSTM's order) in wstream's g, w2_tail, edge_params and the V columns.
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
 #define GGNN_PRECISION_BF16 1
+#define GGNN_PRECISION_F16X2 2
 #define GGNN_DC_SLICE_BYTES 14336 /* 7 column tiles x 2 planes x 1 KB */
 #define GGNN_FLAG_F16_RANGE 1     /* an activation at or beyond +-65504 was clamped in a two-piece fp16 split */
 typedef struct ggnn_dec_cell_sweep {

@@ -354,6 +354,10 @@ class TorchEmulatorBackend:
             o3[b][:, :n_out] = res
         return out
 
+    @staticmethod
+    def f16_projection():
+        return True   # (GGNN_PRECISION_F16X2 is fp32-equivalent: the emulation computes it in fp32)
+
     def project_batch(self, problems):
         """(x, F, h, wp, bp, out[, precision]); precision GGNN_PRECISION_BF16: both operands rounded to bf16, products
         accumulated in fp32 (what the HIP kernel's single-product mode computes)."""

@@ -6,8 +6,10 @@ them; dist_train.py:76-93's pattern): init_process_group(backend, device_id=...)
      -- rank 0 also rolls all 8 out alone and the gathered result must equal it bit for bit,
   3. DistributedDataParallel(model, device_ids=[dev]) on rank-specific mini-batches: the gradients must be the mean of
      the two ranks' local gradients (each computed here without DDP, exchanged with an all-gather).
-    python rccl_worker2.py PORT RANK BACKEND N_DEVICES
-BACKEND 'nccl' (RCCL; needs one GPU per rank: N_DEVICES >= 2) or 'gloo' (both ranks on cuda:0 -- the same code with host
+  4. BASELINE config 4 AS STATED: 64 perturbed trajectories, trajectory t on rank t mod WORLD (8 per rank on an 8-GPU
+     node), gathered result == rank 0 rolling all 64 out alone, bit for bit.
+    python rccl_worker2.py PORT RANK BACKEND N_DEVICES [WORLD = 2]
+BACKEND 'nccl' (RCCL; needs one GPU per rank: N_DEVICES >= WORLD) or 'gloo' (all ranks on cuda:0 -- the same code with host
 staging of the collectives: validates this file on a one-GPU box).  Prints 'RANK<r>_OK' on success."""
 import os
 import sys
@@ -30,7 +32,9 @@ WORLD = 2
 
 
 def main():
+    global WORLD
     port, rank, backend, n_dev = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    WORLD = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     dev = torch.device("cuda", rank % n_dev)
     torch.cuda.set_device(dev)
     torch.set_num_threads(1)
@@ -57,6 +61,14 @@ def main():
             for k in alone:
                 assert sharded[k].shape == alone[k].shape and torch.equal(sharded[k], alone[k]), k
         dist.barrier()
+        # 4. config 4 as stated: 64 trajectories, t -> rank t mod WORLD
+        graphs = [(synthetic.perturbed_copy(x0, 1e-3, 1000 + t), ei0, ea0) for t in range(64)]
+        sharded = rollout_trajectories(R, Cm, graphs, span=6, n_steps=3, rank=rank, world=WORLD, device=dev)
+        if rank == 0:
+            alone = rollout_trajectories(R, Cm, graphs, span=6, n_steps=3, rank=0, world=1, device=dev)
+            for k in alone:
+                assert sharded[k].shape[0] == 64 and torch.equal(sharded[k], alone[k]), k
+        dist.barrier()
         # 3. DDP: gradients = mean over the ranks of the local gradients
         x, ei, ea, _ = synthetic.disjoint_union(
             [(synthetic.perturbed_copy(x0, 1e-3, 2000 + 4 * rank + t), ei0, ea0) for t in range(4)])
@@ -75,7 +87,7 @@ def main():
         torch.cuda.synchronize()
         both = gather_states(local, WORLD)
         for n, p in Rt.named_parameters():
-            mean = (both[0][n] + both[1][n]) / 2
+            mean = sum(both[r][n] for r in range(WORLD)) / WORLD
             tol = 1e-6 * max(float(mean.abs().max()), 1e-6)
             assert float((p.grad - mean).abs().max()) <= tol, n
         dist.barrier()

@@ -72,6 +72,47 @@ def test_two_rank_gloo_gather(tmp_path):
     assert np.array_equal(got["res"].numpy(), ref.numpy())  # same code, same seeds -> same bits
 
 
+def _run_cfg4(t):
+    """BASELINE config 4's trajectory t: the 40 um fixture with joints perturbed by RandomState(1000 + t), ONE oracle
+    step (64 of them have to fit the CPU suite) -> joint xy | grain (area, extraV) as one row."""
+    x, ei, ea = load_graph("40")
+    x = synthetic.perturbed_copy(x, 1e-3, 1000 + t)
+    R, Cm = oracle_models(10020)
+    X, EI, EA = tt(x), tt(ei), tt(ea)
+    oracle.rollout_step(R, Cm, X, EI, EA, 6)
+    return torch.cat([X["joint"][:, :2].reshape(-1), X["grain"][:, 3:5].reshape(-1)])
+
+
+def _cfg4_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert shard_trajectories(64, rank, world) == list(range(rank, 64, world)) and len(shard_trajectories(64, rank, world)) == 8
+    res = run_sharded(64, _run_cfg4, rank, world)
+    # the state gather reuses its buffers: a second gather of the same layout must not disturb the protocol
+    for rep in range(2):
+        states = gather_states({"xy": res[rank::world].clone() + rep}, world)
+        assert all(torch.equal(states[r]["xy"], res[r::world] + rep) for r in range(world))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg4_sixty_four_trajectories_over_eight_ranks(tmp_path):
+    """BASELINE config 4 as stated -- 64 independent trajectories, trajectory t on rank t mod 8, 8 per rank, one
+    all-gather of the results -- on eight gloo ranks: the gathered [64, ...] result equals the single-process one bit
+    for bit, in trajectory order, on the path bench.py --workload cfg4 --gpus 8 takes (shard_trajectories, run_sharded,
+    gather_states)."""
+    torch.set_num_threads(1)
+    ref = torch.stack([_run_cfg4(t) for t in range(64)])
+    out = str(tmp_path / "cfg4.pt")
+    mp.spawn(_cfg4_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    got = torch.load(out)
+    assert got.shape == ref.shape == (64, 236 * 2 + 118 * 2)
+    assert np.array_equal(got.numpy(), ref.numpy())
+
+
 # ---------------------------------------------------------------------------------------
 # training (SURVEY 8f-3): DistributedDataParallel exactly as dist_train.py:82 wraps the model
 # ---------------------------------------------------------------------------------------

@@ -153,6 +153,36 @@ def test_gemm_arithmetic_is_fp32_equivalent():
     assert err < bound, f"decoder projection error {err:.2e} of sum|x||w| (mode {backend().lib.ggnn_gemm_mode()})"
 
 
+def test_three_product_projection_is_fp32_equivalent():
+    """GGNN_PRECISION_F16X2 (the fused decoder plan's value projection: two fp16 pieces per operand, three MFMA products)
+    against the fp64 product on operands spanning 1e-3 .. 1e1 row by row: within 5e-7 of sum |x||w| + |b| -- two pieces keep
+    22 significand bits per operand, 2 x 2^-22 = 4.8e-7 per term at worst (measured 3.4e-7 where the six-product split,
+    with its 24 fp32 accumulations per output, gives 8.0e-7) --, never worse than the six-product result; ragged row
+    counts and every feature width."""
+    if backend().lib.ggnn_gemm_mode() != 1:
+        pytest.skip("split GEMM kernels only")
+    rs = np.random.RandomState(6)
+    for M, F, ncols in ((4096, 8, 768), (4099, 11, 384), (20000, 8, 768), (7, 3, 96)):
+        x = torch.from_numpy((rs.standard_normal((M, F)) * 10 ** rs.uniform(-3, 1, (M, 1))).astype(np.float32))
+        h = torch.from_numpy(np.tanh(rs.standard_normal((M, 96))).astype(np.float32))
+        Fp = (F + 3) & ~3
+        wp = torch.zeros(ncols, Fp + 96)
+        wp[:, :F] = torch.from_numpy((rs.standard_normal((ncols, F)) * 10 ** rs.uniform(-2, 0, (ncols, 1))).astype(np.float32))
+        wp[:, Fp:] = torch.from_numpy((rs.standard_normal((ncols, 96)) * 10 ** rs.uniform(-2, 0, (ncols, 1))).astype(np.float32))
+        bp = torch.from_numpy(rs.standard_normal(ncols).astype(np.float32))
+        xin = torch.cat([x, torch.zeros(M, Fp - F), h], 1).double()
+        ref = xin @ wp.double().t() + bp.double()
+        scale = xin.abs() @ wp.double().abs().t() + bp.double().abs()
+        out3, out6 = torch.empty(M, ncols, device=DEV), torch.empty(M, ncols, device=DEV)
+        args = (x.to(DEV), F, h.to(DEV), wp.to(DEV), bp.to(DEV))
+        backend().project_batch([(*args, out3, _lib.GGNN_PRECISION_F16X2)])
+        backend().project_batch([(*args, out6)])
+        e3 = float(((out3.cpu().double() - ref).abs() / scale).max())
+        e6 = float(((out6.cpu().double() - ref).abs() / scale).max())
+        assert e3 < 5e-7, f"three-product projection M={M} F={F}: {e3:.2e} of sum|x||w| (six products: {e6:.2e})"
+        assert e6 < 1.2e-6 and e3 < e6 + 1e-7
+
+
 @pytest.mark.parametrize("M,K,n_out,batch,transposed,with_cin", [
     (20000, 224, 96, 4, False, False),      # gate GEMM of the decoder's joints: z_g = agg_g W2_g^T
     (20000, 96, 224, 4, True, False),       # its input gradient: g_agg_g = g_z_g W2_g

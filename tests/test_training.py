@@ -377,8 +377,8 @@ def test_ddp_over_rccl_as_the_reference_wraps_it():
     print(r.stdout.strip().splitlines()[-1])
 
 
-def _run_two_ranks(backend, n_dev):
-    """Start tests/rccl_worker2.py twice (ranks 0 and 1, as torchrun would) and wait for both."""
+def _run_two_ranks(backend, n_dev, world=2):
+    """Start tests/rccl_worker2.py `world` times (one process per rank, as torchrun would) and wait for all."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -386,8 +386,8 @@ def _run_two_ranks(backend, n_dev):
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker2.py")
-    procs = [subprocess.Popen([sys.executable, script, str(port), str(r), backend, str(n_dev)], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, script, str(port), str(r), backend, str(n_dev), str(world)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
     try:
         for p in procs:
@@ -415,9 +415,12 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible():
     collectives over xGMI) and `bench.py --gpus 2` reporting two RCCL ranks.  Skipped on a one-GPU box."""
     import json
     import subprocess
-    if torch.cuda.device_count() < 2:
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
         pytest.skip("needs two GPUs (one RCCL rank per device)")
     _run_two_ranks("nccl", 2)
+    if n_dev > 2:   # every visible GPU: config 4's 64 trajectories over min(n, 8) RCCL ranks
+        _run_two_ranks("nccl", min(n_dev, 8), world=min(n_dev, 8))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200,
