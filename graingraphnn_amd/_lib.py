@@ -162,7 +162,7 @@ class AdamArgs(Structure):
     _fields_ = [("table", c_void_p), ("chunk_tensor", c_void_p), ("chunk_index", c_void_p), ("step", c_void_p),
                 ("grad", c_void_p * GGNN_ADAM_MAX_TENSORS), ("lr", c_float * GGNN_ADAM_MAX_GROUPS),
                 ("weight_decay", c_float * GGNN_ADAM_MAX_GROUPS), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("n_chunks", c_int32), ("n_tensors", c_int32)]
+                ("n_chunks", c_int32), ("n_tensors", c_int32), ("hyper", c_void_p)]
 
 
 class MseArgs(Structure):

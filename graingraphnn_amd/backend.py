@@ -44,7 +44,7 @@ class HipBackend:
         self._tape = None  # while a list: every hot-path launch is also recorded as (cfunc, name, cargs)
         self._range_flags = {}  # device -> int32 word the fp16 two-piece kernels report clamped activations in
         self._rowgemm_ws = {}   # (device, stream, bytes) -> weight-plane workspace of ggnn_rowgemm
-        self._mse_ws = {}       # device -> partial sums + arrival counter of ggnn_masked_mse
+        self._mse_ws = {}       # (device, stream) -> partial sums + arrival counter of ggnn_masked_mse
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
@@ -564,9 +564,12 @@ class HipBackend:
             grads.append(g)
             a.pred[k], a.target[k], a.mask[k], a.g_pred[k] = p.data_ptr(), y.data_ptr(), ptr(m), ptr(g)
             a.n[k], a.mask_div[k] = p.numel(), div
-        ws = self._mse_ws.get(loss.device)
+        # one workspace per (device, stream): two losses in flight on different streams (a capture on a side stream beside
+        # eager work, two models training in threads) must not share the arrival counter and the partial sums
+        key = (loss.device, torch.cuda.current_stream(loss.device).cuda_stream)
+        ws = self._mse_ws.get(key)
         if ws is None:
-            ws = self._mse_ws[loss.device] = torch.zeros(_lib.GGNN_MSE_BLOCKS + 1, dtype=torch.float64, device=loss.device)
+            ws = self._mse_ws[key] = torch.zeros(_lib.GGNN_MSE_BLOCKS + 1, dtype=torch.float64, device=loss.device)
         a.workspace, a.loss, a.scale, a.n_terms = ws.data_ptr(), loss.data_ptr(), scale, len(terms)
         self._launch(self.lib.ggnn_masked_mse, "ggnn_masked_mse", ctypes.byref(a), _lib.current_stream())
         return grads

@@ -23,6 +23,48 @@
 
 namespace ggnn {
 
+// ---- per-row power-of-two scaling of the streamed operand (fp32-equivalent mode) ----
+// The two-piece fp16 split has an ABSOLUTE resolution of 2^-36 (common.h): fine for activations, not for the gradient rows
+// the backward products stream (1e-4 .. 1e-10 per node: g_z, gP).  Every row is therefore multiplied by 2^(141 - e), e =
+// biased exponent of the row's largest magnitude SO FAR (exact; largest element in [2^14, 2^15)), and the accumulators
+// carry the same factor: a row element 2^-k below the row's largest keeps a relative resolution of max(2^-22, 2^(k - 51)),
+// whatever the row's magnitude, and no finite fp32 row saturates.  A row holding an inf or a NaN poisons its outputs
+// (scale = NaN), as an fp32 product would: gradient overflow checks keep working.
+struct RowScale {
+  int e = 0;                 // biased exponent the scale belongs to (0: nothing but zeros seen)
+  float s = 0.f, inv = 0.f;  // 2^(141 - e) and its reciprocal
+};
+// the largest magnitude (as bits: dc_track) over the four k-group lanes that hold pieces of this lane's row
+__device__ __forceinline__ uint32_t rg_row_amax(uint32_t am, int lane) {
+  am = max(am, (uint32_t)__builtin_amdgcn_ds_swizzle((int)am, 0x401F));               // lane ^ 16 (bit mode: xor 0x10)
+  am = max(am, (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)am));    // lane ^ 32
+  return am;
+}
+// Adopt `am` into the row's scale; returns the exact factor (a power of two, or 1) the accumulators have to be multiplied
+// with because the scale went down.
+__device__ __forceinline__ float rg_rescale(RowScale& R, uint32_t am) {
+  const int e = (int)(am >> 23);
+  if (e <= R.e && R.s != 0.f) return 1.0f;
+  float f = 1.0f;
+  if (R.s != 0.f) f = e - R.e > 126 ? 0.f : __uint_as_float((uint32_t)(127 - (e - R.e)) << 23);
+  R.e = e;
+  if (e == 255) {
+    R.s = R.inv = __builtin_nanf("");
+  } else {
+    const int es = min(max(268 - e, 1), 253);
+    R.s = __uint_as_float((uint32_t)es << 23);
+    R.inv = __uint_as_float((uint32_t)(254 - es) << 23);
+  }
+  return f;
+}
+__device__ __forceinline__ void rg_track8(uint32_t& am, const f32x4 a, const f32x4 b) {
+  dc_track(am, a[0], a[1]);
+  dc_track(am, a[2], a[3]);
+  dc_track(am, b[0], b[1]);
+  dc_track(am, b[2], b[3]);
+}
+
+
 constexpr int RG_WAVES = 8;
 constexpr int RG_MAX_CT = 14;                 // n_out <= 224
 
@@ -125,7 +167,6 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
   };
   dma_group(0);
   load_rows(0, rows[0]);
-  uint32_t unused_amax = 0u;
 
   int q = 0;
   for (int b = 0; b < A.batch; ++b) {
@@ -133,7 +174,8 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
     DcAcc acc[NCT];   // (bf16 mode: the cross terms stay zero and the compiler drops them)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct].zero();
-    if (A.c_in != nullptr) {
+    [[maybe_unused]] RowScale rs;   // fp32-equivalent mode: the accumulators hold rs.s x the product
+    if (BF16 && A.c_in != nullptr) {
       const float* __restrict__ cin = A.c_in + (int64_t)b * A.c_bstride + row * A.ldc + 4 * kq;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
@@ -147,6 +189,20 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
       const int ns = group_steps(q);
       auto run_group = [&](f32x4 (&cur)[GS][2], f32x4 (&nxt)[GS][2]) __attribute__((always_inline)) {
         load_rows(q + 1, nxt);                           // the next group's rows: in flight during this group's MFMAs
+        if constexpr (!BF16) {   // this group's share of the row: its largest magnitude may lower the row's scale
+          uint32_t am = 0u;
+#pragma unroll
+          for (int i = 0; i < GS; ++i)
+            if (i < ns) rg_track8(am, cur[i][0], cur[i][1]);
+          const float f = rg_rescale(rs, rg_row_amax(am, lane));
+          if (f != 1.0f) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+              acc[ct].m *= f;
+              acc[ct].c *= f;
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < GS; ++i) {
           if (i < ns) {
@@ -155,7 +211,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
               xb[0] = (u32x4){pack_bf16(cur[i][0][0], cur[i][0][1]), pack_bf16(cur[i][0][2], cur[i][0][3]),
                               pack_bf16(cur[i][1][0], cur[i][1][1]), pack_bf16(cur[i][1][2], cur[i][1][3])};
             } else {
-              dc_split(cur[i][0], cur[i][1], xb, unused_amax);
+              dc_split(cur[i][0] * rs.s, cur[i][1] * rs.s, xb);
             }
             const u32x4* ps = pw + i * (SLICE / 16);
             if constexpr (BF16) {
@@ -174,10 +230,19 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
       if (q & 1) run_group(rows[1], rows[0]);
       else run_group(rows[0], rows[1]);
     }
+    if constexpr (BF16) {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      if (16 * ct < A.n_out) {
-        *reinterpret_cast<f32x4*>(crow + 16 * ct) = BF16 ? acc[ct].m : acc[ct].value();
+      for (int ct = 0; ct < NCT; ++ct)
+        if (16 * ct < A.n_out) *reinterpret_cast<f32x4*>(crow + 16 * ct) = acc[ct].m;
+    } else {
+      const float* __restrict__ cin = A.c_in != nullptr ? A.c_in + (int64_t)b * A.c_bstride + row * A.ldc + 4 * kq : nullptr;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        if (16 * ct < A.n_out) {
+          f32x4 v = acc[ct].value() * rs.inv;
+          if (cin != nullptr) v += ld16f(cin + 16 * ct);
+          *reinterpret_cast<f32x4*>(crow + 16 * ct) = v;
+        }
       }
     }
   }
@@ -226,13 +291,20 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_resident_kernel(const g
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // W[b] is in LDS; from here on the waves run free
   const u32x4* pw = reinterpret_cast<const u32x4*>(smem) + lane;
-  uint32_t unused_amax = 0u;
   auto run_tile = [&](f32x4 (&cur)[NKSM][2], f32x4 (&nxt)[NKSM][2]) __attribute__((always_inline)) {
     load_rows(t + stride, nxt);
     const int64_t row = tile_row(t);
     DcAcc acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct].zero();
+    [[maybe_unused]] RowScale rs;   // the whole row is in registers: one scale (RowScale above)
+    if constexpr (!BF16) {
+      uint32_t am = 0u;
+#pragma unroll
+      for (int i = 0; i < NKSM; ++i)
+        if (i < nks) rg_track8(am, cur[i][0], cur[i][1]);
+      rg_rescale(rs, rg_row_amax(am, lane));
+    }
 #pragma unroll
     for (int i = 0; i < NKSM; ++i) {
       if (i < nks) {
@@ -248,7 +320,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_resident_kernel(const g
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
         } else {
-          dc_split(cur[i][0], cur[i][1], xb, unused_amax);
+          dc_split(cur[i][0] * rs.s, cur[i][1] * rs.s, xb);
           dc_kstep<NCT>(ps, xb, acc);
         }
       }
@@ -265,7 +337,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_resident_kernel(const g
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
-      *reinterpret_cast<f32x4*>(A.c + coff + 16 * ct) = (BF16 ? acc[ct].m : acc[ct].value()) + cin[ct];
+      *reinterpret_cast<f32x4*>(A.c + coff + 16 * ct) = (BF16 ? acc[ct].m : acc[ct].value() * rs.inv) + cin[ct];
   };
   while (t < n_tiles) {
     run_tile(rows[0], rows[1]);

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(const ggnn_adam_args A
   const float s = A.step[ti] + 1.0f;
   if (grad != nullptr) {
     // torch.optim.Adam (single-tensor formulation): step_size = lr / (1 - beta1^s); denom = sqrt(v) / sqrt(1 - beta2^s) + eps
-    const float lr = A.lr[T.group], wd = A.weight_decay[T.group];
+    const float lr = A.hyper != nullptr ? A.hyper[T.group] : A.lr[T.group];
+    const float wd = A.hyper != nullptr ? A.hyper[GGNN_ADAM_MAX_GROUPS + T.group] : A.weight_decay[T.group];
     const float bc1 = 1.0f - powf(A.beta1, s), bc2 = 1.0f - powf(A.beta2, s);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const int64_t i1 = min(T.n, i0 + AD_CHUNK);

@@ -419,8 +419,10 @@ class FusedAdam(torch.optim.Optimizer):
     the parameter and its moments, size, group) sits in a table in device memory; what changes from step to step -- the
     gradients' addresses (new tensors after every backward), the groups' learning rates (a scheduler edits
     `param_groups[i]["lr"]`) -- travels in the launch's arguments.  The step counts live on the device and the call
-    increments them itself, so `step()` can be captured in a hipGraph (`GraphedTrainStep`); a captured step replays the
-    learning rates it was captured with, as torch's capturable Adam does with a float `lr`.
+    increments them itself, so `step()` can be captured in a hipGraph (`GraphedTrainStep`).  The groups' learning rates and
+    weight decays are read from a small DEVICE array (`ggnn_adam_args.hyper`) that `sync_hyperparams()` refreshes from
+    `param_groups` with an uncaptured copy whenever they changed -- step() does it outside a capture, GraphedTrainStep
+    before every replay -- so a scheduler on top (train.py:91: StepLR) is followed by the replayed steps too.
 
     Same arithmetic as torch.optim.Adam(amsgrad=False, maximize=False): tests compare the two.  State per parameter
     (`state_dict`): "step", "exp_avg", "exp_avg_sq" -- views of three flat device buffers."""
@@ -472,7 +474,29 @@ class FusedAdam(torch.optim.Optimizer):
                 ci += list(range(nc))
             launches.append((t0, cnt, torch.tensor(ct, dtype=torch.int32, device=dev),
                              torch.tensor(ci, dtype=torch.int32, device=dev)))
-        self._built = dict(ps=ps, m=m, v=v, step=step, dev_table=dev_table, launches=launches, params_at=[p.data_ptr() for p, _ in ps])
+        hyper = torch.zeros(2 * _lib.GGNN_ADAM_MAX_GROUPS, device=dev)
+        hyper_host = torch.zeros(2 * _lib.GGNN_ADAM_MAX_GROUPS).pin_memory()
+        self._built = dict(ps=ps, m=m, v=v, step=step, dev_table=dev_table, launches=launches, params_at=[p.data_ptr() for p, _ in ps],
+                           hyper=hyper, hyper_host=hyper_host, hyper_seen=None)
+
+    def sync_hyperparams(self):
+        """Copy the groups' lr / weight_decay into the device array the update kernel reads, if they changed since the last
+        copy.  Not capturable (a captured copy would replay the captured values): called by step() outside a capture and
+        by GraphedTrainStep before every replay."""
+        if self._built is None:
+            self._build()
+        b = self._built
+        G = _lib.GGNN_ADAM_MAX_GROUPS
+        now = tuple((float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups)
+        if now == b["hyper_seen"]:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GGNNError("FusedAdam: lr / weight_decay changed inside a hipGraph capture: call sync_hyperparams() before it")
+        torch.cuda.current_stream().synchronize()   # (an earlier copy from the pinned staging array may still be queued)
+        for gi, (lr, wd) in enumerate(now):
+            b["hyper_host"][gi], b["hyper_host"][G + gi] = lr, wd
+        b["hyper"].copy_(b["hyper_host"], non_blocking=True)
+        b["hyper_seen"] = now
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -483,6 +507,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         if self._built is None:
             self._build()
+        self.sync_hyperparams()
         b = self._built
         be = default_backend()
         g0 = self.param_groups[0]
@@ -503,6 +528,7 @@ class FusedAdam(torch.optim.Optimizer):
             for gi, g in enumerate(self.param_groups):
                 a.lr[gi], a.weight_decay[gi] = g["lr"], g["weight_decay"]
             a.beta1, a.beta2, a.eps = g0["betas"][0], g0["betas"][1], g0["eps"]
+            a.hyper = b["hyper"].data_ptr()
             a.n_chunks, a.n_tensors = ct.numel(), cnt
             be.adam_step(a)
         return loss
@@ -607,5 +633,7 @@ class GraphedTrainStep:
             for k, v in (src or {}).items():
                 if v is not dst[k]:
                     dst[k].copy_(v)
+        if hasattr(self.opt, "sync_hyperparams"):   # FusedAdam: a scheduler's new learning rates reach the replayed update
+            self.opt.sync_hyperparams()
         self.graph.replay()
         return self._loss

@@ -434,7 +434,10 @@ int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn
  *   w        : element (b, n, k) at w + b * w_bstride + n * w_nstride + k * w_kstride  (n_out <= 224, n_out % 16 == 0;
  *              either orientation of a stored matrix: a gradient uses the transpose of the forward's weight)
  *   c, c_in  : element (b, m, n) at c + b * c_bstride + m * ldc + n; c_in optional (may equal c)
- *   precision: 0 = fp32-equivalent (two fp16 pieces per operand, three MFMA products; |a|, |w| < 65504);
+ *   precision: 0 = fp32-equivalent (two fp16 pieces per operand, three MFMA products; |w| < 65504; the rows of `a` may be
+ *              ANY finite fp32 values -- every row is scaled by a power of two taken from its largest magnitude before it
+ *              is split and the accumulators carry the factor, so gradient rows of 1e-10 keep the resolution activations
+ *              of 1 have; a row holding an inf or a NaN gives NaN outputs, as an fp32 product would);
  *              GGNN_PRECISION_BF16 = one bf16 product, fp32 accumulation (what torch.autocast(bfloat16) defines)
  *   workspace: ggnn_rowgemm_workspace_bytes(K, n_out, batch) bytes, 16-byte aligned: the weights as MFMA operand
  *              planes (they change with every optimizer step).  prepacked == 0: the call packs them itself (two launches:
@@ -574,8 +577,12 @@ int ggnn_heads_regressor_backward(int64_t n_joint, int64_t n_grain, const float*
  * M x Nc result -- the gradient of a packed projection ([ncols, F + 97]) or gate ([96, Kg] per gate) weight
  * matrix, replacing the BLAS call autograd would make for x.t() @ g (which does not split K).  The reduction is
  * split over the chip in a fixed way; the call writes partial[s][b][M][Nc], s < ggnn_wgrad_splits(K, M, Nc, batch),
- * and sums over s into `out` (in index order; out == NULL: left to the caller).  Exact fp32 products (v_mfma_f32_16x16x4_f32).  M, Nc, lda, ldb, a_bstride,
- * b_bstride multiples of 4 (pad B with zero columns otherwise); a, b 16-byte aligned. */
+ * and sums over s into `out` (in index order; out == NULL: left to the caller).  Arithmetic: fp32-equivalent over fp32's
+ * whole range either way -- exact fp32 products (v_mfma_f32_16x16x4_f32) for the short results, and for the TALL ones
+ * (M >= 512: the packed projection's gradient) under the default GEMM mode both operands as three exact bf16 pieces with
+ * six products per k-step (2e-8 of sum |a||b| against an fp64 product; gradients of 1e-10 keep their 24 bits, which a
+ * two-piece fp16 split would not give them).  M, Nc, lda, ldb, a_bstride, b_bstride multiples of 4 (pad B with zero columns
+ * otherwise); a, b 16-byte aligned. */
 typedef struct ggnn_wgrad_args {
   const float* a;  /* [batch] x [K, lda] row-major, first M columns used; batch b starts at a + b * a_bstride */
   const float* b;  /* [batch] x [K, ldb], first Nc columns used; batch b starts at b + b * b_bstride */
@@ -596,7 +603,10 @@ int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, i
  * tensors in one launch.  `table` (DEVICE memory, n_tensors entries, built once) holds what is fixed: the addresses of a
  * parameter and its two moment buffers, its size, its parameter group.  Workgroup c of the launch updates elements
  * [chunk_index[c] * GGNN_ADAM_CHUNK, +GGNN_ADAM_CHUNK) of tensor chunk_tensor[c] (DEVICE arrays of n_chunks entries, built once
- * from the sizes).  What changes per step comes by value: grad[t] (NULL: tensor t is skipped), lr / weight_decay per group.
+ * from the sizes).  What changes per step comes by value: grad[t] (NULL: tensor t is skipped), lr / weight_decay per group --
+ * or, with `hyper` set, lr and weight_decay are read from DEVICE memory (hyper[g] = lr of group g, hyper[GGNN_ADAM_MAX_GROUPS + g]
+ * = its weight_decay): a call captured in a hipGraph then follows a learning-rate schedule (train.py:91, StepLR) through
+ * an uncaptured copy into that array between replays, where by-value arguments would replay the captured rates for ever.
  * step (DEVICE, n_tensors floats, 0 before the first call): step[t] = updates tensor t has had so far -- read for the bias
  * corrections and incremented by the call itself (a second small launch) where grad[t] != NULL (torch keeps a count per
  * parameter: one without a gradient does not advance), so a captured call replays correctly.  A model with more tensors
@@ -622,6 +632,7 @@ typedef struct ggnn_adam_args {
   float lr[GGNN_ADAM_MAX_GROUPS], weight_decay[GGNN_ADAM_MAX_GROUPS];
   float beta1, beta2, eps;
   int32_t n_chunks, n_tensors;
+  const float* hyper;   /* optional, DEVICE: [2][GGNN_ADAM_MAX_GROUPS] lr | weight_decay per group, read instead of the by-value ones */
 } ggnn_adam_args;
 int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream);
 

@@ -240,6 +240,42 @@ def test_rowgemm_against_float64(M, K, n_out, batch, transposed, with_cin):
     assert torch.equal(o2[:, :, :n_out], ob[:, :, :n_out])
 
 
+@pytest.mark.parametrize("M,K,n_out,batch,transposed", [
+    (4096, 224, 96, 4, False),      # resident planes (the gate GEMM's shapes)
+    (4096, 96, 224, 2, True),       # its input gradient g_agg = g_z W2
+    (4099, 1248, 96, 1, True)])     # streamed planes: g_h += gP Wp[:, h columns]
+def test_rowgemm_keeps_its_resolution_on_gradient_sized_rows(M, K, n_out, batch, transposed):
+    """The backward products stream GRADIENT rows (g_z, gP: 1e-4 .. 1e-10 per node, masked nodes exactly 0).  The
+    two-piece fp16 split resolves 2^-36 absolutely, which would be 1.5e-4 of a 1e-7 element: ggnn_rowgemm scales every
+    row by a power of two from its largest magnitude (include/ggnn.h).  Rows spanning 1e-3 .. 1e-12 row by row (and 1e3
+    within a row) against the fp64 product: the same 5e-7 of sum |a||w| as O(1) rows; all-zero rows give exact zeros; a
+    row with an inf or a NaN gives NaN outputs in that row only."""
+    be = backend()
+    rs = np.random.RandomState(M + K)
+    a = rs.standard_normal((batch, M, K)) * 10 ** rs.uniform(-12, -3, (batch, M, 1)) * 10 ** rs.uniform(-3, 0, (batch, M, K))
+    a[:, 5] = 0.0                                     # a masked node
+    a = torch.from_numpy(a.astype(np.float32)).to(DEV)
+    wshape = (batch, K, n_out) if transposed else (batch, n_out, K)
+    w = torch.from_numpy((rs.standard_normal(wshape) * 0.3).astype(np.float32)).to(DEV)
+    out = torch.empty(batch, M, n_out, device=DEV)
+    be.rowgemm(a, w, out, K, n_out, batch=batch, transposed=transposed)
+    A64 = a.cpu().double()
+    W64 = (w.transpose(1, 2) if transposed else w).cpu().double()
+    ref = A64 @ W64.transpose(1, 2)
+    norm = A64.abs() @ W64.abs().transpose(1, 2)
+    got = out.cpu().double()
+    live = norm > 0
+    err = float(((got - ref).abs()[live] / norm[live]).max())
+    assert err < 5e-7 * max(1.0, (K / 96) ** 0.5), f"rowgemm on gradient-sized rows: {err:.2e} of sum |a||w|"
+    assert bool((out[:, 5] == 0).all())
+    a[0, 7, 3] = float("inf")
+    a[batch - 1, 9, K - 1] = float("nan")
+    be.rowgemm(a, w, out, K, n_out, batch=batch, transposed=transposed)
+    bad = torch.isnan(out).all(-1)
+    assert bool(bad[0, 7]) and bool(bad[batch - 1, 9]) and int(bad.sum()) == 2
+    assert bool(torch.isfinite(out[~bad]).all())
+
+
 def _gate_problem(N, Ka, mode, seed):
     """Random operands of one ggnn_lstm_epilogue problem in the workspace layout (gate stride padded
     to 32 floats) + its float64 result."""
@@ -712,6 +748,80 @@ def test_cfg3_ten_step_rollout_as_benched(mode):
     for et in EDGE_TYPES:
         assert_close(ro.edge_attr_dict()[et], oEA[et], f"cfg3 10 steps edge_attr {et}")
     print(f"cfg3 10-step rollout ({mode}): worst per-tensor error {worst:.2e}")
+
+
+@torch.no_grad()
+def test_cfg3_five_hundred_step_rollout_checked_along_its_trajectory():
+    """BASELINE config 3 at full length: the 500-step rollout bench.py times (test.py:353-407's loop: both forwards,
+    update, grain-centre refresh through the global frame, edge refresh; hipGraph replay, default launch plan).
+      * all 500 steps: run twice from the same inputs -> bit-identical states and predictions; every state finite;
+      * at 26 points ALONG the HIP trajectory (steps 0-2, every few dozen steps, the last two; 329-331 among them -- the
+        oracle's own trajectory puts a grain centre on the fold boundary there) the oracle is given the HIP state and both
+        take ONE step from identical inputs: every prediction and the state after the step within the 1e-4 contract.
+        Grain centres are compared modulo the fold (frac() may land on either side of 0 / 1); an edge length that
+        involves a grain whose centre landed on the other side is excluded, and at most a handful of grains may do so."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea, off = synthetic.honeycomb(100, 10, 0, return_offset=True)
+    R, Cm = product_models(0, 0.3, DEV)
+    oR, oC = oracle_models(0, 0.3)
+    ooff = torch.from_numpy(off)
+    GJ, JG, JJ = EDGE_TYPES
+
+    def rollout():
+        X, EI, EA = tt(x, DEV), tt(ei, DEV), tt(ea, DEV)
+        return X, GrainRollout(R, Cm, X, EI, EA, 6, use_graph=True, refresh_centres=True, domain_factor=10.0,
+                               domain_offset=ooff)
+
+    # (1) the whole trajectory twice: bit-reproducible and finite
+    Xa, ra = rollout()
+    Xb, rb = rollout()
+    for seg in range(10):
+        ra.run(50)
+        rb.run(50)
+        for nt in Xa:
+            assert bool(torch.isfinite(Xa[nt]).all()), f"step {50 * (seg + 1)}: x {nt} not finite"
+            assert torch.equal(Xa[nt], Xb[nt]), f"step {50 * (seg + 1)}: x {nt} differs between two identical runs"
+    for k in ra.pred:
+        assert torch.equal(ra.pred[k], rb.pred[k]) and bool(torch.isfinite(ra.pred[k]).all()), k
+    for et in EDGE_TYPES:
+        assert torch.equal(ra.edge_attr_dict()[et], rb.edge_attr_dict()[et]), et
+    assert not ra.range_exceeded()
+
+    # (2) one step from identical inputs at points along the trajectory
+    checks = [0, 1, 2, 5, 10, 20, 40, 60, 80, 100, 130, 160, 200, 240, 280, 320, 329, 330, 331, 360, 400, 440, 470, 490,
+              498, 499]
+    X, ro = rollout()
+    oEI = tt(ei)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    worst, flipped_total, done = 0.0, 0, 0
+    try:
+        for step in checks:
+            ro.run(step - done)
+            torch.cuda.synchronize()
+            oX = {nt: X[nt].cpu().clone() for nt in X}
+            oEA = {et: ro.edge_attr_dict()[et].cpu().clone() for et in EDGE_TYPES}
+            pred = {k: v.clone() for k, v in ro.step().items()}
+            done = step + 1
+            opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6, centres=(10.0, ooff))
+            for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+                worst = max(worst, assert_close(pred[k], opred[k], f"cfg3 step {step} {k}"))
+            assert_close(X["joint"], oX["joint"], f"cfg3 step {step} x joint")
+            assert_close(X["grain"][:, 2:], oX["grain"][:, 2:], f"cfg3 step {step} x grain[2:]")
+            d = (X["grain"][:, :2].cpu() - oX["grain"][:, :2]).abs()
+            assert float(torch.minimum(d, 1 - d).max()) < 1e-4, f"cfg3 step {step}: grain centres"
+            flipped = (d > 0.5).any(1)                      # centres that landed on the other side of the fold
+            flipped_total += int(flipped.sum())
+            hea = ro.edge_attr_dict()
+            assert_close(hea[JJ], oEA[JJ], f"cfg3 step {step} edge_attr {JJ}")
+            for et, grain_row in ((GJ, 0), (JG, 1)):
+                keep = ~flipped[oEI[et][grain_row]]
+                assert_close(hea[et].cpu().view(-1)[keep], oEA[et].view(-1)[keep], f"cfg3 step {step} edge_attr {et}")
+    finally:
+        torch.set_num_threads(threads)
+    assert flipped_total <= 5, f"{flipped_total} grain centres on the other side of the fold over {len(checks)} checked steps"
+    print(f"cfg3 500-step rollout: {len(checks)} one-step checks along the trajectory, worst per-tensor error {worst:.2e}, "
+          f"{flipped_total} centre(s) across the fold")
 
 
 # ---------------------------------------------------------------------------------------

@@ -605,6 +605,54 @@ def test_graphed_train_step_follows_the_eager_step(fused):
 
 
 @pytest.mark.gpu
+def test_captured_fused_adam_step_follows_a_learning_rate_schedule():
+    """train.py:91 puts StepLR(gamma = 0.5) on top of Adam.  A FusedAdam.step() captured in a hipGraph reads its learning
+    rates from device memory, refreshed by sync_hyperparams() between replays: ten replayed steps under StepLR(step_size
+    = 3) with a second group's weight decay changed half-way equal eager torch.optim.Adam under the same schedule (with
+    the rates passed by value the replays would keep the captured ones: the parameters end ~40 % away)."""
+    from graingraphnn_amd import training
+    dev = "cuda"
+    rs = np.random.RandomState(21)
+    shapes = [(96, 104), (4097,), (7,)]
+    pa = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(sh).astype(np.float32)).to(dev)) for sh in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:2]}, {"params": ps[2:], "lr": 4e-3, "weight_decay": 0.02}]
+    oa = training.FusedAdam(groups(pa), lr=2e-3)
+    ob = torch.optim.Adam(groups(pb), lr=2e-3)
+    sa = torch.optim.lr_scheduler.StepLR(oa, step_size=3, gamma=0.5)
+    sb = torch.optim.lr_scheduler.StepLR(ob, step_size=3, gamma=0.5)
+    grads = [torch.zeros_like(p) for p in pa]          # static gradient buffers: what a captured backward writes into
+    for p, g in zip(pa, grads):
+        p.grad = g
+    oa.sync_hyperparams()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            oa.step()
+    torch.cuda.current_stream().wait_stream(st)
+    start = [p.detach().clone() for p in pa]
+    for k in range(10):
+        for g, pbk in zip(grads, pb):
+            g.copy_(torch.from_numpy((rs.standard_normal(g.shape) * 0.1).astype(np.float32)).to(dev))
+            pbk.grad = g.clone()
+        if k == 5:
+            for o in (oa, ob):
+                o.param_groups[1]["weight_decay"] = 0.05
+        oa.sync_hyperparams()      # (GraphedTrainStep.__call__ does this before every replay)
+        graph.replay()
+        ob.step()
+        sa.step()
+        sb.step()
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 2e-3 * 0.5 ** 3
+    for i, (a, b, a0) in enumerate(zip(pa, pb, start)):
+        moved = float((b - a0).abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(moved, 1e-3), (i, float((a - b).abs().max()), moved)
+    assert float(oa.state[pa[0]]["step"]) == 10.0
+
+
+@pytest.mark.gpu
 def test_fused_adam_follows_torch_adam():
     """training.FusedAdam (ggnn_adam_step: every tensor in one launch, step count on the device) against torch.optim.Adam
     on copies of the same tensors: two groups with their own learning rate and weight decay, a learning rate changed
