@@ -812,11 +812,15 @@ def test_cfg3_five_hundred_step_rollout_checked_along_its_trajectory():
             assert float(torch.minimum(d, 1 - d).max()) < 1e-4, f"cfg3 step {step}: grain centres"
             flipped = (d > 0.5).any(1)                      # centres that landed on the other side of the fold
             flipped_total += int(flipped.sum())
+            # edge lengths are differences of coordinates: along a 500-step random-weight trajectory some edges shrink to
+            # ~1e-3 of the box, where the coordinates' own rounding (1e-7 of a folded coordinate ~1) is more than 1e-4 OF THE
+            # LENGTH -- the element-wise floor of these comparisons is therefore 5e-6 absolute (the coordinates themselves
+            # are held to the 1e-4 contract above; the per-tensor bound on the lengths stays 1e-4 of the longest)
             hea = ro.edge_attr_dict()
-            assert_close(hea[JJ], oEA[JJ], f"cfg3 step {step} edge_attr {JJ}")
+            assert_close(hea[JJ], oEA[JJ], f"cfg3 step {step} edge_attr {JJ}", atol=5e-6)
             for et, grain_row in ((GJ, 0), (JG, 1)):
                 keep = ~flipped[oEI[et][grain_row]]
-                assert_close(hea[et].cpu().view(-1)[keep], oEA[et].view(-1)[keep], f"cfg3 step {step} edge_attr {et}")
+                assert_close(hea[et].cpu().view(-1)[keep], oEA[et].view(-1)[keep], f"cfg3 step {step} edge_attr {et}", atol=5e-6)
     finally:
         torch.set_num_threads(threads)
     assert flipped_total <= 5, f"{flipped_total} grain centres on the other side of the fold over {len(checks)} checked steps"

@@ -648,7 +648,9 @@ def test_captured_fused_adam_step_follows_a_learning_rate_schedule():
     assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 2e-3 * 0.5 ** 3
     for i, (a, b, a0) in enumerate(zip(pa, pb, start)):
         moved = float((b - a0).abs().max())
-        assert float((a - b).abs().max()) <= 2e-5 * max(moved, 1e-3), (i, float((a - b).abs().max()), moved)
+        # (a few roundings of a parameter of magnitude ~3 on top of the update's own tolerance; a replay that kept the
+        # captured rates would be off by ~0.4 x moved)
+        assert float((a - b).abs().max()) <= 2e-5 * moved + 1e-6 * float(b.abs().max()), (i, float((a - b).abs().max()), moved)
     assert float(oa.state[pa[0]]["step"]) == 10.0
 
 
