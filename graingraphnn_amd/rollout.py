@@ -81,6 +81,9 @@ class GrainRollout:
         # GGNN_TAIL=join (development, A/B runs): the plain two-stream plan -- update, centres, refresh and edge
         # records behind a join of both streams -- instead of the pipelined one
         self.pipeline_tail = os.environ.get("GGNN_TAIL", "") != "join"
+        # GGNN_PIPE=r4 (development, A/B runs): the round-4 pipelined plan, whose Rmodel.update waits for the classifier's
+        # decoder; default: the regressor's tail runs UNDER the classifier's decoder (_enqueue_steps_overlapped)
+        self.overlap_tail = os.environ.get("GGNN_PIPE", "") != "r4"
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.concurrent else None
         self.refresh_centres = refresh_centres
         self.domain_factor = float(domain_factor)
@@ -144,6 +147,9 @@ class GrainRollout:
         self.pred["edge_event"] = torch.empty(E, dtype=torch.float32, device=dev)
         self.pred["edge"] = torch.empty(E, 2, dtype=torch.float32, device=dev)
         self.einfo = alloc_einfo(self.graph, dev)
+        # second set of edge records and the classifier's private copy of x (_enqueue_steps_overlapped): made on first use
+        self._einfo_other = None
+        self._xc = None
         self._graphs = None
         self._seen = None
 
@@ -158,6 +164,8 @@ class GrainRollout:
 
     def _enqueue_steps(self, n_steps: int):
         if self._pipelined():
+            if self.overlap_tail:
+                return self._enqueue_steps_overlapped(n_steps)
             return self._enqueue_steps_pipelined(n_steps)
         for _ in range(n_steps):
             self._enqueue_forward_update()
@@ -210,6 +218,76 @@ class GrainRollout:
                                     [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo[et])
                                      for et in EDGE_TYPES])
             self.edge_attr, self._ea_other = ea_next, ea
+        main.wait_stream(st_c)
+        self._einfo_fresh = True
+        return events
+
+    def _overlap_buffers(self):
+        """The second set of edge records and the classifier's copy of x (outside any capture: _capture calls this first)."""
+        if self._pipelined() and self.overlap_tail:
+            if self._einfo_other is None:
+                self._einfo_other = alloc_einfo(self.graph, self.x["joint"].device)
+            if self._xc is None:
+                self._xc = {nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES}
+
+    def _enqueue_steps_overlapped(self, n_steps: int):
+        """`n_steps` static-topology steps on two streams with the regressor's tail -- heads + Rmodel.update, grain
+        centres, z clamp + edge lengths + the NEXT step's edge records -- UNDER the classifier's decoder cell.  In the
+        round-4 plan (_enqueue_steps_pipelined) that tail waited for the classifier's decoder, the last reader of x and of
+        the edge records: at 10 000 grains the two decoder cells are 393 workgroups in two rounds of the chip, the
+        regressor's finishes ~100 us before the classifier's, and the tail (three launch-bound kernels, ~25 us + the
+        cross-stream hand-overs) then ran on an idle chip (profiles/r5_step_timeline.txt).  Here the classifier reads a
+        private copy of x (taken at the top of its step: 1.1 MB) and the edge lengths / edge records alternate between
+        two sets -- the refresh of step k writes the set of step k + 1 while the classifier still reads the set of step k
+        -- so nothing the tail writes is read by the classifier's forward of the same step.  Cross-stream edges per step:
+          * the classifier waits for `ready` (x, edge lengths and records of this step are final; recorded by the
+            regressor's stream at the top of the step);
+          * Rmodel.update waits for `copied` (the classifier has taken its copy of x; early in the step: no stall);
+          * the NEXT step's regressor forward waits for `swept` (the classifier's decoder cell of this step is done: the
+            chip is free, and the edge records it read may be overwritten by the next refresh); the classifier's heads
+            run behind `swept`, beside the next step's first kernels.
+        Same kernels on the same operands as the single-stream plan: bit-identical results
+        (test_pipelined_two_stream_rollout_equals_the_single_stream_plan)."""
+        be, x, p = self.be, self.x, self.pred
+        self._overlap_buffers()
+        xc = self._xc
+        main = torch.cuda.current_stream()
+        st_c = self._side[1]
+        events = []        # kept alive until the streams are joined (and a capture has ended)
+        swept_prev = None    # the classifier's decoder of the previous step of this block
+        for _ in range(n_steps):
+            ea, ea_next = self.edge_attr, self._ea_other
+            einfo, einfo_next = self.einfo, self._einfo_other
+            ready, copied, swept = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            events += [ready, copied, swept]
+            if swept_prev is not None:
+                main.wait_event(swept_prev)
+            ready.record(main)
+            with torch.cuda.stream(st_c):
+                st_c.wait_event(ready)
+                for nt in NODE_TYPES:
+                    xc[nt].copy_(x[nt])
+                copied.record(st_c)
+                enc, dec = self.packed["C"]
+                h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
+                swept.record(st_c)
+                be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                                    self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+            enc, dec = self.packed["R"]
+            hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
+            main.wait_event(copied)
+            # heads + Rmodel.update in one launch; z clamp + edge lengths + next records in one launch
+            be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
+                                      p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
+            if self.refresh_centres:
+                be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
+                                 self.domain_factor, self.domain_offset)
+            be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
+                                    [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
+                                     for et in EDGE_TYPES])
+            swept_prev = swept
+            self.edge_attr, self._ea_other = ea_next, ea
+            self.einfo, self._einfo_other = einfo_next, einfo
         main.wait_stream(st_c)
         self._einfo_fresh = True
         return events
@@ -291,9 +369,10 @@ class GrainRollout:
         edge_attr buffers: a graph is only valid from the buffer it was captured on, so graphs are kept per
         buffer (`_graphs[(n_steps, id of the current buffer)]`), and an odd number of steps leaves the other one
         current after every replay."""
+        self._overlap_buffers()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        state = (self.edge_attr, self._ea_other, self._einfo_fresh)
+        state = (self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other)
         with torch.cuda.stream(s):
             # the capture records, it does not execute: x / edge_attr are left untouched
             g = torch.cuda.CUDAGraph()
@@ -301,7 +380,7 @@ class GrainRollout:
                 keep = self._enqueue_steps(n_steps)   # (its stream events outlive the capture)
         torch.cuda.current_stream().wait_stream(s)
         del keep
-        self.edge_attr, self._ea_other, self._einfo_fresh = state
+        self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other = state
         return g
 
     def _replay(self, n_steps: int):
@@ -316,6 +395,8 @@ class GrainRollout:
         if self._pipelined():
             if n_steps % 2:
                 self.edge_attr, self._ea_other = self._ea_other, self.edge_attr
+                if self.overlap_tail:   # (the edge records alternate with the edge lengths)
+                    self.einfo, self._einfo_other = self._einfo_other, self.einfo
             self._einfo_fresh = True
         else:
             self._einfo_fresh = False

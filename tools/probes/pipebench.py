@@ -24,7 +24,7 @@ for u in unrolls:
         ro.run(n)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"unroll {u:3d}: {n / dt:8.1f} steps/s  {dt / n * 1e6:7.1f} us/step  (pipe={os.environ.get('GGNN_PIPE', 'decoupled')})", flush=True)
+        print(f"unroll {u:3d}: {n / dt:8.1f} steps/s  {dt / n * 1e6:7.1f} us/step  (pipe={os.environ.get('GGNN_PIPE', 'tail under the classifier decoder')})", flush=True)
     except Exception as exc:
         print(f"unroll {u:3d}: FAILED {type(exc).__name__}: {str(exc).splitlines()[0]}", flush=True)
         break
