@@ -474,6 +474,220 @@ class GrainRollout:
         self.switched.append(switches)
         return pred, events, switches
 
+    # -- event-driven mode without a host stall per quiet step ------------------------------------------------------
+    # steps per block in run_events while the topology is quiet (a graph-to-graph boundary costs ~25 us at the 10k-grain
+    # graph); after an eventful step the blocks start again at one step (enqueued eagerly: every event drops the captured
+    # graphs with the topology) and double while the steps stay quiet
+    EVENTS_UNROLL = 8
+
+    def _spec_state(self):
+        """Buffers of the speculative event loop (run_events): a ring of 2 x EVENTS_UNROLL slots, slot = step index mod
+        ring size -- x as the step found it (the copy the classifier's forward reads anyway), the step's predictions,
+        the grain centres as they were before the step's refresh, its event counts (device + pinned host) -- plus the
+        two alternating sets of edge lengths / edge records (set = slot parity).  Graphs are captured per (first slot,
+        number of steps).  Rebuilt after every topology change."""
+        S = getattr(self, "_spec", None)
+        if S is not None and S["topology"] is self.graph and S["ea"][S["cur"] & 1] is self.edge_attr \
+                and S["einfo"][S["cur"] & 1] is self.einfo:
+            return S
+        self._overlap_buffers()
+        dev = self.x["joint"].device
+        D = 2 * max(1, int(self.EVENTS_UNROLL))
+        S = self._spec = {
+            "topology": self.graph, "cur": 0, "D": D,
+            "ea": [self.edge_attr, self._ea_other], "einfo": [self.einfo, self._einfo_other],
+            "xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
+            "pred": [{k: torch.empty_like(v) for k, v in self.pred.items()} for _ in range(D)],
+            "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
+            "evf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
+            "evh": [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(D)],
+            "graphs": {}}
+        return S
+
+    def _enqueue_spec_step(self, slot: int, swept_prev=None):
+        """One step with events ASSUMED ABSENT: the overlapped two-stream step (_enqueue_steps_overlapped) on the edge
+        set of the slot's parity + a snapshot of the grain centres before they are refreshed + the event counts of this
+        step's predictions (ggnn_detect_events) copied to pinned host memory.  Nothing an event would need is
+        overwritten by the steps enqueued behind it: they use other slots of the ring."""
+        S, be, x = self._spec, self.be, self.x
+        s = slot & 1
+        ea, ea_next, einfo, einfo_next = S["ea"][s], S["ea"][1 - s], S["einfo"][s], S["einfo"][1 - s]
+        p, xc = S["pred"][slot], S["xs"][slot]
+        main, st_c = torch.cuda.current_stream(), self._side[1]
+        ready, copied, updated, swept, headed = (torch.cuda.Event() for _ in range(5))
+        st_d = self._side[0]   # the event counts go out on a stream of their own: neither model's chain waits for them
+        if swept_prev is not None:
+            main.wait_event(swept_prev)   # the previous step's classifier decoder: the chip is free, its edge set may go
+        ready.record(main)
+        with torch.cuda.stream(st_c):
+            st_c.wait_event(ready)
+            for nt in NODE_TYPES:
+                xc[nt].copy_(x[nt])
+            copied.record(st_c)
+            enc, dec = self.packed["C"]
+            h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
+            swept.record(st_c)
+            be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+            headed.record(st_c)
+        enc, dec = self.packed["R"]
+        hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
+        main.wait_event(copied)
+        be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
+                                  p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
+        updated.record(main)
+        S["cen"][slot].copy_(x["grain"][:, :2])
+        if self.refresh_centres:
+            be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
+                             self.domain_factor, self.domain_offset)
+        be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
+                                [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
+                                 for et in EDGE_TYPES])
+        with torch.cuda.stream(st_d):
+            st_d.wait_event(updated)   # grain_area of this step
+            st_d.wait_event(headed)    # ... and its edge_event
+            be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
+                             self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot])
+            S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
+        return [ready, copied, updated, headed, swept]
+
+    def _enqueue_spec_steps(self, slots):
+        """The steps of a block back to back (a step's regressor forward waits for the previous step's classifier
+        decoder, not for its heads and event counts), the streams joined behind the last one."""
+        keep, swept = [], None
+        for sl in slots:
+            ev = self._enqueue_spec_step(sl, swept)
+            swept = ev[-1]
+            keep += ev
+        torch.cuda.current_stream().wait_stream(self._side[1])
+        torch.cuda.current_stream().wait_stream(self._side[0])
+        return keep
+
+    def _spec_launch(self, n: int):
+        """Enqueue `n` speculative steps from the current slot on; returns (their slots, the event behind them)."""
+        S = self._spec
+        slots = [(S["cur"] + i) % S["D"] for i in range(n)]
+        if self.use_graph and n > 1:
+            g = S["graphs"].get((slots[0], n))
+            if g is None:
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        keep = self._enqueue_spec_steps(slots)
+                torch.cuda.current_stream().wait_stream(st)
+                del keep
+                S["graphs"][(slots[0], n)] = g
+            g.replay()
+        else:
+            self._enqueue_spec_steps(slots)
+        done = torch.cuda.Event()
+        done.record()
+        self._spec_adopt(slots[-1])
+        self._einfo_fresh = True   # (the last step's refresh prepared the records of the step to come)
+        return slots, done
+
+    def _spec_adopt(self, slot: int):
+        """The rollout's current buffers := the state behind the step of `slot`."""
+        S = self._spec
+        nxt = (slot + 1) & 1
+        self.pred = S["pred"][slot]
+        self.edge_attr, self._ea_other = S["ea"][nxt], S["ea"][1 - nxt]
+        self.einfo, self._einfo_other = S["einfo"][nxt], S["einfo"][1 - nxt]
+        S["cur"] = (slot + 1) % S["D"]
+
+    def run_events(self, n_steps: int):
+        """`n_steps` steps of the full loop of test.py:382-575 (forwards, Rmodel.update, topological events, grain
+        centres, edge refresh) WITHOUT a host stall per quiet step: the steps are enqueued EVENTS_UNROLL at a time as if
+        they had no events (one captured graph per block), each step's event counts travel to pinned host memory, and
+        the host reads the counts of a block only after the next block is enqueued -- the device never waits for the
+        host while the topology is quiet.  When a step did have events, every step enqueued behind it is void: x is
+        taken back from the copy the following step made at its top, the grain centres from the snapshot taken before
+        the eventful step's refresh, that step's predictions are still in their own slot; the events are then applied
+        exactly as step_events does (host-side topology update, refresh on the new topology) and the loop goes on from
+        the next step.  Same results, bit for bit, as n_steps x step_events()
+        (test_speculative_event_loop_equals_step_events).  Needs the two-stream launch plan (joint_launches=False,
+        concurrent=True); otherwise runs step_events in a loop.  Returns (grain_events, switching_lists): one entry per step."""
+        if not hasattr(self, "mask"):
+            raise _lib.GGNNError("call enable_events(mask, ...) first")
+        if not (self._pipelined() and self.overlap_tail):
+            out = [self.step_events()[1:] for _ in range(n_steps)]
+            return [e for e, _ in out], [sw for _, sw in out]
+        self.refresh_weights()
+        ev_out, sw_out = [], []
+        none = (np.zeros(0, np.int64), np.zeros((0, 2), np.int64))
+
+        def finish(step_events):   # book-keeping of one completed step
+            ev_out.append(step_events[0])
+            sw_out.append(step_events[1])
+            self.grain_events.append(step_events[0])
+            self.switched.append(step_events[1])
+            self.steps_done += 1
+
+        K = max(1, int(self.EVENTS_UNROLL))
+        quiet_blocks = getattr(self, "_spec_quiet_blocks", 0)
+        blocks = []   # enqueued, unchecked: (slots, done event), oldest first
+        while len(ev_out) < n_steps:
+            in_flight = sum(len(b[0]) for b in blocks)
+            if len(blocks) < 2 and len(ev_out) + in_flight < n_steps:
+                self._spec_state()
+                self._ensure_edge_records()
+                size = min(K, 1 << min(quiet_blocks + len(blocks), 16))
+                size = min(size, K - self._spec["cur"] % K)   # blocks end on multiples of K: full blocks reuse two graphs
+                blocks.append(self._spec_launch(min(size, n_steps - len(ev_out) - in_flight)))
+                if len(blocks) < 2 and len(ev_out) + in_flight + len(blocks[-1][0]) < n_steps:
+                    continue   # keep one block queued behind the one whose counts are read
+            S = self._spec
+            slots, done = blocks.pop(0)
+            done.synchronize()
+            hit = next((i for i, sl in enumerate(slots) if int(S["evh"][sl][0]) or int(S["evh"][sl][1])), None)
+            if hit is None:
+                for _ in slots:
+                    finish(none)
+                quiet_blocks += 1
+                self._spec_quiet_blocks = quiet_blocks
+                continue
+            quiet_blocks = self._spec_quiet_blocks = 0
+            for _ in range(hit):
+                finish(none)
+            slot = slots[hit]
+            # the step of `slot` saw events: whatever was enqueued behind it is void
+            torch.cuda.current_stream().synchronize()
+            void = len(slots) - hit - 1 + sum(len(b[0]) for b in blocks)
+            blocks = []
+            if void:
+                nxt = S["xs"][(slot + 1) % S["D"]]
+                for nt in NODE_TYPES:
+                    self.x[nt].copy_(nxt[nt])                # x as the step behind found it (= after the eventful step)
+                self._spec_adopt(slot)
+                # the void steps refreshed the edge sets past this point: lengths and records are recomputed from x below
+                self._einfo_fresh = False
+            keep_centres = self.x["grain"][:, :2].clone()
+            self.x["grain"][:, :2].copy_(S["cen"][slot])     # the centres the events must see: before the refresh
+            def stands():   # the step stands as enqueued (its refresh ran on the unchanged topology)
+                self.x["grain"][:, :2].copy_(keep_centres)
+                if void:   # ... but its edge lengths were overwritten by the void steps: the same kernel on the same x
+                    self.be.step_refresh(self.x["joint"], self.x["grain"], self.zmax, self.flags,
+                                         [(self.graph.edge_index[et], self.x[et[0]], self.x[et[-1]], self.edge_attr[et])
+                                          for et in EDGE_TYPES])
+            try:
+                events, switches = self._apply_events()
+            except Exception:
+                # the host-side update refused the events (it leaves masks, coordinates and edge lists untouched): the step
+                # is kept as a quiet one, so that a caller who catches the error can go on from a consistent state
+                stands()
+                finish(none)
+                raise
+            if len(events) or len(switches):
+                self._quiet_steps = 0
+                self._run_segment("ref")                     # centres + edge lengths on the new topology
+                self._einfo_fresh = False
+            else:   # the device-side trigger was conservative
+                stands()
+            finish((events, switches))
+        return ev_out, sw_out
+
     def _apply_events(self):
         """Host round trip: read the predictions back, rewire, upload the new lists."""
         from .topology import update_topology

@@ -958,6 +958,51 @@ def test_event_rollout_reproduces_reference_trajectory(use_graph):
     assert bool(torch.isfinite(X["joint"]).all())
 
 
+@pytest.mark.parametrize("use_graph,chunks", [(True, (5,)), (True, (3, 2)), (False, (1, 4))])
+@torch.no_grad()
+def test_speculative_event_loop_equals_step_events(use_graph, chunks):
+    """GrainRollout.run_events (every step enqueued as if it had no events, the counts of step k - 1 read after step k is
+    enqueued, the step behind an eventful one discarded and x / centres / predictions taken back) against step_events,
+    which stops at every step: the seeded 40 um trajectory whose steps 3 and 4 eliminate 22 and 75 grains -- an eventful
+    step with a discarded step behind it, one that is the last of its call, quiet steps before and after -- must give
+    the same events, edge lists, masks and the same state bit for bit."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+    kw = dict(use_graph=use_graph, refresh_centres=True, joint_launches=False, concurrent=True)
+    Xa, Xb = tt(x, DEV), tt(x, DEV)
+    ra = GrainRollout(R, Cm, Xa, tt(ei, DEV), tt(ea, DEV), 6, **kw)
+    rb = GrainRollout(R, Cm, Xb, tt(ei, DEV), tt(ea, DEV), 6, **kw)
+    ra.enable_events(mask, 1e-4, 0.6)
+    rb.enable_events(mask, 1e-4, 0.6)
+    ev_a, sw_a = [], []
+    for _ in range(sum(chunks)):
+        _, e, sw = ra.step_events()
+        ev_a.append(e)
+        sw_a.append(sw)
+    ev_b, sw_b = [], []
+    for n in chunks:
+        e, sw = rb.run_events(n)
+        ev_b += e
+        sw_b += sw
+    torch.cuda.synchronize()
+    assert [len(e) for e in ev_a][:4] == [0, 0, 22, 75]
+    for k in range(sum(chunks)):
+        assert np.array_equal(ev_a[k], ev_b[k]) and np.array_equal(sw_a[k], sw_b[k]), k
+    for et in EDGE_TYPES:
+        assert torch.equal(ra.edge_index[et], rb.edge_index[et]), et
+        assert torch.equal(ra.edge_attr_dict()[et], rb.edge_attr_dict()[et]), et
+    assert np.array_equal(ra.mask["grain"], rb.mask["grain"]) and np.array_equal(ra.mask["joint"], rb.mask["joint"])
+    for nt in Xa:
+        assert torch.equal(Xa[nt], Xb[nt]), nt
+    last_quiet = len(ev_a[-1]) == 0 and len(sw_a[-1]) == 0
+    for k in ra.pred:   # (after an eventful step the per-edge buffers are fresh ones of the new size: nothing to compare)
+        if last_quiet or k not in ("edge_event", "edge"):
+            assert torch.equal(ra.pred[k], rb.pred[k]), (k, [len(e) for e in ev_a])
+    assert ra.steps_done == rb.steps_done == sum(chunks)
+
+
 @torch.no_grad()
 def test_detect_events_counts():
     be = backend()
