@@ -514,7 +514,8 @@ def train_step_records():
     script = os.path.join(ROOT, "tests", "bench_train_step.py")
     out = []
     for extra in (["--graph", "--ggnn-adam"], ["--graph", "--ggnn-adam", "--cfg3", "--roofline"],
-                  ["--graph", "--ggnn-adam", "--cfg3", "--bf16"], ["--graph", "--fused", "--cfg3"], ["--graph", "--cfg3"], ["--cfg3"]):
+                  ["--graph", "--ggnn-adam", "--cfg3", "--bf16"], ["--graph", "--ggnn-adam", "--cfg3", "--classifier"],
+                  ["--graph", "--fused", "--cfg3"], ["--graph", "--cfg3"], ["--cfg3"]):
         try:
             r = subprocess.run([sys.executable, script, "--no-cpu", "--json", "--steps", "20"] + extra,
                                capture_output=True, text=True, timeout=300)

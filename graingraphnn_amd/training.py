@@ -406,9 +406,12 @@ def regressor_loss_recorded(y_dict, pred, mask):
 def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
     """train.py:40-70 (edge_len off): BCE-with-logits over the labelled edges (label > -1)."""
     y, z = y_dict["edge_event"], pred["edge_event"]
-    keep = y > -1
-    return torch.nn.functional.binary_cross_entropy_with_logits(
-        z[keep], y[keep].to(z.dtype), pos_weight=torch.tensor(pos_weight, device=z.device, dtype=z.dtype))
+    # the mean over the labelled edges as a weighted sum over all of them: no boolean indexing (its size is data: a host
+    # synchronisation per step, and not capturable in a hipGraph); same value up to the order of the fp32 sum
+    keep = (y > -1).to(z.dtype)
+    per_edge = torch.nn.functional.binary_cross_entropy_with_logits(
+        z, y.clamp(min=0).to(z.dtype), pos_weight=z.new_full((), float(pos_weight)), reduction="none")   # (a fill, not a host copy: capturable)
+    return (per_edge * keep).sum() / keep.sum()
 
 
 class FusedAdam(torch.optim.Optimizer):

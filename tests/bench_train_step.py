@@ -20,24 +20,35 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from graingraphnn_amd import synthetic, training  # noqa: E402
-from graingraphnn_amd.models import GrainNN_regressor  # noqa: E402
+from graingraphnn_amd.models import GrainNN_classifier, GrainNN_regressor  # noqa: E402
 from graingraphnn_amd.seeding import load_seeded  # noqa: E402
 
 
-def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fused=False, whatif=()):
+def run(model, X, EI, EA, y, mask, steps, sync, autocast=False, graph=False, fused=False, whatif=(), stage="regressor"):
     """`whatif` (development): pieces left out to see what they cost -- "noopt" (no optimizer step), "sumloss" (the loss
     replaced by a plain sum of the predictions)."""
     model.train()
-    if fused == "ggnn":
-        opt = training.FusedAdam(model.parameters(), lr=5e-3)
+    if stage == "classifier":
+        # train.py:83-91 (classifier_transfered, parameters.py:97-134): three parameter groups with their own learning rates
+        params = [{"params": list(model.gclstm_encoder.parameters()), "lr": 2.5e-3 * 0.1 * 0.1},
+                  {"params": list(model.gclstm_decoder.parameters()), "lr": 2.5e-3 * 0.1},
+                  {"params": list(model.lin2.parameters())}]
+        lr = 2.5e-3
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=graph, **({"fused": True} if fused else {}))
+        params, lr = model.parameters(), 5e-3
+    if fused == "ggnn":
+        opt = training.FusedAdam(params, lr=lr)
+    else:
+        opt = torch.optim.Adam(params, lr=lr, capturable=graph, **({"fused": True} if fused else {}))
     losses = []
 
     def one():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             pred = model(X, EI, EA)
-            loss = (pred["joint"].sum() + pred["grain"].sum()) if "sumloss" in whatif else training.regressor_loss(y, pred, mask)
+            if stage == "classifier":
+                loss = training.classifier_loss(y, pred, 1.0)
+            else:
+                loss = (pred["joint"].sum() + pred["grain"].sum()) if "sumloss" in whatif else training.regressor_loss(y, pred, mask)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if "noopt" not in whatif:
@@ -149,6 +160,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--cfg3", action="store_true")
+    ap.add_argument("--classifier", action="store_true",
+                    help="the classifier stage (train.py:40-71, 83-91): BCE-with-logits on the edge events, three parameter groups")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     ap.add_argument("--fused", action="store_true", help="torch.optim.Adam(fused=True): 14 optimizer launches instead of ~40")
@@ -175,14 +188,23 @@ def main():
     X, EI, EA = synthetic.to_torch(x, ei, ea, dev)
     Y = {k: torch.from_numpy(v).to(dev) for k, v in y.items()}
     M = {k: torch.from_numpy(v).to(dev) for k, v in mask.items()}
+    stage = "classifier" if args.classifier else "regressor"
+    if args.classifier:
+        Cm = load_seeded(GrainNN_classifier(synthetic.default_hyper(dev), R), 1, 1.0).to(dev)
+        E = EI[("joint", "connect", "joint")].size(1)
+        lab = rs.randint(-1, 2, E).astype(np.float32)          # -1: unlabelled edge (train.py:46), 0 / 1: no event / event
+        Y = {"edge_event": torch.from_numpy(lab).to(dev)}
+        R = Cm
     dt, losses = run(R, X, EI, EA, Y, M, args.steps, torch.cuda.synchronize, args.bf16, args.graph, "ggnn" if args.ggnn_adam else args.fused,
-                     tuple(w for w in args.whatif.split(",") if w))
+                     tuple(w for w in args.whatif.split(",") if w), stage)
     if args.json:
         import json
         extra = {"kernel_rooflines": kernel_rooflines(R, X, EI, EA, Y, M, args.bf16)} if args.roofline else {}
         print(json.dumps({**extra, "workload": name, "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
                           "launch": "hipGraph replay (training.GraphedTrainStep recipe)" if args.graph else "eager",
-                          "what": "forward, loss (train.py:31-37), backward, Adam step of the regressor; " +
+                          "what": ("forward, loss (train.py:40-71: BCE with logits over the labelled edges), backward, Adam step (three "
+                                   "parameter groups, train.py:83-91) of the classifier; " if args.classifier else
+                                   "forward, loss (train.py:31-37), backward, Adam step of the regressor; ") +
                                   ("torch.autocast(bfloat16): the decoder projection in bf16 MFMA arithmetic "
                                    "(GGNN_PRECISION_BF16), sweeps / softmax / LSTM / gradients fp32" if args.bf16 else "fp32"),
                           "optimizer": "training.FusedAdam (ggnn_adam_step)" if args.ggnn_adam else "torch.optim.Adam(fused=True)" if args.fused else "torch.optim.Adam (default: foreach)",
