@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
-    "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows",
+    "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -165,6 +165,24 @@ class AdamArgs(Structure):
                 ("n_chunks", c_int32), ("n_tensors", c_int32), ("hyper", c_void_p)]
 
 
+GGNN_PACK_OUTPUTS = 9
+
+
+class PackArgs(Structure):
+    """Mirror of `ggnn_pack_args`."""
+    _fields_ = [("flat2", c_void_p), ("kq", c_void_p), ("kq_idx", c_void_p), ("idx3", c_void_p), ("packed", c_void_p),
+                ("n_flat", c_int64), ("zero", c_int64), ("n_packed", c_int64),
+                ("nb", c_int32), ("r", c_int32), ("c", c_int32), ("L", c_int32), ("coef", c_float), ("reserved", c_int32)]
+
+
+class PackBwdArgs(Structure):
+    """Mirror of `ggnn_pack_bwd_args`."""
+    _fields_ = [("fwd", PackArgs), ("g_out", c_void_p * GGNN_PACK_OUTPUTS), ("g_off", c_int64 * (GGNN_PACK_OUTPUTS + 1)),
+                ("g_w", c_int64 * GGNN_PACK_OUTPUTS), ("g_rs", c_int64 * GGNN_PACK_OUTPUTS), ("g_cs", c_int64 * GGNN_PACK_OUTPUTS),
+                ("inv", c_void_p), ("inv_kq", c_void_p), ("g_flat2", c_void_p), ("g_kq", c_void_p), ("g_flat", c_void_p),
+                ("n_flat2", c_int64), ("n_kq", c_int64), ("inv_m", c_int32), ("inv_kq_m", c_int32)]
+
+
 class MseArgs(Structure):
     """Mirror of `ggnn_mse_args`."""
     _fields_ = [("pred", c_void_p * GGNN_MSE_MAX_TERMS), ("target", c_void_p * GGNN_MSE_MAX_TERMS),
@@ -285,6 +303,10 @@ def _declare(lib):
     lib.ggnn_sum_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p]
     lib.ggnn_masked_mse.restype = c_int
     lib.ggnn_masked_mse.argtypes = [POINTER(MseArgs), c_void_p]
+    lib.ggnn_pack_weights.restype = c_int
+    lib.ggnn_pack_weights.argtypes = [POINTER(PackArgs), c_void_p]
+    lib.ggnn_pack_weights_backward.restype = c_int
+    lib.ggnn_pack_weights_backward.argtypes = [POINTER(PackBwdArgs), c_void_p]
     lib.ggnn_heads_regressor_backward.restype = c_int
     lib.ggnn_heads_regressor_backward.argtypes = [c_int64, c_int64] + [c_void_p] * 11
     lib.ggnn_heads_classifier.restype = c_int

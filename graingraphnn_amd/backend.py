@@ -541,6 +541,58 @@ class HipBackend:
         """ggnn_adam_step (include/ggnn.h) on a filled `_lib.AdamArgs` (training.FusedAdam builds it)."""
         self._launch(self.lib.ggnn_adam_step, "ggnn_adam_step", ctypes.byref(args), _lib.current_stream())
 
+    @staticmethod
+    def _pack_args(plan, flat2, kq, packed=None):
+        a = _lib.PackArgs()
+        a.flat2, a.kq, a.kq_idx, a.idx3 = flat2.data_ptr(), kq.data_ptr(), plan.kq_idx.data_ptr(), plan.idx3.data_ptr()
+        a.packed = 0 if packed is None else packed.data_ptr()
+        a.n_flat, a.zero, a.n_packed = plan.n_flat, plan.zero, plan.n_packed
+        a.nb, a.r, a.c, a.L = plan.mr_shape[0], plan.mr_shape[1], plan.mr_shape[2], plan.idx3.size(1)
+        a.coef = plan.k_coef
+        return a
+
+    def pack_weights(self, plan, flat2, kq, packed):
+        """ggnn_pack_weights: `flat2` [plan.n_flat2] holds the parameters in its first n_flat entries; fills the operands
+        `kq` [plan.n_kq], the products and `packed` [plan.n_packed] (train_pack._PackWeights)."""
+        _require_cuda(flat2, kq, packed)
+        if flat2.dtype != torch.float32 or packed.dtype != torch.float32 or kq.dtype != torch.float32 \
+                or flat2.numel() != plan.n_flat2 or kq.numel() != plan.n_kq or packed.numel() != plan.n_packed \
+                or not flat2.is_contiguous() or not packed.is_contiguous() or not kq.is_contiguous():
+            raise _lib.GGNNError("ggnn_pack_weights: flat2 [n_flat2], kq [n_kq] and packed [n_packed] must be contiguous float32")
+        a = self._pack_args(plan, flat2, kq, packed)
+        self._launch(self.lib.ggnn_pack_weights, "ggnn_pack_weights", ctypes.byref(a), _lib.current_stream())
+
+    def pack_weights_backward(self, plan, flat2, kq, grads, g_flat2, g_kq, g_flat):
+        """ggnn_pack_weights_backward: `grads` = the gradients of the nine packed outputs (None: zero), contiguous float32 of
+        plan.out_sizes; workspaces g_flat2 [n_flat2], g_kq [n_kq]; g_flat [n_flat] receives the parameters' gradient."""
+        _require_cuda(flat2, g_flat2, g_kq, g_flat, *[g for g in grads if g is not None])
+        if len(grads) != _lib.GGNN_PACK_OUTPUTS or g_flat2.numel() != plan.n_flat2 or g_kq.numel() != plan.n_kq \
+                or g_flat.numel() != plan.n_flat:
+            raise _lib.GGNNError("ggnn_pack_weights_backward: nine output gradients and workspaces of the plan's sizes")
+        b = _lib.PackBwdArgs()
+        b.fwd = self._pack_args(plan, flat2, kq)
+        b.fwd.packed = g_flat.data_ptr()   # (unused by the backward; must not be NULL)
+        off = 0
+        for s, (g, n) in enumerate(zip(grads, plan.out_sizes)):
+            if g is not None and (g.dtype != torch.float32 or g.numel() != n):
+                raise _lib.GGNNError("ggnn_pack_weights_backward: output gradients must be float32 of the outputs' sizes")
+            b.g_out[s] = None if g is None else g.data_ptr()
+            b.g_off[s] = off
+            off += n
+            if g is None or g.is_contiguous():
+                b.g_w[s], b.g_rs[s], b.g_cs[s] = max(n, 1), 0, 1
+            elif g.dim() == 2:          # a column block of a wider matrix (or of its transpose): read in place
+                b.g_w[s], b.g_rs[s], b.g_cs[s] = g.size(1), g.stride(0), g.stride(1)
+            elif g.dim() == 1:          # a column of a matrix
+                b.g_w[s], b.g_rs[s], b.g_cs[s] = 1, g.stride(0), 1
+            else:
+                raise _lib.GGNNError("ggnn_pack_weights_backward: a non-contiguous output gradient must be 1-D or 2-D")
+        b.g_off[_lib.GGNN_PACK_OUTPUTS] = off
+        b.inv, b.inv_kq = plan.inv.data_ptr(), plan.inv_kq.data_ptr()
+        b.g_flat2, b.g_kq, b.g_flat = g_flat2.data_ptr(), g_kq.data_ptr(), g_flat.data_ptr()
+        b.n_flat2, b.n_kq, b.inv_m, b.inv_kq_m = plan.n_flat2, plan.n_kq, plan.inv.size(1), plan.inv_kq.size(1)
+        self._launch(self.lib.ggnn_pack_weights_backward, "ggnn_pack_weights_backward", ctypes.byref(b), _lib.current_stream())
+
     def masked_mse(self, terms, scale, loss, want_grad=True):
         """ggnn_masked_mse: `terms` = [(pred, target, mask or None)], contiguous float32 CUDA tensors; mask has the shape
         of pred or one entry per leading row of it.  Returns the gradients [g_pred] (None each with want_grad=False)."""

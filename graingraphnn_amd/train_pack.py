@@ -217,7 +217,8 @@ class PackPlan:
         K_all[K_all < 0] = Z
         Q_all[Q_all < 0] = Z
         kq_idx = torch.cat([K_all.reshape(-1), Q_all.reshape(-1)])
-        kq_coef = torch.cat([torch.full((K_all.numel(),), 1.0 / math.sqrt(c)), torch.ones(Q_all.numel())])   # periodGATconv.py:226
+        self.k_coef = 1.0 / math.sqrt(c)                                                                       # periodGATconv.py:226
+        kq_coef = torch.cat([torch.full((K_all.numel(),), self.k_coef), torch.ones(Q_all.numel())])
         blank = lambda *key: torch.full_like(idx_of(*key), Z)
         fill = lambda *shape: torch.full(shape, Z)
         layers = []
@@ -285,14 +286,28 @@ class _PackWeights(torch.autograd.Function):
         dev = params[0].device
         flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
         torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
+        ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
+        ctx.set_materialize_grads(False)
+        if dev.type == "cuda":
+            # the device side in two launches (csrc/pack.hip): the products straight from the parameters through the
+            # operands' index tables, then the gather-sum -- where the recorded ops below are a fill, two gathers, a
+            # multiply, a library GEMM and a reduction
+            from .backend import default_backend
+            packed = torch.empty(plan.n_packed, dtype=torch.float32, device=dev)
+            kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
+            default_backend().pack_weights(plan, flat2, kq, packed)
+            ctx.hip = True
+            ctx.save_for_backward(kq)
+            ctx.flat2 = flat2   # (only its size and the zero slot's index matter to the backward: kept for the argument check)
+            outs = torch.split(packed, plan.out_sizes)
+            return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
+        ctx.hip = False
         flat2[plan.zero:].zero_()
         kq = flat2[plan.kq_idx] * plan.kq_coef
         torch.bmm(kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape),
                   out=flat2[plan.n_flat:plan.zero].view(plan.mr_shape))
         packed = flat2[plan.idx3].sum(1) if plan.idx3.size(1) > 1 else flat2[plan.idx3[:, 0]]
-        ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
         ctx.save_for_backward(kq)
-        ctx.set_materialize_grads(False)
         outs = torch.split(packed, plan.out_sizes)
         return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
 
@@ -302,6 +317,20 @@ class _PackWeights(torch.autograd.Function):
         plan = ctx.plan
         kq, = ctx.saved_tensors
         dev = kq.device
+        if ctx.hip:   # four launches (csrc/pack.hip) instead of ~12 recorded ops, two of them library GEMMs
+            from .backend import default_backend
+            flat2 = ctx.flat2
+            g_flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
+            g_kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
+            g_flat = torch.empty(plan.n_flat, dtype=torch.float32, device=dev)
+            # (the projection's weight and bias gradients arrive as column blocks of one [ncols, K + 1] product: read in place)
+            gs = [None if g is None else (g if g.is_contiguous() or g.dim() <= 2 else g.contiguous()) for g in grads]
+            default_backend().pack_weights_backward(plan, flat2, kq, gs, g_flat2, g_kq, g_flat)
+            outs = torch._foreach_mul([p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)], 1.0)
+            zeros = [g_flat.new_empty(sh) for sh in ctx.unused_shapes]
+            if zeros:
+                torch._foreach_zero_(zeros)
+            return (None, None, *outs, *zeros)
         g_packed = torch.empty(plan.n_packed + 1, dtype=torch.float32, device=dev)
         slots = [s.view(sh) for s, sh in zip(torch.split(g_packed[:plan.n_packed], plan.out_sizes), plan.out_shapes)]
         have = [(s, g) for s, g in zip(slots, grads) if g is not None]

@@ -599,6 +599,47 @@ int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
  * per edge type), in a fixed order.  in: [batch, n_rows, n_cols] contiguous, n_cols % 4 == 0, 16-byte aligned. */
 int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream);
 
+/* Training path: the nine packed weight matrices of a cell (projection weights and biases of both node types, relocation
+ * columns per edge type, gate weights: graingraphnn_amd/packing.py) from its parameters, differentiable -- the device side of
+ * train_pack._PackWeights.  The packing is described by index tables (train_pack.PackPlan): with
+ *   flat2 = [ the cell's parameters, concatenated (n_flat) | nb products [r, c] | one zero slot ],  zero = n_flat + nb r c,
+ * every packed entry is the sum of L elements of flat2 (idx3 [n_packed, L]; the index `zero` reads 0), and product b is
+ * (coef K_b) Q_b with K_b [r, 96], Q_b [96, c] themselves gathered from flat2: kq_idx = [K entries (nb r 96) | Q entries
+ * (nb 96 c)].  ggnn_pack_weights: the caller has written the parameters to flat2[0 .. n_flat); the call fills the products
+ * and `packed`.  ggnn_pack_weights_backward: g_out[s] = gradient of output s (NULL: zero), output s being
+ * packed[g_off[s] .. g_off[s + 1]); inv [n_flat2, inv_m] = the packed entries that read each element of flat2 (padding:
+ * n_packed), inv_kq [n_flat, inv_kq_m] = the operand entries that read each parameter (padding: n_kq = nb 96 (r + c));
+ * g_flat2 [n_flat2] and g_kq [n_kq] are workspaces, g_flat [n_flat] receives the parameters' gradient.  Plain fp32 fmas. */
+#define GGNN_PACK_OUTPUTS 9
+typedef struct ggnn_pack_args {
+  float* flat2;
+  float* kq;                /* [nb 96 (r + c)] the products' operands gathered from flat2 (K side x coef): written by the forward, read by the backward */
+  const int64_t* kq_idx;
+  const int64_t* idx3;
+  float* packed;
+  int64_t n_flat, zero, n_packed;
+  int32_t nb, r, c, L;
+  float coef;
+  int32_t reserved;
+} ggnn_pack_args;
+typedef struct ggnn_pack_bwd_args {
+  ggnn_pack_args fwd;                       /* as in the forward call (packed is not used) */
+  const float* g_out[GGNN_PACK_OUTPUTS];
+  int64_t g_off[GGNN_PACK_OUTPUTS + 1];
+  int64_t g_w[GGNN_PACK_OUTPUTS], g_rs[GGNN_PACK_OUTPUTS], g_cs[GGNN_PACK_OUTPUTS];   /* element e of output s = g_out[s][(e / w) rs + (e % w) cs]: a
+                                                                                         contiguous gradient is (w = its size, rs = 0, cs = 1), a column
+                                                                                         block of a wider matrix (w = its width, rs = the row stride) */
+  const int64_t* inv;
+  const int64_t* inv_kq;
+  float* g_flat2;
+  float* g_kq;
+  float* g_flat;
+  int64_t n_flat2, n_kq;
+  int32_t inv_m, inv_kq_m;
+} ggnn_pack_bwd_args;
+int ggnn_pack_weights(const ggnn_pack_args* args, ggnn_stream_t stream);
+int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_stream_t stream);
+
 /* Training path: torch.optim.Adam's update (train.py:82-91; amsgrad / maximize off) for up to GGNN_ADAM_MAX_TENSORS parameter
  * tensors in one launch.  `table` (DEVICE memory, n_tensors entries, built once) holds what is fixed: the addresses of a
  * parameter and its two moment buffers, its size, its parameter group.  Workgroup c of the launch updates elements

@@ -909,6 +909,45 @@ def test_index_table_packing_equals_the_recorded_torch_ops(encoder):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("encoder,width", [(True, 96), (False, 96)])
+def test_pack_kernels_equal_the_recorded_torch_ops_on_the_gpu(encoder, width):
+    """ggnn_pack_weights / ggnn_pack_weights_backward (csrc/pack.hip: the packing of a cell's parameters in two launches,
+    its backward in four) against the layout definition run as recorded torch ops on the same device: the packed matrices
+    (entries that are one parameter or a sum of parameters bit for bit, the product entries to fp32 rounding of a 96-term
+    sum) and the gradient of a random functional of all nine outputs with respect to every parameter.  (Narrow layers go
+    through the same kernels with zero-padded tables: test_hip_training_gradients_of_narrow_layers_match_the_oracle.)"""
+    from graingraphnn_amd import train_pack
+    R = product_models(123, 1.0, "cuda")[0] if width == 96 else _narrow_models(width, 123, "cuda")[0][0]
+    cell = (R.gclstm_encoder if encoder else R.gclstm_decoder).cell_list[0]
+    gates, sees_h = ("ico", False) if encoder else ("ifco", True)
+    F = cell.in_channels_dict
+    g = torch.Generator().manual_seed(5)
+    res = {}
+    for name, fn in (("hip", train_pack.packed_weights), ("ops", train_pack.packed_weights_ops)):
+        R.zero_grad()
+        layout, wp, bp, ep, w2 = fn(cell, gates, F, sees_h)
+        outs = train_pack._outputs_in_order(wp, bp, ep, w2)
+        if name == "hip":
+            probes = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+        res[name] = ([o.detach().clone() for o in outs],
+                     {n: (None if p.grad is None else p.grad.clone()) for n, p in cell.named_parameters()})
+    for a, b in zip(res["hip"][0], res["ops"][0]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6)
+    n_checked = 0
+    for n, gt in res["hip"][1].items():
+        go = res["ops"][1][n]
+        if encoder and (n.startswith("conv_f.") or n.startswith("b_f.")):
+            assert gt is not None and not bool(gt.any()), n
+            continue
+        assert gt is not None and go is not None, n
+        assert float((gt - go).abs().max()) <= 2e-6 * max(float(go.abs().max()), 1e-6) + 1e-7, n
+        n_checked += 1
+    assert n_checked >= 100
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("G", [4, 3])
 def test_lstm_train_kernels_against_autograd_of_the_update(G):
     """ggnn_lstm_train_forward / _backward through the C ABI against torch autograd of heteropgclstm.py:140-183's
