@@ -124,6 +124,7 @@ class GrainRollout:
             self._pack_weights()
             self._graphs = None
             self._graph_fwd = self._graph_ref = None
+            self._spec = None   # (run_events' captured blocks hold the old buffers' addresses too)
 
     def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
