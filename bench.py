@@ -741,7 +741,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "replicas": world, "launch": ("eager" if args.no_graph else f"hipGraph replay ({ro.RUN_UNROLL} steps per graph)") + (", R+C in the same launches" if ro.joint_launches else
                                   ", R|C on two streams" if ro.concurrent else ", R then C on one stream"),
-                       "decoder_plan": ("one kernel per decoder cell (ggnn_decoder_cell_batch)"
+                       "decoder_plan": (("one kernel per decoder cell (ggnn_decoder_cell_batch)"
+                                         if X["joint"].size(0) >= getattr(default_backend(), "fused_decoder_min_joints", 0) else
+                                         f"projection + sweeps + gate GEMM: fewer than {default_backend().fused_decoder_min_joints} junctions "
+                                         "(the fused cell is the plan of the larger graphs; GGNN_DEC=fused forces it)")
                                         if getattr(default_backend(), "fused_decoder", False) is True else
                                         f"fused_decoder={getattr(default_backend(), 'fused_decoder', False)!r}: projection + sweeps + gate "
                                         "GEMM where not fused (GGNN_DEC)"),

@@ -38,6 +38,7 @@ def _f32c(t, name):
 
 class HipBackend:
     name = "hip"
+    FUSED_DECODER_MIN_JOINTS = 6000
 
     def __init__(self):
         self.lib = _lib.load()
@@ -51,10 +52,18 @@ class HipBackend:
         # The decoder cell of a model: ONE kernel (ggnn_decoder_cell_batch, the default with the bf16 / fp16 matrix-core
         # GEMM mode) or projection + sweeps + gate GEMM (GGNN_DEC=split; always under GGNN_GEMM=fp32).
         # GGNN_DEC=fused-classifier / fused-regressor: the fused cell for that model only (development).
-        dec = os.environ.get("GGNN_DEC", "fused")
+        # By default (GGNN_DEC unset) the plan follows the graph's size (engine.run_cells): a fused cell is one dependent
+        # chain of ~110 us per 16-node tile however few tiles there are, so below FUSED_DECODER_MIN_JOINTS junctions the
+        # three short kernels win (1 043-grain fixture: 8 080 vs 5 620 steps/s; 64 x 118 grains batched: 205 k vs 220 k
+        # trajectory-steps/s; 10 000 grains: 2 380 vs 2 920 steps/s).  GGNN_DEC=fused: the fused cell whatever the size.
+        dec = os.environ.get("GGNN_DEC", "auto")
         self.fused_decoder = False
-        if self.lib.ggnn_gemm_mode() == 1 and dec.startswith("fused"):
-            self.fused_decoder = {"fused": True, "fused-classifier": "classifier", "fused-regressor": "regressor"}.get(dec, False)
+        self.fused_decoder_min_joints = 0
+        if self.lib.ggnn_gemm_mode() == 1 and (dec == "auto" or dec.startswith("fused")):
+            self.fused_decoder = {"auto": True, "fused": True, "fused-classifier": "classifier",
+                                  "fused-regressor": "regressor"}.get(dec, False)
+            if dec == "auto":
+                self.fused_decoder_min_joints = int(os.environ.get("GGNN_DEC_MIN_JOINTS", str(self.FUSED_DECODER_MIN_JOINTS)))
 
     def f16_projection(self) -> bool:
         """The fused decoder plan's value projection in the cells' three-product arithmetic (GGNN_PRECISION_F16X2) when the

@@ -129,6 +129,8 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
         fd = getattr(backend, "fused_decoder", False)
         if fd not in (False, True):   # one model's decoder only: the classifier's has one live destination type
             fd = fd == ("classifier" if sum(bool(lay[nt].live) for nt in NODE_TYPES) == 1 else "regressor")
+        if fd and x["joint"].size(0) < getattr(backend, "fused_decoder_min_joints", 0):
+            fd = False   # a small graph: three short kernels beat one long dependent chain per tile (backend.py)
         if pc.dcs and fd:
             # decoder: everything on the destination side in one kernel (ggnn_decoder_cell_batch); the projection only
             # emits the source-side value rows

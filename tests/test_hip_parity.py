@@ -380,6 +380,25 @@ def test_three_kernel_decoder_plan_in_a_subprocess():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_fused_decoder_plan_on_the_fixtures_in_a_subprocess():
+    """By default the decoder plan follows the graph's size (backend.FUSED_DECODER_MIN_JOINTS: the fixtures of the golden
+    tests run the three-kernel plan, the 10k-grain tests the fused cell).  GGNN_DEC=fused forces the fused decoder cell
+    whatever the size: the cell, forward and rollout goldens and the launch-tape test once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GGNN_DEC") == "fused":
+        assert backend().fused_decoder is True and backend().fused_decoder_min_joints == 0
+        return
+    if backend().lib.ggnn_gemm_mode() == 1 and "GGNN_DEC" not in os.environ:
+        assert backend().fused_decoder is True and backend().fused_decoder_min_joints == backend().FUSED_DECODER_MIN_JOINTS
+    env = dict(os.environ, GGNN_DEC="fused")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "cell_golden or forward_golden or rollout_golden or tape or fused_decoder_plan or ragged or tiny"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------
 # op level: PeriodConv and HeteroPGCLSTM against the reference's golden vectors (cfg1)
 # ---------------------------------------------------------------------------------------
@@ -1792,7 +1811,9 @@ def test_forward_launch_tape_tracks_inputs_weights_and_topology():
         # second forward -- the classifier's first call -- and is part of the tape key, so the regressor's tape of
         # step 0 (recorded with the estimate) is recorded again at step 1; results are the same either way.
         # (the fused decoder cell -- the default plan -- is projection + one kernel instead of projection + sweeps + gates)
-        n_launches = 7 - (2 if be.fused_encoder else 0) - (1 if be.fused_decoder else 0)
+        # (... when it runs: by default only from backend.fused_decoder_min_joints junctions on)
+        fused_dec = bool(be.fused_decoder) and X["joint"].size(0) >= be.fused_decoder_min_joints
+        n_launches = 7 - (2 if be.fused_encoder else 0) - (1 if fused_dec else 0)
         assert replays == [n_launches] * 6, replays
         # new weights -> the tape is dropped and re-recorded
         R.linear["joint"].bias.add_(0.5)
