@@ -194,7 +194,7 @@ class EventTimedBackend:
         # (sweeps [(csr, einfo, h_src, v_src, v_off, ep)], x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
         flops = nbytes = canon = 0.0
         n_sweeps = 0
-        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
+        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out, *_ in problems:
             n, n_in = x_dst.size(0), len(sweeps)
             flops += 2.0 * n * 4 * (n_in * (128 * 112 + 98 * 96) + 128 * 96)
             nbytes += 4.0 * n * (x_dst.size(1) + 96 + 96 + 2 * 96) + 2.0 * wstream.numel()

@@ -229,7 +229,7 @@ class HipBackend:
         node type) problems in one launch.  Each item: (sweeps, x_dst, wstream, w2_tail, h_out, c_out) with sweeps =
         [(csr, einfo)] for the 1 or 2 incoming edge types; wstream / w2_tail: packing.encoder_cell_stream."""
         arr = (EncCellArgs * len(problems))()
-        for a, (sweeps, x_dst, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
+        for a, (sweeps, x_dst, wstream, w2_tail, h_out, c_out, *rest) in zip(arr, problems):
             _require_cuda(x_dst, wstream, w2_tail, h_out, c_out)
             n, n_in = x_dst.size(0), len(sweeps)
             for t, name in ((x_dst, "x_dst"), (h_out, "h_out"), (c_out, "c_out"), (w2_tail, "w2_tail")):
@@ -255,7 +255,8 @@ class HipBackend:
                 sw.rowptr, sw.einfo, sw.E = csr.rowptr.data_ptr(), einfo.data_ptr(), csr.E
             a.x_dst, a.h_out, a.c_out = x_dst.data_ptr(), h_out.data_ptr(), c_out.data_ptr()
             a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()
-            a.flags = self.range_flag(x_dst.device).data_ptr()
+            # (optional last element of a problem: the caller's own flag word -- a rollout's -- instead of the device-wide one)
+            a.flags = (rest[0] if rest and rest[0] is not None else self.range_flag(x_dst.device)).data_ptr()
             a.n_dst, a.ldx, a.n_in, a.f_dst = n, x_dst.stride(0), n_in, x_dst.size(1)
         self._launch(self.lib.ggnn_encoder_cell_batch, "ggnn_encoder_cell_batch", arr, len(problems),
                      _lib.current_stream())
@@ -271,11 +272,12 @@ class HipBackend:
             flag = self._range_flags[key] = torch.zeros(1, dtype=torch.int32, device=key)
         return flag
 
-    def range_exceeded(self, device="cuda", clear=True) -> bool:
+    def range_exceeded(self, device="cuda", clear=True, flag=None) -> bool:
         """True when a fused cell has clamped an activation to fp16's range since the flag was last cleared: its
         results are then NOT the reference's (re-run with GGNN_DEC=split / GGNN_ENC=split, whose bf16 x 3 split
-        covers fp32's range).  One host sync."""
-        flag = self.range_flag(device)
+        covers fp32's range).  One host sync.  `flag`: a caller's own word (GrainRollout keeps one per rollout, so that
+        two rollouts on a device do not consume each other's reports); default: the device-wide word."""
+        flag = self.range_flag(device) if flag is None else flag
         hit = bool(int(flag.item()) & _lib.GGNN_FLAG_F16_RANGE)
         if hit and clear:
             flag.zero_()
@@ -287,7 +289,7 @@ class HipBackend:
         sweeps = [(csr, einfo, h_src, v_src, v_off, edge_params)] for the 1 or 2 incoming edge types; wstream /
         w2_tail: packing.decoder_cell_stream."""
         arr = (DecCellArgs * len(problems))()
-        for a, (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out) in zip(arr, problems):
+        for a, (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out, *rest) in zip(arr, problems):
             _require_cuda(x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
             n, n_in = x_dst.size(0), len(sweeps)
             for t, name in ((x_dst, "x_dst"), (h_dst, "h_dst"), (c_in, "c_in"), (h_out, "h_out"), (c_out, "c_out"),
@@ -327,7 +329,8 @@ class HipBackend:
             a.x_dst, a.h_dst, a.c_in = x_dst.data_ptr(), h_dst.data_ptr(), c_in.data_ptr()
             a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
             a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()
-            a.flags = self.range_flag(x_dst.device).data_ptr()
+            # (optional last element of a problem: the caller's own flag word -- a rollout's -- instead of the device-wide one)
+            a.flags = (rest[0] if rest and rest[0] is not None else self.range_flag(x_dst.device)).data_ptr()
             a.n_dst, a.ldx, a.ldh, a.n_in, a.f_dst = n, x_dst.stride(0), h_dst.stride(0), n_in, x_dst.size(1)
         self._launch(self.lib.ggnn_decoder_cell_batch, "ggnn_decoder_cell_batch", arr, len(problems),
                      _lib.current_stream())

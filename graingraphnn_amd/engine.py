@@ -107,7 +107,7 @@ def prepare_edges(backend, graph: GraphCSR, x: Dict[str, torch.Tensor],
 
 
 def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo: Dict[ET, torch.Tensor],
-              after_projection=None, after_sweeps=None):
+              after_projection=None, after_sweeps=None, range_flag=None):
     """One HeteroPGCLSTM.forward for every entry of `cells` -- (pc, h_in, c_in, proj, agg, h_out,
     c_out), the same cell (encoder or decoder) of one or more models on the same graph, x and edge
     geometry (test.py:382-383 runs the regressor and the classifier on the same x_dict) -- in THREE
@@ -116,6 +116,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     launch of the cell that reads x (the projection; with the fused decoder cell, that kernel) and `after_sweeps`
     behind the last launch that reads the edge records (a caller may record stream events there)."""
     projs, sweeps, enc_sweeps, gates, enc_cells, dec_cells = [], [], [], [], [], []
+    flag = () if range_flag is None else (range_flag,)   # the caller's own range-flag word for the fused cells
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
         if pc.ecs and getattr(backend, "fused_encoder", False):
@@ -124,7 +125,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
             for nt in NODE_TYPES:
                 if lay[nt].live:
                     enc_cells.append(([(graph.csr[et], einfo[et]) for et in lay[nt].dst_ets], x[nt], pc.ecs[nt],
-                                      pc.ect[nt], h_out[nt], c_out[nt]))
+                                      pc.ect[nt], h_out[nt], c_out[nt], *flag))
             continue
         fd = getattr(backend, "fused_decoder", False)
         if fd not in (False, True):   # one model's decoder only: the classifier's has one live destination type
@@ -142,7 +143,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                 if lay[nt].live:
                     dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
                                        for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
-                                      h_out[nt], c_out[nt]))
+                                      h_out[nt], c_out[nt], *flag))
             continue
         for nt in NODE_TYPES:
             P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
@@ -211,9 +212,10 @@ def run_encoder_decoder_multi(backend, models, graph: GraphCSR, x: Dict[str, tor
                               einfo: Dict[ET, torch.Tensor], x_read=None, einfo_read=None):
     """The encoder cells of all `models` = [(enc, dec, workspace), ...] in three launches, then
     their decoder cells in three more (every model keeps its own weights, workspace and state)."""
+    flag = getattr(models[0][2], "range_flag", None)   # (models launched together belong to one rollout: one word)
     run_cells(backend, [(enc, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1) for enc, _, ws in models],
-              graph, x, einfo)
+              graph, x, einfo, range_flag=flag)
     # (x_read / einfo_read: called once the last launch that reads x -- the decoder projection -- / the edge
     # records -- the decoder sweeps -- is enqueued)
     run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2) for _, dec, ws in models],
-              graph, x, einfo, after_projection=x_read, after_sweeps=einfo_read)
+              graph, x, einfo, after_projection=x_read, after_sweeps=einfo_read, range_flag=flag)

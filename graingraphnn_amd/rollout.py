@@ -65,8 +65,12 @@ class GrainRollout:
         self.packed = {}
         self.ws = {}
         self._pack_weights()
+        # this rollout's own range-flag word (include/ggnn.h, OPERAND RANGE): the fused cells of its launches report here,
+        # so that two rollouts on a device neither consume nor raise each other's reports
+        self._range_word = torch.zeros(1, dtype=torch.int32, device=dev)
         for name in ("R", "C"):
             self.ws[name] = Workspace(*self.packed[name], self.n_nodes, dev)
+            self.ws[name].range_flag = self._range_word
         nj, ng = self.n_nodes["joint"], self.n_nodes["grain"]
         f32 = dict(dtype=torch.float32, device=dev)
         self.pred.update({"joint": torch.empty(nj, 2, **f32), "grain": torch.empty(ng, 2, **f32),
@@ -756,7 +760,7 @@ class GrainRollout:
         """True when a fused cell has clamped an activation to fp16's range since the last check (include/ggnn.h,
         OPERAND RANGE): the trajectory since then is NOT the reference's -- re-run with GGNN_DEC=split GGNN_ENC=split.
         state() checks it (it synchronises anyway); one 4-byte read-back."""
-        return self.be.range_exceeded(self.x["joint"].device, clear)
+        return self.be.range_exceeded(self.x["joint"].device, clear, flag=self._range_word)
 
     def state(self):
         """Final state a caller gathers across ranks: joint xy and grain (area, extraV).  Raises when the fused

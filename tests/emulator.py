@@ -93,7 +93,7 @@ class TorchEmulatorBackend:
             assert not bool(v[:, :, 4:].any())
             return v[:, :, :4].reshape(-1, 16)
 
-        for sweeps, x_dst, wstream, w2_tail, h_out, c_out in problems:
+        for sweeps, x_dst, wstream, w2_tail, h_out, c_out, *_ in problems:
             n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
             from graingraphnn_amd.packing import DC_SLICE_I16
             assert wstream.numel() == 3 * (4 * n_in + 1) * DC_SLICE_I16 and tuple(w2_tail.shape) == (3, n_in, 6, 64)
@@ -232,7 +232,7 @@ class TorchEmulatorBackend:
         u_h | u4 = W1 [h | x | 1], the sweep, lin_l2 + (b_l2, w_edge) on the aggregates; then the skip block and the
         LSTM update.  Everything is computed from the DECODED weight stream, so a packing error shows up here."""
         self.calls = getattr(self, "calls", []) + ["decoder_cell_batch"]   # (which plan ran: test_decoder_plan_per_model)
-        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out in problems:
+        for sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out, *_ in problems:
             n, n_in, F = x_dst.size(0), len(sweeps), x_dst.size(1)
             from graingraphnn_amd.packing import DC_SLICE_I16
             assert wstream.numel() == 4 * (7 * n_in + 4) * DC_SLICE_I16 and tuple(w2_tail.shape) == (4, n_in, 6, 64)

@@ -380,6 +380,28 @@ def test_three_kernel_decoder_plan_in_a_subprocess():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@torch.no_grad()
+def test_a_rollout_reports_its_own_range_flag():
+    """Two rollouts on one device: an activation beyond fp16's range in one (include/ggnn.h, OPERAND RANGE) is reported by
+    THAT rollout's range_exceeded() / state() and by nobody else's -- the fused cells of a rollout's launches write the
+    rollout's own flag word, not the device-wide one."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    Xa, Xb = tt(x, DEV), tt(x, DEV)
+    ra = GrainRollout(R, Cm, Xa, tt(ei, DEV), tt(ea, DEV), 6)
+    rb = GrainRollout(R, Cm, Xb, tt(ei, DEV), tt(ea, DEV), 6)
+    backend().range_exceeded(DEV)                   # clear the device-wide word
+    Xa["joint"][17, 5] = 7.0e4                      # a feature beyond fp16's range (the encoder cell is fused at every size)
+    ra.step()
+    rb.step()
+    assert not rb.range_exceeded() and not backend().range_exceeded(DEV)
+    assert ra.range_exceeded(clear=False)
+    with pytest.raises(_lib.GGNNError):
+        ra.state()
+    rb.state()
+
+
 def test_fused_decoder_plan_on_the_fixtures_in_a_subprocess():
     """By default the decoder plan follows the graph's size (backend.FUSED_DECODER_MIN_JOINTS: the fixtures of the golden
     tests run the three-kernel plan, the 10k-grain tests the fused cell).  GGNN_DEC=fused forces the fused decoder cell
