@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 22
+#define GGNN_ABI_VERSION 21
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -425,19 +425,6 @@ typedef struct ggnn_dec_cell_args {
   int32_t n_in, f_dst;
 } ggnn_dec_cell_args;
 int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
-/* The same cell with the attention scores computed ONCE per edge for the four gates (csrc/dec_cell2.hip): phase A gathers a
- * source's hidden row and the edge record once per edge type and leaves the four raw scores of every edge in `score_ws`,
- * phase B gathers the value rows gate by gate.  Same operands and results up to the rounding of the softmax's order of
- * operations (alpha = exp(s - max) / sum applied per edge instead of one division of the sum per row); the weight stream
- * holds the same slices in another order with the rows of the score blocks / the columns of the lin_l2 blocks permuted:
- * packing.decoder_cell2_stream.
- *   score_ws[e] : [max(E_e, 1)][4] floats of scratch per incoming edge type, 16-byte aligned, private to the launch while
- *                 it runs (a launch on another stream needs its own). */
-typedef struct ggnn_dec_cell2_args {
-  ggnn_dec_cell_args cell;
-  float* score_ws[2];
-} ggnn_dec_cell2_args;
-int ggnn_decoder_cell2_batch(const ggnn_dec_cell2_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training path: C[b] = A[b] . W[b]^T (+ C_in[b]) for a TALL A and a SMALL W -- the gate GEMM of a cell
