@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 22
+GGNN_ABI_VERSION = 21
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -34,7 +34,6 @@ EXPORTED_SYMBOLS = (
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
     "ggnn_decoder_cell_batch",
-    "ggnn_decoder_cell2_batch",
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
@@ -264,8 +263,6 @@ def _declare(lib):
     lib.ggnn_encoder_cell_batch.argtypes = [POINTER(EncCellArgs), c_int, c_void_p]
     lib.ggnn_decoder_cell_batch.restype = c_int
     lib.ggnn_decoder_cell_batch.argtypes = [POINTER(DecCellArgs), c_int, c_void_p]
-    lib.ggnn_decoder_cell2_batch.restype = c_int
-    lib.ggnn_decoder_cell2_batch.argtypes = [POINTER(DecCellArgs), c_int, c_void_p]
     lib.ggnn_aggregate_bwd_partials.restype = c_int64
     lib.ggnn_aggregate_bwd_partials.argtypes = [c_int64]
     lib.ggnn_period_gat_aggregate_backward.restype = c_int

@@ -46,7 +46,6 @@ class HipBackend:
         self._range_flags = {}  # device -> int32 word the fp16 two-piece kernels report clamped activations in
         self._rowgemm_ws = {}   # (device, stream, bytes) -> weight-plane workspace of ggnn_rowgemm
         self._mse_ws = {}       # (device, stream) -> partial sums + arrival counter of ggnn_masked_mse
-        self.decoder_cell_variant = int(os.environ.get("GGNN_DC", "1"))   # 2: the phase-shifted cell (csrc/dec_cell2.hip)
         # encoder cell as ONE fused sweep + gate GEMM launch (ggnn_encoder_cell_batch; bf16x6 arithmetic
         # only).  GGNN_ENC=split keeps the sweep and the gate GEMM as separate launches (development).
         self.fused_encoder = (self.lib.ggnn_gemm_mode() == 1 and os.environ.get("GGNN_ENC", "") != "split")
@@ -290,19 +289,6 @@ class HipBackend:
         sweeps = [(csr, einfo, h_src, v_src, v_off, edge_params)] for the 1 or 2 incoming edge types; wstream /
         w2_tail: packing.decoder_cell_stream."""
         arr = (DecCellArgs * len(problems))()
-        self._fill_decoder_cells(arr, problems)
-        self._launch(self.lib.ggnn_decoder_cell_batch, "ggnn_decoder_cell_batch", arr, len(problems),
-                     _lib.current_stream())
-
-    def decoder_cell2_batch(self, problems):
-        """ggnn_decoder_cell2_batch (include/ggnn.h): decoder_cell_batch's problems with wstream / w2_tail from
-        packing.decoder_cell2_stream."""
-        arr = (DecCellArgs * len(problems))()
-        self._fill_decoder_cells(arr, problems)
-        self._launch(self.lib.ggnn_decoder_cell2_batch, "ggnn_decoder_cell2_batch", arr, len(problems),
-                     _lib.current_stream())
-
-    def _fill_decoder_cells(self, arr, problems):
         for a, (sweeps, x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out, *rest) in zip(arr, problems):
             _require_cuda(x_dst, h_dst, c_in, wstream, w2_tail, h_out, c_out)
             n, n_in = x_dst.size(0), len(sweeps)
@@ -346,6 +332,8 @@ class HipBackend:
             # (optional last element of a problem: the caller's own flag word -- a rollout's -- instead of the device-wide one)
             a.flags = (rest[0] if rest and rest[0] is not None else self.range_flag(x_dst.device)).data_ptr()
             a.n_dst, a.ldx, a.ldh, a.n_in, a.f_dst = n, x_dst.stride(0), h_dst.stride(0), n_in, x_dst.size(1)
+        self._launch(self.lib.ggnn_decoder_cell_batch, "ggnn_decoder_cell_batch", arr, len(problems),
+                     _lib.current_stream())
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
                            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None,

@@ -116,7 +116,6 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     launch of the cell that reads x (the projection; with the fused decoder cell, that kernel) and `after_sweeps`
     behind the last launch that reads the edge records (a caller may record stream events there)."""
     projs, sweeps, enc_sweeps, gates, enc_cells, dec_cells = [], [], [], [], [], []
-    dec_v2 = False
     flag = () if range_flag is None else (range_flag,)   # the caller's own range-flag word for the fused cells
     for pc, h_in, c_in, proj, agg, h_out, c_out in cells:
         lay = pc.layout
@@ -142,12 +141,9 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
                                   _lib.GGNN_PRECISION_F16X2 if pc.wpv_f16 and backend.f16_projection() else 0))
             for nt in NODE_TYPES:
                 if lay[nt].live:
-                    v2 = bool(pc.dcs2) and getattr(backend, "decoder_cell_variant", 1) == 2
                     dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
-                                       for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt],
-                                      pc.dcs2[nt] if v2 else pc.dcs[nt], pc.dct2[nt] if v2 else pc.dct[nt],
+                                       for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
                                       h_out[nt], c_out[nt], *flag))
-                    dec_v2 = v2
             continue
         for nt in NODE_TYPES:
             P = proj[nt][:, :lay[nt].ncols] if proj[nt].size(1) != lay[nt].ncols else proj[nt]
@@ -175,7 +171,7 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
     if sweeps:
         backend.aggregate_batch(sweeps)
     if dec_cells:
-        (backend.decoder_cell2_batch if dec_v2 else backend.decoder_cell_batch)(dec_cells)   # reads the destination nodes' features: x's last reader
+        backend.decoder_cell_batch(dec_cells)   # reads the destination nodes' features: x's last reader
         if after_projection is not None:
             after_projection()
     if after_sweeps is not None:

@@ -25,7 +25,6 @@ Layouts (C = 96, G = number of gates, F = features of the node type, Fp = roundu
       [lin_l2.weight of incoming edge type 0 | ... | (b_l2, w_edge) of type 0 | ...]
 """
 import math
-import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Tuple
 
@@ -133,8 +132,6 @@ class PackedCell:
     ect: Dict[str, torch.Tensor] = field(default_factory=dict)
     dcs: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_stream (int16)
     dct: Dict[str, torch.Tensor] = field(default_factory=dict)   # node type -> decoder_cell_tail [4, n_in, 6, 64]
-    dcs2: Dict[str, torch.Tensor] = field(default_factory=dict)  # ... of the phase-shifted cell (GGNN_DC=2)
-    dct2: Dict[str, torch.Tensor] = field(default_factory=dict)
 
 
 @torch.no_grad()
@@ -258,57 +255,6 @@ def decoder_cell_stream(wp, bp, w2, lay: "NodeLayout"):
     for d in range(n_in):
         for k in range(2):
             tail[:, d, :, k, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
-    return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
-
-
-# The phase-shifted decoder cell's layouts (include/ggnn.h, csrc/dec_cell2.hip).  Its sweep runs on a node's 96 channels spread
-# over the 16 lanes of a DPP row -- lane m owns channels 3 m ..+2 and 48 + 3 m ..+2 -- and P1 (tile rows as the A operand)
-# leaves column 16 nb + m of the score block in lane m: so row 16 nb + m of a P1 block is the score row of channel
-# DC_P1_ROW[16 nb + m] (the 16 u4 rows behind stay in place).  The aggregates return to the matrix layout through 0/1
-# selector MFMAs, which leave lane (node, k-group kq) with the channels of lanes 4 kq .. 4 kq + 3: column k = 32 ks + 8 kq + j
-# of a lin_l2 block multiplies aggregate channel DC_P3_COL[k].
-def _dc_channel(m: int, cc: int) -> int:
-    return 3 * m + cc if cc < 3 else 48 + 3 * m + cc - 3
-
-
-DC_P1_ROW = tuple(_dc_channel(i % 16, i // 16) for i in range(C)) + tuple(range(C, C + 16))
-DC_P3_COL = tuple(_dc_channel(4 * ((k % 32) // 8) + k % 4, 2 * (k // 32) + (k % 8) // 4) for k in range(C))
-assert sorted(DC_P1_ROW) == list(range(C + 16)) and sorted(DC_P3_COL) == list(range(C))
-
-
-@torch.no_grad()
-def decoder_cell2_stream(wp, bp, w2, lay: "NodeLayout"):
-    """`wstream` / `w2_tail` for ggnn_decoder_cell2_batch (include/ggnn.h): decoder_cell_stream's blocks in the same
-    order with the score rows and the lin_l2 columns permuted (DC_P1_ROW, DC_P3_COL); the tail meets sum alpha in
-    k-group 0 and sum alpha a_e in k-group 3."""
-    F, Fp, G = lay.F, lay.Fp, lay.G
-    assert G == 4 and wp.size(1) == Fp + C and F + 1 <= 16
-    n_in = len(lay.dst_ets)
-    p1 = torch.tensor(DC_P1_ROW, device=wp.device)
-    p3 = torch.tensor(DC_P3_COL, device=wp.device)
-
-    def block(rows, bias):
-        out = torch.zeros(rows.size(0), 128, dtype=torch.float32, device=wp.device)
-        out[:, :C] = rows[:, Fp:Fp + C]
-        out[:, C:C + F] = rows[:, :F]
-        out[:, C + F] = bias
-        return out
-
-    slices = []
-    for gi, g in enumerate(DC_GATE_ORDER):
-        for d, et in dc_edge_order(gi, lay.dst_ets):
-            u = slice(lay.u_off[et] + g * C, lay.u_off[et] + (g + 1) * C)
-            t = slice(lay.u4_off[et] + g * U4, lay.u4_off[et] + (g + 1) * U4)
-            slices.append(_plane_slices(block(torch.cat([wp[u], wp[t]]), torch.cat([bp[u], bp[t]]))[p1].contiguous()))
-            slices.append(_plane_slices(w2[g][:, d * C:(d + 1) * C][:, p3].contiguous()))
-        sk = slice(lay.s_off + g * C, lay.s_off + (g + 1) * C)
-        slices.append(_plane_slices(block(wp[sk], bp[sk])))
-    stream = torch.cat(slices).contiguous()
-    assert stream.size(0) == 4 * (7 * n_in + 4)
-    tail = torch.zeros(G, n_in, 6, 4, 16, dtype=torch.float32, device=wp.device)   # g e ct k m   (lane l = 16 k + m)
-    for d in range(n_in):
-        for k, slot in enumerate((0, 3)):
-            tail[:, d, :, slot, :] = w2[:, :, n_in * C + 2 * d + k].view(G, 6, 16)
     return stream.view(-1), tail.view(G, n_in, 6, 64).contiguous()
 
 
@@ -536,7 +482,7 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
                                                            {et: F_of[et[0]] for et in lay.dst_ets})
         except ValueError:   # a weight beyond fp16's range (or not finite): sweep + gate GEMM launches instead
             ecs, ect = {}, {}
-    wpv, bpv, vof, dcs, dct, dcs2, dct2 = {}, {}, {}, {}, {}, {}, {}
+    wpv, bpv, vof, dcs, dct = {}, {}, {}, {}, {}
     if k2 and all(F + 1 <= 16 for F in in_channels.values()):   # decoder: the fused cell's operands
         for nt in NODE_TYPES:
             lay = layout[nt]
@@ -550,14 +496,12 @@ def pack_cell(cell, in_channels: Dict[str, int], encoder: bool, edge_types=EDGE_
             for nt in NODE_TYPES:
                 if layout[nt].live:
                     dcs[nt], dct[nt] = decoder_cell_stream(wp[nt], bp[nt], w2[nt], layout[nt])
-                    if os.environ.get("GGNN_DC", "1") == "2":
-                        dcs2[nt], dct2[nt] = decoder_cell2_stream(wp[nt], bp[nt], w2[nt], layout[nt])
         except ValueError:   # a weight that is not finite or beyond fp16's range: the cell runs on the three-kernel
-            dcs, dct, dcs2, dct2 = {}, {}, {}, {}   # plan (projection + sweeps + gate GEMM, bf16 x 3: the full fp32 range, NaNs propagate)
+            dcs, dct = {}, {}   # plan (projection + sweeps + gate GEMM, bf16 x 3: the full fp32 range, NaNs propagate)
     # the value projection of the fused plan runs in the cells' arithmetic (three products) when its weights allow
     wpv_f16 = bool(dcs) and all(bool(torch.isfinite(w).all()) and float(w.abs().max()) < 65504.0 for w in wpv.values())
     return PackedCell(G=G, k2=k2, layout=layout, wp=wp, bp=bp, ep=ep, w2=w2, w2p=w2p, wvf=wvf, ecs=ecs, ect=ect,
-                      wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct, dcs2=dcs2, dct2=dct2, wpv_f16=wpv_f16)
+                      wpv=wpv, bpv=bpv, vof=vof, dcs=dcs, dct=dct, wpv_f16=wpv_f16)
 
 
 @torch.no_grad()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 22
+#define GGNN_ABI_VERSION 21
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -425,11 +425,6 @@ typedef struct ggnn_dec_cell_args {
   int32_t n_in, f_dst;
 } ggnn_dec_cell_args;
 int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
-/* The same cell with the two halves of a workgroup one program item apart (csrc/dec_cell2.hip): one half's GEMM block
- * runs beside the other half's sweep.  Same operands and results (bit for bit: the same operations in the same order per
- * node); the weight stream holds the same slices in the same order with the rows of the score blocks and the columns of
- * the lin_l2 blocks permuted and the tail in k-groups 0 | 3: packing.decoder_cell2_stream. */
-int ggnn_decoder_cell2_batch(const ggnn_dec_cell_args* args, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training path: C[b] = A[b] . W[b]^T (+ C_in[b]) for a TALL A and a SMALL W -- the gate GEMM of a cell

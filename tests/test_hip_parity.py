@@ -1703,59 +1703,6 @@ def test_fused_decoder_cell_against_its_contract(n_dst, ins, hub):
     assert torch.equal(keep[0], h) and torch.equal(keep[1], c)      # no atomics: bit-reproducible
 
 
-def _cell2_problem(prob):
-    """The problem of _dec_cell_problem with its weight stream permuted for ggnn_decoder_cell2_batch
-    (packing.decoder_cell2_stream's layout) -- index permutations of the int16 slice image, no arithmetic."""
-    from graingraphnn_amd.packing import DC_P1_ROW, DC_P3_COL, DC_SLICE_I16
-    sweeps, xd, h_dst, c_in, wstream, tail, h, c = prob[:8]
-    n_in = len(sweeps)
-    S = wstream.view(-1, DC_SLICE_I16)
-    dec = lambda sl, NB: sl[:, :NB * 1024].view(sl.size(0), NB, 2, 4, 16, 8).permute(2, 1, 4, 0, 3, 5).reshape(2, 16 * NB, -1)
-
-    def enc(pl):
-        P, rows, K = pl.shape
-        fr = pl.reshape(P, rows // 16, 16, K // 32, 4, 8).permute(3, 1, 0, 4, 2, 5).reshape(K // 32, -1)
-        out = torch.zeros(K // 32, DC_SLICE_I16, dtype=torch.int16, device=pl.device)
-        out[:, :fr.size(1)] = fr
-        return out
-    r1, c3 = torch.tensor(DC_P1_ROW, device=DEV), torch.tensor(DC_P3_COL, device=DEV)
-    out, s_ = [], 0
-    for gi in range(4):
-        for d in range(n_in):
-            out += [enc(dec(S[s_:s_ + 4], 7)[:, r1]), enc(dec(S[s_ + 4:s_ + 7], 6)[:, :, c3])]
-            s_ += 7
-        out.append(S[s_:s_ + 4])
-        s_ += 4
-    t4 = tail.view(4, n_in, 6, 4, 16)
-    t2 = torch.zeros_like(t4)
-    t2[:, :, :, 0], t2[:, :, :, 3] = t4[:, :, :, 0], t4[:, :, :, 1]
-    return (sweeps, xd, h_dst, c_in, torch.cat(out).contiguous().view(-1), t2.view(4, n_in, 6, 64).contiguous(),
-            torch.empty_like(h), torch.empty_like(c))
-
-
-@pytest.mark.parametrize("n_dst,ins,hub", [
-    (236, [(118, 11, 708), (236, 8, 708)], 0), (118, [(236, 8, 708)], 0),
-    (1, [(1, 11, 1)], 0), (5, [(9, 8, 11), (5, 8, 0)], 0), (17, [(30, 12, 60)], 0), (33, [(40, 8, 0), (33, 8, 0)], 0),
-    (50, [(70, 8, 400), (70, 11, 1300)], 37), (50, [(70, 11, 1300)], 900), (67, [(30, 8, 500)], 0),
-    (20000, [(10000, 11, 60000), (20000, 8, 60000)], 0), (10000, [(20000, 8, 60000)], 0)])
-@torch.no_grad()
-def test_phase_shifted_decoder_cell_equals_the_fused_cell(n_dst, ins, hub):
-    """ggnn_decoder_cell2_batch (the halves of a workgroup one program item apart, csrc/dec_cell2.hip) against
-    ggnn_decoder_cell_batch on the same weights: the contract test's shapes; bit-reproducible."""
-    be = backend()
-    rs = np.random.RandomState(n_dst + 7 * len(ins) + hub)
-    prob = _dec_cell_problem(be, rs, n_dst, ins, hub)
-    be.decoder_cell_batch([prob])
-    p2 = _cell2_problem(prob)
-    be.decoder_cell2_batch([p2])
-    assert_close(p2[6], prob[6], "phase-shifted decoder cell h", 1e-5, 1e-6)
-    assert_close(p2[7], prob[7], "phase-shifted decoder cell c", 1e-5, 1e-6)
-    keep = [p2[6].clone(), p2[7].clone()]
-    p2[6].fill_(float("nan")), p2[7].fill_(float("nan"))
-    be.decoder_cell2_batch([p2])
-    assert torch.equal(keep[0], p2[6]) and torch.equal(keep[1], p2[7])
-
-
 @torch.no_grad()
 def test_fused_decoder_cell_batch_of_four_equals_single_calls():
     """Four problems (two node types x two models) in one ggnn_decoder_cell_batch = four single calls."""

@@ -12,7 +12,7 @@ from graingraphnn_amd import _lib, synthetic
 if os.environ.get("GGNN_ABI"):   # timing an older build of the library (its results on this tree's stream image are not checked here)
     _lib.GGNN_ABI_VERSION = int(os.environ["GGNN_ABI"])
 from graingraphnn_amd.backend import default_backend
-from test_hip_parity import _cell2_problem, _dec_cell_problem
+from test_hip_parity import _dec_cell_problem
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
@@ -27,20 +27,16 @@ GJ, JG, JJ = synthetic.EDGE_TYPES
 EDGES = {2: [hei[GJ], hei[JJ]], 1: [hei[JG]]}
 mk = lambda n, ins: _dec_cell_problem(be, rs, n, ins, F_dst=8 if len(ins) == 2 else 11, edges=EDGES[len(ins)])
 pj, pg, pj2 = mk(*J), mk(*Gr), mk(*J)
-run = be.decoder_cell_batch
-if os.environ.get("GGNN_DC") == "2":   # the phase-shifted cell (csrc/dec_cell2.hip)
-    pj, pg, pj2 = _cell2_problem(pj), _cell2_problem(pg), _cell2_problem(pj2)
-    run = be.decoder_cell2_batch
 out = []
 for name, probs in (("regressor", [pj, pg]), ("classifier", [pj2]), ("both", [pj, pg, pj2])):
     for _ in range(3):
-        run(probs)
+        be.decoder_cell_batch(probs)
     torch.cuda.synchronize()
     ts = []
     for _ in range(a.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(probs)
+        be.decoder_cell_batch(probs)
         e1.record()
         e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)

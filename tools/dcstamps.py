@@ -10,9 +10,7 @@ import numpy as np
 import torch
 from graingraphnn_amd import _lib
 from graingraphnn_amd.backend import default_backend
-from test_hip_parity import _cell2_problem, _dec_cell_problem
-V2 = os.environ.get("GGNN_DC") == "2"   # the phase-shifted cell (csrc/dec_cell2.hip)
-SFX = "_dec2" if V2 else "_dec"
+from test_hip_parity import _dec_cell_problem
 
 SLOTS, WAVES = 20, 8192
 be = default_backend()
@@ -28,15 +26,13 @@ for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classi
                      ("regressor, random sources", [J, Gr])):
     probs = [_dec_cell_problem(be, rs, n, ins, F_dst=8 if len(ins) == 2 else 11,
                                edges=None if "random" in name else EDGES[len(ins)]) for n, ins in shapes]
-    if V2:
-        probs = [_cell2_problem(p) for p in probs]
     for _ in range(3):
         torch.cuda.synchronize()
-        assert getattr(lib, "ggnn_debug_stamps_clear" + SFX)() == 0
-        (be.decoder_cell2_batch if V2 else be.decoder_cell_batch)(probs)
+        assert lib.ggnn_debug_stamps_clear_dec() == 0
+        be.decoder_cell_batch(probs)
     torch.cuda.synchronize()
     buf = np.zeros(WAVES * SLOTS, dtype=np.uint64)
-    assert getattr(lib, "ggnn_debug_stamps" + SFX)(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.ggnn_debug_stamps_dec(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     st = buf.reshape(WAVES, SLOTS).astype(np.int64)
     st = st[st[:, 0] > 0]
     t0 = st[:, 0].min()
@@ -53,6 +49,6 @@ for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classi
         life = us(m[:, 16] - m[:, 0])
         print(f"  wave life        med {np.median(life):7.2f}  max {life.max():7.2f} us")
         for i, nm in ((5, "sum P1 (scores)"), (6, "sum P2 (sweep)"), (7, "sum P3 (lin_l2)"), (8, "sum P4 (skip)"),
-                      (9, "sum LSTM"), (12, "sum barriers passed in sweeps (cell2)"), (4, "  of which slice wait + barrier"), (11, "  of which slice DMA issue")):
+                      (9, "sum LSTM"), (4, "  of which slice wait + barrier"), (11, "  of which slice DMA issue")):
             r = us(m[:, i])
             print(f"  {nm:32s} med {np.median(r):7.2f}  max {r.max():7.2f} us")
