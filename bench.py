@@ -664,6 +664,13 @@ def main():
         ro.run(ro.RUN_UNROLL * settle)
         untimed_steps = args.warmup + ro.RUN_UNROLL * settle
     gather_states(ro.state(), world)  # warm-up of the collective too (communicator set-up is lazy)
+    if not args.events and os.environ.get("GGNN_BENCH_PREROLL", "1") != "0":
+        # the first gather sets up host buffers (and the communicator) while the GPU idles for milliseconds; one more
+        # untimed replay + gather puts the device where every later region finds it (the first 20-step region measured
+        # 4-5 % below its own back-to-back repeats without it, on every box); counted in config.untimed_steps
+        ro.run(ro.RUN_UNROLL)
+        gather_states(ro.state(), world)
+        untimed_steps += ro.RUN_UNROLL
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
