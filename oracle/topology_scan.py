@@ -1,22 +1,16 @@
-"""Event-driven topology update of the grain graph, host side.
+"""TEST INFRASTRUCTURE (oracle): the event-driven topology update of the grain graph with the reference's own
+FULL-ARRAY SCANS -- every lookup is a mask over a whole edge list, as models.py writes it.  This was the product's
+implementation until round 5; the product (graingraphnn_amd/topology.py) now answers the same lookups from column indices
+and is checked against this file on large random event sequences (tests/test_topology.py), both against the reference's
+golden vectors.  Only tests may import it.
 
 Restates `GrainNN_classifier.update` of the reference (models.py:612-842 with its helpers
 `delete_grain_index` :861-893, `switching_edge_index` :896-1051, `point_in_triangle` :1055-1070,
 `periodic_move` :1103-1106) for the periodic, nucleation-free configuration every shipped script
-runs (test.py:88 `--nucleation_density 0`).  It is integer / index work on a few edges per event
-and inherently sequential (every event rewires the lists the next one reads), so it runs on the
-host on numpy arrays between device steps; the device side only sees new `edge_index` tensors,
-for which `engine.graph_for` rebuilds the CSR.
-
-The reference answers every lookup ("the columns whose source is p", "the junctions of grain g",
-"grains left with two junctions") with a mask over a WHOLE edge list -- some forty scans per
-eliminated grain, 57-75 ms of an eventful step at the 10k-grain graph (tools/probes/evstep.py).
-Here the lookups are answered from COLUMN INDICES (`_ColumnIndex`: columns grouped by value once
-per call with one stable argsort, later rewrites kept in a side table, every answer filtered by
-the list's current content) and a running count of columns per grain: the work of an event is
-proportional to the degree of what it touches.  Same answers in the same (increasing column)
-order, so the results are the scan formulation's bit for bit (oracle/topology_scan.py, kept as
-the test oracle, and the reference's golden vectors).
+runs (test.py:88 `--nucleation_density 0`).  It is integer / index work on a few hundred edges
+per event and inherently sequential (every event rewires the lists the next one reads), so it
+runs on the host on numpy arrays between device steps; the device side only sees new
+`edge_index` tensors, for which `engine.graph_for` rebuilds the CSR.
 
 Bit-exactness contract (tests/golden/golden_cfg1_events.npz, produced by the unmodified
 reference): identical `edge_index` COLUMN ORDER (edges are rewritten in place, new edges are
@@ -25,7 +19,7 @@ fp32 junction coordinates.  Reference behaviours that look accidental are kept b
 trained models were run with them, each marked KEEP below.
 """
 from itertools import combinations
-from typing import Dict, List, Optional, Sequence, Set, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -55,35 +49,6 @@ class TopologyError(RuntimeError):
     """The lists are not a valid grain graph (the reference asserts / raises KeyError here)."""
 
 
-class _ColumnIndex:
-    """`cols(row, v)`: the columns c with row[c] == v, in increasing order -- what `np.flatnonzero(row == v)` returns --
-    without scanning `row`.  Built from the row's content at the start of a call (columns grouped by value: one stable
-    argsort); a column that is REWRITTEN to v afterwards, or appended with value v, is noted in a side table; every answer
-    is filtered by the row's current content, so overwritten and dead columns drop out by themselves."""
-
-    def __init__(self, row: np.ndarray):
-        n_keys = int(row.max()) + 1 if row.size else 0
-        if row.size and int(row.min()) < 0:
-            raise TopologyError("negative node index in an edge list")
-        # columns grouped by value, increasing inside a group: the keys value * E + column are distinct, so any sort of
-        # them is the stable sort by value (numpy's vectorised int64 sort: 1 ms for 60 000 columns, a stable argsort 5)
-        self.order = np.argsort(row * np.int64(row.size) + np.arange(row.size, dtype=np.int64))
-        self.start = np.zeros(n_keys + 1, dtype=np.int64)
-        np.cumsum(np.bincount(row, minlength=n_keys), out=self.start[1:])
-        self.later: Dict[int, Set[int]] = {}
-
-    def note(self, col: int, v: int) -> None:
-        self.later.setdefault(int(v), set()).add(int(col))
-
-    def cols(self, row: np.ndarray, v: int) -> List[int]:
-        v = int(v)
-        base = self.order[self.start[v]:self.start[v + 1]].tolist() if 0 <= v < len(self.start) - 1 else []
-        late = self.later.get(v)
-        if late:
-            base = sorted(set(base) | late)
-        return [c for c in base if row[c] == v]
-
-
 class GrainTopology:
     """Mutable junction-junction (`pp`) and junction-grain (`pq`) edge lists of one graph."""
 
@@ -94,84 +59,46 @@ class GrainTopology:
         self.xj, self.yj = x_joint, y_joint          # fp32, modified in place
         self.mask_grain, self.mask_joint = mask_grain, mask_joint
         self.active = None if active_joints is None else set(int(v) for v in active_joints)
-        self._pp0, self._pp1 = _ColumnIndex(self.pp[0]), _ColumnIndex(self.pp[1])
-        self._pq0, self._pq1 = _ColumnIndex(self.pq[0]), _ColumnIndex(self.pq[1])
-        # columns per grain (the counts of np.unique(pq[1])) and the grains that are down to one or two
-        self._n_of_grain = np.bincount(self.pq[1]).astype(np.int64) if self.pq.shape[1] else np.zeros(0, np.int64)
-        self._few: Set[int] = set(np.flatnonzero((self._n_of_grain >= 1) & (self._n_of_grain <= 2)).tolist())
-        self._n_dead = 0
 
     # -- lookups (column order is the reference's `.nonzero()` order) -------------------------
     def joints_of(self, grain: int) -> np.ndarray:
-        return self.pq[0, self._pq1.cols(self.pq[1], grain)]
+        return self.pq[0, self.pq[1] == grain]
 
     def pq_cols_of_joint(self, joint: int) -> np.ndarray:
-        return np.asarray(self._pq0.cols(self.pq[0], joint), dtype=np.int64)
+        return np.flatnonzero(self.pq[0] == joint)
 
     def has_pq(self, joint: int, grain: int) -> bool:
-        return any(self.pq[1, c] == grain for c in self._pq0.cols(self.pq[0], joint))
+        return bool(np.any((self.pq[0] == joint) & (self.pq[1] == grain)))
 
     def is_active(self, joint: int) -> bool:
         return self.active is None or int(joint) in self.active
-
-    def _out_cols(self, p: int) -> List[int]:
-        """Columns of pp whose source is p."""
-        return self._pp0.cols(self.pp[0], p)
-
-    # -- writes that the indices and the per-grain counts follow ----------------------------------
-    def _recount(self, grain: int, by: int) -> None:
-        n = self._n_of_grain[grain] = self._n_of_grain[grain] + by
-        if 1 <= n <= 2:
-            self._few.add(int(grain))
-        else:
-            self._few.discard(int(grain))
-
-    def _set_grain(self, col: int, grain: int) -> None:
-        self._recount(int(self.pq[1, col]), -1)
-        self.pq[1, col] = grain
-        self._recount(int(grain), +1)
-        self._pq1.note(col, grain)
-
-    def _kill_pq(self, cols: Sequence[int]) -> None:
-        for c in cols:
-            self._recount(int(self.pq[1, c]), -1)
-            self._n_dead += 1
-            self.pq[:, c] = DEAD
 
     # -- models.py:861-893 -------------------------------------------------------------------
     def remove_two_sided_grain(self, grain: int) -> None:
         """A grain reduced to two junctions disappears: its junctions p1, p2 die and their two
         outer neighbours are joined by a new edge pair appended at the end."""
-        if grain == DEAD:
-            # (np.unique in the reference counts the dead marker like a grain; with one or two dead columns it would be
-            # "removed" here -- never the case once a grain is gone, which kills at least eight columns)
-            raise TopologyError("the dead-column marker was counted as a two-sided grain")
         corners = self.joints_of(grain)
         if len(corners) != 2:
             raise TopologyError(f"grain {grain} has {len(corners)} junctions, expected 2")
         p1, p2 = int(corners[0]), int(corners[1])
         pp = self.pp
-        try:
-            n1 = int(next(pp[1, c] for c in self._out_cols(p1) if pp[1, c] != p2))
-            n2 = int(next(pp[1, c] for c in self._out_cols(p2) if pp[1, c] != p1))
-        except StopIteration:
-            raise TopologyError(f"junctions {p1}, {p2} of grain {grain} have no outer neighbour") from None
-        E = pp.shape[1]
+        n1 = int(pp[1, (pp[0] == p1) & (pp[1] != p2)][0])
+        n2 = int(pp[1, (pp[0] == p2) & (pp[1] != p1)][0])
         self.pp = pp = np.concatenate([pp, np.array([[n1, n2], [n2, n1]], dtype=np.int64)], axis=1)
-        self._pp0.note(E, n1), self._pp1.note(E, n2), self._pp0.note(E + 1, n2), self._pp1.note(E + 1, n1)
         self.mask_grain[grain] = 0
         self.mask_joint[p1] = 0
         self.mask_joint[p2] = 0
-        self._kill_pq(self._pq1.cols(self.pq[1], grain))
+        self.pq[:, self.pq[1] == grain] = DEAD
         for j in (p1, p2):
-            self._kill_pq(self._pq0.cols(self.pq[0], j))
-            pp[:, self._pp0.cols(pp[0], j)] = DEAD
-            pp[:, self._pp1.cols(pp[1], j)] = DEAD
+            self.pq[:, self.pq[0] == j] = DEAD
+            pp[:, pp[0] == j] = DEAD
+            pp[:, pp[1] == j] = DEAD
 
     def remove_all_two_sided(self) -> List[int]:
         """models.py:708-717 / 741-750.  KEEP: the DEAD marker itself takes part in the count
         (it never has <= 2 columns once a grain has been removed)."""
-        found = ([DEAD] if 1 <= self._n_dead <= 2 else []) + sorted(self._few)   # np.unique order: ascending
+        grains, counts = np.unique(self.pq[1], return_counts=True)
+        found = [int(g) for g in grains[counts <= 2]]
         for g in found:
             self.remove_two_sided_grain(g)
         return found
@@ -190,20 +117,23 @@ class GrainTopology:
             p1, p2 = int(pp[0, cols[k]]), int(pp[1, cols[k]])
             if not (self.is_active(p1) and self.is_active(p2)):
                 continue
-            c1, c2 = self._pq0.cols(pq[0], p1), self._pq0.cols(pq[0], p2)
-            g1, g2 = [int(pq[1, c]) for c in c1], [int(pq[1, c]) for c in c2]
-            e1 = [c for c in self._out_cols(p1) if pp[1, c] != p2]   # columns p1 -> its other neighbours
-            e2 = [c for c in self._out_cols(p2) if pp[1, c] != p1]
-            n1, n2 = [int(pp[1, c]) for c in e1], [int(pp[1, c]) for c in e2]
-            grow_from_1 = [g for g in g1 if g not in g2]   # grain of p1 only: becomes a neighbour of p2
-            grow_from_2 = [g for g in g2 if g not in g1]   # grain of p2 only: becomes a neighbour of p1
-            shrink = [g for g in g1 if g in g2]
+            c1, c2 = self.pq_cols_of_joint(p1), self.pq_cols_of_joint(p2)
+            g1, g2 = pq[1, c1], pq[1, c2]
+            e1 = np.flatnonzero((pp[0] == p1) & (pp[1] != p2))   # columns p1 -> its other neighbours
+            e2 = np.flatnonzero((pp[0] == p2) & (pp[1] != p1))
+            n1, n2 = pp[1, e1], pp[1, e2]
+            shared1 = np.isin(g1, g2)
+            grow_from_1 = g1[~shared1]            # grain of p1 only: becomes a neighbour of p2
+            grow_from_2 = g2[~np.isin(g2, g1)]    # grain of p2 only: becomes a neighbour of p1
+            shrink = g1[shared1]
             if len(shrink) != 2 or len(grow_from_1) != 1 or len(grow_from_2) != 1:
                 raise TopologyError(f"junctions {p1}, {p2} do not share exactly two grains")
-            sa, sb = shrink
-            c1 = [c1[i] for i in range(3) if g1[i] == sa] + [c1[i] for i in range(3) if g1[i] == sb]
-            c2 = [c2[i] for i in range(3) if g2[i] == sa] + [c2[i] for i in range(3) if g2[i] == sb]
+            sa, sb = int(shrink[0]), int(shrink[1])
+            c1 = [int(c1[i]) for i in range(3) if g1[i] == sa] + [int(c1[i]) for i in range(3) if g1[i] == sb]
+            c2 = [int(c2[i]) for i in range(3) if g2[i] == sa] + [int(c2[i]) for i in range(3) if g2[i] == sb]
             # order each junction's two outer neighbours as (the one on grain sa, the one on sb)
+            e1, n1 = [int(v) for v in e1], [int(v) for v in n1]
+            e2, n2 = [int(v) for v in e2], [int(v) for v in n2]
             if not self.has_pq(n1[0], sa):
                 e1.reverse(), n1.reverse()
             if not self.has_pq(n2[0], sa):
@@ -235,18 +165,12 @@ class GrainTopology:
             if flip:
                 c1.reverse(), c2.reverse(), e1.reverse(), e2.reverse()
                 a1, b1, a2, b2 = b1, a1, b2, a2
-            self._set_grain(c1[1], grow_from_2[0])
-            self._set_grain(c2[0], grow_from_1[0])
+            pq[1, c1[1]] = grow_from_2[0]
+            pq[1, c2[0]] = grow_from_1[0]
             pp[0, e1[1]] = p2
-            self._pp0.note(e1[1], p2)
             pp[0, e2[0]] = p1
-            self._pp0.note(e2[0], p1)
-            for c in [c for c in self._out_cols(a2) if pp[1, c] == p2]:
-                pp[1, c] = p1
-                self._pp1.note(c, p1)
-            for c in [c for c in self._out_cols(b1) if pp[1, c] == p1]:
-                pp[1, c] = p2
-                self._pp1.note(c, p2)
+            pp[1, (pp[0] == a2) & (pp[1] == p2)] = p1
+            pp[1, (pp[0] == b1) & (pp[1] == p1)] = p2
         for p in touched:
             # KEEP (models.py:903, 1045-1047): the reference remembers a VIEW of the rewound
             # position, so the displacement feature of every touched junction comes out as 0.
@@ -266,19 +190,19 @@ class GrainTopology:
         edge_cols, across = [], []
         for p, q in combinations([int(v) for v in corners], 2):
             lo, hi = min(p, q), max(p, q)
-            hit = [c for c in self._out_cols(lo) if pp[1, c] == hi]
+            hit = np.flatnonzero((pp[0] == lo) & (pp[1] == hi))
             if len(hit) == 0:
                 continue
-            edge_cols.extend(hit)
-            other_lo = [int(pq[1, c]) for c in self._pq0.cols(pq[0], lo) if pq[1, c] != grain]
-            other_hi = [int(pq[1, c]) for c in self._pq0.cols(pq[0], hi) if pq[1, c] != grain]
+            edge_cols.append(hit)
+            other_lo = pq[1, (pq[0] == lo) & (pq[1] != grain)]
+            other_hi = pq[1, (pq[0] == hi) & (pq[1] != grain)]
             if other_lo[0] in other_hi:
-                across.append(other_lo[0])
+                across.append(int(other_lo[0]))
             elif other_lo[1] in other_hi:
-                across.append(other_lo[1])
+                across.append(int(other_lo[1]))
             else:
                 raise TopologyError(f"edge ({lo}, {hi}) of grain {grain} has no grain on its other side")
-        edge_cols = np.asarray(edge_cols, dtype=np.int64)
+        edge_cols = np.concatenate(edge_cols) if edge_cols else np.zeros(0, np.int64)
         if len(across) != len(corners):
             raise TopologyError(f"grain {grain}: {len(corners)} junctions but {len(across)} edges")
         if len(set(across)) != len(across):

@@ -116,3 +116,52 @@ def test_classifier_update_is_a_drop_in():
     gs = {"active_grains": torch.arange(118), "active_joints": torch.tensor([j for j in range(236) if j != corner])}
     Cm.update(x, ei, None, y, mask, gs, 0.0)
     assert torch.equal(ei[JJ], t(EV[i + k(JJ)])) and int(mask["grain"].sum()) == 118
+
+
+def _random_events(n, seed, depth, n_elim, n_switch):
+    """`depth` chained updates on an n x n periodic honeycomb with random predictions: (arguments of every call)."""
+    from graingraphnn_amd import synthetic
+    rs = np.random.RandomState(seed)
+    x, ei, _ = synthetic.honeycomb(n, 1, seed)
+    xj = np.ascontiguousarray(x["joint"], dtype=np.float32)
+    n_g, n_j = x["grain"].shape[0], xj.shape[0]
+    state = dict(xj=xj, pp=ei[JJ].astype(np.int64), pq=ei[JG].astype(np.int64),
+                 mg=np.ones((n_g, 1), np.int64), mj=np.ones((n_j, 1), np.int64))
+    for _ in range(depth):
+        yj = (rs.normal(0, 0.02 / n, (n_j, 2)) * 5).astype(np.float32)
+        yg = rs.normal(0, 1, (n_g, 2)).astype(np.float32)
+        live = np.flatnonzero(state["mg"][:, 0] > 0)
+        ge = rs.choice(live, size=min(n_elim, len(live)), replace=False)
+        prob = np.zeros(state["pp"].shape[1], np.float32)
+        up = np.flatnonzero(state["pp"][0] < state["pp"][1])
+        prob[rs.choice(up, size=min(n_switch, len(up)), replace=False)] = rs.uniform(0.7, 1.0, min(n_switch, len(up)))
+        yield state, yj, yg, prob, ge
+
+
+@pytest.mark.parametrize("n,seed,n_elim,n_switch", [(12, 0, 3, 4), (12, 1, 6, 0), (20, 2, 8, 10), (40, 3, 20, 25)])
+def test_indexed_lookups_equal_the_scan_formulation_on_random_events(n, seed, n_elim, n_switch):
+    """The product answers the update's lookups from column indices; oracle/topology_scan.py answers them with the
+    reference's full-array masks.  Four chained updates on honeycombs of up to 1 600 grains with random eliminations and
+    switches: identical lists (column order included), masks, coordinates, event lists -- or the same refusal."""
+    from oracle import topology_scan as scan
+    compared = 0
+    for state, yj, yg, prob, ge in _random_events(n, seed, 4, n_elim, n_switch):
+        a = dict(xj=state["xj"].copy(), yj=yj.copy(), mg=state["mg"].copy(), mj=state["mj"].copy())
+        b = dict(xj=state["xj"].copy(), yj=yj.copy(), mg=state["mg"].copy(), mj=state["mj"].copy())
+        res = []
+        for mod, s in ((scan, a), (__import__("graingraphnn_amd.topology", fromlist=["x"]), b)):
+            try:
+                res.append(mod.update_topology(s["xj"], state["pp"], state["pq"], s["yj"], yg, prob, ge, s["mg"], s["mj"], 0.6))
+            except (mod.TopologyError, IndexError) as err:
+                res.append(type(err).__name__)
+        if isinstance(res[0], str) or isinstance(res[1], str):
+            assert isinstance(res[0], str) and isinstance(res[1], str), (res[0] if isinstance(res[0], str) else "ok",
+                                                                         res[1] if isinstance(res[1], str) else "ok")
+            break   # (both refused these events: the chain ends here)
+        for u, v in zip(res[0], res[1]):
+            assert np.array_equal(u, v)
+        for key in ("xj", "yj", "mg", "mj"):
+            assert np.array_equal(a[key], b[key]), key
+        compared += 1
+        state.update(xj=b["xj"], pp=res[1][0], pq=res[1][1], mg=b["mg"], mj=b["mj"])
+    assert compared >= 1
