@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 21
+GGNN_ABI_VERSION = 22
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -21,6 +21,7 @@ GGNN_EDGE_PARAM_ROWS = 3
 GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
 GGNN_PRECISION_F16X2 = 2
+GGNN_ETOPOLOGY = -3
 GGNN_FLAG_F16_RANGE = 1
 GGNN_ADAM_CHUNK, GGNN_ADAM_MAX_TENSORS, GGNN_ADAM_MAX_GROUPS = 4096, 384, 8
 GGNN_ROWGEMM_MAX_PACK = 8
@@ -39,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
-    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_step_refresh",
+    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
 
@@ -128,6 +129,21 @@ class DecCellArgs(Structure):
         ("wstream", c_void_p), ("w2_tail", c_void_p), ("flags", c_void_p),
         ("n_dst", c_int64), ("ldx", c_int64), ("ldh", c_int64),
         ("n_in", c_int32), ("f_dst", c_int32),
+    ]
+
+
+class TopologyArgs(Structure):
+    """Mirror of `ggnn_topology_args` (host memory)."""
+    _fields_ = [
+        ("pp", c_void_p), ("pq", c_void_p),
+        ("n_pp", c_int64), ("n_pq", c_int64), ("pp_cap", c_int64), ("pq_cap", c_int64),
+        ("x_joint", c_void_p), ("y_joint", c_void_p), ("y_grain_area", c_void_p), ("edge_prob", c_void_p),
+        ("grain_event", c_void_p), ("mask_grain", c_void_p), ("mask_joint", c_void_p),
+        ("active_grain", c_void_p), ("active_joint", c_void_p), ("switching", c_void_p), ("events_extra", c_void_p),
+        ("n_joint", c_int64), ("n_grain", c_int64), ("ldx", c_int64), ("ldyg", c_int64), ("n_grain_event", c_int64),
+        ("switching_cap", c_int64), ("extra_cap", c_int64), ("n_switching", c_int64), ("n_extra", c_int64),
+        ("threshold", ctypes.c_double),
+        ("error", ctypes.c_char * 192),
     ]
 
 
@@ -324,6 +340,8 @@ def _declare(lib):
     lib.ggnn_detect_events.restype = c_int
     lib.ggnn_detect_events.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64,
                                        c_float, c_void_p, c_void_p]
+    lib.ggnn_topology_update.restype = c_int
+    lib.ggnn_topology_update.argtypes = [POINTER(TopologyArgs)]
     lib.ggnn_workspace_bytes.restype = c_size_t
     lib.ggnn_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
 

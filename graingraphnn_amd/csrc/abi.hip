@@ -31,6 +31,7 @@ extern "C" const char* ggnn_error_string(int code) {
     case GGNN_OK: return "ok";
     case GGNN_EINVAL: return "invalid argument (null pointer, size, alignment or unsupported width)";
     case GGNN_ELAUNCH: return "HIP launch / memset failed";
+    case GGNN_ETOPOLOGY: return "the edge lists are not a valid grain graph (ggnn_topology_args.error)";
     default: return "unknown ggnn error code";
   }
 }

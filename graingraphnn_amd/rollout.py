@@ -702,13 +702,18 @@ class GrainRollout:
         ge = np.flatnonzero(live & (area < np.float32(self.area_threshold)))
         ge = ge[np.argsort(area[ge], kind="stable")]                         # test.py:418-420
         prob = torch.sigmoid(p["edge_event"]).cpu().numpy()
-        if len(ge) == 0 and not np.any((prob > self.edge_threshold) &
-                                       (self.edge_index[ET_JJ][0].cpu().numpy() < self.edge_index[ET_JJ][1].cpu().numpy())):
+        # the lists this method uploaded at the last event are still on the host (2 MB of read-back at the 10k-grain graph)
+        host = getattr(self, "_ei_host", None)
+        if host is not None and host[0] is self.edge_index[ET_JJ] and host[1] is self.edge_index[("joint", "pull", "grain")] \
+                and host[4] == (host[0]._version, host[1]._version):   # (the same tensors, not written since)
+            ei_jj, ei_jg = host[2], host[3]
+        else:
+            ei_jj = self.edge_index[ET_JJ].cpu().numpy()
+            ei_jg = self.edge_index[("joint", "pull", "grain")].cpu().numpy()
+        if len(ge) == 0 and not np.any((prob > self.edge_threshold) & (ei_jj[0] < ei_jj[1])):
             return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)         # the trigger was conservative
         xj = self.x["joint"].cpu().numpy()
         yj, yg = p["joint"].cpu().numpy(), p["grain"].cpu().numpy()
-        ei_jj = self.edge_index[ET_JJ].cpu().numpy()
-        ei_jg = self.edge_index[("joint", "pull", "grain")].cpu().numpy()
         # the rewiring mutates its arguments in place: give it copies and commit masks, coordinates
         # and edge lists together, so a TopologyError leaves the rollout at the pre-event state
         mg, mj = self.mask["grain"].copy(), self.mask["joint"].copy()
@@ -721,6 +726,8 @@ class GrainRollout:
         new_ei = {ET_JJ: torch.from_numpy(pp).to(dev), ("joint", "pull", "grain"): torch.from_numpy(pq).to(dev),
                   ("grain", "push", "joint"): torch.from_numpy(np.ascontiguousarray(qp)).to(dev)}
         self._set_topology(new_ei, lasting=False)
+        jj, jg = new_ei[ET_JJ], new_ei[("joint", "pull", "grain")]
+        self._ei_host = (jj, jg, pp, pq, (jj._version, jg._version))
         self._graph_fwd = self._graph_ref = None
         return events, switches
 

@@ -1,304 +1,46 @@
-"""Event-driven topology update of the grain graph, host side.
+"""Event-driven topology update of the grain graph, host side: the binding of
+`ggnn_topology_update` (include/ggnn.h, csrc/topology.hip -- host code in the C-ABI library).
 
-Restates `GrainNN_classifier.update` of the reference (models.py:612-842 with its helpers
+It restates `GrainNN_classifier.update` of the reference (models.py:612-842 with its helpers
 `delete_grain_index` :861-893, `switching_edge_index` :896-1051, `point_in_triangle` :1055-1070,
 `periodic_move` :1103-1106) for the periodic, nucleation-free configuration every shipped script
-runs (test.py:88 `--nucleation_density 0`).  It is integer / index work on a few edges per event
-and inherently sequential (every event rewires the lists the next one reads), so it runs on the
-host on numpy arrays between device steps; the device side only sees new `edge_index` tensors,
-for which `engine.graph_for` rebuilds the CSR.
+runs (test.py:88 `--nucleation_density 0`).  The work is integer / index work on a few edges per
+event and inherently sequential (every event rewires the lists the next one reads), so it runs on
+the host between device steps; the device side only sees new `edge_index` tensors, for which
+`engine.graph_for` rebuilds the CSR.
 
-The reference answers every lookup ("the columns whose source is p", "the junctions of grain g",
-"grains left with two junctions") with a mask over a WHOLE edge list -- some forty scans per
-eliminated grain, 57-75 ms of an eventful step at the 10k-grain graph (tools/probes/evstep.py).
-Here the lookups are answered from COLUMN INDICES (`_ColumnIndex`: columns grouped by value once
-per call with one stable argsort, later rewrites kept in a side table, every answer filtered by
-the list's current content) and a running count of columns per grain: the work of an event is
-proportional to the degree of what it touches.  Same answers in the same (increasing column)
-order, so the results are the scan formulation's bit for bit (oracle/topology_scan.py, kept as
-the test oracle, and the reference's golden vectors).
+The reference answers every lookup with a mask over a whole edge list (57-75 ms of host time per
+eventful step at the 10k-grain graph, measured with that formulation: oracle/topology_scan.py, now
+the test oracle); the library answers them from column indices and running counts in native code
+(profiles/r5_event_step_breakdown.txt).
 
 Bit-exactness contract (tests/golden/golden_cfg1_events.npz, produced by the unmodified
 reference): identical `edge_index` COLUMN ORDER (edges are rewritten in place, new edges are
 appended, dead columns are dropped at the end -- never re-sorted), identical masks, identical
-fp32 junction coordinates.  Reference behaviours that look accidental are kept because the
-trained models were run with them, each marked KEEP below.
+fp32 junction coordinates.
 """
-from itertools import combinations
-from typing import Dict, List, Optional, Sequence, Set, Tuple
+import ctypes
+from typing import Optional, Sequence
 
 import numpy as np
 
+from . import _lib
+
 GJ, JG, JJ = ("grain", "push", "joint"), ("joint", "pull", "grain"), ("joint", "connect", "joint")
-JOINT_SCALING = np.float32(5.0)  # models.py:398 scaling['joint']
-DEAD = -1                        # marker of a removed column until the final clean-up
-
-
-def _wrap_to(p: np.ndarray, ref: np.ndarray) -> np.ndarray:
-    """Periodic image of p nearest to ref (models.py:1103-1106), fp32."""
-    rel = p - ref
-    return p - (rel > 0.5).astype(np.float32) + (rel < -0.5).astype(np.float32)
-
-
-def _inside_triangle(t, v1, v2, v3) -> bool:
-    """models.py:1055-1070, evaluated in fp32 in the reference's operation order."""
-    a, b, c = _wrap_to(v1, t), _wrap_to(v2, t), _wrap_to(v3, t)
-
-    def side(p, q, r):
-        return (p[0] - r[0]) * (q[1] - r[1]) - (q[0] - r[0]) * (p[1] - r[1])
-
-    d = (side(t, a, b), side(t, b, c), side(t, c, a))
-    return not (any(v < 0 for v in d) and any(v > 0 for v in d))
 
 
 class TopologyError(RuntimeError):
     """The lists are not a valid grain graph (the reference asserts / raises KeyError here)."""
 
 
-class _ColumnIndex:
-    """`cols(row, v)`: the columns c with row[c] == v, in increasing order -- what `np.flatnonzero(row == v)` returns --
-    without scanning `row`.  Built from the row's content at the start of a call (columns grouped by value: one stable
-    argsort); a column that is REWRITTEN to v afterwards, or appended with value v, is noted in a side table; every answer
-    is filtered by the row's current content, so overwritten and dead columns drop out by themselves."""
-
-    def __init__(self, row: np.ndarray):
-        n_keys = int(row.max()) + 1 if row.size else 0
-        if row.size and int(row.min()) < 0:
-            raise TopologyError("negative node index in an edge list")
-        # columns grouped by value, increasing inside a group: the keys value * E + column are distinct, so any sort of
-        # them is the stable sort by value (numpy's vectorised int64 sort: 1 ms for 60 000 columns, a stable argsort 5)
-        self.order = np.argsort(row * np.int64(row.size) + np.arange(row.size, dtype=np.int64))
-        self.start = np.zeros(n_keys + 1, dtype=np.int64)
-        np.cumsum(np.bincount(row, minlength=n_keys), out=self.start[1:])
-        self.later: Dict[int, Set[int]] = {}
-
-    def note(self, col: int, v: int) -> None:
-        self.later.setdefault(int(v), set()).add(int(col))
-
-    def cols(self, row: np.ndarray, v: int) -> List[int]:
-        v = int(v)
-        base = self.order[self.start[v]:self.start[v + 1]].tolist() if 0 <= v < len(self.start) - 1 else []
-        late = self.later.get(v)
-        if late:
-            base = sorted(set(base) | late)
-        return [c for c in base if row[c] == v]
-
-
-class GrainTopology:
-    """Mutable junction-junction (`pp`) and junction-grain (`pq`) edge lists of one graph."""
-
-    def __init__(self, ei_jj: np.ndarray, ei_jg: np.ndarray, x_joint: np.ndarray, y_joint: np.ndarray,
-                 mask_grain: np.ndarray, mask_joint: np.ndarray, active_joints: Optional[np.ndarray] = None):
-        self.pp = np.array(ei_jj, dtype=np.int64, copy=True)
-        self.pq = np.array(ei_jg, dtype=np.int64, copy=True)
-        self.xj, self.yj = x_joint, y_joint          # fp32, modified in place
-        self.mask_grain, self.mask_joint = mask_grain, mask_joint
-        self.active = None if active_joints is None else set(int(v) for v in active_joints)
-        self._pp0, self._pp1 = _ColumnIndex(self.pp[0]), _ColumnIndex(self.pp[1])
-        self._pq0, self._pq1 = _ColumnIndex(self.pq[0]), _ColumnIndex(self.pq[1])
-        # columns per grain (the counts of np.unique(pq[1])) and the grains that are down to one or two
-        self._n_of_grain = np.bincount(self.pq[1]).astype(np.int64) if self.pq.shape[1] else np.zeros(0, np.int64)
-        self._few: Set[int] = set(np.flatnonzero((self._n_of_grain >= 1) & (self._n_of_grain <= 2)).tolist())
-        self._n_dead = 0
-
-    # -- lookups (column order is the reference's `.nonzero()` order) -------------------------
-    def joints_of(self, grain: int) -> np.ndarray:
-        return self.pq[0, self._pq1.cols(self.pq[1], grain)]
-
-    def pq_cols_of_joint(self, joint: int) -> np.ndarray:
-        return np.asarray(self._pq0.cols(self.pq[0], joint), dtype=np.int64)
-
-    def has_pq(self, joint: int, grain: int) -> bool:
-        return any(self.pq[1, c] == grain for c in self._pq0.cols(self.pq[0], joint))
-
-    def is_active(self, joint: int) -> bool:
-        return self.active is None or int(joint) in self.active
-
-    def _out_cols(self, p: int) -> List[int]:
-        """Columns of pp whose source is p."""
-        return self._pp0.cols(self.pp[0], p)
-
-    # -- writes that the indices and the per-grain counts follow ----------------------------------
-    def _recount(self, grain: int, by: int) -> None:
-        n = self._n_of_grain[grain] = self._n_of_grain[grain] + by
-        if 1 <= n <= 2:
-            self._few.add(int(grain))
-        else:
-            self._few.discard(int(grain))
-
-    def _set_grain(self, col: int, grain: int) -> None:
-        self._recount(int(self.pq[1, col]), -1)
-        self.pq[1, col] = grain
-        self._recount(int(grain), +1)
-        self._pq1.note(col, grain)
-
-    def _kill_pq(self, cols: Sequence[int]) -> None:
-        for c in cols:
-            self._recount(int(self.pq[1, c]), -1)
-            self._n_dead += 1
-            self.pq[:, c] = DEAD
-
-    # -- models.py:861-893 -------------------------------------------------------------------
-    def remove_two_sided_grain(self, grain: int) -> None:
-        """A grain reduced to two junctions disappears: its junctions p1, p2 die and their two
-        outer neighbours are joined by a new edge pair appended at the end."""
-        if grain == DEAD:
-            # (np.unique in the reference counts the dead marker like a grain; with one or two dead columns it would be
-            # "removed" here -- never the case once a grain is gone, which kills at least eight columns)
-            raise TopologyError("the dead-column marker was counted as a two-sided grain")
-        corners = self.joints_of(grain)
-        if len(corners) != 2:
-            raise TopologyError(f"grain {grain} has {len(corners)} junctions, expected 2")
-        p1, p2 = int(corners[0]), int(corners[1])
-        pp = self.pp
-        try:
-            n1 = int(next(pp[1, c] for c in self._out_cols(p1) if pp[1, c] != p2))
-            n2 = int(next(pp[1, c] for c in self._out_cols(p2) if pp[1, c] != p1))
-        except StopIteration:
-            raise TopologyError(f"junctions {p1}, {p2} of grain {grain} have no outer neighbour") from None
-        E = pp.shape[1]
-        self.pp = pp = np.concatenate([pp, np.array([[n1, n2], [n2, n1]], dtype=np.int64)], axis=1)
-        self._pp0.note(E, n1), self._pp1.note(E, n2), self._pp0.note(E + 1, n2), self._pp1.note(E + 1, n1)
-        self.mask_grain[grain] = 0
-        self.mask_joint[p1] = 0
-        self.mask_joint[p2] = 0
-        self._kill_pq(self._pq1.cols(self.pq[1], grain))
-        for j in (p1, p2):
-            self._kill_pq(self._pq0.cols(self.pq[0], j))
-            pp[:, self._pp0.cols(pp[0], j)] = DEAD
-            pp[:, self._pp1.cols(pp[1], j)] = DEAD
-
-    def remove_all_two_sided(self) -> List[int]:
-        """models.py:708-717 / 741-750.  KEEP: the DEAD marker itself takes part in the count
-        (it never has <= 2 columns once a grain has been removed)."""
-        found = ([DEAD] if 1 <= self._n_dead <= 2 else []) + sorted(self._few)   # np.unique order: ascending
-        for g in found:
-            self.remove_two_sided_grain(g)
-        return found
-
-    # -- models.py:896-1051 ------------------------------------------------------------------
-    def switch_edges(self, cols: Sequence[int], vanishing_grain: Optional[int]) -> List[int]:
-        """Neighbour switching (T1) of the junction-junction columns `cols`, in order.  Returns
-        grains that turn out to be squeezed between the switching junctions (forced eliminations)."""
-        cols = np.asarray(cols, dtype=np.int64)
-        forced: List[int] = []
-        touched = np.unique(self.pp[:, cols].T.reshape(-1)) if len(cols) else np.zeros(0, np.int64)
-        for p in touched:
-            self.xj[p, :2] -= self.yj[p] / JOINT_SCALING     # back to the position before this step
-        pp, pq, xj = self.pp, self.pq, self.xj
-        for k in range(len(cols)):
-            p1, p2 = int(pp[0, cols[k]]), int(pp[1, cols[k]])
-            if not (self.is_active(p1) and self.is_active(p2)):
-                continue
-            c1, c2 = self._pq0.cols(pq[0], p1), self._pq0.cols(pq[0], p2)
-            g1, g2 = [int(pq[1, c]) for c in c1], [int(pq[1, c]) for c in c2]
-            e1 = [c for c in self._out_cols(p1) if pp[1, c] != p2]   # columns p1 -> its other neighbours
-            e2 = [c for c in self._out_cols(p2) if pp[1, c] != p1]
-            n1, n2 = [int(pp[1, c]) for c in e1], [int(pp[1, c]) for c in e2]
-            grow_from_1 = [g for g in g1 if g not in g2]   # grain of p1 only: becomes a neighbour of p2
-            grow_from_2 = [g for g in g2 if g not in g1]   # grain of p2 only: becomes a neighbour of p1
-            shrink = [g for g in g1 if g in g2]
-            if len(shrink) != 2 or len(grow_from_1) != 1 or len(grow_from_2) != 1:
-                raise TopologyError(f"junctions {p1}, {p2} do not share exactly two grains")
-            sa, sb = shrink
-            c1 = [c1[i] for i in range(3) if g1[i] == sa] + [c1[i] for i in range(3) if g1[i] == sb]
-            c2 = [c2[i] for i in range(3) if g2[i] == sa] + [c2[i] for i in range(3) if g2[i] == sb]
-            # order each junction's two outer neighbours as (the one on grain sa, the one on sb)
-            if not self.has_pq(n1[0], sa):
-                e1.reverse(), n1.reverse()
-            if not self.has_pq(n2[0], sa):
-                e2.reverse(), n2.reverse()
-            a1, b1 = n1
-            a2, b2 = n2
-            if vanishing_grain is None and (a1 == a2 or b1 == b2):
-                continue                          # a triangle would collapse: not a pure switch
-            if a1 == a2 and sa != vanishing_grain:
-                forced.append(sa)
-            if b1 == b2 and sb != vanishing_grain:
-                forced.append(sb)
-            # both junctions move to the (periodic) mid point of the edge
-            x2_near = _wrap_to(xj[p2, :2], xj[p1, :2])
-            mid = np.float32(0.5) * (xj[p1, :2] + x2_near)
-            new_p2 = _wrap_to(mid, xj[p2, :2])
-            xj[p1, :2], xj[p2, :2] = mid, new_p2
-            flip = _inside_triangle(xj[p2, :2], xj[p1, :2], xj[a1, :2], xj[a2, :2])
-            # look ahead: junctions that later switches of this call still need keep their side
-            later = set(int(v) for v in pp[:, cols[k:]].reshape(-1))
-            if a2 in later and b2 not in later:
-                flip = False
-            if b2 in later and a2 not in later:
-                flip = True
-            if a1 in later and b1 not in later:
-                flip = True
-            if b1 in later and a1 not in later:
-                flip = False
-            if flip:
-                c1.reverse(), c2.reverse(), e1.reverse(), e2.reverse()
-                a1, b1, a2, b2 = b1, a1, b2, a2
-            self._set_grain(c1[1], grow_from_2[0])
-            self._set_grain(c2[0], grow_from_1[0])
-            pp[0, e1[1]] = p2
-            self._pp0.note(e1[1], p2)
-            pp[0, e2[0]] = p1
-            self._pp0.note(e2[0], p1)
-            for c in [c for c in self._out_cols(a2) if pp[1, c] == p2]:
-                pp[1, c] = p1
-                self._pp1.note(c, p1)
-            for c in [c for c in self._out_cols(b1) if pp[1, c] == p1]:
-                pp[1, c] = p2
-                self._pp1.note(c, p2)
-        for p in touched:
-            # KEEP (models.py:903, 1045-1047): the reference remembers a VIEW of the rewound
-            # position, so the displacement feature of every touched junction comes out as 0.
-            self.yj[p] = JOINT_SCALING * (xj[p, :2] - xj[p, :2])
-            xj[p, 6:8] = self.yj[p]
-        return forced
-
-    # -- models.py:628-717 -------------------------------------------------------------------
-    def eliminate_grain(self, grain: int, y_grain_area: np.ndarray, pending_switches: List[int]) -> Optional[List[int]]:
-        """Shrink `grain` to two sides by switching all but two of its edges (those towards the
-        neighbours with the smallest predicted area change go first), then remove it.  Returns the
-        force-eliminated grains, or None if the grain was skipped."""
-        corners = self.joints_of(grain)
-        if len(corners) == 0 or not all(self.is_active(int(p)) for p in corners):
-            return None
-        pp, pq = self.pp, self.pq
-        edge_cols, across = [], []
-        for p, q in combinations([int(v) for v in corners], 2):
-            lo, hi = min(p, q), max(p, q)
-            hit = [c for c in self._out_cols(lo) if pp[1, c] == hi]
-            if len(hit) == 0:
-                continue
-            edge_cols.extend(hit)
-            other_lo = [int(pq[1, c]) for c in self._pq0.cols(pq[0], lo) if pq[1, c] != grain]
-            other_hi = [int(pq[1, c]) for c in self._pq0.cols(pq[0], hi) if pq[1, c] != grain]
-            if other_lo[0] in other_hi:
-                across.append(other_lo[0])
-            elif other_lo[1] in other_hi:
-                across.append(other_lo[1])
-            else:
-                raise TopologyError(f"edge ({lo}, {hi}) of grain {grain} has no grain on its other side")
-        edge_cols = np.asarray(edge_cols, dtype=np.int64)
-        if len(across) != len(corners):
-            raise TopologyError(f"grain {grain}: {len(corners)} junctions but {len(across)} edges")
-        if len(set(across)) != len(across):
-            return None
-        order = np.argsort(y_grain_area[np.asarray(across, dtype=np.int64)], kind="stable")
-        cols = edge_cols[order[:-2]]
-        forced = self.switch_edges(cols, vanishing_grain=grain)
-        for g in [grain] + forced:
-            self.remove_two_sided_grain(g)
-        for c in cols:
-            if int(c) in pending_switches:
-                pending_switches.remove(int(c))
-        self.remove_all_two_sided()
-        return forced
-
-    def finish(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """models.py:845-858 + :837: drop dead columns (order kept); grain->joint = flipped joint->grain."""
-        pq = self.pq[:, self.pq[0] != DEAD]
-        pp = self.pp[:, self.pp[0] != DEAD]
-        return pp, pq, pq[::-1].copy()
+def _flags(ids: Optional[Sequence[int]], n: int) -> Optional[np.ndarray]:
+    """Index list of an active window -> one byte per node (None = everything is active)."""
+    if ids is None:
+        return None
+    f = np.zeros(n, dtype=np.uint8)
+    ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+    f[ids[(ids >= 0) & (ids < n)]] = 1
+    return f
 
 
 def update_topology(x_joint: np.ndarray, ei_jj: np.ndarray, ei_jg: np.ndarray, y_joint: np.ndarray,
@@ -308,28 +50,53 @@ def update_topology(x_joint: np.ndarray, ei_jj: np.ndarray, ei_jg: np.ndarray, y
     """One call of the reference's `Cmodel.update` (nucleation off).  `x_joint` [N_j, 8] fp32,
     `y_joint` [N_j, 2] fp32 and the masks are modified in place.  `edge_prob` = sigmoid of the
     classifier's `edge_event` logits, `grain_event` = grains below the area threshold, smallest
-    first (test.py:418-420).  Returns (ei_jj, ei_jg, ei_gj, switching_list [S, 2], grain_event')."""
-    topo = GrainTopology(ei_jj, ei_jg, x_joint, y_joint, mask_grain, mask_joint, active_joints)
-    src, dst = topo.pp[0], topo.pp[1]
-    pending = [int(c) for c in np.flatnonzero((edge_prob > threshold) & (src < dst))]
-    active_g = None if active_grains is None else set(int(v) for v in active_grains)
-    extra: List[int] = []
-    for grain in [int(g) for g in grain_event]:
-        if active_g is not None and grain not in active_g:
-            continue
-        forced = topo.eliminate_grain(grain, y_grain[:, 0], pending)
-        if forced:
-            extra.extend(forced)
-    # neighbour switching, most probable edge first (ties: lower column first)
-    pending = [pending[i] for i in np.argsort(-edge_prob[np.asarray(pending, dtype=np.int64)], kind="stable")] \
-        if pending else []
-    pending = [c for c in pending if topo.pp[0, c] != DEAD]
-    topo.switch_edges(pending, vanishing_grain=None)
-    switching_list = topo.pp[:, np.asarray(pending, dtype=np.int64)].T.copy() if pending \
-        else np.zeros((0, 2), np.int64)
-    extra.extend(topo.remove_all_two_sided())
-    events = np.concatenate([np.asarray(grain_event, dtype=np.int64).reshape(-1),
-                             np.asarray(extra, dtype=np.int64)]) if extra \
-        else np.asarray(grain_event, dtype=np.int64).reshape(-1)
-    pp, pq, qp = topo.finish()
-    return pp, pq, qp, switching_list, events
+    first (test.py:418-420).  Returns (ei_jj, ei_jg, ei_gj, switching_list [S, 2], grain_event').
+    Raises TopologyError when the lists are not a valid grain graph; the in-place arguments are then
+    untouched (the library works on copies that are committed together)."""
+    lib = _lib.load()
+    n_j, n_g = int(mask_joint.shape[0]), int(mask_grain.shape[0])
+    for name, a, cols in (("x_joint", x_joint, None), ("y_joint", y_joint, 2)):
+        if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2 or a.shape[0] != n_j \
+                or (cols is not None and a.shape[1] != cols):
+            raise ValueError(f"{name} must be a float32 numpy array [{n_j}, {cols or '>= 8'}]")
+    if x_joint.shape[1] < 8:
+        raise ValueError("x_joint needs the 8 junction features (columns 6, 7 = the displacement the events reset)")
+    ge = np.ascontiguousarray(np.asarray(grain_event, dtype=np.int64).reshape(-1))
+    n_pp, n_pq = int(ei_jj.shape[1]), int(ei_jg.shape[1])
+    # every removed grain appends two columns before the dead ones are dropped; forced eliminations and two-sided grains
+    # come on top of `grain_event`: bounded by the number of grains
+    cap = n_pp + 2 * n_g + 2
+    pp = np.empty((2, cap), dtype=np.int64)
+    pp[:, :n_pp] = ei_jj
+    pq = np.array(ei_jg, dtype=np.int64, order="C", copy=True)
+    xj, yj = np.array(x_joint, order="C", copy=True), np.array(y_joint, order="C", copy=True)
+    mg = np.ascontiguousarray(mask_grain.reshape(-1).astype(np.int64))
+    mj = np.ascontiguousarray(mask_joint.reshape(-1).astype(np.int64))
+    area = np.ascontiguousarray(np.asarray(y_grain, dtype=np.float32)[:, 0])
+    prob = np.ascontiguousarray(np.asarray(edge_prob, dtype=np.float32).reshape(-1))
+    if prob.shape[0] != n_pp or area.shape[0] != n_g:
+        raise ValueError("edge_prob needs one entry per junction edge, y_grain one row per grain")
+    act_g, act_j = _flags(active_grains, n_g), _flags(active_joints, n_j)
+    switching = np.empty((max(n_pp, 1), 2), dtype=np.int64)
+    extra = np.empty(n_g + 1, dtype=np.int64)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    A = _lib.TopologyArgs()
+    A.pp, A.pq, A.n_pp, A.n_pq, A.pp_cap, A.pq_cap = p(pp), p(pq), n_pp, n_pq, cap, n_pq
+    A.x_joint, A.y_joint, A.y_grain_area, A.edge_prob = p(xj), p(yj), p(area), p(prob)
+    A.grain_event, A.mask_grain, A.mask_joint = p(ge), p(mg), p(mj)
+    A.active_grain, A.active_joint, A.switching, A.events_extra = p(act_g), p(act_j), p(switching), p(extra)
+    A.n_joint, A.n_grain, A.ldx, A.ldyg, A.n_grain_event = n_j, n_g, xj.shape[1], 1, ge.shape[0]
+    A.switching_cap, A.extra_cap, A.threshold = switching.shape[0], extra.shape[0], float(threshold)
+    rc = lib.ggnn_topology_update(ctypes.byref(A))
+    if rc == _lib.GGNN_ETOPOLOGY:
+        raise TopologyError(A.error.decode(errors="replace"))
+    _lib.check(rc, "ggnn_topology_update")
+    # commit: coordinates, displacement features and masks in place, the lists as new arrays
+    x_joint[...] = xj
+    y_joint[...] = yj
+    mask_grain[...] = mg.reshape(mask_grain.shape)
+    mask_joint[...] = mj.reshape(mask_joint.shape)
+    new_pp = pp[:, :A.n_pp].copy()
+    new_pq = pq[:, :A.n_pq].copy()
+    events = np.concatenate([ge, extra[:A.n_extra]]) if A.n_extra else ge
+    return new_pp, new_pq, new_pq[::-1].copy(), switching[:A.n_switching].copy(), events

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 21
+#define GGNN_ABI_VERSION 22
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -34,6 +34,7 @@ extern "C" {
 #define GGNN_OK 0
 #define GGNN_EINVAL (-1)  /* bad argument (null pointer, size, alignment, unsupported width) */
 #define GGNN_ELAUNCH (-2) /* hipLaunch / hipMemsetAsync reported an error */
+#define GGNN_ETOPOLOGY (-3) /* ggnn_topology_update: the lists are not a valid grain graph (message in args->error) */
 
 typedef void* ggnn_stream_t; /* hipStream_t */
 
@@ -528,6 +529,45 @@ int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x
 int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
                        float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
                        int64_t E, float logit_threshold, int32_t* flags, ggnn_stream_t stream);
+/* The host-side topology update those counts trigger: one call of the reference's `Cmodel.update`
+ * (models.py:612-842 with delete_grain_index :861-893, switching_edge_index :896-1051, point_in_triangle :1055-1070,
+ * periodic_move :1103-1106), nucleation off.  HOST memory throughout, no stream: grains of `grain_event` (those below the
+ * area threshold, smallest first, test.py:418-420) are eliminated, junction edges with edge_prob > threshold are switched
+ * (most probable first), grains left with two junctions are removed.  Bit-exact contract: the edge lists keep the
+ * reference's COLUMN ORDER (columns rewritten in place, new columns appended, dead columns dropped at the end), masks and
+ * fp32 junction coordinates are the reference's.
+ *   pp, pq      : [2][cap] int64 junction->junction / junction->grain lists (row r at pp + r * pp_cap), n_pp / n_pq columns in
+ *                 use; updated IN PLACE, n_pp / n_pq = the new column counts.  pp_cap >= n_pp + 2 (removed grains): every
+ *                 removed grain appends two columns before the dead ones are dropped.
+ *   x_joint     : [n_joint, ldx >= 8] fp32, columns 0, 1 (position) and 6, 7 (displacement feature) are rewritten for the
+ *                 junctions an event moves; y_joint [n_joint, 2] likewise
+ *   y_grain_area: element g at y_grain_area[g * ldyg] (the regressor's y_grain[:, 0]);  edge_prob [n_pp] = sigmoid(edge_event)
+ *   mask_grain / mask_joint : [n] int64, 1 = live; eliminated grains and their junctions are cleared
+ *   active_grain / active_joint : optional [n] bytes, 0 = outside the active window (models.py:640-645, 911): frozen
+ *   switching   : out [switching_cap][2] the switched junction pairs, n_switching of them
+ *   events_extra: out [extra_cap] grains eliminated beyond `grain_event` (forced / two-sided), n_extra of them
+ * Returns GGNN_OK, GGNN_EINVAL, or GGNN_ETOPOLOGY with a message in `error` (the reference asserts / raises there); on an error
+ * the in/out arrays are in an undefined state: pass copies (graingraphnn_amd/topology.py does). */
+typedef struct ggnn_topology_args {
+  int64_t* pp;
+  int64_t* pq;
+  int64_t n_pp, n_pq, pp_cap, pq_cap;
+  float* x_joint;
+  float* y_joint;
+  const float* y_grain_area;
+  const float* edge_prob;
+  const int64_t* grain_event;
+  int64_t* mask_grain;
+  int64_t* mask_joint;
+  const uint8_t* active_grain;
+  const uint8_t* active_joint;
+  int64_t* switching;
+  int64_t* events_extra;
+  int64_t n_joint, n_grain, ldx, ldyg, n_grain_event, switching_cap, extra_cap, n_switching, n_extra;
+  double threshold;
+  char error[192];
+} ggnn_topology_args;
+int ggnn_topology_update(ggnn_topology_args* args);
 typedef struct ggnn_refresh_edge {
   const int64_t* edge_index; /* [2, E] */
   const float* x_src;
