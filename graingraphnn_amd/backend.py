@@ -93,9 +93,11 @@ class HipBackend:
                 check(rc, name)
 
     # -- CSR ---------------------------------------------------------------------------
-    def build_csr(self, edge_index, n_src, n_dst):
+    def build_csr(self, edge_index, n_src, n_dst, checks=None):
         """edge_index [2, E] int64 (cuda) -> CSR.  Raises IndexError on out-of-range indices
-        (one host sync, only when a topology is first seen)."""
+        (one host sync, only when a topology is first seen).  `checks`: a list the range check is appended to instead
+        of being made here -- a caller that builds several lists (engine.GraphCSR: three per topology, after every
+        topological event) runs them behind the last build, one synchronisation instead of one per list."""
         _require_cuda(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise _lib.GGNNError("edge_index must be int64 [2, E]")
@@ -115,8 +117,13 @@ class HipBackend:
                                       ptr(row), ptr(unit_ptr), ptr(units), ptr(flags), ptr(ws), nbytes,
                                       _lib.current_stream()),
               "ggnn_build_csr")
-        if int(flags[0].item()) & 1:
-            raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
+        def in_range():
+            if int(flags[0].item()) & 1:
+                raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
+        if checks is None:
+            in_range()
+        else:
+            checks.append(in_range)
         return CSR(rowptr, col, perm, row, unit_ptr, units, E)
 
     # -- per-edge geometry -------------------------------------------------------------

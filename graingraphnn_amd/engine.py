@@ -24,12 +24,15 @@ class GraphCSR:
         self.csr = {}
         self.edge_index = {}
         self.n_nodes = dict(n_nodes)
+        checks = []   # the three range checks behind the last build: one host synchronisation per topology
         for et in EDGE_TYPES:
             if et not in edge_index_dict:
                 raise KeyError(f"edge_index_dict lacks edge type {et}")
             ei = edge_index_dict[et]
             self.edge_index[et] = ei.contiguous()
-            self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]])
+            self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]], checks)
+        for check in checks:
+            check()
 
     def n_edges(self, et):
         return self.edge_index[et].size(1)

@@ -498,15 +498,23 @@ class GrainRollout:
         self._overlap_buffers()
         dev = self.x["joint"].device
         D = 2 * max(1, int(self.EVENTS_UNROLL))
+        per_edge = ("edge_event", "edge")   # the predictions that follow the junction edge list
+        if S is not None and S["D"] == D:
+            # a new topology (after an event): the per-node slots, the centre snapshots and the (pinned) count words stay --
+            # the node sets never change -- only the per-edge predictions follow the new edge list
+            keep = {k: S[k] for k in ("xs", "cen", "evf", "evh")}
+            pred = [{k: (torch.empty_like(self.pred[k]) if k in per_edge else v) for k, v in slot.items()}
+                    for slot in S["pred"]]
+        else:
+            keep = {"xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
+                    "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
+                    "evf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "evh": [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(D)]}
+            pred = [{k: torch.empty_like(v) for k, v in self.pred.items()} for _ in range(D)]
         S = self._spec = {
             "topology": self.graph, "cur": 0, "D": D,
             "ea": [self.edge_attr, self._ea_other], "einfo": [self.einfo, self._einfo_other],
-            "xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
-            "pred": [{k: torch.empty_like(v) for k, v in self.pred.items()} for _ in range(D)],
-            "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
-            "evf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
-            "evh": [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(D)],
-            "graphs": {}}
+            "pred": pred, "graphs": {}, **keep}
         return S
 
     def _enqueue_spec_step(self, slot: int, swept_prev=None):
