@@ -89,3 +89,25 @@ for rnd in range(a.rounds):
     print(f"  refresh on the new topology              {t_ref:8.3f} ms")
     print(f"  next three single steps                  " + " ".join(f"{v:.3f}" for v in t_next) + " ms")
     print(f"  next {2 * ro.EVENTS_UNROLL} steps (graphs re-captured)        {t_block:8.3f} ms")
+
+# --- a stretch in which EVERY step is eventful: the threshold follows the k-th smallest area the previous step predicted ---
+K_GRAINS, N_STEPS = 3, 100
+import graingraphnn_amd.topology as topo_mod
+done, n_ev, refused = 0, 0, None
+sync()
+t0 = time.perf_counter()
+try:
+    for _ in range(N_STEPS):
+        area = ro.pred["grain_area"]
+        live = ro._live_grain > 0
+        kth = torch.kthvalue(area[live], K_GRAINS).values
+        ro.area_threshold = float(np.nextafter(np.float32(kth.item()), np.float32(1)))
+        ev, _ = ro.run_events(1)
+        n_ev += len(ev[0])
+        done += 1
+except topo_mod.TopologyError as err:
+    refused = str(err)
+sync()
+dt = (time.perf_counter() - t0) * 1e3
+print(f"{done} consecutive eventful steps, {n_ev} grains eliminated ({n_ev / max(done, 1):.1f} per step): {dt / max(done, 1):.3f} ms per step "
+      f"= {max(done, 1) / dt * 1e3:.0f} steps/s (incl. one threshold read-back per step)" + (f"; stopped: {refused}" if refused else ""))
