@@ -19,7 +19,12 @@ static __device__ unsigned long long ggnn_stamp_buf[GGNN_STAMP_WAVES * GGNN_STAM
   do {                                                                                             \
     if ((threadIdx.x & 63) == 0) {                                                                 \
       const unsigned w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                     \
-      if (w_ < GGNN_STAMP_WAVES) ggnn_stamp_buf[w_ * GGNN_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); \
+      if (w_ < GGNN_STAMP_WAVES) {                                                                 \
+        ggnn_stamp_buf[w_ * GGNN_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime();            \
+        /* slots 17 / 18: the shader clock counter beside stamps 0 / 16 (the clock a kernel held) */ \
+        if ((i) == 0) ggnn_stamp_buf[w_ * GGNN_STAMP_SLOTS + 17] = __builtin_readcyclecounter();     \
+        if ((i) == 16) ggnn_stamp_buf[w_ * GGNN_STAMP_SLOTS + 18] = __builtin_readcyclecounter();    \
+      }                                                                                            \
     }                                                                                              \
   } while (0)
 #define GGNN_STAMP_VAL(i, v)                                                                       \

@@ -48,6 +48,8 @@ for name, shapes in (("regressor (joint + grain), honeycomb", [J, Gr]), ("classi
             print(f"  {nm:16s} med {np.median(r):7.2f}  min {r.min():7.2f}  max {r.max():7.2f} us")
         life = us(m[:, 16] - m[:, 0])
         print(f"  wave life        med {np.median(life):7.2f}  max {life.max():7.2f} us")
+        clk = (m[:, 18] - m[:, 17]) / np.maximum(m[:, 16] - m[:, 0], 1) * 100.0   # shader clocks per 100 MHz tick
+        print(f"  shader clock     med {np.median(clk):7.0f} MHz (cycle counter / real-time counter over the wave's life)")
         for i, nm in ((5, "sum P1 (scores)"), (6, "sum P2 (sweep)"), (7, "sum P3 (lin_l2)"), (8, "sum P4 (skip)"),
                       (9, "sum LSTM"), (4, "  of which slice wait + barrier"), (11, "  of which slice DMA issue")):
             r = us(m[:, i])
