@@ -165,3 +165,38 @@ def test_indexed_lookups_equal_the_scan_formulation_on_random_events(n, seed, n_
         compared += 1
         state.update(xj=b["xj"], pp=res[1][0], pq=res[1][1], mg=b["mg"], mj=b["mj"])
     assert compared >= 1
+
+
+def test_c_abi_refuses_bad_arguments_and_missing_room():
+    """ggnn_topology_update through the C ABI: null pointers and inconsistent sizes are GGNN_EINVAL; an edge list without
+    room for the two columns a removed grain appends is GGNN_ETOPOLOGY with a message, not a write past the end."""
+    import ctypes
+    from graingraphnn_amd import _lib
+    lib = _lib.load()
+    A = _lib.TopologyArgs()
+    assert lib.ggnn_topology_update(None) == -1
+    assert lib.ggnn_topology_update(ctypes.byref(A)) == -1          # all pointers null
+    i = "elim1__in_"
+    pp, pq = np.ascontiguousarray(EV[i + k(JJ)]).copy(), np.ascontiguousarray(EV[i + k(JG)]).copy()
+    xj, yj = EV[i + "x_joint"].copy(), EV[i + "y_joint"].copy()
+    area = np.ascontiguousarray(EV[i + "y_grain"][:, 0])
+    prob = np.zeros(pp.shape[1], np.float32)
+    ge = np.ascontiguousarray(EV[i + "grain_event"].astype(np.int64).reshape(-1))
+    assert len(ge) >= 1
+    mg = np.ascontiguousarray(EV[i + "mask_grain"].reshape(-1).astype(np.int64))
+    mj = np.ascontiguousarray(EV[i + "mask_joint"].reshape(-1).astype(np.int64))
+    sw, extra = np.empty((8, 2), np.int64), np.empty(8, np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    A.pp, A.pq, A.n_pp, A.n_pq, A.pp_cap, A.pq_cap = p(pp), p(pq), pp.shape[1], pq.shape[1], pp.shape[1], pq.shape[1]
+    A.x_joint, A.y_joint, A.y_grain_area, A.edge_prob = p(xj), p(yj), p(area), p(prob)
+    A.grain_event, A.mask_grain, A.mask_joint, A.switching, A.events_extra = p(ge), p(mg), p(mj), p(sw), p(extra)
+    A.n_joint, A.n_grain, A.ldx, A.ldyg, A.n_grain_event = len(mj), len(mg), xj.shape[1], 1, len(ge)
+    A.switching_cap, A.extra_cap, A.threshold = 8, 8, 0.6
+    A.ldx = 4
+    assert lib.ggnn_topology_update(ctypes.byref(A)) == -1          # fewer than the 8 junction features
+    A.ldx = xj.shape[1]
+    A.pp_cap = pp.shape[1] - 1
+    assert lib.ggnn_topology_update(ctypes.byref(A)) == -1          # capacity below the columns in use
+    A.pp_cap = pp.shape[1]                                          # no room for the appended pair
+    assert lib.ggnn_topology_update(ctypes.byref(A)) == _lib.GGNN_ETOPOLOGY
+    assert b"room" in A.error
