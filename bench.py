@@ -671,6 +671,14 @@ def main():
         ro.run(ro.RUN_UNROLL)
         gather_states(ro.state(), world)
         untimed_steps += ro.RUN_UNROLL
+        if world > 1:
+            # ... and a rehearsal of the bracket's collectives (barrier, the MAX all-reduce of the times): their first calls
+            # set up connections (measured with two gloo ranks on one GPU: the first region took 84 ms, its repeats 15)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.zeros(1, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
