@@ -525,6 +525,19 @@ def train_step_records():
     return out
 
 
+def event_mode_record():
+    """SURVEY 8 f-2 beside the headline: a quiet step of the event-driven loop against a static step and an eventful step piece
+    by piece (host-side rewiring, CSR rebuild, the rest), at the 10k-grain graph (tests/bench_event_step.py, child process;
+    a failure leaves a string in the record and never touches the headline)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_event_step.py")], capture_output=True, text=True,
+                           timeout=300)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 -- informational record only
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -797,6 +810,7 @@ def main():
                     line["config"]["native_fp32_gemm_steps_per_s"] = None
             if not args.events:
                 line["train_step"] = train_step_records()
+                line["event_mode"] = event_mode_record()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
