@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 22
+GGNN_ABI_VERSION = 23
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -31,7 +31,7 @@ MODE_LSTM, MODE_LSTM_H0, MODE_RAW = 0, 1, 2
 # Every symbol include/ggnn.h declares (tests/test_cabi.py checks the library exports them all).
 EXPORTED_SYMBOLS = (
     "ggnn_version", "ggnn_error_string", "ggnn_gemm_mode", "ggnn_csr_workspace_bytes", "ggnn_csr_max_units",
-    "ggnn_build_csr",
+    "ggnn_build_csr", "ggnn_build_csr_batch",
     "ggnn_edge_prepare", "ggnn_project", "ggnn_project_batch", "ggnn_period_gat_aggregate",
     "ggnn_period_gat_aggregate_batch", "ggnn_period_gat_aggregate_enc_batch", "ggnn_encoder_cell_batch",
     "ggnn_decoder_cell_batch",
@@ -129,6 +129,15 @@ class DecCellArgs(Structure):
         ("wstream", c_void_p), ("w2_tail", c_void_p), ("flags", c_void_p),
         ("n_dst", c_int64), ("ldx", c_int64), ("ldh", c_int64),
         ("n_in", c_int32), ("f_dst", c_int32),
+    ]
+
+
+class CsrArgs(Structure):
+    """Mirror of `ggnn_csr_args`."""
+    _fields_ = [
+        ("edge_index", c_void_p), ("E", c_int64), ("n_src", c_int64), ("n_dst", c_int64),
+        ("rowptr", c_void_p), ("col", c_void_p), ("perm", c_void_p), ("row", c_void_p), ("unit_ptr", c_void_p),
+        ("units", c_void_p), ("flags", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -262,6 +271,8 @@ def _declare(lib):
     lib.ggnn_build_csr.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]
+    lib.ggnn_build_csr_batch.restype = c_int
+    lib.ggnn_build_csr_batch.argtypes = [POINTER(CsrArgs), c_int, c_void_p]
     lib.ggnn_edge_prepare.restype = c_int
     lib.ggnn_edge_prepare.argtypes = [POINTER(PrepareEdge), c_int, c_void_p]
     lib.ggnn_project.restype = c_int

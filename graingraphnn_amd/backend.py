@@ -93,38 +93,47 @@ class HipBackend:
                 check(rc, name)
 
     # -- CSR ---------------------------------------------------------------------------
-    def build_csr(self, edge_index, n_src, n_dst, checks=None):
+    def build_csr(self, edge_index, n_src, n_dst):
         """edge_index [2, E] int64 (cuda) -> CSR.  Raises IndexError on out-of-range indices
-        (one host sync, only when a topology is first seen).  `checks`: a list the range check is appended to instead
-        of being made here -- a caller that builds several lists (engine.GraphCSR: three per topology, after every
-        topological event) runs them behind the last build, one synchronisation instead of one per list."""
-        _require_cuda(edge_index)
-        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
-            raise _lib.GGNNError("edge_index must be int64 [2, E]")
-        ei = edge_index.contiguous()
-        E = ei.size(1)
-        dev = ei.device
-        rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
-        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-        perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-        row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-        unit_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
-        units = torch.zeros(self.lib.ggnn_csr_max_units(E, n_dst), 8, dtype=torch.int32, device=dev)
-        flags = torch.zeros(2, dtype=torch.int32, device=dev)
-        nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(self.lib.ggnn_build_csr(ptr(ei), E, n_src, n_dst, ptr(rowptr), ptr(col), ptr(perm),
-                                      ptr(row), ptr(unit_ptr), ptr(units), ptr(flags), ptr(ws), nbytes,
-                                      _lib.current_stream()),
-              "ggnn_build_csr")
-        def in_range():
-            if int(flags[0].item()) & 1:
-                raise IndexError(f"edge_index has entries outside [0,{n_src}) x [0,{n_dst})")
-        if checks is None:
-            in_range()
-        else:
-            checks.append(in_range)
-        return CSR(rowptr, col, perm, row, unit_ptr, units, E)
+        (one host sync, only when a topology is first seen)."""
+        return self.build_csr_batch([(edge_index, n_src, n_dst)])[0]
+
+    def build_csr_batch(self, lists):
+        """[(edge_index [2, E] int64 cuda, n_src, n_dst)] -> [CSR]: ggnn_build_csr_batch, up to four lists per sequence of
+        launches (engine.GraphCSR builds the three edge types of a topology in one; a topological event rebuilds them),
+        one range check = one host synchronisation behind the last."""
+        out, todo = [], list(lists)
+        while todo:
+            chunk, todo = todo[:4], todo[4:]
+            arr = (_lib.CsrArgs * len(chunk))()
+            keep = []
+            for a, (edge_index, n_src, n_dst) in zip(arr, chunk):
+                _require_cuda(edge_index)
+                if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+                    raise _lib.GGNNError("edge_index must be int64 [2, E]")
+                ei = edge_index.contiguous()
+                E, dev = ei.size(1), ei.device
+                rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+                col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+                perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+                row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+                unit_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+                units = torch.zeros(self.lib.ggnn_csr_max_units(E, n_dst), 8, dtype=torch.int32, device=dev)
+                flags = torch.zeros(2, dtype=torch.int32, device=dev)
+                nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                a.edge_index, a.E, a.n_src, a.n_dst = ei.data_ptr(), E, n_src, n_dst
+                a.rowptr, a.col, a.perm, a.row = rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), row.data_ptr()
+                a.unit_ptr, a.units, a.flags = unit_ptr.data_ptr(), units.data_ptr(), flags.data_ptr()
+                a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+                keep.append((ei, ws, flags, n_src, n_dst))
+                out.append(CSR(rowptr, col, perm, row, unit_ptr, units, E))
+            check(self.lib.ggnn_build_csr_batch(arr, len(chunk), _lib.current_stream()), "ggnn_build_csr_batch")
+            bad = torch.stack([k[2][0] for k in keep]).cpu()   # (the synchronisation; also keeps ei / ws alive until here)
+            for k, f in zip(keep, bad.tolist()):
+                if f & 1:
+                    raise IndexError(f"edge_index has entries outside [0,{k[3]}) x [0,{k[4]})")
+        return out
 
     # -- per-edge geometry -------------------------------------------------------------
     def edge_prepare(self, items):

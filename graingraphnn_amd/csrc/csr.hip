@@ -7,25 +7,45 @@
 
 namespace ggnn {
 
-__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ ei, int64_t E,
-                                                        int64_t n_src, int64_t n_dst,
-                                                        int32_t* __restrict__ counts,
-                                                        int32_t* __restrict__ flags) {
+// A unit (the unit table the LDS-DMA aggregation sweep walks) is one destination row restricted to at most
+// GGNN_UNIT_EDGES consecutive in-edges (rows without edges still get one empty unit so that their output is written).
+// The descriptor is 32 bytes: {i, p0, nact | first<<8 | last<<9, 0, j0, j1, j2, 0}; absent edges repeat j0 (or 0) so that
+// every unit issues the same number of row loads.
+//
+// ---- up to four lists per launch (ggnn_build_csr_batch): blockIdx.y = the list; a topological event rebuilds the
+// three edge types' tables, and eight launches per list -- two of them single-workgroup scans -- were most of that ----
+constexpr int CSR_MAX_BATCH = 4;
+struct CsrBatch {
+  ggnn_csr_args p[CSR_MAX_BATCH];
+};
+__device__ __forceinline__ int32_t* csr_counts(const ggnn_csr_args& P) { return reinterpret_cast<int32_t*>(P.workspace); }
+__device__ __forceinline__ int32_t* csr_cursor(const ggnn_csr_args& P) { return csr_counts(P) + P.n_dst + 1; }
+
+__global__ __launch_bounds__(256) void csr_zero_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P.n_dst) csr_counts(P)[i] = 0;
+}
+__global__ __launch_bounds__(256) void csr_count_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.y];
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int64_t s = ei[e], d = ei[E + e];
-  if ((uint64_t)s >= (uint64_t)n_src || (uint64_t)d >= (uint64_t)n_dst) {
-    atomicOr(flags, 1);
+  if (e >= P.E) return;
+  const int64_t s = P.edge_index[e], d = P.edge_index[P.E + e];
+  if ((uint64_t)s >= (uint64_t)P.n_src || (uint64_t)d >= (uint64_t)P.n_dst) {
+    atomicOr(P.flags, 1);
     return;
   }
-  atomicAdd(&counts[d], 1);
+  atomicAdd(&csr_counts(P)[d], 1);
 }
-
-// Single-workgroup exclusive scan over n counts (n is at most a few 10^5 here); writes
-// rowptr[0..n] and a copy into cursor[0..n-1] for the fill pass.
-__global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restrict__ counts,
-                                                        int64_t n, int32_t* __restrict__ rowptr,
-                                                        int32_t* __restrict__ cursor) {
+// Single-workgroup exclusive scan over a list's n_dst counts (a few 10^4 here), one workgroup per list: writes out[0..n] and
+// a copy into cursor[0..n-1] for the fill pass.  UNITS: counts -> unit_ptr, else counts -> rowptr
+template <bool UNITS>
+__global__ __launch_bounds__(1024) void csr_scan_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.x];
+  const int32_t* __restrict__ counts = csr_counts(P);
+  int32_t* __restrict__ out = UNITS ? P.unit_ptr : P.rowptr;
+  int32_t* __restrict__ cursor = csr_cursor(P);
+  const int64_t n = P.n_dst;
   __shared__ int32_t s_wave[16];
   __shared__ int32_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,7 +54,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restric
   for (int64_t base = 0; base < n; base += 1024) {
     const int64_t i = base + tid;
     const int32_t v = i < n ? counts[i] : 0;
-    int32_t incl = v;  // inclusive scan inside the wave
+    int32_t incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int32_t t = __shfl_up(incl, off, 64);
@@ -47,38 +67,32 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restric
     const int32_t carry = s_carry;
     const int32_t excl = carry + wave_off + incl - v;
     if (i < n) {
-      rowptr[i] = excl;
+      out[i] = excl;
       cursor[i] = excl;
     }
     __syncthreads();
     if (tid == 1023) s_carry = carry + wave_off + incl;
     __syncthreads();
   }
-  if (tid == 0) rowptr[n] = s_carry;
+  if (tid == 0) out[n] = s_carry;
 }
-
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E,
-                                                       int64_t n_src, int64_t n_dst,
-                                                       int32_t* __restrict__ cursor,
-                                                       int32_t* __restrict__ perm) {
+__global__ __launch_bounds__(256) void csr_fill_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.y];
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int64_t s = ei[e], d = ei[E + e];
-  if ((uint64_t)s >= (uint64_t)n_src || (uint64_t)d >= (uint64_t)n_dst) return;
-  const int32_t pos = atomicAdd(&cursor[d], 1);
-  perm[pos] = (int32_t)e;
+  if (e >= P.E) return;
+  const int64_t s = P.edge_index[e], d = P.edge_index[P.E + e];
+  if ((uint64_t)s >= (uint64_t)P.n_src || (uint64_t)d >= (uint64_t)P.n_dst) return;
+  const int32_t pos = atomicAdd(&csr_cursor(P)[d], 1);
+  P.perm[pos] = (int32_t)e;
 }
-
-// One thread per destination row: order the row's slots by original edge id (rows are
-// 3..12 long on grain graphs), then resolve the source node of each slot.
-__global__ __launch_bounds__(256) void csr_sort_kernel(const int64_t* __restrict__ ei,
-                                                       const int32_t* __restrict__ rowptr,
-                                                       int64_t n_dst, int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ col,
-                                                       int32_t* __restrict__ row) {
+// One thread per destination row: order the row's slots by original edge id (rows are 3..12 long on grain graphs), resolve
+// the source node of each slot, and leave the row's unit count in `counts` for the second scan
+__global__ __launch_bounds__(256) void csr_sort_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_dst) return;
-  const int32_t beg = rowptr[i], end = rowptr[i + 1];
+  if (i >= P.n_dst) return;
+  const int32_t beg = P.rowptr[i], end = P.rowptr[i + 1];
+  int32_t* __restrict__ perm = P.perm;
   for (int32_t a = beg + 1; a < end; ++a) {
     const int32_t key = perm[a];
     int32_t b = a - 1;
@@ -89,47 +103,31 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int64_t* __restrict
     perm[b + 1] = key;
   }
   for (int32_t a = beg; a < end; ++a) {
-    col[a] = (int32_t)ei[perm[a]];
-    row[a] = (int32_t)i;
+    P.col[a] = (int32_t)P.edge_index[perm[a]];
+    P.row[a] = (int32_t)i;
   }
+  const int32_t deg = end - beg;
+  csr_counts(P)[i] = deg == 0 ? 1 : (deg + GGNN_UNIT_EDGES - 1) / GGNN_UNIT_EDGES;
 }
-
-// ---- unit table for the LDS-DMA aggregation sweep -------------------------------------
-// A unit is one destination row restricted to at most GGNN_UNIT_EDGES consecutive in-edges
-// (rows without edges still get one empty unit so that their output is written).  The
-// descriptor is 32 bytes: {i, p0, nact | first<<8 | last<<9, 0, j0, j1, j2, 0}; absent
-// edges repeat j0 (or 0) so that every unit issues the same number of row loads.
-__global__ __launch_bounds__(256) void csr_unit_count_kernel(const int32_t* __restrict__ rowptr,
-                                                             int64_t n_dst,
-                                                             int32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void csr_unit_fill_batch_kernel(const CsrBatch B) {
+  const ggnn_csr_args& P = B.p[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_dst) return;
-  const int32_t deg = rowptr[i + 1] - rowptr[i];
-  cnt[i] = deg == 0 ? 1 : (deg + GGNN_UNIT_EDGES - 1) / GGNN_UNIT_EDGES;
-}
-
-__global__ __launch_bounds__(256) void csr_unit_fill_kernel(const int32_t* __restrict__ rowptr,
-                                                            const int32_t* __restrict__ col,
-                                                            const int32_t* __restrict__ unit_ptr,
-                                                            int64_t n_dst,
-                                                            int32_t* __restrict__ units) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_dst) return;
-  const int32_t beg = rowptr[i], end = rowptr[i + 1];
-  int32_t u = unit_ptr[i];
+  if (i >= P.n_dst) return;
+  const int32_t beg = P.rowptr[i], end = P.rowptr[i + 1];
+  int32_t u = P.unit_ptr[i];
   int32_t p = beg;
   do {
     const int32_t nact = min(GGNN_UNIT_EDGES, end - p);
     const int32_t first = p == beg, last = p + GGNN_UNIT_EDGES >= end;
-    int32_t* d = units + 8 * (int64_t)u;
-    const int32_t j0 = nact > 0 ? col[p] : 0;
+    int32_t* d = P.units + 8 * (int64_t)u;
+    const int32_t j0 = nact > 0 ? P.col[p] : 0;
     d[0] = (int32_t)i;
     d[1] = p;
     d[2] = nact | (first << 8) | (last << 9);
     d[3] = 0;
     d[4] = j0;
-    d[5] = nact > 1 ? col[p + 1] : j0;
-    d[6] = nact > 2 ? col[p + 2] : j0;
+    d[5] = nact > 1 ? P.col[p + 1] : j0;
+    d[6] = nact > 2 ? P.col[p + 2] : j0;
     d[7] = 0;
     ++u;
     p += GGNN_UNIT_EDGES;
@@ -147,37 +145,44 @@ extern "C" int64_t ggnn_csr_max_units(int64_t E, int64_t n_dst) {
   return (n_dst > 0 ? n_dst : 0) + (E > 0 ? E : 0) / GGNN_UNIT_EDGES + 1;
 }
 
+extern "C" int ggnn_build_csr_batch(const ggnn_csr_args* problems, int n_problems, ggnn_stream_t stream_) {
+  using namespace ggnn;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!problems || n_problems < 1 || n_problems > CSR_MAX_BATCH) return GGNN_EINVAL;
+  CsrBatch B;
+  int64_t max_E = 0, max_n = 0;
+  for (int k = 0; k < CSR_MAX_BATCH; ++k) {
+    B.p[k] = problems[k < n_problems ? k : 0];
+    if (k >= n_problems) continue;
+    const ggnn_csr_args& P = B.p[k];
+    if (P.E < 0 || P.n_src < 0 || P.n_dst <= 0 || !P.rowptr || !P.flags || !P.workspace) return GGNN_EINVAL;
+    if (P.E > 0 && (!P.edge_index || !P.col || !P.perm || !P.row)) return GGNN_EINVAL;
+    if (!P.unit_ptr || !P.units || !aligned16(P.units)) return GGNN_EINVAL;
+    if (P.E >= INT32_MAX || P.n_dst >= INT32_MAX || P.n_src >= INT32_MAX) return GGNN_EINVAL;
+    if (P.workspace_bytes < ggnn_csr_workspace_bytes(P.E, P.n_dst) || ((uintptr_t)P.workspace & 3)) return GGNN_EINVAL;
+    max_E = P.E > max_E ? P.E : max_E;
+    max_n = P.n_dst > max_n ? P.n_dst : max_n;
+  }
+  const unsigned ny = (unsigned)n_problems;
+  const unsigned eb = (unsigned)((max_E + 255) / 256), nb = (unsigned)((max_n + 255) / 256);
+  hipLaunchKernelGGL(csr_zero_batch_kernel, dim3(nb, ny), dim3(256), 0, stream, B);
+  if (max_E > 0) hipLaunchKernelGGL(csr_count_batch_kernel, dim3(eb, ny), dim3(256), 0, stream, B);
+  hipLaunchKernelGGL(csr_scan_batch_kernel<false>, dim3(ny), dim3(1024), 0, stream, B);
+  if (max_E > 0) hipLaunchKernelGGL(csr_fill_batch_kernel, dim3(eb, ny), dim3(256), 0, stream, B);
+  // (rows sorted, sources resolved, and the rows' unit counts left in `counts` for the second scan; a list without edges
+  // still gets its unit counts: one empty unit per row)
+  hipLaunchKernelGGL(csr_sort_batch_kernel, dim3(nb, ny), dim3(256), 0, stream, B);
+  hipLaunchKernelGGL(csr_scan_batch_kernel<true>, dim3(ny), dim3(1024), 0, stream, B);
+  hipLaunchKernelGGL(csr_unit_fill_batch_kernel, dim3(nb, ny), dim3(256), 0, stream, B);
+  return launch_status();
+}
+
 extern "C" int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t n_dst,
                               int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row,
                               int32_t* unit_ptr, int32_t* units, int32_t* flags, void* workspace, size_t workspace_bytes, ggnn_stream_t stream_) {
-  using namespace ggnn;
-  hipStream_t stream = (hipStream_t)stream_;
-  if (E < 0 || n_src < 0 || n_dst <= 0 || !rowptr || !flags || !workspace) return GGNN_EINVAL;
-  if (E > 0 && (!edge_index || !col || !perm || !row)) return GGNN_EINVAL;
-  if (!unit_ptr || !units || !aligned16(units)) return GGNN_EINVAL;
-  if (E >= INT32_MAX || n_dst >= INT32_MAX || n_src >= INT32_MAX) return GGNN_EINVAL;
-  if (workspace_bytes < ggnn_csr_workspace_bytes(E, n_dst)) return GGNN_EINVAL;
-  int32_t* counts = (int32_t*)workspace;
-  int32_t* cursor = counts + n_dst + 1;
-  if (hipMemsetAsync(counts, 0, (size_t)n_dst * sizeof(int32_t), stream) != hipSuccess)
-    return GGNN_ELAUNCH;
-  const unsigned eb = (unsigned)((E + 255) / 256), nb = (unsigned)((n_dst + 255) / 256);
-  if (E > 0)
-    hipLaunchKernelGGL(csr_count_kernel, dim3(eb), dim3(256), 0, stream, edge_index, E, n_src,
-                       n_dst, counts, flags);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_dst, rowptr,
-                     cursor);
-  if (E > 0) {
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(eb), dim3(256), 0, stream, edge_index, E, n_src,
-                       n_dst, cursor, perm);
-    hipLaunchKernelGGL(csr_sort_kernel, dim3(nb), dim3(256), 0, stream, edge_index, rowptr,
-                       n_dst, perm, col, row);
-  }
-  // unit table: per-row unit counts -> exclusive scan (cursor is free again) -> descriptors
-  hipLaunchKernelGGL(csr_unit_count_kernel, dim3(nb), dim3(256), 0, stream, rowptr, n_dst, counts);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_dst, unit_ptr,
-                     cursor);
-  hipLaunchKernelGGL(csr_unit_fill_kernel, dim3(nb), dim3(256), 0, stream, rowptr, col, unit_ptr,
-                     n_dst, units);
-  return launch_status();
+  ggnn_csr_args P;
+  P.edge_index = edge_index, P.E = E, P.n_src = n_src, P.n_dst = n_dst;
+  P.rowptr = rowptr, P.col = col, P.perm = perm, P.row = row, P.unit_ptr = unit_ptr, P.units = units, P.flags = flags;
+  P.workspace = workspace, P.workspace_bytes = workspace_bytes;
+  return ggnn_build_csr_batch(&P, 1, stream_);
 }

@@ -24,15 +24,16 @@ class GraphCSR:
         self.csr = {}
         self.edge_index = {}
         self.n_nodes = dict(n_nodes)
-        checks = []   # the three range checks behind the last build: one host synchronisation per topology
         for et in EDGE_TYPES:
             if et not in edge_index_dict:
                 raise KeyError(f"edge_index_dict lacks edge type {et}")
-            ei = edge_index_dict[et]
-            self.edge_index[et] = ei.contiguous()
-            self.csr[et] = backend.build_csr(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]], checks)
-        for check in checks:
-            check()
+            self.edge_index[et] = edge_index_dict[et].contiguous()
+        lists = [(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]]) for et in EDGE_TYPES]
+        if hasattr(backend, "build_csr_batch"):   # the three edge types in one sequence of launches, one synchronisation
+            built = backend.build_csr_batch(lists)
+        else:
+            built = [backend.build_csr(*l) for l in lists]
+        self.csr = dict(zip(EDGE_TYPES, built))
 
     def n_edges(self, et):
         return self.edge_index[et].size(1)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 22
+#define GGNN_ABI_VERSION 23
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -78,6 +78,22 @@ int ggnn_build_csr(const int64_t* edge_index, int64_t E, int64_t n_src, int64_t 
                    int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* row, int32_t* unit_ptr,
                    int32_t* units, int32_t* flags, void* workspace, size_t workspace_bytes,
                    ggnn_stream_t stream);
+/* The same build for up to four lists in one sequence of launches (a topological event rebuilds the three edge types'
+ * tables: seven launches instead of twenty-four).  Fields as the arguments of ggnn_build_csr. */
+typedef struct ggnn_csr_args {
+  const int64_t* edge_index;
+  int64_t E, n_src, n_dst;
+  int32_t* rowptr;
+  int32_t* col;
+  int32_t* perm;
+  int32_t* row;
+  int32_t* unit_ptr;
+  int32_t* units;
+  int32_t* flags;
+  void* workspace;
+  size_t workspace_bytes;
+} ggnn_csr_args;
+int ggnn_build_csr_batch(const ggnn_csr_args* problems, int n_problems, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-edge record in CSR order, computed once per forward and shared by every gate of the

@@ -15,7 +15,7 @@ class TorchEmulatorBackend:
     name = "torch-emulator (tests only)"
     fused_encoder = True  # engine.run_cells: encoder cells through encoder_cell_batch (False: sweep + gate epilogue)
 
-    def build_csr(self, edge_index, n_src, n_dst, checks=None):
+    def build_csr(self, edge_index, n_src, n_dst):
         src, dst = edge_index[0], edge_index[1]
         if ((src < 0) | (src >= n_src) | (dst < 0) | (dst >= n_dst)).any():
             raise IndexError("edge_index out of range")
