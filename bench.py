@@ -532,8 +532,11 @@ def event_mode_record():
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_event_step.py")], capture_output=True, text=True,
-                           timeout=300)
-        return json.loads(r.stdout.strip().splitlines()[-1])
+                           timeout=420)
+        try:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return {"error": "no record", "stderr_tail": r.stderr[-400:]}
     except Exception as e:  # noqa: BLE001 -- informational record only
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 

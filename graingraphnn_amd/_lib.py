@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 23
+GGNN_ABI_VERSION = 24
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -40,7 +40,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
-    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_step_refresh",
+    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
+    "ggnn_topology_counts", "ggnn_topology_export", "ggnn_topology_close", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
 
@@ -307,7 +308,7 @@ def _declare(lib):
                                                 c_float, c_float, c_void_p, c_void_p]
     lib.ggnn_step_refresh_prepare.restype = c_int
     lib.ggnn_step_refresh_prepare.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p,
-                                              POINTER(PrepareEdge), c_int, c_void_p]
+                                              POINTER(PrepareEdge), c_int, c_void_p, c_void_p, c_void_p]
     lib.ggnn_lstm_train_forward.restype = c_int
     lib.ggnn_lstm_train_forward.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                             c_int, c_void_p]
@@ -353,6 +354,17 @@ def _declare(lib):
                                        c_float, c_void_p, c_void_p]
     lib.ggnn_topology_update.restype = c_int
     lib.ggnn_topology_update.argtypes = [POINTER(TopologyArgs)]
+    lib.ggnn_topology_open.restype = c_int
+    lib.ggnn_topology_open.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                       POINTER(c_void_p), ctypes.c_char_p]
+    lib.ggnn_topology_apply.restype = c_int
+    lib.ggnn_topology_apply.argtypes = [c_void_p, POINTER(TopologyArgs)]
+    lib.ggnn_topology_counts.restype = c_int
+    lib.ggnn_topology_counts.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64)]
+    lib.ggnn_topology_export.restype = c_int
+    lib.ggnn_topology_export.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]
+    lib.ggnn_topology_close.restype = None
+    lib.ggnn_topology_close.argtypes = [c_void_p]
     lib.ggnn_workspace_bytes.restype = c_size_t
     lib.ggnn_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
 

@@ -98,10 +98,11 @@ class HipBackend:
         (one host sync, only when a topology is first seen)."""
         return self.build_csr_batch([(edge_index, n_src, n_dst)])[0]
 
-    def build_csr_batch(self, lists):
+    def build_csr_batch(self, lists, check=True):
         """[(edge_index [2, E] int64 cuda, n_src, n_dst)] -> [CSR]: ggnn_build_csr_batch, up to four lists per sequence of
         launches (engine.GraphCSR builds the three edge types of a topology in one; a topological event rebuilds them),
-        one range check = one host synchronisation behind the last."""
+        one range check = one host synchronisation behind the last (`check=False`: lists the caller has validated -- the
+        kernels skip an out-of-range edge either way --: no read-back, the host goes on enqueueing)."""
         out, todo = [], list(lists)
         while todo:
             chunk, todo = todo[:4], todo[4:]
@@ -128,7 +129,9 @@ class HipBackend:
                 a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
                 keep.append((ei, ws, flags, n_src, n_dst))
                 out.append(CSR(rowptr, col, perm, row, unit_ptr, units, E))
-            check(self.lib.ggnn_build_csr_batch(arr, len(chunk), _lib.current_stream()), "ggnn_build_csr_batch")
+            _lib.check(self.lib.ggnn_build_csr_batch(arr, len(chunk), _lib.current_stream()), "ggnn_build_csr_batch")
+            if not check:   # (ei / ws / flags are only used by launches on this stream: the allocator keeps them until those ran)
+                continue
             bad = torch.stack([k[2][0] for k in keep]).cpu()   # (the synchronisation; also keeps ei / ws alive until here)
             for k, f in zip(keep, bad.tolist()):
                 if f & 1:
@@ -687,10 +690,18 @@ class HipBackend:
                      x_grain.size(1), ptr(w), ptr(b), ptr(y_joint), ptr(y_grain), ptr(grain_area), dz, zmax,
                      ptr(flags), _lib.current_stream())
 
-    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items):
+    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items, mirror=None):
         """step_refresh + edge_prepare of the next forward in one launch (ggnn_step_refresh_prepare); items as
-        edge_prepare: (csr, edge_attr [E] COO order -- WRITTEN here --, x_src, x_dst, einfo_out)."""
+        edge_prepare: (csr, edge_attr [E] COO order -- WRITTEN here --, x_src, x_dst, einfo_out).  `mirror` = (x_joint',
+        x_grain'): second copies of the node features as they stand behind this call (include/ggnn.h)."""
         _require_cuda(x_joint, x_grain, flags)
+        mj = mg = None
+        if mirror is not None:
+            mj, mg = mirror
+            _require_cuda(mj, mg)
+            if mj.shape != x_joint.shape or mg.shape != x_grain.shape or mj.stride() != x_joint.stride() \
+                    or mg.stride() != x_grain.stride() or mj.dtype != torch.float32 or mg.dtype != torch.float32:
+                raise _lib.GGNNError("mirror tensors must have the shape and strides of x_joint / x_grain")
         arr = (PrepareEdge * max(len(items), 1))()
         for k, (csr, ea, xs, xd, einfo) in enumerate(items):
             _require_cuda(csr.col, ea, xs, xd, einfo)
@@ -703,7 +714,7 @@ class HipBackend:
             a.ldx_src, a.ldx_dst, a.E, a.f_src = xs.stride(0), xd.stride(0), ea.numel(), xs.size(1)
         self._launch(self.lib.ggnn_step_refresh_prepare, "ggnn_step_refresh_prepare", ptr(x_joint), x_joint.size(0),
                      x_joint.stride(0), ptr(x_grain), x_grain.size(0), x_grain.stride(0), zmax, ptr(flags), arr,
-                     len(items), _lib.current_stream())
+                     len(items), None if mj is None else ptr(mj), None if mg is None else ptr(mg), _lib.current_stream())
 
     def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
                          edge_event, edge):

@@ -135,16 +135,27 @@ __global__ __launch_bounds__(256) void edge_prepare_kernel(const PrepareArgs P) 
 }
 
 // z clamp of every node (test.py:405-407) in the first workgroups, then refresh + records per edge
+// (x_joint_mirror / x_grain_mirror: optional second copies of the node features as they stand BEHIND this step -- every
+// column, the clamped z included -- for a reader that runs beside the next step's in-place updates of x: rollout.py)
 __global__ __launch_bounds__(256) void refresh_prepare_kernel(const PrepareArgs P, float* __restrict__ x_joint,
                                                               int64_t n_joint, int64_t ldxj, float* __restrict__ x_grain,
                                                               int64_t n_grain, int64_t ldxg, float zmax,
-                                                              const int32_t* __restrict__ flags, int node_blocks) {
+                                                              const int32_t* __restrict__ flags, int node_blocks,
+                                                              float* __restrict__ x_joint_mirror,
+                                                              float* __restrict__ x_grain_mirror) {
   const bool clamp = flags[1] != 0;
   if ((int)blockIdx.x < node_blocks) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (clamp && t < n_joint + n_grain) {
-      if (t < n_joint) x_joint[t * ldxj + 2] = zmax;
-      else x_grain[(t - n_joint) * ldxg + 2] = zmax;
+    if (t < n_joint + n_grain) {
+      const bool jt = t < n_joint;
+      float* row = jt ? x_joint + t * ldxj : x_grain + (t - n_joint) * ldxg;
+      if (clamp) row[2] = zmax;
+      float* mir = jt ? x_joint_mirror : x_grain_mirror;
+      if (mir != nullptr) {
+        const int64_t ld = jt ? ldxj : ldxg;
+        mir += (jt ? t : t - n_joint) * ld;
+        for (int64_t c = 0; c < ld; ++c) mir[c] = (clamp && c == 2) ? zmax : row[c];
+      }
     }
     return;
   }
@@ -377,9 +388,12 @@ extern "C" int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_type
 
 extern "C" int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
                                          int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
-                                         const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream) {
+                                         const ggnn_prepare_edge* edges, int n_edge_types, float* x_joint_mirror,
+                                         float* x_grain_mirror, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!x_joint || !x_grain || !flags || n_joint <= 0 || n_grain <= 0 || ldx_joint < 3 || ldx_grain < 3) return GGNN_EINVAL;
+  if ((x_joint_mirror == nullptr) != (x_grain_mirror == nullptr) || x_joint_mirror == x_joint || x_grain_mirror == x_grain)
+    return GGNN_EINVAL;
   if (!edges || n_edge_types < 1 || n_edge_types > 3) return GGNN_EINVAL;
   PrepareArgs P;
   P.n_et = n_edge_types;
@@ -403,7 +417,7 @@ extern "C" int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_
   if (node_blocks + P.b_off[n_edge_types] >= INT32_MAX) return GGNN_EINVAL;
   hipLaunchKernelGGL(refresh_prepare_kernel, dim3((unsigned)(node_blocks + P.b_off[n_edge_types])), dim3(256), 0,
                      (hipStream_t)stream, P, x_joint, n_joint, ldx_joint, x_grain, n_grain, ldx_grain, zmax, flags,
-                     (int)node_blocks);
+                     (int)node_blocks, x_joint_mirror, x_grain_mirror);
   return launch_status();
 }
 

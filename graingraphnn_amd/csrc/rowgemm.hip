@@ -45,16 +45,21 @@ __device__ __forceinline__ uint32_t rg_row_amax(uint32_t am, int lane) {
 __device__ __forceinline__ float rg_rescale(RowScale& R, uint32_t am) {
   const int e = (int)(am >> 23);
   if (e <= R.e && R.s != 0.f) return 1.0f;
+  const bool had = R.s != 0.f;
+  const int es_old = (int)(__float_as_uint(R.s) >> 23);   // (a finite power of two when `had`: a NaN scale returns above)
   float f = 1.0f;
-  if (R.s != 0.f) f = e - R.e > 126 ? 0.f : __uint_as_float((uint32_t)(127 - (e - R.e)) << 23);
-  R.e = e;
   if (e == 255) {
+    if (had) f = e - R.e > 126 ? 0.f : __uint_as_float((uint32_t)(127 - (e - R.e)) << 23);
     R.s = R.inv = __builtin_nanf("");
   } else {
+    // the factor follows the CLAMPED scale exponents: for rows at or below 2^-112 the scale stays at 2^126 while the
+    // row's exponent still rises, and the accumulators must then stay as they are
     const int es = min(max(268 - e, 1), 253);
+    if (had) f = es_old - es > 126 ? 0.f : __uint_as_float((uint32_t)(127 - (es_old - es)) << 23);
     R.s = __uint_as_float((uint32_t)es << 23);
     R.inv = __uint_as_float((uint32_t)(254 - es) << 23);
   }
+  R.e = e;
   return f;
 }
 __device__ __forceinline__ void rg_track8(uint32_t& am, const f32x4 a, const f32x4 b) {

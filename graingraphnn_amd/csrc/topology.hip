@@ -35,45 +35,147 @@ constexpr float JOINT_SCALING = 5.0f;   // models.py:398 scaling['joint']
 
 struct Refused {};   // thrown with the message already in args.error
 
-// `cols(v)`: the columns c with row[c] == v, in increasing order, without scanning the row.
-struct ColumnIndex {
-  const int64_t* row = nullptr;   // the indexed row (re-pointed when the list is reallocated)
-  std::vector<int64_t> order, start;
-  std::unordered_map<int64_t, std::vector<int64_t>> later;   // columns rewritten to / appended with a value afterwards
-
-  void build(const int64_t* r, int64_t n, int64_t n_keys) {
-    row = r;
-    start.assign(n_keys + 1, 0);
-    for (int64_t c = 0; c < n; ++c) ++start[r[c] + 1];
-    for (int64_t k = 0; k < n_keys; ++k) start[k + 1] += start[k];
-    order.resize(n);
-    std::vector<int64_t> fill(start.begin(), start.end() - 1);
-    for (int64_t c = 0; c < n; ++c) order[fill[r[c]]++] = c;   // counting sort: increasing columns inside a group
+// `cols(v)`: the columns c with row[c] == v, in increasing order, without scanning the row.  Exact at every moment: a
+// column is moved between the lists of its old and its new value when it is rewritten (round 5 rebuilt this index by a counting
+// sort at every call and filtered stale entries at every lookup: four O(E) passes per call for a handful of events).
+struct KeyIndex {
+  std::vector<std::vector<int64_t>> at;
+  void init(int64_t n_keys) { at.assign((size_t)n_keys, {}); }
+  void add(int64_t key, int64_t col) {
+    auto& v = at[(size_t)key];
+    if (v.empty() || v.back() < col) v.push_back(col);
+    else v.insert(std::lower_bound(v.begin(), v.end(), col), col);
   }
-  void note(int64_t col, int64_t v) { later[v].push_back(col); }
+  void drop(int64_t key, int64_t col) {
+    auto& v = at[(size_t)key];
+    auto it = std::lower_bound(v.begin(), v.end(), col);
+    if (it != v.end() && *it == col) v.erase(it);
+  }
   void cols(int64_t v, std::vector<int64_t>& out) const {
-    out.clear();
-    if (v >= 0 && v + 1 < (int64_t)start.size())
-      for (int64_t k = start[v]; k < start[v + 1]; ++k) out.push_back(order[k]);
-    auto it = later.find(v);
-    if (it != later.end()) {
-      out.insert(out.end(), it->second.begin(), it->second.end());
-      std::sort(out.begin(), out.end());
-      out.erase(std::unique(out.begin(), out.end()), out.end());
-    }
-    out.erase(std::remove_if(out.begin(), out.end(), [&](int64_t c) { return row[c] != v; }), out.end());
+    if (v >= 0 && v < (int64_t)at.size()) out = at[(size_t)v];
+    else out.clear();
   }
 };
 
+}  // namespace
+
+// The lists of one trajectory between two calls (ggnn_topology_open / _apply / _export / _close, include/ggnn.h): columns keep a
+// STABLE number for the session's life -- rewritten in place, new ones appended, removed ones left behind as DEAD -- so the
+// indices and the per-grain counts persist and a call costs what its events touch, plus one pass that renumbers the live
+// columns for the caller (the reference drops dead columns at the end of every update: the caller's column c is the c-th live
+// stable column).  Every write of a call is journalled: a refused call leaves the session and the caller's arrays as they were.
+struct ggnn_topology_session {
+  int64_t n_joint = 0, n_grain = 0;
+  std::vector<int64_t> arr[4];          // pp0, pp1, pq0, pq1 by stable column
+  KeyIndex idx[4];
+  std::vector<int64_t> ext_pp, ext_pq;  // caller's column -> stable column
+  std::vector<int64_t> n_of_grain;      // columns per grain: the counts of np.unique(pq[1])
+  std::vector<int64_t> few;             // grains with one or two columns, unsorted (membership checked against n_of_grain)
+  struct Undo { int kind; int64_t col, old; };          // kind 0..3: arr[kind][col] was `old`; 4: two pp columns appended
+  struct UndoF { float* p; float old; };
+  struct UndoM { int64_t* p; int64_t old; };
+  std::vector<Undo> undo;
+  std::vector<UndoF> undo_f;
+  std::vector<UndoM> undo_m;
+
+  void recount(int64_t g, int by) {
+    const int64_t n = n_of_grain[(size_t)g] += by;
+    if (n >= 1 && n <= 2) few.push_back(g);   // (duplicates and stale entries are dropped when the list is read)
+  }
+  void raw_put(int kind, int64_t col, int64_t v) {
+    int64_t& slot = arr[kind][(size_t)col];
+    const int64_t old = slot;
+    if (old == v) return;
+    if (old != -1) {
+      idx[kind].drop(old, col);
+      if (kind == 3) recount(old, -1);
+    }
+    slot = v;
+    if (v != -1) {
+      idx[kind].add(v, col);
+      if (kind == 3) recount(v, +1);
+    }
+  }
+  void put(int kind, int64_t col, int64_t v) {
+    const int64_t old = arr[kind][(size_t)col];
+    if (old == v) return;
+    undo.push_back({kind, col, old});
+    raw_put(kind, col, v);
+  }
+  int64_t append_pp(int64_t a, int64_t b) {
+    const int64_t col = (int64_t)arr[0].size();
+    arr[0].push_back(-1), arr[1].push_back(-1);
+    undo.push_back({4, col, 0});
+    raw_put(0, col, a), raw_put(1, col, b);
+    return col;
+  }
+  void put_f(float* p, float v) {
+    undo_f.push_back({p, *p});
+    *p = v;
+  }
+  void put_m(int64_t* p, int64_t v) {
+    undo_m.push_back({p, *p});
+    *p = v;
+  }
+  void commit() { undo.clear(), undo_f.clear(), undo_m.clear(); }
+  void rollback() {
+    for (size_t k = undo.size(); k-- > 0;) {
+      const Undo& u = undo[k];
+      if (u.kind < 4) raw_put(u.kind, u.col, u.old);
+      else raw_put(0, u.col, -1), raw_put(1, u.col, -1), arr[0].pop_back(), arr[1].pop_back();
+    }
+    for (size_t k = undo_f.size(); k-- > 0;) *undo_f[k].p = undo_f[k].old;
+    for (size_t k = undo_m.size(); k-- > 0;) *undo_m[k].p = undo_m[k].old;
+    commit();
+  }
+  // the caller's numbering of the live columns (and, when most stable columns are dead, a fresh start from the live ones)
+  void renumber() {
+    for (int l = 0; l < 2; ++l) {
+      std::vector<int64_t>& ext = l ? ext_pq : ext_pp;
+      const std::vector<int64_t>& a = arr[2 * l];
+      ext.clear();
+      for (int64_t c = 0; c < (int64_t)a.size(); ++c)
+        if (a[(size_t)c] != -1) ext.push_back(c);
+    }
+    if (arr[0].size() > 2 * ext_pp.size() + 1024 || arr[2].size() > 2 * ext_pq.size() + 1024) {
+      std::vector<int64_t> live[4];
+      for (int k = 0; k < 4; ++k)
+        for (int64_t c : (k < 2 ? ext_pp : ext_pq)) live[k].push_back(arr[k][(size_t)c]);
+      load(live[0].data(), live[1].data(), (int64_t)live[0].size(), live[2].data(), live[3].data(), (int64_t)live[2].size());
+    }
+  }
+  void load(const int64_t* p0, const int64_t* p1, int64_t n_pp, const int64_t* q0, const int64_t* q1, int64_t n_pq) {
+    const int64_t* src[4] = {p0, p1, q0, q1};
+    for (int k = 0; k < 4; ++k) {
+      const int64_t n = k < 2 ? n_pp : n_pq;
+      arr[k].assign(src[k], src[k] + n);
+      idx[k].init(k == 3 ? n_grain : n_joint);
+      for (int64_t c = 0; c < n; ++c) idx[k].at[(size_t)arr[k][(size_t)c]].push_back(c);
+    }
+    n_of_grain.assign((size_t)n_grain, 0);
+    for (int64_t c = 0; c < n_pq; ++c) ++n_of_grain[(size_t)arr[3][(size_t)c]];
+    few.clear();
+    for (int64_t g = 0; g < n_grain; ++g)
+      if (n_of_grain[(size_t)g] >= 1 && n_of_grain[(size_t)g] <= 2) few.push_back(g);
+    ext_pp.resize((size_t)n_pp), ext_pq.resize((size_t)n_pq);
+    for (int64_t c = 0; c < n_pp; ++c) ext_pp[(size_t)c] = c;
+    for (int64_t c = 0; c < n_pq; ++c) ext_pq[(size_t)c] = c;
+  }
+};
+
+namespace {
+
+using Session = ggnn_topology_session;
+
+// One call of the reference's update on a session's lists.
 struct Topology {
   ggnn_topology_args& A;
-  int64_t *pp0, *pp1, *pq0, *pq1;
-  int64_t n_pp, n_pq;
-  ColumnIndex ipp0, ipp1, ipq0, ipq1;
-  std::vector<int64_t> n_of_grain;   // columns per grain: the counts of np.unique(pq[1])
-  std::vector<int64_t> few;          // grains with one or two columns, unsorted (membership checked against n_of_grain)
-  int64_t n_dead = 0;
-  std::vector<int64_t> t0, t1, t2;   // scratch of the lookups
+  Session& S;
+  std::vector<int64_t>&pp0, &pp1, &pq0, &pq1;
+  KeyIndex &ipp0, &ipp1, &ipq0, &ipq1;
+  std::vector<int64_t>& n_of_grain;
+  std::vector<int64_t>& few;
+  int64_t n_dead = 0;                // pq columns killed by THIS call (the reference's list still holds them as -1)
 
   [[noreturn]] void refuse(const char* fmt, ...) {
     va_list ap;
@@ -94,36 +196,20 @@ struct Topology {
   float* yj(int64_t j) { return A.y_joint + joint(j) * 2; }
   bool is_active(int64_t j) { return A.active_joint == nullptr || A.active_joint[joint(j)] != 0; }
 
-  explicit Topology(ggnn_topology_args& a) : A(a) {
-    pp0 = A.pp, pp1 = A.pp + A.pp_cap, pq0 = A.pq, pq1 = A.pq + A.pq_cap;
-    n_pp = A.n_pp, n_pq = A.n_pq;
-    for (int64_t c = 0; c < n_pp; ++c) joint(pp0[c]), joint(pp1[c]);
-    for (int64_t c = 0; c < n_pq; ++c) joint(pq0[c]), grain_id(pq1[c]);
-    ipp0.build(pp0, n_pp, A.n_joint), ipp1.build(pp1, n_pp, A.n_joint);
-    ipq0.build(pq0, n_pq, A.n_joint), ipq1.build(pq1, n_pq, A.n_grain);
-    n_of_grain.assign(A.n_grain, 0);
-    for (int64_t c = 0; c < n_pq; ++c) ++n_of_grain[pq1[c]];
-    for (int64_t g = 0; g < A.n_grain; ++g)
-      if (n_of_grain[g] >= 1 && n_of_grain[g] <= 2) few.push_back(g);
-  }
+  Topology(ggnn_topology_args& a, Session& s)
+      : A(a), S(s), pp0(s.arr[0]), pp1(s.arr[1]), pq0(s.arr[2]), pq1(s.arr[3]), ipp0(s.idx[0]), ipp1(s.idx[1]),
+        ipq0(s.idx[2]), ipq1(s.idx[3]), n_of_grain(s.n_of_grain), few(s.few) {}
 
-  // -- writes that the indices and the per-grain counts follow --
-  void recount(int64_t g, int by) {
-    const int64_t n = n_of_grain[g] += by;
-    if (n >= 1 && n <= 2) few.push_back(g);   // (duplicates and stale entries are dropped when the list is read)
-  }
-  void set_grain(int64_t col, int64_t g) {
-    recount(pq1[col], -1);
-    pq1[col] = grain_id(g);
-    recount(g, +1);
-    ipq1.note(col, g);
-  }
+  // -- writes that the indices, the per-grain counts and the journal follow --
+  void set_grain(int64_t col, int64_t g) { S.put(3, col, grain_id(g)); }
   void kill_pq(const std::vector<int64_t>& cols) {
     for (int64_t c : cols) {
-      recount(pq1[c], -1);
       ++n_dead;
-      pq0[c] = pq1[c] = DEAD;
+      S.put(2, c, DEAD), S.put(3, c, DEAD);
     }
+  }
+  void kill_pp(const std::vector<int64_t>& cols) {
+    for (int64_t c : cols) S.put(0, c, DEAD), S.put(1, c, DEAD);
   }
   bool has_pq(int64_t j, int64_t g) {
     std::vector<int64_t> c;
@@ -150,23 +236,19 @@ struct Topology {
       if (pp1[k] != p1) { n2 = pp1[k]; break; }
     if (n1 == DEAD || n2 == DEAD)
       refuse("junctions %lld, %lld of grain %lld have no outer neighbour", (long long)p1, (long long)p2, (long long)grain);
-    if (n_pp + 2 > A.pp_cap) refuse("the junction edge list needs room for two more columns (pp_cap)");
-    const int64_t E = n_pp;
-    pp0[E] = n1, pp1[E] = n2, pp0[E + 1] = n2, pp1[E + 1] = n1;
-    n_pp += 2;
-    ipp0.note(E, n1), ipp1.note(E, n2), ipp0.note(E + 1, n2), ipp1.note(E + 1, n1);
-    A.mask_grain[grain_id(grain)] = 0;
-    A.mask_joint[joint(p1)] = 0;
-    A.mask_joint[joint(p2)] = 0;
+    S.append_pp(n1, n2), S.append_pp(n2, n1);
+    S.put_m(&A.mask_grain[grain_id(grain)], 0);
+    S.put_m(&A.mask_joint[joint(p1)], 0);
+    S.put_m(&A.mask_joint[joint(p2)], 0);
     ipq1.cols(grain, c);
     kill_pq(c);
     for (int64_t j : {p1, p2}) {
       ipq0.cols(j, c);
       kill_pq(c);
       ipp0.cols(j, c);
-      for (int64_t k : c) pp0[k] = pp1[k] = DEAD;
+      kill_pp(c);
       ipp1.cols(j, c);
-      for (int64_t k : c) pp0[k] = pp1[k] = DEAD;
+      kill_pp(c);
     }
   }
 
@@ -214,8 +296,8 @@ struct Topology {
     touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
     for (int64_t p : touched) {   // back to the position before this step
       float *x = xj(p), *y = yj(p);
-      x[0] = x[0] - y[0] / JOINT_SCALING;
-      x[1] = x[1] - y[1] / JOINT_SCALING;
+      S.put_f(&x[0], x[0] - y[0] / JOINT_SCALING);
+      S.put_f(&x[1], x[1] - y[1] / JOINT_SCALING);
     }
     std::vector<int64_t> c1, c2, e1, e2, tmp;
     for (size_t k = 0; k < cols.size(); ++k) {
@@ -242,8 +324,10 @@ struct Topology {
         if (!in(g1, g)) grow2.push_back(g);
       if (shrink.size() != 2 || grow1.size() != 1 || grow2.size() != 1)
         refuse("junctions %lld, %lld do not share exactly two grains", (long long)p1, (long long)p2);
-      if (c1.size() < 3 || c2.size() < 3 || n1.size() != 2 || n2.size() != 2)
+      if (c1.size() < 3 || c2.size() < 3 || n1.size() < 2 || n2.size() < 2)
         refuse("junctions %lld, %lld do not have three grains and three neighbours each", (long long)p1, (long long)p2);
+      // (models.py:951-965 goes on with the FIRST TWO other neighbours of a junction that has more)
+      e1.resize(2), n1.resize(2), e2.resize(2), n2.resize(2);
       const int64_t sa = shrink[0], sb = shrink[1];
       std::vector<int64_t> d1, d2;   // each junction's columns of (sa, sb)
       for (int i = 0; i < 3; ++i)
@@ -269,7 +353,7 @@ struct Topology {
       mid[0] = 0.5f * (x1[0] + near2[0]);
       mid[1] = 0.5f * (x1[1] + near2[1]);
       wrap_to(mid, x2, new2);
-      x1[0] = mid[0], x1[1] = mid[1], x2[0] = new2[0], x2[1] = new2[1];
+      S.put_f(&x1[0], mid[0]), S.put_f(&x1[1], mid[1]), S.put_f(&x2[0], new2[0]), S.put_f(&x2[1], new2[1]);
       bool flip = inside_triangle(x2, x1, xj(a1), xj(a2));
       // look ahead: junctions that later switches of this call still need keep their side
       auto later = [&](int64_t j) {
@@ -289,23 +373,23 @@ struct Topology {
       }
       set_grain(d1[1], grow2[0]);
       set_grain(d2[0], grow1[0]);
-      pp0[e1[1]] = p2, ipp0.note(e1[1], p2);
-      pp0[e2[0]] = p1, ipp0.note(e2[0], p1);
+      S.put(0, e1[1], p2);
+      S.put(0, e2[0], p1);
       ipp0.cols(a2, tmp);
       for (int64_t c : tmp)
-        if (pp1[c] == p2) pp1[c] = p1, ipp1.note(c, p1);
+        if (pp1[c] == p2) S.put(1, c, p1);
       ipp0.cols(b1, tmp);
       for (int64_t c : tmp)
-        if (pp1[c] == p1) pp1[c] = p2, ipp1.note(c, p2);
+        if (pp1[c] == p1) S.put(1, c, p2);
     }
     for (int64_t p : touched) {
       // KEEP (models.py:903, 1045-1047): the reference remembers a VIEW of the rewound position, so the displacement
       // feature of every touched junction comes out as 0 (x - x: NaN for a non-finite coordinate, as there).
       float *x = xj(p), *y = yj(p);
-      y[0] = JOINT_SCALING * (x[0] - x[0]);
-      y[1] = JOINT_SCALING * (x[1] - x[1]);
+      S.put_f(&y[0], JOINT_SCALING * (x[0] - x[0]));
+      S.put_f(&y[1], JOINT_SCALING * (x[1] - x[1]));
       if (A.ldx < 8) refuse("x_joint needs 8 feature columns");
-      x[6] = y[0], x[7] = y[1];
+      S.put_f(&x[6], y[0]), S.put_f(&x[7], y[1]);
     }
     return forced;
   }
@@ -336,9 +420,10 @@ struct Topology {
         for (int64_t c : tmp)
           if (pq1[c] != grain) other_hi.push_back(pq1[c]);
         auto in = [&](int64_t g) { return std::find(other_hi.begin(), other_hi.end(), g) != other_hi.end(); };
-        if (other_lo.size() < 2) refuse("junction %lld of grain %lld does not have two other grains", (long long)lo, (long long)grain);
+        // (models.py:668-673 tests Nq1[0] first: a junction with ONE other grain passes when that grain is across the edge)
+        if (other_lo.empty()) refuse("junction %lld of grain %lld has no other grain", (long long)lo, (long long)grain);
         if (in(other_lo[0])) across.push_back(other_lo[0]);
-        else if (in(other_lo[1])) across.push_back(other_lo[1]);
+        else if (other_lo.size() >= 2 && in(other_lo[1])) across.push_back(other_lo[1]);
         else refuse("edge (%lld, %lld) of grain %lld has no grain on its other side", (long long)lo, (long long)hi, (long long)grain);
       }
     if (across.size() != corners.size())
@@ -372,9 +457,18 @@ struct Topology {
 
   void run() {
     const float thr = (float)A.threshold;   // (numpy compares the fp32 probabilities with the Python float in fp32)
+    // the caller's column c is the session's stable column ext_pp[c] (same relative order)
     std::vector<int64_t> pending, extra, forced;
-    for (int64_t c = 0; c < A.n_pp; ++c)
-      if (A.edge_prob[c] > thr && pp0[c] < pp1[c]) pending.push_back(c);
+    std::unordered_map<int64_t, float> prob_of;   // probabilities of the pending columns, by stable column
+    const int64_t n_ext = (int64_t)S.ext_pp.size();
+    for (int64_t c = 0; c < n_ext; ++c) {
+      const int64_t k = S.ext_pp[(size_t)c];
+      if (A.edge_prob[c] > thr && pp0[(size_t)k] < pp1[(size_t)k]) pending.push_back(k), prob_of[k] = A.edge_prob[c];
+    }
+    // the output lists' room is checked BEFORE anything is rewritten (the switching list only shrinks from here on; every
+    // grain and the dead-column marker can be reported at most once)
+    if ((int64_t)pending.size() > A.switching_cap) refuse("switching list: room for %lld pairs needed", (long long)pending.size());
+    if (A.extra_cap < A.n_grain + 1) refuse("event list: room for n_grain + 1 = %lld grains needed", (long long)(A.n_grain + 1));
     for (int64_t k = 0; k < A.n_grain_event; ++k) {
       const int64_t g = grain_id(A.grain_event[k]);
       if (A.active_grain != nullptr && !A.active_grain[g]) continue;
@@ -383,52 +477,146 @@ struct Topology {
     }
     // neighbour switching, most probable edge first (ties: lower column first): argsort(-prob, stable), NaN last
     std::stable_sort(pending.begin(), pending.end(), [&](int64_t a, int64_t b) {
-      const float u = -A.edge_prob[a], v = -A.edge_prob[b];
+      const float u = -prob_of[a], v = -prob_of[b];
       return (u < v) || (std::isnan(v) && !std::isnan(u));
     });
-    pending.erase(std::remove_if(pending.begin(), pending.end(), [&](int64_t c) { return pp0[c] == DEAD; }), pending.end());
+    pending.erase(std::remove_if(pending.begin(), pending.end(), [&](int64_t c) { return pp0[(size_t)c] == DEAD; }), pending.end());
     switch_edges(pending, false, DEAD);
-    if ((int64_t)pending.size() > A.switching_cap) refuse("switching list: room for %lld pairs needed", (long long)pending.size());
     A.n_switching = (int64_t)pending.size();
-    for (size_t i = 0; i < pending.size(); ++i) A.switching[2 * i] = pp0[pending[i]], A.switching[2 * i + 1] = pp1[pending[i]];
+    for (size_t i = 0; i < pending.size(); ++i)
+      A.switching[2 * i] = pp0[(size_t)pending[i]], A.switching[2 * i + 1] = pp1[(size_t)pending[i]];
     const std::vector<int64_t> last = remove_all_two_sided();
     extra.insert(extra.end(), last.begin(), last.end());
     if ((int64_t)extra.size() > A.extra_cap) refuse("event list: room for %lld more grains needed", (long long)extra.size());
     A.n_extra = (int64_t)extra.size();
     std::copy(extra.begin(), extra.end(), A.events_extra);
-    // models.py:845-858: drop dead columns (order kept)
-    int64_t w = 0;
-    for (int64_t c = 0; c < n_pp; ++c)
-      if (pp0[c] != DEAD) pp0[w] = pp0[c], pp1[w] = pp1[c], ++w;
-    A.n_pp = w;
-    w = 0;
-    for (int64_t c = 0; c < n_pq; ++c)
-      if (pq0[c] != DEAD) pq0[w] = pq0[c], pq1[w] = pq1[c], ++w;
-    A.n_pq = w;
   }
 };
 
+int check_apply_args(const ggnn_topology_args& A) {
+  if (!A.x_joint || !A.y_joint || !A.y_grain_area || !A.edge_prob || !A.mask_grain || !A.mask_joint ||
+      (A.n_grain_event > 0 && !A.grain_event) || !A.switching || !A.events_extra)
+    return GGNN_EINVAL;
+  if (A.n_joint <= 0 || A.n_grain <= 0 || A.ldx < 8 || A.ldyg < 1 || A.n_grain_event < 0 || A.switching_cap < 0 || A.extra_cap < 0)
+    return GGNN_EINVAL;
+  return GGNN_OK;
+}
+
+// Validates and loads the lists; the message of a refusal goes to `error` (192 bytes) when given.
+int open_session(const int64_t* pp0, const int64_t* pp1, int64_t n_pp, const int64_t* pq0, const int64_t* pq1, int64_t n_pq,
+                 int64_t n_joint, int64_t n_grain, Session** out, char* error) {
+  if (!out || n_pp < 0 || n_pq < 0 || n_joint <= 0 || n_grain <= 0 || (n_pp > 0 && (!pp0 || !pp1)) || (n_pq > 0 && (!pq0 || !pq1)))
+    return GGNN_EINVAL;
+  auto bad = [&](const char* what, int64_t v, int64_t n) {
+    if (error) snprintf(error, 192, "%s index %lld outside [0, %lld)", what, (long long)v, (long long)n);
+    return GGNN_ETOPOLOGY;
+  };
+  for (int64_t c = 0; c < n_pp; ++c) {
+    if (pp0[c] < 0 || pp0[c] >= n_joint) return bad("junction", pp0[c], n_joint);
+    if (pp1[c] < 0 || pp1[c] >= n_joint) return bad("junction", pp1[c], n_joint);
+  }
+  for (int64_t c = 0; c < n_pq; ++c) {
+    if (pq0[c] < 0 || pq0[c] >= n_joint) return bad("junction", pq0[c], n_joint);
+    if (pq1[c] < 0 || pq1[c] >= n_grain) return bad("grain", pq1[c], n_grain);
+  }
+  try {
+    Session* s = new Session();
+    s->n_joint = n_joint, s->n_grain = n_grain;
+    s->load(pp0, pp1, n_pp, pq0, pq1, n_pq);
+    *out = s;
+  } catch (const std::exception& e) {
+    if (error) snprintf(error, 192, "%s", e.what());
+    return GGNN_ETOPOLOGY;
+  }
+  return GGNN_OK;
+}
+
+int apply_session(Session& S, ggnn_topology_args& A) {
+  A.error[0] = 0;
+  A.n_switching = A.n_extra = 0;
+  if (const int rc = check_apply_args(A)) return rc;
+  if (A.n_joint != S.n_joint || A.n_grain != S.n_grain) return GGNN_EINVAL;
+  S.commit();
+  try {
+    Topology T(A, S);
+    T.run();
+    S.commit();
+    S.renumber();   // models.py:845-858: the dead columns are dropped (order kept) -- here: skipped by the caller's numbering
+  } catch (const Refused&) {
+    S.rollback();
+    return GGNN_ETOPOLOGY;
+  } catch (const std::exception& e) {
+    S.rollback();
+    snprintf(A.error, sizeof(A.error), "%s", e.what());
+    return GGNN_ETOPOLOGY;
+  }
+  A.n_pp = (int64_t)S.ext_pp.size(), A.n_pq = (int64_t)S.ext_pq.size();
+  return GGNN_OK;
+}
+
 }  // namespace
 
+extern "C" int ggnn_topology_open(const int64_t* pp, int64_t n_pp, int64_t pp_ld, const int64_t* pq, int64_t n_pq,
+                                  int64_t pq_ld, int64_t n_joint, int64_t n_grain, ggnn_topology_session** session,
+                                  char* error) {
+  if (error) error[0] = 0;
+  if (pp_ld < n_pp || pq_ld < n_pq) return GGNN_EINVAL;
+  return open_session(pp, pp ? pp + pp_ld : nullptr, n_pp, pq, pq ? pq + pq_ld : nullptr, n_pq, n_joint, n_grain, session, error);
+}
+
+extern "C" void ggnn_topology_close(ggnn_topology_session* session) { delete session; }
+
+extern "C" int ggnn_topology_apply(ggnn_topology_session* session, ggnn_topology_args* args) {
+  if (!session || !args) return GGNN_EINVAL;
+  return apply_session(*session, *args);
+}
+
+extern "C" int ggnn_topology_counts(const ggnn_topology_session* session, int64_t* n_pp, int64_t* n_pq) {
+  if (!session || !n_pp || !n_pq) return GGNN_EINVAL;
+  *n_pp = (int64_t)session->ext_pp.size(), *n_pq = (int64_t)session->ext_pq.size();
+  return GGNN_OK;
+}
+
+extern "C" int ggnn_topology_export(const ggnn_topology_session* session, int64_t* pp, int64_t pp_ld, int64_t* pq,
+                                    int64_t pq_ld, int64_t* qp, int64_t qp_ld) {
+  if (!session) return GGNN_EINVAL;
+  const Session& S = *session;
+  const int64_t n_pp = (int64_t)S.ext_pp.size(), n_pq = (int64_t)S.ext_pq.size();
+  if ((pp && pp_ld < n_pp) || (pq && pq_ld < n_pq) || (qp && qp_ld < n_pq)) return GGNN_EINVAL;
+  if (pp)
+    for (int64_t c = 0; c < n_pp; ++c) {
+      const size_t k = (size_t)S.ext_pp[(size_t)c];
+      pp[c] = S.arr[0][k], pp[pp_ld + c] = S.arr[1][k];
+    }
+  for (int64_t c = 0; c < n_pq && (pq || qp); ++c) {
+    const size_t k = (size_t)S.ext_pq[(size_t)c];
+    if (pq) pq[c] = S.arr[2][k], pq[pq_ld + c] = S.arr[3][k];
+    if (qp) qp[c] = S.arr[3][k], qp[qp_ld + c] = S.arr[2][k];
+  }
+  return GGNN_OK;
+}
+
+// The stateless form: a session for one call on the caller's arrays.
 extern "C" int ggnn_topology_update(ggnn_topology_args* args) {
   if (!args) return GGNN_EINVAL;
   ggnn_topology_args& A = *args;
   A.error[0] = 0;
   A.n_switching = A.n_extra = 0;
-  if (!A.pp || !A.pq || !A.x_joint || !A.y_joint || !A.y_grain_area || !A.edge_prob || !A.mask_grain || !A.mask_joint ||
-      (A.n_grain_event > 0 && !A.grain_event) || !A.switching || !A.events_extra)
-    return GGNN_EINVAL;
-  if (A.n_pp < 0 || A.n_pq < 0 || A.pp_cap < A.n_pp || A.pq_cap < A.n_pq || A.n_joint <= 0 || A.n_grain <= 0 || A.ldx < 8 ||
-      A.ldyg < 1 || A.n_grain_event < 0 || A.switching_cap < 0 || A.extra_cap < 0)
-    return GGNN_EINVAL;
-  try {
-    Topology T(A);
-    T.run();
-  } catch (const Refused&) {
-    return GGNN_ETOPOLOGY;
-  } catch (const std::exception& e) {
-    snprintf(A.error, sizeof(A.error), "%s", e.what());
-    return GGNN_ETOPOLOGY;
+  if (!A.pp || !A.pq) return GGNN_EINVAL;
+  if (const int rc = check_apply_args(A)) return rc;
+  if (A.n_pp < 0 || A.n_pq < 0 || A.pp_cap < A.n_pp || A.pq_cap < A.n_pq) return GGNN_EINVAL;
+  Session* s = nullptr;
+  int rc = open_session(A.pp, A.pp + A.pp_cap, A.n_pp, A.pq, A.pq + A.pq_cap, A.n_pq, A.n_joint, A.n_grain, &s, A.error);
+  if (rc != GGNN_OK) return rc;
+  rc = apply_session(*s, A);
+  if (rc == GGNN_OK) {
+    if (A.n_pp > A.pp_cap || A.n_pq > A.pq_cap) {
+      snprintf(A.error, sizeof(A.error), "the junction edge list needs room for %lld columns (pp_cap)", (long long)A.n_pp);
+      rc = GGNN_ETOPOLOGY;
+    } else {
+      rc = ggnn_topology_export(s, A.pp, A.pp_cap, A.pq, A.pq_cap, nullptr, 0);
+    }
   }
-  return GGNN_OK;
+  delete s;
+  return rc;
 }

@@ -20,7 +20,9 @@ ET = Tuple[str, str, str]
 class GraphCSR:
     """Destination-grouped neighbour lists of the three edge types of one topology."""
 
-    def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int]):
+    def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int], trusted: bool = False):
+        """trusted: the lists come from the library's own topology update (validated on the host, topology.py): the
+        range check of the build -- a read-back, i.e. a host synchronisation -- is skipped."""
         self.csr = {}
         self.edge_index = {}
         self.n_nodes = dict(n_nodes)
@@ -30,7 +32,7 @@ class GraphCSR:
             self.edge_index[et] = edge_index_dict[et].contiguous()
         lists = [(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]]) for et in EDGE_TYPES]
         if hasattr(backend, "build_csr_batch"):   # the three edge types in one sequence of launches, one synchronisation
-            built = backend.build_csr_batch(lists)
+            built = backend.build_csr_batch(lists, check=not trusted) if trusted else backend.build_csr_batch(lists)
         else:
             built = [backend.build_csr(*l) for l in lists]
         self.csr = dict(zip(EDGE_TYPES, built))
@@ -43,7 +45,7 @@ _graph_cache: Dict[tuple, GraphCSR] = {}
 _GRAPH_CACHE_MAX = 8
 
 
-def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
+def graph_for(backend, edge_index_dict, n_nodes, trusted: bool = False) -> GraphCSR:
     """CSR of `edge_index_dict`, rebuilt only when a tensor is replaced or modified in place
     (Cmodel.update swaps the tensors after a topological event, models.py:841-845)."""
     key = tuple((et, edge_index_dict[et].data_ptr(), edge_index_dict[et]._version,
@@ -51,7 +53,7 @@ def graph_for(backend, edge_index_dict, n_nodes) -> GraphCSR:
     key = key + tuple(sorted(n_nodes.items()))
     g = _graph_cache.get(key)
     if g is None:
-        g = GraphCSR(backend, edge_index_dict, n_nodes)
+        g = GraphCSR(backend, edge_index_dict, n_nodes, trusted)
         if len(_graph_cache) >= _GRAPH_CACHE_MAX:
             _graph_cache.pop(next(iter(_graph_cache)))
         _graph_cache[key] = g

@@ -130,18 +130,19 @@ class GrainRollout:
             self._graph_fwd = self._graph_ref = None
             self._spec = None   # (run_events' captured blocks hold the old buffers' addresses too)
 
-    def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True):
+    def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True, trusted=False):
         """(Re)build everything that depends on the edge lists: CSR + unit tables, the edge-length
         buffers (refreshed in place every step), the per-edge geometry records and the per-edge
-        outputs.  Called once at construction and after every topological event."""
+        outputs.  Called once at construction and after every topological event (`trusted`: lists the
+        library's own update produced -- no range check, no read-back)."""
         dev = self.x["joint"].device
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
-        self.graph = graph_for(self.be, self.edge_index, self.n_nodes)
+        self.graph = graph_for(self.be, self.edge_index, self.n_nodes, trusted)
         if edge_attr_dict is not None:
             self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
                               for et in EDGE_TYPES}
-        else:  # lengths are recomputed by the refresh that follows an event
-            self.edge_attr = {et: torch.zeros(self.edge_index[et].size(1), device=dev) for et in EDGE_TYPES}
+        else:  # lengths are recomputed by the refresh that follows an event (every element: nothing to initialise)
+            self.edge_attr = {et: torch.empty(self.edge_index[et].size(1), device=dev) for et in EDGE_TYPES}
         # second buffer of the pipelined step (_enqueue_step_pipelined): the refresh writes the lengths of step
         # k + 1 while the classifier's head still reads those of step k
         self._ea_other = {et: torch.empty_like(self.edge_attr[et]) for et in EDGE_TYPES}
@@ -152,11 +153,21 @@ class GrainRollout:
         self.pred["edge_event"] = torch.empty(E, dtype=torch.float32, device=dev)
         self.pred["edge"] = torch.empty(E, 2, dtype=torch.float32, device=dev)
         self.einfo = alloc_einfo(self.graph, dev)
-        # second set of edge records and the classifier's private copy of x (_enqueue_steps_overlapped): made on first use
+        # second set of edge records (_enqueue_steps_overlapped): made on first use; the classifier's copies of x keep
+        # their buffers (the node sets never change) but no longer mirror x
         self._einfo_other = None
-        self._xc = None
+        if not hasattr(self, "_xc"):
+            self._xc = self._xc_other = None
+        self._x_written_outside()
         self._graphs = None
         self._seen = None
+
+    def _x_written_outside(self):
+        """x was (or is about to be) advanced by something other than the overlapped two-stream step / the speculative
+        event step: their mirrors of x (the copies the classifier's forward reads) are stale."""
+        self._xc_fresh = False
+        if getattr(self, "_spec", None) is not None:
+            self._spec["xs_valid"] = None
 
     # -- one step, enqueued on the current stream --------------------------------------
     def _pipelined(self):
@@ -176,6 +187,7 @@ class GrainRollout:
             self._enqueue_forward_update()
             self._enqueue_refresh()
         self._einfo_fresh = False
+        self._x_written_outside()
 
     def _enqueue_steps_pipelined(self, n_steps: int):
         """`n_steps` static-topology steps on two streams with the small launches hidden and no join between
@@ -225,15 +237,19 @@ class GrainRollout:
             self.edge_attr, self._ea_other = ea_next, ea
         main.wait_stream(st_c)
         self._einfo_fresh = True
+        self._x_written_outside()
         return events
 
     def _overlap_buffers(self):
-        """The second set of edge records and the classifier's copy of x (outside any capture: _capture calls this first)."""
+        """The second set of edge records and the classifier's two alternating copies of x (outside any capture:
+        _capture calls this first)."""
         if self._pipelined() and self.overlap_tail:
             if self._einfo_other is None:
                 self._einfo_other = alloc_einfo(self.graph, self.x["joint"].device)
             if self._xc is None:
                 self._xc = {nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES}
+                self._xc_other = {nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES}
+                self._xc_fresh = False
 
     def _enqueue_steps_overlapped(self, n_steps: int):
         """`n_steps` static-topology steps on two streams with the regressor's tail -- heads + Rmodel.update, grain
@@ -242,20 +258,21 @@ class GrainRollout:
         the edge records: at 10 000 grains the two decoder cells are 393 workgroups in two rounds of the chip, the
         regressor's finishes ~100 us before the classifier's, and the tail (three launch-bound kernels, ~25 us + the
         cross-stream hand-overs) then ran on an idle chip (profiles/r5_step_timeline.txt).  Here the classifier reads a
-        private copy of x (taken at the top of its step: 1.1 MB) and the edge lengths / edge records alternate between
-        two sets -- the refresh of step k writes the set of step k + 1 while the classifier still reads the set of step k
-        -- so nothing the tail writes is read by the classifier's forward of the same step.  Cross-stream edges per step:
-          * the classifier waits for `ready` (x, edge lengths and records of this step are final; recorded by the
-            regressor's stream at the top of the step);
-          * Rmodel.update waits for `copied` (the classifier has taken its copy of x; early in the step: no stall);
+        private copy of x and the copies / edge lengths / edge records alternate between two sets -- the refresh of step
+        k writes the set of step k + 1 (the copy of x as a by-product of its pass over the nodes: ggnn_step_refresh_prepare's
+        mirror, ABI 24; round 5 copied x at the top of the classifier's step, two copy kernels at the head of its chain)
+        while the classifier still reads the set of step k -- so nothing the tail writes is read by the classifier's
+        forward of the same step.  Cross-stream edges per step:
+          * the classifier waits for `ready` (its copy of x, edge lengths and records of this step are final; recorded by
+            the regressor's stream at the top of the step);
           * the NEXT step's regressor forward waits for `swept` (the classifier's decoder cell of this step is done: the
-            chip is free, and the edge records it read may be overwritten by the next refresh); the classifier's heads
-            run behind `swept`, beside the next step's first kernels.
+            chip is free, and the copy of x / edge records it read may be overwritten by the next refresh); the
+            classifier's heads run behind `swept`, beside the next step's first kernels.
+        Needs self._xc to mirror x already (step() / run() see to that: _ensure_edge_records).
         Same kernels on the same operands as the single-stream plan: bit-identical results
         (test_pipelined_two_stream_rollout_equals_the_single_stream_plan)."""
         be, x, p = self.be, self.x, self.pred
         self._overlap_buffers()
-        xc = self._xc
         main = torch.cuda.current_stream()
         st_c = self._side[1]
         events = []        # kept alive until the streams are joined (and a capture has ended)
@@ -263,16 +280,14 @@ class GrainRollout:
         for _ in range(n_steps):
             ea, ea_next = self.edge_attr, self._ea_other
             einfo, einfo_next = self.einfo, self._einfo_other
-            ready, copied, swept = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            events += [ready, copied, swept]
+            xc, xc_next = self._xc, self._xc_other
+            ready, swept = torch.cuda.Event(), torch.cuda.Event()
+            events += [ready, swept]
             if swept_prev is not None:
                 main.wait_event(swept_prev)
             ready.record(main)
             with torch.cuda.stream(st_c):
                 st_c.wait_event(ready)
-                for nt in NODE_TYPES:
-                    xc[nt].copy_(x[nt])
-                copied.record(st_c)
                 enc, dec = self.packed["C"]
                 h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
                 swept.record(st_c)
@@ -280,8 +295,7 @@ class GrainRollout:
                                     self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
             enc, dec = self.packed["R"]
             hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
-            main.wait_event(copied)
-            # heads + Rmodel.update in one launch; z clamp + edge lengths + next records in one launch
+            # heads + Rmodel.update in one launch; z clamp + edge lengths + next records + next copy of x in one launch
             be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                       p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
             if self.refresh_centres:
@@ -289,24 +303,36 @@ class GrainRollout:
                                  self.domain_factor, self.domain_offset)
             be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
                                     [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
-                                     for et in EDGE_TYPES])
+                                     for et in EDGE_TYPES], mirror=(xc_next["joint"], xc_next["grain"]))
             swept_prev = swept
             self.edge_attr, self._ea_other = ea_next, ea
             self.einfo, self._einfo_other = einfo_next, einfo
+            self._xc, self._xc_other = xc_next, xc
         main.wait_stream(st_c)
         self._einfo_fresh = True
+        self._xc_fresh = True
+        if getattr(self, "_spec", None) is not None:
+            self._spec["xs_valid"] = None
         return events
 
-    def _ensure_edge_records(self):
-        """Before a pipelined step outside a capture: einfo must hold the records of the step to come.  They are
-        stale after construction, a topology change, an event-mode or single-stream step, and when the caller
-        wrote into x / edge_attr (in-place Python writes bump the tensors' version counters; the kernels do not)."""
+    def _ensure_edge_records(self, mirror=True):
+        """Before a pipelined step outside a capture: einfo must hold the records of the step to come and (overlapped
+        plan, `mirror`) the classifier's copy of x must equal x.  They are stale after construction, a topology change,
+        an event-mode or single-stream step, and when the caller wrote into x / edge_attr (in-place Python writes bump
+        the tensors' version counters; the kernels do not)."""
         seen = tuple(t._version for t in self.x.values()) + tuple(sorted(
             t._version for t in (*self.edge_attr.values(), *self._ea_other.values())))
+        if seen != self._seen:
+            self._x_written_outside()
         if not self._einfo_fresh or seen != self._seen:
             prepare_edges(self.be, self.graph, self.x, self.edge_attr, self.einfo)
             self._einfo_fresh = True
         self._seen = seen
+        if mirror and self.overlap_tail and not self._xc_fresh:
+            self._overlap_buffers()
+            for nt in NODE_TYPES:
+                self._xc[nt].copy_(self.x[nt])
+            self._xc_fresh = True
 
     def _enqueue_forward_update(self):
         """test.py:382-402: both forwards, Rmodel.update, z advance."""
@@ -377,7 +403,8 @@ class GrainRollout:
         self._overlap_buffers()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        state = (self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other)
+        state = (self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other, self._xc,
+                 self._xc_other, self._xc_fresh)
         with torch.cuda.stream(s):
             # the capture records, it does not execute: x / edge_attr are left untouched
             g = torch.cuda.CUDAGraph()
@@ -385,14 +412,16 @@ class GrainRollout:
                 keep = self._enqueue_steps(n_steps)   # (its stream events outlive the capture)
         torch.cuda.current_stream().wait_stream(s)
         del keep
-        self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other = state
+        (self.edge_attr, self._ea_other, self._einfo_fresh, self.einfo, self._einfo_other, self._xc, self._xc_other,
+         self._xc_fresh) = state
         return g
 
     def _replay(self, n_steps: int):
         """`n_steps` steps from the hipGraph captured for this step count and the current edge_attr buffer."""
         if self._graphs is None:
             self._graphs = {}
-        key = (n_steps, self.edge_attr[ET_JJ].data_ptr())
+        key = (n_steps, self.edge_attr[ET_JJ].data_ptr(), self.einfo[ET_JJ].data_ptr(),
+               self._xc["joint"].data_ptr() if self._xc is not None else 0)
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = self._capture(n_steps)
@@ -400,11 +429,19 @@ class GrainRollout:
         if self._pipelined():
             if n_steps % 2:
                 self.edge_attr, self._ea_other = self._ea_other, self.edge_attr
-                if self.overlap_tail:   # (the edge records alternate with the edge lengths)
+                if self.overlap_tail:   # (the edge records and the classifier's copies of x alternate with the edge lengths)
                     self.einfo, self._einfo_other = self._einfo_other, self.einfo
+                    self._xc, self._xc_other = self._xc_other, self._xc
             self._einfo_fresh = True
+            if self.overlap_tail:   # (the last step's refresh left its mirror of x in the now-current copy)
+                self._xc_fresh = True
+                if getattr(self, "_spec", None) is not None:
+                    self._spec["xs_valid"] = None
+            else:
+                self._x_written_outside()
         else:
             self._einfo_fresh = False
+            self._x_written_outside()
 
     # -- event-driven mode ------------------------------------------------
     def enable_events(self, mask, area_threshold: float = 1e-4, edge_threshold: float = 0.6):
@@ -455,6 +492,7 @@ class GrainRollout:
             raise _lib.GGNNError("call enable_events(mask, ...) first")
         self.refresh_weights()
         self._einfo_fresh = False   # this mode prepares its edge records at the start of every step
+        self._x_written_outside()
         self._run_segment("fwd")
         p = self.pred
         self.be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
@@ -487,10 +525,12 @@ class GrainRollout:
 
     def _spec_state(self):
         """Buffers of the speculative event loop (run_events): a ring of 2 x EVENTS_UNROLL slots, slot = step index mod
-        ring size -- x as the step found it (the copy the classifier's forward reads anyway), the step's predictions,
-        the grain centres as they were before the step's refresh, its event counts (device + pinned host) -- plus the
-        two alternating sets of edge lengths / edge records (set = slot parity).  Graphs are captured per (first slot,
-        number of steps).  Rebuilt after every topology change."""
+        ring size -- x as the step found it (the copy the classifier's forward reads anyway: written by the refresh of
+        the step before, ggnn_step_refresh_prepare's mirror), the step's predictions, the grain centres as they were
+        before the step's refresh, its z-clamp flag (test.py:405: written by the step's Rmodel.update, read by its
+        refresh), its event counts and its own fp16-range word (device + pinned host: [grains, edges, range, -]) --
+        plus the two alternating sets of edge lengths / edge records (set = slot parity).  Graphs are captured per
+        (first slot, number of steps).  Rebuilt after every topology change."""
         S = getattr(self, "_spec", None)
         if S is not None and S["topology"] is self.graph and S["ea"][S["cur"] & 1] is self.edge_attr \
                 and S["einfo"][S["cur"] & 1] is self.einfo:
@@ -502,41 +542,42 @@ class GrainRollout:
         if S is not None and S["D"] == D:
             # a new topology (after an event): the per-node slots, the centre snapshots and the (pinned) count words stay --
             # the node sets never change -- only the per-edge predictions follow the new edge list
-            keep = {k: S[k] for k in ("xs", "cen", "evf", "evh")}
+            keep = {k: S[k] for k in ("xs", "cen", "evf", "evh", "zf")}
             pred = [{k: (torch.empty_like(self.pred[k]) if k in per_edge else v) for k, v in slot.items()}
                     for slot in S["pred"]]
         else:
             keep = {"xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
                     "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
-                    "evf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
-                    "evh": [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(D)]}
+                    "evf": [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "evh": [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(D)],
+                    "zf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)]}
             pred = [{k: torch.empty_like(v) for k, v in self.pred.items()} for _ in range(D)]
         S = self._spec = {
             "topology": self.graph, "cur": 0, "D": D,
             "ea": [self.edge_attr, self._ea_other], "einfo": [self.einfo, self._einfo_other],
-            "pred": pred, "graphs": {}, **keep}
+            "pred": pred, "graphs": {}, "xs_valid": None, **keep}
         return S
 
     def _enqueue_spec_step(self, slot: int, swept_prev=None):
         """One step with events ASSUMED ABSENT: the overlapped two-stream step (_enqueue_steps_overlapped) on the edge
         set of the slot's parity + a snapshot of the grain centres before they are refreshed + the event counts of this
         step's predictions (ggnn_detect_events) copied to pinned host memory.  Nothing an event would need is
-        overwritten by the steps enqueued behind it: they use other slots of the ring."""
+        overwritten by the steps enqueued behind it: they use other slots of the ring (the copy of x the step leaves
+        for the next one, its z-clamp flag and its range word included).  Needs S["xs"][slot] to equal x (_spec_launch)."""
         S, be, x = self._spec, self.be, self.x
         s = slot & 1
         ea, ea_next, einfo, einfo_next = S["ea"][s], S["ea"][1 - s], S["einfo"][s], S["einfo"][1 - s]
-        p, xc = S["pred"][slot], S["xs"][slot]
+        p, xc, xc_next, zf = S["pred"][slot], S["xs"][slot], S["xs"][(slot + 1) % S["D"]], S["zf"][slot]
         main, st_c = torch.cuda.current_stream(), self._side[1]
-        ready, copied, updated, swept, headed = (torch.cuda.Event() for _ in range(5))
+        ready, updated, swept, headed = (torch.cuda.Event() for _ in range(4))
         st_d = self._side[0]   # the event counts go out on a stream of their own: neither model's chain waits for them
+        for name in ("R", "C"):   # the fused cells of this step report to the slot's own word (a void step's report is dropped)
+            self.ws[name].range_flag = S["evf"][slot][2:3]
         if swept_prev is not None:
             main.wait_event(swept_prev)   # the previous step's classifier decoder: the chip is free, its edge set may go
         ready.record(main)
         with torch.cuda.stream(st_c):
             st_c.wait_event(ready)
-            for nt in NODE_TYPES:
-                xc[nt].copy_(x[nt])
-            copied.record(st_c)
             enc, dec = self.packed["C"]
             h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
             swept.record(st_c)
@@ -545,33 +586,37 @@ class GrainRollout:
             headed.record(st_c)
         enc, dec = self.packed["R"]
         hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
-        main.wait_event(copied)
         be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
-                                  p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
+                                  p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, zf)
         updated.record(main)
         S["cen"][slot].copy_(x["grain"][:, :2])
         if self.refresh_centres:
             be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
                              self.domain_factor, self.domain_offset)
-        be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
+        be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, zf,
                                 [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
-                                 for et in EDGE_TYPES])
+                                 for et in EDGE_TYPES], mirror=(xc_next["joint"], xc_next["grain"]))
         with torch.cuda.stream(st_d):
-            st_d.wait_event(updated)   # grain_area of this step
-            st_d.wait_event(headed)    # ... and its edge_event
+            st_d.wait_event(updated)   # grain_area of this step (and every cell of the regressor has reported its range)
+            st_d.wait_event(headed)    # ... and its edge_event (the classifier's cells have, too)
             be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
                              self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot])
             S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
-        return [ready, copied, updated, headed, swept]
+            S["evf"][slot][2:3].zero_()   # (the range word is sticky on the device: cleared once it has been copied out)
+        return [ready, updated, headed, swept]
 
     def _enqueue_spec_steps(self, slots):
         """The steps of a block back to back (a step's regressor forward waits for the previous step's classifier
         decoder, not for its heads and event counts), the streams joined behind the last one."""
         keep, swept = [], None
-        for sl in slots:
-            ev = self._enqueue_spec_step(sl, swept)
-            swept = ev[-1]
-            keep += ev
+        try:
+            for sl in slots:
+                ev = self._enqueue_spec_step(sl, swept)
+                swept = ev[-1]
+                keep += ev
+        finally:
+            for name in ("R", "C"):
+                self.ws[name].range_flag = self._range_word
         torch.cuda.current_stream().wait_stream(self._side[1])
         torch.cuda.current_stream().wait_stream(self._side[0])
         return keep
@@ -580,6 +625,11 @@ class GrainRollout:
         """Enqueue `n` speculative steps from the current slot on; returns (their slots, the event behind them)."""
         S = self._spec
         slots = [(S["cur"] + i) % S["D"] for i in range(n)]
+        if S["xs_valid"] != slots[0]:   # the first step's copy of x (later ones get theirs from the refresh before them)
+            for nt in NODE_TYPES:
+                S["xs"][slots[0]][nt].copy_(self.x[nt])
+        S["xs_valid"] = (slots[-1] + 1) % S["D"]
+        self._xc_fresh = False
         if self.use_graph and n > 1:
             g = S["graphs"].get((slots[0], n))
             if g is None:
@@ -645,7 +695,7 @@ class GrainRollout:
             in_flight = sum(len(b[0]) for b in blocks)
             if len(blocks) < 2 and len(ev_out) + in_flight < n_steps:
                 self._spec_state()
-                self._ensure_edge_records()
+                self._ensure_edge_records(mirror=False)
                 size = min(K, 1 << min(quiet_blocks + len(blocks), 16))
                 size = min(size, K - self._spec["cur"] % K)   # blocks end on multiples of K: full blocks reuse two graphs
                 blocks.append(self._spec_launch(min(size, n_steps - len(ev_out) - in_flight)))
@@ -655,6 +705,9 @@ class GrainRollout:
             slots, done = blocks.pop(0)
             done.synchronize()
             hit = next((i for i, sl in enumerate(slots) if int(S["evh"][sl][0]) or int(S["evh"][sl][1])), None)
+            # the fp16-range reports of the steps that stand (a void step ran on a topology the trajectory never had)
+            if any(int(S["evh"][sl][2]) for sl in (slots if hit is None else slots[:hit + 1])):
+                self._range_hit = True
             if hit is None:
                 for _ in slots:
                     finish(none)
@@ -669,6 +722,9 @@ class GrainRollout:
             torch.cuda.current_stream().synchronize()
             void = len(slots) - hit - 1 + sum(len(b[0]) for b in blocks)
             blocks = []
+            self._x_written_outside()
+            # the z-clamp flag as the eventful step's Rmodel.update left it (test.py:405): the refreshes below read it
+            self.flags.copy_(S["zf"][slot])
             if void:
                 nxt = S["xs"][(slot + 1) % S["D"]]
                 for nt in NODE_TYPES:
@@ -701,42 +757,120 @@ class GrainRollout:
             finish((events, switches))
         return ev_out, sw_out
 
+    def _event_buffers(self):
+        """Pinned host staging of the event round trip, sized once (the lists only shrink: a removed grain appends two
+        junction columns and drops at least eight; a list that grows past its room gets new buffers)."""
+        E, n_pq = self.edge_index[ET_JJ].size(1), self.edge_index[("joint", "pull", "grain")].size(1)
+        B = getattr(self, "_evb", None)
+        if B is not None and B["cap"] >= 2 * (E + n_pq) and B["prob_cap"] >= E:
+            return B
+        nj, ng = self.n_nodes["joint"], self.n_nodes["grain"]
+        fj = self.x["joint"].size(1)
+        cap = 2 * (E + n_pq) + 1024
+        f = torch.empty(ng + (E + 512) + nj * fj + 2 * nj + 2 * ng, dtype=torch.float32).pin_memory()
+        o = [0]
+
+        def take(n, shape):
+            v = f[o[0]:o[0] + n].view(shape)
+            o[0] += n
+            return v
+        B = self._evb = {"cap": cap, "prob_cap": E + 512, "area": take(ng, (ng,)), "prob": take(E + 512, (E + 512,)),
+                         "xj": take(nj * fj, (nj, fj)), "yj": take(2 * nj, (nj, 2)), "yg": take(2 * ng, (ng, 2)),
+                         "lists": torch.empty(cap, dtype=torch.int64).pin_memory(),
+                         "live": torch.empty(ng, dtype=torch.int32).pin_memory()}
+        B["np"] = {k: B[k].numpy() for k in ("area", "prob", "xj", "yj", "yg", "lists", "live")}
+        return B
+
+    def _topology_session(self):
+        """The library-side lists of this trajectory (topology.TopologySession): opened from the device lists at the first
+        event (one read-back), afterwards patched by every update -- as long as the rollout's edge lists are the ones the
+        session produced last."""
+        from .topology import TopologySession
+        jj, jg = self.edge_index[ET_JJ], self.edge_index[("joint", "pull", "grain")]
+        T = getattr(self, "_topo", None)
+        if T is not None and T[1] is jj and T[2] is jg and T[3] == (jj._version, jg._version):
+            return T[0]
+        if T is not None:
+            T[0].close()
+        ses = TopologySession(jj.cpu().numpy(), jg.cpu().numpy(), self.n_nodes["joint"], self.n_nodes["grain"])
+        self._topo = (ses, jj, jg, (jj._version, jg._version))
+        return ses
+
     def _apply_events(self):
-        """Host round trip: read the predictions back, rewire, upload the new lists."""
-        from .topology import update_topology
+        """Host round trip of an eventful step: the predictions and junction coordinates travel to pinned host memory in
+        one batch of asynchronous copies behind ONE synchronisation, the library's session rewires its lists in place
+        (ggnn_topology_apply: a refused update leaves everything as it was), the new lists, coordinates and masks travel
+        back asynchronously and the CSR tables are rebuilt without a read-back -- the host returns to enqueueing the next
+        step while the device is still uploading (round 5: six synchronous read-backs, three pageable uploads, the lists
+        copied five times on the host and every lookup table rebuilt per call; profiles/r6_event_step_breakdown.txt)."""
+        from .topology import TopologyError  # noqa: F401  (raised by the session; callers catch it from here)
+        import time
         p, dev = self.pred, self.x["joint"].device
-        area = p["grain_area"].cpu().numpy()
+        JG, GJ = ("joint", "pull", "grain"), ("grain", "push", "joint")
+        hook = getattr(self, "rewire_hook", None)   # test infrastructure: see below
+        T = getattr(self, "event_timing", None)      # a dict: host-side seconds of the pieces (tests/bench_event_step.py)
+        t0 = time.perf_counter()
+        ses = self._topology_session() if hook is None else None
+        B = self._event_buffers()
+        N = B["np"]
+        E = self.edge_index[ET_JJ].size(1)
+        if ses is not None and ses.n_pp != E:
+            raise _lib.GGNNError("the topology session and the rollout's junction edge list disagree")
+        prob_d = torch.sigmoid(p["edge_event"])
+        B["area"].copy_(p["grain_area"], non_blocking=True)
+        B["prob"][:E].copy_(prob_d, non_blocking=True)
+        B["xj"].copy_(self.x["joint"], non_blocking=True)
+        B["yj"].copy_(p["joint"], non_blocking=True)
+        B["yg"].copy_(p["grain"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        t1 = time.perf_counter()
+        area, prob = N["area"], N["prob"][:E]
         live = self.mask["grain"][:, 0] > 0
         ge = np.flatnonzero(live & (area < np.float32(self.area_threshold)))
         ge = ge[np.argsort(area[ge], kind="stable")]                         # test.py:418-420
-        prob = torch.sigmoid(p["edge_event"]).cpu().numpy()
-        # the lists this method uploaded at the last event are still on the host (2 MB of read-back at the 10k-grain graph)
-        host = getattr(self, "_ei_host", None)
-        if host is not None and host[0] is self.edge_index[ET_JJ] and host[1] is self.edge_index[("joint", "pull", "grain")] \
-                and host[4] == (host[0]._version, host[1]._version):   # (the same tensors, not written since)
-            ei_jj, ei_jg = host[2], host[3]
+        # (the session ignores edges at or below the threshold and the (dst, src) twin of every pair: with no grain below
+        # the area threshold either, the update is the identity -- the device-side trigger was conservative)
+        mg, mj = self.mask["grain"], self.mask["joint"]
+        if not (mg.dtype == np.int64 and mg.flags.c_contiguous and mj.dtype == np.int64 and mj.flags.c_contiguous):
+            mg, mj = self.mask["grain"], self.mask["joint"] = np.ascontiguousarray(mg, np.int64), np.ascontiguousarray(mj, np.int64)
+        lists = N["lists"]
+        if hook is None:
+            events, switches = ses.apply(N["xj"], N["yj"], N["yg"][:, 0], prob, ge, mg, mj, self.edge_threshold)
+            if len(events) == 0 and len(switches) == 0:
+                return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
+            n_pp, n_pq = ses.n_pp, ses.n_pq
+            ses.export(lists[:2 * n_pp].reshape(2, n_pp), lists[2 * n_pp:2 * (n_pp + n_pq)].reshape(2, n_pq))
         else:
-            ei_jj = self.edge_index[ET_JJ].cpu().numpy()
-            ei_jg = self.edge_index[("joint", "pull", "grain")].cpu().numpy()
-        if len(ge) == 0 and not np.any((prob > self.edge_threshold) & (ei_jj[0] < ei_jj[1])):
-            return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)         # the trigger was conservative
-        xj = self.x["joint"].cpu().numpy()
-        yj, yg = p["joint"].cpu().numpy(), p["grain"].cpu().numpy()
-        # the rewiring mutates its arguments in place: give it copies and commit masks, coordinates
-        # and edge lists together, so a TopologyError leaves the rollout at the pre-event state
-        mg, mj = self.mask["grain"].copy(), self.mask["joint"].copy()
-        pp, pq, qp, switches, events = update_topology(
-            xj, ei_jj, ei_jg, yj, yg, prob, ge, mg, mj, self.edge_threshold)
-        self.mask["grain"], self.mask["joint"] = mg, mj
-        self.x["joint"].copy_(torch.from_numpy(xj))
-        p["joint"].copy_(torch.from_numpy(yj))
-        self._live_grain.copy_(torch.from_numpy(self.mask["grain"][:, 0].astype(np.int32)))
-        new_ei = {ET_JJ: torch.from_numpy(pp).to(dev), ("joint", "pull", "grain"): torch.from_numpy(pq).to(dev),
-                  ("grain", "push", "joint"): torch.from_numpy(np.ascontiguousarray(qp)).to(dev)}
-        self._set_topology(new_ei, lasting=False)
-        jj, jg = new_ei[ET_JJ], new_ei[("joint", "pull", "grain")]
-        self._ei_host = (jj, jg, pp, pq, (jj._version, jg._version))
+            # `rewire_hook`: another implementation of the update with topology.update_topology's signature (the tests'
+            # scan oracle, tests/fuzz_events.py) on copies that are committed together, like the reference's call
+            if len(ge) == 0 and not np.any(prob > np.float32(self.edge_threshold)):
+                return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
+            xj, yj, mg2, mj2 = N["xj"].copy(), N["yj"].copy(), mg.copy(), mj.copy()
+            pp, pq, _, switches, events = hook(xj, self.edge_index[ET_JJ].cpu().numpy(), self.edge_index[JG].cpu().numpy(),
+                                               yj, N["yg"], prob.copy(), ge, mg2, mj2, self.edge_threshold)
+            if len(events) == 0 and len(switches) == 0:
+                return np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
+            N["xj"][...], N["yj"][...], mg[...], mj[...] = xj, yj, mg2, mj2
+            n_pp, n_pq = pp.shape[1], pq.shape[1]
+            lists[:2 * n_pp] = pp.reshape(-1)
+            lists[2 * n_pp:2 * (n_pp + n_pq)] = pq.reshape(-1)
+        t2 = time.perf_counter()
+        self.x["joint"].copy_(B["xj"], non_blocking=True)
+        p["joint"].copy_(B["yj"], non_blocking=True)
+        if len(events):
+            N["live"][:] = mg[:, 0]
+            self._live_grain.copy_(B["live"], non_blocking=True)
+        d = torch.empty(2 * (n_pp + n_pq), dtype=torch.int64, device=dev)
+        d.copy_(B["lists"][:2 * (n_pp + n_pq)], non_blocking=True)
+        jj, jg = d[:2 * n_pp].view(2, n_pp), d[2 * n_pp:].view(2, n_pq)
+        new_ei = {ET_JJ: jj, JG: jg, GJ: torch.stack((jg[1], jg[0]))}
+        t3 = time.perf_counter()
+        self._set_topology(new_ei, lasting=False, trusted=True)
+        if ses is not None:
+            self._topo = (ses, jj, jg, (jj._version, jg._version))
         self._graph_fwd = self._graph_ref = None
+        if T is not None:
+            T.update(readback_s=t1 - t0, rewiring_s=t2 - t1, upload_enqueue_s=t3 - t2, set_topology_s=time.perf_counter() - t3)
         return events, switches
 
     def step(self):
@@ -775,7 +909,10 @@ class GrainRollout:
         """True when a fused cell has clamped an activation to fp16's range since the last check (include/ggnn.h,
         OPERAND RANGE): the trajectory since then is NOT the reference's -- re-run with GGNN_DEC=split GGNN_ENC=split.
         state() checks it (it synchronises anyway); one 4-byte read-back."""
-        return self.be.range_exceeded(self.x["joint"].device, clear, flag=self._range_word)
+        hit = getattr(self, "_range_hit", False)   # (reports of run_events' committed steps, read with their event counts)
+        if clear:
+            self._range_hit = False
+        return self.be.range_exceeded(self.x["joint"].device, clear, flag=self._range_word) or hit
 
     def state(self):
         """Final state a caller gathers across ranks: joint xy and grain (area, extraV).  Raises when the fused

@@ -408,10 +408,14 @@ def classifier_loss(y_dict, pred, pos_weight: float = 1.0):
     y, z = y_dict["edge_event"], pred["edge_event"]
     # the mean over the labelled edges as a weighted sum over all of them: no boolean indexing (its size is data: a host
     # synchronisation per step, and not capturable in a hipGraph); same value up to the order of the fp32 sum
-    keep = (y > -1).to(z.dtype)
+    # An unlabelled edge is masked BEFORE the loss (train.py:44-47 indexes it away): its logit, finite or not, reaches
+    # neither the value (inf * 0 = NaN otherwise) nor the gradients.
+    labelled = y > -1
+    keep = labelled.to(z.dtype)
     per_edge = torch.nn.functional.binary_cross_entropy_with_logits(
-        z, y.clamp(min=0).to(z.dtype), pos_weight=z.new_full((), float(pos_weight)), reduction="none")   # (a fill, not a host copy: capturable)
-    return (per_edge * keep).sum() / keep.sum()
+        torch.where(labelled, z, torch.zeros_like(z)), y.clamp(min=0).to(z.dtype),
+        pos_weight=z.new_full((), float(pos_weight)), reduction="none")   # (a fill, not a host copy: capturable)
+    return torch.where(labelled, per_edge, torch.zeros_like(per_edge)).sum() / keep.sum()
 
 
 class FusedAdam(torch.optim.Optimizer):

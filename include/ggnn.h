@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 23
+#define GGNN_ABI_VERSION 24
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -563,7 +563,11 @@ int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64
  *   switching   : out [switching_cap][2] the switched junction pairs, n_switching of them
  *   events_extra: out [extra_cap] grains eliminated beyond `grain_event` (forced / two-sided), n_extra of them
  * Returns GGNN_OK, GGNN_EINVAL, or GGNN_ETOPOLOGY with a message in `error` (the reference asserts / raises there); on an error
- * the in/out arrays are in an undefined state: pass copies (graingraphnn_amd/topology.py does). */
+ * the in/out arrays are in an undefined state: pass copies (graingraphnn_amd/topology.py does).  The room of the output lists
+ * (switching_cap >= the edges above the threshold, extra_cap >= n_grain + 1) is checked before anything is rewritten.
+ * Refusals where the reference would go on (reachable on degenerate lists only; the reference's own result there is an
+ * artefact of tensor indexing): a junction pair of an eliminated grain joined by more than one column, and a junction with
+ * fewer than three grain columns or fewer than two other neighbours in a switch (the reference raises IndexError). */
 typedef struct ggnn_topology_args {
   int64_t* pp;
   int64_t* pq;
@@ -584,6 +588,28 @@ typedef struct ggnn_topology_args {
   char error[192];
 } ggnn_topology_args;
 int ggnn_topology_update(ggnn_topology_args* args);
+/* The same update on lists that live in the library between calls (ABI 24; graingraphnn_amd/rollout.py keeps one session per
+ * trajectory): the reference's loop calls Cmodel.update at EVERY step (test.py:418-426), and a stateless call rebuilds its
+ * lookup tables from the whole lists each time (four O(E) sorts for a handful of events).  A session keeps the lists, the
+ * tables and the per-grain counts and patches them as the events rewrite columns; a call costs what its events touch plus
+ * one pass that renumbers the live columns.  HOST memory, no stream, one thread per session at a time.
+ *   ggnn_topology_open   : pp [2][n_pp] (row r at pp + r * pp_ld), pq likewise -> *session.  GGNN_ETOPOLOGY (message in
+ *                          `error`, 192 bytes, may be NULL) for an index outside [0, n_joint) / [0, n_grain).
+ *   ggnn_topology_apply  : one update; of `args` pp / pq / *_cap are ignored (the session holds the lists), everything else
+ *                          as for ggnn_topology_update; n_pp / n_pq = the new column counts.  A refused call
+ *                          (GGNN_ETOPOLOGY) leaves the session AND x_joint / y_joint / the masks exactly as they were.
+ *   ggnn_topology_export : the current lists in the reference's column order into the caller's arrays (any may be NULL):
+ *                          pp [2][>= n_pp], pq [2][>= n_pq], qp = pq with its rows exchanged (the grain -> junction list,
+ *                          models.py:841).
+ *   ggnn_topology_counts, ggnn_topology_close. */
+typedef struct ggnn_topology_session ggnn_topology_session;
+int ggnn_topology_open(const int64_t* pp, int64_t n_pp, int64_t pp_ld, const int64_t* pq, int64_t n_pq, int64_t pq_ld,
+                       int64_t n_joint, int64_t n_grain, ggnn_topology_session** session, char* error);
+int ggnn_topology_apply(ggnn_topology_session* session, ggnn_topology_args* args);
+int ggnn_topology_counts(const ggnn_topology_session* session, int64_t* n_pp, int64_t* n_pq);
+int ggnn_topology_export(const ggnn_topology_session* session, int64_t* pp, int64_t pp_ld, int64_t* pq, int64_t pq_ld,
+                         int64_t* qp, int64_t qp_ld);
+void ggnn_topology_close(ggnn_topology_session* session);
 typedef struct ggnn_refresh_edge {
   const int64_t* edge_index; /* [2, E] */
   const float* x_src;
@@ -598,10 +624,15 @@ int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint, float*
 /* ggnn_step_refresh + ggnn_edge_prepare of the NEXT forward in ONE launch: z clamp of every node when
  * flags[1] is set, then per CSR slot the edge length from the min-image xy offsets (written to
  * edge_attr[perm[p]], the COO order: edges[k].edge_attr is an OUTPUT here) and the einfo record with that
- * length.  Same values as the two calls in sequence (the length is the same expression on the same operands). */
+ * length.  Same values as the two calls in sequence (the length is the same expression on the same operands).
+ * x_joint_mirror / x_grain_mirror (ABI 24; both or neither, NULL = none; same shape and leading dimension as x_joint /
+ * x_grain, not x itself): every row of x as it stands behind this call (the clamped z included) is also written there --
+ * the copy of the node features that the classifier's forward of the NEXT step reads (test.py:382-383 hands both models
+ * the same x_dict) while Rmodel.update of that step already rewrites x in place (graingraphnn_amd/rollout.py). */
 int ggnn_step_refresh_prepare(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
                               int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,
-                              const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
+                              const ggnn_prepare_edge* edges, int n_edge_types, float* x_joint_mirror,
+                              float* x_grain_mirror, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training path: the LSTM update of HeteroPGCLSTM.forward (heteropgclstm.py:140-183) with the

@@ -395,10 +395,13 @@ class TorchEmulatorBackend:
         self.heads_regressor(h_joint, h_grain, x_grain, w, b, y_joint, y_grain, grain_area)
         self.step_update(x_joint, x_grain, y_joint, y_grain, dz, zmax, flags)
 
-    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items):
+    def step_refresh_prepare(self, x_joint, x_grain, zmax, flags, items, mirror=None):
         if int(flags[1]):
             x_joint[:, 2] = zmax
             x_grain[:, 2] = zmax
+        if mirror is not None:
+            mirror[0].copy_(x_joint)
+            mirror[1].copy_(x_grain)
         for csr, ea, xs, xd, einfo in items:
             col, perm, row = csr.col.long(), csr.perm.long(), csr.row.long()
             E = ea.numel()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU fuzz (not collected by pytest): event-driven rollouts on the 40 um and 120 um fixtures under random models and thresholds --
 GrainRollout.step_events with the SCAN ORACLE's rewiring (oracle/topology_scan.py, the reference's formulation) against
-GrainRollout.run_events with the product's native rewiring (ggnn_topology_update): same events, switches, edge lists, masks and
+GrainRollout.run_events with the product's native rewiring (the library's topology session: ggnn_topology_apply): same events, switches, edge lists, masks and
 state bit for bit, or the same refusal at the same step.   python tests/fuzz_events.py [n_cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,8 +37,7 @@ with torch.no_grad():
         ra.enable_events(mask, area_thr, edge_thr)
         rb.enable_events(mask, area_thr, edge_thr)
         ev_a, sw_a, err_a = [], [], None
-        # rollout a: one step at a time, rewiring by the scan oracle (_apply_events imports the function at call time)
-        native_update = native.update_topology
+        # rollout a: one step at a time, rewiring by the scan oracle
 
         def scan_update(*args, **kw2):
             try:
@@ -46,14 +45,12 @@ with torch.no_grad():
             except (scan.TopologyError, IndexError, ValueError) as err:
                 raise native.TopologyError(str(err)) from None
         try:
-            native.update_topology = scan_update
+            ra.rewire_hook = scan_update   # (GrainRollout._apply_events: the update by another implementation)
             for _ in range(steps):
                 _, e, sw = ra.step_events()
                 ev_a.append(e), sw_a.append(sw)
         except native.TopologyError as err:
             err_a = str(err)
-        finally:
-            native.update_topology = native_update
         ev_b, sw_b, err_b = [], [], None
         try:
             left = steps

@@ -1045,6 +1045,42 @@ def test_speculative_event_loop_equals_step_events(use_graph, chunks):
 
 
 @torch.no_grad()
+def test_speculative_event_loop_restores_the_z_clamp_flag_of_the_eventful_step():
+    """test.py:405's flag is written by every step's Rmodel.update and read by its refresh.  Grain 0 is put
+    3.5 steps below zmax, so the flag is raised from the fourth step on; the third step (22 grains vanish on the seeded 40 um
+    trajectory) has speculative steps enqueued behind it that raise the flag before the host sees the events.  The
+    refresh that follows the rewiring must read the THIRD step's flag (not raised): otherwise every node's z is clamped one
+    step early and the trajectory leaves step_events'."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+    kw = dict(use_graph=True, refresh_centres=True, joint_launches=False, concurrent=True)
+    dz, zmax = np.float32(6 / 121), np.float32(120 / 121)
+    x = {k: v.copy() for k, v in x.items()}
+    x["grain"][0, 2] = zmax - np.float32(3.5) * dz
+    Xa, Xb = tt(x, DEV), tt(x, DEV)
+    ra = GrainRollout(R, Cm, Xa, tt(ei, DEV), tt(ea, DEV), 6, **kw)
+    rb = GrainRollout(R, Cm, Xb, tt(ei, DEV), tt(ea, DEV), 6, **kw)
+    ra.enable_events(mask, 1e-4, 0.6)
+    rb.enable_events(mask, 1e-4, 0.6)
+    ev_a, z_a = [], []
+    for _ in range(6):
+        ev_a.append(ra.step_events()[1])
+        z_a.append(float(Xa["joint"][:, 2].max()))
+    ev_b, _ = rb.run_events(6)
+    torch.cuda.synchronize()
+    assert any(len(e) for e in ev_a[:3]), [len(e) for e in ev_a]     # an eventful step before the crossing ...
+    assert z_a[2] < float(zmax) and z_a[3] == float(zmax), z_a       # ... and the clamp from the fourth step on
+    for k in range(6):
+        assert np.array_equal(ev_a[k], ev_b[k]), k
+    for nt in Xa:
+        assert torch.equal(Xa[nt], Xb[nt]), nt
+    for et in EDGE_TYPES:
+        assert torch.equal(ra.edge_index[et], rb.edge_index[et]) and torch.equal(ra.edge_attr_dict()[et], rb.edge_attr_dict()[et])
+
+
+@torch.no_grad()
 def test_detect_events_counts():
     be = backend()
     rs = np.random.RandomState(2)
@@ -1982,9 +2018,11 @@ def test_fused_glue_launches_equal_the_separate_calls(clamp):
     xb, eab, pb, fb, eib = fresh()
     be.heads_regressor_update(h["joint"], h["grain"], xb["joint"], xb["grain"], w, b, pb["joint"], pb["grain"],
                               pb["area"], dz, zmax, fb)
+    mirror = (torch.full_like(xb["joint"], 7.0), torch.full_like(xb["grain"], 7.0))
     be.step_refresh_prepare(xb["joint"], xb["grain"], zmax, fb,
-                            [(graph.csr[et], eab[et], xb[et[0]], xb[et[-1]], eib[et]) for et in EDGE_TYPES])
+                            [(graph.csr[et], eab[et], xb[et[0]], xb[et[-1]], eib[et]) for et in EDGE_TYPES], mirror=mirror)
     assert int(fa[1]) == int(fb[1]) == int(clamp)
+    assert torch.equal(mirror[0], xb["joint"]) and torch.equal(mirror[1], xb["grain"])   # (ABI 24: the classifier's copy)
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
     for nt in xa:

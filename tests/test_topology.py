@@ -167,9 +167,88 @@ def test_indexed_lookups_equal_the_scan_formulation_on_random_events(n, seed, n_
     assert compared >= 1
 
 
+@pytest.mark.parametrize("n,seed,n_elim,n_switch", [(12, 5, 3, 4), (20, 6, 8, 10), (40, 7, 12, 20)])
+def test_session_equals_chained_stateless_updates(n, seed, n_elim, n_switch):
+    """TopologySession (lists, lookup tables and counts kept in the library and patched by every update: ggnn_topology_open /
+    _apply / _export) against the stateless call on the lists it returned last time: six chained updates with random
+    eliminations and switches give identical lists, masks, coordinates and event lists; a refused update leaves the session
+    and the in-place arrays exactly as they were, and the session goes on from there."""
+    from graingraphnn_amd.topology import TopologySession
+    ses, compared, refused = None, 0, 0
+    for state, yj, yg, prob, ge in _random_events(n, seed, 6, n_elim, n_switch):
+        if ses is None:
+            ses = TopologySession(state["pp"], state["pq"], state["mj"].shape[0], state["mg"].shape[0])
+        a = dict(xj=state["xj"].copy(), yj=yj.copy(), mg=state["mg"].copy(), mj=state["mj"].copy())
+        b = dict(xj=state["xj"].copy(), yj=yj.copy(), mg=state["mg"].copy(), mj=state["mj"].copy())
+        try:
+            ra = update_topology(a["xj"], state["pp"], state["pq"], a["yj"], yg, prob, ge, a["mg"], a["mj"], 0.6)
+        except TopologyError:
+            ra = None
+        try:
+            ev, sw = ses.apply(b["xj"], b["yj"], yg[:, 0], prob, ge, b["mg"], b["mj"], 0.6)
+        except TopologyError:
+            assert ra is None
+            refused += 1
+            for key in ("xj", "yj", "mg", "mj"):   # nothing was touched ...
+                assert np.array_equal(b[key], a[key]) and np.array_equal(b[key], state[key] if key != "yj" else yj), key
+            pp, pq, qp = ses.export()              # ... and the lists are those of the last accepted update
+            assert np.array_equal(pp, state["pp"]) and np.array_equal(pq, state["pq"])
+            continue
+        assert ra is not None
+        pp, pq, qp = ses.export()
+        assert np.array_equal(pp, ra[0]) and np.array_equal(pq, ra[1]) and np.array_equal(qp, ra[2])
+        assert np.array_equal(sw, ra[3]) and np.array_equal(ev, ra[4])
+        for key in ("xj", "yj", "mg", "mj"):
+            assert np.array_equal(a[key], b[key]), key
+        compared += 1
+        state.update(xj=b["xj"], pp=pp, pq=pq, mg=b["mg"], mj=b["mj"])
+    assert compared >= 2, (compared, refused)
+    # export into wider (staging) arrays: rows at the arrays' own stride
+    wide = np.full((2, ses.n_pp + 7), -5, np.int64)
+    ses.export(pp=wide)
+    assert np.array_equal(wide[:, :ses.n_pp], state["pp"]) and (wide[:, ses.n_pp:] == -5).all()
+    ses.close()
+
+
+def test_session_shrinks_its_tables_when_most_columns_are_dead():
+    """Eliminations until fewer than half of the session's columns are live (it then restarts its numbering from the live
+    ones: ggnn_topology_session::renumber): still the stateless call's results."""
+    from graingraphnn_amd.topology import TopologySession
+    from graingraphnn_amd import synthetic
+    rs = np.random.RandomState(11)
+    x, ei, _ = synthetic.honeycomb(40, 1, 3)
+    xj = np.ascontiguousarray(x["joint"], dtype=np.float32)
+    n_g, n_j = x["grain"].shape[0], xj.shape[0]
+    pp, pq = ei[JJ].astype(np.int64), ei[JG].astype(np.int64)
+    mg, mj = np.ones((n_g, 1), np.int64), np.ones((n_j, 1), np.int64)
+    ses = TopologySession(pp, pq, n_j, n_g)
+    done = 0
+    for _ in range(400):
+        live = np.flatnonzero(mg[:, 0] > 0)
+        if len(live) < 40:
+            break
+        yj = np.zeros((n_j, 2), np.float32)
+        yg = rs.normal(0, 1, (n_g, 2)).astype(np.float32)
+        ge = rs.choice(live, size=4, replace=False)
+        prob = np.zeros(pp.shape[1], np.float32)
+        a = dict(xj=xj.copy(), yj=yj.copy(), mg=mg.copy(), mj=mj.copy())
+        try:
+            ra = update_topology(a["xj"], pp, pq, a["yj"], yg, prob, ge, a["mg"], a["mj"], 0.6)
+        except TopologyError:
+            with pytest.raises(TopologyError):
+                ses.apply(xj, yj, yg[:, 0], prob, ge, mg, mj, 0.6)
+            continue
+        ses.apply(xj, yj, yg[:, 0], prob, ge, mg, mj, 0.6)
+        pp, pq, _ = ses.export()
+        assert np.array_equal(pp, ra[0]) and np.array_equal(pq, ra[1])
+        assert np.array_equal(xj, a["xj"]) and np.array_equal(mg, a["mg"]) and np.array_equal(mj, a["mj"])
+        done += 1
+    assert done >= 20 and pp.shape[1] < ei[JJ].shape[1] // 2, (done, pp.shape)
+
+
 def test_c_abi_refuses_bad_arguments_and_missing_room():
-    """ggnn_topology_update through the C ABI: null pointers and inconsistent sizes are GGNN_EINVAL; an edge list without
-    room for the two columns a removed grain appends is GGNN_ETOPOLOGY with a message, not a write past the end."""
+    """ggnn_topology_update through the C ABI: null pointers and inconsistent sizes are GGNN_EINVAL; an output list without
+    room is GGNN_ETOPOLOGY with a message BEFORE anything is rewritten, not a write past the end."""
     import ctypes
     from graingraphnn_amd import _lib
     lib = _lib.load()
@@ -185,18 +264,51 @@ def test_c_abi_refuses_bad_arguments_and_missing_room():
     assert len(ge) >= 1
     mg = np.ascontiguousarray(EV[i + "mask_grain"].reshape(-1).astype(np.int64))
     mj = np.ascontiguousarray(EV[i + "mask_joint"].reshape(-1).astype(np.int64))
-    sw, extra = np.empty((8, 2), np.int64), np.empty(8, np.int64)
+    sw, extra = np.empty((8, 2), np.int64), np.empty(len(mg) + 1, np.int64)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     A.pp, A.pq, A.n_pp, A.n_pq, A.pp_cap, A.pq_cap = p(pp), p(pq), pp.shape[1], pq.shape[1], pp.shape[1], pq.shape[1]
     A.x_joint, A.y_joint, A.y_grain_area, A.edge_prob = p(xj), p(yj), p(area), p(prob)
     A.grain_event, A.mask_grain, A.mask_joint, A.switching, A.events_extra = p(ge), p(mg), p(mj), p(sw), p(extra)
     A.n_joint, A.n_grain, A.ldx, A.ldyg, A.n_grain_event = len(mj), len(mg), xj.shape[1], 1, len(ge)
-    A.switching_cap, A.extra_cap, A.threshold = 8, 8, 0.6
+    A.switching_cap, A.extra_cap, A.threshold = 8, len(extra), 0.6
     A.ldx = 4
     assert lib.ggnn_topology_update(ctypes.byref(A)) == -1          # fewer than the 8 junction features
     A.ldx = xj.shape[1]
     A.pp_cap = pp.shape[1] - 1
     assert lib.ggnn_topology_update(ctypes.byref(A)) == -1          # capacity below the columns in use
-    A.pp_cap = pp.shape[1]                                          # no room for the appended pair
+    A.pp_cap = pp.shape[1]
+    A.extra_cap = 8                                                 # no room for the forced eliminations' report
     assert lib.ggnn_topology_update(ctypes.byref(A)) == _lib.GGNN_ETOPOLOGY
     assert b"room" in A.error
+    assert np.array_equal(pp, EV[i + k(JJ)]) and np.array_equal(xj, EV[i + "x_joint"])   # refused before anything was rewritten
+    A.extra_cap = len(extra)
+    assert lib.ggnn_topology_update(ctypes.byref(A)) == 0 and A.n_pp < pp.shape[1]     # (the result fits the columns in use)
+
+
+def test_host_code_under_sanitizers():
+    """csrc/topology.hip -- host code, the only part of the library that is not a kernel -- as plain C++ under
+    AddressSanitizer + UndefinedBehaviourSanitizer (`make -C graingraphnn_amd/csrc host-asan`), and this file's tests run
+    against that build in a child process (GGNN_TOPOLOGY_LIB redirects topology.py's calls; the sanitizer runtimes are
+    preloaded).  CPU only: no GPU sanitizer runs exist on this pool."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("GGNN_TOPOLOGY_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    runtimes = [subprocess.run([gxx, f"-print-file-name={n}"], capture_output=True, text=True).stdout.strip()
+                for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(r) and os.path.exists(r) for r in runtimes):
+        pytest.skip("sanitizer runtimes not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "graingraphnn_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "host-asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, GGNN_TOPOLOGY_LIB=os.path.join(csrc, "build", "libggnn_topology_asan.so"),
+               LD_PRELOAD=" ".join(runtimes), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr \
+        and "runtime error" not in r.stderr, r.stdout[-3000:] + r.stderr[-3000:]
