@@ -52,6 +52,22 @@ def build(device, n=100, fold=10, seed=0, scale=0.3):
     return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea, float(fold), off)
 
 
+def build_generated(device, lxd=368.0, fold=9.0, seed=0, scale=0.3):
+    """The reference generator's structure at the headline's size (--lxd=368 -> 9 775 grains), folded by the
+    INTEGER factor nearest to lxd / 40 (test.py:29-55 folds by lxd / 40 = 9.2; a non-integer factor leaves edges across the
+    global seam with inconsistent min-images), models as in `build`."""
+    x, ei, ea = synthetic.generate(lxd, seed)
+    x, ea = {k: v.copy() for k, v in x.items()}, {k: v.copy() for k, v in ea.items()}
+    off = synthetic.scale_feature_patchs(fold, x, ea)
+    hp = synthetic.default_hyper(device)
+    R = GrainNN_regressor(hp)
+    Cm = GrainNN_classifier(hp, R)
+    load_seeded(R, seed, scale).eval()
+    load_seeded(Cm, seed + 1, scale).eval()
+    X, EI, EA = synthetic.to_torch(x, ei, ea, device)
+    return R.to(device), Cm.to(device), X, EI, EA, (x, ei, ea, float(fold), off)
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak
 
@@ -560,10 +576,13 @@ def main():
                          "one fires; not the headline metric")
     ap.add_argument("--events-quiet", action="store_true",
                     help="--events with thresholds no prediction reaches: what the event machinery costs on a quiet step")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "gen368"],
                     help="cfg3 (default, the BASELINE metric): 10k-grain honeycomb; cfg2: the 120 um fixture "
                          "(1043 grains); cfg4: 64 perturbed 40 um trajectories sharded over the ranks, each "
-                         "rank batching its shard as one disjoint-union graph (--steps = steps per trajectory)")
+                         "rank batching its shard as one disjoint-union graph (--steps = steps per trajectory); "
+                         "gen368: the reference generator's own 368 um structure (graph_trajectory.py --mode=generate "
+                         "--lxd=368: 9 775 grains / 19 550 junctions / 58 650 edges per type, nodes in Qhull order, "
+                         "SURVEY 8(d)'s cross-check) -- the headline's size on a node numbering that is not a lattice's")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -598,6 +617,12 @@ def main():
                     "type, fold 10, static topology, R+C forward + update + grain-centre refresh + edge "
                     "refresh per step, weights "
                     "RandomState(0) x0.3")
+    elif args.workload == "gen368":
+        R, Cm, X, EI, EA, inputs = build_generated(device)
+        workload = ("gen368: synthetic.generate(lxd=368, seed=0) = the reference generator's sample (graph_trajectory.py "
+                    f"--mode=generate --lxd=368), {X['grain'].size(0)} grains / {X['joint'].size(0)} junctions / "
+                    f"{EI[('joint', 'connect', 'joint')].size(1)} edges per type, nodes and edges in the generator's (Qhull) order, "
+                    "x9 patch folding, static topology, weights RandomState(0) x0.3; one replica per rank")
     else:
         from graingraphnn_amd.dist import shard_trajectories
         gold = os.path.join(ROOT, "tests", "golden")

@@ -77,8 +77,17 @@ struct DcAcc {
 #ifndef GGNN_KSTEP_AHEAD
 #define GGNN_KSTEP_AHEAD 1
 #endif
-template <int NB>
-__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB]) {
+struct DcNoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `mid`: called once behind the MFMAs of column tile GGNN_KSTEP_MID (development: where in a k-step the wave issues its share
+// of the next slice's LDS-DMA -- at the top, in front of the first fragment read, or between two column tiles' MFMAs)
+#ifndef GGNN_KSTEP_MID
+#define GGNN_KSTEP_MID 0
+#endif
+template <int NB, typename Mid = DcNoMid>
+__device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32x4 (&xb)[DC_PL], DcAcc (&acc)[NB],
+                                         Mid mid = Mid()) {
   constexpr int AH = GGNN_KSTEP_AHEAD < NB ? GGNN_KSTEP_AHEAD : NB - 1;
   u32x4 wf[AH + 1][DC_PL];
 #pragma unroll
@@ -95,6 +104,7 @@ __device__ __forceinline__ void dc_kstep(const u32x4* __restrict__ pw, const u32
     mfma_x3h(wf[nb % (AH + 1)], xb, acc[nb].m, acc[nb].c);
     if (nb + AH < NB) __builtin_amdgcn_sched_group_barrier(0x100, DC_PL, 0);  // DS read
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                         // MFMA
+    if (nb == GGNN_KSTEP_MID) mid();
   }
 }
 

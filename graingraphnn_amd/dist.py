@@ -23,12 +23,6 @@ def _check_shardable(n_traj: int, world: int):
         raise ValueError(f"more ranks ({world}) than trajectories ({n_traj}): every rank needs at least one")
 
 
-def _staging(t: torch.Tensor) -> torch.Tensor:
-    """RCCL ('nccl') moves device buffers directly; the 'gloo' backend (CPU tests, single-GPU
-    smoke runs) needs host buffers."""
-    return t.contiguous().cpu() if dist.get_backend() == "gloo" else t.contiguous()
-
-
 def pack_state(state: Dict[str, torch.Tensor]):
     """A dict of tensors as ONE byte buffer (keys in sorted order, every segment 16-byte aligned so that it can be
     viewed back as its own dtype) + the layout needed to take it apart again: (packed uint8 tensor, keys, sizes)."""
@@ -137,12 +131,14 @@ def run_sharded(n_traj: int, run_one: Callable[[int], torch.Tensor], rank: int, 
         local[i] = r
     if world <= 1 or not dist.is_initialized():
         return local[:n_traj]
-    staged = _staging(local)
-    bufs = [torch.empty_like(staged) for _ in range(world)]
-    dist.all_gather(bufs, staged)
+    # ONE packed collective on buffers that are kept per layout (gather_states / StateGather: send, flat receive and --
+    # under gloo -- pinned host staging are allocated at the first call of a shape and reused; round 5 allocated `world`
+    # receive tensors per call here)
+    shards = gather_states({"shard": local}, world)
     out = torch.empty((n_traj,) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
-    for t in range(n_traj):
-        out[t] = bufs[t % world][t // world].to(proto.device)
+    for r in range(world):
+        n_r = len(range(r, n_traj, world))   # trajectories t = r, r + world, ...: rows 0 .. n_r - 1 of rank r's shard
+        out[r::world] = shards[r]["shard"][:n_r]
     return out
 
 

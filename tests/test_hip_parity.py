@@ -792,6 +792,35 @@ def test_cfg3_ten_step_rollout_as_benched(mode):
 
 
 @torch.no_grad()
+def test_generated_368um_structure_two_steps_against_the_oracle():
+    """The headline's size on a node numbering that is NOT the lattice's (bench.py --workload gen368): the
+    reference generator's own 368 um sample (graph_trajectory.py:1289-1333 via synthetic.generate: 9 775 grains / 19 550
+    junctions / 58 650 edges per type, nodes and edges in Qhull order, in-degrees of grains 3..13), folded x9, as
+    bench.py builds it; two steps of the benched rollout (fused cells, two streams, hipGraph) against the oracle."""
+    import bench
+    from graingraphnn_amd import GrainRollout
+    R, Cm, X, EI, EA, (x, ei, ea, fold, off) = bench.build_generated(DEV)
+    assert X["grain"].size(0) == 9775 and X["joint"].size(0) == 19550 and EI[JJ].size(1) == 58650
+    oR, oC = oracle_models(0, 0.3)
+    oX, oEI, oEA = tt(x), tt(ei), tt(ea)
+    ooff = torch.from_numpy(off)
+    ro = GrainRollout(R, Cm, X, EI, EA, 6, use_graph=True, refresh_centres=True, domain_factor=fold, domain_offset=ooff)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        for step in range(2):
+            pred = {k: v.clone() for k, v in ro.step().items()}
+            opred, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6, centres=(fold, ooff))
+            for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+                assert_close(pred[k], opred[k], f"gen368 step {step} {k}")
+    finally:
+        torch.set_num_threads(threads)
+    assert_close(X["joint"], oX["joint"], "gen368 x joint")
+    assert_close(X["grain"][:, 2:], oX["grain"][:, 2:], "gen368 x grain[2:]")
+    assert not ro.range_exceeded()
+
+
+@torch.no_grad()
 def test_cfg3_five_hundred_step_rollout_checked_along_its_trajectory():
     """BASELINE config 3 at full length: the 500-step rollout bench.py times (test.py:353-407's loop: both forwards,
     update, grain-centre refresh through the global frame, edge refresh; hipGraph replay, default launch plan).
@@ -1120,6 +1149,55 @@ def test_cfg4_batched_trajectories_match_individual_rollouts():
             _, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
         assert_close(got["joint_xy"][t], oX["joint"][:, :2], f"cfg4 trajectory {t} joint xy")
         assert_close(got["grain_area_v"][t], oX["grain"][:, 3:5], f"cfg4 trajectory {t} grain area/extraV")
+
+
+@torch.no_grad()
+def test_cfg4_as_baseline_states_it_64_trajectories_20_steps():
+    """BASELINE config 4 at its stated size: 64 perturbed 40 um trajectories x 20 steps.
+      * one GPU holding all 64 as ONE disjoint-union graph (15 104 junctions: the FUSED decoder cell is the plan) -- every
+        trajectory bit-equal to its own rollout under the same plan, seven of them within 1e-4 of the oracle;
+      * the shard of one of eight ranks (trajectories t = r mod 8: 1 888 junctions, the THREE-KERNEL decoder plan) at 20
+        steps -- bit-equal to the individual rollouts under that plan and within tolerance of the fused results."""
+    from graingraphnn_amd import GrainRollout
+    from graingraphnn_amd.dist import rollout_trajectories, shard_trajectories
+    be = backend()
+    x, ei, ea = load_graph("40")
+    graphs = [(synthetic.perturbed_copy(x, 1e-3, 1000 + t), ei, ea) for t in range(64)]
+    R, Cm = product_models(10020, 1.0, DEV)
+    if be.fused_decoder is not True or not 8 * 236 < be.fused_decoder_min_joints <= 64 * 236:
+        pytest.skip("the decoder plan is forced by the environment (GGNN_DEC / GGNN_GEMM): the size rule is what this test is about")
+    got = rollout_trajectories(R, Cm, graphs, 6, 20, 0, 1, DEV)
+    assert got["joint_xy"].shape == (64, 236, 2) and got["grain_area_v"].shape == (64, 118, 2)
+    assert bool(torch.isfinite(got["joint_xy"]).all()) and bool(torch.isfinite(got["grain_area_v"]).all())
+    mine = shard_trajectories(64, 3, 8)
+    assert mine == list(range(3, 64, 8))
+    shard = rollout_trajectories(R, Cm, [graphs[t] for t in mine], 6, 20, 0, 1, DEV)
+
+    def alone(t, min_joints):
+        keep = be.fused_decoder_min_joints
+        be.fused_decoder_min_joints = min_joints
+        try:
+            X = tt(graphs[t][0], DEV)
+            GrainRollout(R, Cm, X, tt(ei, DEV), tt(ea, DEV), 6).run(20)
+            return X
+        finally:
+            be.fused_decoder_min_joints = keep
+    for t in range(64):
+        X = alone(t, 0)                                     # the fused decoder cell, as in the 64-trajectory union
+        assert torch.equal(got["joint_xy"][t], X["joint"][:, :2]), f"trajectory {t} joints (fused plan)"
+        assert torch.equal(got["grain_area_v"][t], X["grain"][:, 3:5]), f"trajectory {t} grains (fused plan)"
+    for i, t in enumerate(mine):
+        X = alone(t, 10 ** 9)                               # the three-kernel plan, as in a rank's 8-trajectory union
+        assert torch.equal(shard["joint_xy"][i], X["joint"][:, :2]), f"trajectory {t} joints (split plan)"
+        assert torch.equal(shard["grain_area_v"][i], X["grain"][:, 3:5]), f"trajectory {t} grains (split plan)"
+        assert_close(shard["joint_xy"][i], got["joint_xy"][t], f"trajectory {t}: split plan vs fused plan, 20 steps")
+    oR, oC = oracle_models(10020, 1.0)
+    for t in (0, 9, 18, 27, 36, 45, 63):
+        oX, oEI, oEA = tt(graphs[t][0]), tt(ei), tt(ea)
+        for _ in range(20):
+            _, oEA = oracle.rollout_step(oR, oC, oX, oEI, oEA, 6)
+        assert_close(got["joint_xy"][t], oX["joint"][:, :2], f"cfg4 x 20 steps, trajectory {t} joint xy")
+        assert_close(got["grain_area_v"][t], oX["grain"][:, 3:5], f"cfg4 x 20 steps, trajectory {t} grain area/extraV")
 
 
 # ---------------------------------------------------------------------------------------

@@ -565,3 +565,21 @@ def test_disjoint_union_offsets():
         shift = np.array([[slices[1][et[0]][0]], [slices[1][et[-1]][0]]])
         assert np.array_equal(ei[et][:, n1:], g2[1][et] + shift)
         assert ea[et].shape[0] == ei[et].shape[1]
+
+
+def test_classifier_loss_ignores_unlabelled_edges_like_the_reference_indexing():
+    """train.py:44-47 indexes the unlabelled edges (label -1) away before the loss: a non-finite logit there reaches neither
+    the value nor a gradient (the capturable weighted-sum form multiplied inf by 0)."""
+    from graingraphnn_amd import training
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(40, generator=g)
+    y = (torch.rand(40, generator=g) > 0.5).float()
+    y[::5] = -1.0
+    z[0], z[5], z[10] = float("inf"), float("-inf"), float("nan")
+    z.requires_grad_(True)
+    loss = training.classifier_loss({"edge_event": y}, {"edge_event": z}, 2.0)
+    keep = y > -1
+    want = torch.nn.functional.binary_cross_entropy_with_logits(z.detach()[keep], y[keep], pos_weight=torch.tensor(2.0))
+    assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-6
+    loss.backward()
+    assert bool(torch.isfinite(z.grad).all()) and bool((z.grad[~keep] == 0).all())
