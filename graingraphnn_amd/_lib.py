@@ -351,7 +351,7 @@ def _declare(lib):
                                        c_float, c_void_p, c_int64, c_int64, c_void_p]
     lib.ggnn_detect_events.restype = c_int
     lib.ggnn_detect_events.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64,
-                                       c_float, c_void_p, c_void_p]
+                                       c_float, c_void_p, c_void_p, c_void_p]
     lib.ggnn_topology_update.restype = c_int
     lib.ggnn_topology_update.argtypes = [POINTER(TopologyArgs)]
     lib.ggnn_topology_open.restype = c_int

@@ -107,6 +107,10 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     ++q_cur;
   };
   dma_group(0);
+#ifdef EC_EXP_PRIO
+  // development (profiles/r6_enc_cell_experiments.txt): one static priority for the second-dispatched half of the workgroup
+  if (wave >= EC_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   uint32_t amax = 0u;   // largest magnitude this lane has split into fp16 pieces, as bits (dc_track: NaN and inf stay visible)
 

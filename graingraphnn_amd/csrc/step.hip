@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void grain_centres_kernel(
 __global__ __launch_bounds__(256) void detect_events_kernel(
     const float* __restrict__ grain_area, const int32_t* __restrict__ live_grain, int64_t n_grain,
     float area_threshold, const float* __restrict__ edge_event, const int64_t* __restrict__ ei_jj,
-    int64_t E, float logit_threshold, int32_t* __restrict__ flags) {
+    int64_t E, float logit_threshold, int32_t* __restrict__ flags, int32_t* __restrict__ range_word) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // (the caller's fp16-range word travels with the counts and starts its next use clean: one thread moves it)
+  if (range_word != nullptr && t == 0) flags[2] = atomicExch(range_word, 0);
   bool g = false, e = false;
   if (t < n_grain) g = live_grain[t] > 0 && grain_area[t] < area_threshold;
   else if (t - n_grain < E) {
@@ -195,16 +197,16 @@ extern "C" int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, con
 extern "C" int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
                                   float area_threshold, const float* edge_event,
                                   const int64_t* edge_index_jj, int64_t E, float logit_threshold,
-                                  int32_t* flags, ggnn_stream_t stream) {
+                                  int32_t* flags, int32_t* range_word, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!grain_area || !live_grain || !flags || n_grain <= 0 || E < 0) return GGNN_EINVAL;
   if (E > 0 && (!edge_event || !edge_index_jj)) return GGNN_EINVAL;
   const int64_t nblk = (n_grain + E + 255) / 256;
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
-  if (hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return GGNN_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, (range_word ? 3 : 2) * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return GGNN_ELAUNCH;
   hipLaunchKernelGGL(detect_events_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                      grain_area, live_grain, n_grain, area_threshold, edge_event, edge_index_jj, E,
-                     logit_threshold, flags);
+                     logit_threshold, flags, range_word);
   return launch_status();
 }
 

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <unordered_map>
 #include <vector>
 
@@ -68,7 +69,11 @@ struct ggnn_topology_session {
   int64_t n_joint = 0, n_grain = 0;
   std::vector<int64_t> arr[4];          // pp0, pp1, pq0, pq1 by stable column
   KeyIndex idx[4];
-  std::vector<int64_t> ext_pp, ext_pq;  // caller's column -> stable column
+  // The caller numbers the LIVE columns 0 .. n - 1 in stable order.  Only the junction list is ever addressed by the
+  // caller (edge_prob[c]): a Fenwick tree over the liveness of its stable columns answers "the c-th live column" in
+  // O(log E) and follows a removed / appended column in O(log E) -- no per-call renumbering pass.
+  std::vector<int32_t> fen;             // 1-based partial sums of live_pp
+  int64_t fen_n = 0, n_live[2] = {0, 0};   // tree size (a power of two >= the stable columns it can hold); live pp / pq columns
   std::vector<int64_t> n_of_grain;      // columns per grain: the counts of np.unique(pq[1])
   std::vector<int64_t> few;             // grains with one or two columns, unsorted (membership checked against n_of_grain)
   struct Undo { int kind; int64_t col, old; };          // kind 0..3: arr[kind][col] was `old`; 4: two pp columns appended
@@ -82,10 +87,24 @@ struct ggnn_topology_session {
     const int64_t n = n_of_grain[(size_t)g] += by;
     if (n >= 1 && n <= 2) few.push_back(g);   // (duplicates and stale entries are dropped when the list is read)
   }
+  void fen_add(int64_t col, int by) {
+    for (int64_t i = col + 1; i <= fen_n; i += i & -i) fen[(size_t)i] += by;
+  }
+  int64_t kth_live_pp(int64_t c) const {   // stable column of the caller's column c (0 <= c < n_live[0])
+    int64_t pos = 0, rest = c + 1;
+    for (int64_t step = fen_n; step > 0; step >>= 1)
+      if (pos + step <= fen_n && fen[(size_t)(pos + step)] < rest) pos += step, rest -= fen[(size_t)pos];
+    return pos;   // (0-based stable column: the first position whose prefix count reaches c + 1)
+  }
   void raw_put(int kind, int64_t col, int64_t v) {
     int64_t& slot = arr[kind][(size_t)col];
     const int64_t old = slot;
     if (old == v) return;
+    if ((kind & 1) == 0 && (old == -1 || v == -1)) {   // row 0 of a list decides whether a column is live
+      const int by = v == -1 ? -1 : +1;
+      n_live[kind >> 1] += by;
+      if (kind == 0) fen_add(col, by);
+    }
     if (old != -1) {
       idx[kind].drop(old, col);
       if (kind == 3) recount(old, -1);
@@ -104,6 +123,7 @@ struct ggnn_topology_session {
   }
   int64_t append_pp(int64_t a, int64_t b) {
     const int64_t col = (int64_t)arr[0].size();
+    if (col >= fen_n) throw std::length_error("the junction edge list outgrew the session's room (2 columns per grain)");
     arr[0].push_back(-1), arr[1].push_back(-1);
     undo.push_back({4, col, 0});
     raw_put(0, col, a), raw_put(1, col, b);
@@ -128,21 +148,14 @@ struct ggnn_topology_session {
     for (size_t k = undo_m.size(); k-- > 0;) *undo_m[k].p = undo_m[k].old;
     commit();
   }
-  // the caller's numbering of the live columns (and, when most stable columns are dead, a fresh start from the live ones)
-  void renumber() {
-    for (int l = 0; l < 2; ++l) {
-      std::vector<int64_t>& ext = l ? ext_pq : ext_pp;
-      const std::vector<int64_t>& a = arr[2 * l];
-      ext.clear();
-      for (int64_t c = 0; c < (int64_t)a.size(); ++c)
-        if (a[(size_t)c] != -1) ext.push_back(c);
-    }
-    if (arr[0].size() > 2 * ext_pp.size() + 1024 || arr[2].size() > 2 * ext_pq.size() + 1024) {
-      std::vector<int64_t> live[4];
-      for (int k = 0; k < 4; ++k)
-        for (int64_t c : (k < 2 ? ext_pp : ext_pq)) live[k].push_back(arr[k][(size_t)c]);
-      load(live[0].data(), live[1].data(), (int64_t)live[0].size(), live[2].data(), live[3].data(), (int64_t)live[2].size());
-    }
+  // when most stable columns are dead: a fresh start from the live ones (keeps the O(E) passes of export short)
+  void rebase_if_sparse() {
+    if ((int64_t)arr[0].size() <= 2 * n_live[0] + 1024 && (int64_t)arr[2].size() <= 2 * n_live[1] + 1024) return;
+    std::vector<int64_t> live[4];
+    for (int k = 0; k < 4; ++k)
+      for (size_t c = 0; c < arr[k].size(); ++c)
+        if (arr[k & 2][c] != -1) live[k].push_back(arr[k][c]);
+    load(live[0].data(), live[1].data(), (int64_t)live[0].size(), live[2].data(), live[3].data(), (int64_t)live[2].size());
   }
   void load(const int64_t* p0, const int64_t* p1, int64_t n_pp, const int64_t* q0, const int64_t* q1, int64_t n_pq) {
     const int64_t* src[4] = {p0, p1, q0, q1};
@@ -157,9 +170,15 @@ struct ggnn_topology_session {
     few.clear();
     for (int64_t g = 0; g < n_grain; ++g)
       if (n_of_grain[(size_t)g] >= 1 && n_of_grain[(size_t)g] <= 2) few.push_back(g);
-    ext_pp.resize((size_t)n_pp), ext_pq.resize((size_t)n_pq);
-    for (int64_t c = 0; c < n_pp; ++c) ext_pp[(size_t)c] = c;
-    for (int64_t c = 0; c < n_pq; ++c) ext_pq[(size_t)c] = c;
+    n_live[0] = n_pp, n_live[1] = n_pq;
+    fen_n = 1;
+    while (fen_n < n_pp + 2 * n_grain + 2) fen_n <<= 1;   // (a removed grain appends two columns)
+    fen.assign((size_t)fen_n + 1, 0);
+    for (int64_t i = 1; i <= fen_n; ++i) {   // O(n) construction: every node passes its sum on to its parent
+      if (i <= n_pp) fen[(size_t)i] += 1;
+      const int64_t up = i + (i & -i);
+      if (up <= fen_n) fen[(size_t)up] += fen[(size_t)i];
+    }
   }
 };
 
@@ -457,13 +476,14 @@ struct Topology {
 
   void run() {
     const float thr = (float)A.threshold;   // (numpy compares the fp32 probabilities with the Python float in fp32)
-    // the caller's column c is the session's stable column ext_pp[c] (same relative order)
+    // the caller's column c is the session's c-th live stable column (same relative order)
     std::vector<int64_t> pending, extra, forced;
     std::unordered_map<int64_t, float> prob_of;   // probabilities of the pending columns, by stable column
-    const int64_t n_ext = (int64_t)S.ext_pp.size();
+    const int64_t n_ext = S.n_live[0];
     for (int64_t c = 0; c < n_ext; ++c) {
-      const int64_t k = S.ext_pp[(size_t)c];
-      if (A.edge_prob[c] > thr && pp0[(size_t)k] < pp1[(size_t)k]) pending.push_back(k), prob_of[k] = A.edge_prob[c];
+      if (!(A.edge_prob[c] > thr)) continue;
+      const int64_t k = S.kth_live_pp(c);
+      if (pp0[(size_t)k] < pp1[(size_t)k]) pending.push_back(k), prob_of[k] = A.edge_prob[c];
     }
     // the output lists' room is checked BEFORE anything is rewritten (the switching list only shrinks from here on; every
     // grain and the dead-column marker can be reported at most once)
@@ -541,7 +561,7 @@ int apply_session(Session& S, ggnn_topology_args& A) {
     Topology T(A, S);
     T.run();
     S.commit();
-    S.renumber();   // models.py:845-858: the dead columns are dropped (order kept) -- here: skipped by the caller's numbering
+    S.rebase_if_sparse();   // (models.py:845-858 drops the dead columns, order kept -- here the caller's numbering skips them)
   } catch (const Refused&) {
     S.rollback();
     return GGNN_ETOPOLOGY;
@@ -550,7 +570,7 @@ int apply_session(Session& S, ggnn_topology_args& A) {
     snprintf(A.error, sizeof(A.error), "%s", e.what());
     return GGNN_ETOPOLOGY;
   }
-  A.n_pp = (int64_t)S.ext_pp.size(), A.n_pq = (int64_t)S.ext_pq.size();
+  A.n_pp = S.n_live[0], A.n_pq = S.n_live[1];
   return GGNN_OK;
 }
 
@@ -573,7 +593,7 @@ extern "C" int ggnn_topology_apply(ggnn_topology_session* session, ggnn_topology
 
 extern "C" int ggnn_topology_counts(const ggnn_topology_session* session, int64_t* n_pp, int64_t* n_pq) {
   if (!session || !n_pp || !n_pq) return GGNN_EINVAL;
-  *n_pp = (int64_t)session->ext_pp.size(), *n_pq = (int64_t)session->ext_pq.size();
+  *n_pp = session->n_live[0], *n_pq = session->n_live[1];
   return GGNN_OK;
 }
 
@@ -581,17 +601,24 @@ extern "C" int ggnn_topology_export(const ggnn_topology_session* session, int64_
                                     int64_t pq_ld, int64_t* qp, int64_t qp_ld) {
   if (!session) return GGNN_EINVAL;
   const Session& S = *session;
-  const int64_t n_pp = (int64_t)S.ext_pp.size(), n_pq = (int64_t)S.ext_pq.size();
+  const int64_t n_pp = S.n_live[0], n_pq = S.n_live[1];
   if ((pp && pp_ld < n_pp) || (pq && pq_ld < n_pq) || (qp && qp_ld < n_pq)) return GGNN_EINVAL;
-  if (pp)
-    for (int64_t c = 0; c < n_pp; ++c) {
-      const size_t k = (size_t)S.ext_pp[(size_t)c];
-      pp[c] = S.arr[0][k], pp[pp_ld + c] = S.arr[1][k];
+  // one pass over the stable columns, the live ones written out in order
+  if (pp) {
+    const int64_t *a0 = S.arr[0].data(), *a1 = S.arr[1].data();
+    int64_t w = 0;
+    for (size_t k = 0, n = S.arr[0].size(); k < n; ++k)
+      if (a0[k] != -1) pp[w] = a0[k], pp[pp_ld + w] = a1[k], ++w;
+  }
+  if (pq || qp) {
+    const int64_t *a0 = S.arr[2].data(), *a1 = S.arr[3].data();
+    int64_t w = 0;
+    for (size_t k = 0, n = S.arr[2].size(); k < n; ++k) {
+      if (a0[k] == -1) continue;
+      if (pq) pq[w] = a0[k], pq[pq_ld + w] = a1[k];
+      if (qp) qp[w] = a1[k], qp[qp_ld + w] = a0[k];
+      ++w;
     }
-  for (int64_t c = 0; c < n_pq && (pq || qp); ++c) {
-    const size_t k = (size_t)S.ext_pq[(size_t)c];
-    if (pq) pq[c] = S.arr[2][k], pq[pq_ld + c] = S.arr[3][k];
-    if (qp) qp[c] = S.arr[3][k], qp[qp_ld + c] = S.arr[2][k];
   }
   return GGNN_OK;
 }

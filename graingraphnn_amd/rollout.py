@@ -334,9 +334,11 @@ class GrainRollout:
                 self._xc[nt].copy_(self.x[nt])
             self._xc_fresh = True
 
-    def _enqueue_forward_update(self):
-        """test.py:382-402: both forwards, Rmodel.update, z advance."""
+    def _enqueue_forward_update(self, joint=None):
+        """test.py:382-402: both forwards, Rmodel.update, z advance.  `joint`: True = the regressor and the classifier in the
+        same launches whatever the rollout's plan (same kernels on the same operands, bit-identical results)."""
         be, x, ea, p = self.be, self.x, self.edge_attr, self.pred
+        joint = self.joint_launches if joint is None else joint
         # edge geometry once per step, shared by both models and all four cells
         einfo = prepare_edges(be, self.graph, x, ea, self.einfo)
 
@@ -353,7 +355,7 @@ class GrainRollout:
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                 self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
 
-        if self.joint_launches:
+        if joint:
             run_encoder_decoder_multi(be, [(*self.packed["R"], self.ws["R"]), (*self.packed["C"], self.ws["C"])],
                                       self.graph, x, einfo)
             be.heads_regressor(self.ws["R"].h2["joint"], self.ws["R"].h2["grain"], x["grain"], self.w_reg[0],
@@ -481,6 +483,11 @@ class GrainRollout:
                 torch.cuda.current_stream().wait_stream(st)
                 setattr(self, attr, g)
             getattr(self, attr).replay()
+        elif which == "fwd":
+            # eager launches (the steps around an event: every event replaces the topology the graphs were captured on) are
+            # bound by the HOST's launch rate at any graph size -- ~20 launches + stream forks of the two-stream plan take
+            # 0.49 ms where the kernels take 0.35 (profiles/r6_event_step_breakdown.txt): R and C share every launch here
+            self._enqueue_forward_update(joint=True)
         else:
             fn()
 
@@ -542,7 +549,7 @@ class GrainRollout:
         if S is not None and S["D"] == D:
             # a new topology (after an event): the per-node slots, the centre snapshots and the (pinned) count words stay --
             # the node sets never change -- only the per-edge predictions follow the new edge list
-            keep = {k: S[k] for k in ("xs", "cen", "evf", "evh", "zf")}
+            keep = {k: S[k] for k in ("xs", "cen", "evf", "evh", "zf", "rw")}
             pred = [{k: (torch.empty_like(self.pred[k]) if k in per_edge else v) for k, v in slot.items()}
                     for slot in S["pred"]]
         else:
@@ -550,7 +557,8 @@ class GrainRollout:
                     "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
                     "evf": [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(D)],
                     "evh": [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(D)],
-                    "zf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)]}
+                    "zf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "rw": [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(D)]}
             pred = [{k: torch.empty_like(v) for k, v in self.pred.items()} for _ in range(D)]
         S = self._spec = {
             "topology": self.graph, "cur": 0, "D": D,
@@ -572,7 +580,7 @@ class GrainRollout:
         ready, updated, swept, headed = (torch.cuda.Event() for _ in range(4))
         st_d = self._side[0]   # the event counts go out on a stream of their own: neither model's chain waits for them
         for name in ("R", "C"):   # the fused cells of this step report to the slot's own word (a void step's report is dropped)
-            self.ws[name].range_flag = S["evf"][slot][2:3]
+            self.ws[name].range_flag = S["rw"][slot]
         if swept_prev is not None:
             main.wait_event(swept_prev)   # the previous step's classifier decoder: the chip is free, its edge set may go
         ready.record(main)
@@ -599,10 +607,10 @@ class GrainRollout:
         with torch.cuda.stream(st_d):
             st_d.wait_event(updated)   # grain_area of this step (and every cell of the regressor has reported its range)
             st_d.wait_event(headed)    # ... and its edge_event (the classifier's cells have, too)
+            # (the slot's range word travels in flags[2] and is cleared by the same launch: it is sticky on the device)
             be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
-                             self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot])
+                             self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot], S["rw"][slot])
             S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
-            S["evf"][slot][2:3].zero_()   # (the range word is sticky on the device: cleared once it has been copied out)
         return [ready, updated, headed, swept]
 
     def _enqueue_spec_steps(self, slots):
@@ -828,6 +836,8 @@ class GrainRollout:
         live = self.mask["grain"][:, 0] > 0
         ge = np.flatnonzero(live & (area < np.float32(self.area_threshold)))
         ge = ge[np.argsort(area[ge], kind="stable")]                         # test.py:418-420
+        if getattr(self, "max_grain_events", None) is not None:   # probe hook (tests/bench_event_step.py): random weights
+            ge = ge[:int(self.max_grain_events)]                  # tie the predicted areas of hundreds of grains
         # (the session ignores edges at or below the threshold and the (dst, src) twin of every pair: with no grain below
         # the area threshold either, the update is the identity -- the device-side trigger was conservative)
         mg, mj = self.mask["grain"], self.mask["joint"]

@@ -541,10 +541,13 @@ int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x
 /* Event detection for the host-side topology update (test.py:418, models.py:624-626):
  * flags[0] = number of grains with live_grain > 0 and grain_area < area_threshold,
  * flags[1] = number of junction-junction edges with src < dst and edge_event (a logit) >
- * logit_threshold.  flags: [2] int32 device words (zeroed by the call). */
+ * logit_threshold.  flags: [2] int32 device words (zeroed by the call).
+ * range_word (ABI 24; NULL = none): an OPERAND RANGE word (below) of the step whose predictions these are -- flags must
+ * then hold THREE words: flags[2] = the word's value, and the word is cleared for its next use (the speculative event loop
+ * reads a step's counts and its range report in one copy and drops the report of a step it voids: rollout.py). */
 int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
                        float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
-                       int64_t E, float logit_threshold, int32_t* flags, ggnn_stream_t stream);
+                       int64_t E, float logit_threshold, int32_t* flags, int32_t* range_word, ggnn_stream_t stream);
 /* The host-side topology update those counts trigger: one call of the reference's `Cmodel.update`
  * (models.py:612-842 with delete_grain_index :861-893, switching_edge_index :896-1051, point_in_triangle :1055-1070,
  * periodic_move :1103-1106), nucleation off.  HOST memory throughout, no stream: grains of `grain_event` (those below the

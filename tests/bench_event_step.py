@@ -57,8 +57,12 @@ def rollout_for(workload):
 
 
 def kth_area_threshold(ro, k):
+    """A threshold just above the k-th smallest predicted area of the live grains.  Random weights tie the predicted areas of
+    hundreds of grains: `GrainRollout.max_grain_events` (a probe hook: at most that many grains per step, smallest
+    first) keeps a step at k eliminations + whatever they force."""
     area = ro.pred["grain_area"].cpu().numpy()
     live = ro.mask["grain"][:, 0] > 0
+    ro.max_grain_events = k
     return float(np.nextafter(np.float32(np.sort(area[live])[k - 1]), np.float32(1))), int(live.sum())
 
 
@@ -84,6 +88,8 @@ def steady_eventful(workload, k, n_steps):
         if i >= 2:   # (the first events of a process pay one-off allocations and the session's start)
             ms.append(t), grains.append(int(len(ev)))
     ro.area_threshold = -1.0
+    for _ in range(4):
+        ro.step_events()   # (two quiet steps, then the segment graphs are captured)
     t_quiet, _ = timed(lambda: [ro.step_events() for _ in range(10)])
     return {"workload": workload, "grains_start": int(mask["grain"].shape[0]), "eventful_steps_timed": len(ms),
             "grains_per_step": grains, "ms_per_step_median": round(float(np.median(ms)), 3) if ms else None,

@@ -451,7 +451,10 @@ class TorchEmulatorBackend:
             x_grain[g, :2] = m
 
     def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,
-                      logit_threshold, flags):
+                      logit_threshold, flags, range_word=None):
+        if range_word is not None:
+            flags[2] = int(range_word[0])
+            range_word.zero_()
         flags[0] = int(((live_grain > 0) & (grain_area < area_threshold)).sum())
         flags[1] = int(((edge_event > logit_threshold) & (edge_index_jj[0] < edge_index_jj[1])).sum())
 

@@ -1094,14 +1094,14 @@ def test_speculative_event_loop_restores_the_z_clamp_flag_of_the_eventful_step()
     ra.enable_events(mask, 1e-4, 0.6)
     rb.enable_events(mask, 1e-4, 0.6)
     ev_a, z_a = [], []
-    for _ in range(6):
+    for _ in range(4):   # (the clamp moves every node's z to 0.99 at once: random weights then eliminate most grains)
         ev_a.append(ra.step_events()[1])
         z_a.append(float(Xa["joint"][:, 2].max()))
-    ev_b, _ = rb.run_events(6)
+    ev_b, _ = rb.run_events(4)
     torch.cuda.synchronize()
     assert any(len(e) for e in ev_a[:3]), [len(e) for e in ev_a]     # an eventful step before the crossing ...
     assert z_a[2] < float(zmax) and z_a[3] == float(zmax), z_a       # ... and the clamp from the fourth step on
-    for k in range(6):
+    for k in range(4):
         assert np.array_equal(ev_a[k], ev_b[k]), k
     for nt in Xa:
         assert torch.equal(Xa[nt], Xb[nt]), nt
