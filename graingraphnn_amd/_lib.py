@@ -348,7 +348,7 @@ def _declare(lib):
                                       c_float, c_void_p, POINTER(RefreshEdge), c_int, c_void_p]
     lib.ggnn_grain_centres.restype = c_int
     lib.ggnn_grain_centres.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                       c_float, c_void_p, c_int64, c_int64, c_void_p]
+                                       c_float, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
     lib.ggnn_detect_events.restype = c_int
     lib.ggnn_detect_events.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64,
                                        c_float, c_void_p, c_void_p, c_void_p]

@@ -733,10 +733,15 @@ class HipBackend:
                                         x_grain.size(1), ptr(y_joint), ptr(y_grain), dz, zmax,
                                         ptr(flags), _lib.current_stream()), "ggnn_step_update")
 
-    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None):
+    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None, centres_before=None):
         """x_grain[:, :2] <- region centres of the grains' junction polygons (graph.update(),
-        graph_datastruct.py:681-708 + test.py:556-559).  csr_jg: CSR of (joint, pull, grain)."""
-        _require_cuda(x_joint, x_grain, csr_jg.rowptr, domain_offset)
+        graph_datastruct.py:681-708 + test.py:556-559).  csr_jg: CSR of (joint, pull, grain).  centres_before
+        ([n_grain, 2] fp32, contiguous): receives x_grain[:, :2] as the call found them."""
+        _require_cuda(x_joint, x_grain, csr_jg.rowptr, domain_offset, centres_before)
+        if centres_before is not None:
+            _f32c(centres_before, "centres_before")
+            if tuple(centres_before.shape) != (x_grain.size(0), 2):
+                raise _lib.GGNNError("centres_before must be [n_grain, 2]")
         if csr_jg.rowptr.numel() != x_grain.size(0) + 1:
             raise _lib.GGNNError("csr_jg must have one row per grain")
         if domain_offset is not None:
@@ -749,7 +754,7 @@ class HipBackend:
                                           x_joint.size(0), x_joint.stride(0),
                                           ptr(domain_offset) if domain_offset is not None else None,
                                           float(domain_factor), ptr(x_grain), x_grain.size(0),
-                                          x_grain.stride(0), _lib.current_stream()),
+                                          x_grain.stride(0), ptr(centres_before), _lib.current_stream()),
               "ggnn_grain_centres")
 
     def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,

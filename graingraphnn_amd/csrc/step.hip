@@ -41,9 +41,14 @@ __global__ __launch_bounds__(256) void step_update_kernel(
 __global__ __launch_bounds__(256) void grain_centres_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ x_joint, int64_t ldxj, const float* __restrict__ offset,
-    float factor, float* __restrict__ x_grain, int64_t ldxg, int64_t n_grain, int64_t n_joint) {
+    float factor, float* __restrict__ x_grain, int64_t ldxg, int64_t n_grain, int64_t n_joint,
+    float* __restrict__ centres_before) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= n_grain) return;
+  if (centres_before != nullptr) {   // the centres as this call found them (the speculative event loop's snapshot)
+    centres_before[2 * g] = x_grain[g * ldxg];
+    centres_before[2 * g + 1] = x_grain[g * ldxg + 1];
+  }
   const int p0 = rowptr[g], p1 = rowptr[g + 1];
   if (p1 - p0 <= 1) return;  // graph_datastruct.py:685: such a region keeps its centre
   const bool folded = factor > 1.0f;
@@ -181,7 +186,7 @@ extern "C" int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joi
 extern "C" int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x_joint,
                                   int64_t n_joint, int64_t ldx_joint, const float* domain_offset,
                                   float domain_factor, float* x_grain, int64_t n_grain,
-                                  int64_t ldx_grain, ggnn_stream_t stream) {
+                                  int64_t ldx_grain, float* centres_before, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!rowptr || !col || !x_joint || !x_grain) return GGNN_EINVAL;
   if (n_joint <= 0 || n_grain <= 0 || ldx_joint < 2 || ldx_grain < 2) return GGNN_EINVAL;
@@ -190,7 +195,7 @@ extern "C" int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, con
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
   hipLaunchKernelGGL(grain_centres_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                      rowptr, col, x_joint, ldx_joint, domain_offset, domain_factor, x_grain,
-                     ldx_grain, n_grain, n_joint);
+                     ldx_grain, n_grain, n_joint, centres_before);
   return launch_status();
 }
 

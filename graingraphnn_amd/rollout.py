@@ -265,9 +265,12 @@ class GrainRollout:
         forward of the same step.  Cross-stream edges per step:
           * the classifier waits for `ready` (its copy of x, edge lengths and records of this step are final; recorded by
             the regressor's stream at the top of the step);
-          * the NEXT step's regressor forward waits for `swept` (the classifier's decoder cell of this step is done: the
-            chip is free, and the copy of x / edge records it read may be overwritten by the next refresh); the
-            classifier's heads run behind `swept`, beside the next step's first kernels.
+          * the NEXT step's refresh (the first launch that writes into the set this step's classifier reads: copy of x,
+            edge lengths, edge records) waits for `headed` (the classifier's heads -- the last reader, of the edge lengths
+            -- are done).  Round 5 held the whole next regressor forward back until the classifier's decoder had
+            finished ("the chip is free"); when the classifier's decoder is the one that ends last -- which of the two
+            decoder cells gets the compute units first is the hardware's choice -- that left 60 us per step with only
+            its last workgroups running (profiles/r6_step_timeline.txt): now the regressor's next encoder fills them.
         Needs self._xc to mirror x already (step() / run() see to that: _ensure_edge_records).
         Same kernels on the same operands as the single-stream plan: bit-identical results
         (test_pipelined_two_stream_rollout_equals_the_single_stream_plan)."""
@@ -276,23 +279,21 @@ class GrainRollout:
         main = torch.cuda.current_stream()
         st_c = self._side[1]
         events = []        # kept alive until the streams are joined (and a capture has ended)
-        swept_prev = None    # the classifier's decoder of the previous step of this block
+        headed_prev = None    # the classifier's heads of the previous step of this block
         for _ in range(n_steps):
             ea, ea_next = self.edge_attr, self._ea_other
             einfo, einfo_next = self.einfo, self._einfo_other
             xc, xc_next = self._xc, self._xc_other
-            ready, swept = torch.cuda.Event(), torch.cuda.Event()
-            events += [ready, swept]
-            if swept_prev is not None:
-                main.wait_event(swept_prev)
+            ready, headed = torch.cuda.Event(), torch.cuda.Event()
+            events += [ready, headed]
             ready.record(main)
             with torch.cuda.stream(st_c):
                 st_c.wait_event(ready)
                 enc, dec = self.packed["C"]
                 h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
-                swept.record(st_c)
                 be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                     self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+                headed.record(st_c)
             enc, dec = self.packed["R"]
             hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
             # heads + Rmodel.update in one launch; z clamp + edge lengths + next records + next copy of x in one launch
@@ -301,10 +302,12 @@ class GrainRollout:
             if self.refresh_centres:
                 be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
                                  self.domain_factor, self.domain_offset)
+            if headed_prev is not None:
+                main.wait_event(headed_prev)   # the previous step's classifier has read the set this refresh writes
             be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, self.flags,
                                     [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
                                      for et in EDGE_TYPES], mirror=(xc_next["joint"], xc_next["grain"]))
-            swept_prev = swept
+            headed_prev = headed
             self.edge_attr, self._ea_other = ea_next, ea
             self.einfo, self._einfo_other = einfo_next, einfo
             self._xc, self._xc_other = xc_next, xc
@@ -566,7 +569,7 @@ class GrainRollout:
             "pred": pred, "graphs": {}, "xs_valid": None, **keep}
         return S
 
-    def _enqueue_spec_step(self, slot: int, swept_prev=None):
+    def _enqueue_spec_step(self, slot: int, headed_prev=None):
         """One step with events ASSUMED ABSENT: the overlapped two-stream step (_enqueue_steps_overlapped) on the edge
         set of the slot's parity + a snapshot of the grain centres before they are refreshed + the event counts of this
         step's predictions (ggnn_detect_events) copied to pinned host memory.  Nothing an event would need is
@@ -577,18 +580,15 @@ class GrainRollout:
         ea, ea_next, einfo, einfo_next = S["ea"][s], S["ea"][1 - s], S["einfo"][s], S["einfo"][1 - s]
         p, xc, xc_next, zf = S["pred"][slot], S["xs"][slot], S["xs"][(slot + 1) % S["D"]], S["zf"][slot]
         main, st_c = torch.cuda.current_stream(), self._side[1]
-        ready, updated, swept, headed = (torch.cuda.Event() for _ in range(4))
+        ready, updated, headed = (torch.cuda.Event() for _ in range(3))
         st_d = self._side[0]   # the event counts go out on a stream of their own: neither model's chain waits for them
         for name in ("R", "C"):   # the fused cells of this step report to the slot's own word (a void step's report is dropped)
             self.ws[name].range_flag = S["rw"][slot]
-        if swept_prev is not None:
-            main.wait_event(swept_prev)   # the previous step's classifier decoder: the chip is free, its edge set may go
         ready.record(main)
         with torch.cuda.stream(st_c):
             st_c.wait_event(ready)
             enc, dec = self.packed["C"]
             h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
-            swept.record(st_c)
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                 self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
             headed.record(st_c)
@@ -597,10 +597,13 @@ class GrainRollout:
         be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                   p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, zf)
         updated.record(main)
-        S["cen"][slot].copy_(x["grain"][:, :2])
-        if self.refresh_centres:
+        if self.refresh_centres:   # (the snapshot of the centres the events must see rides with the launch that replaces them)
             be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
-                             self.domain_factor, self.domain_offset)
+                             self.domain_factor, self.domain_offset, centres_before=S["cen"][slot])
+        else:
+            S["cen"][slot].copy_(x["grain"][:, :2])
+        if headed_prev is not None:
+            main.wait_event(headed_prev)   # the previous step's classifier has read the edge set this refresh writes
         be.step_refresh_prepare(x["joint"], x["grain"], self.zmax, zf,
                                 [(self.graph.csr[et], ea_next[et], x[et[0]], x[et[-1]], einfo_next[et])
                                  for et in EDGE_TYPES], mirror=(xc_next["joint"], xc_next["grain"]))
@@ -611,16 +614,17 @@ class GrainRollout:
             be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
                              self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot], S["rw"][slot])
             S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
-        return [ready, updated, headed, swept]
+        return [ready, updated, headed]
 
     def _enqueue_spec_steps(self, slots):
-        """The steps of a block back to back (a step's regressor forward waits for the previous step's classifier
-        decoder, not for its heads and event counts), the streams joined behind the last one."""
-        keep, swept = [], None
+        """The steps of a block back to back (a step's refresh waits for the previous step's classifier heads -- the last
+        reader of the edge set it writes --, nothing else of a step waits for the step before on the other stream), the
+        streams joined behind the last one."""
+        keep, headed = [], None
         try:
             for sl in slots:
-                ev = self._enqueue_spec_step(sl, swept)
-                swept = ev[-1]
+                ev = self._enqueue_spec_step(sl, headed)
+                headed = ev[-1]
                 keep += ev
         finally:
             for name in ("R", "C"):

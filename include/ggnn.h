@@ -533,11 +533,13 @@ int ggnn_step_update(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* 
  * x_grain[g, 0:2] = centre, or frac(centre * domain_factor) when domain_factor > 1.
  * fp32 (the reference's numpy scalars promote to fp64: differences are <= 1 ulp of fp32).
  * domain_offset: [n_joint, 2] or NULL (= 0).  Runs between ggnn_step_update and
- * ggnn_step_refresh so that the refreshed edge lengths see the new centres. */
+ * ggnn_step_refresh so that the refreshed edge lengths see the new centres.
+ * centres_before (ABI 24): NULL, or [n_grain, 2] that receives x_grain[:, 0:2] as the call found them (what a topological
+ * event of this step must see: the speculative event loop keeps it per step instead of copying the columns out). */
 int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x_joint,
                        int64_t n_joint, int64_t ldx_joint, const float* domain_offset,
                        float domain_factor, float* x_grain, int64_t n_grain, int64_t ldx_grain,
-                       ggnn_stream_t stream);
+                       float* centres_before, ggnn_stream_t stream);
 /* Event detection for the host-side topology update (test.py:418, models.py:624-626):
  * flags[0] = number of grains with live_grain > 0 and grain_area < area_threshold,
  * flags[1] = number of junction-junction edges with src < dst and edge_event (a logit) >

@@ -429,7 +429,9 @@ class TorchEmulatorBackend:
         x_grain[:, 2] += dz
         flags[1] = int(x_grain[0, 2] > torch.tensor(zmax, dtype=torch.float32))
 
-    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None):
+    def grain_centres(self, csr_jg, x_joint, x_grain, domain_factor=1.0, domain_offset=None, centres_before=None):
+        if centres_before is not None:
+            centres_before.copy_(x_grain[:, :2])
         rowptr, col = csr_jg.rowptr.tolist(), csr_jg.col.tolist()
         f = torch.tensor(domain_factor, dtype=torch.float32)
         xy = x_joint[:, :2].clone()
