@@ -108,21 +108,40 @@ class HipBackend:
             chunk, todo = todo[:4], todo[4:]
             arr = (_lib.CsrArgs * len(chunk))()
             keep = []
+            arena = None
+            if not check:
+                # unchecked builds run once per topological event: every table of the chunk out of ONE allocation (two
+                # dozen allocator calls and six fills otherwise; the unit table's unused tail and the range flags that
+                # nobody reads stay uninitialised)
+                r4 = lambda n: (n + 3) & ~3   # int32 counts in multiples of 16 bytes
+                need = sum(2 * r4(n_dst + 1) + 3 * r4(max(int(ei_.size(1)), 1)) + 8 * self.lib.ggnn_csr_max_units(int(ei_.size(1)), n_dst)
+                           + 4 + r4(self.lib.ggnn_csr_workspace_bytes(int(ei_.size(1)), n_dst) // 4 + 1) for ei_, _, n_dst in chunk)
+                arena = [torch.empty(need, dtype=torch.int32, device=chunk[0][0].device), 0]
+
+            def take(n, like_zeros=False, shape=None, dev=None):
+                if arena is None:
+                    t = (torch.zeros if like_zeros else torch.empty)(n, dtype=torch.int32, device=dev)
+                else:
+                    t = arena[0][arena[1]:arena[1] + n]
+                    arena[1] += (n + 3) & ~3
+                return t if shape is None else t.view(shape)
             for a, (edge_index, n_src, n_dst) in zip(arr, chunk):
                 _require_cuda(edge_index)
                 if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
                     raise _lib.GGNNError("edge_index must be int64 [2, E]")
                 ei = edge_index.contiguous()
                 E, dev = ei.size(1), ei.device
-                rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
-                col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-                perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-                row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-                unit_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
-                units = torch.zeros(self.lib.ggnn_csr_max_units(E, n_dst), 8, dtype=torch.int32, device=dev)
-                flags = torch.zeros(2, dtype=torch.int32, device=dev)
+                rowptr = take(n_dst + 1, dev=dev)
+                col = take(max(E, 1), dev=dev)
+                perm = take(max(E, 1), dev=dev)
+                row = take(max(E, 1), dev=dev)
+                unit_ptr = take(n_dst + 1, dev=dev)
+                n_units = self.lib.ggnn_csr_max_units(E, n_dst)
+                units = take(8 * n_units, True, (n_units, 8), dev)
+                flags = take(2, True, dev=dev)
                 nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                ws = take(nbytes // 4 + 1, dev=dev).view(torch.uint8)[:nbytes] if arena is not None else \
+                    torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 a.edge_index, a.E, a.n_src, a.n_dst = ei.data_ptr(), E, n_src, n_dst
                 a.rowptr, a.col, a.perm, a.row = rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), row.data_ptr()
                 a.unit_ptr, a.units, a.flags = unit_ptr.data_ptr(), units.data_ptr(), flags.data_ptr()

@@ -138,6 +138,8 @@ class GrainRollout:
         dev = self.x["joint"].device
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
         self.graph = graph_for(self.be, self.edge_index, self.n_nodes, trusted)
+        if trusted and edge_attr_dict is None:
+            return self._set_topology_buffers_from_one_allocation(dev)
         if edge_attr_dict is not None:
             self.edge_attr = {et: edge_attr_dict[et].detach().clone().contiguous().view(-1).float()
                               for et in EDGE_TYPES}
@@ -158,6 +160,33 @@ class GrainRollout:
         self._einfo_other = None
         if not hasattr(self, "_xc"):
             self._xc = self._xc_other = None
+        self._x_written_outside()
+        self._graphs = None
+        self._seen = None
+
+    def _set_topology_buffers_from_one_allocation(self, dev):
+        """The per-edge buffers of a topology the event loop installs (every step, on the reference's trajectories): both
+        sets of edge lengths and edge records and the per-edge predictions as views of ONE allocation, nothing
+        initialised -- the refresh that follows an event writes every length, ggnn_edge_prepare / ggnn_step_refresh_prepare
+        every record (zero padding included) before anything reads them."""
+        E = {et: self.edge_index[et].size(1) for et in EDGE_TYPES}
+        r4 = lambda n: (n + 3) & ~3
+        rec = {et: (E[et] + _lib.GGNN_UNIT_EDGES) * _lib.GGNN_EINFO_ROW for et in EDGE_TYPES}
+        total = sum(2 * r4(E[et]) + 2 * r4(rec[et]) for et in EDGE_TYPES) + r4(E[ET_JJ]) + r4(2 * E[ET_JJ])
+        buf, o = torch.empty(total, dtype=torch.float32, device=dev), [0]
+
+        def take(n, shape=None):
+            v = buf[o[0]:o[0] + n]
+            o[0] += r4(n)
+            return v if shape is None else v.view(shape)
+        self.edge_attr = {et: take(E[et]) for et in EDGE_TYPES}
+        self._ea_other = {et: take(E[et]) for et in EDGE_TYPES}
+        shape = lambda et: (E[et] + _lib.GGNN_UNIT_EDGES, _lib.GGNN_EINFO_ROW)
+        self.einfo = {et: take(rec[et], shape(et)) for et in EDGE_TYPES}
+        self._einfo_other = {et: take(rec[et], shape(et)) for et in EDGE_TYPES}
+        self._einfo_fresh = False
+        self.pred["edge_event"] = take(E[ET_JJ])
+        self.pred["edge"] = take(2 * E[ET_JJ], (E[ET_JJ], 2))
         self._x_written_outside()
         self._graphs = None
         self._seen = None
@@ -553,8 +582,13 @@ class GrainRollout:
             # a new topology (after an event): the per-node slots, the centre snapshots and the (pinned) count words stay --
             # the node sets never change -- only the per-edge predictions follow the new edge list
             keep = {k: S[k] for k in ("xs", "cen", "evf", "evh", "zf", "rw")}
-            pred = [{k: (torch.empty_like(self.pred[k]) if k in per_edge else v) for k, v in slot.items()}
-                    for slot in S["pred"]]
+            E = self.pred["edge_event"].numel()
+            Ea = (E + 3) & ~3                                                     # (16-byte aligned segments)
+            flat = torch.empty(3 * D * Ea, dtype=torch.float32, device=dev)   # one allocation for all slots
+            edge_bufs = [{"edge_event": flat[3 * i * Ea:3 * i * Ea + E],
+                          "edge": flat[3 * i * Ea + Ea:3 * i * Ea + Ea + 2 * E].view(E, 2)} for i in range(D)]
+            pred = [{k: (edge_bufs[i][k] if k in per_edge else v) for k, v in slot.items()}
+                    for i, slot in enumerate(S["pred"])]
         else:
             keep = {"xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
                     "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
