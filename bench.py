@@ -293,7 +293,7 @@ def measure_roofline(ro, n_steps):
         sweep = {"bound": "hbm", "kernel": "ggnn::aggregate_kernel<4, true>", "plan": "GGNN_DEC=split",
                  "achieved": round(achieved, 1),
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                 "traffic": pmc_traffic("ggnn::aggregate_kernel<4, true>"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r5_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record", "avg_launch_us": round(d["avg_us"], 2),
+                 "traffic": pmc_traffic("ggnn::aggregate_kernel<4, true>"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r6_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record", "avg_launch_us": round(d["avg_us"], 2),
                  "event_bracket_us": round(d["bracket_us"], 2), "bracket_overhead_us": round(d["overhead_us"], 2),
                  "algorithmic_bytes_per_launch": int(d["work"]), "launches_timed": d["n"],
                  "sweeps_per_launch": d["per_launch"]}
@@ -306,7 +306,7 @@ def measure_roofline(ro, n_steps):
         achieved = f["work3"] / f["avg_us"] / 1e3
         roof = {"bound": "hbm", "kernel": "ggnn::dec_cell_kernel", "plan": "default (GGNN_DEC=fused)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ggnn::dec_cell_kernel", "fused"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r5_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ggnn::dec_cell_kernel", "fused"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r6_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
                 "avg_launch_us": round(f["avg_us"], 2), "event_bracket_us": round(f["bracket_us"], 2),
                 "bracket_overhead_us": round(f["overhead_us"], 2), "algorithmic_bytes_per_launch": int(f["work3"]),
                 "bytes_as_built_per_launch": int(f["work2"]), "launches_timed": f["n"],
@@ -333,7 +333,7 @@ def measure_roofline(ro, n_steps):
         enc = {"bound": "mfma", "kernel": "ggnn::enc_cell_kernel (the whole encoder cell of a model: one launch)",
                "achieved": round(busy * FP16_MFMA_PEAK_TFLOPS, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                "frac": round(busy, 4), "avg_launch_us": round(c["avg_us"], 2), "problems_per_launch": c["per_launch"],
-               "traffic": pmc_traffic("ggnn::enc_cell_kernel", "fused"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r5_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
+               "traffic": pmc_traffic("ggnn::enc_cell_kernel", "fused"), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r6_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
                "mfma_cycles_per_launch": int(c["work"]),
                "note": "frac = matrix-pipe cycles of the launch (fp16 MFMAs at 16 cycles: three per fp32 product, half of "
                        "every 16-slot k-step's 32-deep reduction is padding; six fp32 MFMAs of 32 cycles per pass) / "
@@ -349,7 +349,7 @@ def measure_roofline(ro, n_steps):
             gbs = nbytes / g["avg_us"] / 1e3
             tf = flops / g["avg_us"] / 1e6
             gemm.append({"bound": "hbm", "kernel": name, "plan": plan, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, plan), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r5_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, plan), "traffic_source": "recorded rocprofv3 --pmc passes (profiles/r6_pmc_kernels.json: tools/profile_round.sh on this library, matched by ABI + source hash); null traffic = no matching record",
                          "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": round(g["avg_us"], 2),
                          "problems_per_launch": g["per_launch"],
                          "fp32_equivalent_tflops": round(tf, 1),
@@ -375,11 +375,11 @@ def kernel_source_hash():
 
 def pmc_traffic(kernel, plan="split"):
     """HBM-side bytes per launch of `kernel` from the rocprofv3 --pmc passes recorded in
-    profiles/r5_pmc_kernels.json (PMC collection cannot run inside this process; the file says how it was taken
+    profiles/r6_pmc_kernels.json (PMC collection cannot run inside this process; the file says how it was taken
     and corrected, tools/pmc_kernels.py).  The record is stamped with the ABI version and a hash of the kernels'
     sources: None when the file is absent or does not describe the library that is running."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r6_pmc_kernels.json")) as f:
             doc = json.load(f)
         if doc["kernel_source_hash"] != kernel_source_hash():
             return None

@@ -537,6 +537,11 @@ class GrainRollout:
         self.be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
                               self.graph.edge_index[ET_JJ], self._logit_trigger, self._ev_flags)
         self._ev_host.copy_(self._ev_flags, non_blocking=True)
+        # behind an eventful step the next one is eventful too, on the reference's trajectories (README.md:68-69: events at
+        # nearly every step): what the rewiring reads travels to the host behind the counts, one synchronisation instead of two
+        payload = self._quiet_steps == 0 and getattr(self, "_evb", None) is not None and getattr(self, "rewire_hook", None) is None
+        if payload:
+            self._enqueue_event_readback()
         torch.cuda.current_stream().synchronize()
         events, switches = np.zeros(0, np.int64), np.zeros((0, 2), np.int64)
         pred = self.pred
@@ -545,7 +550,7 @@ class GrainRollout:
             # the caller gets this step's predictions on the PRE-event edge list, as the
             # reference's loop does (test.py:383-426 keeps `pred` across Cmodel.update)
             pred = dict(self.pred)
-            events, switches = self._apply_events()
+            events, switches = self._apply_events(payload_ready=payload)
         if len(events) or len(switches):
             self._quiet_steps = 0
         else:
@@ -842,7 +847,19 @@ class GrainRollout:
         self._topo = (ses, jj, jg, (jj._version, jg._version))
         return ses
 
-    def _apply_events(self):
+    def _enqueue_event_readback(self):
+        """What the rewiring reads -- predicted areas, switching probabilities, junction coordinates and displacements -- as
+        asynchronous copies into the pinned staging buffers (the caller synchronises)."""
+        B, p = self._event_buffers(), self.pred
+        E = self.edge_index[ET_JJ].size(1)
+        prob_d = torch.sigmoid(p["edge_event"])
+        B["area"].copy_(p["grain_area"], non_blocking=True)
+        B["prob"][:E].copy_(prob_d, non_blocking=True)
+        B["xj"].copy_(self.x["joint"], non_blocking=True)
+        B["yj"].copy_(p["joint"], non_blocking=True)
+        B["yg"].copy_(p["grain"], non_blocking=True)
+
+    def _apply_events(self, payload_ready=False):
         """Host round trip of an eventful step: the predictions and junction coordinates travel to pinned host memory in
         one batch of asynchronous copies behind ONE synchronisation, the library's session rewires its lists in place
         (ggnn_topology_apply: a refused update leaves everything as it was), the new lists, coordinates and masks travel
@@ -862,13 +879,9 @@ class GrainRollout:
         E = self.edge_index[ET_JJ].size(1)
         if ses is not None and ses.n_pp != E:
             raise _lib.GGNNError("the topology session and the rollout's junction edge list disagree")
-        prob_d = torch.sigmoid(p["edge_event"])
-        B["area"].copy_(p["grain_area"], non_blocking=True)
-        B["prob"][:E].copy_(prob_d, non_blocking=True)
-        B["xj"].copy_(self.x["joint"], non_blocking=True)
-        B["yj"].copy_(p["joint"], non_blocking=True)
-        B["yg"].copy_(p["grain"], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if not payload_ready:
+            self._enqueue_event_readback()
+            torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
         area, prob = N["area"], N["prob"][:E]
         live = self.mask["grain"][:, 0] > 0

@@ -3,7 +3,7 @@
 tools/profile_decoder.sh writes (separate rocprofv3 --pmc passes over `bench.py --steps 5 --warmup 2 --profile
 --no-graph --serial`; bytes = 128 RDREQ_128B + 64 RDREQ_64B + 32 RDREQ_32B (+ 64 x the rest) read, 64 WRREQ_64B
 + 32 x the rest written: the request counters of the L2's memory side, MI355X_MICROARCH.md section HBM) ->
-profiles/r5_pmc_kernels.json, stamped with the ABI version and a hash of the kernels' sources.  bench.py quotes
+profiles/r6_pmc_kernels.json, stamped with the ABI version and a hash of the kernels' sources.  bench.py quotes
 a kernel's traffic only from a record whose stamp matches the library it runs.
 
     python tools/pmc_kernels.py gpurun_out/TAG/pmc_split_summary.csv [gpurun_out/TAG/pmc_fused_summary.csv]
@@ -54,7 +54,7 @@ def main(paths):
                                  "mfma_busy_cycles": int(float(r["mfma_busy_Mcycles"]) * 1e6),
                                  "wait_any_frac": float(r["wait_any_frac"]), "wait_inst_frac": float(r["wait_inst_frac"])}
         doc["plans"][plan] = rows
-    out = os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")
+    out = os.path.join(ROOT, "profiles", "r6_pmc_kernels.json")
     if os.path.exists(out) and len(doc["plans"]) < 2:   # keep the other plan's record of an earlier run (its own stamp)
         try:
             old = json.load(open(out))

@@ -16,7 +16,7 @@ for plan in fused split; do
     i=$((i+1))
     timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $OUT/pmc_$plan/$i -- python3 bench.py --steps 5 --warmup 2 --profile --no-graph --serial > $OUT/pmc_${plan}_$i.log 2>&1
   done
-  if [ $plan = split ]; then python3 tools/pmc_aggregate.py $OUT/pmc_split $OUT/r5_pmc_aggregate_sweep.json > $OUT/pmc_aggregate.log 2>&1; fi
+  if [ $plan = split ]; then python3 tools/pmc_aggregate.py $OUT/pmc_split $OUT/r6_pmc_aggregate_sweep.json > $OUT/pmc_aggregate.log 2>&1; fi
   python3 - $OUT $plan <<'PY'
 import csv, glob, os, sys, collections
 out, plan = sys.argv[1], sys.argv[2]
@@ -46,9 +46,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default
 find $OUT/default -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/default_command_kernel_stats.csv
 rm -rf $OUT/default
 python3 tools/kernel_table.py $OUT/serial_fused_kernel_stats.csv $OUT/serial_split_kernel_stats.csv $OUT/joint_kernel_stats.csv > $OUT/kernel_table.txt
-cp $OUT/r5_pmc_aggregate_sweep.json profiles/r5_pmc_aggregate_sweep.json 2>/dev/null   # so that the bench lines below quote them
+cp $OUT/r6_pmc_aggregate_sweep.json profiles/r6_pmc_aggregate_sweep.json 2>/dev/null   # so that the bench lines below quote them
 python3 tools/pmc_kernels.py $OUT/pmc_split_summary.csv $OUT/pmc_fused_summary.csv > $OUT/pmc_kernels.log 2>&1
-cp profiles/r5_pmc_kernels.json $OUT/r5_pmc_kernels.json
+cp profiles/r6_pmc_kernels.json $OUT/r6_pmc_kernels.json
 timeout 600 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench_driver_command.err
 GGNN_DEC=split timeout 600 python3 bench.py --no-cpu-baseline > $OUT/bench_split_plan.json 2> $OUT/bench_split_plan.err
