@@ -214,7 +214,7 @@ class EventTimedBackend:
             n, n_in = x_dst.size(0), len(sweeps)
             flops += 2.0 * n * 4 * (n_in * (128 * 112 + 98 * 96) + 128 * 96)
             nbytes += 4.0 * n * (x_dst.size(1) + 96 + 96 + 2 * 96) + 2.0 * wstream.numel()
-            for csr, einfo, h_src, v_src, v_off, ep in sweeps:   # value rows + hidden rows of the sources, edge records
+            for csr, einfo, h_src, v_src, v_off, ep, *_ in sweeps:   # value rows + hidden rows of the sources, edge records
                 nbytes += 4.0 * (h_src.size(0) * (4 * 96 + 96) + csr.E * 20 + csr.E + n + 1)
                 canon += algorithmic_bytes(h_src.size(0), n, csr.E, 4)   # what the cell's sweeps are defined to move
                 n_sweeps += 1

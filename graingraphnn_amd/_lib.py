@@ -21,6 +21,7 @@ GGNN_EDGE_PARAM_ROWS = 3
 GGNN_DC_SLICE_BYTES = 14336
 GGNN_PRECISION_BF16 = 1
 GGNN_PRECISION_F16X2 = 2
+GGNN_OUT_BLOCK_MAJOR = 0x100
 GGNN_ETOPOLOGY = -3
 GGNN_FLAG_F16_RANGE = 1
 GGNN_ADAM_CHUNK, GGNN_ADAM_MAX_TENSORS, GGNN_ADAM_MAX_GROUPS = 4096, 384, 8
@@ -118,7 +119,7 @@ class DecCellSweep(Structure):
         ("rowptr", c_void_p), ("col", c_void_p), ("einfo", c_void_p), ("h_src", c_void_p), ("v_src", c_void_p),
         ("edge_params", c_void_p),
         ("E", c_int64), ("n_src", c_int64), ("ldh_src", c_int64), ("ldv", c_int64),
-        ("v_off", c_int32), ("reserved", c_int32),
+        ("v_off", c_int32), ("v_block_major", c_int32),
     ]
 
 

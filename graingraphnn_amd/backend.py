@@ -65,6 +65,9 @@ class HipBackend:
             if dec == "auto":
                 self.fused_decoder_min_joints = int(os.environ.get("GGNN_DEC_MIN_JOINTS", str(self.FUSED_DECODER_MIN_JOINTS)))
 
+        # the fused decoder plan's value rows as [blocks][N][96] (GGNN_OUT_BLOCK_MAJOR; GGNN_VLAYOUT=rows: [N, ncols], A/B runs)
+        self.value_rows_block_major = os.environ.get("GGNN_VLAYOUT", "rows") == "block"
+
     def f16_projection(self) -> bool:
         """The fused decoder plan's value projection in the cells' three-product arithmetic (GGNN_PRECISION_F16X2) when the
         packed weights allow; GGNN_PROJ=x6 keeps the six-product split (development, A/B runs)."""
@@ -345,7 +348,8 @@ class HipBackend:
                                      "number of incoming edge types")
             if tuple(w2_tail.shape) != (4, n_in, 6, 64) or not w2_tail.is_contiguous():
                 raise _lib.GGNNError("ggnn_decoder_cell_batch: w2_tail must be contiguous [4, n_in, 6, 64]")
-            for sw, (csr, einfo, h_src, v_src, v_off, ep) in zip(a.sweeps, sweeps):
+            for sw, (csr, einfo, h_src, v_src, v_off, ep, *v_bm) in zip(a.sweeps, sweeps):
+                v_bm = bool(v_bm and v_bm[0])   # optional 7th element: v_src is GGNN_OUT_BLOCK_MAJOR ([blocks][n_src][96])
                 _require_cuda(csr.rowptr, csr.col, einfo, h_src, v_src, ep)
                 if csr.rowptr.numel() != n + 1:
                     raise _lib.GGNNError("the sweep's CSR does not have one row per destination node")
@@ -356,6 +360,9 @@ class HipBackend:
                     if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.size(0) != h_src.size(0):
                         raise _lib.GGNNError(f"ggnn_decoder_cell_batch: {name} must be float32 [n_src, *] with unit "
                                              "column stride")
+                if v_bm and (not v_src.is_contiguous() or v_off % 96):
+                    raise _lib.GGNNError("ggnn_decoder_cell_batch: block-major value rows live in a contiguous buffer, "
+                                         "v_off a multiple of 96")
                 if h_src.size(1) < 96 or v_off < 0 or v_off + 4 * 96 > v_src.size(1):
                     raise _lib.GGNNError("ggnn_decoder_cell_batch: h_src needs 96 columns, the four gates' value rows "
                                          "must lie inside a v_src row")
@@ -364,6 +371,7 @@ class HipBackend:
                 sw.rowptr, sw.col, sw.einfo = csr.rowptr.data_ptr(), csr.col.data_ptr(), einfo.data_ptr()
                 sw.h_src, sw.v_src, sw.edge_params = h_src.data_ptr(), v_src.data_ptr(), ep.data_ptr()
                 sw.E, sw.n_src, sw.ldh_src, sw.ldv, sw.v_off = csr.E, h_src.size(0), h_src.stride(0), v_src.stride(0), v_off
+                sw.v_block_major = int(v_bm)
             a.x_dst, a.h_dst, a.c_in = x_dst.data_ptr(), h_dst.data_ptr(), c_in.data_ptr()
             a.h_out, a.c_out = h_out.data_ptr(), c_out.data_ptr()
             a.wstream, a.w2_tail = wstream.data_ptr(), w2_tail.data_ptr()

@@ -255,10 +255,12 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
           const float* w = ep + ch + (cc < 3 ? cc : CH2 + cc - 3);
           wv[cc] = {w[0], w[C], w[2 * C]};
         }
-        const float* __restrict__ vbase = Sw.v_src + Sw.v_off + g * C + ch;
+        // value rows of (edge type, gate): 96 columns of a [n_src, ldv] row, or (v_block_major) a [n_src, 96] matrix of their own
+        const float* __restrict__ vbase = Sw.v_block_major ? Sw.v_src + (int64_t)(Sw.v_off / C + g) * Sw.n_src * C + ch
+                                                           : Sw.v_src + Sw.v_off + g * C + ch;
         const float* __restrict__ hbase = Sw.h_src + ch;
         const float* __restrict__ einfo = Sw.einfo;
-        const uint32_t ldv = (uint32_t)Sw.ldv, ldh = (uint32_t)Sw.ldh_src;
+        const uint32_t ldv = Sw.v_block_major ? (uint32_t)C : (uint32_t)Sw.ldv, ldh = (uint32_t)Sw.ldh_src;
         const int* __restrict__ rp = csr + e * (17 + DC_CW);
         const int* __restrict__ colw = rp + 17;
         const int pbase = rp[0], e_last = max((int)Sw.E - 1, 0);
@@ -554,8 +556,9 @@ extern "C" int ggnn_decoder_cell_batch(const ggnn_dec_cell_args* args, int n_pro
       const ggnn_dec_cell_sweep& Sw = A.in[e];
       if (!Sw.rowptr || !Sw.einfo || !Sw.h_src || !Sw.v_src || !Sw.edge_params || !aligned16(Sw.einfo)) return GGNN_EINVAL;
       if (Sw.E < 0 || Sw.n_src <= 0 || (Sw.E > 0 && !Sw.col)) return GGNN_EINVAL;
-      if (Sw.ldh_src < C || Sw.v_off < 0 || Sw.v_off + 4 * C > Sw.ldv) return GGNN_EINVAL;
-      if (Sw.n_src * Sw.ldh_src >= INT32_MAX || Sw.n_src * Sw.ldv >= INT32_MAX ||
+      if (Sw.ldh_src < C || Sw.v_off < 0) return GGNN_EINVAL;
+      if (Sw.v_block_major ? (Sw.v_block_major != 1 || Sw.v_off % C != 0) : Sw.v_off + 4 * C > Sw.ldv) return GGNN_EINVAL;
+      if (Sw.n_src * Sw.ldh_src >= INT32_MAX || Sw.n_src * (Sw.v_block_major ? (int64_t)C : Sw.ldv) >= INT32_MAX ||
           (Sw.E + GGNN_UNIT_EDGES) * GGNN_EINFO_ROW >= INT32_MAX)
         return GGNN_EINVAL;  // gathered rows are addressed with 32-bit offsets
     }

@@ -215,9 +215,10 @@ extern "C" int ggnn_project_batch(const ggnn_project_args* args, int n_problems,
     if (A.k2 != k2 || (k2 != 0 && k2 != C)) return GGNN_EINVAL;
     if (k2 != 0 && (!A.H || A.ldh < k2 || (A.ldh & 3) || !aligned16(A.H))) return GGNN_EINVAL;
     if (A.ncols <= 0 || A.ncols % PJ_BN != 0 || A.ldo < A.ncols || (A.ldo & 3)) return GGNN_EINVAL;
+    const int prec = A.precision & ~GGNN_OUT_BLOCK_MAJOR;
     if (A.precision != 0 &&
-        ((A.precision != GGNN_PRECISION_BF16 && A.precision != GGNN_PRECISION_F16X2) || k2 != C || gemm_mode() != GGNN_GEMM_BF16X6))
-      return GGNN_EINVAL;   // (the one- and three-product forms exist for the decoder shape on the split kernel only)
+        ((prec != 0 && prec != GGNN_PRECISION_BF16 && prec != GGNN_PRECISION_F16X2) || k2 != C || gemm_mode() != GGNN_GEMM_BF16X6))
+      return GGNN_EINVAL;   // (the one- and three-product forms and the block-major output exist for the decoder shape on the split kernel only)
     if (!aligned16(A.Wp) || !aligned16(A.bias) || !aligned16(A.out)) return GGNN_EINVAL;
     // a tile's first row is a 64-bit base; only the offsets INSIDE a 16-row tile are formed in 32 bits
     if (16 * std::max(A.ldo, std::max(A.ldx, A.ldh)) >= INT32_MAX || A.M >= ((int64_t)1 << 40)) return GGNN_EINVAL;

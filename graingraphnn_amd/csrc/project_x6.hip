@@ -49,8 +49,7 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
   const float* __restrict__ H = A.H;
   const float* __restrict__ Wp = A.Wp;
   const float* __restrict__ bias = A.bias;
-  float* __restrict__ out = A.out;
-  const int64_t ldx = A.ldx, ldh = A.ldh, M = A.M, ldo = A.ldo;
+  const int64_t ldx = A.ldx, ldh = A.ldh, M = A.M;
   const int F = A.F, ncols = A.ncols;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -58,6 +57,12 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
   const int nb_n = ncols / PX_BN;
   const int bn = blk % nb_n, ms = blk / nb_n;
   const int n0 = bn * PX_BN;
+  // GGNN_OUT_BLOCK_MAJOR (ggnn.h): the 96 columns this workgroup produces are a contiguous [M, 96] block of their own -- every
+  // tile's 6 KB leave as one contiguous run instead of sixteen 384-byte pieces 4 * ldo bytes apart
+  const bool block_major = (A.precision & GGNN_OUT_BLOCK_MAJOR) != 0;
+  float* __restrict__ out = block_major ? A.out + (int64_t)bn * M * PX_BN : A.out;
+  const int64_t ldo = block_major ? PX_BN : A.ldo;
+  const int n0_out = block_major ? 0 : n0;
 
   // ---- prologue: split the weight tile into its three planes ----
 #pragma unroll
@@ -118,7 +123,7 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
     const int idx = lane + it * 64, r = idx / FP, k = min(idx - r * FP, F - 1);
     ox[it] = (int)min((int64_t)r, M - 1) * (int)ldx + k;
   }
-  const int oo = (int)min((int64_t)lr, M - 1) * (int)ldo + n0 + 4 * kq;
+  const int oo = (int)min((int64_t)lr, M - 1) * (int)ldo + n0_out + 4 * kq;
   auto load_tile = [&](int64_t mt) {  // unconditional: nothing here uses a loaded value
     const int64_t m0 = min(mt * PX_BM, m_last);
     const float* hb = H + m0 * ldh;
@@ -251,13 +256,14 @@ __global__ __launch_bounds__(PX_WAVES * 64, 1) void project_x6_kernel(const Proj
   // (xcd_remap) they run side by side behind ONE L2, which then reads their node rows from memory once instead of once
   // per column tile (speed only).
   const int blk = xcd_remap((int)blockIdx.x - B.wg_off[k], B.wg_off[k + 1] - B.wg_off[k]), Fp = (A.F + 3) & ~3;
-  if (A.precision == GGNN_PRECISION_F16X2) {
+  const int precision = A.precision & ~GGNN_OUT_BLOCK_MAJOR;
+  if (precision == GGNN_PRECISION_F16X2) {
     if (Fp == 4) project_x6_body<4, 3>(A, blk, B.m_splits[k], lds);
     else if (Fp == 8) project_x6_body<8, 3>(A, blk, B.m_splits[k], lds);
     else project_x6_body<12, 3>(A, blk, B.m_splits[k], lds);
     return;
   }
-  if (A.precision == GGNN_PRECISION_BF16) {
+  if (precision == GGNN_PRECISION_BF16) {
     if (Fp == 4) project_x6_body<4, 1>(A, blk, B.m_splits[k], lds);
     else if (Fp == 8) project_x6_body<8, 1>(A, blk, B.m_splits[k], lds);
     else project_x6_body<12, 1>(A, blk, B.m_splits[k], lds);

@@ -141,13 +141,17 @@ def run_cells(backend, cells, graph: GraphCSR, x: Dict[str, torch.Tensor], einfo
         if pc.dcs and fd:
             # decoder: everything on the destination side in one kernel (ggnn_decoder_cell_batch); the projection only
             # emits the source-side value rows
+            # the value rows: written once by the projection, gathered 96 columns (one edge type and gate) at a time by the
+            # cell -- as [blocks][N][96] (GGNN_OUT_BLOCK_MAJOR) every workgroup of the projection stores one contiguous run
+            vbm = getattr(backend, "value_rows_block_major", False)
             for nt in NODE_TYPES:
                 if nt in pc.wpv:
                     projs.append((x[nt], lay[nt].F, h_in[nt], pc.wpv[nt], pc.bpv[nt], proj[nt][:, :pc.wpv[nt].size(0)],
-                                  _lib.GGNN_PRECISION_F16X2 if pc.wpv_f16 and backend.f16_projection() else 0))
+                                  (_lib.GGNN_PRECISION_F16X2 if pc.wpv_f16 and backend.f16_projection() else 0)
+                                  | (_lib.GGNN_OUT_BLOCK_MAJOR if vbm else 0)))
             for nt in NODE_TYPES:
                 if lay[nt].live:
-                    dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et])
+                    dec_cells.append(([(graph.csr[et], einfo[et], h_in[et[0]], proj[et[0]], pc.vof[et], pc.ep[et], vbm)
                                        for et in lay[nt].dst_ets], x[nt], h_in[nt], c_in[nt], pc.dcs[nt], pc.dct[nt],
                                       h_out[nt], c_out[nt], *flag))
             continue

@@ -155,7 +155,11 @@ typedef struct ggnn_project_args {
                         the range are clamped: the caller checks its weights, packing.pack_cell; the node rows are the
                         ones ggnn_decoder_cell_batch checks and reports) -- the value rows of the fused decoder plan;
                         GGNN_PRECISION_BF16 (k2 == 96 only): operands rounded to bf16, ONE bf16 MFMA product per
-                        k-step, fp32 accumulate -- what torch.autocast(bfloat16) asks of a linear (training path) */
+                        k-step, fp32 accumulate -- what torch.autocast(bfloat16) asks of a linear (training path).
+                        | GGNN_OUT_BLOCK_MAJOR (k2 == 96 only, ABI 24): `out` is [ncols / 96][M][96] -- every block of 96
+                        columns a contiguous [M, 96] matrix of its own (ldo is ignored) -- instead of [M, ldo]: the layout
+                        of the fused decoder plan's value rows, which are written once here and gathered 96 columns
+                        (one edge type and gate) at a time by ggnn_decoder_cell_batch (v_block_major) */
 } ggnn_project_args;
 int ggnn_project_batch(const ggnn_project_args* args, int n_problems, ggnn_stream_t stream);
 
@@ -416,6 +420,7 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * n_src * ld < 2^31 for every gathered operand; up to four problems per call. */
 #define GGNN_PRECISION_BF16 1
 #define GGNN_PRECISION_F16X2 2
+#define GGNN_OUT_BLOCK_MAJOR 0x100 /* or-ed into ggnn_project_args.precision: see there */
 #define GGNN_DC_SLICE_BYTES 14336 /* 7 column tiles x 2 planes x 1 KB */
 #define GGNN_FLAG_F16_RANGE 1     /* an activation at or beyond +-65504 was clamped in a two-piece fp16 split */
 typedef struct ggnn_dec_cell_sweep {
@@ -426,7 +431,9 @@ typedef struct ggnn_dec_cell_sweep {
   const float* v_src;        /* [n_src, ldv] */
   const float* edge_params;  /* [4][GGNN_EDGE_PARAM_ROWS][96] */
   int64_t E, n_src, ldh_src, ldv;
-  int32_t v_off, reserved;
+  int32_t v_off;         /* first of the four gates' 96 value columns inside a v_src row (a multiple of 96 when block-major) */
+  int32_t v_block_major; /* ABI 24: 0 = v_src is [n_src, ldv]; 1 = v_src is GGNN_OUT_BLOCK_MAJOR: [blocks][n_src][96], the
+                            four gates' blocks v_off / 96 .. + 3 (ldv is ignored) */
 } ggnn_dec_cell_sweep;
 typedef struct ggnn_dec_cell_args {
   ggnn_dec_cell_sweep in[2];
