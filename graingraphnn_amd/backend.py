@@ -65,8 +65,11 @@ class HipBackend:
             if dec == "auto":
                 self.fused_decoder_min_joints = int(os.environ.get("GGNN_DEC_MIN_JOINTS", str(self.FUSED_DECODER_MIN_JOINTS)))
 
-        # the fused decoder plan's value rows as [blocks][N][96] (GGNN_OUT_BLOCK_MAJOR; GGNN_VLAYOUT=rows: [N, ncols], A/B runs)
-        self.value_rows_block_major = os.environ.get("GGNN_VLAYOUT", "rows") == "block"
+        # the fused decoder plan's value rows as [blocks][N][96] (GGNN_OUT_BLOCK_MAJOR: every workgroup of the projection
+        # stores contiguous runs, and a (edge type, gate) pass of the cell gathers from one dense [N, 96] matrix --
+        # dec_cell_kernel 110.2 -> 105.5 us, project_x6_kernel 22.8 -> 21.9 us per launch, 3 020 -> 3 054 steps/s on one box,
+        # profiles/r6_value_rows_layout.txt); GGNN_VLAYOUT=rows: [N, ncols] (A/B runs)
+        self.value_rows_block_major = os.environ.get("GGNN_VLAYOUT", "block") != "rows"
 
     def f16_projection(self) -> bool:
         """The fused decoder plan's value projection in the cells' three-product arithmetic (GGNN_PRECISION_F16X2) when the

@@ -14,6 +14,7 @@ C = 96
 class TorchEmulatorBackend:
     name = "torch-emulator (tests only)"
     fused_encoder = True  # engine.run_cells: encoder cells through encoder_cell_batch (False: sweep + gate epilogue)
+    value_rows_block_major = True   # the fused decoder plan's value rows as [blocks][N][96], like HipBackend's default
 
     def build_csr(self, edge_index, n_src, n_dst):
         src, dst = edge_index[0], edge_index[1]
@@ -242,7 +243,7 @@ class TorchEmulatorBackend:
             for gi, g in enumerate((0, 2, 1, 3)):
                 z = torch.zeros(n, C)
                 order = list(enumerate(sweeps))
-                for d, (csr, einfo, h_src, v_src, v_off, ep) in (order[::-1] if gi & 1 else order):   # ggnn.h: backwards for the 2nd and 4th gate
+                for d, (csr, einfo, h_src, v_src, v_off, ep, *v_bm) in (order[::-1] if gi & 1 else order):   # ggnn.h: backwards for the 2nd and 4th gate
                     W1 = self._decode_slices(wstream, s, 4, 7)        # [112, 128]
                     W3 = self._decode_slices(wstream, s + 4, 3, 6)    # [96, 96]
                     s += 7
@@ -258,7 +259,13 @@ class TorchEmulatorBackend:
                     p = (sc - smax[dst]).exp()
                     den = torch.zeros(n).index_add(0, dst, p)
                     alpha = p / (den[dst] + 1e-16)
-                    val = torch.relu(v_src[src, v_off + g * C: v_off + (g + 1) * C] + reloc @ ep[g])
+                    if v_bm and v_bm[0]:   # GGNN_OUT_BLOCK_MAJOR: block v_off / 96 + g of [blocks][n_src][96]
+                        n_src = v_src.size(0)
+                        b0 = (v_off // C + g) * n_src * C
+                        v_g = v_src.reshape(-1)[b0:b0 + n_src * C].view(n_src, C)[src]
+                    else:
+                        v_g = v_src[src, v_off + g * C: v_off + (g + 1) * C]
+                    val = torch.relu(v_g + reloc @ ep[g])
                     A = torch.zeros(n, C).index_add(0, dst, alpha[:, None] * val)
                     sa = torch.zeros(n).index_add(0, dst, alpha)
                     sae = torch.zeros(n).index_add(0, dst, alpha * a)
@@ -362,11 +369,19 @@ class TorchEmulatorBackend:
         """(x, F, h, wp, bp, out[, precision]); precision GGNN_PRECISION_BF16: both operands rounded to bf16, products
         accumulated in fp32 (what the HIP kernel's single-product mode computes)."""
         for x, F, h, wp, bp, out, *rest in problems:
-            if rest and rest[0] == 1:
+            prec = rest[0] if rest else 0
+            target = out
+            if prec & 0x100:   # GGNN_OUT_BLOCK_MAJOR: [ncols / 96][M][96] at the front of out's storage
+                target = torch.empty(x.size(0), wp.size(0))
+            if prec & 0xff == 1:
                 r = lambda t: None if t is None else t.to(torch.bfloat16).float()
-                self.project(r(x), F, r(h), r(wp), bp, out)
+                self.project(r(x), F, r(h), r(wp), bp, target)
             else:
-                self.project(x, F, h, wp, bp, out)
+                self.project(x, F, h, wp, bp, target)
+            if prec & 0x100:
+                M, nc = target.shape
+                base = out._base if out._base is not None else out
+                base.view(-1)[:M * nc] = target.view(M, nc // 96, 96).permute(1, 0, 2).reshape(-1)
 
     def lstm_epilogue_batch(self, problems):
         for prob in problems:

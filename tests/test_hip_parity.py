@@ -1784,6 +1784,39 @@ def _dec_cell_problem(be, rs, n_dst, ins, hub=0, F_dst=8, edges=None):
             torch.empty(n_dst, 96, device=DEV), torch.empty(n_dst, 96, device=DEV))
 
 
+@torch.no_grad()
+def test_block_major_value_rows_equal_the_row_major_layout():
+    """GGNN_OUT_BLOCK_MAJOR (ABI 24): the projection writes every 96 columns as a contiguous [M, 96] block and the decoder
+    cell gathers them from there (v_block_major) -- same bits as the [M, ncols] layout, for a ragged node count, under both
+    arithmetic modes of the projection."""
+    be = backend()
+    rs = np.random.RandomState(5)
+    f = lambda *shape, lo=-1.0, hi=1.0: torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32)).to(DEV)
+    M, F, ncols = 1003, 8, 768
+    x, h, wp, bp = f(M, F, lo=0.0), f(M, 96), f(ncols, 8 + 96, lo=-0.2, hi=0.2), f(ncols)
+    for prec in (_lib.GGNN_PRECISION_F16X2, 0):
+        rows = torch.empty(M, ncols, device=DEV)
+        blocks = torch.full((M, ncols + 96), 7.0, device=DEV)   # (a wider buffer, as the workspace's: the blocks fill its front)
+        be.project_batch([(x, F, h, wp, bp, rows, prec)])
+        be.project_batch([(x, F, h, wp, bp, blocks[:, :ncols], prec | _lib.GGNN_OUT_BLOCK_MAJOR)])
+        got = blocks.view(-1)[:M * ncols].view(ncols // 96, M, 96)
+        assert torch.equal(got.permute(1, 0, 2).reshape(M, ncols), rows), prec
+    # the decoder cell on the same value rows in both layouts
+    prob = _dec_cell_problem(be, np.random.RandomState(11), 236, [(118, 11, 708), (236, 8, 708)])
+    be.decoder_cell_batch([prob])
+    h_rows, c_rows = prob[6].clone(), prob[7].clone()
+    sweeps = []
+    for csr, einfo, h_src, v_src, v_off, ep in prob[0]:
+        n, w = v_src.shape
+        w96 = w // 96 * 96
+        bm = torch.zeros(n, w, device=DEV)
+        bm.view(-1)[:n * w96] = v_src[:, :w96].reshape(n, w96 // 96, 96).permute(1, 0, 2).reshape(-1)
+        sweeps.append((csr, einfo, h_src, bm, v_off, ep, True))
+    prob2 = (sweeps,) + tuple(prob[1:6]) + (torch.empty_like(prob[6]), torch.empty_like(prob[7]))
+    be.decoder_cell_batch([prob2])
+    assert torch.equal(prob2[6], h_rows) and torch.equal(prob2[7], c_rows)
+
+
 @pytest.mark.parametrize("n_dst,ins,hub", [
     (236, [(118, 11, 708), (236, 8, 708)], 0),      # junctions of the 40 um fixture: two incoming edge types
     (118, [(236, 8, 708)], 0),                      # grains: one
