@@ -309,56 +309,56 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
             U.vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
           }
         };
+        // Every product-sum is an explicit fma and contraction is off: the two variants of the sweep (and a row computed
+        // by two overlapping tiles of a ragged end) must give the same bits, whatever the compiler would have chosen to
+        // fuse in each inlined copy.
+        // NO BRANCH (round 6): every gathered operand is consumed UNCONDITIONALLY (an edge beyond the row's end holds the
+        // clamped load of a real edge: finite, weighted with an exact zero), inactive edges and exhausted rows are selects.
+        // With the uses under `if (t < nact)` -- rounds 3-5 -- the compiler SANK gathers into those blocks: the ISA had the
+        // hidden-row loads of a row's second edge behind the branch with an s_waitcnt vmcnt(0) of their own, a third
+        // dependent memory round trip per pair of rows in every pass.  Same operations on the same operands for the active
+        // edges, exact zeros added for the others: bit-identical results (tools/probes/dccheck.py), classifier launch
+        // 128 -> 118 us in tools/dcbench.py, 3 160-3 190 -> 3 290-3 360 steps/s on one box.
         auto fold = [&](Row& r, const Unit& U) __attribute__((always_inline)) {
-          // Every product-sum is an explicit fma and contraction is off: the two variants of the sweep (and a row
-          // computed by two overlapping tiles of a ragged end) must give the same bits, whatever the compiler would
-          // have chosen to fuse in each inlined copy.
 #pragma clang fp contract(off)
           const int nact = min(max(r.pe - r.p, 0), GGNN_UNIT_EDGES);
-          if (nact > 0) {
-            float s[GGNN_UNIT_EDGES];
-            float mnew = r.mx;
+          float s[GGNN_UNIT_EDGES];
+          float mnew = r.mx;
 #pragma unroll
-            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
-              s[t] = -INFINITY;
-              if (t < nact) {
-                float part = r.u4 * U.x4[t];
-                part = __builtin_fmaf(r.uh0.x, U.hh[t][0].x, part);
-                part = __builtin_fmaf(r.uh0.y, U.hh[t][0].y, part);
-                part = __builtin_fmaf(r.uh0.z, U.hh[t][0].z, part);
-                part = __builtin_fmaf(r.uh1.x, U.hh[t][1].x, part);
-                part = __builtin_fmaf(r.uh1.y, U.hh[t][1].y, part);
-                part = __builtin_fmaf(r.uh1.z, U.hh[t][1].z, part);
-                s[t] = row_sum(part);   // 1 / sqrt(96) is folded into u
-                mnew = fmaxf(mnew, s[t]);
-              }
-            }
-            const float scale = __expf(r.mx - mnew);   // exp(-inf) = 0 on a row's first unit
-            r.den = r.den * scale;
-            r.sae = r.sae * scale;
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) r.acc[cc] = r.acc[cc] * scale;
-#pragma unroll
-            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
-              if (t < nact) {
-                // lane k of every 16-lane row -> the whole row (ds_swizzle bit mode: and 0x10, or k)
-                const int xi = __builtin_bit_cast(int, U.x4[t]);
-                const float rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (0 << 5) | 0x10));
-                const float ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (1 << 5) | 0x10));
-                const float rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (2 << 5) | 0x10));
-                const float pw_ = __expf(s[t] - mnew);
-                r.den = r.den + pw_;
-                r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);   // lane 13: sum alpha a_e (other lanes: unused)
-                const float v[6] = {U.vv[t][0].x, U.vv[t][0].y, U.vv[t][0].z, U.vv[t][1].x, U.vv[t][1].y, U.vv[t][1].z};
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                  const float val = __builtin_fmaf(wv[cc].z, rz, __builtin_fmaf(wv[cc].y, ry, __builtin_fmaf(wv[cc].x, rx, v[cc])));
-                  r.acc[cc] = __builtin_fmaf(pw_, fmaxf(val, 0.f), r.acc[cc]);
-                }
-              }
-            }
-            r.mx = mnew;
+          for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+            float part = r.u4 * U.x4[t];
+            part = __builtin_fmaf(r.uh0.x, U.hh[t][0].x, part);
+            part = __builtin_fmaf(r.uh0.y, U.hh[t][0].y, part);
+            part = __builtin_fmaf(r.uh0.z, U.hh[t][0].z, part);
+            part = __builtin_fmaf(r.uh1.x, U.hh[t][1].x, part);
+            part = __builtin_fmaf(r.uh1.y, U.hh[t][1].y, part);
+            part = __builtin_fmaf(r.uh1.z, U.hh[t][1].z, part);
+            const float st = row_sum(part);   // 1 / sqrt(96) is folded into u
+            s[t] = t < nact ? st : -INFINITY;
+            mnew = fmaxf(mnew, s[t]);
           }
+          const float scale = nact > 0 ? __expf(r.mx - mnew) : 1.0f;   // exp(-inf) = 0 on a row's first unit
+          r.den = r.den * scale;
+          r.sae = r.sae * scale;
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc) r.acc[cc] = r.acc[cc] * scale;
+#pragma unroll
+          for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
+            const int xi = __builtin_bit_cast(int, U.x4[t]);
+            const float rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (0 << 5) | 0x10));
+            const float ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (1 << 5) | 0x10));
+            const float rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (2 << 5) | 0x10));
+            const float pw_ = t < nact ? __expf(s[t] - mnew) : 0.f;
+            r.den = r.den + pw_;
+            r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);
+            const float v[6] = {U.vv[t][0].x, U.vv[t][0].y, U.vv[t][0].z, U.vv[t][1].x, U.vv[t][1].y, U.vv[t][1].z};
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+              const float val = __builtin_fmaf(wv[cc].z, rz, __builtin_fmaf(wv[cc].y, ry, __builtin_fmaf(wv[cc].x, rx, v[cc])));
+              r.acc[cc] = __builtin_fmaf(pw_, fmaxf(val, 0.f), r.acc[cc]);
+            }
+          }
+          r.mx = mnew;
           r.p += GGNN_UNIT_EDGES;
         };
         auto close_row = [&](const Row& r, int n) __attribute__((always_inline)) {  // the row's aggregate over the u it was computed from
