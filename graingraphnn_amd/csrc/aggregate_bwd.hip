@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggre
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const float val = v[c] + wv[c][0] * rec[t][0] + wv[c][1] * rec[t][1] + wv[c][2] * rec[t][2];
-          dv[c] += val > 0.f ? al * go[t][c] : 0.f;
+          // (the relu mask as a factor, not a branch around the product: under `val > 0 ? al * go : 0` the compiler sank one
+          // element of the gathered gradient row behind the branch, a dword load with an s_waitcnt vmcnt(0) of its own --
+          // a dependent memory round trip per unit; same value for finite operands)
+          dv[c] += (val > 0.f ? al : 0.f) * go[t][c];
           if (HAS_H) dh[c] += dd * uh[t][c];
         }
       }
