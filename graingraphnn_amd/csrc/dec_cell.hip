@@ -292,21 +292,33 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
         // A tile whose in-edges fit the LDS index window (all but hub tiles) finds every source index there; a load
         // under `if` would drag a full wait to the branch merge and serialise the edges, so the choice is made once
         // per tile, wave-uniformly, between two straight-line variants of the gather.
-        const bool in_window = __builtin_amdgcn_readfirstlane(rp[16] - pbase) <= DC_CW;
-        auto gather = [&](const Row& r, Unit& U, auto window_tag) __attribute__((always_inline)) {   // unconditional (clamped) loads, back to back
+        // (two entries of the window stay spare: a row's three consecutive indices are read from ONE clamped position)
+        const bool in_window = __builtin_amdgcn_readfirstlane(rp[16] - pbase) <= DC_CW - 2;
+        // the source nodes of a row's next three in-edges: ALL index reads of the rows in flight go out before the first
+        // address is formed (interleaved with the gathers -- rounds 3-5 -- every edge paid its own LDS round trip in front
+        // of its loads: six exposed ds_read latencies per pair of rows)
+        auto sources = [&](const Row& r, int (&j)[GGNN_UNIT_EDGES], auto window_tag) __attribute__((always_inline)) {
           constexpr bool WINDOW = decltype(window_tag)::value;
+          if constexpr (WINDOW) {
+            // three consecutive window entries from one address (an active edge's entry is col[p + t]; behind the row's
+            // end they belong to the next rows or repeat the list's last entry: valid nodes, weighted with exact zeros)
+            const int* __restrict__ w = colw + min(max(r.p - pbase, 0), DC_CW - GGNN_UNIT_EDGES);
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) j[t] = has_edges ? w[t] : 0;
+          } else {
+#pragma unroll
+            for (int t = 0; t < GGNN_UNIT_EDGES; ++t) j[t] = has_edges ? Sw.col[min(r.p + t, e_last)] : 0;
+          }
+        };
+        auto gather = [&](const Row& r, Unit& U, const int (&j)[GGNN_UNIT_EDGES]) __attribute__((always_inline)) {   // unconditional (clamped) loads, back to back
 #pragma unroll
           for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
             const int pt = min(r.p + t, e_last);
-            int j;
-            if constexpr (WINDOW) j = colw[min(max(pt - pbase, 0), DC_CW - 1)];
-            else j = has_edges ? Sw.col[pt] : 0;
-            if (!has_edges) j = 0;
-            U.hh[t][0] = ld3(hbase + (uint32_t)j * ldh);
-            U.hh[t][1] = ld3(hbase + (uint32_t)j * ldh + CH2);
+            U.hh[t][0] = ld3(hbase + (uint32_t)j[t] * ldh);
+            U.hh[t][1] = ld3(hbase + (uint32_t)j[t] * ldh + CH2);
             U.x4[t] = einfo[(uint32_t)pt * GGNN_EINFO_ROW + lr];
-            U.vv[t][0] = ld3(vbase + (uint32_t)j * ldv);
-            U.vv[t][1] = ld3(vbase + (uint32_t)j * ldv + CH2);
+            U.vv[t][0] = ld3(vbase + (uint32_t)j[t] * ldv);
+            U.vv[t][1] = ld3(vbase + (uint32_t)j[t] * ldv + CH2);
           }
         };
         // Every product-sum is an explicit fma and contraction is off: the two variants of the sweep (and a row computed
@@ -345,9 +357,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
 #pragma unroll
           for (int t = 0; t < GGNN_UNIT_EDGES; ++t) {
             const int xi = __builtin_bit_cast(int, U.x4[t]);
-            const float rx = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (0 << 5) | 0x10));
-            const float ry = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (1 << 5) | 0x10));
-            const float rz = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, (2 << 5) | 0x10));
+            // lane k of every 16-lane row -> the whole row: DPP row_newbcast (a vector-ALU move that the consumer can carry
+            // as an operand modifier; rounds 3-5 used ds_swizzle: an LDS-pipe operation with a wait of its own)
+            const float rx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x150, 0xF, 0xF, true));
+            const float ry = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x151, 0xF, 0xF, true));
+            const float rz = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x152, 0xF, 0xF, true));
             const float pw_ = t < nact ? __expf(s[t] - mnew) : 0.f;
             r.den = r.den + pw_;
             r.sae = __builtin_fmaf(pw_, U.x4[t], r.sae);
@@ -391,8 +405,11 @@ __device__ __forceinline__ void dec_cell_body(const ggnn_dec_cell_args& A, const
             open_row(rb, nb);
             do {
               Unit ua, ub;
-              gather(ra, ua, window_tag);
-              gather(rb, ub, window_tag);
+              int ja[GGNN_UNIT_EDGES], jb[GGNN_UNIT_EDGES];
+              sources(ra, ja, window_tag);
+              sources(rb, jb, window_tag);
+              gather(ra, ua, ja);
+              gather(rb, ub, jb);
               fold(ra, ua);
               fold(rb, ub);
             } while (__builtin_amdgcn_ballot_w64(ra.p < ra.pe || rb.p < rb.pe) != 0);
