@@ -80,7 +80,12 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
   int q_cur = 0;
   [[maybe_unused]] unsigned long long st_wait = 0, st_a = 0, st_p3 = 0, st_p4 = 0, st_lstm = 0;
   GGNN_STAMP(0);
-  auto dma_group = [&](int q) {
+#ifndef EC_DMA_PARTS
+#define EC_DMA_PARTS 1
+#endif
+  // `part` of EC_DMA_PARTS: the wave's pieces of a group are requested in that many instalments through the pass that
+  // precedes it (development, profiles/r6_enc_cell_experiments.txt; 1 = all of them at the top of the pass)
+  auto dma_group = [&](int q, int part = 0) {
     if (q >= n_groups) return;
     const int g = q / n_in, e = q - g * n_in;
     const int s0 = g * per_gate + 4 * e;                  // first slice of the group in the stream
@@ -88,7 +93,10 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     const int np = EC_NPA + (ns - 1) * EC_NP3;
     const unsigned char* src = wsrc + (size_t)s0 * EC_SLICE;
     const uint32_t dst = slice_lds + (q & 1) * (EC_GROUP * EC_SLICE);
-    for (int p = wave; p < np; p += EC_WAVES) {
+    constexpr int per_part = (8 + EC_DMA_PARTS - 1) / EC_DMA_PARTS;   // (a wave has at most 8 pieces of a 62-piece group)
+    const int p_lo = EC_DMA_PARTS == 1 ? wave : wave + EC_WAVES * per_part * part;
+    const int p_hi = EC_DMA_PARTS == 1 ? np : min(np, wave + EC_WAVES * per_part * (part + 1));
+    for (int p = p_lo; p < p_hi; p += EC_WAVES) {
       // piece p of the group: the 14 pieces of its first slice, then 12 per slice (the last 2 KB of those are unused)
       const int sl = p < EC_NPA ? 0 : 1 + (p - EC_NPA) / EC_NP3;
       const int off = sl * EC_SLICE + (p < EC_NPA ? p : (p - EC_NPA) % EC_NP3) * 1024;
@@ -96,7 +104,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     }
   };
   auto begin_group = [&]() -> const u32x4* {   // the group about to be used landed at the previous end_group
-    dma_group(q_cur + 1);
+    dma_group(q_cur + 1, 0);
     return reinterpret_cast<const u32x4*>(smem + (q_cur & 1) * (EC_GROUP * EC_SLICE)) + lane;
   };
   auto end_group = [&]() {
@@ -106,7 +114,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
     st_wait += GGNN_STAMP_NOW() - w0;
     ++q_cur;
   };
-  dma_group(0);
+  for (int k = 0; k < EC_DMA_PARTS; ++k) dma_group(0, k);
 #ifdef EC_EXP_PRIO
   // development (profiles/r6_enc_cell_experiments.txt): one static priority for the second-dispatched half of the workgroup
   if (wave >= EC_WAVES / 2) __builtin_amdgcn_s_setprio(1);
@@ -275,6 +283,7 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
         }
       }
       [[maybe_unused]] const unsigned long long t_b = GGNN_STAMP_NOW();
+      if (EC_DMA_PARTS > 1) dma_group(q_cur + 1, 1);
 
       // ================= P3: pre += lin_l2(e, g) . agg + (b_l2, w_edge) . (sum alpha, sum alpha a) =================
       {
@@ -291,7 +300,10 @@ __device__ __forceinline__ void enc_cell_body(const ggnn_enc_cell_args& A, const
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) part[ct].zero();
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) dc_kstep<6>(pw + (1 + ks) * (EC_SLICE / 16), ab[ks], part);
+        for (int ks = 0; ks < 3; ++ks) {
+          dc_kstep<6>(pw + (1 + ks) * (EC_SLICE / 16), ab[ks], part);
+          if (EC_DMA_PARTS > 2 && ks + 2 < EC_DMA_PARTS) dma_group(q_cur + 1, ks + 2);
+        }
         // ... and, behind the gate's last edge type, P4: the summed skip term + gate bias (16 feature slots: one k-step)
         if (e == n_in - 1) dc_kstep<6>(pw + 4 * (EC_SLICE / 16), xs, part);
 #pragma unroll
