@@ -393,6 +393,11 @@ int ggnn_encoder_cell_batch(const ggnn_enc_cell_args* args, int n_problems, ggnn
  * operands out and the cell runs on projection + sweeps + gate GEMM, whose bf16 x 3 split covers fp32's range); an
  * activation outside it is clamped to +-65504 AND reported: the kernel ORs GGNN_FLAG_F16_RANGE into *flags (when
  * given), which graingraphnn_amd's backend reads at the end of a rollout / on request (range_exceeded).
+ * FINITE OPERANDS are assumed by the sweep (round 6): it folds a row's in-edges three at a time WITHOUT a branch, the
+ * slots behind the row's last edge filled with the (clamped) gather of a neighbouring edge and weighted with an exact
+ * zero -- bit-identical to skipping them while the gathered hidden / value rows are finite; a NaN or inf in ANOTHER row
+ * of h_src / v_src can then reach this row one step earlier than message passing would carry it (0 x inf).  The
+ * flag word reports non-finite operands either way.
  *
  * Per incoming edge type:
  *   rowptr, col : destination-grouped CSR of the edge type (ggnn_build_csr)
