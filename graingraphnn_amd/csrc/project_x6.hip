@@ -65,16 +65,22 @@ __device__ __forceinline__ void project_x6_body(const ggnn_project_args& A, int 
   const int n0_out = block_major ? 0 : n0;
 
   // ---- prologue: split the weight tile into its three planes ----
+  // All eight loads of a lane FIRST, unconditional (the k slots behind the row's end clamp to its last pair and are zeroed by a
+  // select), then the splits: under `if (k < 96 + FP)` -- rounds 2-5 -- the compiler kept every load inside its branch with an
+  // s_waitcnt vmcnt(0) behind it: eight dependent memory round trips at the head of every workgroup of a 22 us kernel.
+  constexpr int PX_PRO = PX_BN * 64 / (PX_WAVES * 64);
+  f32x2_ wab[PX_PRO];
 #pragma unroll
-  for (int it = 0; it < PX_BN * 64 / (PX_WAVES * 64); ++it) {  // 12 independent load->split->write chains
+  for (int it = 0; it < PX_PRO; ++it) {
     const int idx = tid + it * PX_WAVES * 64;
-    const int r = idx >> 6, kp = idx & 63, k = 2 * kp;  // k, k+1 never straddle a segment (96, FP even)
-    float a = 0.f, b = 0.f;
-    if (k < 96 + FP) {
-      const float* w = Wp + (int64_t)(n0 + r) * KP + (k < 96 ? FP + k : k - 96);
-      a = w[0];
-      b = w[1];
-    }
+    const int r = idx >> 6, k = min(2 * (idx & 63), 96 + FP - 2);  // k, k+1 never straddle a segment (96, FP even)
+    wab[it] = *reinterpret_cast<const f32x2_*>(Wp + (int64_t)(n0 + r) * KP + (k < 96 ? FP + k : k - 96));
+  }
+#pragma unroll
+  for (int it = 0; it < PX_PRO; ++it) {
+    const int idx = tid + it * PX_WAVES * 64;
+    const int r = idx >> 6, kp = idx & 63, k = 2 * kp;
+    const float a = k < 96 + FP ? wab[it][0] : 0.f, b = k < 96 + FP ? wab[it][1] : 0.f;
     uint32_t p0, p1, p2 = 0u;
     if constexpr (NPROD == 3) split_f16x2(a, b, p0, p1);
     else split_bf16x3(a, b, p0, p1, p2);
