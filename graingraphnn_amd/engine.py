@@ -207,24 +207,27 @@ def gate_problems(pc: PackedCell, proj, agg, c_in, h_out, c_out):
 
 def run_encoder_decoder(backend, enc: PackedCell, dec: PackedCell, graph: GraphCSR, ws: Workspace,
                         x: Dict[str, torch.Tensor], edge_attr: Dict[ET, torch.Tensor],
-                        einfo: Optional[Dict[ET, torch.Tensor]] = None, x_read=None, einfo_read=None):
+                        einfo: Optional[Dict[ET, torch.Tensor]] = None, x_read=None, einfo_read=None, after_encoder=None):
     """models.py:422-426 / 581-585: encoder from zero state, decoder from the encoder's (h, c),
     both on the same x_dict.  `einfo` (from prepare_edges) may be shared by several models that
-    see the same x / edge_attr; when absent it is computed here.  Returns the decoder's (h, c)."""
+    see the same x / edge_attr; when absent it is computed here.  Returns the decoder's (h, c).
+    `after_encoder`: called once the encoder cell's launches are enqueued (a caller may record a stream event there)."""
     if einfo is None:
         ea = {et: _edge_attr_1d(edge_attr[et]) for et in EDGE_TYPES}
         einfo = ws.einfo = prepare_edges(backend, graph, x, ea, ws.einfo)
-    run_encoder_decoder_multi(backend, [(enc, dec, ws)], graph, x, einfo, x_read, einfo_read)
+    run_encoder_decoder_multi(backend, [(enc, dec, ws)], graph, x, einfo, x_read, einfo_read, after_encoder)
     return ws.h2, ws.c2
 
 
 def run_encoder_decoder_multi(backend, models, graph: GraphCSR, x: Dict[str, torch.Tensor],
-                              einfo: Dict[ET, torch.Tensor], x_read=None, einfo_read=None):
+                              einfo: Dict[ET, torch.Tensor], x_read=None, einfo_read=None, after_encoder=None):
     """The encoder cells of all `models` = [(enc, dec, workspace), ...] in three launches, then
     their decoder cells in three more (every model keeps its own weights, workspace and state)."""
     flag = getattr(models[0][2], "range_flag", None)   # (models launched together belong to one rollout: one word)
     run_cells(backend, [(enc, None, None, ws.proj, ws.agg_enc, ws.h1, ws.c1) for enc, _, ws in models],
               graph, x, einfo, range_flag=flag)
+    if after_encoder is not None:
+        after_encoder()
     # (x_read / einfo_read: called once the last launch that reads x -- the decoder projection -- / the edge
     # records -- the decoder sweeps -- is enqueued)
     run_cells(backend, [(dec, ws.h1, ws.c1, ws.proj, ws.agg_dec, ws.h2, ws.c2) for _, dec, ws in models],

@@ -88,6 +88,9 @@ class GrainRollout:
         # GGNN_PIPE=r4 (development, A/B runs): the round-4 pipelined plan, whose Rmodel.update waits for the classifier's
         # decoder; default: the regressor's tail runs UNDER the classifier's decoder (_enqueue_steps_overlapped)
         self.overlap_tail = os.environ.get("GGNN_PIPE", "") != "r4"
+        # where the classifier's chain of a step starts relative to the regressor's: "none" = together with it (default),
+        # "enc" / "dec" = behind its encoder / decoder cell (development switch, see _enqueue_steps_overlapped)
+        self.classifier_lead = os.environ.get("GGNN_C_AFTER", "none")
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.concurrent else None
         self.refresh_centres = refresh_centres
         self.domain_factor = float(domain_factor)
@@ -313,18 +316,28 @@ class GrainRollout:
             ea, ea_next = self.edge_attr, self._ea_other
             einfo, einfo_next = self.einfo, self._einfo_other
             xc, xc_next = self._xc, self._xc_other
-            ready, headed = torch.cuda.Event(), torch.cuda.Event()
-            events += [ready, headed]
+            ready, headed, lead = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            events += [ready, headed, lead]
             ready.record(main)
+            enc, dec = self.packed["R"]
+            # GGNN_C_AFTER=enc / dec (development; default: none) start the classifier's chain BEHIND the regressor's encoder
+            # / decoder cell instead of beside it (`lead`), so that the regressor's tail -- three launch-bound kernels,
+            # ~40 us -- runs under the classifier's decoder cell rather than on an idle chip.  Measured a wash: one box
+            # 3 288-3 491 steps/s (none) vs 3 460-3 503 (enc) vs 3 176-3 201 (dec), a second box 3 523-3 626 (none) vs
+            # 3 466-3 536 (enc) -- profiles/r6_step_timeline.txt; the results are bit-identical either way.
+            stage = self.classifier_lead
+            hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo,
+                                        x_read=(lambda: lead.record(main)) if stage == "dec" else None,
+                                        after_encoder=(lambda: lead.record(main)) if stage == "enc" else None)
             with torch.cuda.stream(st_c):
                 st_c.wait_event(ready)
+                if stage in ("enc", "dec"):
+                    st_c.wait_event(lead)
                 enc, dec = self.packed["C"]
                 h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
                 be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                     self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
                 headed.record(st_c)
-            enc, dec = self.packed["R"]
-            hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
             # heads + Rmodel.update in one launch; z clamp + edge lengths + next records + next copy of x in one launch
             be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                       p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, self.flags)
@@ -624,15 +637,20 @@ class GrainRollout:
         for name in ("R", "C"):   # the fused cells of this step report to the slot's own word (a void step's report is dropped)
             self.ws[name].range_flag = S["rw"][slot]
         ready.record(main)
+        lead, stage = torch.cuda.Event(), self.classifier_lead   # (the classifier behind the regressor's encoder cell: see _enqueue_steps_overlapped)
+        enc, dec = self.packed["R"]
+        hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo,
+                                    x_read=(lambda: lead.record(main)) if stage == "dec" else None,
+                                    after_encoder=(lambda: lead.record(main)) if stage == "enc" else None)
         with torch.cuda.stream(st_c):
             st_c.wait_event(ready)
+            if stage in ("enc", "dec"):
+                st_c.wait_event(lead)
             enc, dec = self.packed["C"]
             h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
                                 self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
             headed.record(st_c)
-        enc, dec = self.packed["R"]
-        hr, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["R"], x, ea, einfo)
         be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                   p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, zf)
         updated.record(main)
@@ -653,7 +671,7 @@ class GrainRollout:
             be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
                              self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot], S["rw"][slot])
             S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
-        return [ready, updated, headed]
+        return [ready, lead, updated, headed]
 
     def _enqueue_spec_steps(self, slots):
         """The steps of a block back to back (a step's refresh waits for the previous step's classifier heads -- the last
