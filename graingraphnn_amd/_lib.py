@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 LIB_NAME = "libggnn.so"
 LIB_PATH = os.environ.get("GGNN_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-GGNN_ABI_VERSION = 24
+GGNN_ABI_VERSION = 25
 GGNN_UNIT_EDGES = 3
 GGNN_EINFO_ROW = 20
 GGNN_C = 96
@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
+    "ggnn_lstm_train_forward_batch", "ggnn_lstm_train_backward_batch", "ggnn_train_input_rows",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
@@ -82,7 +83,7 @@ class AggregateArgs(Structure):
         ("ldp_src", c_int64), ("ldp_dst", c_int64), ("ld_agg", c_int64),
         ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
         ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
-        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
+        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("pad_n", c_int32),
     ]
 
 
@@ -164,7 +165,26 @@ class WgradArgs(Structure):
         ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p), ("out", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("a_bstride", c_int64), ("b_bstride", c_int64), ("K", c_int64),
         ("M", c_int32), ("Nc", c_int32), ("batch", c_int32), ("n_split", c_int32),
+        ("b_ins", c_void_p), ("ld_ins", c_int64), ("ins_off", c_int32), ("ins_w", c_int32),
     ]
+
+
+GGNN_LSTM_TRAIN_MAX = 4
+GGNN_TRAIN_ROWS_MAX = 4
+
+
+class LstmTrainProblem(Structure):
+    """Mirror of `ggnn_lstm_train_problem`."""
+    _fields_ = [("z", c_void_p), ("p_dst", c_void_p), ("c_in", c_void_p), ("h_out", c_void_p), ("c_out", c_void_p),
+                ("g_h", c_void_p), ("g_c", c_void_p), ("g_z", c_void_p), ("g_p_dst", c_void_p), ("g_c_in", c_void_p),
+                ("ldp", c_int64), ("N", c_int64), ("s_off", c_int32), ("pad_off", c_int32), ("pad_n", c_int32),
+                ("reserved", c_int32)]
+
+
+class TrainRowsProblem(Structure):
+    """Mirror of `ggnn_train_rows_problem`."""
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("ldx", c_int64), ("ldo", c_int64), ("N", c_int64), ("F", c_int32),
+                ("reserved", c_int32)]
 
 
 class RowGemmArgs(Structure):
@@ -193,13 +213,15 @@ class AdamArgs(Structure):
 
 
 GGNN_PACK_OUTPUTS = 9
+GGNN_PACK_TENSOR_SHIFT = 40
 
 
 class PackArgs(Structure):
     """Mirror of `ggnn_pack_args`."""
     _fields_ = [("flat2", c_void_p), ("kq", c_void_p), ("kq_idx", c_void_p), ("idx3", c_void_p), ("packed", c_void_p),
                 ("n_flat", c_int64), ("zero", c_int64), ("n_packed", c_int64),
-                ("nb", c_int32), ("r", c_int32), ("c", c_int32), ("L", c_int32), ("coef", c_float), ("reserved", c_int32)]
+                ("nb", c_int32), ("r", c_int32), ("c", c_int32), ("L", c_int32), ("coef", c_float), ("reserved", c_int32),
+                ("params", c_void_p)]
 
 
 class PackBwdArgs(Structure):
@@ -207,7 +229,7 @@ class PackBwdArgs(Structure):
     _fields_ = [("fwd", PackArgs), ("g_out", c_void_p * GGNN_PACK_OUTPUTS), ("g_off", c_int64 * (GGNN_PACK_OUTPUTS + 1)),
                 ("g_w", c_int64 * GGNN_PACK_OUTPUTS), ("g_rs", c_int64 * GGNN_PACK_OUTPUTS), ("g_cs", c_int64 * GGNN_PACK_OUTPUTS),
                 ("inv", c_void_p), ("inv_kq", c_void_p), ("g_flat2", c_void_p), ("g_kq", c_void_p), ("g_flat", c_void_p),
-                ("n_flat2", c_int64), ("n_kq", c_int64), ("inv_m", c_int32), ("inv_kq_m", c_int32)]
+                ("n_flat2", c_int64), ("n_kq", c_int64), ("inv_m", c_int32), ("inv_kq_m", c_int32), ("n_tail", c_int64)]
 
 
 class MseArgs(Structure):
@@ -231,7 +253,7 @@ class AggregateBwdArgs(Structure):
         ("ldh_src", c_int64), ("n_src", c_int64), ("n_dst", c_int64), ("E", c_int64),
         ("n_partials", c_int64),
         ("v_off", c_int32), ("u_off", c_int32), ("u4_off", c_int32), ("a_off", c_int32),
-        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("reserved", c_int32),
+        ("a_gstride", c_int32), ("sc_off", c_int32), ("n_gates", c_int32), ("g_h_accumulate", c_int32),
     ]
 
 
@@ -316,6 +338,11 @@ def _declare(lib):
     lib.ggnn_lstm_train_backward.restype = c_int
     lib.ggnn_lstm_train_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]
+    for fn in (lib.ggnn_lstm_train_forward_batch, lib.ggnn_lstm_train_backward_batch):
+        fn.restype = c_int
+        fn.argtypes = [POINTER(LstmTrainProblem), c_int, c_int, c_void_p]
+    lib.ggnn_train_input_rows.restype = c_int
+    lib.ggnn_train_input_rows.argtypes = [POINTER(TrainRowsProblem), c_int, c_void_p]
     lib.ggnn_wgrad_splits.restype = c_int
     lib.ggnn_wgrad_splits.argtypes = [c_int64, c_int, c_int, c_int]
     lib.ggnn_wgrad.restype = c_int

@@ -222,7 +222,7 @@ class HipBackend:
     # -- aggregation -------------------------------------------------------------------
     @staticmethod
     def _sweep_args(a, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
-                    a_gstride, sc_off, n_gates):
+                    a_gstride, sc_off, n_gates, pad_n=0):
         _require_cuda(csr.unit_ptr, einfo, p_src, p_dst, h_src, ep, agg)
         a.unit_ptr, a.units, a.einfo = csr.unit_ptr.data_ptr(), csr.units.data_ptr(), einfo.data_ptr()
         a.p_src, a.p_dst = p_src.data_ptr(), p_dst.data_ptr()
@@ -233,11 +233,13 @@ class HipBackend:
         a.n_src, a.n_dst, a.E = p_src.size(0), p_dst.size(0), csr.E
         a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
+        a.pad_n = pad_n
 
     def aggregate(self, *sweep):
         """One sweep of ggnn_period_gat_aggregate (include/ggnn.h): (csr, einfo, p_src, p_dst, h_src,
-        ep, agg, v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates).  h_src: the source node
-        type's hidden state [n_src, 96] or None (encoder)."""
+        ep, agg, v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates[, pad_n]).  h_src: the source node
+        type's hidden state [n_src, 96] or None (encoder); pad_n: columns behind the sweep's scalars that it zeroes in
+        every gate row (the training path's padded gate rows)."""
         a = AggregateArgs()
         self._sweep_args(a, *sweep)
         check(self.lib.ggnn_period_gat_aggregate(ctypes.byref(a), _lib.current_stream()),
@@ -386,13 +388,15 @@ class HipBackend:
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
                            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None,
-                           ep_partial_out=None):
+                           ep_partial_out=None, g_h_into=None):
         """ggnn_period_gat_aggregate_backward (include/ggnn.h).  `rcsr`: CSR of the flipped
         edge_index (grouped by source), `r_slot` [E] int32: forward CSR slot of every reverse slot.
         Returns (g_p_dst, g_p_src, g_h_src or None, g_ep [n_gates, 3, 96]); the gradient tensors
         have the layout of their operands, columns the sweep does not read are zero.
         `ep_partial_out` [>= aggregate_bwd_partials(n_dst), n_gates, 3, 96]: the per-workgroup partial sums of g_ep go
-        there and g_ep is returned as None -- the caller sums them (one reduction for the sweeps of a cell)."""
+        there and g_ep is returned as None -- the caller sums them (one reduction for the sweeps of a cell).
+        `g_h_into` [n_src, 96]: an earlier sweep's g_h_src of the same source node type -- this sweep ADDS its own to it in
+        place (g_h_accumulate) and returns it."""
         _require_cuda(csr.rowptr, rcsr.rowptr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg)
         dev = p_src.device
         E, G = csr.E, n_gates
@@ -421,12 +425,18 @@ class HipBackend:
         if g_p_dst.shape != p_dst.shape or g_p_src.shape != p_src.shape or g_p_dst.stride(0) != p_dst.stride(0) \
                 or g_p_src.stride(0) != p_src.stride(0):
             raise _lib.GGNNError("gradient buffers must have the layout of their operands")
-        g_h_src = None if h_src is None else torch.empty_like(h_src)
+        if g_h_into is not None and (h_src is None or g_h_into.shape != h_src.shape or not g_h_into.is_contiguous()
+                                     or g_h_into.dtype != torch.float32):
+            raise _lib.GGNNError("g_h_into must be a contiguous float32 tensor of h_src's shape")
+        g_h_src = None if h_src is None else (g_h_into if g_h_into is not None else torch.empty(h_src.shape, **f32))
+        a.g_h_accumulate = 1 if g_h_into is not None else 0
         a.edge_alpha, a.edge_ds, a.ep_partial = scratch[0].data_ptr(), scratch[1].data_ptr(), ep_partial.data_ptr()
         a.g_p_dst, a.g_p_src = g_p_dst.data_ptr(), g_p_src.data_ptr()
         a.g_h_src = None if g_h_src is None else g_h_src.data_ptr()
         a.ldp_src, a.ldp_dst, a.ld_agg = p_src.stride(0), p_dst.stride(0), agg.stride(0)
         a.ldh_src = 0 if h_src is None else h_src.stride(0)
+        if g_h_src is not None and h_src.stride(0) != g_h_src.stride(0):
+            raise _lib.GGNNError("aggregate_backward: h_src rows must be contiguous (g_h_src has its layout)")
         a.n_src, a.n_dst, a.E, a.n_partials = p_src.size(0), p_dst.size(0), E, n_part
         a.v_off, a.u_off, a.u4_off, a.a_off, a.a_gstride, a.sc_off, a.n_gates = (
             v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates)
@@ -497,11 +507,63 @@ class HipBackend:
                      ptr(g_h), ptr(g_c), ptr(g_z), ptr(g_p_dst), 0 if g_p_dst is None else g_p_dst.stride(0), s_off,
                      ptr(g_c_in), N, G, _lib.current_stream())
 
-    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0):
+    def lstm_train_forward_batch(self, problems, n_gates):
+        """ggnn_lstm_train_forward_batch: [(z [G, N, 96], p_dst, s_off, c_in or None, h_out, c_out)] -- the node types of a
+        cell in one launch."""
+        arr = (_lib.LstmTrainProblem * len(problems))()
+        for a, (z, p_dst, s_off, c_in, h_out, c_out) in zip(arr, problems):
+            _require_cuda(z, p_dst, c_in, h_out, c_out)
+            if not z.is_contiguous() or z.dim() != 3 or z.size(0) != n_gates or z.size(2) != _lib.GGNN_C \
+                    or not (h_out.is_contiguous() and c_out.is_contiguous()) or (c_in is not None and not c_in.is_contiguous()):
+                raise _lib.GGNNError("z [G, N, 96], c_in, h_out, c_out [N, 96] must be contiguous")
+            a.z, a.p_dst, a.c_in, a.h_out, a.c_out = ptr(z), ptr(p_dst), ptr(c_in), ptr(h_out), ptr(c_out)
+            a.ldp, a.N, a.s_off = p_dst.stride(0), z.size(1), s_off
+        self._launch(self.lib.ggnn_lstm_train_forward_batch, "ggnn_lstm_train_forward_batch", arr, len(problems), n_gates,
+                     _lib.current_stream())
+
+    def lstm_train_backward_batch(self, problems, n_gates):
+        """ggnn_lstm_train_backward_batch: [(z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in, pad_off, pad_n)]; the
+        call also zeroes g_p_dst[:, pad_off : pad_off + pad_n] (pad_n <= 96, multiples of 4)."""
+        arr = (_lib.LstmTrainProblem * len(problems))()
+        for a, (z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in, pad_off, pad_n) in zip(arr, problems):
+            _require_cuda(z, c_in, c_out, g_h, g_c, g_z, g_p_dst, g_c_in)
+            for t in (z, c_in, c_out, g_h, g_c, g_z, g_c_in):
+                if t is not None and not t.is_contiguous():
+                    raise _lib.GGNNError("lstm_train_backward: z, g_z [G, N, 96] and the [N, 96] operands must be contiguous")
+            if g_z.shape != z.shape or z.dim() != 3 or z.size(0) != n_gates:
+                raise _lib.GGNNError("g_z must have the shape of z [G, N, 96]")
+            a.z, a.c_in, a.c_out, a.g_h, a.g_c = ptr(z), ptr(c_in), ptr(c_out), ptr(g_h), ptr(g_c)
+            a.g_z, a.g_p_dst, a.g_c_in = ptr(g_z), ptr(g_p_dst), ptr(g_c_in)
+            a.ldp, a.N, a.s_off = 0 if g_p_dst is None else g_p_dst.stride(0), z.size(1), s_off
+            a.pad_off, a.pad_n = pad_off, pad_n
+        self._launch(self.lib.ggnn_lstm_train_backward_batch, "ggnn_lstm_train_backward_batch", arr, len(problems), n_gates,
+                     _lib.current_stream())
+
+    def train_input_rows(self, problems):
+        """ggnn_train_input_rows: [(x [N, >= F], F)] -> [out [N, roundup4(F) + 4] = [x[:, :F] | 0 .. | 1 0 0 0]] in one launch."""
+        arr = (_lib.TrainRowsProblem * len(problems))()
+        outs = []
+        for a, (x, F) in zip(arr, problems):
+            _require_cuda(x)
+            if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1 or x.size(1) < F:
+                raise _lib.GGNNError("ggnn_train_input_rows: x must be float32 [N, >= F] with unit column stride")
+            out = torch.empty(x.size(0), ((F + 3) & ~3) + 4, dtype=torch.float32, device=x.device)
+            outs.append(out)
+            a.x, a.out, a.ldx, a.ldo, a.N, a.F = ptr(x), ptr(out), x.stride(0), out.stride(0), x.size(0), F
+        self._launch(self.lib.ggnn_train_input_rows, "ggnn_train_input_rows", arr, len(problems), _lib.current_stream())
+        return outs
+
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0):
         """ggnn_wgrad: C[batch, M, Nc] = A_k^T B_k; A_k = K rows of M floats, row pitch lda, from element
-        k * a_bstride of the contiguous tensor `a` on (B_k likewise).  Returns the sum over the splits."""
-        _require_cuda(a, b)
-        for t, ld, bs, w in ((a, lda, a_bstride, M), (b, ldb, b_bstride, Nc)):
+        k * a_bstride of the contiguous tensor `a` on (B_k likewise).  Returns the sum over the splits.
+        `b_ins` [K, w] (contiguous): B is `b` with these w columns inserted at column ins_off (Nc counts them)."""
+        _require_cuda(a, b, b_ins)
+        ins_w = 0
+        if b_ins is not None:
+            if b_ins.dtype != torch.float32 or b_ins.dim() != 2 or not b_ins.is_contiguous() or b_ins.size(0) < K or batch != 1:
+                raise _lib.GGNNError("wgrad: b_ins must be a contiguous float32 [K, w] matrix (batch 1)")
+            ins_w = b_ins.size(1)
+        for t, ld, bs, w in ((a, lda, a_bstride, M), (b, ldb, b_bstride, Nc - ins_w)):
             if t.dtype != torch.float32 or not t.is_contiguous() or ld < w \
                     or (batch - 1) * bs + (K - 1) * ld + w > t.numel():
                 raise _lib.GGNNError("wgrad: operands must be contiguous float32 tensors that hold every addressed row")
@@ -512,6 +574,8 @@ class HipBackend:
         w.a, w.b, w.partial, w.out = a.data_ptr(), b.data_ptr(), partial.data_ptr(), ptr(out)
         w.lda, w.ldb, w.a_bstride, w.b_bstride, w.K = lda, ldb, a_bstride, b_bstride, K
         w.M, w.Nc, w.batch, w.n_split = M, Nc, batch, S
+        if b_ins is not None:
+            w.b_ins, w.ld_ins, w.ins_off, w.ins_w = b_ins.data_ptr(), b_ins.stride(0), ins_off, ins_w
         self._launch(self.lib.ggnn_wgrad, "ggnn_wgrad", ctypes.byref(w), _lib.current_stream())
         return out if S > 1 else partial[0]
 
@@ -554,6 +618,7 @@ class HipBackend:
         `c_in`: optional, same layout as out (may be out itself);
         `planes`: the weight planes of exactly this (w, K, n_out, batch, transposed, bf16) from `rowgemm_pack`."""
         _require_cuda(a, w, out, c_in)
+        given = out   # (returned as given: a [M, n] result must not come back as [1, M, n] -- autograd would sum_to_size it)
         if a.dim() == 2:
             a = a.unsqueeze(0)
         if out.dim() == 2:
@@ -586,7 +651,7 @@ class HipBackend:
         g.M, g.lda, g.ldc = M, a.stride(1), out.stride(1)
         g.a_bstride, g.c_bstride = a.stride(0) if batch > 1 else 0, out.stride(0) if batch > 1 else 0
         self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
-        return out
+        return given
 
     def sum_rows(self, t):
         """ggnn_sum_rows: [batch, rows, cols] contiguous float32 -> [batch, cols], the sum over the rows in a fixed order."""
@@ -603,32 +668,40 @@ class HipBackend:
         self._launch(self.lib.ggnn_adam_step, "ggnn_adam_step", ctypes.byref(args), _lib.current_stream())
 
     @staticmethod
-    def _pack_args(plan, flat2, kq, packed=None):
+    def _pack_args(plan, flat2, kq, packed=None, params=None):
         a = _lib.PackArgs()
-        a.flat2, a.kq, a.kq_idx, a.idx3 = flat2.data_ptr(), kq.data_ptr(), plan.kq_idx.data_ptr(), plan.idx3.data_ptr()
+        if params is None:
+            a.flat2, a.kq, a.kq_idx, a.idx3 = flat2.data_ptr(), kq.data_ptr(), plan.kq_idx.data_ptr(), plan.idx3.data_ptr()
+        else:   # the parameters read where they lie: encoded index tables + the DEVICE table of their addresses
+            if params.dtype != torch.int64 or params.numel() != len(plan.sizes) or not params.is_cuda:
+                raise _lib.GGNNError("ggnn_pack_weights: params must be a device int64 table with one address per parameter tensor")
+            a.flat2, a.kq, a.kq_idx, a.idx3 = flat2.data_ptr(), kq.data_ptr(), plan.kq_idx_enc.data_ptr(), plan.idx3_enc.data_ptr()
+            a.params = params.data_ptr()
         a.packed = 0 if packed is None else packed.data_ptr()
         a.n_flat, a.zero, a.n_packed = plan.n_flat, plan.zero, plan.n_packed
         a.nb, a.r, a.c, a.L = plan.mr_shape[0], plan.mr_shape[1], plan.mr_shape[2], plan.idx3.size(1)
         a.coef = plan.k_coef
         return a
 
-    def pack_weights(self, plan, flat2, kq, packed):
-        """ggnn_pack_weights: `flat2` [plan.n_flat2] holds the parameters in its first n_flat entries; fills the operands
-        `kq` [plan.n_kq], the products and `packed` [plan.n_packed] (train_pack._PackWeights)."""
+    def pack_weights(self, plan, flat2, kq, packed, params=None):
+        """ggnn_pack_weights: `flat2` [plan.n_flat2] holds the parameters in its first n_flat entries -- or, with `params` (a
+        device int64 table of the parameter tensors' addresses), they are read where they lie and that part of flat2 is not
+        touched; fills the operands `kq` [plan.n_kq], the products and `packed` [plan.n_packed] (train_pack._PackWeights)."""
         _require_cuda(flat2, kq, packed)
         if flat2.dtype != torch.float32 or packed.dtype != torch.float32 or kq.dtype != torch.float32 \
                 or flat2.numel() != plan.n_flat2 or kq.numel() != plan.n_kq or packed.numel() != plan.n_packed \
                 or not flat2.is_contiguous() or not packed.is_contiguous() or not kq.is_contiguous():
             raise _lib.GGNNError("ggnn_pack_weights: flat2 [n_flat2], kq [n_kq] and packed [n_packed] must be contiguous float32")
-        a = self._pack_args(plan, flat2, kq, packed)
+        a = self._pack_args(plan, flat2, kq, packed, params)
         self._launch(self.lib.ggnn_pack_weights, "ggnn_pack_weights", ctypes.byref(a), _lib.current_stream())
 
     def pack_weights_backward(self, plan, flat2, kq, grads, g_flat2, g_kq, g_flat):
         """ggnn_pack_weights_backward: `grads` = the gradients of the nine packed outputs (None: zero), contiguous float32 of
-        plan.out_sizes; workspaces g_flat2 [n_flat2], g_kq [n_kq]; g_flat [n_flat] receives the parameters' gradient."""
+        plan.out_sizes; workspaces g_flat2 [n_flat2], g_kq [n_kq]; g_flat [>= n_flat] receives the parameters' gradient in its
+        first n_flat entries and zeros behind them (n_tail: the parameters without effect)."""
         _require_cuda(flat2, g_flat2, g_kq, g_flat, *[g for g in grads if g is not None])
         if len(grads) != _lib.GGNN_PACK_OUTPUTS or g_flat2.numel() != plan.n_flat2 or g_kq.numel() != plan.n_kq \
-                or g_flat.numel() != plan.n_flat:
+                or g_flat.numel() < plan.n_flat or not g_flat.is_contiguous():
             raise _lib.GGNNError("ggnn_pack_weights_backward: nine output gradients and workspaces of the plan's sizes")
         b = _lib.PackBwdArgs()
         b.fwd = self._pack_args(plan, flat2, kq)
@@ -652,6 +725,7 @@ class HipBackend:
         b.inv, b.inv_kq = plan.inv.data_ptr(), plan.inv_kq.data_ptr()
         b.g_flat2, b.g_kq, b.g_flat = g_flat2.data_ptr(), g_kq.data_ptr(), g_flat.data_ptr()
         b.n_flat2, b.n_kq, b.inv_m, b.inv_kq_m = plan.n_flat2, plan.n_kq, plan.inv.size(1), plan.inv_kq.size(1)
+        b.n_tail = g_flat.numel() - plan.n_flat
         self._launch(self.lib.ggnn_pack_weights_backward, "ggnn_pack_weights_backward", ctypes.byref(b), _lib.current_stream())
 
     def masked_mse(self, terms, scale, loss, want_grad=True):

@@ -345,6 +345,9 @@ void aggregate_kernel(const AggregateBatch B) {
         orow[A.sc_off] = den * inv;
         orow[A.sc_off + 1] = sae * inv;
       }
+      // (training path: the gate row's padding behind this sweep's scalars -- it meets zero weight columns of the gate GEMM and
+      // must be finite -- is zeroed here instead of by a fill launch of the caller)
+      for (int k = l16; k < A.pad_n; k += 16) orow[A.sc_off + 2 + k] = 0.f;
     }
     if (!more) break;
     u = un;
@@ -444,7 +447,7 @@ static int check_sweep(ggnn_aggregate_args& A) {
   if (A.v_off + (int64_t)G * C > A.ldp_src || A.u4_off + (int64_t)G * 16 > A.ldp_dst) return GGNN_EINVAL;
   if (has_h && A.u_off + (int64_t)G * C > A.ldp_dst) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
-  if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
+  if (A.pad_n < 0 || (int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 + A.pad_n > A.ld_agg) return GGNN_EINVAL;
   return GGNN_OK;
 }
 }  // namespace ggnn

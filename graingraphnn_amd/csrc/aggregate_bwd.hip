@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggre
     const int beg = A.r_rowptr[j], end = A.r_rowptr[j + 1];
     float v[6], dv[6] = {}, dh[6] = {};
     ld6(A.p_src + j * A.ldp_src + A.v_off + L.gc * C + L.ch, v);
+    // g_h_accumulate: the cell's earlier sweep from this source node type wrote the row -- add to it (requested here, used
+    // behind the row's edges)
+    float prev[6] = {};
+    if (HAS_H && A.g_h_accumulate) ld6(A.g_h_src + j * A.ldh_src + L.ch, prev);
     for (int q0 = beg; q0 < end; q0 += U) {
       int64_t pp[U], ii[U];
 #pragma unroll
@@ -264,6 +268,8 @@ __global__ __launch_bounds__(256) void aggregate_bwd_src_kernel(const ggnn_aggre
         dh[c] += __shfl_xor(dh[c], 16, 64);
         dh[c] += __shfl_xor(dh[c], 32, 64);
       }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dh[c] += prev[c];   // (outside the branch below: the load stays at the top of the row)
       if (L.g == 0) st6(A.g_h_src + j * A.ldh_src + L.ch, dh);
     }
   }
@@ -303,6 +309,7 @@ extern "C" int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args*
   if ((int64_t)(G - 1) * A.a_gstride + A.a_off + C > A.ld_agg) return GGNN_EINVAL;
   if ((int64_t)(G - 1) * A.a_gstride + A.sc_off + 2 > A.ld_agg) return GGNN_EINVAL;
   if (A.n_partials != ggnn_aggregate_bwd_partials(A.n_dst)) return GGNN_EINVAL;
+  if (A.g_h_accumulate != 0 && A.g_h_accumulate != 1) return GGNN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid_d((unsigned)A.n_partials);
   const int64_t want_s = (A.n_src + AB_WAVES - 1) / AB_WAVES;

@@ -14,9 +14,20 @@ constexpr int PK_THREADS = 128;
 
 // flat2[j], the zero slot reading 0 -- as an unconditional (clamped) load and a select: a load under a branch makes every
 // gathered element its own dependent round trip, which is what the first version of these kernels spent its time in
-__device__ __forceinline__ float pk_read(const float* __restrict__ v, int64_t j, int64_t zero) {
-  const float x = v[j == zero ? 0 : j];
-  return j == zero ? 0.f : x;
+// With A.params (ABI 25) an entry that addresses a parameter carries (tensor + 1) in its high bits and the offset inside that
+// tensor below them, and is read where the tensor lies (no concatenated copy of the parameters in flat2[0 .. n_flat)): one more
+// dependent load, of the tensor's address out of a table of a few hundred entries.  Entries of the product region and the
+// zero slot are plain flat2 indices either way.
+__device__ __forceinline__ float pk_read(const ggnn_pack_args& A, int64_t e) {
+  const int64_t t = e >> GGNN_PACK_TENSOR_SHIFT, lo = e & (((int64_t)1 << GGNN_PACK_TENSOR_SHIFT) - 1);
+  const bool is_zero = e == A.zero;
+  const float* base = A.flat2;
+  if (A.params) {                                              // (uniform branch on a kernel argument)
+    const float* pt = A.params[t ? t - 1 : 0];                 // (unconditional, clamped: no load under a per-lane branch)
+    base = t ? pt : A.flat2;
+  }
+  const float x = base[is_zero ? A.n_flat : lo];               // (flat2[n_flat]: the first product entry, always there)
+  return is_zero ? 0.f : x;
 }
 // flat2[n_flat + (b r + row) c + col] = sum_k coef flat2[kq_idx[(b r + row) 96 + k]] * flat2[kq_idx[n_k + (b 96 + k) c + col]]
 // One workgroup per (product b, slab of PK_ROWS rows): Q_b [96, c] is gathered into LDS once (40 KB) and serves the slab's rows;
@@ -27,7 +38,7 @@ constexpr int PK_ROWS = 4;   // rows of a product per workgroup: 12 x 27 workgro
 __global__ __launch_bounds__(256) void pack_operands_kernel(const ggnn_pack_args A) {
   const int64_t n_k = (int64_t)A.nb * A.r * GGNN_C, n_kq = n_k + (int64_t)A.nb * GGNN_C * A.c;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n_kq) A.kq[i] = pk_read(A.flat2, A.kq_idx[i], A.zero) * (i < n_k ? A.coef : 1.0f);
+  if (i < n_kq) A.kq[i] = pk_read(A, A.kq_idx[i]) * (i < n_k ? A.coef : 1.0f);
 }
 __global__ __launch_bounds__(PK_THREADS) void pack_products_kernel(const ggnn_pack_args A) {
   extern __shared__ float lds[];
@@ -58,8 +69,8 @@ __global__ __launch_bounds__(PK_THREADS) void pack_products_kernel(const ggnn_pa
 __global__ __launch_bounds__(256) void pack_gather_kernel(const ggnn_pack_args A) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= A.n_packed) return;
-  float s = pk_read(A.flat2, A.idx3[i * A.L], A.zero);
-  for (int t = 1; t < A.L; ++t) s += pk_read(A.flat2, A.idx3[i * A.L + t], A.zero);
+  float s = pk_read(A, A.idx3[i * A.L]);
+  for (int t = 1; t < A.L; ++t) s += pk_read(A, A.idx3[i * A.L + t]);
   A.packed[i] = s;
 }
 
@@ -136,7 +147,10 @@ __global__ __launch_bounds__(PK_THREADS) void pack_bwd_q_kernel(const ggnn_pack_
 // g_flat[p] = g_flat2[p] + sum_m g_kq[inv_kq[p M + m]]
 __global__ __launch_bounds__(256) void pack_bwd_params_kernel(const ggnn_pack_bwd_args A) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= A.fwd.n_flat) return;
+  if (p >= A.fwd.n_flat) {
+    if (p < A.fwd.n_flat + A.n_tail) A.g_flat[p] = 0.f;   // parameters read without effect (the encoder's forget gate)
+    return;
+  }
   float s = 0.f;
   for (int m = 0; m < A.inv_kq_m; ++m) {
     const int64_t i = A.inv_kq[p * A.inv_kq_m + m];
@@ -173,7 +187,7 @@ extern "C" int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_s
   const ggnn_pack_args& F = A.fwd;
   if (!A.inv || !A.inv_kq || !A.g_flat2 || !A.g_kq || !A.g_flat || A.inv_m < 1 || A.inv_m > 16 || A.inv_kq_m < 1 || A.inv_kq_m > 16)
     return GGNN_EINVAL;
-  if (A.n_flat2 != F.zero + 1 || A.n_kq != (int64_t)F.nb * GGNN_C * (F.r + F.c) || A.g_off[0] != 0 || A.g_off[GGNN_PACK_OUTPUTS] != F.n_packed)
+  if (A.n_tail < 0 || A.n_flat2 != F.zero + 1 || A.n_kq != (int64_t)F.nb * GGNN_C * (F.r + F.c) || A.g_off[0] != 0 || A.g_off[GGNN_PACK_OUTPUTS] != F.n_packed)
     return GGNN_EINVAL;
   for (int s = 0; s < GGNN_PACK_OUTPUTS; ++s)
     if (A.g_off[s + 1] < A.g_off[s] || (A.g_out[s] != nullptr && A.g_w[s] < 1)) return GGNN_EINVAL;
@@ -184,6 +198,6 @@ extern "C" int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_s
   static_assert(GGNN_C % PK_ROWS == 0, "slabs of k");
   hipLaunchKernelGGL(pack_bwd_q_kernel, dim3((unsigned)F.nb, (unsigned)(GGNN_C / PK_ROWS)), dim3(PK_THREADS),
                      (size_t)F.r * PK_ROWS * sizeof(float), st, A);
-  hipLaunchKernelGGL(pack_bwd_params_kernel, dim3((unsigned)((F.n_flat + 255) / 256)), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(pack_bwd_params_kernel, dim3((unsigned)((F.n_flat + A.n_tail + 255) / 256)), dim3(256), 0, st, A);
   return launch_status();
 }

@@ -177,3 +177,54 @@ extern "C" int ggnn_masked_mse(const ggnn_mse_args* args, ggnn_stream_t stream) 
   hipLaunchKernelGGL(masked_mse_kernel, dim3(GGNN_MSE_BLOCKS), dim3(MSE_THREADS), 0, (hipStream_t)stream, *args);
   return launch_status();
 }
+
+// ---- ggnn_train_input_rows: [x | 0 .. | 1 0 0 0], the data part of the weight gradients' B operands (include/ggnn.h) ----
+namespace ggnn {
+struct TrainRowsBatch {
+  ggnn_train_rows_problem p[GGNN_TRAIN_ROWS_MAX];
+  int blk_off[GGNN_TRAIN_ROWS_MAX + 1];
+  int n;
+};
+// a thread per output float4 (Fp / 4 + 1 <= 4 of them per row)
+__global__ __launch_bounds__(256) void train_input_rows_kernel(const TrainRowsBatch B) {
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.blk_off[k + 1]) ++k;
+  const ggnn_train_rows_problem& P = B.p[k];
+  const int Fp = (P.F + 3) & ~3, Q = Fp / 4 + 1;
+  const int64_t t = (int64_t)((int)blockIdx.x - B.blk_off[k]) * 256 + threadIdx.x;
+  if (t >= P.N * Q) return;
+  const int64_t n = t / Q;
+  const int c0 = (int)(t - n * Q) * 4;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const float xv = P.x[n * P.ldx + min(c, P.F - 1)];
+    v[j] = c < P.F ? xv : (c == Fp ? 1.0f : 0.0f);
+  }
+  *reinterpret_cast<f32x4*>(P.out + n * P.ldo + c0) = f32x4{v[0], v[1], v[2], v[3]};
+}
+}  // namespace ggnn
+
+extern "C" int ggnn_train_input_rows(const ggnn_train_rows_problem* problems, int n_problems, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!problems || n_problems < 1 || n_problems > GGNN_TRAIN_ROWS_MAX) return GGNN_EINVAL;
+  TrainRowsBatch B;
+  B.n = 0;
+  B.blk_off[0] = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    const ggnn_train_rows_problem& P = problems[k];
+    if (P.N < 0) return GGNN_EINVAL;
+    if (P.N == 0) continue;
+    const int Fp = (P.F + 3) & ~3;
+    if (!P.x || !P.out || P.F < 3 || P.F > 12 || P.ldx < P.F || P.ldo < Fp + 4 || (P.ldo & 3) || !aligned16(P.out)) return GGNN_EINVAL;
+    const int64_t blocks = (P.N * (Fp / 4 + 1) + 255) / 256;
+    if (B.blk_off[B.n] + blocks >= 0x7fffffff) return GGNN_EINVAL;
+    B.p[B.n] = P;
+    B.blk_off[B.n + 1] = B.blk_off[B.n] + (int)blocks;
+    ++B.n;
+  }
+  if (B.n == 0) return 0;
+  hipLaunchKernelGGL(train_input_rows_kernel, dim3((unsigned)B.blk_off[B.n]), dim3(256), 0, (hipStream_t)stream, B);
+  return launch_status();
+}

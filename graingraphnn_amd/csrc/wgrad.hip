@@ -59,7 +59,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const ggnn_wgrad_args W, 
   const int ca = min(m0 + TA * li, W.M - TA);
   const int cb4 = min(n0 + 4 * li, W.Nc - 4), cb2 = min(n0 + 64 + 2 * li, W.Nc - 2), cb1 = min(n0 + 96 + li, W.Nc - 1);
   const float* A = W.a + (int64_t)b * W.a_bstride + (int64_t)lq * W.lda + ca;
-  const float* B = W.b + (int64_t)b * W.b_bstride + (int64_t)lq * W.ldb;
+  // this lane's three column pieces of B; with an inserted operand (b_ins, ABI 25: boundaries are multiples of 4, so a piece
+  // lies in one of the two matrices) each piece has its own base and row pitch
+  const float *B4, *B2, *B1;
+  int64_t ld4, ld2, ld1;
+  auto piece = [&](int c, const float*& p, int64_t& ld) {
+    const bool in = W.b_ins != nullptr && c >= W.ins_off && c < W.ins_off + W.ins_w;
+    const int cc = in ? c - W.ins_off : (W.b_ins != nullptr && c >= W.ins_off + W.ins_w ? c - W.ins_w : c);
+    ld = in ? W.ld_ins : W.ldb;
+    p = (in ? W.b_ins : W.b + (int64_t)b * W.b_bstride) + (int64_t)lq * ld + cc;
+  };
+  piece(cb4, B4, ld4);
+  piece(cb2, B2, ld2);
+  piece(cb1, B1, ld1);
 
   f32x4 acc[TA][WG_TB];
 #pragma unroll
@@ -77,14 +89,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const ggnn_wgrad_args W, 
   float rb1[WG_U];
   auto load = [&](int j, int64_t k) {  // the 4 rows from k (all below k_end): 4 loads
     const float* pa = A + k * W.lda;
-    const float* pb = B + k * W.ldb;
     if constexpr (TA == 4)
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(pa));
     else
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ra[j]) : "v"(pa));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4[j]) : "v"(pb + cb4));
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rb2[j]) : "v"(pb + cb2));
-    asm volatile("global_load_dword %0, %1, off" : "=v"(rb1[j]) : "v"(pb + cb1));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4[j]) : "v"(B4 + k * ld4));
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rb2[j]) : "v"(B2 + k * ld2));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(rb1[j]) : "v"(B1 + k * ld1));
   };
   auto compute = [&](int j) {
 #pragma unroll
@@ -204,8 +215,18 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6s_kernel(const ggnn_wgrad_args
   const float* A = W.a + (int64_t)b * W.a_bstride + ca;
   // B duty: rows 8 wave + j of a group, columns n0 + lane and n0 + 64 + lane (clamped: columns beyond Nc feed result
   // columns that are never stored)
-  const float* Bq = W.b + (int64_t)b * W.b_bstride;
   const int c0 = min(n0 + lane, W.Nc - 1), c1 = min(n0 + 64 + lane, W.Nc - 1);
+  // (with an inserted operand, b_ins: a column comes from one of two matrices)
+  const float *Bq0, *Bq1;
+  int64_t ldq0, ldq1;
+  auto column = [&](int c, const float*& p, int64_t& ld) {
+    const bool in = W.b_ins != nullptr && c >= W.ins_off && c < W.ins_off + W.ins_w;
+    const int cc = in ? c - W.ins_off : (W.b_ins != nullptr && c >= W.ins_off + W.ins_w ? c - W.ins_w : c);
+    ld = in ? W.ld_ins : W.ldb;
+    p = (in ? W.b_ins : W.b + (int64_t)b * W.b_bstride) + cc;
+  };
+  column(c0, Bq0, ldq0);
+  column(c1, Bq1, ldq1);
   // where this lane's two columns go: tile = column / 16, fragment lane = 16 wave + column % 16
   const int frag0 = ((lane >> 4) * 3 * 64 + 16 * wave + li) * 16, frag1 = frag0 + 4 * 3 * 64 * 16;
   const bool has_c1 = lane < WG_NB - 64;
@@ -234,8 +255,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6s_kernel(const ggnn_wgrad_args
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int64_t rb = min(k + 8 * wave + j, k_end - 1);
-      r.b0[j] = Bq[rb * W.ldb + c0];
-      r.b1[j] = Bq[rb * W.ldb + c1];
+      r.b0[j] = Bq0[rb * ldq0];
+      r.b1[j] = Bq1[rb * ldq1];
     }
     if (active) {
 #pragma unroll
@@ -378,7 +399,15 @@ extern "C" int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream) {
   if (!args) return GGNN_EINVAL;
   ggnn_wgrad_args W = *args;
   if (!W.a || !W.b || !W.partial || W.K <= 0 || W.M <= 0 || W.Nc <= 0 || W.batch <= 0) return GGNN_EINVAL;
-  if ((W.M & 3) || (W.Nc & 3) || W.lda < W.M || W.ldb < W.Nc) return GGNN_EINVAL;
+  if (W.b_ins) {   // B = b with the columns of b_ins inserted (include/ggnn.h)
+    if (W.batch != 1 || W.ins_off < 0 || W.ins_w <= 0 || (W.ins_off & 3) || (W.ins_w & 3) || (W.ld_ins & 3) || W.ld_ins < W.ins_w ||
+        W.ins_off + W.ins_w > W.Nc || !aligned16(W.b_ins))
+      return GGNN_EINVAL;
+  } else {
+    W.ins_off = W.ins_w = 0;
+    W.ld_ins = 0;
+  }
+  if ((W.M & 3) || (W.Nc & 3) || W.lda < W.M || W.ldb < W.Nc - W.ins_w) return GGNN_EINVAL;
   if ((W.lda & 3) || (W.ldb & 3) || (W.a_bstride & 3) || (W.b_bstride & 3) || !aligned16(W.a) || !aligned16(W.b))
     return GGNN_EINVAL;  // dwordx4 row pieces
   const WgradPlan p = wgrad_plan(W.K, W.M, W.Nc, W.batch);

@@ -94,10 +94,11 @@ def _check_x(x: torch.Tensor, F: int, name: str):
         raise _lib.GGNNError(f"x_dict['{name}'] must be float32 [N, {F}] with unit column stride")
 
 
-def alloc_einfo(graph: GraphCSR, device):
-    """[E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] per edge type: the tail rows pad the last unit's reads."""
-    return {et: torch.zeros(graph.n_edges(et) + _lib.GGNN_UNIT_EDGES, _lib.GGNN_EINFO_ROW, dtype=torch.float32,
-                            device=device)
+def alloc_einfo(graph: GraphCSR, device, zero: bool = True):
+    """[E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] per edge type: the tail rows pad the last unit's reads.  zero=False: for a
+    buffer that goes through ggnn_edge_prepare before anything reads it (that call writes the tail rows as zeros)."""
+    make = torch.zeros if zero else torch.empty
+    return {et: make(graph.n_edges(et) + _lib.GGNN_UNIT_EDGES, _lib.GGNN_EINFO_ROW, dtype=torch.float32, device=device)
             for et in EDGE_TYPES}
 
 

@@ -20,7 +20,7 @@ from typing import Dict
 
 import torch
 
-from . import _pins
+from . import _lib, _pins
 from torch.autograd.function import once_differentiable
 
 from .packing import C, EDGE_TYPES, NODE_TYPES, et_key, node_layout
@@ -244,8 +244,35 @@ class PackPlan:
         inv = _inverse(idx3, self.n_flat2, Z, self.n_packed)
         inv_kq = _inverse(kq_idx.view(-1, 1), n_flat, Z, self.n_kq)
         to = lambda t: t.to(device)
+        # the same two tables for the device side reading every parameter where it lies (ggnn_pack_args.params): an entry
+        # below n_flat becomes ((tensor + 1) << 40) | offset inside the tensor
+        starts = torch.cumsum(torch.tensor([0] + self.sizes), 0)
+
+        def encoded(idx):
+            t = torch.searchsorted(starts, idx.clamp(max=n_flat - 1), right=True) - 1
+            return torch.where(idx < n_flat, ((t + 1) << _lib.GGNN_PACK_TENSOR_SHIFT) | (idx - starts[t]), idx)
+        self.idx3_enc, self.kq_idx_enc = to(encoded(idx3)), to(encoded(kq_idx))
+        self._ptables = {}
         self.idx3, self.kq_idx, self.kq_coef = to(idx3), to(kq_idx), to(kq_coef)
         self.inv, self.inv_kq = to(inv), to(inv_kq)
+
+
+def _param_table(plan, params):
+    """DEVICE int64 array of the parameter tensors' addresses (ggnn_pack_args.params), made when the set of addresses is
+    new (model.to(...), a fresh model on the same plan) -- an upload, so not inside a hipGraph capture: the eager warm-up
+    steps before a capture have made it."""
+    key = tuple(p.data_ptr() for p in params)
+    t = plan._ptables.get(key)
+    if t is None:
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.GGNNError("training path: parameters must be contiguous float32 tensors")
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GGNNError("training path: a parameter's storage moved between the warm-up steps and the hipGraph capture")
+        if len(plan._ptables) >= 8:
+            plan._ptables.pop(next(iter(plan._ptables)))
+        t = plan._ptables[key] = torch.tensor(key, dtype=torch.int64).to(params[0].device)
+    return _pins.note(t)
 
 
 def _inverse(idx, n_src, skip, n_dst):
@@ -285,23 +312,24 @@ class _PackWeights(torch.autograd.Function):
     def forward(ctx, plan, n_used, *params):
         dev = params[0].device
         flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
-        torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
         ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
         ctx.set_materialize_grads(False)
         if dev.type == "cuda":
-            # the device side in two launches (csrc/pack.hip): the products straight from the parameters through the
-            # operands' index tables, then the gather-sum -- where the recorded ops below are a fill, two gathers, a
-            # multiply, a library GEMM and a reduction
+            # the device side in three launches (csrc/pack.hip): the products' operands and the products straight from the
+            # parameters through the index tables, then the gather-sum -- where the recorded ops below are a cat, a fill, two
+            # gathers, a multiply, a library GEMM and a reduction.  The parameters are read where they lie (a device table of
+            # their addresses): no concatenated copy.
             from .backend import default_backend
             packed = torch.empty(plan.n_packed, dtype=torch.float32, device=dev)
             kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
-            default_backend().pack_weights(plan, flat2, kq, packed)
+            default_backend().pack_weights(plan, flat2, kq, packed, params=_param_table(plan, params[:n_used]))
             ctx.hip = True
             ctx.save_for_backward(kq)
             ctx.flat2 = flat2   # (only its size and the zero slot's index matter to the backward: kept for the argument check)
             outs = torch.split(packed, plan.out_sizes)
             return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
         ctx.hip = False
+        torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
         flat2[plan.zero:].zero_()
         kq = flat2[plan.kq_idx] * plan.kq_coef
         torch.bmm(kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape),
@@ -322,15 +350,16 @@ class _PackWeights(torch.autograd.Function):
             flat2 = ctx.flat2
             g_flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
             g_kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
-            g_flat = torch.empty(plan.n_flat, dtype=torch.float32, device=dev)
+            # one buffer for every parameter's gradient -- the last launch writes the used parameters' part and zeros behind it
+            # (the encoder's forget gate) -- handed out as VIEWS: AccumulateGrad adopts a view as .grad without a copy (it is
+            # the only reference), where round 5 paid three multi-tensor launches per cell for separate tensors
+            unused_sizes = [math.prod(sh) for sh in ctx.unused_shapes]
+            g_flat = torch.empty(plan.n_flat + sum(unused_sizes), dtype=torch.float32, device=dev)
             # (the projection's weight and bias gradients arrive as column blocks of one [ncols, K + 1] product: read in place)
             gs = [None if g is None else (g if g.is_contiguous() or g.dim() <= 2 else g.contiguous()) for g in grads]
             default_backend().pack_weights_backward(plan, flat2, kq, gs, g_flat2, g_kq, g_flat)
-            outs = torch._foreach_mul([p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)], 1.0)
-            zeros = [g_flat.new_empty(sh) for sh in ctx.unused_shapes]
-            if zeros:
-                torch._foreach_zero_(zeros)
-            return (None, None, *outs, *zeros)
+            pieces = torch.split(g_flat, plan.sizes + unused_sizes)
+            return (None, None, *[p.view(sh) for p, sh in zip(pieces, plan.shapes + list(ctx.unused_shapes))])
         g_packed = torch.empty(plan.n_packed + 1, dtype=torch.float32, device=dev)
         slots = [s.view(sh) for s, sh in zip(torch.split(g_packed[:plan.n_packed], plan.out_sizes), plan.out_shapes)]
         have = [(s, g) for s, g in zip(slots, grads) if g is not None]

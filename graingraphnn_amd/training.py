@@ -75,11 +75,14 @@ def train_topology(backend, graph) -> TrainTopology:
 # consumes them is _PackedCell.
 # ---------------------------------------------------------------------------------------
 
-def _wgrad2d(backend, a, b):
+def _wgrad2d(backend, a, b, b_ins=None, ins_off=0):
     """a^T b for contiguous a [K, M], b [K, Nc] through ggnn_wgrad, in the cheaper of the two orientations: a wave
     computes a (32 or 64) x 112 block whatever part of it is inside the matrix, so a narrow factor (the encoder's
-    [x | 1]: 12 columns) belongs on the row side."""
+    [x | 1]: 12 columns) belongs on the row side.  `b_ins` [K, w]: b stands for itself with these columns inserted at
+    column ins_off (read where they lie, ggnn_wgrad_args.b_ins: no concatenated copy; the product keeps this orientation)."""
     K, M, Nc = a.size(0), a.size(1), b.size(1)
+    if b_ins is not None:
+        return backend.wgrad(a, b, K, M, Nc + b_ins.size(1), M, Nc, b_ins=b_ins, ins_off=ins_off)[0]
 
     def blocks(m, n):  # 16-row tiles a launch computes for an m x n result (wgrad.hip: wgrad_plan)
         ta = 4 if m % 64 == 0 or m >= 512 else 2
@@ -111,7 +114,7 @@ class _PackedCell(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x_g, x_j, h_g, h_j, c_g, c_j, wp_g, wp_j, bp_g, bp_j, ep_gj, ep_jg, ep_jj, w2_g, w2_j,
-                backend, topo, einfo, layout, G, bf16=False):
+                backend, topo, einfo, layout, G, bf16=False, xs=None):
         x = {"grain": x_g.contiguous(), "joint": x_j.contiguous()}
         sees_h = h_g is not None
         h = {"grain": h_g.contiguous() if sees_h else None, "joint": h_j.contiguous() if sees_h else None}
@@ -133,18 +136,17 @@ class _PackedCell(torch.autograd.Function):
             prec = _lib.GGNN_PRECISION_BF16 if (bf16 and sees_h and x6) else 0
             problems.append((x[nt], lay.F, h[nt], wp[nt], bp[nt], P[nt], prec))
             # the sweeps write every aggregate and scalar column of every row; the pad columns behind them meet zero
-            # columns of w2 and only have to be finite
+            # columns of w2 and only have to be finite: the sweep of the node type's last edge type zeroes them (pad_n)
             agg[nt] = torch.empty(n, G * lay.Kg, **f32)
-            used = len(lay.dst_ets) * (C + 2)
-            if used < lay.Kg:
-                agg[nt].view(n, G, lay.Kg)[:, :, used:].zero_()
         backend.project_batch(problems)
         sweeps = []
         for et in EDGE_TYPES:
             s, d = et[0], et[-1]
+            used = len(layout[d].dst_ets) * (C + 2)
+            pad_n = layout[d].Kg - used if layout[d].sc_off[et] + 2 == used else 0
             sweeps.append((topo.graph.csr[et], einfo[et], P[s], P[d], h[s], ep[et], agg[d], layout[s].v_off[et],
                            layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et], layout[d].Kg,
-                           layout[d].sc_off[et], G))
+                           layout[d].sc_off[et], G, pad_n))
         backend.aggregate_batch(sweeps)
         # the weight planes of the cell's row GEMMs -- the gate GEMM of both node types now, its input gradient and the
         # hidden-state gradient in the backward pass -- packed by ONE launch (they were ten small launches per step)
@@ -153,7 +155,7 @@ class _PackedCell(torch.autograd.Function):
         if sees_h:
             specs += [(wp[nt][:, layout[nt].Fp:layout[nt].Fp + C], layout[nt].ncols, C, 1, True, bf16) for nt in NODE_TYPES]
         planes = backend.rowgemm_pack(specs) if hasattr(backend, "rowgemm_pack") else [None] * len(specs)
-        z, out = {}, []
+        z, out, updates = {}, [], []
         for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             # the gate GEMM z_g = agg_g W2_g^T (ggnn_rowgemm: two-piece fp16 = fp32-equivalent; one bf16 product under
@@ -162,12 +164,16 @@ class _PackedCell(torch.autograd.Function):
             backend.rowgemm(agg[nt].view(n, G, lay.Kg).transpose(0, 1), w2[nt], z[nt], lay.Kg, C, batch=G, bf16=bf16,
                             planes=planes[k])
             h_new, c_new = torch.empty(n, C, **f32), torch.empty(n, C, **f32)
-            backend.lstm_train_forward(z[nt], P[nt], lay.s_off, c[nt], h_new, c_new)
+            updates.append((z[nt], P[nt], lay.s_off, c[nt], h_new, c_new))
             out += [h_new, c_new]
+        backend.lstm_train_forward_batch(updates, G)   # (both node types in one launch)
         saved = []
         for nt in NODE_TYPES:
             saved += [x[nt], h[nt], c[nt], wp[nt], w2[nt], P[nt], agg[nt], z[nt]]
-        ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES])
+        if xs is None:   # (a caller without the step's data rows: made here, one launch)
+            xs = dict(zip(NODE_TYPES, backend.train_input_rows([(x[nt], layout[nt].F) for nt in NODE_TYPES])))
+        ctx.save_for_backward(*saved, *out, *[ep[et] for et in EDGE_TYPES], *[einfo[et] for et in EDGE_TYPES],
+                              *[xs[nt] for nt in NODE_TYPES])
         ctx.misc = (backend, topo, layout, G, sees_h, bf16, planes[2:])   # (the backward's planes: held until then)
         ctx.set_materialize_grads(False)
         return tuple(out)                                           # h_grain, c_grain, h_joint, c_joint
@@ -184,25 +190,31 @@ class _PackedCell(torch.autograd.Function):
             c_new[nt] = t[16 + 2 * k + 1]
         ep = dict(zip(EDGE_TYPES, t[20:23]))
         einfo = dict(zip(EDGE_TYPES, t[23:26]))
+        xs = dict(zip(NODE_TYPES, t[26:28]))   # [x | 0 .. | 1 0 0 0] per node type (ggnn_train_input_rows)
         g_h_out = {"grain": g_hg, "joint": g_hj}
         g_c_out = {"grain": g_cg, "joint": g_cj}
         f32 = dict(dtype=torch.float32, device=P["joint"].device)
-        gP, g_agg, g_w2, g_c = {}, {}, {}, {}
+        gP, g_agg, g_w2, g_c, g_z, updates = {}, {}, {}, {}, {}, []
+        ok = lambda g: None if g is None else g.contiguous()
         for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             gP[nt] = torch.empty_like(P[nt])
-            used = max(lay.u4_off[et] + G * 16 for et in lay.dst_ets)   # columns behind it are padding
-            if used < lay.ncols:
+            used = max(lay.u4_off[et] + G * 16 for et in lay.dst_ets)   # columns behind it are padding: zeroed by the update
+            pad_n = lay.ncols - used
+            if pad_n > C or pad_n % 4 or used % 4:                      # (not a layout packing.node_layout makes)
                 gP[nt][:, used:].zero_()
-            g_z = torch.empty_like(z[nt])
+                pad_n = 0
+            g_z[nt] = torch.empty_like(z[nt])
             g_c[nt] = torch.empty(n, C, **f32) if sees_h else None
-            ok = lambda g: None if g is None else g.contiguous()
-            backend.lstm_train_backward(z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z, gP[nt],
-                                        lay.s_off, g_c[nt])
-            g_w2[nt] = backend.wgrad(g_z, agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
+            updates.append((z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z[nt], gP[nt], lay.s_off, g_c[nt],
+                            used, pad_n))
+        backend.lstm_train_backward_batch(updates, G)   # (both node types in one launch)
+        for k, nt in enumerate(NODE_TYPES):
+            lay, n = layout[nt], x[nt].size(0)
+            g_w2[nt] = backend.wgrad(g_z[nt], agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
                                      b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
-            backend.rowgemm(g_z, w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
+            backend.rowgemm(g_z[nt], w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
                             transposed=True, bf16=bf16, planes=planes[k])                      # g_agg_g = g_z_g W2_g
         gh_src = {nt: None for nt in NODE_TYPES}
         # the per-workgroup partial sums of the three sweeps' edge-parameter gradients side by side: one reduction
@@ -213,18 +225,18 @@ class _PackedCell(torch.autograd.Function):
             _, _, g_h, _ = backend.aggregate_backward(
                 topo.graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo[et], P[s], P[d], h[s], ep[et], agg[d],
                 g_agg[d], layout[s].v_off[et], layout[d].u_off.get(et, 0), layout[d].u4_off[et], layout[d].a_off[et],
-                layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s], ep_partial_out=ep_part[k])
+                layout[d].Kg, layout[d].sc_off[et], G, out_p_dst=gP[d], out_p_src=gP[s], ep_partial_out=ep_part[k],
+                g_h_into=gh_src[s])   # (the second sweep out of a node type adds to the first one's rows in place)
             if g_h is not None:
-                gh_src[s] = g_h if gh_src[s] is None else gh_src[s].add_(g_h)
+                gh_src[s] = g_h
         g_ep = dict(zip(EDGE_TYPES, backend.sum_rows(ep_part.view(len(EDGE_TYPES), max(n_part), -1)).view(-1, G, 3, C)))
         g_wp, g_bp, g_h = {}, {}, {}
         for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
             F, Fp = lay.F, lay.Fp
             Kp = Fp + (C if sees_h else 0)                              # columns of wp: [x (F) | 0 (Fp - F) | h]
-            parts = [x[nt][:, :F]] + ([_zeros(P[nt].device, n, Fp - F)] if Fp > F else []) + ([h[nt]] if sees_h else [])
-            xin = torch.cat(parts + [_ones(P[nt].device, n, 1 + (-(Kp + 1)) % 4)], 1)   # [.. | 1 | 0 ..]: 4 k columns
-            g_wpb = _wgrad2d(backend, gP[nt], xin)                                          # [ncols, Kp + 1 + pad]
+            # the other factor [x | 0 | h | 1 0 0 0] = the step's data rows with the hidden state inserted at column Fp
+            g_wpb = _wgrad2d(backend, gP[nt], xs[nt], h[nt] if sees_h else None, Fp)        # [ncols, Kp + 4]
             g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
             g_h[nt] = None
             if sees_h:   # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]                 [N, 96]
@@ -232,10 +244,10 @@ class _PackedCell(torch.autograd.Function):
                                           c_in=gh_src[nt], transposed=True, bf16=bf16, planes=planes[2 + k])
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
-                g_w2["grain"], g_w2["joint"], None, None, None, None, None, None)
+                g_w2["grain"], g_w2["joint"], None, None, None, None, None, None, None)
 
 
-def cell_forward(cell, backend, topo, einfo, x, h, c):
+def cell_forward(cell, backend, topo, einfo, x, h, c, xs=None):
     """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation: the packed
     weights are assembled from the parameters by recorded torch ops, the cell itself is _PackedCell.
     h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped).
@@ -251,7 +263,7 @@ def cell_forward(cell, backend, topo, einfo, x, h, c):
         x["grain"], x["joint"], None if h is None else h["grain"], None if h is None else h["joint"],
         None if c is None else c["grain"], None if c is None else c["joint"], wp["grain"], wp["joint"], bp["grain"],
         bp["joint"], ep[EDGE_TYPES[0]], ep[EDGE_TYPES[1]], ep[EDGE_TYPES[2]], w2["grain"], w2["joint"], backend, topo,
-        einfo, layout, G, bf16)
+        einfo, layout, G, bf16, xs)
     return {"grain": hg, "joint": hj}, {"grain": cg, "joint": cj}
 
 
@@ -265,11 +277,15 @@ def encoder_decoder(model, x_dict, edge_index_dict, edge_attr):
     topo = train_topology(be, graph)
     x = {nt: x_dict[nt].detach().contiguous() for nt in NODE_TYPES}
     with torch.no_grad():
-        einfo = alloc_einfo(graph, x["joint"].device)
+        # (ggnn_edge_prepare writes the zero padding records behind the E edges itself: no fill)
+        einfo = alloc_einfo(graph, x["joint"].device, zero=False)
         be.edge_prepare([(graph.csr[et], _edge_attr_1d(edge_attr[et]), x[et[0]], x[et[-1]], einfo[et])
                          for et in EDGE_TYPES])
-    h, c = cell_forward(model.gclstm_encoder.cell_list[0], be, topo, einfo, x, None, None)
-    h, c = cell_forward(model.gclstm_decoder.cell_list[0], be, topo, einfo, x, h, c)
+        # the data part of the weight gradients' second factor, [x | 0 .. | 1 0 0 0] per node type: one launch per step,
+        # shared by the two cells' backward passes
+        xs = dict(zip(NODE_TYPES, be.train_input_rows([(x[nt], model.in_channels_dict[nt]) for nt in NODE_TYPES])))
+    h, c = cell_forward(model.gclstm_encoder.cell_list[0], be, topo, einfo, x, None, None, xs)
+    h, c = cell_forward(model.gclstm_decoder.cell_list[0], be, topo, einfo, x, h, c, xs)
     return h, graph
 
 
@@ -308,10 +324,12 @@ class _RegressorHeads(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, h_joint, h_grain, x_grain, w_j, b_j, w_g, b_g, backend):
         h_joint, h_grain = h_joint.contiguous(), h_grain.contiguous()
-        w, b = torch.stack([w_j, w_g]), torch.cat([b_j, b_g])             # [2, 2, 96], [4] (packing.pack_regressor_heads)
-        ctx.width = w.size(2)
-        if ctx.width != C:    # layer_size < 96: zero columns for the padded (exactly zero) channels of h
-            w = torch.nn.functional.pad(w, (0, C - ctx.width))
+        ctx.width = w_j.size(1)
+        if ctx.width == C:    # [w_joint | w_grain | b_joint | b_grain] by one launch
+            wb = torch.cat([w_j.reshape(-1), w_g.reshape(-1), b_j, b_g])
+            w, b = wb[:4 * C].view(2, 2, C), wb[4 * C:]                   # [2, 2, 96], [4] (packing.pack_regressor_heads)
+        else:                 # layer_size < 96: zero columns for the padded (exactly zero) channels of h
+            w, b = torch.nn.functional.pad(torch.stack([w_j, w_g]), (0, C - ctx.width)), torch.cat([b_j, b_g])
         nj, ng = h_joint.size(0), h_grain.size(0)
         f32 = dict(dtype=torch.float32, device=h_joint.device)
         y_joint, y_grain, area = torch.empty(nj, 2, **f32), torch.empty(ng, 2, **f32), torch.empty(ng, **f32)
@@ -329,12 +347,16 @@ class _RegressorHeads(torch.autograd.Function):
         be = ctx.backend
         ok = lambda g: None if g is None else g.contiguous()
         gpj, gpg, ghj, ghg = be.heads_regressor_backward(w, y_joint, y_grain, ok(g_yj), ok(g_yg), ok(g_area))
-        out = []
-        for gp, h in ((gpj, h_joint), (gpg, h_grain)):   # [g_pre | 0]^T [h | 1 | 0]: weight and bias gradient in one product
-            xin = torch.cat([h, _ones(h.device, h.size(0), 4)], 1)
-            gw = be.wgrad(gp, xin, h.size(0), 4, C + 4, 4, C + 4)[0]
-            out += [gw[:2, :ctx.width], gw[:2, C]]
-        return ghj, ghg, None, out[0], out[1], out[2], out[3], None
+        rows, wd = [], ctx.width
+        for gp, h in ((gpj, h_joint), (gpg, h_grain)):   # [g_pre | 0]^T [h | 1 0 0 0]: weight and bias gradient in one product,
+            # the second factor = the constant [1 0 0 0] rows with h inserted in front of them (read where it lies)
+            gw = _wgrad2d(be, gp, _ones(h.device, h.size(0), 4), h, 0)                     # [4, 100]
+            rows += [gw[0, :wd], gw[1, :wd], gw[0, C:C + 1], gw[1, C:C + 1]]
+        # the four parameter gradients as views of one buffer made by one launch (row pieces of the two products): a view is
+        # adopted as .grad without a copy, where four strided slices cost four copies
+        flat = torch.cat(rows)
+        n = 2 * wd + 2
+        return ghj, ghg, None, flat[:2 * wd].view(2, wd), flat[2 * wd:n], flat[n:n + 2 * wd].view(2, wd), flat[n + 2 * wd:], None
 
 
 def regressor_forward(model, x_dict, edge_index_dict, edge_attr):
@@ -379,7 +401,10 @@ class _MaskedMSE(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g_loss):
         grads = ctx.saved_tensors
-        out = [g * g_loss if ctx.needs_input_grad[3 + k] else None for k, g in enumerate(grads)] if grads else []
+        out = []
+        if grads:   # (one multi-tensor launch for the terms' gradients)
+            scaled = torch._foreach_mul(list(grads), g_loss)
+            out = [g if ctx.needs_input_grad[3 + k] else None for k, g in enumerate(scaled)]
         out += [None] * (ctx.n_terms - len(out))
         return (None, None, None, *out, *([None] * (2 * ctx.n_terms)))
 
@@ -612,6 +637,7 @@ class GraphedTrainStep:
         # Everything the captured launches read out of the package's evictable caches (constant blocks, CSR and
         # reverse-CSR tables) is pinned here for the lifetime of the step object: the graph holds raw addresses.
         self._pins = []
+        self._one = None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), _pins.collect(self._pins):
@@ -628,7 +654,9 @@ class GraphedTrainStep:
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             loss = self.loss_fn(self.model(self.x, self.ei, self.ea), self.y)
         self.opt.zero_grad(set_to_none=True)   # (inside the capture the new .grad tensors come from the graph's pool)
-        loss.backward()
+        if self._one is None or self._one.shape != loss.shape or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)   # (the root gradient, made once: backward() would fill a new one per step)
+        loss.backward(self._one)
         self.opt.step()
         return loss
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 24
+#define GGNN_ABI_VERSION 25
 #define GGNN_C 96              /* hidden width (hyper.layer_size of every shipped model) */
 #define GGNN_MAX_GATES 4       /* i, f, c, o */
 #define GGNN_EDGE_PARAM_ROWS 3 /* per gate: W_value[:, 0:3] (the value side of the min-image correction) */
@@ -193,7 +193,10 @@ typedef struct ggnn_aggregate_args {
   const float* edge_params; /* [n_gates][GGNN_EDGE_PARAM_ROWS][96] = W_value[:, 0..2] */
   float* agg;               /* [n_dst, ld_agg] */
   int64_t ldp_src, ldp_dst, ld_agg, ldh_src, n_src, n_dst, E;
-  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
+  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates;
+  int32_t pad_n;            /* ABI 25: the sweep also writes zeros into agg[i, g a_gstride + sc_off + 2 .. + pad_n) of every gate
+                               row (the padding between the last edge type's scalars and the next gate row, which the training
+                               path's gate GEMM multiplies with zero weight columns: it has to be finite); 0 = nothing */
 } ggnn_aggregate_args;
 int ggnn_period_gat_aggregate(const ggnn_aggregate_args* args, ggnn_stream_t stream);
 /* The 1..6 sweeps of one cell (HeteroConv over the edge types, heteropgclstm.py:148-183; of one
@@ -263,7 +266,9 @@ typedef struct ggnn_aggregate_bwd_args {
   float* g_p_src;          /* [n_src, ldp_src] out */
   float* g_h_src;          /* [n_src, ldh_src] out, or NULL */
   int64_t ldp_src, ldp_dst, ld_agg, ldh_src, n_src, n_dst, E, n_partials;
-  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, reserved;
+  int32_t v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates;
+  int32_t g_h_accumulate;  /* ABI 25: 1 = g_h_src += (the sweeps of a cell that share a source node type add into one buffer
+                              the first of them wrote), 0 = g_h_src is written */
 } ggnn_aggregate_bwd_args;
 int64_t ggnn_aggregate_bwd_partials(int64_t n_dst); /* rows of ep_partial the call writes (one per workgroup of its destination pass) */
 int ggnn_period_gat_aggregate_backward(const ggnn_aggregate_bwd_args* args, ggnn_stream_t stream);
@@ -667,6 +672,28 @@ int ggnn_lstm_train_forward(float* z, const float* p_dst, int64_t ldp, int s_off
 int ggnn_lstm_train_backward(const float* z, const float* c_in, const float* c_out, const float* g_h,
                              const float* g_c, float* g_z, float* g_p_dst, int64_t ldp, int s_off,
                              float* g_c_in, int64_t N, int n_gates, ggnn_stream_t stream);
+/* ABI 25: the same two updates for the node types of a cell (1..GGNN_LSTM_TRAIN_MAX problems of one gate count) in ONE launch
+ * each way.  The forward reads (z, p_dst, ldp, s_off, c_in) and writes (z, h_out, c_out); the backward reads (z, c_in,
+ * c_out, g_h, g_c) and writes (g_z, g_p_dst, g_c_in), fields as in the single calls.  Backward only: it also writes zeros
+ * into g_p_dst[n, pad_off .. pad_off + pad_n) (the projection gradient's padding columns, which no kernel of the cell's
+ * backward writes and the weight gradient reads: pad_off % 4 == 0, pad_n % 4 == 0, pad_n <= 96; 0 = nothing). */
+#define GGNN_LSTM_TRAIN_MAX 4
+typedef struct ggnn_lstm_train_problem {
+  float* z;
+  const float* p_dst;
+  const float* c_in;
+  float* h_out;
+  float* c_out;
+  const float* g_h;
+  const float* g_c;
+  float* g_z;
+  float* g_p_dst;
+  float* g_c_in;
+  int64_t ldp, N;
+  int32_t s_off, pad_off, pad_n, reserved;
+} ggnn_lstm_train_problem;
+int ggnn_lstm_train_forward_batch(const ggnn_lstm_train_problem* problems, int n_problems, int n_gates, ggnn_stream_t stream);
+int ggnn_lstm_train_backward_batch(const ggnn_lstm_train_problem* problems, int n_problems, int n_gates, ggnn_stream_t stream);
 
 /* Training path: backward of ggnn_heads_regressor.  From the gradients of (y_joint [n_joint, 2], y_grain [n_grain, 2],
  * grain_area [n_grain]; any may be NULL = zero) and the forward's saved y_joint / y_grain: g_pre_* [n, 4] = gradient of
@@ -686,7 +713,12 @@ int ggnn_heads_regressor_backward(int64_t n_joint, int64_t n_grain, const float*
  * (M >= 512: the packed projection's gradient) under the default GEMM mode both operands as three exact bf16 pieces with
  * six products per k-step (2e-8 of sum |a||b| against an fp64 product; gradients of 1e-10 keep their 24 bits, which a
  * two-piece fp16 split would not give them).  M, Nc, lda, ldb, a_bstride, b_bstride multiples of 4 (pad B with zero columns
- * otherwise); a, b 16-byte aligned. */
+ * otherwise); a, b 16-byte aligned.
+ * ABI 25, b_ins != NULL: B is `b` with the ins_w columns of `b_ins` [K, ld_ins] INSERTED at column ins_off -- column c of B is
+ * b[c] for c < ins_off, b_ins[c - ins_off] for the next ins_w columns, b[c - ins_w] behind them (Nc counts all of them; b holds
+ * Nc - ins_w columns) -- so that the weight gradient of a projection reads [x | 0 | h | 1 0 0 0] from the data skeleton
+ * [x | 0 | 1 0 0 0] (ggnn_train_input_rows, once per step) and the hidden state where it lies, without a concatenated copy.
+ * ins_off, ins_w, ld_ins multiples of 4, b_ins 16-byte aligned, batch == 1. */
 typedef struct ggnn_wgrad_args {
   const float* a;  /* [batch] x [K, lda] row-major, first M columns used; batch b starts at a + b * a_bstride */
   const float* b;  /* [batch] x [K, ldb], first Nc columns used; batch b starts at b + b * b_bstride */
@@ -694,9 +726,25 @@ typedef struct ggnn_wgrad_args {
   float* out;      /* [batch, M, Nc] out: the sum over the splits, or NULL (16-byte aligned) */
   int64_t lda, ldb, a_bstride, b_bstride, K;
   int32_t M, Nc, batch, n_split;
+  const float* b_ins;  /* or NULL */
+  int64_t ld_ins;
+  int32_t ins_off, ins_w;
 } ggnn_wgrad_args;
 int ggnn_wgrad_splits(int64_t K, int M, int Nc, int batch);
 int ggnn_wgrad(const ggnn_wgrad_args* args, ggnn_stream_t stream);
+
+/* Training path (ABI 25): the data part of the weight gradients' B operands, for the node types of a step in one launch:
+ * out[n, 0 .. Fp + 4) = [x[n, 0 .. F) | 0 .. (Fp - F zeros) | 1 0 0 0], Fp = F rounded up to 4 -- what the encoder's projection
+ * gradient multiplies with as it is, and the decoder's with the hidden state inserted at column Fp (ggnn_wgrad, b_ins).
+ * out 16-byte aligned, ldo >= Fp + 4, ldo % 4 == 0; 3 <= F <= 12. */
+#define GGNN_TRAIN_ROWS_MAX 4
+typedef struct ggnn_train_rows_problem {
+  const float* x;
+  float* out;
+  int64_t ldx, ldo, N;
+  int32_t F, reserved;
+} ggnn_train_rows_problem;
+int ggnn_train_input_rows(const ggnn_train_rows_problem* problems, int n_problems, ggnn_stream_t stream);
 
 /* Training path: out[b][j] = sum_r in[b][r][j], b < batch -- the caller's reduction over the partial sums of
  * ggnn_period_gat_aggregate_backward (ep_partial: n_rows = ggnn_aggregate_bwd_partials rows of n_cols = n_gates * 288 floats
@@ -725,7 +773,13 @@ typedef struct ggnn_pack_args {
   int32_t nb, r, c, L;
   float coef;
   int32_t reserved;
+  const float* const* params;   /* ABI 25, or NULL: DEVICE array of the parameter tensors' addresses.  With it the entries of kq_idx
+                                   and idx3 that address a parameter are ENCODED as ((t + 1) << GGNN_PACK_TENSOR_SHIFT) | (offset
+                                   inside tensor t) and read from params[t] where the tensor lies (flat2[0 .. n_flat) is then not
+                                   read: no concatenated copy of the parameters); entries >= n_flat (products, zero slot) stay
+                                   plain flat2 indices.  NULL: every entry is a plain flat2 index. */
 } ggnn_pack_args;
+#define GGNN_PACK_TENSOR_SHIFT 40
 typedef struct ggnn_pack_bwd_args {
   ggnn_pack_args fwd;                       /* as in the forward call (packed is not used) */
   const float* g_out[GGNN_PACK_OUTPUTS];
@@ -740,6 +794,8 @@ typedef struct ggnn_pack_bwd_args {
   float* g_flat;
   int64_t n_flat2, n_kq;
   int32_t inv_m, inv_kq_m;
+  int64_t n_tail;   /* ABI 25: g_flat has n_flat + n_tail elements; the tail is written with zeros (the gradient of the parameters
+                       the reference's forward reads without effect: the encoder's forget gate) */
 } ggnn_pack_bwd_args;
 int ggnn_pack_weights(const ggnn_pack_args* args, ggnn_stream_t stream);
 int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_stream_t stream);

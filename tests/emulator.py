@@ -161,7 +161,7 @@ class TorchEmulatorBackend:
         return out
 
     def aggregate(self, csr, einfo, p_src, p_dst, h_src, ep, agg, v_off, u_off, u4_off, a_off,
-                  a_gstride, sc_off, n_gates):
+                  a_gstride, sc_off, n_gates, pad_n=0):
         with torch.no_grad():
             vals = self._aggregate_values(csr, einfo, p_src, p_dst, h_src, ep, v_off, u_off, u4_off, n_gates)
         for g, (val, sa, sae) in enumerate(vals):
@@ -169,10 +169,11 @@ class TorchEmulatorBackend:
             agg[:, base + a_off: base + a_off + C] = val
             agg[:, base + sc_off] = sa
             agg[:, base + sc_off + 1] = sae
+            agg[:, base + sc_off + 2: base + sc_off + 2 + pad_n] = 0.0   # (ggnn_aggregate_args.pad_n)
 
     def aggregate_backward(self, csr, rcsr, r_slot, einfo, p_src, p_dst, h_src, ep, agg, g_agg,
                            v_off, u_off, u4_off, a_off, a_gstride, sc_off, n_gates, out_p_dst=None, out_p_src=None,
-                           ep_partial_out=None):
+                           ep_partial_out=None, g_h_into=None):
         """ggnn_period_gat_aggregate_backward by autograd of the emulated forward.  The reverse
         CSR is checked for what the HIP kernel relies on, then not needed."""
         E = csr.E
@@ -207,7 +208,10 @@ class TorchEmulatorBackend:
             ep_partial_out[:n_part] = 0.0
             ep_partial_out[0] = g_ep
             g_ep = None
-        return (g_p_dst, g_p_src, None if hl is None else z(grads[3], h_src), g_ep)
+        g_h = None if hl is None else z(grads[3], h_src)
+        if g_h_into is not None:   # (g_h_accumulate: added in place to the earlier sweep's rows)
+            g_h = g_h_into.add_(g_h)
+        return (g_p_dst, g_p_src, g_h, g_ep)
 
     @staticmethod
     def aggregate_bwd_partials(n_dst):
@@ -333,7 +337,35 @@ class TorchEmulatorBackend:
             for g in range(G):
                 g_p_dst[:, s_off + g * C: s_off + (g + 1) * C] = g_z[g]
 
-    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0):
+    def lstm_train_forward_batch(self, problems, n_gates):
+        for p in problems:
+            assert p[0].size(0) == n_gates
+            self.lstm_train_forward(*p)
+
+    def lstm_train_backward_batch(self, problems, n_gates):
+        for (z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in, pad_off, pad_n) in problems:
+            assert z.size(0) == n_gates and pad_n % 4 == 0 and pad_off % 4 == 0 and 0 <= pad_n <= C
+            self.lstm_train_backward(z, c_in, c_out, g_h, g_c, g_z, g_p_dst, s_off, g_c_in)
+            if pad_n:
+                g_p_dst[:, pad_off:pad_off + pad_n] = 0.0
+
+    @staticmethod
+    def train_input_rows(problems):
+        outs = []
+        for x, F in problems:
+            Fp = (F + 3) & ~3
+            out = torch.zeros(x.size(0), Fp + 4)
+            out[:, :F] = x[:, :F]
+            out[:, Fp] = 1.0
+            outs.append(out)
+        return outs
+
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0):
+        if b_ins is not None:   # (ggnn_wgrad_args.b_ins: the columns of b_ins inserted into b at ins_off)
+            assert batch == 1 and ins_off % 4 == 0 and b_ins.size(1) % 4 == 0 and b_ins.is_contiguous()
+            bm = torch.as_strided(b.reshape(-1), (K, Nc - b_ins.size(1)), (ldb, 1), b.reshape(-1).storage_offset())
+            b = torch.cat([bm[:, :ins_off], b_ins[:K], bm[:, ins_off:]], 1).contiguous()
+            ldb = Nc
         fa, fb = a.reshape(-1), b.reshape(-1)   # (as_strided offsets are absolute in the storage)
         oa, ob = fa.storage_offset(), fb.storage_offset()
         return torch.stack([torch.as_strided(fa, (K, M), (lda, 1), oa + k * a_bstride).t()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_host_only_queries():
     lib = _lib.load()
-    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 24
+    assert lib.ggnn_version() == _lib.GGNN_ABI_VERSION == 25
     assert lib.ggnn_error_string(0) == b"ok"
     assert b"invalid" in lib.ggnn_error_string(-1)
     assert lib.ggnn_csr_workspace_bytes(60000, 20000) == (2 * 20000 + 2) * 4

@@ -1015,3 +1015,129 @@ def test_second_derivatives_are_refused(monkeypatch):
     g, = torch.autograd.grad(loss, w, create_graph=True)
     with pytest.raises(RuntimeError, match="once_differentiable|differentiate twice"):
         g.pow(2).sum().backward()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,ins_off,tail", [(20000, 2112, 12, 4), (10000, 1248, 12, 4), (20000, 4, 0, 4), (333, 672, 8, 8),
+                                               (1000, 64, 0, 4)])
+def test_wgrad_with_an_inserted_operand_equals_the_concatenated_one(K, M, ins_off, tail):
+    """ggnn_wgrad_args.b_ins (ABI 25): B = the data rows [x | 0 | 1 0 0 0] with the 96 hidden-state columns inserted at
+    column ins_off, read from the two matrices where they lie -- bit for bit the product with the concatenated copy, on both
+    kernels (the exact fp32 MFMA for the short results, the shared-B bf16x3 kernel for M >= 512).  Bad insertions are refused."""
+    from graingraphnn_amd import _lib
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(K + M)
+    a = torch.randn(K, M, generator=g).cuda()
+    outer = torch.randn(K, ins_off + tail, generator=g).cuda()
+    h = torch.randn(K, 96, generator=g).cuda()
+    Nc = ins_off + tail + 96
+    cat = torch.cat([outer[:, :ins_off], h, outer[:, ins_off:]], 1).contiguous()
+    want = be.wgrad(a, cat, K, M, Nc, M, Nc)
+    got = be.wgrad(a, outer, K, M, Nc, M, outer.size(1), b_ins=h, ins_off=ins_off)
+    assert got.shape == want.shape == (1, M, Nc) and torch.equal(got, want)
+    ref = a.double().t() @ cat.double()
+    assert float((got[0].double() - ref).abs().max()) <= 3e-6 * float((a.double().abs().t() @ cat.double().abs()).max())
+    with pytest.raises(_lib.GGNNError):
+        be.wgrad(a, outer, K, M, Nc, M, outer.size(1), b_ins=h, ins_off=ins_off + 2)        # ins_off % 4 != 0
+    with pytest.raises(_lib.GGNNError):
+        be.wgrad(a, outer, K, M, Nc + 4, M, outer.size(1), b_ins=h, ins_off=ins_off)        # b narrower than Nc - ins_w
+    with pytest.raises(_lib.GGNNError):
+        be.wgrad(a, outer, K, M, Nc, M, outer.size(1), b_ins=h[:, :94], ins_off=ins_off)    # not contiguous / width % 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [4, 3])
+def test_batched_lstm_train_updates_equal_the_single_calls_and_zero_the_padding(G):
+    """ggnn_lstm_train_forward_batch / _backward_batch (ABI 25): two node types of different sizes in one launch each way,
+    bit for bit the two single calls; the backward also zeroes the padding columns it is given and nothing else."""
+    from graingraphnn_amd import _lib
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(10 + G)
+    shapes = [(501, 1248, 384 + 96, 1184, 64), (1203, 672, 96, 640, 32)]   # N, ldp, s_off, pad_off, pad_n
+    fwd, bwd, single = [], [], []
+    for N, ldp, s_off, pad_off, pad_n in shapes:
+        gemm = torch.randn(G, N, 96, generator=g).cuda()
+        P = torch.randn(N, ldp, generator=g).cuda()
+        c_in = torch.randn(N, 96, generator=g).cuda() if G == 4 else None
+        g_h, g_c = torch.randn(N, 96, generator=g).cuda(), torch.randn(N, 96, generator=g).cuda()
+        z1, h1, c1 = gemm.clone(), torch.empty(N, 96, device="cuda"), torch.empty(N, 96, device="cuda")
+        be.lstm_train_forward(z1, P, s_off, c_in, h1, c1)
+        gz1, gP1 = torch.empty_like(z1), torch.full((N, ldp), 7.0, device="cuda")
+        gc1 = torch.empty(N, 96, device="cuda") if G == 4 else None
+        be.lstm_train_backward(z1, c_in, c1, g_h, g_c, gz1, gP1, s_off, gc1)
+        single.append((z1, h1, c1, gz1, gP1, gc1))
+        z2, h2, c2 = gemm.clone(), torch.empty(N, 96, device="cuda"), torch.empty(N, 96, device="cuda")
+        fwd.append((z2, P, s_off, c_in, h2, c2))
+        gz2, gP2 = torch.empty_like(z2), torch.full((N, ldp), 7.0, device="cuda")
+        gc2 = torch.empty(N, 96, device="cuda") if G == 4 else None
+        bwd.append((z2, c_in, c2, g_h, g_c, gz2, gP2, s_off, gc2, pad_off, pad_n))
+    be.lstm_train_forward_batch(fwd, G)
+    be.lstm_train_backward_batch(bwd, G)
+    for (z1, h1, c1, gz1, gP1, gc1), f, b, (N, ldp, s_off, pad_off, pad_n) in zip(single, fwd, bwd, shapes):
+        assert torch.equal(f[0], z1) and torch.equal(f[4], h1) and torch.equal(f[5], c1)
+        assert torch.equal(b[5], gz1) and (gc1 is None or torch.equal(b[8], gc1))
+        gP2 = b[6]
+        assert bool((gP2[:, pad_off:pad_off + pad_n] == 0).all())
+        gP1[:, pad_off:pad_off + pad_n] = 0.0
+        assert torch.equal(gP2, gP1)                                   # (everything else as the single call left it)
+    with pytest.raises(_lib.GGNNError):
+        be.lstm_train_backward_batch([bwd[0][:9] + (bwd[0][9] + 2, 32)], G)     # pad_off % 4 != 0
+    with pytest.raises(_lib.GGNNError):
+        be.lstm_train_backward_batch([bwd[0][:9] + (shapes[0][1] - 32, 64)], G)  # padding beyond the row
+
+
+@pytest.mark.gpu
+def test_train_input_rows_and_sweep_padding_and_accumulated_hidden_gradient():
+    """The three small ABI 25 additions of the training step against their torch expressions: ggnn_train_input_rows
+    ([x | 0 | 1 0 0 0]); ggnn_aggregate_args.pad_n (the sweep zeroes the padding behind its scalars in every gate row and
+    leaves the result otherwise bit-identical); ggnn_aggregate_bwd_args.g_h_accumulate (the second sweep out of a node type
+    adds its hidden-state gradient to the first one's in place = the sum of the two separate results)."""
+    from graingraphnn_amd.backend import default_backend
+    from graingraphnn_amd.engine import alloc_einfo, graph_for
+    from graingraphnn_amd.training import train_topology
+    be = default_backend()
+    g = torch.Generator().manual_seed(77)
+    x9, x11 = torch.randn(1000, 9, generator=g).cuda(), torch.randn(517, 14, generator=g).cuda()[:, :11]
+    o9, o11 = be.train_input_rows([(x9, 9), (x11, 11)])
+    for x, F, o in ((x9, 9, o9), (x11, 11, o11)):
+        want = torch.zeros(x.size(0), 16, device="cuda")
+        want[:, :F], want[:, 12] = x[:, :F], 1.0
+        assert torch.equal(o, want)
+    x, ei, ea = load_graph("40")
+    X, EI, EA = ({k: v.cuda() for k, v in tt(t).items()} for t in (x, ei, ea))
+    graph = graph_for(be, EI, {nt: X[nt].size(0) for nt in X})
+    topo = train_topology(be, graph)
+    einfo = alloc_einfo(graph, "cuda", zero=False)
+    be.edge_prepare([(graph.csr[et], EA[et].reshape(-1), X[et[0]], X[et[-1]], einfo[et]) for et in graph.csr])
+    G, C = 4, 96
+    nj, ng = X["joint"].size(0), X["grain"].size(0)
+    ldp, Kg = 1248, 224
+    P = {"joint": torch.randn(nj, ldp, generator=g).cuda() * 0.3, "grain": torch.randn(ng, ldp, generator=g).cuda() * 0.3}
+    H = {"joint": torch.randn(nj, C, generator=g).cuda() * 0.3, "grain": torch.randn(ng, C, generator=g).cuda() * 0.3}
+    ep = torch.randn(G, 3, C, generator=g).cuda() * 0.1
+    et_jj = [et for et in EDGE_TYPES if et[0] == "joint" and et[-1] == "joint"][0]
+    et_jg = [et for et in EDGE_TYPES if et[0] == "joint" and et[-1] == "grain"][0]
+    # forward: pad_n
+    sweep = lambda agg, pad: (graph.csr[et_jj], einfo[et_jj], P["joint"], P["joint"], H["joint"], ep, agg, 0, 384, 768, 96, Kg,
+                              2 * C + 2, G, pad)
+    a0, a1 = torch.full((nj, G * Kg), 5.0, device="cuda"), torch.full((nj, G * Kg), 5.0, device="cuda")
+    be.aggregate_batch([sweep(a0, 0)])
+    be.aggregate_batch([sweep(a1, Kg - (2 * C + 4))])
+    v0, v1 = a0.view(nj, G, Kg), a1.view(nj, G, Kg)
+    assert bool((v0[:, :, 2 * C + 4:] == 5.0).all()) and bool((v1[:, :, 2 * C + 4:] == 0.0).all())
+    assert torch.equal(v0[:, :, :2 * C + 4], v1[:, :, :2 * C + 4])
+    # backward: the joints are the source of two edge types
+    g_agg = {"joint": torch.randn(nj, G * Kg, generator=g).cuda(), "grain": torch.randn(ng, G * Kg, generator=g).cuda()}
+    agg = {"joint": a1, "grain": torch.zeros(ng, G * Kg, device="cuda")}
+    be.aggregate_batch([(graph.csr[et_jg], einfo[et_jg], P["joint"], P["grain"], H["joint"], ep, agg["grain"], 0, 384, 768, 0, Kg,
+                         C, G, 0)])
+
+    def back(et, a_off, sc_off, into):
+        d = et[-1]
+        return be.aggregate_backward(graph.csr[et], topo.rcsr[et], topo.r_slot[et], einfo[et], P["joint"], P[d], H["joint"], ep,
+                                     agg[d], g_agg[d], 0, 384, 768, a_off, Kg, sc_off, G, g_h_into=into)[2]
+    gh_jj, gh_jg = back(et_jj, 96, 2 * C + 2, None), back(et_jg, 0, C, None)
+    both = back(et_jg, 0, C, back(et_jj, 96, 2 * C + 2, None))
+    assert torch.equal(both, gh_jj + gh_jg)
