@@ -39,7 +39,8 @@ EXPORTED_SYMBOLS = (
     "ggnn_aggregate_bwd_partials", "ggnn_period_gat_aggregate_backward",
     "ggnn_lstm_epilogue", "ggnn_lstm_epilogue_batch", "ggnn_heads_regressor", "ggnn_heads_regressor_update",
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
-    "ggnn_lstm_train_forward_batch", "ggnn_lstm_train_backward_batch", "ggnn_train_input_rows",
+    "ggnn_lstm_train_forward_batch", "ggnn_lstm_train_backward_batch", "ggnn_train_input_rows", "ggnn_sum_rows_batch",
+    "ggnn_pack_weights_batch", "ggnn_pack_weights_backward_batch",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
@@ -181,6 +182,15 @@ class LstmTrainProblem(Structure):
                 ("reserved", c_int32)]
 
 
+GGNN_SUM_ROWS_MAX = 8
+
+
+class SumRowsProblem(Structure):
+    """Mirror of `ggnn_sum_rows_problem`."""
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("n_rows", c_int64), ("n_cols", c_int64), ("batch", c_int32),
+                ("reserved", c_int32)]
+
+
 class TrainRowsProblem(Structure):
     """Mirror of `ggnn_train_rows_problem`."""
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("ldx", c_int64), ("ldo", c_int64), ("N", c_int64), ("F", c_int32),
@@ -214,6 +224,7 @@ class AdamArgs(Structure):
 
 GGNN_PACK_OUTPUTS = 9
 GGNN_PACK_TENSOR_SHIFT = 40
+GGNN_PACK_MAX = 2
 
 
 class PackArgs(Structure):
@@ -341,6 +352,8 @@ def _declare(lib):
     for fn in (lib.ggnn_lstm_train_forward_batch, lib.ggnn_lstm_train_backward_batch):
         fn.restype = c_int
         fn.argtypes = [POINTER(LstmTrainProblem), c_int, c_int, c_void_p]
+    lib.ggnn_sum_rows_batch.restype = c_int
+    lib.ggnn_sum_rows_batch.argtypes = [POINTER(SumRowsProblem), c_int, c_void_p]
     lib.ggnn_train_input_rows.restype = c_int
     lib.ggnn_train_input_rows.argtypes = [POINTER(TrainRowsProblem), c_int, c_void_p]
     lib.ggnn_wgrad_splits.restype = c_int
@@ -363,6 +376,10 @@ def _declare(lib):
     lib.ggnn_pack_weights.argtypes = [POINTER(PackArgs), c_void_p]
     lib.ggnn_pack_weights_backward.restype = c_int
     lib.ggnn_pack_weights_backward.argtypes = [POINTER(PackBwdArgs), c_void_p]
+    lib.ggnn_pack_weights_batch.restype = c_int
+    lib.ggnn_pack_weights_batch.argtypes = [POINTER(PackArgs), c_int, c_void_p]
+    lib.ggnn_pack_weights_backward_batch.restype = c_int
+    lib.ggnn_pack_weights_backward_batch.argtypes = [POINTER(PackBwdArgs), c_int, c_void_p]
     lib.ggnn_heads_regressor_backward.restype = c_int
     lib.ggnn_heads_regressor_backward.argtypes = [c_int64, c_int64] + [c_void_p] * 11
     lib.ggnn_heads_classifier.restype = c_int

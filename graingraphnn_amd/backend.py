@@ -553,10 +553,12 @@ class HipBackend:
         self._launch(self.lib.ggnn_train_input_rows, "ggnn_train_input_rows", arr, len(problems), _lib.current_stream())
         return outs
 
-    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0):
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0, defer=None):
         """ggnn_wgrad: C[batch, M, Nc] = A_k^T B_k; A_k = K rows of M floats, row pitch lda, from element
         k * a_bstride of the contiguous tensor `a` on (B_k likewise).  Returns the sum over the splits.
-        `b_ins` [K, w] (contiguous): B is `b` with these w columns inserted at column ins_off (Nc counts them)."""
+        `b_ins` [K, w] (contiguous): B is `b` with these w columns inserted at column ins_off (Nc counts them).
+        `defer` (a list): the sum over the splits is NOT made by this call -- the returned tensor is filled by
+        `sum_rows_batch(defer)`, which the caller runs once for several postponed reductions."""
         _require_cuda(a, b, b_ins)
         ins_w = 0
         if b_ins is not None:
@@ -571,7 +573,9 @@ class HipBackend:
         partial = torch.empty(S, batch, M, Nc, dtype=torch.float32, device=a.device)
         out = torch.empty(batch, M, Nc, dtype=torch.float32, device=a.device) if S > 1 else None
         w = _lib.WgradArgs()
-        w.a, w.b, w.partial, w.out = a.data_ptr(), b.data_ptr(), partial.data_ptr(), ptr(out)
+        w.a, w.b, w.partial, w.out = a.data_ptr(), b.data_ptr(), partial.data_ptr(), (None if defer is not None else ptr(out))
+        if defer is not None and S > 1:
+            defer.append((partial.view(1, S, -1), out.view(1, -1)))
         w.lda, w.ldb, w.a_bstride, w.b_bstride, w.K = lda, ldb, a_bstride, b_bstride, K
         w.M, w.Nc, w.batch, w.n_split = M, Nc, batch, S
         if b_ins is not None:
@@ -663,6 +667,20 @@ class HipBackend:
                      _lib.current_stream())
         return out
 
+    def sum_rows_batch(self, problems):
+        """ggnn_sum_rows_batch: [(in [batch, rows, cols], out [batch, cols])] contiguous float32 -- out = the sum over the rows,
+        all problems in one launch (chunks of GGNN_SUM_ROWS_MAX)."""
+        for i0 in range(0, len(problems), _lib.GGNN_SUM_ROWS_MAX):
+            chunk = problems[i0:i0 + _lib.GGNN_SUM_ROWS_MAX]
+            arr = (_lib.SumRowsProblem * len(chunk))()
+            for a, (t, out) in zip(arr, chunk):
+                _require_cuda(t, out)
+                if t.dtype != torch.float32 or t.dim() != 3 or not t.is_contiguous() or t.size(2) % 4 or out.dtype != torch.float32 \
+                        or not out.is_contiguous() or out.numel() != t.size(0) * t.size(2):
+                    raise _lib.GGNNError("ggnn_sum_rows_batch: contiguous float32 [batch, rows, cols] (cols % 4 == 0) -> [batch, cols]")
+                a.in_, a.out, a.n_rows, a.n_cols, a.batch = t.data_ptr(), out.data_ptr(), t.size(1), t.size(2), t.size(0)
+            self._launch(self.lib.ggnn_sum_rows_batch, "ggnn_sum_rows_batch", arr, len(chunk), _lib.current_stream())
+
     def adam_step(self, args):
         """ggnn_adam_step (include/ggnn.h) on a filled `_lib.AdamArgs` (training.FusedAdam builds it)."""
         self._launch(self.lib.ggnn_adam_step, "ggnn_adam_step", ctypes.byref(args), _lib.current_stream())
@@ -687,23 +705,39 @@ class HipBackend:
         """ggnn_pack_weights: `flat2` [plan.n_flat2] holds the parameters in its first n_flat entries -- or, with `params` (a
         device int64 table of the parameter tensors' addresses), they are read where they lie and that part of flat2 is not
         touched; fills the operands `kq` [plan.n_kq], the products and `packed` [plan.n_packed] (train_pack._PackWeights)."""
-        _require_cuda(flat2, kq, packed)
-        if flat2.dtype != torch.float32 or packed.dtype != torch.float32 or kq.dtype != torch.float32 \
-                or flat2.numel() != plan.n_flat2 or kq.numel() != plan.n_kq or packed.numel() != plan.n_packed \
-                or not flat2.is_contiguous() or not packed.is_contiguous() or not kq.is_contiguous():
-            raise _lib.GGNNError("ggnn_pack_weights: flat2 [n_flat2], kq [n_kq] and packed [n_packed] must be contiguous float32")
-        a = self._pack_args(plan, flat2, kq, packed, params)
-        self._launch(self.lib.ggnn_pack_weights, "ggnn_pack_weights", ctypes.byref(a), _lib.current_stream())
+        self.pack_weights_batch([(plan, flat2, kq, packed, params)])
+
+    def pack_weights_batch(self, cells):
+        """ggnn_pack_weights_batch: [(plan, flat2, kq, packed, params)] -- the cells of a step with every launch shared."""
+        arr = (_lib.PackArgs * len(cells))()
+        for k, (plan, flat2, kq, packed, params) in enumerate(cells):
+            _require_cuda(flat2, kq, packed)
+            if flat2.dtype != torch.float32 or packed.dtype != torch.float32 or kq.dtype != torch.float32 \
+                    or flat2.numel() != plan.n_flat2 or kq.numel() != plan.n_kq or packed.numel() != plan.n_packed \
+                    or not flat2.is_contiguous() or not packed.is_contiguous() or not kq.is_contiguous():
+                raise _lib.GGNNError("ggnn_pack_weights: flat2 [n_flat2], kq [n_kq] and packed [n_packed] must be contiguous float32")
+            arr[k] = self._pack_args(plan, flat2, kq, packed, params)
+        self._launch(self.lib.ggnn_pack_weights_batch, "ggnn_pack_weights_batch", arr, len(cells), _lib.current_stream())
 
     def pack_weights_backward(self, plan, flat2, kq, grads, g_flat2, g_kq, g_flat):
         """ggnn_pack_weights_backward: `grads` = the gradients of the nine packed outputs (None: zero), contiguous float32 of
         plan.out_sizes; workspaces g_flat2 [n_flat2], g_kq [n_kq]; g_flat [>= n_flat] receives the parameters' gradient in its
         first n_flat entries and zeros behind them (n_tail: the parameters without effect)."""
+        self.pack_weights_backward_batch([(plan, flat2, kq, grads, g_flat2, g_kq, g_flat)])
+
+    def pack_weights_backward_batch(self, cells):
+        """ggnn_pack_weights_backward_batch: [(plan, flat2, kq, grads, g_flat2, g_kq, g_flat)], every launch shared."""
+        arr = (_lib.PackBwdArgs * len(cells))()
+        for k, (plan, flat2, kq, grads, g_flat2, g_kq, g_flat) in enumerate(cells):
+            self._pack_bwd_args(arr[k], plan, flat2, kq, grads, g_flat2, g_kq, g_flat)
+        self._launch(self.lib.ggnn_pack_weights_backward_batch, "ggnn_pack_weights_backward_batch", arr, len(cells),
+                     _lib.current_stream())
+
+    def _pack_bwd_args(self, b, plan, flat2, kq, grads, g_flat2, g_kq, g_flat):
         _require_cuda(flat2, g_flat2, g_kq, g_flat, *[g for g in grads if g is not None])
         if len(grads) != _lib.GGNN_PACK_OUTPUTS or g_flat2.numel() != plan.n_flat2 or g_kq.numel() != plan.n_kq \
                 or g_flat.numel() < plan.n_flat or not g_flat.is_contiguous():
             raise _lib.GGNNError("ggnn_pack_weights_backward: nine output gradients and workspaces of the plan's sizes")
-        b = _lib.PackBwdArgs()
         b.fwd = self._pack_args(plan, flat2, kq)
         b.fwd.packed = g_flat.data_ptr()   # (unused by the backward; must not be NULL)
         off = 0
@@ -726,7 +760,6 @@ class HipBackend:
         b.g_flat2, b.g_kq, b.g_flat = g_flat2.data_ptr(), g_kq.data_ptr(), g_flat.data_ptr()
         b.n_flat2, b.n_kq, b.inv_m, b.inv_kq_m = plan.n_flat2, plan.n_kq, plan.inv.size(1), plan.inv_kq.size(1)
         b.n_tail = g_flat.numel() - plan.n_flat
-        self._launch(self.lib.ggnn_pack_weights_backward, "ggnn_pack_weights_backward", ctypes.byref(b), _lib.current_stream())
 
     def masked_mse(self, terms, scale, loss, want_grad=True):
         """ggnn_masked_mse: `terms` = [(pred, target, mask or None)], contiguous float32 CUDA tensors; mask has the shape

@@ -6,6 +6,8 @@
 // parameters through the operands' index tables; the gather-sum), four backward (the gradient of flat2 through the inverse
 // table, the two operand gradients of the products, the gradient of the parameters).  Products of [r <= 110, 96] x [96, c <=
 // 110] blocks (c <= 128): plain fp32 fmas on operands staged in LDS.
+#include <algorithm>
+
 #include "common.h"
 
 namespace ggnn {
@@ -35,16 +37,39 @@ __device__ __forceinline__ float pk_read(const ggnn_pack_args& A, int64_t e) {
 // table for every row -- 96 dependent index -> value round trips per thread: 40 us per cell where this takes a few.)
 constexpr int PK_ROWS = 4;   // rows of a product per workgroup: 12 x 27 workgroups per launch at the shipped shapes
 // kq[i] = flat2[kq_idx[i]] (x coef on the K side): the operands of the products, dense (also what the backward reads)
-__global__ __launch_bounds__(256) void pack_operands_kernel(const ggnn_pack_args A) {
+// The cells of a step in one launch each (ggnn_pack_weights_batch: the encoder's and the decoder's packing are independent and
+// each of these kernels is a few microseconds of latency): workgroup -> (cell, its block) through the offsets.
+struct PackBatch {
+  ggnn_pack_args a[GGNN_PACK_MAX];
+  int off[GGNN_PACK_MAX + 1];
+  int n;
+};
+struct PackBwdBatch {
+  ggnn_pack_bwd_args a[GGNN_PACK_MAX];
+  int off[GGNN_PACK_MAX + 1];
+  int n;
+};
+template <class B>
+__device__ __forceinline__ int pk_cell(const B& b, int& blk) {
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= b.off[k + 1]) ++k;
+  blk = (int)blockIdx.x - b.off[k];
+  return k;
+}
+__global__ __launch_bounds__(256) void pack_operands_kernel(const PackBatch B) {
+  int blk;
+  const ggnn_pack_args& A = B.a[pk_cell(B, blk)];
   const int64_t n_k = (int64_t)A.nb * A.r * GGNN_C, n_kq = n_k + (int64_t)A.nb * GGNN_C * A.c;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
   if (i < n_kq) A.kq[i] = pk_read(A, A.kq_idx[i]) * (i < n_k ? A.coef : 1.0f);
 }
-__global__ __launch_bounds__(PK_THREADS) void pack_products_kernel(const ggnn_pack_args A) {
+__global__ __launch_bounds__(PK_THREADS) void pack_products_kernel(const PackBatch B) {
   extern __shared__ float lds[];
+  int blk;
+  const ggnn_pack_args& A = B.a[pk_cell(B, blk)];
   float* __restrict__ q = lds;                       // [96][c]
   float* __restrict__ kr = lds + GGNN_C * A.c;       // [PK_ROWS][96]
-  const int64_t b = blockIdx.x, row0 = (int64_t)blockIdx.y * PK_ROWS;
+  const int64_t b = blk % A.nb, row0 = (int64_t)(blk / A.nb) * PK_ROWS;
   const int tid = threadIdx.x, nrow = (int)min((int64_t)PK_ROWS, A.r - row0);
   const int64_t n_k = (int64_t)A.nb * A.r * GGNN_C;
   const float* __restrict__ qd = A.kq + n_k + b * GGNN_C * A.c;
@@ -66,8 +91,10 @@ __global__ __launch_bounds__(PK_THREADS) void pack_products_kernel(const ggnn_pa
 }
 
 // packed[i] = sum_t flat2[idx3[i L + t]]   (terms in the order t = 0, 1, 2: torch's sum over the last dimension of [n, L])
-__global__ __launch_bounds__(256) void pack_gather_kernel(const ggnn_pack_args A) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pack_gather_kernel(const PackBatch B) {
+  int blk;
+  const ggnn_pack_args& A = B.a[pk_cell(B, blk)];
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
   if (i >= A.n_packed) return;
   float s = pk_read(A, A.idx3[i * A.L]);
   for (int t = 1; t < A.L; ++t) s += pk_read(A, A.idx3[i * A.L + t]);
@@ -84,8 +111,10 @@ __device__ __forceinline__ float pk_gpacked(const ggnn_pack_bwd_args& A, int64_t
   return A.g_out[s][row * A.g_rs[s] + col * A.g_cs[s]];
 }
 // g_flat2[j] = sum_m g_packed[inv[j M + m]]
-__global__ __launch_bounds__(256) void pack_bwd_flat2_kernel(const ggnn_pack_bwd_args A) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pack_bwd_flat2_kernel(const PackBwdBatch B) {
+  int blk;
+  const ggnn_pack_bwd_args& A = B.a[pk_cell(B, blk)];
+  const int64_t j = (int64_t)blk * 256 + threadIdx.x;
   if (j >= A.n_flat2) return;
   float s = pk_gpacked(A, A.inv[j * A.inv_m]);
   for (int m = 1; m < A.inv_m; ++m) s += pk_gpacked(A, A.inv[j * A.inv_m + m]);
@@ -93,13 +122,15 @@ __global__ __launch_bounds__(256) void pack_bwd_flat2_kernel(const ggnn_pack_bwd
 }
 // g_kq[(b r + row) 96 + k] = coef sum_col g_m[b, row, col] Q[b, k, col]        (gradient of the K operand, coefficient applied)
 // Same slabs as the forward: Q_b in LDS, PK_ROWS rows of g_m beside it; a thread owns one k and walks the slab's rows.
-__global__ __launch_bounds__(PK_THREADS) void pack_bwd_k_kernel(const ggnn_pack_bwd_args A) {
+__global__ __launch_bounds__(PK_THREADS) void pack_bwd_k_kernel(const PackBwdBatch B) {
   extern __shared__ float lds[];
+  int blk;
+  const ggnn_pack_bwd_args& A = B.a[pk_cell(B, blk)];
   const ggnn_pack_args& F = A.fwd;
   const int cp = F.c | 1;                             // odd row stride: a thread per k reads q[k * cp + col] conflict-free
   float* __restrict__ q = lds;                        // [96][cp]
   float* __restrict__ gm = lds + GGNN_C * cp;         // [PK_ROWS][c]
-  const int64_t b = blockIdx.x, row0 = (int64_t)blockIdx.y * PK_ROWS;
+  const int64_t b = blk % F.nb, row0 = (int64_t)(blk / F.nb) * PK_ROWS;
   const int tid = threadIdx.x, nrow = (int)min((int64_t)PK_ROWS, F.r - row0);
   const int64_t n_k = (int64_t)F.nb * F.r * GGNN_C;
   const float* __restrict__ qd = F.kq + n_k + b * GGNN_C * F.c;
@@ -121,11 +152,13 @@ __global__ __launch_bounds__(PK_THREADS) void pack_bwd_k_kernel(const ggnn_pack_
 // g_kq[n_k + (b 96 + k) c + col] = sum_row (coef K[b, row, k]) g_m[b, row, col]   (gradient of the Q operand)
 // One workgroup per (product b, slab of PK_ROWS values of k): the slab's K columns [r][PK_ROWS] in LDS; g_m rows stream
 // from memory, coalesced over the column a thread owns.
-__global__ __launch_bounds__(PK_THREADS) void pack_bwd_q_kernel(const ggnn_pack_bwd_args A) {
+__global__ __launch_bounds__(PK_THREADS) void pack_bwd_q_kernel(const PackBwdBatch B) {
   extern __shared__ float lds[];
+  int blk;
+  const ggnn_pack_bwd_args& A = B.a[pk_cell(B, blk)];
   const ggnn_pack_args& F = A.fwd;
   float* __restrict__ kc = lds;                       // [r][PK_ROWS]
-  const int64_t b = blockIdx.x, k0 = (int64_t)blockIdx.y * PK_ROWS;
+  const int64_t b = blk % F.nb, k0 = (int64_t)(blk / F.nb) * PK_ROWS;
   const int tid = threadIdx.x;
   for (int i = tid; i < F.r * PK_ROWS; i += PK_THREADS)   // (kq's K side already carries the coefficient)
     kc[i] = F.kq[(b * F.r + i / PK_ROWS) * GGNN_C + k0 + i % PK_ROWS];
@@ -145,8 +178,10 @@ __global__ __launch_bounds__(PK_THREADS) void pack_bwd_q_kernel(const ggnn_pack_
   }
 }
 // g_flat[p] = g_flat2[p] + sum_m g_kq[inv_kq[p M + m]]
-__global__ __launch_bounds__(256) void pack_bwd_params_kernel(const ggnn_pack_bwd_args A) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pack_bwd_params_kernel(const PackBwdBatch B) {
+  int blk;
+  const ggnn_pack_bwd_args& A = B.a[pk_cell(B, blk)];
+  const int64_t p = (int64_t)blk * 256 + threadIdx.x;
   if (p >= A.fwd.n_flat) {
     if (p < A.fwd.n_flat + A.n_tail) A.g_flat[p] = 0.f;   // parameters read without effect (the encoder's forget gate)
     return;
@@ -165,39 +200,83 @@ static bool pack_args_ok(const ggnn_pack_args& A) {
          (int64_t)A.nb * A.r < INT32_MAX && (A.n_packed + 255) / 256 < INT32_MAX;
 }
 
+static bool pack_bwd_args_ok(const ggnn_pack_bwd_args& A) {
+  const ggnn_pack_args& F = A.fwd;
+  if (!pack_args_ok(F)) return false;
+  if (!A.inv || !A.inv_kq || !A.g_flat2 || !A.g_kq || !A.g_flat || A.inv_m < 1 || A.inv_m > 16 || A.inv_kq_m < 1 || A.inv_kq_m > 16)
+    return false;
+  if (A.n_tail < 0 || A.n_flat2 != F.zero + 1 || A.n_kq != (int64_t)F.nb * GGNN_C * (F.r + F.c) || A.g_off[0] != 0 ||
+      A.g_off[GGNN_PACK_OUTPUTS] != F.n_packed)
+    return false;
+  for (int s = 0; s < GGNN_PACK_OUTPUTS; ++s)
+    if (A.g_off[s + 1] < A.g_off[s] || (A.g_out[s] != nullptr && A.g_w[s] < 1)) return false;
+  return true;
+}
+
+// block offsets of a launch whose cell k takes count(k) workgroups; false if they do not fit an int
+template <class B, class Count>
+static bool pk_offsets(B& b, int n, Count count) {
+  b.n = n;
+  b.off[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int64_t c = count(k);
+    if (c <= 0 || b.off[k] + c >= INT32_MAX) return false;
+    b.off[k + 1] = b.off[k] + (int)c;
+  }
+  return true;
+}
+
 }  // namespace ggnn
 
-extern "C" int ggnn_pack_weights(const ggnn_pack_args* args, ggnn_stream_t stream) {
+extern "C" int ggnn_pack_weights_batch(const ggnn_pack_args* args, int n_cells, ggnn_stream_t stream) {
   using namespace ggnn;
-  if (!args || !pack_args_ok(*args)) return GGNN_EINVAL;
-  const ggnn_pack_args& A = *args;
+  if (!args || n_cells < 1 || n_cells > GGNN_PACK_MAX) return GGNN_EINVAL;
+  PackBatch B;
+  size_t lds = 0;
+  for (int k = 0; k < n_cells; ++k) {
+    if (!pack_args_ok(args[k])) return GGNN_EINVAL;
+    B.a[k] = args[k];
+    lds = std::max(lds, (size_t)(GGNN_C * args[k].c + PK_ROWS * GGNN_C) * sizeof(float));
+  }
   hipStream_t st = (hipStream_t)stream;
-  const int64_t n_kq = (int64_t)A.nb * GGNN_C * (A.r + A.c);
-  hipLaunchKernelGGL(pack_operands_kernel, dim3((unsigned)((n_kq + 255) / 256)), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(pack_products_kernel, dim3((unsigned)A.nb, (unsigned)((A.r + PK_ROWS - 1) / PK_ROWS)), dim3(PK_THREADS),
-                     (size_t)(GGNN_C * A.c + PK_ROWS * GGNN_C) * sizeof(float), st, A);
-  hipLaunchKernelGGL(pack_gather_kernel, dim3((unsigned)((A.n_packed + 255) / 256)), dim3(256), 0, st, A);
+  auto A = [&](int k) -> const ggnn_pack_args& { return args[k]; };
+  if (!pk_offsets(B, n_cells, [&](int k) { return ((int64_t)A(k).nb * GGNN_C * (A(k).r + A(k).c) + 255) / 256; })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_operands_kernel, dim3((unsigned)B.off[n_cells]), dim3(256), 0, st, B);
+  if (!pk_offsets(B, n_cells, [&](int k) { return (int64_t)A(k).nb * ((A(k).r + PK_ROWS - 1) / PK_ROWS); })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_products_kernel, dim3((unsigned)B.off[n_cells]), dim3(PK_THREADS), lds, st, B);
+  if (!pk_offsets(B, n_cells, [&](int k) { return (A(k).n_packed + 255) / 256; })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_gather_kernel, dim3((unsigned)B.off[n_cells]), dim3(256), 0, st, B);
   return launch_status();
 }
 
-extern "C" int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_stream_t stream) {
+extern "C" int ggnn_pack_weights_backward_batch(const ggnn_pack_bwd_args* args, int n_cells, ggnn_stream_t stream) {
   using namespace ggnn;
-  if (!args || !pack_args_ok(args->fwd)) return GGNN_EINVAL;
-  const ggnn_pack_bwd_args& A = *args;
-  const ggnn_pack_args& F = A.fwd;
-  if (!A.inv || !A.inv_kq || !A.g_flat2 || !A.g_kq || !A.g_flat || A.inv_m < 1 || A.inv_m > 16 || A.inv_kq_m < 1 || A.inv_kq_m > 16)
-    return GGNN_EINVAL;
-  if (A.n_tail < 0 || A.n_flat2 != F.zero + 1 || A.n_kq != (int64_t)F.nb * GGNN_C * (F.r + F.c) || A.g_off[0] != 0 || A.g_off[GGNN_PACK_OUTPUTS] != F.n_packed)
-    return GGNN_EINVAL;
-  for (int s = 0; s < GGNN_PACK_OUTPUTS; ++s)
-    if (A.g_off[s + 1] < A.g_off[s] || (A.g_out[s] != nullptr && A.g_w[s] < 1)) return GGNN_EINVAL;
+  if (!args || n_cells < 1 || n_cells > GGNN_PACK_MAX) return GGNN_EINVAL;
+  PackBwdBatch B;
+  size_t lds_k = 0, lds_q = 0;
+  for (int k = 0; k < n_cells; ++k) {
+    if (!pack_bwd_args_ok(args[k])) return GGNN_EINVAL;
+    B.a[k] = args[k];
+    const ggnn_pack_args& F = args[k].fwd;
+    lds_k = std::max(lds_k, (size_t)(GGNN_C * (F.c | 1) + PK_ROWS * F.c) * sizeof(float));
+    lds_q = std::max(lds_q, (size_t)F.r * PK_ROWS * sizeof(float));
+  }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pack_bwd_flat2_kernel, dim3((unsigned)((A.n_flat2 + 255) / 256)), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(pack_bwd_k_kernel, dim3((unsigned)F.nb, (unsigned)((F.r + PK_ROWS - 1) / PK_ROWS)), dim3(PK_THREADS),
-                     (size_t)(GGNN_C * (F.c | 1) + PK_ROWS * F.c) * sizeof(float), st, A);
+  auto F = [&](int k) -> const ggnn_pack_args& { return args[k].fwd; };
+  if (!pk_offsets(B, n_cells, [&](int k) { return (args[k].n_flat2 + 255) / 256; })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_bwd_flat2_kernel, dim3((unsigned)B.off[n_cells]), dim3(256), 0, st, B);
+  if (!pk_offsets(B, n_cells, [&](int k) { return (int64_t)F(k).nb * ((F(k).r + PK_ROWS - 1) / PK_ROWS); })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_bwd_k_kernel, dim3((unsigned)B.off[n_cells]), dim3(PK_THREADS), lds_k, st, B);
   static_assert(GGNN_C % PK_ROWS == 0, "slabs of k");
-  hipLaunchKernelGGL(pack_bwd_q_kernel, dim3((unsigned)F.nb, (unsigned)(GGNN_C / PK_ROWS)), dim3(PK_THREADS),
-                     (size_t)F.r * PK_ROWS * sizeof(float), st, A);
-  hipLaunchKernelGGL(pack_bwd_params_kernel, dim3((unsigned)((F.n_flat + A.n_tail + 255) / 256)), dim3(256), 0, st, A);
+  if (!pk_offsets(B, n_cells, [&](int k) { return (int64_t)F(k).nb * (GGNN_C / PK_ROWS); })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_bwd_q_kernel, dim3((unsigned)B.off[n_cells]), dim3(PK_THREADS), lds_q, st, B);
+  if (!pk_offsets(B, n_cells, [&](int k) { return (F(k).n_flat + args[k].n_tail + 255) / 256; })) return GGNN_EINVAL;
+  hipLaunchKernelGGL(pack_bwd_params_kernel, dim3((unsigned)B.off[n_cells]), dim3(256), 0, st, B);
   return launch_status();
+}
+
+extern "C" int ggnn_pack_weights(const ggnn_pack_args* args, ggnn_stream_t stream) { return ggnn_pack_weights_batch(args, 1, stream); }
+
+extern "C" int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_stream_t stream) {
+  return ggnn_pack_weights_backward_batch(args, 1, stream);
 }

@@ -139,6 +139,64 @@ __global__ __launch_bounds__(SR_QUADS * SR_GROUPS) void sum_rows_kernel(const fl
   }
 }
 
+// ... several such sums in one launch (ggnn_sum_rows_batch: the split-K partials of a cell's four weight gradients and the
+// edge-parameter partials of its sweeps, which nothing reads before the cell's backward pass ends)
+// Two ways through a problem, the ones ggnn_wgrad chooses between for its own reduction (wgrad.hip), so that a postponed
+// reduction gives the bits of an immediate one: MANY rows of a small result (sum_rows_tree: the summation tree above), or a
+// thread per result quad that walks the rows in index order, eight loads in flight (few rows of a large result).
+__host__ __device__ inline bool sum_rows_tree(int64_t n_rows, int64_t n4) { return n_rows > 48 && n4 <= 16384; }
+struct SumRowsBatch {
+  ggnn_sum_rows_problem p[GGNN_SUM_ROWS_MAX];
+  int blk_off[GGNN_SUM_ROWS_MAX + 1];   // first workgroup of every problem: (column blocks) x batch of them each
+  int n;
+};
+__global__ __launch_bounds__(SR_QUADS * SR_GROUPS) void sum_rows_batch_kernel(const SumRowsBatch B) {
+  __shared__ f32x4 red[SR_GROUPS][SR_QUADS];
+  int k = 0;
+  while (k + 1 < B.n && (int)blockIdx.x >= B.blk_off[k + 1]) ++k;
+  const ggnn_sum_rows_problem& P = B.p[k];
+  const int q = threadIdx.x % SR_QUADS, rg = threadIdx.x / SR_QUADS;
+  const int64_t n4 = P.n_cols / 4, n_rows = P.n_rows, blk = (int)blockIdx.x - B.blk_off[k];
+  if (!sum_rows_tree(n_rows, n4)) {   // (uniform per workgroup)
+    const int64_t nbw = (n4 + 255) / 256, bw = blk / nbw, i = (blk - bw * nbw) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* __restrict__ pw = reinterpret_cast<const f32x4*>(P.in) + bw * n_rows * n4 + i;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t s = 0;
+    for (; s + 8 <= n_rows; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = pw[(s + j) * n4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; s < n_rows; ++s) acc += pw[s * n4];
+    reinterpret_cast<f32x4*>(P.out)[bw * n4 + i] = acc;
+    return;
+  }
+  const int64_t nb = (n4 + SR_QUADS - 1) / SR_QUADS;
+  const int64_t b = blk / nb, col = (blk - b * nb) * SR_QUADS + q;
+  const bool live = col < n4;
+  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(P.in) + b * n_rows * n4 + (live ? col : 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = rg;
+  for (; r + 7 * SR_GROUPS < n_rows; r += 8 * SR_GROUPS) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(r + j * SR_GROUPS) * n4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; r < n_rows; r += SR_GROUPS) acc += p[r * n4];
+  red[rg][q] = acc;
+  __syncthreads();
+  if (rg == 0 && live) {
+    f32x4 t = red[0][q];
+    for (int g = 1; g < SR_GROUPS; ++g) t += red[g][q];
+    reinterpret_cast<f32x4*>(P.out)[b * n4 + col] = t;
+  }
+}
+
 int launch_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int batch, hipStream_t stream) {
   if (!in || !out || n_rows <= 0 || n_cols <= 0 || (n_cols & 3) || batch < 1 || batch > 65535) return GGNN_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return GGNN_EINVAL;
@@ -153,6 +211,26 @@ int launch_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols,
 
 extern "C" int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream) {
   return ggnn::launch_sum_rows(in, out, n_rows, n_cols, batch, (hipStream_t)stream);
+}
+
+extern "C" int ggnn_sum_rows_batch(const ggnn_sum_rows_problem* problems, int n_problems, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!problems || n_problems < 1 || n_problems > GGNN_SUM_ROWS_MAX) return GGNN_EINVAL;
+  SumRowsBatch B;
+  B.n = n_problems;
+  B.blk_off[0] = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    const ggnn_sum_rows_problem& P = problems[k];
+    if (!P.in || !P.out || P.n_rows <= 0 || P.n_cols <= 0 || (P.n_cols & 3) || P.batch < 1 || !aligned16(P.in) || !aligned16(P.out))
+      return GGNN_EINVAL;
+    const int64_t n4 = P.n_cols / 4;
+    const int64_t nb = (sum_rows_tree(P.n_rows, n4) ? (n4 + SR_QUADS - 1) / SR_QUADS : (n4 + 255) / 256) * P.batch;
+    if (B.blk_off[k] + nb >= INT32_MAX) return GGNN_EINVAL;
+    B.p[k] = P;
+    B.blk_off[k + 1] = B.blk_off[k] + (int)nb;
+  }
+  hipLaunchKernelGGL(sum_rows_batch_kernel, dim3((unsigned)B.blk_off[n_problems]), dim3(SR_QUADS * SR_GROUPS), 0, (hipStream_t)stream, B);
+  return launch_status();
 }
 
 extern "C" int ggnn_adam_step(const ggnn_adam_args* args, ggnn_stream_t stream) {

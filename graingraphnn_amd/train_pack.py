@@ -305,88 +305,105 @@ def pack_plan(cell, gates, F, sees_h, device) -> PackPlan:
 
 
 class _PackWeights(torch.autograd.Function):
-    """(plan, n_used, *parameters) -> the nine packed matrices (views of one buffer).  parameters[n_used:] are
-    read by the reference but contribute nothing (the encoder's forget gate: f * c with c = 0): zero gradient."""
+    """(plans, counts, *parameters) -> the nine packed matrices of every cell (views of one buffer per cell).  plans: one
+    PackPlan per cell (the encoder's and the decoder's of a step share every launch: ggnn_pack_weights_batch); counts[k] =
+    (n_used, n_all): cell k's parameters come next in `parameters`, the first n_used of them in the plan's order, the others
+    are read by the reference but contribute nothing (the encoder's forget gate: f * c with c = 0): zero gradient."""
 
     @staticmethod
-    def forward(ctx, plan, n_used, *params):
+    def forward(ctx, plans, counts, *params):
         dev = params[0].device
-        flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
-        ctx.plan, ctx.n_used, ctx.unused_shapes = plan, n_used, [tuple(p.shape) for p in params[n_used:]]
+        ctx.plans, ctx.counts = plans, counts
         ctx.set_materialize_grads(False)
-        if dev.type == "cuda":
-            # the device side in three launches (csrc/pack.hip): the products' operands and the products straight from the
-            # parameters through the index tables, then the gather-sum -- where the recorded ops below are a cat, a fill, two
-            # gathers, a multiply, a library GEMM and a reduction.  The parameters are read where they lie (a device table of
-            # their addresses): no concatenated copy.
+        cells, at = [], 0
+        for plan, (n_used, n_all) in zip(plans, counts):
+            cells.append((plan, params[at:at + n_used], [tuple(p.shape) for p in params[at + n_used:at + n_all]]))
+            at += n_all
+        ctx.unused_shapes = [c[2] for c in cells]
+        ctx.hip = dev.type == "cuda"
+        flat2s = [torch.empty(plan.n_flat2, dtype=torch.float32, device=dev) for plan, _, _ in cells]
+        if ctx.hip:
+            # the device side in three launches for all cells (csrc/pack.hip): the products' operands and the products
+            # straight from the parameters through the index tables, then the gather-sum -- where the recorded ops below are
+            # a cat, a fill, two gathers, a multiply, a library GEMM and a reduction per cell.  The parameters are read where
+            # they lie (a device table of their addresses): no concatenated copy.
             from .backend import default_backend
-            packed = torch.empty(plan.n_packed, dtype=torch.float32, device=dev)
-            kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
-            default_backend().pack_weights(plan, flat2, kq, packed, params=_param_table(plan, params[:n_used]))
-            ctx.hip = True
-            ctx.save_for_backward(kq)
-            ctx.flat2 = flat2   # (only its size and the zero slot's index matter to the backward: kept for the argument check)
-            outs = torch.split(packed, plan.out_sizes)
-            return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
-        ctx.hip = False
-        torch.cat([p.reshape(-1) for p in params[:n_used]], out=flat2[:plan.n_flat])
-        flat2[plan.zero:].zero_()
-        kq = flat2[plan.kq_idx] * plan.kq_coef
-        torch.bmm(kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape),
-                  out=flat2[plan.n_flat:plan.zero].view(plan.mr_shape))
-        packed = flat2[plan.idx3].sum(1) if plan.idx3.size(1) > 1 else flat2[plan.idx3[:, 0]]
-        ctx.save_for_backward(kq)
-        outs = torch.split(packed, plan.out_sizes)
-        return tuple(o.view(sh) for o, sh in zip(outs, plan.out_shapes))
+            packed = [torch.empty(plan.n_packed, dtype=torch.float32, device=dev) for plan, _, _ in cells]
+            kqs = [torch.empty(plan.n_kq, dtype=torch.float32, device=dev) for plan, _, _ in cells]
+            default_backend().pack_weights_batch([(plan, f2, kq, pk, _param_table(plan, used))
+                                                  for (plan, used, _), f2, kq, pk in zip(cells, flat2s, kqs, packed)])
+            ctx.flat2s = flat2s   # (only their sizes and the zero slot's index matter to the backward: kept for the argument check)
+        else:
+            packed, kqs = [], []
+            for (plan, used, _), flat2 in zip(cells, flat2s):
+                torch.cat([p.reshape(-1) for p in used], out=flat2[:plan.n_flat])
+                flat2[plan.zero:].zero_()
+                kq = flat2[plan.kq_idx] * plan.kq_coef
+                torch.bmm(kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape),
+                          out=flat2[plan.n_flat:plan.zero].view(plan.mr_shape))
+                packed.append(flat2[plan.idx3].sum(1) if plan.idx3.size(1) > 1 else flat2[plan.idx3[:, 0]])
+                kqs.append(kq)
+        ctx.save_for_backward(*kqs)
+        outs = []
+        for (plan, _, _), pk in zip(cells, packed):
+            outs += [o.view(sh) for o, sh in zip(torch.split(pk, plan.out_sizes), plan.out_shapes)]
+        return tuple(outs)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
-        plan = ctx.plan
-        kq, = ctx.saved_tensors
-        dev = kq.device
-        if ctx.hip:   # four launches (csrc/pack.hip) instead of ~12 recorded ops, two of them library GEMMs
+        kqs = ctx.saved_tensors
+        dev = kqs[0].device
+        n_out = len(grads) // len(ctx.plans)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if ctx.hip:   # four launches for all cells (csrc/pack.hip) instead of ~12 recorded ops per cell, two of them library GEMMs
             from .backend import default_backend
-            flat2 = ctx.flat2
-            g_flat2 = torch.empty(plan.n_flat2, dtype=torch.float32, device=dev)
-            g_kq = torch.empty(plan.n_kq, dtype=torch.float32, device=dev)
-            # one buffer for every parameter's gradient -- the last launch writes the used parameters' part and zeros behind it
-            # (the encoder's forget gate) -- handed out as VIEWS: AccumulateGrad adopts a view as .grad without a copy (it is
-            # the only reference), where round 5 paid three multi-tensor launches per cell for separate tensors
-            unused_sizes = [math.prod(sh) for sh in ctx.unused_shapes]
-            g_flat = torch.empty(plan.n_flat + sum(unused_sizes), dtype=torch.float32, device=dev)
-            # (the projection's weight and bias gradients arrive as column blocks of one [ncols, K + 1] product: read in place)
-            gs = [None if g is None else (g if g.is_contiguous() or g.dim() <= 2 else g.contiguous()) for g in grads]
-            default_backend().pack_weights_backward(plan, flat2, kq, gs, g_flat2, g_kq, g_flat)
-            pieces = torch.split(g_flat, plan.sizes + unused_sizes)
-            return (None, None, *[p.view(sh) for p, sh in zip(pieces, plan.shapes + list(ctx.unused_shapes))])
-        g_packed = torch.empty(plan.n_packed + 1, dtype=torch.float32, device=dev)
-        slots = [s.view(sh) for s, sh in zip(torch.split(g_packed[:plan.n_packed], plan.out_sizes), plan.out_shapes)]
-        have = [(s, g) for s, g in zip(slots, grads) if g is not None]
-        if have:
-            torch._foreach_copy_([s for s, _ in have], [g for _, g in have])
-        for s, g in zip(slots, grads):
-            if g is None:
-                s.zero_()
-        g_packed[plan.n_packed:].zero_()
-        g_flat2 = g_packed[plan.inv].sum(1) if plan.inv.size(1) > 1 else g_packed[plan.inv[:, 0]]
-        g_kq = torch.empty(plan.n_kq + 1, dtype=torch.float32, device=dev)
-        K, Q = kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape)
-        g_m = g_flat2[plan.n_flat:plan.zero].view(plan.mr_shape)          # (pad entries: nobody reads them -> zero)
-        torch.bmm(g_m, Q.transpose(1, 2), out=g_kq[:plan.n_k].view(plan.k_shape))
-        torch.bmm(K.transpose(1, 2), g_m, out=g_kq[plan.n_k:plan.n_kq].view(plan.q_shape))
-        g_kq[:plan.n_kq].mul_(plan.kq_coef)
-        g_kq[plan.n_kq:].zero_()
-        g_via_kq = g_kq[plan.inv_kq].sum(1) if plan.inv_kq.size(1) > 1 else g_kq[plan.inv_kq[:, 0]]
-        g_flat = g_flat2[:plan.n_flat] + g_via_kq
-        # every parameter gets a fresh tensor made by ONE multi-tensor op (a functional foreach allocates its results
-        # on the C++ side): AccumulateGrad adopts it as .grad without a kernel (views of g_flat would cost a clone per
-        # parameter, 142 Python-side allocations 0.3 ms of host time per cell)
-        outs = torch._foreach_mul([p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)], 1.0)
-        zeros = [g_flat.new_empty(sh) for sh in ctx.unused_shapes]
-        if zeros:
-            torch._foreach_zero_(zeros)
-        return (None, None, *outs, *zeros)
+            work, result = [], []
+            for k, (plan, kq, flat2, unused) in enumerate(zip(ctx.plans, kqs, ctx.flat2s, ctx.unused_shapes)):
+                # one buffer for every parameter's gradient -- the last launch writes the used parameters' part and zeros
+                # behind it (the encoder's forget gate) -- handed out as VIEWS: AccumulateGrad adopts a view as .grad without
+                # a copy (it is the only reference), where round 5 paid three multi-tensor launches per cell for separate
+                # tensors
+                unused_sizes = [math.prod(sh) for sh in unused]
+                g_flat = torch.empty(plan.n_flat + sum(unused_sizes), **f32)
+                # (the projection's weight and bias gradients arrive as column blocks of one [ncols, K + 1] product: read in place)
+                gs = [None if g is None else (g if g.is_contiguous() or g.dim() <= 2 else g.contiguous())
+                      for g in grads[k * n_out:(k + 1) * n_out]]
+                work.append((plan, flat2, kq, gs, torch.empty(plan.n_flat2, **f32), torch.empty(plan.n_kq, **f32), g_flat))
+                pieces = torch.split(g_flat, plan.sizes + unused_sizes)
+                result += [p.view(sh) for p, sh in zip(pieces, plan.shapes + list(unused))]
+            default_backend().pack_weights_backward_batch(work)
+            return (None, None, *result)
+        result = []
+        for k, (plan, kq, unused) in enumerate(zip(ctx.plans, kqs, ctx.unused_shapes)):
+            cell_grads = grads[k * n_out:(k + 1) * n_out]
+            g_packed = torch.empty(plan.n_packed + 1, **f32)
+            slots = [s.view(sh) for s, sh in zip(torch.split(g_packed[:plan.n_packed], plan.out_sizes), plan.out_shapes)]
+            have = [(s, g) for s, g in zip(slots, cell_grads) if g is not None]
+            if have:
+                torch._foreach_copy_([s for s, _ in have], [g for _, g in have])
+            for s, g in zip(slots, cell_grads):
+                if g is None:
+                    s.zero_()
+            g_packed[plan.n_packed:].zero_()
+            g_flat2 = g_packed[plan.inv].sum(1) if plan.inv.size(1) > 1 else g_packed[plan.inv[:, 0]]
+            g_kq = torch.empty(plan.n_kq + 1, **f32)
+            K, Q = kq[:plan.n_k].view(plan.k_shape), kq[plan.n_k:].view(plan.q_shape)
+            g_m = g_flat2[plan.n_flat:plan.zero].view(plan.mr_shape)          # (pad entries: nobody reads them -> zero)
+            torch.bmm(g_m, Q.transpose(1, 2), out=g_kq[:plan.n_k].view(plan.k_shape))
+            torch.bmm(K.transpose(1, 2), g_m, out=g_kq[plan.n_k:plan.n_kq].view(plan.q_shape))
+            g_kq[:plan.n_kq].mul_(plan.kq_coef)
+            g_kq[plan.n_kq:].zero_()
+            g_via_kq = g_kq[plan.inv_kq].sum(1) if plan.inv_kq.size(1) > 1 else g_kq[plan.inv_kq[:, 0]]
+            g_flat = g_flat2[:plan.n_flat] + g_via_kq
+            # every parameter gets a fresh tensor made by ONE multi-tensor op (a functional foreach allocates its results
+            # on the C++ side): AccumulateGrad adopts it as .grad without a kernel
+            result += torch._foreach_mul([p.view(sh) for p, sh in zip(torch.split(g_flat, plan.sizes), plan.shapes)], 1.0)
+            zeros = [g_flat.new_empty(sh) for sh in unused]
+            if zeros:
+                torch._foreach_zero_(zeros)
+            result += zeros
+        return (None, None, *result)
 
 
 def _forget_gate_params(cell):
@@ -397,16 +414,34 @@ def _forget_gate_params(cell):
     return [d[k] for d, k in slots if d[k] is not None]
 
 
-def packed_weights(cell, gates, F, sees_h):
-    """-> (layout, wp {nt: [ncols, Fp + k2]}, bp {nt: [ncols]}, ep {et: [G, 3, 96]}, w2 {nt: [G, 96, Kg]}) of the
-    cell, differentiable with respect to every parameter the reference's forward reads."""
+def _cell_inputs(cell, gates, F, sees_h):
     plist, _, _ = cell_params(cell, gates)
     # Encoder: f * c with c = 0.  The reference still runs conv_f, so its parameters receive an exactly zero
     # gradient; they get one here too, which also keeps DistributedDataParallel(model, device_ids=[rank])
     # (dist_train.py:82) usable as written.
     unused = [] if "f" in gates else _forget_gate_params(cell)
     plan = pack_plan(cell, gates, dict(F), sees_h, plist[0].device)
-    o = _PackWeights.apply(plan, len(plist), *plist, *unused)
+    return plan, plist, unused
+
+
+def _as_dicts(plan, o):
     nt_g, nt_j = "grain", "joint"
     return (plan.layout, {nt_g: o[0], nt_j: o[1]}, {nt_g: o[2], nt_j: o[3]}, dict(zip(EDGE_TYPES, o[4:7])),
             {nt_g: o[7], nt_j: o[8]})
+
+
+def packed_weights(cell, gates, F, sees_h):
+    """-> (layout, wp {nt: [ncols, Fp + k2]}, bp {nt: [ncols]}, ep {et: [G, 3, 96]}, w2 {nt: [G, 96, Kg]}) of the
+    cell, differentiable with respect to every parameter the reference's forward reads."""
+    plan, plist, unused = _cell_inputs(cell, gates, F, sees_h)
+    return _as_dicts(plan, _PackWeights.apply((plan,), ((len(plist), len(plist) + len(unused)),), *plist, *unused))
+
+
+def packed_weights_of(cells):
+    """`packed_weights` for several cells at once, [(cell, gates, F, sees_h)] -> [its result per cell]: one autograd function
+    whose launches all cells share (the encoder's and the decoder's packing of a training step)."""
+    ins = [_cell_inputs(*c) for c in cells]
+    o = _PackWeights.apply(tuple(plan for plan, _, _ in ins), tuple((len(pl), len(pl) + len(un)) for _, pl, un in ins),
+                           *[p for _, pl, un in ins for p in (*pl, *un)])
+    n = len(o) // len(ins)
+    return [_as_dicts(plan, o[k * n:(k + 1) * n]) for k, (plan, _, _) in enumerate(ins)]

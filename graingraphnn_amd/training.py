@@ -33,7 +33,7 @@ from . import _lib, _pins
 from .backend import default_backend
 from .engine import _check_x, _edge_attr_1d, alloc_einfo, graph_for
 from .packing import C, EDGE_TYPES, NODE_TYPES
-from .train_pack import _ones, _zeros, packed_weights
+from .train_pack import _ones, _zeros, packed_weights, packed_weights_of
 
 _KG = 128  # row pitch of one gate in the sweep's output: 96 values, sum(alpha), sum(alpha * a), padding
 
@@ -75,21 +75,40 @@ def train_topology(backend, graph) -> TrainTopology:
 # consumes them is _PackedCell.
 # ---------------------------------------------------------------------------------------
 
-def _wgrad2d(backend, a, b, b_ins=None, ins_off=0):
+def _wgrad2d(backend, a, b, b_ins=None, ins_off=0, defer=None):
     """a^T b for contiguous a [K, M], b [K, Nc] through ggnn_wgrad, in the cheaper of the two orientations: a wave
     computes a (32 or 64) x 112 block whatever part of it is inside the matrix, so a narrow factor (the encoder's
     [x | 1]: 12 columns) belongs on the row side.  `b_ins` [K, w]: b stands for itself with these columns inserted at
-    column ins_off (read where they lie, ggnn_wgrad_args.b_ins: no concatenated copy; the product keeps this orientation)."""
+    column ins_off (read where they lie, ggnn_wgrad_args.b_ins: no concatenated copy; the product keeps this orientation).
+    `defer`: see backend.wgrad (the result is complete after backend.sum_rows_batch(defer))."""
     K, M, Nc = a.size(0), a.size(1), b.size(1)
     if b_ins is not None:
-        return backend.wgrad(a, b, K, M, Nc + b_ins.size(1), M, Nc, b_ins=b_ins, ins_off=ins_off)[0]
+        return backend.wgrad(a, b, K, M, Nc + b_ins.size(1), M, Nc, b_ins=b_ins, ins_off=ins_off, defer=defer)[0]
 
     def blocks(m, n):  # 16-row tiles a launch computes for an m x n result (wgrad.hip: wgrad_plan)
         ta = 4 if m % 64 == 0 or m >= 512 else 2
         return -(-m // (16 * ta)) * ta * -(-n // 112)
     if blocks(Nc, M) < blocks(M, Nc):
-        return backend.wgrad(b, a, K, Nc, M, Nc, M)[0].t()
-    return backend.wgrad(a, b, K, M, Nc, M, Nc)[0]
+        return backend.wgrad(b, a, K, Nc, M, Nc, M, defer=defer)[0].t()
+    return backend.wgrad(a, b, K, M, Nc, M, Nc, defer=defer)[0]
+
+
+_weight_streams = {}
+
+
+def _train_streams():
+    """What a cell's backward pass puts on a second stream: letters of GGNN_TRAIN_STREAMS -- "w" the weight gradients, "h"
+    the grains' hidden-state gradient; "" (default "h"?) = one stream."""
+    import os
+    return os.environ.get("GGNN_TRAIN_STREAMS", "")
+
+
+def _weight_stream(device):
+    """The second stream of a cell's backward pass (one per device)."""
+    s = _weight_streams.get(device)
+    if s is None:
+        s = _weight_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class _PackedCell(torch.autograd.Function):
@@ -209,10 +228,37 @@ class _PackedCell(torch.autograd.Function):
             updates.append((z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z[nt], gP[nt], lay.s_off, g_c[nt],
                             used, pad_n))
         backend.lstm_train_backward_batch(updates, G)   # (both node types in one launch)
+        # The WEIGHT gradients on a second stream beside the chain of activation gradients (GGNN_TRAIN_STREAMS=1: all on one
+        # stream): nothing of this backward pass reads them, they are bound by the matrix pipe at one wave per SIMD, and
+        # the sweeps' backward beside them waits for gathers.  Both chains end inside this function (the streams are
+        # joined before it returns: autograd sees results that are ready on its stream), every tensor the second stream reads
+        # is held by this frame until then, and an episode on it starts behind an event of the main stream -- so memory it
+        # allocated and the main stream has since read is not rewritten early.
+        main = torch.cuda.current_stream() if P["joint"].is_cuda else None
+        mode = _train_streams() if main is not None else ""
+        side = _weight_stream(P["joint"].device) if mode else None
+
+        def beside(fn, what="w"):
+            if side is None or what not in mode:
+                return fn()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                return fn()
+
+        # the sums over the split-K partials of the four weight gradients and over the sweeps' edge-parameter partials are
+        # postponed to ONE launch at the end of this backward pass (nothing reads them before)
+        red = [] if hasattr(backend, "sum_rows_batch") and "w" not in mode else None
+
+        def gate_weight_gradients():
+            for nt in NODE_TYPES:
+                lay, n = layout[nt], x[nt].size(0)
+                g_w2[nt] = backend.wgrad(g_z[nt], agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
+                                         b_bstride=lay.Kg, defer=red)                          # [G, 96, Kg]
+        beside(gate_weight_gradients)
         for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
-            g_w2[nt] = backend.wgrad(g_z[nt], agg[nt], n, C, lay.Kg, C, G * lay.Kg, batch=G, a_bstride=n * C,
-                                     b_bstride=lay.Kg)                                         # [G, 96, Kg]
             g_agg[nt] = torch.empty_like(agg[nt])
             backend.rowgemm(g_z[nt], w2[nt], g_agg[nt].view(n, G, lay.Kg).transpose(0, 1), C, lay.Kg, batch=G,
                             transposed=True, bf16=bf16, planes=planes[k])                      # g_agg_g = g_z_g W2_g
@@ -229,25 +275,46 @@ class _PackedCell(torch.autograd.Function):
                 g_h_into=gh_src[s])   # (the second sweep out of a node type adds to the first one's rows in place)
             if g_h is not None:
                 gh_src[s] = g_h
-        g_ep = dict(zip(EDGE_TYPES, backend.sum_rows(ep_part.view(len(EDGE_TYPES), max(n_part), -1)).view(-1, G, 3, C)))
-        g_wp, g_bp, g_h = {}, {}, {}
+        g_wp, g_bp, g_h, g_ep = {}, {}, {}, {}
+
+        def projection_weight_gradients():
+            if red is None:
+                g_ep.update(zip(EDGE_TYPES, backend.sum_rows(ep_part.view(len(EDGE_TYPES), max(n_part), -1)).view(-1, G, 3, C)))
+            else:
+                sums = torch.empty(len(EDGE_TYPES), G * 3 * C, **f32)
+                red.append((ep_part.view(len(EDGE_TYPES), max(n_part), -1), sums))
+                g_ep.update(zip(EDGE_TYPES, sums.view(-1, G, 3, C)))
+            for nt in NODE_TYPES:
+                lay = layout[nt]
+                Kp = lay.Fp + (C if sees_h else 0)                      # columns of wp: [x (F) | 0 (Fp - F) | h]
+                # the other factor [x | 0 | h | 1 0 0 0] = the step's data rows with the hidden state inserted at column Fp
+                g_wpb = _wgrad2d(backend, gP[nt], xs[nt], h[nt] if sees_h else None, lay.Fp, defer=red)   # [ncols, Kp + 4]
+                g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
+        beside(projection_weight_gradients)
         for k, nt in enumerate(NODE_TYPES):
             lay, n = layout[nt], x[nt].size(0)
-            F, Fp = lay.F, lay.Fp
-            Kp = Fp + (C if sees_h else 0)                              # columns of wp: [x (F) | 0 (Fp - F) | h]
-            # the other factor [x | 0 | h | 1 0 0 0] = the step's data rows with the hidden state inserted at column Fp
-            g_wpb = _wgrad2d(backend, gP[nt], xs[nt], h[nt] if sees_h else None, Fp)        # [ncols, Kp + 4]
-            g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
+            Fp = lay.Fp
             g_h[nt] = None
             if sees_h:   # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]                 [N, 96]
-                g_h[nt] = backend.rowgemm(gP[nt], wp[nt][:, Fp:Fp + C], torch.empty(n, C, **f32), lay.ncols, C,
-                                          c_in=gh_src[nt], transposed=True, bf16=bf16, planes=planes[2 + k])
+                # (mode "h": the grains' product beside the joints' -- a wave of ggnn_rowgemm walks the whole reduction of
+                # its 16 rows, so these two launches are 79 and 157 workgroups on 256 compute units)
+                def hidden_state_gradient(k=k, nt=nt, lay=lay, n=n, Fp=Fp):
+                    g_h[nt] = backend.rowgemm(gP[nt], wp[nt][:, Fp:Fp + C], torch.empty(n, C, **f32), lay.ncols, C,
+                                              c_in=gh_src[nt], transposed=True, bf16=bf16, planes=planes[2 + k])
+                if k == 0:
+                    beside(hidden_state_gradient, "h")
+                else:
+                    hidden_state_gradient()
+        if side is not None:
+            main.wait_stream(side)
+        if red:
+            backend.sum_rows_batch(red)
         return (None, None, g_h["grain"], g_h["joint"], g_c["grain"], g_c["joint"], g_wp["grain"], g_wp["joint"],
                 g_bp["grain"], g_bp["joint"], g_ep[EDGE_TYPES[0]], g_ep[EDGE_TYPES[1]], g_ep[EDGE_TYPES[2]],
                 g_w2["grain"], g_w2["joint"], None, None, None, None, None, None, None)
 
 
-def cell_forward(cell, backend, topo, einfo, x, h, c, xs=None):
+def cell_forward(cell, backend, topo, einfo, x, h, c, xs=None, packed=None):
     """HeteroPGCLSTM.forward (heteropgclstm.py:101-183), differentiable, in the packed formulation: the packed
     weights are assembled from the parameters by recorded torch ops, the cell itself is _PackedCell.
     h, c: dicts or None (encoder: zero state; the forget gate multiplies c = 0 and is skipped).
@@ -258,7 +325,7 @@ def cell_forward(cell, backend, topo, einfo, x, h, c, xs=None):
     F = cell.in_channels_dict
     bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
     with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
-        layout, wp, bp, ep, w2 = packed_weights(cell, gates, F, h is not None)
+        layout, wp, bp, ep, w2 = packed if packed is not None else packed_weights(cell, gates, F, h is not None)
     hg, cg, hj, cj = _PackedCell.apply(
         x["grain"], x["joint"], None if h is None else h["grain"], None if h is None else h["joint"],
         None if c is None else c["grain"], None if c is None else c["joint"], wp["grain"], wp["joint"], bp["grain"],
@@ -284,8 +351,12 @@ def encoder_decoder(model, x_dict, edge_index_dict, edge_attr):
         # the data part of the weight gradients' second factor, [x | 0 .. | 1 0 0 0] per node type: one launch per step,
         # shared by the two cells' backward passes
         xs = dict(zip(NODE_TYPES, be.train_input_rows([(x[nt], model.in_channels_dict[nt]) for nt in NODE_TYPES])))
-    h, c = cell_forward(model.gclstm_encoder.cell_list[0], be, topo, einfo, x, None, None, xs)
-    h, c = cell_forward(model.gclstm_decoder.cell_list[0], be, topo, einfo, x, h, c, xs)
+    enc, dec = model.gclstm_encoder.cell_list[0], model.gclstm_decoder.cell_list[0]
+    # both cells' packed weights by one autograd function: its launches (three forward, four backward) are shared
+    with torch.autocast(x["joint"].device.type, enabled=False):   # weight-sized products stay fp32
+        pk_enc, pk_dec = packed_weights_of([(enc, "ico", enc.in_channels_dict, False), (dec, "ifco", dec.in_channels_dict, True)])
+    h, c = cell_forward(enc, be, topo, einfo, x, None, None, xs, pk_enc)
+    h, c = cell_forward(dec, be, topo, einfo, x, h, c, xs, pk_dec)
     return h, graph
 
 
@@ -348,10 +419,13 @@ class _RegressorHeads(torch.autograd.Function):
         ok = lambda g: None if g is None else g.contiguous()
         gpj, gpg, ghj, ghg = be.heads_regressor_backward(w, y_joint, y_grain, ok(g_yj), ok(g_yg), ok(g_area))
         rows, wd = [], ctx.width
+        red = [] if hasattr(be, "sum_rows_batch") else None   # (the two products' split-K sums in one launch)
         for gp, h in ((gpj, h_joint), (gpg, h_grain)):   # [g_pre | 0]^T [h | 1 0 0 0]: weight and bias gradient in one product,
             # the second factor = the constant [1 0 0 0] rows with h inserted in front of them (read where it lies)
-            gw = _wgrad2d(be, gp, _ones(h.device, h.size(0), 4), h, 0)                     # [4, 100]
+            gw = _wgrad2d(be, gp, _ones(h.device, h.size(0), 4), h, 0, defer=red)          # [4, 100]
             rows += [gw[0, :wd], gw[1, :wd], gw[0, C:C + 1], gw[1, C:C + 1]]
+        if red:
+            be.sum_rows_batch(red)
         # the four parameter gradients as views of one buffer made by one launch (row pieces of the two products): a view is
         # adopted as .grad without a copy, where four strided slices cost four copies
         flat = torch.cat(rows)

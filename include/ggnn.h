@@ -750,6 +750,18 @@ int ggnn_train_input_rows(const ggnn_train_rows_problem* problems, int n_problem
  * ggnn_period_gat_aggregate_backward (ep_partial: n_rows = ggnn_aggregate_bwd_partials rows of n_cols = n_gates * 288 floats
  * per edge type), in a fixed order.  in: [batch, n_rows, n_cols] contiguous, n_cols % 4 == 0, 16-byte aligned. */
 int ggnn_sum_rows(const float* in, float* out, int64_t n_rows, int64_t n_cols, int32_t batch, ggnn_stream_t stream);
+/* ABI 25: 1..GGNN_SUM_ROWS_MAX such sums in one launch, each with its own shape -- the reductions a cell's backward pass can
+ * postpone to its end: the split-K partials of its weight gradients (ggnn_wgrad with out == NULL: in = partial, n_rows =
+ * n_split, n_cols = batch M Nc, batch = 1) and the edge-parameter partials of its sweeps.  Same fixed summation tree as
+ * ggnn_sum_rows (32 interleaved row groups, combined in index order). */
+#define GGNN_SUM_ROWS_MAX 8
+typedef struct ggnn_sum_rows_problem {
+  const float* in;   /* [batch, n_rows, n_cols] contiguous, 16-byte aligned */
+  float* out;        /* [batch, n_cols] */
+  int64_t n_rows, n_cols;
+  int32_t batch, reserved;
+} ggnn_sum_rows_problem;
+int ggnn_sum_rows_batch(const ggnn_sum_rows_problem* problems, int n_problems, ggnn_stream_t stream);
 
 /* Training path: the nine packed weight matrices of a cell (projection weights and biases of both node types, relocation
  * columns per edge type, gate weights: graingraphnn_amd/packing.py) from its parameters, differentiable -- the device side of
@@ -799,6 +811,12 @@ typedef struct ggnn_pack_bwd_args {
 } ggnn_pack_bwd_args;
 int ggnn_pack_weights(const ggnn_pack_args* args, ggnn_stream_t stream);
 int ggnn_pack_weights_backward(const ggnn_pack_bwd_args* args, ggnn_stream_t stream);
+/* ABI 25: the same for 1..GGNN_PACK_MAX cells (the encoder's and the decoder's of a training step) with every launch shared:
+ * three launches forward and four backward whatever the number of cells (each of these kernels is a few microseconds of
+ * latency on ~1 MB of data).  Same results as the single calls. */
+#define GGNN_PACK_MAX 2
+int ggnn_pack_weights_batch(const ggnn_pack_args* args, int n_cells, ggnn_stream_t stream);
+int ggnn_pack_weights_backward_batch(const ggnn_pack_bwd_args* args, int n_cells, ggnn_stream_t stream);
 
 /* Training path: torch.optim.Adam's update (train.py:82-91; amsgrad / maximize off) for up to GGNN_ADAM_MAX_TENSORS parameter
  * tensors in one launch.  `table` (DEVICE memory, n_tensors entries, built once) holds what is fixed: the addresses of a

@@ -360,7 +360,7 @@ class TorchEmulatorBackend:
             outs.append(out)
         return outs
 
-    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0):
+    def wgrad(self, a, b, K, M, Nc, lda, ldb, batch=1, a_bstride=0, b_bstride=0, b_ins=None, ins_off=0, defer=None):
         if b_ins is not None:   # (ggnn_wgrad_args.b_ins: the columns of b_ins inserted into b at ins_off)
             assert batch == 1 and ins_off % 4 == 0 and b_ins.size(1) % 4 == 0 and b_ins.is_contiguous()
             bm = torch.as_strided(b.reshape(-1), (K, Nc - b_ins.size(1)), (ldb, 1), b.reshape(-1).storage_offset())

@@ -1141,3 +1141,32 @@ def test_train_input_rows_and_sweep_padding_and_accumulated_hidden_gradient():
     gh_jj, gh_jg = back(et_jj, 96, 2 * C + 2, None), back(et_jg, 0, C, None)
     both = back(et_jg, 0, C, back(et_jj, 96, 2 * C + 2, None))
     assert torch.equal(both, gh_jj + gh_jg)
+
+
+@pytest.mark.gpu
+def test_batched_row_sums_equal_the_single_calls():
+    """ggnn_sum_rows_batch (ABI 25): problems of different shapes in one launch.  Many rows of a small result: bit for bit
+    ggnn_sum_rows (same summation tree); few rows or a large result: the rows added in index order (what ggnn_wgrad does for
+    such a reduction itself) -- so a postponed ggnn_wgrad reduction gives the bits of an immediate one."""
+    from graingraphnn_amd.backend import default_backend
+    be = default_backend()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(3, 768, 1152), (1, 45, 2112 * 112), (1, 313, 400), (1, 2, 4), (4, 19, 96 * 224), (1, 31, 36)]
+    ins = [torch.randn(*s, generator=g).cuda() for s in shapes]
+    outs = [torch.full((s[0], s[2]), 7.0, device="cuda") for s in shapes]
+    be.sum_rows_batch(list(zip(ins, outs)))
+    for t, o in zip(ins, outs):
+        if t.size(1) > 48 and t.size(2) // 4 <= 16384:
+            assert torch.equal(o, be.sum_rows(t))
+        else:
+            acc = torch.zeros_like(o)
+            for r in range(t.size(1)):
+                acc = acc + t[:, r]
+            assert torch.equal(o, acc)
+    for K, M, Nc, batch in ((20000, 96, 224, 1), (20000, 2112, 112, 1), (20000, 4, 100, 1), (10000, 96, 128, 4)):
+        a, b = torch.randn(batch, K, M, generator=g).cuda(), torch.randn(K, batch * Nc, generator=g).cuda()
+        red = []
+        c = be.wgrad(a, b, K, M, Nc, M, batch * Nc, batch=batch, a_bstride=K * M, b_bstride=Nc, defer=red)
+        assert len(red) == 1
+        be.sum_rows_batch(red)
+        assert torch.equal(c, be.wgrad(a, b, K, M, Nc, M, batch * Nc, batch=batch, a_bstride=K * M, b_bstride=Nc))
