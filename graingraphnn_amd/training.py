@@ -97,8 +97,10 @@ _weight_streams = {}
 
 
 def _train_streams():
-    """What a cell's backward pass puts on a second stream: letters of GGNN_TRAIN_STREAMS -- "w" the weight gradients, "h"
-    the grains' hidden-state gradient; "" (default "h"?) = one stream."""
+    """What a cell's backward pass puts on a second stream (development): letters of GGNN_TRAIN_STREAMS -- "w" the weight
+    gradients, "h" the grains' hidden-state gradient; default "": one stream.  Measured on the replayed cfg3 step (r6): "w"
+    +0.04 ms (the kernels overlap and slow each other down by as much), "h" +-0.01 ms at cfg3 and +0.05 ms for four 40 um
+    graphs (profiles/r6_train_step_experiments.txt)."""
     import os
     return os.environ.get("GGNN_TRAIN_STREAMS", "")
 
@@ -228,12 +230,11 @@ class _PackedCell(torch.autograd.Function):
             updates.append((z[nt], c[nt], c_new[nt], ok(g_h_out[nt]), ok(g_c_out[nt]), g_z[nt], gP[nt], lay.s_off, g_c[nt],
                             used, pad_n))
         backend.lstm_train_backward_batch(updates, G)   # (both node types in one launch)
-        # The WEIGHT gradients on a second stream beside the chain of activation gradients (GGNN_TRAIN_STREAMS=1: all on one
-        # stream): nothing of this backward pass reads them, they are bound by the matrix pipe at one wave per SIMD, and
-        # the sweeps' backward beside them waits for gathers.  Both chains end inside this function (the streams are
-        # joined before it returns: autograd sees results that are ready on its stream), every tensor the second stream reads
-        # is held by this frame until then, and an episode on it starts behind an event of the main stream -- so memory it
-        # allocated and the main stream has since read is not rewritten early.
+        # Development switch (GGNN_TRAIN_STREAMS, off by default: no gain measured): the WEIGHT gradients ("w") or the grains'
+        # hidden-state gradient ("h") on a second stream beside the chain of activation gradients.  Both chains end inside
+        # this function (the streams are joined before it returns: autograd sees results that are ready on its stream),
+        # every tensor the second stream reads is held by this frame until then, and an episode on it starts behind an
+        # event of the main stream -- so memory it allocated and the main stream has since read is not rewritten early.
         main = torch.cuda.current_stream() if P["joint"].is_cuda else None
         mode = _train_streams() if main is not None else ""
         side = _weight_stream(P["joint"].device) if mode else None
