@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_step_refresh_prepare", "ggnn_lstm_train_forward", "ggnn_lstm_train_backward",
     "ggnn_lstm_train_forward_batch", "ggnn_lstm_train_backward_batch", "ggnn_train_input_rows", "ggnn_sum_rows_batch",
     "ggnn_pack_weights_batch", "ggnn_pack_weights_backward_batch",
-    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_heads_regressor_backward",
+    "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_rowgemm_pair", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
     "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
     "ggnn_topology_counts", "ggnn_topology_export", "ggnn_topology_close", "ggnn_step_refresh",
@@ -366,6 +366,8 @@ def _declare(lib):
     lib.ggnn_rowgemm_pack.argtypes = [POINTER(RowGemmArgs), c_int, c_void_p]
     lib.ggnn_rowgemm.restype = c_int
     lib.ggnn_rowgemm.argtypes = [POINTER(RowGemmArgs), c_void_p]
+    lib.ggnn_rowgemm_pair.restype = c_int
+    lib.ggnn_rowgemm_pair.argtypes = [POINTER(RowGemmArgs), c_void_p]
     lib.ggnn_adam_step.restype = c_int
     lib.ggnn_adam_step.argtypes = [POINTER(AdamArgs), c_void_p]
     lib.ggnn_sum_rows.restype = c_int

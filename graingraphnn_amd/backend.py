@@ -613,16 +613,9 @@ class HipBackend:
             self._launch(self.lib.ggnn_rowgemm_pack, "ggnn_rowgemm_pack", arr, len(chunk), _lib.current_stream())
         return out
 
-    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False, planes=None):
-        """ggnn_rowgemm (include/ggnn.h): out[b] = a[b] . W[b]^T (+ c_in[b]) for b < batch.
-        `a`   : [M, lda] (batch 1) or [batch, M, lda] float32 view with unit column stride: the first K columns;
-        `w`   : [batch, n_out, >= K] (transposed=False: W[b] = w[b][:, :K]) or [batch, K, >= n_out] (transposed=True:
-                W[b] = w[b][:, :n_out]^T -- a gradient uses the transpose of the forward's weight), or 2-D for batch 1;
-        `out` : [M, ldc] / [batch, M, ldc] float32 view with unit column stride: its first n_out columns are written;
-        `c_in`: optional, same layout as out (may be out itself);
-        `planes`: the weight planes of exactly this (w, K, n_out, batch, transposed, bf16) from `rowgemm_pack`."""
+    def _rowgemm_args(self, a, w, out, K, n_out, batch, c_in, transposed, bf16, planes):
+        """The filled ggnn_rowgemm_args of one product (checks included) and the tensor holding its weight planes."""
         _require_cuda(a, w, out, c_in)
-        given = out   # (returned as given: a [M, n] result must not come back as [1, M, n] -- autograd would sum_to_size it)
         if a.dim() == 2:
             a = a.unsqueeze(0)
         if out.dim() == 2:
@@ -654,8 +647,38 @@ class HipBackend:
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
         g.M, g.lda, g.ldc = M, a.stride(1), out.stride(1)
         g.a_bstride, g.c_bstride = a.stride(0) if batch > 1 else 0, out.stride(0) if batch > 1 else 0
+        return g, ws
+
+    def rowgemm(self, a, w, out, K, n_out, batch=1, c_in=None, transposed=False, bf16=False, planes=None):
+        """ggnn_rowgemm (include/ggnn.h): out[b] = a[b] . W[b]^T (+ c_in[b]) for b < batch.
+        `a`   : [M, lda] (batch 1) or [batch, M, lda] float32 view with unit column stride: the first K columns;
+        `w`   : [batch, n_out, >= K] (transposed=False: W[b] = w[b][:, :K]) or [batch, K, >= n_out] (transposed=True:
+                W[b] = w[b][:, :n_out]^T -- a gradient uses the transpose of the forward's weight), or 2-D for batch 1;
+        `out` : [M, ldc] / [batch, M, ldc] float32 view with unit column stride: its first n_out columns are written
+                (returned as given: a [M, n] result must not come back as [1, M, n] -- autograd would sum_to_size it);
+        `c_in`: optional, same layout as out (may be out itself);
+        `planes`: the weight planes of exactly this (w, K, n_out, batch, transposed, bf16) from `rowgemm_pack`."""
+        g, _ = self._rowgemm_args(a, w, out, K, n_out, batch, c_in, transposed, bf16, planes)
         self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
-        return given
+        return out
+
+    def rowgemm_pair(self, first, second):
+        """ggnn_rowgemm_pair: two LONG products side by side in one grid; each = (a, w, out, K, n_out, c_in, transposed, bf16,
+        planes) with the planes from `rowgemm_pack` (batch 1).  Falls back to two calls where the C entry point would refuse
+        (a product whose weight planes stay in LDS, different output widths or precisions)."""
+        args = [self._rowgemm_args(a, w, out, K, n_out, 1, c_in, transposed, bf16, planes)[0]
+                for (a, w, out, K, n_out, c_in, transposed, bf16, planes) in (first, second)]
+        tiles = lambda n: 6 if n <= 96 else (8 if n <= 128 else 14)
+        streams = lambda g: not (g.K // 32 <= (8 if g.n_out == 96 else 4) and g.n_out in (96, 128, 224)) \
+            and not (g.precision == 0 and g.n_out > 128)
+        if all(g.prepacked and streams(g) for g in args) and tiles(args[0].n_out) == tiles(args[1].n_out) \
+                and args[0].precision == args[1].precision:
+            arr = (_lib.RowGemmArgs * 2)(*args)
+            self._launch(self.lib.ggnn_rowgemm_pair, "ggnn_rowgemm_pair", arr, _lib.current_stream())
+        else:
+            for g in args:
+                self._launch(self.lib.ggnn_rowgemm, "ggnn_rowgemm", ctypes.byref(g), _lib.current_stream())
+        return first[2], second[2]
 
     def sum_rows(self, t):
         """ggnn_sum_rows: [batch, rows, cols] contiguous float32 -> [batch, cols], the sum over the rows in a fixed order."""

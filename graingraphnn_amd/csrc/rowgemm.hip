@@ -126,9 +126,22 @@ __global__ __launch_bounds__(256) void rowgemm_pack_batch_kernel(const RowGemmPa
 // the whole NEXT group (GS x 32 bytes per lane) are requested at the top of the current one -- ~100 KB of rows in
 // flight per compute unit: the kernel streams A from HBM once, and a request per k-step (the first version) had
 // every k-step wait out a full memory round trip (125 us for the 169 MB of the joints' g_h; the library: 102).
+// One or TWO products per launch (ggnn_rowgemm_pair): a wave walks the whole reduction of its 16 rows, so the grid is M / 128
+// workgroups -- 79 and 157 for the grains' and the joints' hidden-state gradient on 256 compute units, one after the other;
+// side by side in one grid they take the time of the longer one.
+struct RowGemmPair {
+  ggnn_rowgemm_args a[2];
+  const u32x4* planes[2];
+  int nks[2];
+  int n_wg0;   // workgroups of the first product (the second one's follow)
+};
 template <int NCT, bool BF16>
-__global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowgemm_args A, const u32x4* __restrict__ planes,
-                                                                const int nks) {
+__global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const RowGemmPair B) {
+  const int which = (int)blockIdx.x >= B.n_wg0 ? 1 : 0;
+  const ggnn_rowgemm_args& A = B.a[which];
+  const u32x4* __restrict__ planes = B.planes[which];
+  const int nks = B.nks[which];
+  const int64_t wg = (int64_t)blockIdx.x - (which ? B.n_wg0 : 0);
   constexpr int P = BF16 ? 1 : 2;
   constexpr int SLICE = NCT * P * 1024;
   // k-steps per group: 4 (n_out <= 128); n_out = 224: 2 in bf16, 1 in fp32 mode (112 accumulator registers: no room for
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(RG_WAVES * 64) void rowgemm_kernel(const ggnn_rowge
   const int64_t M = A.M;
   // a ragged last tile slides back over rows the previous tile also produces (identical duplicate stores); surplus
   // waves repeat the last tile: every wave runs the whole program (the group barriers need no special case)
-  const int64_t row0 = std::max<int64_t>(0, std::min<int64_t>(((int64_t)blockIdx.x * RG_WAVES + wave) * 16, M - 16));
+  const int64_t row0 = std::max<int64_t>(0, std::min<int64_t>((wg * RG_WAVES + wave) * 16, M - 16));
   const int64_t row = std::min<int64_t>(row0 + lr, M - 1);
 
   const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(planes) + lane * 16;
@@ -369,14 +382,19 @@ static int rowgemm_resident_launch(const ggnn_rowgemm_args& A, const u32x4* plan
   return launch_status();
 }
 
+// (the second product may be absent: A1 == nullptr)
 template <int NCT>
-static int rowgemm_launch(const ggnn_rowgemm_args& A, const u32x4* planes, int nks, hipStream_t st) {
-  const int64_t n_wg = (A.M + 16 * RG_WAVES - 1) / (16 * RG_WAVES);
-  if (n_wg >= INT32_MAX) return GGNN_EINVAL;
-  if (A.precision == GGNN_PRECISION_BF16)
-    hipLaunchKernelGGL((rowgemm_kernel<NCT, true>), dim3((unsigned)n_wg), dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+static int rowgemm_launch(const ggnn_rowgemm_args& A0, const ggnn_rowgemm_args* A1, hipStream_t st) {
+  RowGemmPair B;
+  const int64_t n0 = (A0.M + 16 * RG_WAVES - 1) / (16 * RG_WAVES), n1 = A1 ? (A1->M + 16 * RG_WAVES - 1) / (16 * RG_WAVES) : 0;
+  if (n0 + n1 >= INT32_MAX) return GGNN_EINVAL;
+  B.a[0] = A0, B.planes[0] = reinterpret_cast<const u32x4*>(A0.workspace), B.nks[0] = A0.K / 32;
+  B.a[1] = A1 ? *A1 : A0, B.planes[1] = reinterpret_cast<const u32x4*>(B.a[1].workspace), B.nks[1] = B.a[1].K / 32;
+  B.n_wg0 = (int)n0;
+  if (A0.precision == GGNN_PRECISION_BF16)
+    hipLaunchKernelGGL((rowgemm_kernel<NCT, true>), dim3((unsigned)(n0 + n1)), dim3(RG_WAVES * 64), 0, st, B);
   else
-    hipLaunchKernelGGL((rowgemm_kernel<NCT, false>), dim3((unsigned)n_wg), dim3(RG_WAVES * 64), 0, st, A, planes, nks);
+    hipLaunchKernelGGL((rowgemm_kernel<NCT, false>), dim3((unsigned)(n0 + n1)), dim3(RG_WAVES * 64), 0, st, B);
   return launch_status();
 }
 
@@ -470,9 +488,33 @@ extern "C" int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream)
     }
   }
   switch (nct) {
-    case 6: return rowgemm_launch<6>(A, planes, nks, st);
-    case 8: return rowgemm_launch<8>(A, planes, nks, st);
-    case 14: return rowgemm_launch<14>(A, planes, nks, st);
+    case 6: return rowgemm_launch<6>(A, nullptr, st);
+    case 8: return rowgemm_launch<8>(A, nullptr, st);
+    case 14: return rowgemm_launch<14>(A, nullptr, st);
+    default: return GGNN_EINVAL;
+  }
+}
+
+static bool rowgemm_streams(const ggnn_rowgemm_args& A) {   // the streamed kernel in ONE pass (see ggnn_rowgemm)
+  const bool resident = A.n_out == 16 * rowgemm_tiles(A.n_out) && A.K / 32 <= (A.n_out == 96 ? 8 : 4);
+  return !resident && !(A.precision == 0 && A.n_out > 128);
+}
+
+extern "C" int ggnn_rowgemm_pair(const ggnn_rowgemm_args* args, ggnn_stream_t stream) {
+  using namespace ggnn;
+  if (!args) return GGNN_EINVAL;
+  for (int k = 0; k < 2; ++k) {
+    const ggnn_rowgemm_args& A = args[k];
+    if (!A.a || !A.c || A.M <= 0 || !A.prepacked || A.batch != 1 || rowgemm_check_weights(A) != GGNN_OK) return GGNN_EINVAL;
+    if (A.lda < A.K || A.ldc < A.n_out || (A.lda & 3) || (A.ldc & 3)) return GGNN_EINVAL;
+    if (!aligned16(A.a) || !aligned16(A.c) || (A.c_in && !aligned16(A.c_in)) || !rowgemm_streams(A)) return GGNN_EINVAL;
+  }
+  if (rowgemm_tiles(args[0].n_out) != rowgemm_tiles(args[1].n_out) || args[0].precision != args[1].precision) return GGNN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  switch (rowgemm_tiles(args[0].n_out)) {
+    case 6: return rowgemm_launch<6>(args[0], &args[1], st);
+    case 8: return rowgemm_launch<8>(args[0], &args[1], st);
+    case 14: return rowgemm_launch<14>(args[0], &args[1], st);
     default: return GGNN_EINVAL;
   }
 }

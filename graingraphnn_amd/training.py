@@ -292,17 +292,20 @@ class _PackedCell(torch.autograd.Function):
                 g_wpb = _wgrad2d(backend, gP[nt], xs[nt], h[nt] if sees_h else None, lay.Fp, defer=red)   # [ncols, Kp + 4]
                 g_wp[nt], g_bp[nt] = g_wpb[:, :Kp], g_wpb[:, Kp]
         beside(projection_weight_gradients)
-        for k, nt in enumerate(NODE_TYPES):
-            lay, n = layout[nt], x[nt].size(0)
-            Fp = lay.Fp
+        # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]   [N, 96] -- the two node types' products side by side
+        # in ONE grid (ggnn_rowgemm_pair): a wave of ggnn_rowgemm walks the whole reduction of its 16 rows, so they are 79
+        # and 157 workgroups on 256 compute units (one after the other: 44 + 68 us at cfg3)
+        products = [(gP[nt], wp[nt][:, layout[nt].Fp:layout[nt].Fp + C], torch.empty(x[nt].size(0), C, **f32), layout[nt].ncols,
+                     C, gh_src[nt], True, bf16, planes[2 + k]) for k, nt in enumerate(NODE_TYPES)] if sees_h else []
+        for nt in NODE_TYPES:
             g_h[nt] = None
-            if sees_h:   # g_h = (the sweeps' source-side gradient) + gP Wp[:, h columns]                 [N, 96]
-                # (mode "h": the grains' product beside the joints' -- a wave of ggnn_rowgemm walks the whole reduction of
-                # its 16 rows, so these two launches are 79 and 157 workgroups on 256 compute units)
-                def hidden_state_gradient(k=k, nt=nt, lay=lay, n=n, Fp=Fp):
-                    g_h[nt] = backend.rowgemm(gP[nt], wp[nt][:, Fp:Fp + C], torch.empty(n, C, **f32), lay.ncols, C,
-                                              c_in=gh_src[nt], transposed=True, bf16=bf16, planes=planes[2 + k])
-                if k == 0:
+        if sees_h and hasattr(backend, "rowgemm_pair") and "h" not in mode:
+            g_h.update(zip(NODE_TYPES, backend.rowgemm_pair(*products)))
+        elif sees_h:
+            for k, (nt, (a, w, out, K, n_out, c_in, tr, b16, pl)) in enumerate(zip(NODE_TYPES, products)):
+                def hidden_state_gradient(nt=nt, a=a, w=w, out=out, K=K, n_out=n_out, c_in=c_in, tr=tr, b16=b16, pl=pl):
+                    g_h[nt] = backend.rowgemm(a, w, out, K, n_out, c_in=c_in, transposed=tr, bf16=b16, planes=pl)
+                if k == 0:   # (mode "h", development: the grains' product on a second stream beside the joints')
                     beside(hidden_state_gradient, "h")
                 else:
                     hidden_state_gradient()

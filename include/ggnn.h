@@ -496,6 +496,12 @@ typedef struct ggnn_rowgemm_args {
 size_t ggnn_rowgemm_workspace_bytes(int32_t K, int32_t n_out, int32_t batch);
 int ggnn_rowgemm_pack(const ggnn_rowgemm_args* args, int n_products, ggnn_stream_t stream); /* reads w, K, n_out, batch, precision, workspace */
 int ggnn_rowgemm(const ggnn_rowgemm_args* args, ggnn_stream_t stream);
+/* ABI 25: TWO long products (args[0], args[1]: the streamed form -- K / 32 beyond what stays in LDS --, batch == 1, prepacked
+ * planes, the same precision and n_out rounded to the same instantiated width) side by side in one grid: a wave walks the whole
+ * reduction of its 16 rows, so such a product is M / 128 workgroups -- the hidden-state gradients of a training cell's two node
+ * types (79 and 157 workgroups at the 10k-grain graph) then take the time of the longer one.  Same results as two calls;
+ * anything else is refused (GGNN_EINVAL: make two calls). */
+int ggnn_rowgemm_pair(const ggnn_rowgemm_args* args, ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads.

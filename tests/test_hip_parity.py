@@ -240,6 +240,29 @@ def test_rowgemm_against_float64(M, K, n_out, batch, transposed, with_cin):
     assert torch.equal(o2[:, :, :n_out], ob[:, :, :n_out])
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_rowgemm_pair_equals_the_two_single_products(bf16):
+    """ggnn_rowgemm_pair (ABI 25): the two node types' hidden-state gradients (10 000 x 1248 and 20 003 x 2112 -> 96, accumulated
+    into the sweeps' source-side gradient) side by side in one grid -- bit for bit the two single calls; a pair the C entry
+    point would refuse (one product's planes stay in LDS) runs as two calls through the same wrapper."""
+    be = backend()
+    rs = np.random.RandomState(7)
+
+    def product(M, K):
+        a = torch.from_numpy((rs.standard_normal((M, K + 32)) * 10 ** rs.uniform(-6, 0, (M, 1))).astype(np.float32)).to(DEV)
+        w = torch.from_numpy(rs.standard_normal((K, 100)).astype(np.float32)).to(DEV)
+        cin = torch.from_numpy(rs.standard_normal((M, 96)).astype(np.float32)).to(DEV)
+        planes, = be.rowgemm_pack([(w, K, 96, 1, True, bf16)])
+        want = be.rowgemm(a, w, torch.empty(M, 96, device=DEV), K, 96, c_in=cin, transposed=True, bf16=bf16, planes=planes)
+        return (a, w, torch.full((M, 96), float("nan"), device=DEV), K, 96, cin, True, bf16, planes), want
+    (p0, w0), (p1, w1), (p2, w2) = product(10000, 1248), product(20003, 2112), product(777, 128)
+    o0, o1 = be.rowgemm_pair(p0, p1)
+    assert torch.equal(o0, w0) and torch.equal(o1, w1)
+    p0[2].fill_(float("nan"))
+    o0, o2 = be.rowgemm_pair(p0, p2)      # (K = 128: resident planes -> two calls)
+    assert torch.equal(o0, w0) and torch.equal(o2, w2)
+
+
 @pytest.mark.parametrize("M,K,n_out,batch,transposed", [
     (4096, 224, 96, 4, False),      # resident planes (the gate GEMM's shapes)
     (4096, 96, 224, 2, True),       # its input gradient g_agg = g_z W2
