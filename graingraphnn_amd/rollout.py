@@ -21,7 +21,7 @@ from . import _lib
 from .backend import default_backend
 from .engine import (Workspace, _check_x, alloc_einfo, graph_for, prepare_edges, run_encoder_decoder,
                      run_encoder_decoder_multi)
-from .modules import _param_version
+from .modules import _param_version, _param_version_sample
 from .packing import EDGE_TYPES, NODE_TYPES, pack_classifier_heads, pack_regressor_heads
 
 TRAIN_FRAMES = 120  # test.py:190
@@ -115,18 +115,25 @@ class GrainRollout:
     def _pack_weights(self):
         """Fused device weights of both models, and the parameter versions they were packed from."""
         self._wver = (_param_version(self.rmodel), _param_version(self.cmodel))
+        self._wver_sample = (_param_version_sample(self.rmodel), _param_version_sample(self.cmodel))
         for name, m in (("R", self.rmodel), ("C", self.cmodel)):
             self.packed[name] = (m.gclstm_encoder.cell_list[0].packed(True),
                                  m.gclstm_decoder.cell_list[0].packed(False, m._live_out))
         self.w_reg = pack_regressor_heads(self.rmodel.linear)
         self.w_cls = pack_classifier_heads(self.cmodel.lin1, self.cmodel.lin2)
 
-    def refresh_weights(self, force: bool = False):
+    def refresh_weights(self, force: bool = False, sample: bool = False):
         """Re-pack the weights and drop the captured hipGraphs (which hold the old buffers'
         addresses) if a parameter of either model was updated, moved or replaced since they were
-        packed (load_state_dict, an optimizer step, .to()).  Checked on every run() and
-        step_events() call and on every 16th step() call (the check walks 568 tensors, ~0.15 ms);
-        call it directly after changing the models between two step() calls."""
+        packed (load_state_dict, an optimizer step, .to()).  Checked on every run() / run_events() call and
+        on every 16th step() / step_events() call (the check walks 568 tensors, ~0.15 ms: a seventh of an
+        eventful step); the step_events() calls between look at a sample of the tensors (`sample`: every 24th --
+        what changes a model changes all of it); call it directly after changing single parameters
+        between two step() / step_events() calls."""
+        if sample and not force:
+            now = (_param_version_sample(self.rmodel), _param_version_sample(self.cmodel))
+            if now == self._wver_sample:
+                return
         if force or self._wver != (_param_version(self.rmodel), _param_version(self.cmodel)):
             self._pack_weights()
             self._graphs = None
@@ -542,7 +549,7 @@ class GrainRollout:
         host synchronisation unless an event fires."""
         if not hasattr(self, "mask"):
             raise _lib.GGNNError("call enable_events(mask, ...) first")
-        self.refresh_weights()
+        self.refresh_weights(sample=self.steps_done % 16 != 0)
         self._einfo_fresh = False   # this mode prepares its edge records at the start of every step
         self._x_written_outside()
         self._run_segment("fwd")

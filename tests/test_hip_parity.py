@@ -1051,6 +1051,34 @@ def test_event_rollout_reproduces_reference_trajectory(use_graph):
     assert bool(torch.isfinite(X["joint"]).all())
 
 
+@torch.no_grad()
+def test_step_events_loop_follows_new_weights_between_its_steps():
+    """A step_events() loop checks a SAMPLE of the parameter tensors per step (the full walk is a seventh of an eventful
+    step: every 16th step only): load_state_dict between two steps must still be seen at once -- the loop continues bit for
+    bit like a rollout built on the new weights from the same state."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(5, 0.3, DEV)
+    R2, Cm2 = product_models(9, 0.3, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+    X = tt(x, DEV)
+    ro = GrainRollout(R, Cm, X, tt(ei, DEV), tt(ea, DEV), 6, use_graph=True, refresh_centres=True)
+    ro.enable_events(mask, -1.0, 0.999999)
+    for _ in range(3):                       # (steps_done 1..3: the next check is a sampled one)
+        ro.step_events()
+    X2 = {k: v.clone() for k, v in X.items()}
+    ref = GrainRollout(R2, Cm2, X2, {et: v.clone() for et, v in ro.edge_index.items()},
+                       {et: v.clone().view(-1, 1) for et, v in ro.edge_attr.items()}, 6, use_graph=False, refresh_centres=True)
+    ref.enable_events(mask, -1.0, 0.999999)
+    R.load_state_dict(R2.state_dict())
+    Cm.load_state_dict(Cm2.state_dict())
+    for _ in range(2):
+        ro.step_events()
+        ref.step_events()
+    for nt in X:
+        assert torch.equal(X[nt], X2[nt]), nt
+
+
 @pytest.mark.parametrize("use_graph,chunks", [(True, (5,)), (True, (3, 2)), (False, (1, 4))])
 @torch.no_grad()
 def test_speculative_event_loop_equals_step_events(use_graph, chunks):

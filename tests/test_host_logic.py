@@ -583,3 +583,30 @@ def test_classifier_loss_ignores_unlabelled_edges_like_the_reference_indexing():
     assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-6
     loss.backward()
     assert bool(torch.isfinite(z.grad).all()) and bool((z.grad[~keep] == 0).all())
+
+
+def test_sampled_parameter_versions_notice_what_changes_a_whole_model():
+    """rollout.refresh_weights(sample=True) -- the per-step check of a step_events() loop -- looks at every 24th parameter
+    tensor (modules._param_version_sample): an optimizer-style update of all parameters, load_state_dict and a move of the
+    storage each change the sample; the full walk (every 16th step) is the one that notices a single edited tensor."""
+    from graingraphnn_amd.modules import _param_version, _param_version_sample
+    from helpers import product_models
+    R, _ = product_models(3, 1.0)
+    R2, _ = product_models(4, 1.0)
+    full, sample = _param_version(R), _param_version_sample(R)
+    assert 8 <= len(sample) <= len(full) // 20 and set(sample) <= set(full)
+    with torch.no_grad():
+        for p in R.parameters():
+            p.add_(0.0)                                   # an optimizer step bumps every version counter
+    assert _param_version_sample(R) != sample
+    sample = _param_version_sample(R)
+    R.load_state_dict(R2.state_dict())
+    assert _param_version_sample(R) != sample
+    sample, full = _param_version_sample(R), _param_version(R)
+    R.double().float()                                    # new storages
+    assert _param_version_sample(R) != sample
+    sample, full = _param_version_sample(R), _param_version(R)
+    name = "gclstm_decoder.cell_list.0.conv_c.convs.joint__connect__joint.lin_value.weight"
+    with torch.no_grad():
+        dict(R.named_parameters())[name].mul_(1.5)        # one tensor edited in place: the full walk's business
+    assert _param_version(R) != full

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run through gpurun}" || exit 1
+OUT=gpurun_out/r6A
+mkdir -p $OUT
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1 || { tail -40 $OUT/pytest_gpu.log; exit 1; }
+tail -2 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
