@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_pack_weights_batch", "ggnn_pack_weights_backward_batch",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_rowgemm_pair", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
-    "ggnn_heads_classifier", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
+    "ggnn_heads_classifier", "ggnn_heads_classifier_n", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
     "ggnn_topology_counts", "ggnn_topology_export", "ggnn_topology_close", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -62,7 +62,7 @@ class PrepareEdge(Structure):
     _fields_ = [
         ("col", c_void_p), ("perm", c_void_p), ("row", c_void_p), ("edge_attr", c_void_p),
         ("x_src", c_void_p), ("x_dst", c_void_p), ("einfo", c_void_p),
-        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("E", c_int64), ("f_src", c_int64),
+        ("ldx_src", c_int64), ("ldx_dst", c_int64), ("E", c_int64), ("f_src", c_int64), ("E_dev", c_void_p),
     ]
 
 
@@ -284,7 +284,7 @@ class RefreshEdge(Structure):
     _fields_ = [
         ("edge_index", c_void_p), ("x_src", c_void_p), ("x_dst", c_void_p), ("edge_attr", c_void_p),
         ("ldx_src", c_int64), ("ldx_dst", c_int64), ("n_src", c_int64), ("n_dst", c_int64),
-        ("E", c_int64),
+        ("E", c_int64), ("E_dev", c_void_p),
     ]
 
 
@@ -387,6 +387,9 @@ def _declare(lib):
     lib.ggnn_heads_classifier.restype = c_int
     lib.ggnn_heads_classifier.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.ggnn_heads_classifier_n.restype = c_int
+    lib.ggnn_heads_classifier_n.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.ggnn_step_update.restype = c_int
     lib.ggnn_step_update.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                      c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]

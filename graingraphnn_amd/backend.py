@@ -15,11 +15,14 @@ from ._lib import (AggregateArgs, AggregateBwdArgs, AggregateEncArgs, DecCellArg
 
 class CSR:
     """Destination-grouped edge list of one edge type (all int32, device resident)."""
-    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E")
+    __slots__ = ("rowptr", "col", "perm", "row", "unit_ptr", "units", "E", "E_dev")
 
-    def __init__(self, rowptr, col, perm, row, unit_ptr, units, E):
+    def __init__(self, rowptr, col, perm, row, unit_ptr, units, E, E_dev=None):
         self.rowptr, self.col, self.perm, self.row = rowptr, col, perm, row
         self.unit_ptr, self.units, self.E = unit_ptr, units, E
+        # int64 [1] on the device or None: the number of edges the per-edge kernels read at RUN time (tables that are
+        # rebuilt in place under captured launches: GrainRollout's event loop; include/ggnn.h, ggnn_prepare_edge.E_dev)
+        self.E_dev = E_dev
 
 
 def _require_cuda(*tensors):
@@ -104,18 +107,39 @@ class HipBackend:
         (one host sync, only when a topology is first seen)."""
         return self.build_csr_batch([(edge_index, n_src, n_dst)])[0]
 
-    def build_csr_batch(self, lists, check=True):
+    def csr_arena_words(self, E_cap, n_dst):
+        """int32 words of one list's tables inside a caller-owned arena (build_csr_batch(..., into=)), for up to E_cap edges."""
+        r4 = lambda n: (n + 3) & ~3
+        return 2 * r4(n_dst + 1) + 3 * r4(max(int(E_cap), 1)) + 8 * self.lib.ggnn_csr_max_units(int(E_cap), n_dst) + 4 \
+            + r4(self.lib.ggnn_csr_workspace_bytes(int(E_cap), n_dst) // 4 + 1)
+
+    def build_csr_batch(self, lists, check=True, into=None):
         """[(edge_index [2, E] int64 cuda, n_src, n_dst)] -> [CSR]: ggnn_build_csr_batch, up to four lists per sequence of
         launches (engine.GraphCSR builds the three edge types of a topology in one; a topological event rebuilds them),
         one range check = one host synchronisation behind the last (`check=False`: lists the caller has validated -- the
-        kernels skip an out-of-range edge either way --: no read-back, the host goes on enqueueing)."""
+        kernels skip an out-of-range edge either way --: no read-back, the host goes on enqueueing).
+        `into` = (arena int32 tensor, [E_cap per list]) with check=False, at most four lists: the tables are REBUILT IN
+        PLACE -- list k's tables start at the same words of the arena for any E <= E_cap[k] (csr_arena_words), so launches
+        captured on an earlier, larger version of the list keep reading valid tables."""
         out, todo = [], list(lists)
+        if into is not None and (check or len(todo) > 4 or len(into[1]) != len(todo)):
+            raise _lib.GGNNError("build_csr_batch: `into` needs check=False and one capacity per list (at most four lists)")
         while todo:
             chunk, todo = todo[:4], todo[4:]
             arr = (_lib.CsrArgs * len(chunk))()
             keep = []
             arena = None
-            if not check:
+            starts = None
+            if into is not None:
+                arena, starts, at = [into[0], 0], [], 0
+                for (ei_, _, n_dst), cap in zip(chunk, into[1]):
+                    if int(ei_.size(1)) > cap:
+                        raise _lib.GGNNError("build_csr_batch: a list grew beyond the capacity of its arena")
+                    starts.append((at, cap))
+                    at += self.csr_arena_words(cap, n_dst)
+                if at > into[0].numel() or into[0].dtype != torch.int32 or not into[0].is_cuda:
+                    raise _lib.GGNNError("build_csr_batch: the arena is too small for these capacities")
+            elif not check:
                 # unchecked builds run once per topological event: every table of the chunk out of ONE allocation (two
                 # dozen allocator calls and six fills otherwise; the unit table's unused tail and the range flags that
                 # nobody reads stay uninitialised)
@@ -131,19 +155,28 @@ class HipBackend:
                     t = arena[0][arena[1]:arena[1] + n]
                     arena[1] += (n + 3) & ~3
                 return t if shape is None else t.view(shape)
-            for a, (edge_index, n_src, n_dst) in zip(arr, chunk):
+            for k, (a, (edge_index, n_src, n_dst)) in enumerate(zip(arr, chunk)):
                 _require_cuda(edge_index)
                 if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
                     raise _lib.GGNNError("edge_index must be int64 [2, E]")
                 ei = edge_index.contiguous()
                 E, dev = ei.size(1), ei.device
+                cap = E
+                if starts is not None:   # this list's tables at their fixed place, laid out for its capacity
+                    arena[1], cap = starts[k]
+                pad = lambda n: None if cap == E else arena.__setitem__(1, arena[1] + ((max(cap, 1) + 3) & ~3) - ((n + 3) & ~3))
                 rowptr = take(n_dst + 1, dev=dev)
                 col = take(max(E, 1), dev=dev)
+                pad(max(E, 1))
                 perm = take(max(E, 1), dev=dev)
+                pad(max(E, 1))
                 row = take(max(E, 1), dev=dev)
+                pad(max(E, 1))
                 unit_ptr = take(n_dst + 1, dev=dev)
                 n_units = self.lib.ggnn_csr_max_units(E, n_dst)
                 units = take(8 * n_units, True, (n_units, 8), dev)
+                if cap != E:
+                    arena[1] += 8 * (self.lib.ggnn_csr_max_units(cap, n_dst) - n_units)
                 flags = take(2, True, dev=dev)
                 nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
                 ws = take(nbytes // 4 + 1, dev=dev).view(torch.uint8)[:nbytes] if arena is not None else \
@@ -176,6 +209,7 @@ class HipBackend:
             a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
             a.einfo = einfo.data_ptr()
             a.ldx_src, a.ldx_dst, a.E, a.f_src = xs.stride(0), xd.stride(0), ea.numel(), xs.size(1)
+            a.E_dev = ptr(getattr(csr, "E_dev", None))   # (a topology that shrinks in place under captured launches)
         self._launch(self.lib.ggnn_edge_prepare, "ggnn_edge_prepare", arr, len(items), _lib.current_stream())
 
     # -- projection --------------------------------------------------------------------
@@ -872,18 +906,21 @@ class HipBackend:
             a.edge_attr, a.x_src, a.x_dst = ea.data_ptr(), xs.data_ptr(), xd.data_ptr()
             a.einfo = einfo.data_ptr()
             a.ldx_src, a.ldx_dst, a.E, a.f_src = xs.stride(0), xd.stride(0), ea.numel(), xs.size(1)
+            a.E_dev = ptr(getattr(csr, "E_dev", None))   # (a topology that shrinks in place under captured launches)
         self._launch(self.lib.ggnn_step_refresh_prepare, "ggnn_step_refresh_prepare", ptr(x_joint), x_joint.size(0),
                      x_joint.stride(0), ptr(x_grain), x_grain.size(0), x_grain.stride(0), zmax, ptr(flags), arr,
                      len(items), None if mj is None else ptr(mj), None if mg is None else ptr(mg), _lib.current_stream())
 
     def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
-                         edge_event, edge):
-        _require_cuda(h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp, edge_event, edge)
+                         edge_event, edge, E_dev=None):
+        """`E_dev` (int64 [1], device): the number of edges at RUN time (ggnn_heads_classifier_n; edge_index_jj's own width is
+        then the capacity the launch is sized for)."""
+        _require_cuda(h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp, edge_event, edge, E_dev)
         E = edge_index_jj.size(1)
-        check(self.lib.ggnn_heads_classifier(ptr(h_joint), h_joint.size(0), ptr(edge_index_jj), E,
-                                             ptr(edge_attr_jj), ptr(w_node), ptr(w_edge),
-                                             ptr(node_tmp), ptr(edge_event), ptr(edge),
-                                             _lib.current_stream()), "ggnn_heads_classifier")
+        check(self.lib.ggnn_heads_classifier_n(ptr(h_joint), h_joint.size(0), ptr(edge_index_jj), E, ptr(E_dev),
+                                               ptr(edge_attr_jj), ptr(w_node), ptr(w_edge),
+                                               ptr(node_tmp), ptr(edge_event), ptr(edge),
+                                               _lib.current_stream()), "ggnn_heads_classifier")
 
     # -- rollout-step glue -------------------------------------------------------------
     def step_update(self, x_joint, x_grain, y_joint, y_grain, dz, zmax, flags):
@@ -932,11 +969,12 @@ class HipBackend:
                                           _lib.current_stream()), "ggnn_detect_events")
 
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
-        """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E])."""
+        """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E][, E_dev int64 [1] or None])."""
         _require_cuda(x_joint, x_grain, flags)
         arr = (RefreshEdge * max(len(edges), 1))()
-        for k, (ei, xs, xd, ea) in enumerate(edges):
+        for k, (ei, xs, xd, ea, *rest) in enumerate(edges):
             _require_cuda(ei, xs, xd, ea)
+            arr[k].E_dev = ptr(rest[0]) if rest else None
             arr[k].edge_index, arr[k].x_src, arr[k].x_dst = ei.data_ptr(), xs.data_ptr(), xd.data_ptr()
             arr[k].edge_attr = ea.data_ptr()
             arr[k].ldx_src, arr[k].ldx_dst = xs.stride(0), xd.stride(0)

@@ -90,11 +90,13 @@ __device__ __forceinline__ void edge_prepare_body(const PrepareArgs& P, int blk,
   int k = 0;
   while (k + 1 < P.n_et && blk >= P.b_off[k + 1]) ++k;
   const ggnn_prepare_edge& T = P.et[k];
+  const int64_t E = T.E_dev ? *T.E_dev : T.E;   // (E_dev: a captured launch sized for T.E edges on a list that has shrunk in place)
   const int64_t p0 = (int64_t)(blk - P.b_off[k]) * 256, p = p0 + threadIdx.x;
+  if (p0 >= E + GGNN_UNIT_EDGES) return;        // (uniform per workgroup: before the barrier below)
   float rec[GGNN_EINFO_ROW];
 #pragma unroll
   for (int c = 0; c < GGNN_EINFO_ROW; ++c) rec[c] = 0.f;
-  if (p < T.E) {  // the last GGNN_UNIT_EDGES records are zero padding
+  if (p < E) {  // the last GGNN_UNIT_EDGES records are zero padding
     const float* xs = T.x_src + (int64_t)T.col[p] * T.ldx_src;
     const float* xd = T.x_dst + (int64_t)T.row[p] * T.ldx_dst;
 #pragma unroll
@@ -120,7 +122,7 @@ __device__ __forceinline__ void edge_prepare_body(const PrepareArgs& P, int blk,
 #pragma unroll
   for (int c = 0; c < GGNN_EINFO_ROW / 4; ++c) mine[c] = (f32x4){rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]};
   __syncthreads();
-  const int64_t n_rec = min((int64_t)256, T.E + GGNN_UNIT_EDGES - p0);  // records of this workgroup
+  const int64_t n_rec = min((int64_t)256, E + GGNN_UNIT_EDGES - p0);  // records of this workgroup
   const f32x4* src = reinterpret_cast<const f32x4*>(s_rec);
   f32x4* dst = reinterpret_cast<f32x4*>(T.einfo + p0 * GGNN_EINFO_ROW);
 #pragma unroll

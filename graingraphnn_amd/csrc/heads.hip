@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256) void heads_classifier_node_kernel(
 }
 
 __global__ __launch_bounds__(256) void heads_classifier_edge_kernel(
-    const float* __restrict__ node_tmp, int64_t n_joint, const int64_t* __restrict__ ei, int64_t E,
-    const float* __restrict__ edge_attr, const float* __restrict__ w_edge,
+    const float* __restrict__ node_tmp, int64_t n_joint, const int64_t* __restrict__ ei, int64_t E_cap,
+    const int64_t* __restrict__ E_dev, const float* __restrict__ edge_attr, const float* __restrict__ w_edge,
     float* __restrict__ edge_event, float* __restrict__ edge) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t E = E_dev ? *E_dev : E_cap;   // (E_dev: include/ggnn.h, ggnn_prepare_edge)
   if (e >= E) return;
   const int64_t s = ei[e], d = ei[E + e];
   if ((uint64_t)s >= (uint64_t)n_joint || (uint64_t)d >= (uint64_t)n_joint) {
@@ -224,6 +225,14 @@ extern "C" int ggnn_heads_classifier(const float* h_joint, int64_t n_joint,
                                      const float* edge_attr_jj, const float* w_node,
                                      const float* w_edge, float* node_tmp, float* edge_event,
                                      float* edge, ggnn_stream_t stream) {
+  return ggnn_heads_classifier_n(h_joint, n_joint, edge_index_jj, E, nullptr, edge_attr_jj, w_node, w_edge, node_tmp, edge_event,
+                                 edge, stream);
+}
+
+extern "C" int ggnn_heads_classifier_n(const float* h_joint, int64_t n_joint, const int64_t* edge_index_jj, int64_t E,
+                                       const int64_t* E_dev, const float* edge_attr_jj, const float* w_node,
+                                       const float* w_edge, float* node_tmp, float* edge_event, float* edge,
+                                       ggnn_stream_t stream) {
   using namespace ggnn;
   if (!h_joint || !w_node || !w_edge || !node_tmp || n_joint <= 0 || E < 0) return GGNN_EINVAL;
   if (E > 0 && (!edge_index_jj || !edge_attr_jj || !edge_event || !edge)) return GGNN_EINVAL;
@@ -234,6 +243,6 @@ extern "C" int ggnn_heads_classifier(const float* h_joint, int64_t n_joint,
                      h_joint, n_joint, w_node, node_tmp);
   if (E > 0)
     hipLaunchKernelGGL(heads_classifier_edge_kernel, dim3((unsigned)nb_edge), dim3(256), 0, s,
-                       node_tmp, n_joint, edge_index_jj, E, edge_attr_jj, w_edge, edge_event, edge);
+                       node_tmp, n_joint, edge_index_jj, E, E_dev, edge_attr_jj, w_edge, edge_event, edge);
   return launch_status();
 }

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void step_refresh_kernel(
   while (k + 1 < R.n_et && eg >= R.e_off[k + 1]) ++k;
   const ggnn_refresh_edge& T = R.et[k];
   const int64_t e = eg - R.e_off[k];
-  const int64_t s = T.edge_index[e], d = T.edge_index[T.E + e];
+  const int64_t E = T.E_dev ? *T.E_dev : T.E;   // (E_dev: include/ggnn.h, ggnn_prepare_edge)
+  if (e >= E) return;
+  const int64_t s = T.edge_index[e], d = T.edge_index[E + e];
   if ((uint64_t)s >= (uint64_t)T.n_src || (uint64_t)d >= (uint64_t)T.n_dst) {
     T.edge_attr[e] = NAN;  // never reached for an edge_index that passed ggnn_build_csr
     return;

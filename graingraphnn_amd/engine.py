@@ -20,9 +20,11 @@ ET = Tuple[str, str, str]
 class GraphCSR:
     """Destination-grouped neighbour lists of the three edge types of one topology."""
 
-    def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int], trusted: bool = False):
+    def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int], trusted: bool = False, into=None, counts=None):
         """trusted: the lists come from the library's own topology update (validated on the host, topology.py): the
-        range check of the build -- a read-back, i.e. a host synchronisation -- is skipped."""
+        range check of the build -- a read-back, i.e. a host synchronisation -- is skipped.
+        into = (arena, {et: capacity}): the tables are rebuilt IN PLACE inside a caller-owned arena (backend.build_csr_batch);
+        counts = {et: int64 [1] device tensor}: where the per-edge kernels find the number of edges at run time (CSR.E_dev)."""
         self.csr = {}
         self.edge_index = {}
         self.n_nodes = dict(n_nodes)
@@ -31,7 +33,11 @@ class GraphCSR:
                 raise KeyError(f"edge_index_dict lacks edge type {et}")
             self.edge_index[et] = edge_index_dict[et].contiguous()
         lists = [(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]]) for et in EDGE_TYPES]
-        if hasattr(backend, "build_csr_batch"):   # the three edge types in one sequence of launches, one synchronisation
+        if into is not None:
+            built = backend.build_csr_batch(lists, check=False, into=(into[0], [into[1][et] for et in EDGE_TYPES]))
+            for et, csr in zip(EDGE_TYPES, built):
+                csr.E_dev = None if counts is None else counts[et]
+        elif hasattr(backend, "build_csr_batch"):   # the three edge types in one sequence of launches, one synchronisation
             built = backend.build_csr_batch(lists, check=not trusted) if trusted else backend.build_csr_batch(lists)
         else:
             built = [backend.build_csr(*l) for l in lists]

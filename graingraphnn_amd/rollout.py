@@ -146,6 +146,11 @@ class GrainRollout:
         outputs.  Called once at construction and after every topological event (`trusted`: lists the
         library's own update produced -- no range check, no read-back)."""
         dev = self.x["joint"].device
+        if getattr(self, "_cap", None) is not None:
+            if trusted and edge_attr_dict is None and all(edge_index_dict[et].size(1) <= self._cap["cap"][et] for et in EDGE_TYPES):
+                return self._install_topology_in_place(edge_index_dict)
+            self._cap = None   # (a caller's own topology, or one that grew: back to buffers of its own; the segment graphs go)
+            self._graph_fwd = self._graph_ref = None
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
         self.graph = graph_for(self.be, self.edge_index, self.n_nodes, trusted)
         if trusted and edge_attr_dict is None:
@@ -200,6 +205,83 @@ class GrainRollout:
         self._x_written_outside()
         self._graphs = None
         self._seen = None
+
+    # -- a topology that changes IN PLACE (event mode) ---------------------------------------------------------------------
+    def _enter_capacity_mode(self):
+        """enable_events(): the edge lists, the CSR tables and every per-edge buffer move into allocations of the CURRENT
+        lists' size -- the capacity: grain eliminations only remove edges, neighbour switches keep their number -- and stay
+        there: an event rewrites them in place (_install_topology_in_place), the per-edge kernels read the number of edges from
+        device memory (CSR.E_dev), and the hipGraphs of step_events()' two segments keep replaying across events (SURVEY 8
+        f-2: "keep the device rollout running between events"; round 5 dropped every graph with the topology and ran the
+        steps around an event eagerly).  The fused cells need nothing: their grids follow the node sets, their edge windows
+        come from the rebuilt row pointers, and an edge count that is too large only widens a clamp onto stale, valid entries."""
+        be, dev = self.be, self.x["joint"].device
+        if not hasattr(be, "csr_arena_words") or os.environ.get("GGNN_EVENT_GRAPHS", "1") == "0":
+            self._cap = None
+            return
+        cap = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
+        r4 = lambda n: (n + 3) & ~3
+        rec = {et: (cap[et] + _lib.GGNN_UNIT_EDGES) * _lib.GGNN_EINFO_ROW for et in EDGE_TYPES}
+        off, at = {}, 0
+        for name, size in [(("ea", et), cap[et]) for et in EDGE_TYPES] + [(("ea2", et), cap[et]) for et in EDGE_TYPES] \
+                + [(("rec", et), rec[et]) for et in EDGE_TYPES] + [(("rec2", et), rec[et]) for et in EDGE_TYPES] \
+                + [("edge_event", cap[ET_JJ]), ("edge", 2 * cap[ET_JJ])]:
+            off[name] = at
+            at += r4(max(size, 1))
+        old_ea = {et: self.edge_attr[et] for et in EDGE_TYPES}
+        old_ei = {et: self.edge_index[et] for et in EDGE_TYPES}
+        self._cap = {
+            "cap": cap, "off": off, "buf": torch.empty(at, dtype=torch.float32, device=dev),
+            "lists": {et: torch.empty(2 * max(cap[et], 1), dtype=torch.int64, device=dev) for et in EDGE_TYPES},
+            "arena": torch.empty(sum(be.csr_arena_words(cap[et], self.n_nodes[et[-1]]) for et in EDGE_TYPES), dtype=torch.int32,
+                                 device=dev),
+            "counts": torch.zeros(len(EDGE_TYPES), dtype=torch.int64, device=dev),
+            "counts_host": torch.zeros(len(EDGE_TYPES), dtype=torch.int64).pin_memory(),
+        }
+        self._install_topology_in_place(old_ei)
+        for et in EDGE_TYPES:
+            self.edge_attr[et].copy_(old_ea[et])
+        self._graph_fwd = self._graph_ref = None
+
+    def _install_topology_in_place(self, edge_index_dict):
+        """The lists of `edge_index_dict` (device tensors, or already views of the list buffers) become the topology: copied
+        into the list buffers, their sizes into the device-side counts, the CSR tables rebuilt inside the arena, the per-edge
+        tensors re-cut as views of the same allocations.  No address changes: the segment graphs stay."""
+        C, dev = self._cap, self.x["joint"].device
+        E = {et: int(edge_index_dict[et].size(1)) for et in EDGE_TYPES}
+        self.edge_index = {}
+        for k, et in enumerate(EDGE_TYPES):
+            dst = C["lists"][et][:2 * E[et]].view(2, E[et])
+            src = edge_index_dict[et]
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+            self.edge_index[et] = dst
+            C["counts_host"][k] = E[et]
+        C["counts"].copy_(C["counts_host"], non_blocking=True)
+        counts = {et: C["counts"][k:k + 1] for k, et in enumerate(EDGE_TYPES)}
+        from .engine import GraphCSR
+        self.graph = GraphCSR(self.be, self.edge_index, self.n_nodes, trusted=True, into=(C["arena"], C["cap"]), counts=counts)
+        buf, off = C["buf"], C["off"]
+        cut = lambda name, n, shape=None: buf[off[name]:off[name] + n] if shape is None else buf[off[name]:off[name] + n].view(shape)
+        rows = lambda et: E[et] + _lib.GGNN_UNIT_EDGES
+        self.edge_attr = {et: cut(("ea", et), E[et]) for et in EDGE_TYPES}
+        self._ea_other = {et: cut(("ea2", et), E[et]) for et in EDGE_TYPES}
+        self.einfo = {et: cut(("rec", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW)) for et in EDGE_TYPES}
+        self._einfo_other = {et: cut(("rec2", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW))
+                             for et in EDGE_TYPES}
+        self._einfo_fresh = False
+        if not hasattr(self, "pred"):
+            self.pred = {}
+        self.pred["edge_event"] = cut("edge_event", E[ET_JJ])
+        self.pred["edge"] = cut("edge", 2 * E[ET_JJ], (E[ET_JJ], 2))
+        self._x_written_outside()
+        self._graphs = None
+        self._seen = None
+        # a segment graph was captured for the sizes of ITS moment: it stays valid while nothing has grown since
+        got = C.get("captured")
+        if got is not None and any(E[et] > got[et] for et in EDGE_TYPES):
+            self._graph_fwd = self._graph_ref = None
+            C["captured"] = None
 
     def _x_written_outside(self):
         """x was (or is about to be) advanced by something other than the overlapped two-stream step / the speculative
@@ -405,7 +487,7 @@ class GrainRollout:
             enc, dec = self.packed["C"]
             h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], x, ea, einfo, x_read)
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
-                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"], E_dev=self.graph.csr[ET_JJ].E_dev)
 
         if joint:
             run_encoder_decoder_multi(be, [(*self.packed["R"], self.ws["R"]), (*self.packed["C"], self.ws["C"])],
@@ -413,7 +495,7 @@ class GrainRollout:
             be.heads_regressor(self.ws["R"].h2["joint"], self.ws["R"].h2["grain"], x["grain"], self.w_reg[0],
                                self.w_reg[1], p["joint"], p["grain"], p["grain_area"])
             be.heads_classifier(self.ws["C"].h2["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
-                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"], E_dev=self.graph.csr[ET_JJ].E_dev)
         elif self._side is None:
             regressor()
             classifier()
@@ -446,7 +528,7 @@ class GrainRollout:
             be.grain_centres(self.graph.csr[("joint", "pull", "grain")], x["joint"], x["grain"],
                              self.domain_factor, self.domain_offset)
         be.step_refresh(x["joint"], x["grain"], self.zmax, self.flags,
-                        [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et]) for et in EDGE_TYPES])
+                        [(self.graph.edge_index[et], x[et[0]], x[et[-1]], ea[et], self.graph.csr[et].E_dev) for et in EDGE_TYPES])
 
     def _capture(self, n_steps: int = 1):
         """Record `n_steps` steps into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm); the
@@ -518,14 +600,20 @@ class GrainRollout:
         self._quiet_steps = 0
         self._graph_fwd = self._graph_ref = None
         self.grain_events, self.switched = [], []
+        self._enter_capacity_mode()
 
     def _run_segment(self, which):
         """The two halves of a step, replayed from their own hipGraphs once the topology has been
         quiet for two steps (a capture is not worth it while events fire every step)."""
         fn = self._enqueue_forward_update if which == "fwd" else self._enqueue_refresh
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
-        if self.use_graph and self._quiet_steps >= 2:
+        in_place = getattr(self, "_cap", None) is not None   # (the graphs survive events: captured once, at the first step)
+        if self.use_graph and (self._quiet_steps >= 2 or in_place):
             if getattr(self, attr) is None:
+                if in_place:   # valid for as long as no list is longer than now (_install_topology_in_place)
+                    now = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
+                    got = self._cap.get("captured")
+                    self._cap["captured"] = now if got is None else {et: min(now[et], got[et]) for et in EDGE_TYPES}
                 st = torch.cuda.Stream()
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
@@ -946,15 +1034,27 @@ class GrainRollout:
         if len(events):
             N["live"][:] = mg[:, 0]
             self._live_grain.copy_(B["live"], non_blocking=True)
-        d = torch.empty(2 * (n_pp + n_pq), dtype=torch.int64, device=dev)
-        d.copy_(B["lists"][:2 * (n_pp + n_pq)], non_blocking=True)
-        jj, jg = d[:2 * n_pp].view(2, n_pp), d[2 * n_pp:].view(2, n_pq)
-        new_ei = {ET_JJ: jj, JG: jg, GJ: torch.stack((jg[1], jg[0]))}
+        C = getattr(self, "_cap", None)
+        if C is not None and n_pp <= C["cap"][ET_JJ] and n_pq <= C["cap"][JG] and n_pq <= C["cap"][GJ]:
+            # the lists go straight into the buffers the topology lives in (_install_topology_in_place finds them there)
+            jj, jg = C["lists"][ET_JJ][:2 * n_pp].view(2, n_pp), C["lists"][JG][:2 * n_pq].view(2, n_pq)
+            jj.copy_(B["lists"][:2 * n_pp].view(2, n_pp), non_blocking=True)
+            jg.copy_(B["lists"][2 * n_pp:2 * (n_pp + n_pq)].view(2, n_pq), non_blocking=True)
+            gj = C["lists"][GJ][:2 * n_pq].view(2, n_pq)
+            torch.stack((jg[1], jg[0]), out=gj)
+            new_ei = {ET_JJ: jj, JG: jg, GJ: gj}
+        else:
+            d = torch.empty(2 * (n_pp + n_pq), dtype=torch.int64, device=dev)
+            d.copy_(B["lists"][:2 * (n_pp + n_pq)], non_blocking=True)
+            jj, jg = d[:2 * n_pp].view(2, n_pp), d[2 * n_pp:].view(2, n_pq)
+            new_ei = {ET_JJ: jj, JG: jg, GJ: torch.stack((jg[1], jg[0]))}
         t3 = time.perf_counter()
         self._set_topology(new_ei, lasting=False, trusted=True)
         if ses is not None:
+            jj, jg = self.edge_index[ET_JJ], self.edge_index[JG]
             self._topo = (ses, jj, jg, (jj._version, jg._version))
-        self._graph_fwd = self._graph_ref = None
+        if getattr(self, "_cap", None) is None:   # (in place: the segment graphs stay)
+            self._graph_fwd = self._graph_ref = None
         if T is not None:
             T.update(readback_s=t1 - t0, rewiring_s=t2 - t1, upload_enqueue_s=t3 - t2, set_topology_s=time.perf_counter() - t3)
         return events, switches

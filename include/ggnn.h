@@ -117,6 +117,10 @@ typedef struct ggnn_prepare_edge {
   const float* x_dst;     /* [n_dst, ldx_dst] */
   float* einfo;           /* [E + GGNN_UNIT_EDGES, GGNN_EINFO_ROW] out, 16-byte aligned (tail rows are padding) */
   int64_t ldx_src, ldx_dst, E, f_src; /* 3 <= f_src <= 12 source features */
+  const int64_t* E_dev;   /* ABI 25, or NULL: the number of edges read from DEVICE memory when the kernel runs (E is then the
+                             capacity the launch is sized for, *E_dev <= E) -- a launch captured in a hipGraph follows an
+                             edge list that SHRINKS in place (GrainRollout's event loop: grain eliminations remove edges;
+                             the lists, CSR tables and per-edge buffers keep their addresses and capacity) */
 } ggnn_prepare_edge;
 int ggnn_edge_prepare(const ggnn_prepare_edge* edges, int n_edge_types, ggnn_stream_t stream);
 
@@ -532,6 +536,12 @@ int ggnn_heads_classifier(const float* h_joint, int64_t n_joint, const int64_t* 
                           int64_t E, const float* edge_attr_jj, const float* w_node,
                           const float* w_edge, float* node_tmp, float* edge_event, float* edge,
                           ggnn_stream_t stream);
+/* ABI 25: the same with the number of edges read from device memory when the kernels run (E_dev != NULL: edge_index_jj is
+ * [2, *E_dev], E the capacity the launch is sized for; see ggnn_prepare_edge.E_dev). */
+int ggnn_heads_classifier_n(const float* h_joint, int64_t n_joint, const int64_t* edge_index_jj,
+                            int64_t E, const int64_t* E_dev, const float* edge_attr_jj, const float* w_node,
+                            const float* w_edge, float* node_tmp, float* edge_event, float* edge,
+                            ggnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Rollout-step glue on device.
@@ -644,6 +654,7 @@ typedef struct ggnn_refresh_edge {
   const float* x_dst;
   float* edge_attr; /* [E] out */
   int64_t ldx_src, ldx_dst, n_src, n_dst, E;
+  const int64_t* E_dev;      /* ABI 25, or NULL: as in ggnn_prepare_edge (edge_index is [2, *E_dev] then) */
 } ggnn_refresh_edge;
 int ggnn_step_refresh(float* x_joint, int64_t n_joint, int64_t ldx_joint, float* x_grain,
                       int64_t n_grain, int64_t ldx_grain, float zmax, const int32_t* flags,

@@ -458,7 +458,8 @@ class TorchEmulatorBackend:
         self.edge_prepare(items)
 
     def heads_classifier(self, h_joint, edge_index_jj, edge_attr_jj, w_node, w_edge, node_tmp,
-                         edge_event, edge):
+                         edge_event, edge, E_dev=None):
+        assert E_dev is None or int(E_dev[0]) == edge_index_jj.size(1)   # (eager: the count in memory is the tensors' size)
         node_tmp[:, :6] = h_joint @ w_node.t()
         s, d, a = edge_index_jj[0], edge_index_jj[1], edge_attr_jj
         edge[:, 0] = torch.tanh(node_tmp[s, 0] + node_tmp[d, 3] + w_edge[0] * a + w_edge[3])
@@ -511,7 +512,7 @@ class TorchEmulatorBackend:
         if int(flags[1]):
             x_joint[:, 2] = zmax
             x_grain[:, 2] = zmax
-        for ei, xs, xd, ea in edges:
+        for ei, xs, xd, ea, *_ in edges:
             rel = xs[ei[0], :2] - xd[ei[1], :2]
             rel = torch.where(rel > 0.5, -1.0, torch.where(rel < -0.5, 1.0, 0.0)) + rel
             ea.copy_(torch.sqrt(rel[:, 0] ** 2 + rel[:, 1] ** 2))

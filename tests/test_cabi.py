@@ -68,6 +68,6 @@ def test_struct_sizes_match_the_header():
     """ctypes mirrors of the POD argument blocks (natural alignment, no packing)."""
     assert ctypes.sizeof(_lib.AggregateArgs) == 8 * 8 + 7 * 8 + 8 * 4
     assert ctypes.sizeof(_lib.AggregateBwdArgs) == 18 * 8 + 8 * 8 + 8 * 4
-    assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 4 * 8
+    assert ctypes.sizeof(_lib.PrepareEdge) == 7 * 8 + 4 * 8 + 8     # (+ E_dev, ABI 25)
     assert ctypes.sizeof(_lib.EpilogueArgs) == 7 * 8 + 2 * 8 + 4 * 4 + 8 + 8 + 2 * 4
-    assert ctypes.sizeof(_lib.RefreshEdge) == 4 * 8 + 5 * 8
+    assert ctypes.sizeof(_lib.RefreshEdge) == 4 * 8 + 5 * 8 + 8    # (+ E_dev, ABI 25)

@@ -1052,6 +1052,56 @@ def test_event_rollout_reproduces_reference_trajectory(use_graph):
 
 
 @torch.no_grad()
+def test_segment_graphs_survive_topological_events(monkeypatch):
+    """SURVEY 8 f-2, "keep the device rollout running between events": with events enabled the edge lists, the CSR tables and
+    every per-edge buffer live in allocations of the initial lists' size and are rewritten IN PLACE by an event; the hipGraphs
+    of step_events()' two segments are captured once and replayed across events (the per-edge kernels read the number of edges
+    from device memory: ggnn_prepare_edge.E_dev).  The reference's own event trajectory (22 + 75 eliminations in steps 3-4): the
+    same graph objects before and after, state and lists bit for bit those of a rollout that rebuilds everything per event and
+    launches eagerly (GGNN_EVENT_GRAPHS=0), the lists shrinking inside unchanged storage."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+
+    def make(in_place):
+        monkeypatch.setenv("GGNN_EVENT_GRAPHS", "1" if in_place else "0")
+        X = tt(x, DEV)
+        ro = GrainRollout(R, Cm, X, tt(ei, DEV), tt(ea, DEV), 6, use_graph=in_place, refresh_centres=True)
+        ro.enable_events(mask, 1e-4, 0.6)
+        return ro, X
+    ra, Xa = make(True)
+    rb, Xb = make(False)
+    assert ra._cap is not None and rb._cap is None
+    base = {et: ra.edge_index[et].data_ptr() for et in EDGE_TYPES}
+    graphs, sizes = None, []
+    for step in range(1, 6):
+        if step == 5:
+            # a caller's own topology ends the arrangement (buffers of its own again, the graphs go); the loop goes on
+            ra._set_topology({et: v.clone() for et, v in ra.edge_index.items()},
+                             {et: v.clone().view(-1, 1) for et, v in ra.edge_attr.items()})
+            assert ra._cap is None and ra._graph_fwd is None and ra._graph_ref is None
+        pa, ea_, sa = ra.step_events()
+        pb, eb_, sb = rb.step_events()
+        assert ea_.tolist() == eb_.tolist() and np.array_equal(sa, sb), step
+        for k in ("joint", "grain", "grain_area", "edge_event", "edge"):
+            assert torch.equal(pa[k], pb[k]), (step, k)
+        for nt in Xa:
+            assert torch.equal(Xa[nt], Xb[nt]), (step, nt)
+        for et in EDGE_TYPES:
+            assert torch.equal(ra.edge_index[et], rb.edge_index[et]), (step, et)
+            assert torch.equal(ra.edge_attr[et], rb.edge_attr[et]), (step, et)
+            assert step == 5 or ra.edge_index[et].data_ptr() == base[et], (step, et)   # in place: the storage never moves
+        if step == 1:
+            graphs = (ra._graph_fwd, ra._graph_ref)
+            assert graphs[0] is not None and graphs[1] is not None
+        if step < 5:
+            assert (ra._graph_fwd, ra._graph_ref) == graphs, step       # captured once, never dropped
+        sizes.append(ra.edge_index[JJ].size(1))
+    assert sizes == [708, 708, 576, 156, 36]                            # steps 3-5 removed edges
+
+
+@torch.no_grad()
 def test_step_events_loop_follows_new_weights_between_its_steps():
     """A step_events() loop checks a SAMPLE of the parameter tensors per step (the full walk is a seventh of an eventful
     step: every 16th step only): load_state_dict between two steps must still be seen at once -- the loop continues bit for
