@@ -25,6 +25,51 @@ class CSR:
         self.E_dev = E_dev
 
 
+class CsrInPlace:
+    """See HipBackend.csr_in_place."""
+
+    def __init__(self, backend, shapes, device):
+        if not 1 <= len(shapes) <= 4:
+            raise _lib.GGNNError("csr_in_place: one to four lists")
+        self.be, self.shapes = backend, [tuple(int(v) for v in s) for s in shapes]
+        lib = backend.lib
+        r4 = lambda n: (n + 3) & ~3
+        words = sum(backend.csr_arena_words(cap, n_dst) for cap, _, n_dst in self.shapes)
+        self.arena = torch.empty(words, dtype=torch.int32, device=device)
+        self.args = (_lib.CsrArgs * len(self.shapes))()
+        self.csr, at = [], 0
+
+        def take(n, shape=None):
+            nonlocal at
+            t = self.arena[at:at + n]
+            at += r4(n)
+            return t if shape is None else t.view(shape)
+        for a, (cap, n_src, n_dst) in zip(self.args, self.shapes):
+            rowptr, col, perm, row = take(n_dst + 1), take(max(cap, 1)), take(max(cap, 1)), take(max(cap, 1))
+            unit_ptr = take(n_dst + 1)
+            n_units = lib.ggnn_csr_max_units(cap, n_dst)
+            units, flags = take(8 * n_units, (n_units, 8)), take(2)
+            nbytes = lib.ggnn_csr_workspace_bytes(cap, n_dst)
+            ws = take(nbytes // 4 + 1)
+            a.n_src, a.n_dst = n_src, n_dst
+            a.rowptr, a.col, a.perm, a.row = rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), row.data_ptr()
+            a.unit_ptr, a.units, a.flags = unit_ptr.data_ptr(), units.data_ptr(), flags.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes   # (sized for the capacity: enough for any shorter list)
+            self.csr.append(CSR(rowptr, col, perm, row, unit_ptr, units, 0))
+
+    def rebuild(self, lists):
+        for a, csr, ei, (cap, _, _) in zip(self.args, self.csr, lists, self.shapes):
+            if ei.dtype != torch.int64 or ei.dim() != 2 or ei.size(0) != 2 or not ei.is_contiguous() or not ei.is_cuda:
+                raise _lib.GGNNError("edge_index must be a contiguous int64 [2, E] device tensor")
+            E = ei.size(1)
+            if E > cap:
+                raise _lib.GGNNError("csr_in_place: a list grew beyond its capacity")
+            a.edge_index, a.E = ei.data_ptr(), E
+            csr.E = E
+        _lib.check(self.be.lib.ggnn_build_csr_batch(self.args, len(self.shapes), _lib.current_stream()), "ggnn_build_csr_batch")
+        return self.csr
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -112,6 +157,13 @@ class HipBackend:
         r4 = lambda n: (n + 3) & ~3
         return 2 * r4(n_dst + 1) + 3 * r4(max(int(E_cap), 1)) + 8 * self.lib.ggnn_csr_max_units(int(E_cap), n_dst) + 4 \
             + r4(self.lib.ggnn_csr_workspace_bytes(int(E_cap), n_dst) // 4 + 1)
+
+    def csr_in_place(self, shapes, device):
+        """Tables that are rebuilt in place: `shapes` = [(E_cap, n_src, n_dst)] (at most four lists) -> a CsrInPlace whose
+        `rebuild([edge_index [2, E <= E_cap]])` fills the SAME device tables for the new lists (unchecked: validated lists)
+        and returns the same CSR objects with their E updated -- tensors of capacity size, addresses that never change, so
+        launches captured on an earlier, longer version of a list keep reading valid tables."""
+        return CsrInPlace(self, shapes, device)
 
     def build_csr_batch(self, lists, check=True, into=None):
         """[(edge_index [2, E] int64 cuda, n_src, n_dst)] -> [CSR]: ggnn_build_csr_batch, up to four lists per sequence of

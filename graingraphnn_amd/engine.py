@@ -33,7 +33,11 @@ class GraphCSR:
                 raise KeyError(f"edge_index_dict lacks edge type {et}")
             self.edge_index[et] = edge_index_dict[et].contiguous()
         lists = [(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]]) for et in EDGE_TYPES]
-        if into is not None:
+        if into is not None and not isinstance(into, tuple):   # a backend.CsrInPlace: the same tables, refilled
+            built = into.rebuild([l[0] for l in lists])
+            for et, csr in zip(EDGE_TYPES, built):
+                csr.E_dev = None if counts is None else counts[et]
+        elif into is not None:
             built = backend.build_csr_batch(lists, check=False, into=(into[0], [into[1][et] for et in EDGE_TYPES]))
             for et, csr in zip(EDGE_TYPES, built):
                 csr.E_dev = None if counts is None else counts[et]

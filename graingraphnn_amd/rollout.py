@@ -216,7 +216,7 @@ class GrainRollout:
         steps around an event eagerly).  The fused cells need nothing: their grids follow the node sets, their edge windows
         come from the rebuilt row pointers, and an edge count that is too large only widens a clamp onto stale, valid entries."""
         be, dev = self.be, self.x["joint"].device
-        if not hasattr(be, "csr_arena_words") or os.environ.get("GGNN_EVENT_GRAPHS", "1") == "0":
+        if not hasattr(be, "csr_in_place") or os.environ.get("GGNN_EVENT_GRAPHS", "1") == "0":
             self._cap = None
             return
         cap = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
@@ -233,8 +233,7 @@ class GrainRollout:
         self._cap = {
             "cap": cap, "off": off, "buf": torch.empty(at, dtype=torch.float32, device=dev),
             "lists": {et: torch.empty(2 * max(cap[et], 1), dtype=torch.int64, device=dev) for et in EDGE_TYPES},
-            "arena": torch.empty(sum(be.csr_arena_words(cap[et], self.n_nodes[et[-1]]) for et in EDGE_TYPES), dtype=torch.int32,
-                                 device=dev),
+            "csr": be.csr_in_place([(cap[et], self.n_nodes[et[0]], self.n_nodes[et[-1]]) for et in EDGE_TYPES], dev),
             "counts": torch.zeros(len(EDGE_TYPES), dtype=torch.int64, device=dev),
             "counts_host": torch.zeros(len(EDGE_TYPES), dtype=torch.int64).pin_memory(),
         }
@@ -260,7 +259,7 @@ class GrainRollout:
         C["counts"].copy_(C["counts_host"], non_blocking=True)
         counts = {et: C["counts"][k:k + 1] for k, et in enumerate(EDGE_TYPES)}
         from .engine import GraphCSR
-        self.graph = GraphCSR(self.be, self.edge_index, self.n_nodes, trusted=True, into=(C["arena"], C["cap"]), counts=counts)
+        self.graph = GraphCSR(self.be, self.edge_index, self.n_nodes, trusted=True, into=C["csr"], counts=counts)
         buf, off = C["buf"], C["off"]
         cut = lambda name, n, shape=None: buf[off[name]:off[name] + n] if shape is None else buf[off[name]:off[name] + n].view(shape)
         rows = lambda et: E[et] + _lib.GGNN_UNIT_EDGES
