@@ -608,6 +608,14 @@ class GrainRollout:
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
         in_place = getattr(self, "_cap", None) is not None   # (the graphs survive events: captured once, at the first step)
         if self.use_graph and (self._quiet_steps >= 2 or in_place):
+            # a segment graph holds the addresses of the buffers that were current when it was captured: run_events() leaves
+            # other ones current (its slots' predictions, the other set of edge lengths / records) -- captured again then
+            key = (self.edge_attr[ET_JJ].data_ptr(), self.einfo[ET_JJ].data_ptr(), self.pred["joint"].data_ptr(),
+                   self.pred["edge_event"].data_ptr(), self.graph.csr[ET_JJ].rowptr.data_ptr())
+            keys = self.__dict__.setdefault("_segment_keys", {})
+            if getattr(self, attr) is not None and keys.get(attr) != key:
+                setattr(self, attr, None)
+            keys[attr] = key
             if getattr(self, attr) is None:
                 if in_place:   # valid for as long as no list is longer than now (_install_topology_in_place)
                     now = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}

@@ -1102,6 +1102,42 @@ def test_segment_graphs_survive_topological_events(monkeypatch):
 
 
 @torch.no_grad()
+def test_step_events_and_run_events_mix_on_one_rollout():
+    """step_events()' segment graphs hold the addresses of the buffers that were current at their capture; run_events() leaves
+    its own slots' predictions and the other set of edge lengths / records current.  Alternating the two on ONE rollout
+    (quiet steps, the reference trajectory's two eventful steps, a step behind them) gives, bit for bit, what step_events()
+    alone gives."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+
+    def make():
+        X = tt(x, DEV)
+        ro = GrainRollout(R, Cm, X, tt(ei, DEV), tt(ea, DEV), 6, use_graph=True, refresh_centres=True, joint_launches=False,
+                          concurrent=True)
+        ro.enable_events(mask, 1e-4, 0.6)
+        return ro, X
+    ra, Xa = make()
+    rb, Xb = make()
+    plan = [("step", 1), ("run", 1), ("step", 1), ("run", 1), ("step", 1)]   # steps 3 and 4 are the eventful ones
+    for how, n in plan:
+        if how == "run":
+            ev_a, sw_a = ra.run_events(n)
+        else:
+            out = [ra.step_events()[1:] for _ in range(n)]
+            ev_a, sw_a = [o[0] for o in out], [o[1] for o in out]
+        out = [rb.step_events()[1:] for _ in range(n)]
+        for k in range(n):
+            assert ev_a[k].tolist() == out[k][0].tolist() and np.array_equal(sw_a[k], out[k][1]), (how, k)
+        for nt in Xa:
+            assert torch.equal(Xa[nt], Xb[nt]), (how, nt)
+        for et in EDGE_TYPES:
+            assert torch.equal(ra.edge_index[et], rb.edge_index[et]) and torch.equal(ra.edge_attr[et], rb.edge_attr[et]), (how, et)
+    assert ra.edge_index[JJ].size(1) == 36
+
+
+@torch.no_grad()
 def test_step_events_loop_follows_new_weights_between_its_steps():
     """A step_events() loop checks a SAMPLE of the parameter tensors per step (the full walk is a seventh of an eventful
     step: every 16th step only): load_state_dict between two steps must still be seen at once -- the loop continues bit for
