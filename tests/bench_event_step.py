@@ -129,14 +129,16 @@ out = {
     "static_step_us": round(static_us, 1), "quiet_event_step_us": round(quiet_us, 1),
     "quiet_over_static": round(quiet_us / static_us, 3),
     "eventful_step_ms": round(med("forwards_update_ms") + med("apply_events_ms") + med("refresh_ms"), 3),
-    "of_which": {"forwards_update_eager_ms": med("forwards_update_ms"), "apply_events_ms": med("apply_events_ms"),
+    "topology_in_place": getattr(ro, "_cap", None) is not None,   # (the segments' hipGraphs survive events: DESIGN section 6)
+    "of_which": {"forwards_update_ms": med("forwards_update_ms"), "apply_events_ms": med("apply_events_ms"),
                  "apply_events_host_pieces_ms": {k: med(k) for k in ("readback_ms", "rewiring_ms", "upload_enqueue_ms",
                                                                       "set_topology_ms")},
                  "refresh_ms": med("refresh_ms")},
     "grains_per_eventful_step": [r["grains"] for r in steady],
     "statistic": ("cfg3, median of 5 eventful steps after the first; forwards / apply / refresh each bracketed by a "
                   "synchronisation (apply_events' own pieces are host-side intervals: the uploads and the CSR rebuild they "
-                  "enqueue finish inside the apply bracket)"),
+                  "enqueue finish inside the apply bracket); with the topology in place the forwards and the refresh are "
+                  "graph replays, otherwise (GGNN_EVENT_GRAPHS=0) eager launches"),
     "steady_eventful": [steady_eventful("cfg1", 4, 8), steady_eventful("cfg2", 35, 8), steady_eventful("cfg3", 20, 12)],
 }
 print(json.dumps(out))
