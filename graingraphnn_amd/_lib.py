@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "ggnn_pack_weights_batch", "ggnn_pack_weights_backward_batch",
     "ggnn_wgrad_splits", "ggnn_wgrad", "ggnn_rowgemm_workspace_bytes", "ggnn_rowgemm_pack", "ggnn_rowgemm", "ggnn_rowgemm_pair", "ggnn_heads_regressor_backward",
     "ggnn_adam_step", "ggnn_masked_mse", "ggnn_sum_rows", "ggnn_pack_weights", "ggnn_pack_weights_backward",
-    "ggnn_heads_classifier", "ggnn_heads_classifier_n", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
+    "ggnn_heads_classifier", "ggnn_heads_classifier_n", "ggnn_step_update", "ggnn_grain_centres", "ggnn_detect_events", "ggnn_detect_events_n", "ggnn_topology_update", "ggnn_topology_open", "ggnn_topology_apply",
     "ggnn_topology_counts", "ggnn_topology_export", "ggnn_topology_close", "ggnn_step_refresh",
     "ggnn_workspace_bytes",
 )
@@ -402,6 +402,9 @@ def _declare(lib):
     lib.ggnn_detect_events.restype = c_int
     lib.ggnn_detect_events.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64,
                                        c_float, c_void_p, c_void_p, c_void_p]
+    lib.ggnn_detect_events_n.restype = c_int
+    lib.ggnn_detect_events_n.argtypes = [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p,
+                                         c_float, c_void_p, c_void_p, c_void_p]
     lib.ggnn_topology_update.restype = c_int
     lib.ggnn_topology_update.argtypes = [POINTER(TopologyArgs)]
     lib.ggnn_topology_open.restype = c_int

@@ -1007,18 +1007,18 @@ class HipBackend:
               "ggnn_grain_centres")
 
     def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,
-                      logit_threshold, flags, range_word=None):
+                      logit_threshold, flags, range_word=None, E_dev=None):
         """flags[0:2] (int32, device) <- (#grain events, #switch candidates); with `range_word` (int32 [1]) flags[2] <- the
-        word, which is cleared; see ggnn.h."""
-        _require_cuda(grain_area, live_grain, edge_event, edge_index_jj, flags, range_word)
+        word, which is cleared; `E_dev` (int64 [1], device): the number of junction edges at RUN time; see ggnn.h."""
+        _require_cuda(grain_area, live_grain, edge_event, edge_index_jj, flags, range_word, E_dev)
         if live_grain.dtype != torch.int32 or flags.dtype != torch.int32 or flags.numel() < (2 if range_word is None else 3):
             raise _lib.GGNNError("live_grain / flags must be int32 (flags: two words, three with a range word)")
         if range_word is not None and (range_word.dtype != torch.int32 or range_word.numel() < 1):
             raise _lib.GGNNError("range_word must be an int32 word")
-        check(self.lib.ggnn_detect_events(ptr(grain_area), ptr(live_grain), grain_area.numel(),
-                                          float(area_threshold), ptr(edge_event), ptr(edge_index_jj),
-                                          edge_index_jj.size(1), float(logit_threshold), ptr(flags), ptr(range_word),
-                                          _lib.current_stream()), "ggnn_detect_events")
+        check(self.lib.ggnn_detect_events_n(ptr(grain_area), ptr(live_grain), grain_area.numel(),
+                                            float(area_threshold), ptr(edge_event), ptr(edge_index_jj),
+                                            edge_index_jj.size(1), ptr(E_dev), float(logit_threshold), ptr(flags),
+                                            ptr(range_word), _lib.current_stream()), "ggnn_detect_events")
 
     def step_refresh(self, x_joint, x_grain, zmax, flags, edges):
         """edges: list of (edge_index [2,E] int64, x_src, x_dst, edge_attr_out [E][, E_dev int64 [1] or None])."""

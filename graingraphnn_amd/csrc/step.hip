@@ -104,8 +104,10 @@ __global__ __launch_bounds__(256) void grain_centres_kernel(
 __global__ __launch_bounds__(256) void detect_events_kernel(
     const float* __restrict__ grain_area, const int32_t* __restrict__ live_grain, int64_t n_grain,
     float area_threshold, const float* __restrict__ edge_event, const int64_t* __restrict__ ei_jj,
-    int64_t E, float logit_threshold, int32_t* __restrict__ flags, int32_t* __restrict__ range_word) {
+    int64_t E_cap, const int64_t* __restrict__ E_dev, float logit_threshold, int32_t* __restrict__ flags,
+    int32_t* __restrict__ range_word) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t E = E_dev ? *E_dev : E_cap;   // (E_dev: include/ggnn.h, ggnn_prepare_edge)
   // (the caller's fp16-range word travels with the counts and starts its next use clean: one thread moves it)
   if (range_word != nullptr && t == 0) flags[2] = atomicExch(range_word, 0);
   bool g = false, e = false;
@@ -205,6 +207,14 @@ extern "C" int ggnn_detect_events(const float* grain_area, const int32_t* live_g
                                   float area_threshold, const float* edge_event,
                                   const int64_t* edge_index_jj, int64_t E, float logit_threshold,
                                   int32_t* flags, int32_t* range_word, ggnn_stream_t stream) {
+  return ggnn_detect_events_n(grain_area, live_grain, n_grain, area_threshold, edge_event, edge_index_jj, E, nullptr,
+                              logit_threshold, flags, range_word, stream);
+}
+
+extern "C" int ggnn_detect_events_n(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
+                                    float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
+                                    int64_t E, const int64_t* E_dev, float logit_threshold, int32_t* flags,
+                                    int32_t* range_word, ggnn_stream_t stream) {
   using namespace ggnn;
   if (!grain_area || !live_grain || !flags || n_grain <= 0 || E < 0) return GGNN_EINVAL;
   if (E > 0 && (!edge_event || !edge_index_jj)) return GGNN_EINVAL;
@@ -212,7 +222,7 @@ extern "C" int ggnn_detect_events(const float* grain_area, const int32_t* live_g
   if (nblk >= INT32_MAX) return GGNN_EINVAL;
   if (hipMemsetAsync(flags, 0, (range_word ? 3 : 2) * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return GGNN_ELAUNCH;
   hipLaunchKernelGGL(detect_events_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                     grain_area, live_grain, n_grain, area_threshold, edge_event, edge_index_jj, E,
+                     grain_area, live_grain, n_grain, area_threshold, edge_event, edge_index_jj, E, E_dev,
                      logit_threshold, flags, range_word);
   return launch_status();
 }

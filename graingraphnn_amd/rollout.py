@@ -137,7 +137,7 @@ class GrainRollout:
         if force or self._wver != (_param_version(self.rmodel), _param_version(self.cmodel)):
             self._pack_weights()
             self._graphs = None
-            self._graph_fwd = self._graph_ref = None
+            self._drop_segment_graphs()
             self._spec = None   # (run_events' captured blocks hold the old buffers' addresses too)
 
     def _set_topology(self, edge_index_dict, edge_attr_dict=None, lasting=True, trusted=False):
@@ -150,7 +150,7 @@ class GrainRollout:
             if trusted and edge_attr_dict is None and all(edge_index_dict[et].size(1) <= self._cap["cap"][et] for et in EDGE_TYPES):
                 return self._install_topology_in_place(edge_index_dict)
             self._cap = None   # (a caller's own topology, or one that grew: back to buffers of its own; the segment graphs go)
-            self._graph_fwd = self._graph_ref = None
+            self._drop_segment_graphs()
         self.edge_index = {et: edge_index_dict[et] for et in EDGE_TYPES}
         self.graph = graph_for(self.be, self.edge_index, self.n_nodes, trusted)
         if trusted and edge_attr_dict is None:
@@ -240,7 +240,7 @@ class GrainRollout:
         self._install_topology_in_place(old_ei)
         for et in EDGE_TYPES:
             self.edge_attr[et].copy_(old_ea[et])
-        self._graph_fwd = self._graph_ref = None
+        self._drop_segment_graphs()
 
     def _install_topology_in_place(self, edge_index_dict):
         """The lists of `edge_index_dict` (device tensors, or already views of the list buffers) become the topology: copied
@@ -263,11 +263,16 @@ class GrainRollout:
         buf, off = C["buf"], C["off"]
         cut = lambda name, n, shape=None: buf[off[name]:off[name] + n] if shape is None else buf[off[name]:off[name] + n].view(shape)
         rows = lambda et: E[et] + _lib.GGNN_UNIT_EDGES
-        self.edge_attr = {et: cut(("ea", et), E[et]) for et in EDGE_TYPES}
-        self._ea_other = {et: cut(("ea2", et), E[et]) for et in EDGE_TYPES}
-        self.einfo = {et: cut(("rec", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW)) for et in EDGE_TYPES}
-        self._einfo_other = {et: cut(("rec2", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW))
-                             for et in EDGE_TYPES}
+        sets = [{et: cut(("ea", et), E[et]) for et in EDGE_TYPES}, {et: cut(("ea2", et), E[et]) for et in EDGE_TYPES}]
+        recs = [{et: cut(("rec", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW)) for et in EDGE_TYPES},
+                {et: cut(("rec2", et), rows(et) * _lib.GGNN_EINFO_ROW, (rows(et), _lib.GGNN_EINFO_ROW)) for et in EDGE_TYPES}]
+        # which of the two sets is the current one follows the speculative loop's slot parity while its state lives
+        # (run_events' graphs alternate the sets by slot: _spec_state); step_events() alone stays on the first
+        S = getattr(self, "_spec", None)
+        par = (S["cur"] & 1) if (S is not None and S.get("in_place")) else 0
+        C["sets"], C["recs"] = sets, recs
+        self.edge_attr, self._ea_other = sets[par], sets[1 - par]
+        self.einfo, self._einfo_other = recs[par], recs[1 - par]
         self._einfo_fresh = False
         if not hasattr(self, "pred"):
             self.pred = {}
@@ -279,8 +284,10 @@ class GrainRollout:
         # a segment graph was captured for the sizes of ITS moment: it stays valid while nothing has grown since
         got = C.get("captured")
         if got is not None and any(E[et] > got[et] for et in EDGE_TYPES):
-            self._graph_fwd = self._graph_ref = None
+            self._drop_segment_graphs()
             C["captured"] = None
+            if S is not None:
+                S["graphs"], S["captured"] = {}, None
 
     def _x_written_outside(self):
         """x was (or is about to be) advanced by something other than the overlapped two-stream step / the speculative
@@ -597,9 +604,14 @@ class GrainRollout:
         self._ev_flags = torch.zeros(2, dtype=torch.int32, device=dev)
         self._ev_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self._quiet_steps = 0
-        self._graph_fwd = self._graph_ref = None
+        self._drop_segment_graphs()
         self.grain_events, self.switched = [], []
         self._enter_capacity_mode()
+
+    def _drop_segment_graphs(self):
+        """The hipGraphs of step_events()' two segments, all variants (one per set of buffers they were captured on)."""
+        self._graph_fwd = self._graph_ref = None
+        self._segment_graphs = {}
 
     def _run_segment(self, which):
         """The two halves of a step, replayed from their own hipGraphs once the topology has been
@@ -608,15 +620,14 @@ class GrainRollout:
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
         in_place = getattr(self, "_cap", None) is not None   # (the graphs survive events: captured once, at the first step)
         if self.use_graph and (self._quiet_steps >= 2 or in_place):
-            # a segment graph holds the addresses of the buffers that were current when it was captured: run_events() leaves
-            # other ones current (its slots' predictions, the other set of edge lengths / records) -- captured again then
-            key = (self.edge_attr[ET_JJ].data_ptr(), self.einfo[ET_JJ].data_ptr(), self.pred["joint"].data_ptr(),
+            # a segment graph holds the addresses of the buffers that were current when it was captured; run_events() leaves
+            # other ones current (its slots' predictions, the other set of edge lengths / records): a graph per set
+            key = (which, self.edge_attr[ET_JJ].data_ptr(), self.einfo[ET_JJ].data_ptr(), self.pred["joint"].data_ptr(),
                    self.pred["edge_event"].data_ptr(), self.graph.csr[ET_JJ].rowptr.data_ptr())
-            keys = self.__dict__.setdefault("_segment_keys", {})
-            if getattr(self, attr) is not None and keys.get(attr) != key:
-                setattr(self, attr, None)
-            keys[attr] = key
-            if getattr(self, attr) is None:
+            graphs = self.__dict__.setdefault("_segment_graphs", {})
+            if getattr(self, attr) is None:   # (dropped from outside: `ro._graph_fwd = None`)
+                graphs.pop(key, None)
+            if key not in graphs:
                 if in_place:   # valid for as long as no list is longer than now (_install_topology_in_place)
                     now = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
                     got = self._cap.get("captured")
@@ -628,7 +639,8 @@ class GrainRollout:
                     with torch.cuda.graph(g, stream=st):
                         fn()
                 torch.cuda.current_stream().wait_stream(st)
-                setattr(self, attr, g)
+                graphs[key] = g
+            setattr(self, attr, graphs[key])
             getattr(self, attr).replay()
         elif which == "fwd":
             # eager launches (the steps around an event: every event replaces the topology the graphs were captured on) are
@@ -698,6 +710,41 @@ class GrainRollout:
         dev = self.x["joint"].device
         D = 2 * max(1, int(self.EVENTS_UNROLL))
         per_edge = ("edge_event", "edge")   # the predictions that follow the junction edge list
+        C = getattr(self, "_cap", None)
+        if C is not None:
+            # The topology lives in place (_enter_capacity_mode): the two sets of edge lengths / records are the SAME
+            # allocations before and after an event, the slots' per-edge predictions are cut from one allocation of the
+            # capacity, and the graphs of the blocks -- whose per-edge kernels read the number of edges from device memory --
+            # stay valid across events for as long as no list has grown: an event re-cuts the views, nothing else.
+            Ecap, E = C["cap"][ET_JJ], self.pred["edge_event"].numel()
+            Ea = (Ecap + 3) & ~3
+            if S is None or not S.get("in_place") or S["D"] != D or S["flat"].numel() != 3 * D * Ea:
+                S = self._spec = {
+                    "in_place": True, "cur": 0, "D": D, "graphs": {}, "captured": None, "xs_valid": None,
+                    "flat": torch.empty(3 * D * Ea, dtype=torch.float32, device=dev),
+                    "xs": [{nt: torch.empty_like(self.x[nt]) for nt in NODE_TYPES} for _ in range(D)],
+                    "cen": [torch.empty(self.n_nodes["grain"], 2, device=dev) for _ in range(D)],
+                    "evf": [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "evh": [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(D)],
+                    "zf": [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "rw": [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(D)],
+                    "pred": [{k: torch.empty_like(v) for k, v in self.pred.items() if k not in per_edge} for _ in range(D)]}
+            flat = S["flat"]
+            for i, slot in enumerate(S["pred"]):
+                slot["edge_event"] = flat[3 * i * Ea:3 * i * Ea + E]
+                slot["edge"] = flat[3 * i * Ea + Ea:3 * i * Ea + Ea + 2 * E].view(E, 2)
+            par = S["cur"] & 1
+            S["topology"], S["ea"], S["einfo"] = self.graph, C["sets"], C["recs"]
+            if self.edge_attr is not C["sets"][par]:   # (step_events() in between left the first set current: move over)
+                for et in EDGE_TYPES:
+                    C["sets"][par][et].copy_(self.edge_attr[et])
+                self._einfo_fresh = False
+            self.edge_attr, self._ea_other = C["sets"][par], C["sets"][1 - par]
+            self.einfo, self._einfo_other = C["recs"][par], C["recs"][1 - par]
+            sizes = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
+            if S["captured"] is not None and any(sizes[et] > S["captured"][et] for et in EDGE_TYPES):
+                S["graphs"], S["captured"] = {}, None
+            return S
         if S is not None and S["D"] == D:
             # a new topology (after an event): the per-node slots, the centre snapshots and the (pinned) count words stay --
             # the node sets never change -- only the per-edge predictions follow the new edge list
@@ -751,7 +798,7 @@ class GrainRollout:
             enc, dec = self.packed["C"]
             h, _ = run_encoder_decoder(be, enc, dec, self.graph, self.ws["C"], xc, ea, einfo)
             be.heads_classifier(h["joint"], self.graph.edge_index[ET_JJ], ea[ET_JJ], self.w_cls[0],
-                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"])
+                                self.w_cls[1], self._tmp, p["edge_event"], p["edge"], E_dev=self.graph.csr[ET_JJ].E_dev)
             headed.record(st_c)
         be.heads_regressor_update(hr["joint"], hr["grain"], x["joint"], x["grain"], self.w_reg[0], self.w_reg[1],
                                   p["joint"], p["grain"], p["grain_area"], self.dz, self.zmax, zf)
@@ -771,7 +818,8 @@ class GrainRollout:
             st_d.wait_event(headed)    # ... and its edge_event (the classifier's cells have, too)
             # (the slot's range word travels in flags[2] and is cleared by the same launch: it is sticky on the device)
             be.detect_events(p["grain_area"], self._live_grain, self.area_threshold, p["edge_event"],
-                             self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot], S["rw"][slot])
+                             self.graph.edge_index[ET_JJ], self._logit_trigger, S["evf"][slot], S["rw"][slot],
+                             E_dev=self.graph.csr[ET_JJ].E_dev)
             S["evh"][slot].copy_(S["evf"][slot], non_blocking=True)
         return [ready, lead, updated, headed]
 
@@ -804,6 +852,10 @@ class GrainRollout:
         if self.use_graph and n > 1:
             g = S["graphs"].get((slots[0], n))
             if g is None:
+                if S.get("in_place"):   # valid for as long as no list is longer than now (_spec_state)
+                    now = {et: int(self.edge_index[et].size(1)) for et in EDGE_TYPES}
+                    got = S["captured"]
+                    S["captured"] = now if got is None else {et: min(now[et], got[et]) for et in EDGE_TYPES}
                 st = torch.cuda.Stream()
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
@@ -1061,7 +1113,7 @@ class GrainRollout:
             jj, jg = self.edge_index[ET_JJ], self.edge_index[JG]
             self._topo = (ses, jj, jg, (jj._version, jg._version))
         if getattr(self, "_cap", None) is None:   # (in place: the segment graphs stay)
-            self._graph_fwd = self._graph_ref = None
+            self._drop_segment_graphs()
         if T is not None:
             T.update(readback_s=t1 - t0, rewiring_s=t2 - t1, upload_enqueue_s=t3 - t2, set_topology_s=time.perf_counter() - t3)
         return events, switches

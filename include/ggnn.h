@@ -583,6 +583,12 @@ int ggnn_grain_centres(const int32_t* rowptr, const int32_t* col, const float* x
 int ggnn_detect_events(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
                        float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
                        int64_t E, float logit_threshold, int32_t* flags, int32_t* range_word, ggnn_stream_t stream);
+/* ABI 25: the same with the number of junction edges read from device memory when the kernel runs (E_dev != NULL:
+ * edge_index_jj is [2, *E_dev], E the capacity the launch is sized for; see ggnn_prepare_edge.E_dev). */
+int ggnn_detect_events_n(const float* grain_area, const int32_t* live_grain, int64_t n_grain,
+                         float area_threshold, const float* edge_event, const int64_t* edge_index_jj,
+                         int64_t E, const int64_t* E_dev, float logit_threshold, int32_t* flags,
+                         int32_t* range_word, ggnn_stream_t stream);
 /* The host-side topology update those counts trigger: one call of the reference's `Cmodel.update`
  * (models.py:612-842 with delete_grain_index :861-893, switching_edge_index :896-1051, point_in_triangle :1055-1070,
  * periodic_move :1103-1106), nucleation off.  HOST memory throughout, no stream: grains of `grain_event` (those below the

@@ -109,7 +109,8 @@ quiet_us = t_quiet / (25 * ro.EVENTS_UNROLL) * 1e3
 rounds = []
 for rnd in range(6):
     ro.area_threshold = -1.0
-    ro.run_events(1)
+    ro.step_events()   # (a quiet step between the rounds; run_events(1) here would leave ANOTHER slot's buffers current every
+    #                     round, and the segment graphs -- one per set of buffers -- would be captured inside the timed pieces)
     ro.area_threshold, _ = kth_area_threshold(ro, 3)
     ro._einfo_fresh = False
     t_fwd, _ = timed(lambda: ro._run_segment("fwd"))

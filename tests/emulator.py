@@ -501,7 +501,7 @@ class TorchEmulatorBackend:
             x_grain[g, :2] = m
 
     def detect_events(self, grain_area, live_grain, area_threshold, edge_event, edge_index_jj,
-                      logit_threshold, flags, range_word=None):
+                      logit_threshold, flags, range_word=None, E_dev=None):
         if range_word is not None:
             flags[2] = int(range_word[0])
             range_word.zero_()

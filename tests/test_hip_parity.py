@@ -1165,6 +1165,52 @@ def test_step_events_loop_follows_new_weights_between_its_steps():
         assert torch.equal(X[nt], X2[nt]), nt
 
 
+@torch.no_grad()
+def test_speculative_blocks_keep_their_graphs_across_events():
+    """run_events() on a topology that changes in place: the ring of slots and the hipGraphs of its blocks are the SAME objects
+    before and after the trajectory's eventful steps (round 5 and the first half of round 6 rebuilt the ring and re-captured
+    every block after an event), blocks captured before an event are replayed behind it on the shrunken lists, and the
+    result is step_events()' bit for bit.  Two passes of 12 steps (events at 3, 4, 5 of the first), weights x0.5 so that the
+    second pass is quiet and long enough to reuse 2-, 4- and 8-step blocks."""
+    from graingraphnn_amd import GrainRollout
+    x, ei, ea = load_graph("40")
+    R, Cm = product_models(10020, 1.0, DEV)
+    mask = {"grain": np.ones((118, 1)), "joint": np.ones((236, 1))}
+
+    def make():
+        X = tt(x, DEV)
+        ro = GrainRollout(R, Cm, X, tt(ei, DEV), tt(ea, DEV), 6, use_graph=True, refresh_centres=True, joint_launches=False,
+                          concurrent=True)
+        ro.enable_events(mask, 1e-4, 0.6)
+        return ro, X
+    ra, Xa = make()
+    rb, Xb = make()
+    ra.run_events(2)                                   # quiet: a 1-step and (eagerly) ... blocks; the ring exists now
+    S, graphs_before = ra._spec, dict(ra._spec["graphs"])
+    assert S.get("in_place") and ra._cap is not None
+    ev_a, sw_a = ra.run_events(3)                      # steps 3-5: 22, 75 and 27 grains
+    assert [len(e) for e in ev_a] == [22, 75, 27]
+    assert ra._spec is S and all(S["graphs"].get(k) is g for k, g in graphs_before.items())
+    for _ in range(5):
+        rb.step_events()
+    for nt in Xa:
+        assert torch.equal(Xa[nt], Xb[nt]), nt
+    ra.area_threshold = rb.area_threshold = -1.0      # the rest of the trajectory kept quiet: blocks of 1, 2, 4, 8 steps
+    ra.edge_threshold = rb.edge_threshold = 0.999999
+    ra._logit_trigger = rb._logit_trigger = float(np.log(0.999999 / (1.0 - 0.999999)) - 1e-4)
+    ra.run_events(15)
+    captured = dict(S["graphs"])
+    assert ra._spec is S and len(captured) >= 2
+    ra.run_events(16)                                  # the graphs captured so far keep serving (new block shapes may join them)
+    assert all(S["graphs"].get(k) is g for k, g in captured.items())
+    for _ in range(31):
+        rb.step_events()
+    for nt in Xa:
+        assert torch.equal(Xa[nt], Xb[nt]), nt
+    for et in EDGE_TYPES:
+        assert torch.equal(ra.edge_index[et], rb.edge_index[et]) and torch.equal(ra.edge_attr[et], rb.edge_attr[et]), et
+
+
 @pytest.mark.parametrize("use_graph,chunks", [(True, (5,)), (True, (3, 2)), (False, (1, 4))])
 @torch.no_grad()
 def test_speculative_event_loop_equals_step_events(use_graph, chunks):
