@@ -98,6 +98,24 @@ def steady_eventful(workload, k, n_steps):
             "quiet_step_events_ms_per_step_afterwards": round(t_quiet / 10, 3), "stopped": stopped}
 
 
+def sparse_events(period, cycles):
+    """run_events() with ~3 grains eliminated every `period` steps (cfg3): wall time per step -- what an event costs a loop
+    that is otherwise quiet (on the in-place topology the ring of slots and the block graphs survive it)."""
+    ro, X, mask = rollout_for("cfg3")
+    ro.enable_events(mask, area_threshold=-1.0, edge_threshold=0.999999)
+
+    def cycle():
+        ro.area_threshold = -1.0
+        ro.run_events(period - 1)
+        ro.area_threshold, _ = kth_area_threshold(ro, 3)
+        return len(ro.run_events(1)[0][0])
+    for _ in range(3):
+        cycle()
+    t, grains = timed(lambda: [cycle() for _ in range(cycles)])
+    return {"workload": "cfg3", "an_event_every_steps": period, "steps_timed": period * cycles, "grains_per_event": sorted(set(grains)),
+            "ms_per_step": round(t / (period * cycles), 3), "steps_per_s": round(period * cycles / t * 1e3, 1)}
+
+
 ro, X, mask = rollout_for("cfg3")
 ro.run(4 * ro.RUN_UNROLL)
 t_static, _ = timed(lambda: ro.run(20 * ro.RUN_UNROLL))
@@ -141,5 +159,6 @@ out = {
                   "enqueue finish inside the apply bracket); with the topology in place the forwards and the refresh are "
                   "graph replays, otherwise (GGNN_EVENT_GRAPHS=0) eager launches"),
     "steady_eventful": [steady_eventful("cfg1", 4, 8), steady_eventful("cfg2", 35, 8), steady_eventful("cfg3", 20, 12)],
+    "sparse_events_run_events": [sparse_events(16, 8), sparse_events(64, 3)],
 }
 print(json.dumps(out))

@@ -2,7 +2,10 @@
 """GPU fuzz (not collected by pytest): event-driven rollouts on the 40 um and 120 um fixtures under random models and thresholds --
 GrainRollout.step_events with the SCAN ORACLE's rewiring (oracle/topology_scan.py, the reference's formulation) against
 GrainRollout.run_events with the product's native rewiring (the library's topology session: ggnn_topology_apply): same events, switches, edge lists, masks and
-state bit for bit, or the same refusal at the same step.   python tests/fuzz_events.py [n_cases]"""
+state bit for bit, or a refusal by both.  (The native update validates the lists before it rewrites them and refuses a structure with a
+doubly joined junction pair; the scan formulation -- the reference's -- rewrites such a structure once more and fails one step later: a collapse
+from 401 to 32 grains in one step in the single case seen, case 63 of 120.  Such a pair of refusals one step apart is counted separately; everything
+up to the earlier refusal must still be identical.)   python tests/fuzz_events.py [n_cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +21,7 @@ from oracle import topology_scan as scan
 DEV = torch.device("cuda", 0)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rs = np.random.RandomState(7)
-tot_ev = tot_sw = refusals = 0
+tot_ev = tot_sw = refusals = apart = 0
 with torch.no_grad():
     for case in range(n_cases):
         name = "40" if case % 3 else "120"
@@ -65,9 +68,18 @@ with torch.no_grad():
             ev_b, sw_b = rb.grain_events[:], rb.switched[:]
         torch.cuda.synchronize()
         assert (err_a is None) == (err_b is None), (case, err_a, err_b)
-        n_ok = min(len(ev_a), len(ev_b)) if err_a else steps
+        # (run_events keeps a refused step as a quiet one in its lists: not a step to compare)
+        n_ok = min(len(ev_a), len(ev_b) - (1 if err_b else 0)) if err_a else steps
+        if err_a is not None and len(ev_a) != len(ev_b) - 1:
+            apart += 1
         assert err_a is not None or len(ev_a) == len(ev_b) == steps
         for k in range(n_ok):
+            if not (np.array_equal(ev_a[k], ev_b[k]) and np.array_equal(sw_a[k], sw_b[k])):
+                print(f"case {case} ({name}, seed {seed} x{scale}, area<{area_thr:g} p>{edge_thr:g}, graph={kw['use_graph']}) step {k}: "
+                      f"events a {ev_a[k].tolist()} b {ev_b[k].tolist()}; switches a {len(sw_a[k])} b {len(sw_b[k])}; "
+                      f"only in a {sorted(set(map(tuple, sw_a[k].tolist())) - set(map(tuple, sw_b[k].tolist())))[:6]}, "
+                      f"only in b {sorted(set(map(tuple, sw_b[k].tolist())) - set(map(tuple, sw_a[k].tolist())))[:6]}; "
+                      f"per step a {[len(e) for e in ev_a]} b {[len(e) for e in ev_b]}", flush=True)
             assert np.array_equal(ev_a[k], ev_b[k]) and np.array_equal(sw_a[k], sw_b[k]), (case, k)
         if err_a is None:
             for et in EDGE_TYPES:
@@ -83,4 +95,5 @@ with torch.no_grad():
         tot_sw += ns
         print(f"case {case:2d}: fixture {name:>3s} seed {seed:5d} x{scale} area<{area_thr:g} p>{edge_thr:g} {steps:2d} steps, graph={kw['use_graph']}: "
               f"{ne:4d} grains, {ns:3d} switches per step {[len(e) for e in ev_a]}" + (f"  both refused: {err_a[:50]}" if err_a else ""), flush=True)
-print(f"{n_cases} cases, {tot_ev} eliminated grains, {tot_sw} switched edges, {refusals} refused by both: identical")
+print(f"{n_cases} cases, {tot_ev} eliminated grains, {tot_sw} switched edges, {refusals} refused by both"
+      + (f" ({apart} of them one step apart: see the docstring)" if apart else "") + ": identical")
