@@ -614,8 +614,9 @@ class GrainRollout:
         self._segment_graphs = {}
 
     def _run_segment(self, which):
-        """The two halves of a step, replayed from their own hipGraphs once the topology has been
-        quiet for two steps (a capture is not worth it while events fire every step)."""
+        """The two halves of a step, replayed from their own hipGraphs: on the in-place topology (_enter_capacity_mode) from the
+        first step on and across events; otherwise once the topology has been quiet for two steps (an event then drops the
+        graphs with the topology, and a capture is not worth it while events fire every step)."""
         fn = self._enqueue_forward_update if which == "fwd" else self._enqueue_refresh
         attr = "_graph_fwd" if which == "fwd" else "_graph_ref"
         in_place = getattr(self, "_cap", None) is not None   # (the graphs survive events: captured once, at the first step)
@@ -643,8 +644,8 @@ class GrainRollout:
             setattr(self, attr, graphs[key])
             getattr(self, attr).replay()
         elif which == "fwd":
-            # eager launches (the steps around an event: every event replaces the topology the graphs were captured on) are
-            # bound by the HOST's launch rate at any graph size -- ~20 launches + stream forks of the two-stream plan take
+            # eager launches (GGNN_EVENT_GRAPHS=0 / a caller's own topology: the steps around an event, which replaces the
+            # topology the graphs were captured on) are bound by the HOST's launch rate at any graph size -- ~20 launches + stream forks of the two-stream plan take
             # 0.49 ms where the kernels take 0.35 (profiles/r6_event_step_breakdown.txt): R and C share every launch here
             self._enqueue_forward_update(joint=True)
         else:
@@ -690,8 +691,8 @@ class GrainRollout:
 
     # -- event-driven mode without a host stall per quiet step ------------------------------------------------------
     # steps per block in run_events while the topology is quiet (a graph-to-graph boundary costs ~25 us at the 10k-grain
-    # graph); after an eventful step the blocks start again at one step (enqueued eagerly: every event drops the captured
-    # graphs with the topology) and double while the steps stay quiet
+    # graph); after an eventful step the blocks start again at one step and double while the steps stay quiet (on the in-place
+    # topology their graphs are the ones captured before the event; otherwise every event drops them with the topology)
     EVENTS_UNROLL = 8
 
     def _spec_state(self):
@@ -701,7 +702,8 @@ class GrainRollout:
         before the step's refresh, its z-clamp flag (test.py:405: written by the step's Rmodel.update, read by its
         refresh), its event counts and its own fp16-range word (device + pinned host: [grains, edges, range, -]) --
         plus the two alternating sets of edge lengths / edge records (set = slot parity).  Graphs are captured per
-        (first slot, number of steps).  Rebuilt after every topology change."""
+        (first slot, number of steps).  On the in-place topology (_enter_capacity_mode) the ring and the graphs survive events
+        (the views are re-cut); otherwise the per-edge half and the graphs are rebuilt after every topology change."""
         S = getattr(self, "_spec", None)
         if S is not None and S["topology"] is self.graph and S["ea"][S["cur"] & 1] is self.edge_attr \
                 and S["einfo"][S["cur"] & 1] is self.einfo:
