@@ -609,9 +609,10 @@ int ggnn_detect_events_n(const float* grain_area, const int32_t* live_grain, int
  * Returns GGNN_OK, GGNN_EINVAL, or GGNN_ETOPOLOGY with a message in `error` (the reference asserts / raises there); on an error
  * the in/out arrays are in an undefined state: pass copies (graingraphnn_amd/topology.py does).  The room of the output lists
  * (switching_cap >= the edges above the threshold, extra_cap >= n_grain + 1) is checked before anything is rewritten.
- * Refusals where the reference would go on (reachable on degenerate lists only; the reference's own result there is an
- * artefact of tensor indexing): a junction pair of an eliminated grain joined by more than one column, and a junction with
- * fewer than three grain columns or fewer than two other neighbours in a switch (the reference raises IndexError). */
+ * Refusals where the reference would raise an IndexError of its own (reachable on degenerate lists only): a junction with
+ * fewer than three grain columns or fewer than two other neighbours in a switch.  (A junction pair of an eliminated grain
+ * joined by MORE than one column is not refused: the reference indexes the concatenated hits with the order of the edges all
+ * the same, and so does this -- rounds 5-6 refused there, one step before the reference's formulation failed by itself.) */
 typedef struct ggnn_topology_args {
   int64_t* pp;
   int64_t* pq;

@@ -2,10 +2,10 @@
 """GPU fuzz (not collected by pytest): event-driven rollouts on the 40 um and 120 um fixtures under random models and thresholds --
 GrainRollout.step_events with the SCAN ORACLE's rewiring (oracle/topology_scan.py, the reference's formulation) against
 GrainRollout.run_events with the product's native rewiring (the library's topology session: ggnn_topology_apply): same events, switches, edge lists, masks and
-state bit for bit, or a refusal by both.  (The native update validates the lists before it rewrites them and refuses a structure with a
-doubly joined junction pair; the scan formulation -- the reference's -- rewrites such a structure once more and fails one step later: a collapse
-from 401 to 32 grains in one step in the single case seen, case 63 of 120.  Such a pair of refusals one step apart is counted separately; everything
-up to the earlier refusal must still be identical.)   python tests/fuzz_events.py [n_cases]"""
+state bit for bit, or the same refusal at the same step.  (Refusals one step apart are counted separately -- everything up to the earlier one
+must still be identical: until the end of round 6 the native update refused a structure with a doubly joined junction pair that the scan
+formulation, the reference's, rewrites once more before it fails itself -- case 63 of 120, a collapse from 401 to 32 grains in one step; it
+follows the reference there now and no such pair is left in 160 cases.)   python tests/fuzz_events.py [n_cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
