@@ -5,7 +5,7 @@ GrainRollout.run_events with the product's native rewiring (the library's topolo
 state bit for bit, or the same refusal at the same step.  (Refusals one step apart are counted separately -- everything up to the earlier one
 must still be identical: until the end of round 6 the native update refused a structure with a doubly joined junction pair that the scan
 formulation, the reference's, rewrites once more before it fails itself -- case 63 of 120, a collapse from 401 to 32 grains in one step; it
-follows the reference there now and no such pair is left in 160 cases.)   python tests/fuzz_events.py [n_cases]"""
+follows the reference there now and no such pair is left in 500 cases.)   python tests/fuzz_events.py [n_cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
