@@ -15,8 +15,9 @@ and the module is in training mode, i.e. inside the reference's loop (train.py:1
     its input gradient and the hidden-state gradient of the projection through `ggnn_rowgemm` (round 4: they were
     library GEMMs) -- no BLAS call is left inside a cell;
   * the regressor's heads are `_RegressorHeads` (the inference head kernel forward, `ggnn_heads_regressor_backward`
-    + `ggnn_wgrad` backward); the classifier's pair heads are `_RowLinear` (weight gradient through `ggnn_wgrad`)
-    and a few recorded pointwise ops.
+    + `ggnn_wgrad` backward); the classifier's pair heads are `_ClassifierHeads` (the inference kernels forward, a
+    node-level backward: segment sums over the forward / reverse CSR in a fixed order, [n, 6] products; layer_size < 96:
+    `_RowLinear` on the recorded pair matrix).
 
 Under `torch.autocast(bfloat16)` (BASELINE config 5) the cells' dense products -- the decoder projection, the gate
 GEMM, its input gradient, the hidden-state gradient -- run in real bf16 arithmetic on the HIP kernels (operands rounded
@@ -55,6 +56,17 @@ class TrainTopology:
             inv = torch.empty(E, dtype=torch.int32, device=ei.device)
             inv[csr.perm[:E].long()] = torch.arange(E, dtype=torch.int32, device=ei.device)
             self.r_slot[et] = inv[self.rcsr[et].perm[:E].long()].contiguous()
+
+    def jj_index(self):
+        """int64 index tensors of the junction-junction edges for the classifier heads' backward (made once): the original
+        edge of every forward CSR slot, the forward slot of every reverse CSR slot, and the two row pointers."""
+        jj = getattr(self, "_jj", None)
+        if jj is None:
+            et = ("joint", "connect", "joint")
+            csr, rcsr, E = self.graph.csr[et], self.rcsr[et], self.graph.csr[et].E
+            jj = self._jj = {"slot_edge": csr.perm[:E].long(), "rowptr": csr.rowptr.long(),
+                             "r_slot": self.r_slot[et][:E].long(), "r_rowptr": rcsr.rowptr.long()}
+        return jj
 
 
 _topo_cache: Dict[int, TrainTopology] = {}
@@ -447,10 +459,65 @@ def regressor_forward(model, x_dict, edge_index_dict, edge_attr):
     return {"grain": y_grain, "joint": y_joint, "grain_area": area}
 
 
+class _ClassifierHeads(torch.autograd.Function):
+    """The classifier's pair heads (models.py:595-609): pair = [h_j[src] | h_j[dst] | edge length], edge = tanh(lin1(pair)),
+    edge_event = lin2(pair) -- (h_joint, edge length [E], W [3, 193] = rows of lin1 then lin2, b [3]) -> (edge [E, 2],
+    edge_event [E]).  Forward = the inference kernels (`ggnn_heads_classifier`: six partial dots per NODE, combined per
+    edge); the backward stays at the node level too: the pre-activation gradients [E, 3] are summed per source and per
+    destination junction over the reverse / forward CSR (segment sums in a fixed order: reproducible, where autograd's
+    backward of h[src] is an atomic scatter), and the hidden-state and weight gradients are [n, 6] products.  The recorded
+    formulation it replaces materialises the [E, 193] pair matrix each way (46 MB at the 10k-grain graph)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, h, ea, W, b, backend, topo):
+        h, ea = h.contiguous(), ea.contiguous().view(-1)
+        et = ("joint", "connect", "joint")
+        ei = topo.graph.edge_index[et]
+        n, E = h.size(0), ei.size(1)
+        w_node = torch.cat([W[:, :C], W[:, C:2 * C]]).contiguous()           # [6, 96]: packing.pack_classifier_heads' order
+        w_edge = torch.cat([W[:, 2 * C], b]).contiguous()                    # [6]
+        f32 = dict(dtype=torch.float32, device=h.device)
+        node_tmp, edge_event, edge = torch.empty(n, 8, **f32), torch.empty(E, **f32), torch.empty(E, 2, **f32)
+        backend.heads_classifier(h, ei, ea, w_node, w_edge, node_tmp, edge_event, edge)
+        ctx.save_for_backward(h, ea, w_node, edge)
+        ctx.misc = (backend, topo)
+        ctx.set_materialize_grads(False)
+        return edge, edge_event
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_edge, g_event):
+        h, ea, w_node, edge = ctx.saved_tensors
+        backend, topo = ctx.misc
+        et = ("joint", "connect", "joint")
+        n, E = h.size(0), edge.size(0)
+        g_pre = torch.zeros(E, 4, dtype=torch.float32, device=h.device)      # [lin1 (2) | lin2 (1) | 0]
+        if g_edge is not None:
+            g_pre[:, :2] = g_edge * (1.0 - edge * edge)
+        if g_event is not None:
+            g_pre[:, 2] = g_event
+        jj = topo.jj_index()
+        by_dst = g_pre[jj["slot_edge"]]                                       # forward CSR order: grouped by destination
+        as_dst = torch.segment_reduce(by_dst, "sum", offsets=jj["rowptr"])    # [n, 4]
+        as_src = torch.segment_reduce(by_dst[jj["r_slot"]], "sum", offsets=jj["r_rowptr"])
+        g_tmp = torch.cat([as_src[:, :3], as_dst[:, :3], as_dst.new_zeros(n, 2)], 1)   # [n, 8]: the node kernel's partial dots
+        g_h = g_tmp[:, :6] @ w_node
+        g_w_node = backend.wgrad(g_tmp, h, n, 8, C, 8, C)[0][:6]              # [6, 96]
+        g_W = torch.cat([g_w_node[:3], g_w_node[3:], (g_pre[:, :3] * ea.unsqueeze(1)).sum(0).unsqueeze(1)], 1)   # [3, 193]
+        return g_h, None, g_W, g_pre[:, :3].sum(0), None, None
+
+
 def classifier_forward(model, x_dict, edge_index_dict, edge_attr):
     """GrainNN_classifier.forward (models.py:572-611) with autograd."""
     h, graph = encoder_decoder(model, x_dict, edge_index_dict, edge_attr)
     et = ("joint", "connect", "joint")
+    if model.out_channels == C:
+        be = default_backend()
+        edge, edge_event = _ClassifierHeads.apply(h["joint"], edge_attr[et], torch.cat([model.lin1.weight, model.lin2.weight]),
+                                                  torch.cat([model.lin1.bias, model.lin2.bias]), be, train_topology(be, graph))
+        return {"edge_event": edge_event, "edge": edge}
     src, dst = graph.edge_index[et][0], graph.edge_index[et][1]
     hj = h["joint"] if model.out_channels == C else h["joint"][:, :model.out_channels]   # (padded channels: zero)
     pair = torch.cat([hj[src], hj[dst], edge_attr[et].view(-1, 1)], -1)
