@@ -153,7 +153,8 @@ class HipBackend:
         return self.build_csr_batch([(edge_index, n_src, n_dst)])[0]
 
     def csr_arena_words(self, E_cap, n_dst):
-        """int32 words of one list's tables inside a caller-owned arena (build_csr_batch(..., into=)), for up to E_cap edges."""
+        """int32 words of one list's tables (row pointers, columns, permutation, rows, unit tables, flags, workspace) for up
+        to E_cap edges, every table starting on a 16-byte boundary."""
         r4 = lambda n: (n + 3) & ~3
         return 2 * r4(n_dst + 1) + 3 * r4(max(int(E_cap), 1)) + 8 * self.lib.ggnn_csr_max_units(int(E_cap), n_dst) + 4 \
             + r4(self.lib.ggnn_csr_workspace_bytes(int(E_cap), n_dst) // 4 + 1)
@@ -165,39 +166,23 @@ class HipBackend:
         launches captured on an earlier, longer version of a list keep reading valid tables."""
         return CsrInPlace(self, shapes, device)
 
-    def build_csr_batch(self, lists, check=True, into=None):
+    def build_csr_batch(self, lists, check=True):
         """[(edge_index [2, E] int64 cuda, n_src, n_dst)] -> [CSR]: ggnn_build_csr_batch, up to four lists per sequence of
         launches (engine.GraphCSR builds the three edge types of a topology in one; a topological event rebuilds them),
         one range check = one host synchronisation behind the last (`check=False`: lists the caller has validated -- the
-        kernels skip an out-of-range edge either way --: no read-back, the host goes on enqueueing).
-        `into` = (arena int32 tensor, [E_cap per list]) with check=False, at most four lists: the tables are REBUILT IN
-        PLACE -- list k's tables start at the same words of the arena for any E <= E_cap[k] (csr_arena_words), so launches
-        captured on an earlier, larger version of the list keep reading valid tables."""
+        kernels skip an out-of-range edge either way --: no read-back, the host goes on enqueueing).  (Tables that are
+        refilled IN PLACE per event: `csr_in_place`.)"""
         out, todo = [], list(lists)
-        if into is not None and (check or len(todo) > 4 or len(into[1]) != len(todo)):
-            raise _lib.GGNNError("build_csr_batch: `into` needs check=False and one capacity per list (at most four lists)")
         while todo:
             chunk, todo = todo[:4], todo[4:]
             arr = (_lib.CsrArgs * len(chunk))()
             keep = []
             arena = None
-            starts = None
-            if into is not None:
-                arena, starts, at = [into[0], 0], [], 0
-                for (ei_, _, n_dst), cap in zip(chunk, into[1]):
-                    if int(ei_.size(1)) > cap:
-                        raise _lib.GGNNError("build_csr_batch: a list grew beyond the capacity of its arena")
-                    starts.append((at, cap))
-                    at += self.csr_arena_words(cap, n_dst)
-                if at > into[0].numel() or into[0].dtype != torch.int32 or not into[0].is_cuda:
-                    raise _lib.GGNNError("build_csr_batch: the arena is too small for these capacities")
-            elif not check:
+            if not check:
                 # unchecked builds run once per topological event: every table of the chunk out of ONE allocation (two
                 # dozen allocator calls and six fills otherwise; the unit table's unused tail and the range flags that
                 # nobody reads stay uninitialised)
-                r4 = lambda n: (n + 3) & ~3   # int32 counts in multiples of 16 bytes
-                need = sum(2 * r4(n_dst + 1) + 3 * r4(max(int(ei_.size(1)), 1)) + 8 * self.lib.ggnn_csr_max_units(int(ei_.size(1)), n_dst)
-                           + 4 + r4(self.lib.ggnn_csr_workspace_bytes(int(ei_.size(1)), n_dst) // 4 + 1) for ei_, _, n_dst in chunk)
+                need = sum(self.csr_arena_words(int(ei_.size(1)), n_dst) for ei_, _, n_dst in chunk)
                 arena = [torch.empty(need, dtype=torch.int32, device=chunk[0][0].device), 0]
 
             def take(n, like_zeros=False, shape=None, dev=None):
@@ -207,28 +192,19 @@ class HipBackend:
                     t = arena[0][arena[1]:arena[1] + n]
                     arena[1] += (n + 3) & ~3
                 return t if shape is None else t.view(shape)
-            for k, (a, (edge_index, n_src, n_dst)) in enumerate(zip(arr, chunk)):
+            for a, (edge_index, n_src, n_dst) in zip(arr, chunk):
                 _require_cuda(edge_index)
                 if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
                     raise _lib.GGNNError("edge_index must be int64 [2, E]")
                 ei = edge_index.contiguous()
                 E, dev = ei.size(1), ei.device
-                cap = E
-                if starts is not None:   # this list's tables at their fixed place, laid out for its capacity
-                    arena[1], cap = starts[k]
-                pad = lambda n: None if cap == E else arena.__setitem__(1, arena[1] + ((max(cap, 1) + 3) & ~3) - ((n + 3) & ~3))
                 rowptr = take(n_dst + 1, dev=dev)
                 col = take(max(E, 1), dev=dev)
-                pad(max(E, 1))
                 perm = take(max(E, 1), dev=dev)
-                pad(max(E, 1))
                 row = take(max(E, 1), dev=dev)
-                pad(max(E, 1))
                 unit_ptr = take(n_dst + 1, dev=dev)
                 n_units = self.lib.ggnn_csr_max_units(E, n_dst)
                 units = take(8 * n_units, True, (n_units, 8), dev)
-                if cap != E:
-                    arena[1] += 8 * (self.lib.ggnn_csr_max_units(cap, n_dst) - n_units)
                 flags = take(2, True, dev=dev)
                 nbytes = self.lib.ggnn_csr_workspace_bytes(E, n_dst)
                 ws = take(nbytes // 4 + 1, dev=dev).view(torch.uint8)[:nbytes] if arena is not None else \

@@ -23,7 +23,7 @@ class GraphCSR:
     def __init__(self, backend, edge_index_dict, n_nodes: Dict[str, int], trusted: bool = False, into=None, counts=None):
         """trusted: the lists come from the library's own topology update (validated on the host, topology.py): the
         range check of the build -- a read-back, i.e. a host synchronisation -- is skipped.
-        into = (arena, {et: capacity}): the tables are rebuilt IN PLACE inside a caller-owned arena (backend.build_csr_batch);
+        into = a backend.CsrInPlace: the tables are refilled IN PLACE (same device tensors, same addresses);
         counts = {et: int64 [1] device tensor}: where the per-edge kernels find the number of edges at run time (CSR.E_dev)."""
         self.csr = {}
         self.edge_index = {}
@@ -33,12 +33,8 @@ class GraphCSR:
                 raise KeyError(f"edge_index_dict lacks edge type {et}")
             self.edge_index[et] = edge_index_dict[et].contiguous()
         lists = [(self.edge_index[et], n_nodes[et[0]], n_nodes[et[-1]]) for et in EDGE_TYPES]
-        if into is not None and not isinstance(into, tuple):   # a backend.CsrInPlace: the same tables, refilled
+        if into is not None:   # a backend.CsrInPlace: the same tables, refilled
             built = into.rebuild([l[0] for l in lists])
-            for et, csr in zip(EDGE_TYPES, built):
-                csr.E_dev = None if counts is None else counts[et]
-        elif into is not None:
-            built = backend.build_csr_batch(lists, check=False, into=(into[0], [into[1][et] for et in EDGE_TYPES]))
             for et, csr in zip(EDGE_TYPES, built):
                 csr.E_dev = None if counts is None else counts[et]
         elif hasattr(backend, "build_csr_batch"):   # the three edge types in one sequence of launches, one synchronisation
